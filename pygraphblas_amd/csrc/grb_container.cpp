@@ -1,0 +1,546 @@
+// grb_container.cpp — GrB_Matrix / GrB_Vector / GxB_Scalar objects and their host<->HBM mirrors.
+//
+// Replaces the object-model half of the `lib.` surface that pygraphblas calls:
+//   GrB_Matrix_new/free/dup/clear/nrows/ncols/nvals/wait/error/resize/removeElement
+//        (reference call sites: pygraphblas/matrix.py:99-117, 171-175, 627-760, 3353)
+//   GrB_Matrix_build_<T> / setElement_<T> / extractElement_<T> / extractTuples_<T>
+//        (pygraphblas/matrix.py:325-330, 1503-1529, 3180-3308; types.py:87-110)
+//   the Vector and Scalar equivalents (pygraphblas/vector.py:60-95, scalar.py:20-92).
+// Ownership: the library allocates in *_new and frees in *_free(&h); free of NULL / already freed
+// handles is a successful no-op (reference __del__ checks the return code).
+#include "grb_api.hpp"
+#include <algorithm>
+#include <numeric>
+#include <string.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+namespace grb {
+
+// ---- host assemble: apply pending setElement/removeElement in program order ---------------------
+void mat_host_assemble(GrB_Matrix A) {
+  if (A->pending.empty()) return;
+  const size_t ts = A->type->size;
+  auto& P = A->pending;
+  std::vector<uint32_t> ord(P.size());
+  std::iota(ord.begin(), ord.end(), 0u);
+  std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
+    return P[a].i != P[b].i ? P[a].i < P[b].i : P[a].j < P[b].j; });
+  std::vector<GrB_Index> ni, nj; std::vector<uint8_t> nx;
+  ni.reserve(A->hi.size() + P.size()); nj.reserve(A->hi.size() + P.size()); nx.reserve((A->hi.size() + P.size()) * ts);
+  size_t b = 0, nb = A->hi.size(), k = 0;
+  auto push_base = [&](size_t q) { ni.push_back(A->hi[q]); nj.push_back(A->hj[q]); nx.insert(nx.end(), &A->hx[q * ts], &A->hx[q * ts] + ts); };
+  while (k < ord.size()) {
+    size_t e = k;   // [k, e] = run of edits to the same coordinate; the last one wins
+    while (e + 1 < ord.size() && P[ord[e + 1]].i == P[ord[k]].i && P[ord[e + 1]].j == P[ord[k]].j) e++;
+    const auto& last = P[ord[e]];
+    while (b < nb && (A->hi[b] < last.i || (A->hi[b] == last.i && A->hj[b] < last.j))) push_base(b++);
+    if (b < nb && A->hi[b] == last.i && A->hj[b] == last.j) b++;   // replaced or deleted
+    if (!last.del) { ni.push_back(last.i); nj.push_back(last.j); nx.insert(nx.end(), last.x, last.x + ts); }
+    k = e + 1;
+  }
+  while (b < nb) push_base(b++);
+  A->hi.swap(ni); A->hj.swap(nj); A->hx.swap(nx); P.clear(); P.shrink_to_fit();
+}
+
+void mat_invalidate_device(GrB_Matrix A) { A->dev_valid = false; A->csr.clear(); A->csc.clear(); }
+void mat_invalidate_host(GrB_Matrix A) {
+  A->host_valid = false; A->hi.clear(); A->hj.clear(); A->hx.clear(); A->pending.clear();
+  A->hi.shrink_to_fit(); A->hj.shrink_to_fit(); A->hx.shrink_to_fit();
+  A->csc.clear(); A->csr.has_plan = false; A->csr.plan_blocks.reset(); A->csr.plan_aux.reset();
+}
+
+void mat_to_host(GrB_Matrix A) {
+  if (A->host_valid) { mat_host_assemble(A); return; }
+  // download the device CSR and expand to sorted tuples
+  const DevCSR& c = A->csr; const size_t ts = A->type->size;
+  std::vector<uint32_t> rp(c.nrows + 1), col(c.nnz);
+  A->hx.resize(c.nnz * ts);
+  GRB_HIP(hipMemcpyAsync(rp.data(), c.rowptr.p, (c.nrows + 1) * 4ull, hipMemcpyDeviceToHost, stream()));
+  if (c.nnz) {
+    GRB_HIP(hipMemcpyAsync(col.data(), c.col.p, c.nnz * 4ull, hipMemcpyDeviceToHost, stream()));
+    GRB_HIP(hipMemcpyAsync(A->hx.data(), c.val.p, c.nnz * ts, hipMemcpyDeviceToHost, stream()));
+  }
+  GRB_HIP(hipStreamSynchronize(stream()));
+  A->hi.resize(c.nnz); A->hj.resize(c.nnz);
+  for (uint32_t r = 0; r < c.nrows; r++)
+    for (uint32_t p = rp[r]; p < rp[r + 1]; p++) { A->hi[p] = r; A->hj[p] = col[p]; }
+  A->host_valid = true;
+}
+
+void mat_to_device(GrB_Matrix A) {
+  if (A->dev_valid) return;
+  need_device();
+  mat_host_assemble(A);
+  if (A->nrows > GRB_DIM_DEVICE_MAX || A->ncols > GRB_DIM_DEVICE_MAX)
+    fail(GrB_INSUFFICIENT_SPACE, "matrix dimension exceeds the 32-bit index range of the HBM CSR layout");
+  const uint64_t nnz = A->hi.size(); const size_t ts = A->type->size;
+  if (nnz > 0xFFFFFFF0ull) fail(GrB_INSUFFICIENT_SPACE, "more than 2^32 entries in one device matrix");
+  DevCSR& c = A->csr; c.clear();
+  c.nrows = (uint32_t)A->nrows; c.ncols = (uint32_t)A->ncols; c.nnz = nnz;
+  std::vector<uint32_t> rp((size_t)c.nrows + 1, 0), col(nnz);
+  for (uint64_t p = 0; p < nnz; p++) { rp[A->hi[p] + 1]++; col[p] = (uint32_t)A->hj[p]; }
+  for (uint32_t r = 0; r < c.nrows; r++) rp[r + 1] += rp[r];
+  c.rowptr.alloc(((size_t)c.nrows + 1) * 4); c.col.alloc(nnz * 4); c.val.alloc(nnz * ts);
+  GRB_HIP(hipMemcpyAsync(c.rowptr.p, rp.data(), rp.size() * 4, hipMemcpyHostToDevice, stream()));
+  if (nnz) {
+    GRB_HIP(hipMemcpyAsync(c.col.p, col.data(), nnz * 4, hipMemcpyHostToDevice, stream()));
+    GRB_HIP(hipMemcpyAsync(c.val.p, A->hx.data(), nnz * ts, hipMemcpyHostToDevice, stream()));
+  }
+  GRB_HIP(hipStreamSynchronize(stream()));
+  c.valid = true; A->dev_valid = true;
+}
+
+uint64_t mat_nvals(GrB_Matrix A) {
+  if (A->host_valid) { mat_host_assemble(A); return A->hi.size(); }
+  return A->csr.nnz;
+}
+
+const DevCSR& mat_csc(GrB_Matrix A) {
+  mat_to_device(A);
+  if (!A->csc.valid) csr_transpose(A->csr, A->type->size, A->csc);
+  return A->csc;
+}
+
+// ---- vectors ---------------------------------------------------------------------------------------
+void vec_host_assemble(GrB_Vector v) {
+  if (v->pending.empty()) return;
+  const size_t ts = v->type->size; auto& P = v->pending;
+  std::vector<uint32_t> ord(P.size()); std::iota(ord.begin(), ord.end(), 0u);
+  std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return P[a].i < P[b].i; });
+  std::vector<GrB_Index> ni; std::vector<uint8_t> nx;
+  size_t b = 0, nb = v->hi.size(), k = 0;
+  auto push_base = [&](size_t q) { ni.push_back(v->hi[q]); nx.insert(nx.end(), &v->hx[q * ts], &v->hx[q * ts] + ts); };
+  while (k < ord.size()) {
+    size_t e = k; while (e + 1 < ord.size() && P[ord[e + 1]].i == P[ord[k]].i) e++;
+    const auto& last = P[ord[e]];
+    while (b < nb && v->hi[b] < last.i) push_base(b++);
+    if (b < nb && v->hi[b] == last.i) b++;
+    if (!last.del) { ni.push_back(last.i); nx.insert(nx.end(), last.x, last.x + ts); }
+    k = e + 1;
+  }
+  while (b < nb) push_base(b++);
+  v->hi.swap(ni); v->hx.swap(nx); P.clear(); P.shrink_to_fit();
+}
+void vec_invalidate_device(GrB_Vector v) { v->dev_valid = false; v->dval.reset(); v->dpres.reset(); v->dnvals = 0; v->dnvals_known = true; }
+void vec_invalidate_host(GrB_Vector v) {
+  v->host_valid = false; v->hi.clear(); v->hx.clear(); v->pending.clear(); v->hi.shrink_to_fit(); v->hx.shrink_to_fit();
+}
+void vec_to_host(GrB_Vector v) {
+  if (v->host_valid) { vec_host_assemble(v); return; }
+  const size_t ts = v->type->size; const uint64_t n = v->n;
+  std::vector<uint8_t> val(n * ts), pres(n);
+  if (n) {
+    GRB_HIP(hipMemcpyAsync(val.data(), v->dval.p, n * ts, hipMemcpyDeviceToHost, stream()));
+    GRB_HIP(hipMemcpyAsync(pres.data(), v->dpres.p, n, hipMemcpyDeviceToHost, stream()));
+    GRB_HIP(hipStreamSynchronize(stream()));
+  }
+  v->hi.clear(); v->hx.clear();
+  for (uint64_t i = 0; i < n; i++) if (pres[i]) { v->hi.push_back(i); v->hx.insert(v->hx.end(), &val[i * ts], &val[i * ts] + ts); }
+  v->host_valid = true;
+}
+void vec_to_device(GrB_Vector v) {
+  if (v->dev_valid) return;
+  need_device();
+  vec_host_assemble(v);
+  if (v->n > GRB_DIM_DEVICE_MAX) fail(GrB_INSUFFICIENT_SPACE, "vector length exceeds the 32-bit index range of the HBM bitmap layout");
+  const size_t ts = v->type->size; const uint64_t n = v->n;
+  std::vector<uint8_t> val(n * ts, 0), pres(n, 0);
+  for (size_t k = 0; k < v->hi.size(); k++) { pres[v->hi[k]] = 1; memcpy(&val[v->hi[k] * ts], &v->hx[k * ts], ts); }
+  v->dval.alloc(n * ts ? n * ts : 1); v->dpres.alloc(n ? n : 1);
+  if (n) {
+    GRB_HIP(hipMemcpyAsync(v->dval.p, val.data(), n * ts, hipMemcpyHostToDevice, stream()));
+    GRB_HIP(hipMemcpyAsync(v->dpres.p, pres.data(), n, hipMemcpyHostToDevice, stream()));
+    GRB_HIP(hipStreamSynchronize(stream()));
+  }
+  v->dnvals = v->hi.size(); v->dnvals_known = true; v->dev_valid = true;
+}
+uint64_t vec_dev_nvals(GrB_Vector v) {
+  if (!v->dnvals_known) { v->dnvals = count_present(v->dpres.as<uint8_t>(), v->n); v->dnvals_known = true; }
+  return v->dnvals;
+}
+uint64_t vec_nvals(GrB_Vector v) {
+  if (v->host_valid) { vec_host_assemble(v); return v->hi.size(); }
+  return vec_dev_nvals(v);
+}
+
+// sort + combine duplicates for build(); keys are (i,j) pairs (j == 0 for vectors)
+static void build_tuples(GrB_Type type, const GrB_Index* I, const GrB_Index* J, const void* X, int xcode, GrB_Index n,
+                         GrB_Index nrows, GrB_Index ncols, GrB_BinaryOp dup, std::vector<GrB_Index>& hi,
+                         std::vector<GrB_Index>* hj, std::vector<uint8_t>& hx) {
+  const size_t ts = type->size; const size_t xs = type_size(xcode);
+  for (GrB_Index k = 0; k < n; k++) {
+    if (I[k] >= nrows || (J && J[k] >= ncols)) fail(GrB_INDEX_OUT_OF_BOUNDS, "build: index out of bounds");
+  }
+  std::vector<uint64_t> ord(n); std::iota(ord.begin(), ord.end(), 0ull);
+  std::stable_sort(ord.begin(), ord.end(), [&](uint64_t a, uint64_t b) {
+    if (I[a] != I[b]) return I[a] < I[b]; return J ? J[a] < J[b] : false; });
+  hi.clear(); if (hj) hj->clear(); hx.clear();
+  hi.reserve(n); if (hj) hj->reserve(n); hx.reserve(n * ts);
+  uint8_t cur[16], nxt[16];
+  for (GrB_Index k = 0; k < n;) {
+    GrB_Index e = k; const uint64_t o = ord[k];
+    cast_scalar(type->code, cur, xcode, (const uint8_t*)X + o * xs);
+    while (e + 1 < n && I[ord[e + 1]] == I[o] && (!J || J[ord[e + 1]] == J[o])) {
+      e++;
+      cast_scalar(type->code, nxt, xcode, (const uint8_t*)X + ord[e] * xs);
+      if (!dup) fail(GrB_INVALID_VALUE, "build: duplicate index and no dup operator");
+      dispatch_type(type->code, [&]<class T>() { T a, b; memcpy(&a, cur, sizeof(T)); memcpy(&b, nxt, sizeof(T));
+        T z = apply_binop<T>(dup->opcode, a, b); memcpy(cur, &z, sizeof(T)); });
+    }
+    hi.push_back(I[o]); if (hj) hj->push_back(J[o]); hx.insert(hx.end(), cur, cur + ts);
+    k = e + 1;
+  }
+}
+
+}  // namespace grb
+
+using namespace grb;
+
+#define CHECK_MAT(A) do { if (!(A)) return GrB_NULL_POINTER; if (!check_obj(A)) return GrB_UNINITIALIZED_OBJECT; } while (0)
+#define CHECK_VEC(v) CHECK_MAT(v)
+
+extern "C" {
+
+// =================================== Matrix ========================================================
+GrB_Info GrB_Matrix_new(GrB_Matrix* A, GrB_Type type, GrB_Index nrows, GrB_Index ncols) {
+  if (!A) return GrB_NULL_POINTER; *A = nullptr;
+  if (!check_obj(type)) return GrB_UNINITIALIZED_OBJECT;
+  if (type->code >= T_FC32) return GrB_DOMAIN_MISMATCH;   // complex / user types: out of scope
+  if (nrows > GXB_INDEX_MAX || ncols > GXB_INDEX_MAX) return GrB_INVALID_VALUE;
+  auto* m = new (std::nothrow) GrB_Matrix_opaque(); if (!m) return GrB_OUT_OF_MEMORY;
+  m->type = type; m->nrows = nrows; m->ncols = ncols; *A = m; return GrB_SUCCESS;
+}
+GrB_Info GrB_Matrix_free(GrB_Matrix* A) {
+  if (!A || !*A) return GrB_SUCCESS;
+  if (check_obj(*A)) { (*A)->magic = GRB_FREED; delete *A; }
+  *A = nullptr; return GrB_SUCCESS;
+}
+GrB_Info GrB_Matrix_dup(GrB_Matrix* C, const GrB_Matrix A) {
+  if (!C) return GrB_NULL_POINTER; CHECK_MAT(A);
+  GrB_Matrix m = nullptr; GrB_Info info = GrB_Matrix_new(&m, A->type, A->nrows, A->ncols); if (info) return info;
+  info = guarded(A, [&] {
+    m->format = A->format; m->sparsity_control = A->sparsity_control; m->hyper_switch = A->hyper_switch;
+    if (A->host_valid) { mat_host_assemble(A); m->hi = A->hi; m->hj = A->hj; m->hx = A->hx; m->host_valid = true; }
+    else {
+      const DevCSR& s = A->csr; DevCSR& d = m->csr; const size_t ts = A->type->size;
+      d.nrows = s.nrows; d.ncols = s.ncols; d.nnz = s.nnz;
+      d.rowptr.alloc(((size_t)s.nrows + 1) * 4); d.col.alloc(s.nnz * 4); d.val.alloc(s.nnz * ts);
+      GRB_HIP(hipMemcpyAsync(d.rowptr.p, s.rowptr.p, ((size_t)s.nrows + 1) * 4, hipMemcpyDeviceToDevice, stream()));
+      if (s.nnz) { GRB_HIP(hipMemcpyAsync(d.col.p, s.col.p, s.nnz * 4, hipMemcpyDeviceToDevice, stream()));
+                   GRB_HIP(hipMemcpyAsync(d.val.p, s.val.p, s.nnz * ts, hipMemcpyDeviceToDevice, stream())); }
+      d.valid = true; m->dev_valid = true; m->host_valid = false;
+    }
+  });
+  if (info) { GrB_Matrix_free(&m); return info; }
+  *C = m; return GrB_SUCCESS;
+}
+GrB_Info GrB_Matrix_clear(GrB_Matrix A) {
+  CHECK_MAT(A); A->hi.clear(); A->hj.clear(); A->hx.clear(); A->pending.clear(); A->host_valid = true; mat_invalidate_device(A); return GrB_SUCCESS;
+}
+GrB_Info GrB_Matrix_nrows(GrB_Index* n, const GrB_Matrix A) { if (!n) return GrB_NULL_POINTER; CHECK_MAT(A); *n = A->nrows; return GrB_SUCCESS; }
+GrB_Info GrB_Matrix_ncols(GrB_Index* n, const GrB_Matrix A) { if (!n) return GrB_NULL_POINTER; CHECK_MAT(A); *n = A->ncols; return GrB_SUCCESS; }
+GrB_Info GrB_Matrix_nvals(GrB_Index* n, const GrB_Matrix A) {
+  if (!n) return GrB_NULL_POINTER; CHECK_MAT(A); return guarded(A, [&] { *n = mat_nvals(A); });
+}
+GrB_Info GrB_Matrix_wait(GrB_Matrix* A) {
+  if (!A) return GrB_NULL_POINTER; CHECK_MAT(*A);
+  return guarded(*A, [&] { if ((*A)->host_valid) mat_host_assemble(*A); if (device_ok()) GRB_HIP(hipStreamSynchronize(stream())); });
+}
+GrB_Info GrB_Matrix_error(const char** s, const GrB_Matrix A) { if (!s) return GrB_NULL_POINTER; CHECK_MAT(A); *s = A->err.c_str(); return GrB_SUCCESS; }
+GrB_Info GxB_Matrix_type(GrB_Type* t, const GrB_Matrix A) { if (!t) return GrB_NULL_POINTER; CHECK_MAT(A); *t = A->type; return GrB_SUCCESS; }
+GrB_Info GrB_Matrix_resize(GrB_Matrix A, GrB_Index nr, GrB_Index nc) {
+  CHECK_MAT(A); if (nr > GXB_INDEX_MAX || nc > GXB_INDEX_MAX) return GrB_INVALID_VALUE;
+  return guarded(A, [&] {
+    mat_to_host(A); const size_t ts = A->type->size; size_t w = 0;
+    for (size_t k = 0; k < A->hi.size(); k++) if (A->hi[k] < nr && A->hj[k] < nc) {
+      if (w != k) { A->hi[w] = A->hi[k]; A->hj[w] = A->hj[k]; memmove(&A->hx[w * ts], &A->hx[k * ts], ts); } w++; }
+    A->hi.resize(w); A->hj.resize(w); A->hx.resize(w * ts); A->nrows = nr; A->ncols = nc; mat_invalidate_device(A);
+  });
+}
+GrB_Info GrB_Matrix_removeElement(GrB_Matrix A, GrB_Index i, GrB_Index j) {
+  CHECK_MAT(A); if (i >= A->nrows || j >= A->ncols) return GrB_INVALID_INDEX;
+  return guarded(A, [&] { mat_to_host(A); GrB_Matrix_opaque::Pending p{i, j, true, {0}}; A->pending.push_back(p); mat_invalidate_device(A); });
+}
+GrB_Info GxB_Matrix_Option_set(GrB_Matrix A, int field, ...) {
+  CHECK_MAT(A); va_list ap; va_start(ap, field); GrB_Info info = GrB_SUCCESS;
+  switch (field) {
+    case 1: A->format = va_arg(ap, int); break;
+    case 0: A->hyper_switch = va_arg(ap, double); break;
+    case 32: A->sparsity_control = va_arg(ap, int); break;
+    case 34: (void)va_arg(ap, double); break;
+    default: info = GrB_INVALID_VALUE;
+  }
+  va_end(ap); return info;
+}
+GrB_Info GxB_Matrix_Option_get(GrB_Matrix A, int field, ...) {
+  CHECK_MAT(A); va_list ap; va_start(ap, field); GrB_Info info = GrB_SUCCESS;
+  switch (field) {
+    case 1: { int* p = va_arg(ap, int*); if (p) *p = A->format; break; }
+    case 0: { double* p = va_arg(ap, double*); if (p) *p = A->hyper_switch; break; }
+    case 32: { int* p = va_arg(ap, int*); if (p) *p = A->sparsity_control; break; }
+    case 33: { int* p = va_arg(ap, int*); if (p) *p = (A->nrows > GRB_DIM_DEVICE_MAX) ? 1 : 2; break; }  // hypersparse / sparse
+    case 34: { double* p = va_arg(ap, double*); if (p) *p = 0.04; break; }
+    default: info = GrB_INVALID_VALUE;
+  }
+  va_end(ap); return info;
+}
+GrB_Info GxB_Matrix_memoryUsage(size_t* size, const GrB_Matrix A) {
+  if (!size) return GrB_NULL_POINTER; CHECK_MAT(A);
+  *size = sizeof(*A) + A->hi.capacity() * 16 + A->hx.capacity() + A->csr.rowptr.bytes + A->csr.col.bytes + A->csr.val.bytes +
+          A->csc.rowptr.bytes + A->csc.col.bytes + A->csc.val.bytes; return GrB_SUCCESS;
+}
+
+static GrB_Info mat_build(GrB_Matrix C, const GrB_Index* I, const GrB_Index* J, const void* X, int xcode, GrB_Index n, GrB_BinaryOp dup) {
+  CHECK_MAT(C); if (n && (!I || !J || !X)) return GrB_NULL_POINTER;
+  if (dup && !check_obj(dup)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(C, [&] {
+    if (mat_nvals(C) != 0) fail(GrB_OUTPUT_NOT_EMPTY, "build: output already has entries");
+    build_tuples(C->type, I, J, X, xcode, n, C->nrows, C->ncols, dup, C->hi, &C->hj, C->hx);
+    C->host_valid = true; mat_invalidate_device(C);
+  });
+}
+static GrB_Info mat_set(GrB_Matrix C, const void* x, int xcode, GrB_Index i, GrB_Index j) {
+  CHECK_MAT(C); if (i >= C->nrows || j >= C->ncols) return GrB_INVALID_INDEX;
+  return guarded(C, [&] {
+    if (!C->host_valid) mat_to_host(C);
+    GrB_Matrix_opaque::Pending p{i, j, false, {0}}; cast_scalar(C->type->code, p.x, xcode, x);
+    C->pending.push_back(p); mat_invalidate_device(C);
+  });
+}
+static size_t mat_find(GrB_Matrix A, GrB_Index i, GrB_Index j) {   // index into host tuples or SIZE_MAX
+  size_t lo = 0, hi = A->hi.size();
+  while (lo < hi) { size_t m = (lo + hi) / 2; if (A->hi[m] < i || (A->hi[m] == i && A->hj[m] < j)) lo = m + 1; else hi = m; }
+  return (lo < A->hi.size() && A->hi[lo] == i && A->hj[lo] == j) ? lo : SIZE_MAX;
+}
+static GrB_Info mat_get(void* x, int xcode, GrB_Matrix A, GrB_Index i, GrB_Index j) {
+  if (!x) return GrB_NULL_POINTER; CHECK_MAT(A); if (i >= A->nrows || j >= A->ncols) return GrB_INVALID_INDEX;
+  GrB_Info r = GrB_SUCCESS;
+  GrB_Info info = guarded(A, [&] { mat_to_host(A); size_t k = mat_find(A, i, j);
+    if (k == SIZE_MAX) r = GrB_NO_VALUE; else cast_scalar(xcode, x, A->type->code, &A->hx[k * A->type->size]); });
+  return info ? info : r;
+}
+static GrB_Info mat_tuples(GrB_Index* I, GrB_Index* J, void* X, int xcode, GrB_Index* n, GrB_Matrix A) {
+  if (!n) return GrB_NULL_POINTER; CHECK_MAT(A);
+  return guarded(A, [&] {
+    mat_to_host(A); const GrB_Index nv = A->hi.size();
+    if ((I || J || X) && *n < nv) fail(GrB_INSUFFICIENT_SPACE, "extractTuples: output arrays too small");
+    const size_t ts = A->type->size, xs = type_size(xcode);
+    for (GrB_Index k = 0; k < nv; k++) {
+      if (I) I[k] = A->hi[k]; if (J) J[k] = A->hj[k];
+      if (X) cast_scalar(xcode, (uint8_t*)X + k * xs, A->type->code, &A->hx[k * ts]);
+    }
+    *n = nv;
+  });
+}
+
+// =================================== Vector ========================================================
+GrB_Info GrB_Vector_new(GrB_Vector* v, GrB_Type type, GrB_Index n) {
+  if (!v) return GrB_NULL_POINTER; *v = nullptr;
+  if (!check_obj(type)) return GrB_UNINITIALIZED_OBJECT;
+  if (type->code >= T_FC32) return GrB_DOMAIN_MISMATCH;
+  if (n > GXB_INDEX_MAX) return GrB_INVALID_VALUE;
+  auto* w = new (std::nothrow) GrB_Vector_opaque(); if (!w) return GrB_OUT_OF_MEMORY;
+  w->type = type; w->n = n; *v = w; return GrB_SUCCESS;
+}
+GrB_Info GrB_Vector_free(GrB_Vector* v) {
+  if (!v || !*v) return GrB_SUCCESS;
+  if (check_obj(*v)) { (*v)->magic = GRB_FREED; delete *v; }
+  *v = nullptr; return GrB_SUCCESS;
+}
+GrB_Info GrB_Vector_dup(GrB_Vector* w, const GrB_Vector u) {
+  if (!w) return GrB_NULL_POINTER; CHECK_VEC(u);
+  GrB_Vector r = nullptr; GrB_Info info = GrB_Vector_new(&r, u->type, u->n); if (info) return info;
+  info = guarded(u, [&] {
+    if (u->host_valid) { vec_host_assemble(u); r->hi = u->hi; r->hx = u->hx; }
+    else {
+      const size_t ts = u->type->size;
+      r->dval.alloc(u->n * ts ? u->n * ts : 1); r->dpres.alloc(u->n ? u->n : 1);
+      if (u->n) { GRB_HIP(hipMemcpyAsync(r->dval.p, u->dval.p, u->n * ts, hipMemcpyDeviceToDevice, stream()));
+                  GRB_HIP(hipMemcpyAsync(r->dpres.p, u->dpres.p, u->n, hipMemcpyDeviceToDevice, stream())); }
+      r->dnvals = u->dnvals; r->dnvals_known = u->dnvals_known; r->dev_valid = true; r->host_valid = false;
+    }
+  });
+  if (info) { GrB_Vector_free(&r); return info; }
+  *w = r; return GrB_SUCCESS;
+}
+GrB_Info GrB_Vector_clear(GrB_Vector v) { CHECK_VEC(v); v->hi.clear(); v->hx.clear(); v->pending.clear(); v->host_valid = true; vec_invalidate_device(v); return GrB_SUCCESS; }
+GrB_Info GrB_Vector_size(GrB_Index* n, const GrB_Vector v) { if (!n) return GrB_NULL_POINTER; CHECK_VEC(v); *n = v->n; return GrB_SUCCESS; }
+GrB_Info GrB_Vector_nvals(GrB_Index* n, const GrB_Vector v) { if (!n) return GrB_NULL_POINTER; CHECK_VEC(v); return guarded(v, [&] { *n = vec_nvals(v); }); }
+GrB_Info GrB_Vector_wait(GrB_Vector* v) {
+  if (!v) return GrB_NULL_POINTER; CHECK_VEC(*v);
+  return guarded(*v, [&] { if ((*v)->host_valid) vec_host_assemble(*v); if (device_ok()) GRB_HIP(hipStreamSynchronize(stream())); });
+}
+GrB_Info GrB_Vector_error(const char** s, const GrB_Vector v) { if (!s) return GrB_NULL_POINTER; CHECK_VEC(v); *s = v->err.c_str(); return GrB_SUCCESS; }
+GrB_Info GxB_Vector_type(GrB_Type* t, const GrB_Vector v) { if (!t) return GrB_NULL_POINTER; CHECK_VEC(v); *t = v->type; return GrB_SUCCESS; }
+GrB_Info GrB_Vector_resize(GrB_Vector v, GrB_Index n) {
+  CHECK_VEC(v); if (n > GXB_INDEX_MAX) return GrB_INVALID_VALUE;
+  return guarded(v, [&] { vec_to_host(v); const size_t ts = v->type->size; size_t w = 0;
+    while (w < v->hi.size() && v->hi[w] < n) w++;
+    v->hi.resize(w); v->hx.resize(w * ts); v->n = n; vec_invalidate_device(v); });
+}
+GrB_Info GrB_Vector_removeElement(GrB_Vector v, GrB_Index i) {
+  CHECK_VEC(v); if (i >= v->n) return GrB_INVALID_INDEX;
+  return guarded(v, [&] { vec_to_host(v); GrB_Vector_opaque::Pending p{i, true, {0}}; v->pending.push_back(p); vec_invalidate_device(v); });
+}
+GrB_Info GxB_Vector_Option_set(GrB_Vector v, int field, ...) {
+  CHECK_VEC(v); va_list ap; va_start(ap, field); GrB_Info info = GrB_SUCCESS;
+  switch (field) { case 32: v->sparsity_control = va_arg(ap, int); break; case 34: (void)va_arg(ap, double); break;
+                   case 1: (void)va_arg(ap, int); break; case 0: (void)va_arg(ap, double); break; default: info = GrB_INVALID_VALUE; }
+  va_end(ap); return info;
+}
+GrB_Info GxB_Vector_Option_get(GrB_Vector v, int field, ...) {
+  CHECK_VEC(v); va_list ap; va_start(ap, field); GrB_Info info = GrB_SUCCESS;
+  switch (field) {
+    case 32: { int* p = va_arg(ap, int*); if (p) *p = v->sparsity_control; break; }
+    case 33: { int* p = va_arg(ap, int*); if (p) *p = v->dev_valid && !v->host_valid ? (vec_dev_nvals(v) == v->n ? 8 : 4) : 2; break; }
+    case 1: { int* p = va_arg(ap, int*); if (p) *p = 1; break; }
+    case 34: { double* p = va_arg(ap, double*); if (p) *p = 0.04; break; }
+    default: info = GrB_INVALID_VALUE;
+  }
+  va_end(ap); return info;
+}
+GrB_Info GxB_Vector_memoryUsage(size_t* size, const GrB_Vector v) {
+  if (!size) return GrB_NULL_POINTER; CHECK_VEC(v); *size = sizeof(*v) + v->hi.capacity() * 8 + v->hx.capacity() + v->dval.bytes + v->dpres.bytes; return GrB_SUCCESS;
+}
+static GrB_Info vec_build(GrB_Vector w, const GrB_Index* I, const void* X, int xcode, GrB_Index n, GrB_BinaryOp dup) {
+  CHECK_VEC(w); if (n && (!I || !X)) return GrB_NULL_POINTER; if (dup && !check_obj(dup)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(w, [&] {
+    if (vec_nvals(w) != 0) fail(GrB_OUTPUT_NOT_EMPTY, "build: output already has entries");
+    build_tuples(w->type, I, nullptr, X, xcode, n, w->n, 1, dup, w->hi, nullptr, w->hx);
+    w->host_valid = true; vec_invalidate_device(w);
+  });
+}
+static GrB_Info vec_set(GrB_Vector w, const void* x, int xcode, GrB_Index i) {
+  CHECK_VEC(w); if (i >= w->n) return GrB_INVALID_INDEX;
+  return guarded(w, [&] { if (!w->host_valid) vec_to_host(w);
+    GrB_Vector_opaque::Pending p{i, false, {0}}; cast_scalar(w->type->code, p.x, xcode, x); w->pending.push_back(p); vec_invalidate_device(w); });
+}
+static GrB_Info vec_get(void* x, int xcode, GrB_Vector v, GrB_Index i) {
+  if (!x) return GrB_NULL_POINTER; CHECK_VEC(v); if (i >= v->n) return GrB_INVALID_INDEX;
+  GrB_Info r = GrB_SUCCESS;
+  GrB_Info info = guarded(v, [&] { vec_to_host(v);
+    auto it = std::lower_bound(v->hi.begin(), v->hi.end(), i);
+    if (it == v->hi.end() || *it != i) r = GrB_NO_VALUE;
+    else cast_scalar(xcode, x, v->type->code, &v->hx[(it - v->hi.begin()) * v->type->size]); });
+  return info ? info : r;
+}
+static GrB_Info vec_tuples(GrB_Index* I, void* X, int xcode, GrB_Index* n, GrB_Vector v) {
+  if (!n) return GrB_NULL_POINTER; CHECK_VEC(v);
+  return guarded(v, [&] {
+    vec_to_host(v); const GrB_Index nv = v->hi.size();
+    if ((I || X) && *n < nv) fail(GrB_INSUFFICIENT_SPACE, "extractTuples: output arrays too small");
+    const size_t ts = v->type->size, xs = type_size(xcode);
+    for (GrB_Index k = 0; k < nv; k++) { if (I) I[k] = v->hi[k]; if (X) cast_scalar(xcode, (uint8_t*)X + k * xs, v->type->code, &v->hx[k * ts]); }
+    *n = nv;
+  });
+}
+
+// =================================== Scalar ========================================================
+GrB_Info GxB_Scalar_new(GxB_Scalar* s, GrB_Type type) {
+  if (!s) return GrB_NULL_POINTER; *s = nullptr; if (!check_obj(type)) return GrB_UNINITIALIZED_OBJECT;
+  if (type->code >= T_FC32) return GrB_DOMAIN_MISMATCH;
+  auto* r = new (std::nothrow) GxB_Scalar_opaque(); if (!r) return GrB_OUT_OF_MEMORY; r->type = type; *s = r; return GrB_SUCCESS;
+}
+GrB_Info GxB_Scalar_dup(GxB_Scalar* s, const GxB_Scalar t) {
+  if (!s) return GrB_NULL_POINTER; CHECK_MAT(t); auto* r = new (std::nothrow) GxB_Scalar_opaque(); if (!r) return GrB_OUT_OF_MEMORY;
+  r->type = t->type; r->has = t->has; memcpy(r->x, t->x, 16); *s = r; return GrB_SUCCESS;
+}
+GrB_Info GxB_Scalar_clear(GxB_Scalar s) { CHECK_MAT(s); s->has = false; return GrB_SUCCESS; }
+GrB_Info GxB_Scalar_free(GxB_Scalar* s) { if (!s || !*s) return GrB_SUCCESS; if (check_obj(*s)) { (*s)->magic = GRB_FREED; delete *s; } *s = nullptr; return GrB_SUCCESS; }
+GrB_Info GxB_Scalar_nvals(GrB_Index* n, const GxB_Scalar s) { if (!n) return GrB_NULL_POINTER; CHECK_MAT(s); *n = s->has ? 1 : 0; return GrB_SUCCESS; }
+GrB_Info GxB_Scalar_wait(GxB_Scalar* s) { if (!s) return GrB_NULL_POINTER; CHECK_MAT(*s); return GrB_SUCCESS; }
+GrB_Info GxB_Scalar_type(GrB_Type* t, const GxB_Scalar s) { if (!t) return GrB_NULL_POINTER; CHECK_MAT(s); *t = s->type; return GrB_SUCCESS; }
+static GrB_Info scalar_set(GxB_Scalar s, const void* x, int xcode) { CHECK_MAT(s); cast_scalar(s->type->code, s->x, xcode, x); s->has = true; return GrB_SUCCESS; }
+static GrB_Info scalar_get(void* x, int xcode, GxB_Scalar s) { if (!x) return GrB_NULL_POINTER; CHECK_MAT(s); if (!s->has) return GrB_NO_VALUE; cast_scalar(xcode, x, s->type->code, s->x); return GrB_SUCCESS; }
+
+// ---- typed families ---------------------------------------------------------------------------------
+#define GRB_TYPED_CONTAINER(SUF, CT, CODE) \
+  GrB_Info GrB_Matrix_build_##SUF(GrB_Matrix C, const GrB_Index* I, const GrB_Index* J, const CT* X, GrB_Index n, const GrB_BinaryOp dup) { return mat_build(C, I, J, X, CODE, n, dup); } \
+  GrB_Info GrB_Matrix_setElement_##SUF(GrB_Matrix C, CT x, GrB_Index i, GrB_Index j) { return mat_set(C, &x, CODE, i, j); } \
+  GrB_Info GrB_Matrix_extractElement_##SUF(CT* x, const GrB_Matrix A, GrB_Index i, GrB_Index j) { return mat_get(x, CODE, A, i, j); } \
+  GrB_Info GrB_Matrix_extractTuples_##SUF(GrB_Index* I, GrB_Index* J, CT* X, GrB_Index* n, const GrB_Matrix A) { return mat_tuples(I, J, X, CODE, n, A); } \
+  GrB_Info GrB_Vector_build_##SUF(GrB_Vector w, const GrB_Index* I, const CT* X, GrB_Index n, const GrB_BinaryOp dup) { return vec_build(w, I, X, CODE, n, dup); } \
+  GrB_Info GrB_Vector_setElement_##SUF(GrB_Vector w, CT x, GrB_Index i) { return vec_set(w, &x, CODE, i); } \
+  GrB_Info GrB_Vector_extractElement_##SUF(CT* x, const GrB_Vector v, GrB_Index i) { return vec_get(x, CODE, v, i); } \
+  GrB_Info GrB_Vector_extractTuples_##SUF(GrB_Index* I, CT* X, GrB_Index* n, const GrB_Vector v) { return vec_tuples(I, X, CODE, n, v); } \
+  GrB_Info GxB_Scalar_setElement_##SUF(GxB_Scalar s, CT x) { return scalar_set(s, &x, CODE); } \
+  GrB_Info GxB_Scalar_extractElement_##SUF(CT* x, const GxB_Scalar s) { return scalar_get(x, CODE, s); }
+GRB_TYPED_CONTAINER(BOOL, bool, T_BOOL) GRB_TYPED_CONTAINER(INT8, int8_t, T_INT8) GRB_TYPED_CONTAINER(UINT8, uint8_t, T_UINT8)
+GRB_TYPED_CONTAINER(INT16, int16_t, T_INT16) GRB_TYPED_CONTAINER(UINT16, uint16_t, T_UINT16) GRB_TYPED_CONTAINER(INT32, int32_t, T_INT32)
+GRB_TYPED_CONTAINER(UINT32, uint32_t, T_UINT32) GRB_TYPED_CONTAINER(INT64, int64_t, T_INT64) GRB_TYPED_CONTAINER(UINT64, uint64_t, T_UINT64)
+GRB_TYPED_CONTAINER(FP32, float, T_FP32) GRB_TYPED_CONTAINER(FP64, double, T_FP64)
+
+// =================================== bulk / device import-export ===================================
+GrB_Info GrBX_Matrix_import_CSR(GrB_Matrix* A, GrB_Type type, GrB_Index nrows, GrB_Index ncols, GrB_Index nvals,
+                                const uint32_t* rowptr, const uint32_t* colidx, const void* values, int location) {
+  if (!A || !rowptr || (nvals && (!colidx || !values))) return GrB_NULL_POINTER;
+  GrB_Matrix m = nullptr; GrB_Info info = GrB_Matrix_new(&m, type, nrows, ncols); if (info) return info;
+  info = guarded(m, [&] {
+    need_device();
+    if (nrows > GRB_DIM_DEVICE_MAX || ncols > GRB_DIM_DEVICE_MAX || nvals > 0xFFFFFFF0ull) fail(GrB_INSUFFICIENT_SPACE, "import_CSR: 32-bit index range exceeded");
+    DevCSR& c = m->csr; const size_t ts = type->size;
+    c.nrows = (uint32_t)nrows; c.ncols = (uint32_t)ncols; c.nnz = nvals;
+    c.rowptr.alloc((nrows + 1) * 4); c.col.alloc(nvals * 4); c.val.alloc(nvals * ts);
+    hipMemcpyKind k = location ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    GRB_HIP(hipMemcpyAsync(c.rowptr.p, rowptr, (nrows + 1) * 4, k, stream()));
+    if (nvals) { GRB_HIP(hipMemcpyAsync(c.col.p, colidx, nvals * 4, k, stream())); GRB_HIP(hipMemcpyAsync(c.val.p, values, nvals * ts, k, stream())); }
+    GRB_HIP(hipStreamSynchronize(stream()));
+    c.valid = true; m->dev_valid = true; m->host_valid = false;
+  });
+  if (info) { GrB_Matrix_free(&m); return info; }
+  *A = m; return GrB_SUCCESS;
+}
+GrB_Info GrBX_Matrix_export_CSR(const GrB_Matrix A, uint32_t* rowptr, uint32_t* colidx, void* values, int location) {
+  CHECK_MAT(A);
+  return guarded(A, [&] {
+    mat_to_device(A); const DevCSR& c = A->csr; const size_t ts = A->type->size;
+    hipMemcpyKind k = location ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (rowptr) GRB_HIP(hipMemcpyAsync(rowptr, c.rowptr.p, ((size_t)c.nrows + 1) * 4, k, stream()));
+    if (colidx && c.nnz) GRB_HIP(hipMemcpyAsync(colidx, c.col.p, c.nnz * 4, k, stream()));
+    if (values && c.nnz) GRB_HIP(hipMemcpyAsync(values, c.val.p, c.nnz * ts, k, stream()));
+    GRB_HIP(hipStreamSynchronize(stream()));
+  });
+}
+GrB_Info GrBX_Vector_import_Bitmap(GrB_Vector* v, GrB_Type type, GrB_Index n, const void* values, const uint8_t* present, int location) {
+  if (!v || (n && !values)) return GrB_NULL_POINTER;
+  GrB_Vector w = nullptr; GrB_Info info = GrB_Vector_new(&w, type, n); if (info) return info;
+  info = guarded(w, [&] {
+    need_device(); if (n > GRB_DIM_DEVICE_MAX) fail(GrB_INSUFFICIENT_SPACE, "import: vector too long");
+    const size_t ts = type->size; hipMemcpyKind k = location ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    w->dval.alloc(n * ts ? n * ts : 1); w->dpres.alloc(n ? n : 1);
+    if (n) {
+      GRB_HIP(hipMemcpyAsync(w->dval.p, values, n * ts, k, stream()));
+      if (present) GRB_HIP(hipMemcpyAsync(w->dpres.p, present, n, k, stream()));
+      else GRB_HIP(hipMemsetAsync(w->dpres.p, 1, n, stream()));
+    }
+    w->dev_valid = true; w->host_valid = false;
+    w->dnvals = n; w->dnvals_known = !present;
+    GRB_HIP(hipStreamSynchronize(stream()));
+  });
+  if (info) { GrB_Vector_free(&w); return info; }
+  *v = w; return GrB_SUCCESS;
+}
+GrB_Info GrBX_Vector_import_Full(GrB_Vector* v, GrB_Type type, GrB_Index n, const void* values, int location) {
+  return GrBX_Vector_import_Bitmap(v, type, n, values, nullptr, location);
+}
+GrB_Info GrBX_Vector_export_Bitmap(const GrB_Vector v, void* values, uint8_t* present, int location) {
+  CHECK_VEC(v);
+  return guarded(v, [&] {
+    vec_to_device(v); const size_t ts = v->type->size; hipMemcpyKind k = location ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (values && v->n) GRB_HIP(hipMemcpyAsync(values, v->dval.p, v->n * ts, k, stream()));
+    if (present && v->n) GRB_HIP(hipMemcpyAsync(present, v->dpres.p, v->n, k, stream()));
+    GRB_HIP(hipStreamSynchronize(stream()));
+  });
+}
+GrB_Info GrBX_Vector_device_view(GrB_Vector v, void** values, uint8_t** present, GrB_Index* nvals) {
+  CHECK_VEC(v);
+  return guarded(v, [&] { vec_to_device(v); if (values) *values = v->dval.p; if (present) *present = v->dpres.as<uint8_t>(); if (nvals) *nvals = vec_dev_nvals(v); });
+}
+GrB_Info GrBX_Vector_device_touch(GrB_Vector v) {
+  CHECK_VEC(v);
+  return guarded(v, [&] { if (!v->dev_valid) fail(GrB_INVALID_VALUE, "device_touch: vector has no device view");
+    vec_invalidate_host(v); v->dnvals_known = false; });
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+// grb_device.hpp — device-side helpers shared by the HIP kernels (wave64 only: gfx950).
+#pragma once
+#include "grb_internal.hpp"
+#include <string.h>
+
+namespace grb {
+
+// ---- 64-lane cross-lane primitives ----------------------------------------------------------------
+template <class T> __device__ __forceinline__ T shfl_xor_t(T v, int m) {
+  if constexpr (sizeof(T) == 8) {
+    union { T t; int i[2]; } u; u.t = v;
+    u.i[0] = __shfl_xor(u.i[0], m, 64); u.i[1] = __shfl_xor(u.i[1], m, 64); return u.t;
+  } else if constexpr (sizeof(T) == 4) {
+    union { T t; int i; } u; u.t = v; u.i = __shfl_xor(u.i, m, 64); return u.t;
+  } else {
+    union { T t; uint16_t s; uint8_t b; } u; u.s = 0; u.t = v;
+    int x = __shfl_xor((int)u.s, m, 64); u.s = (uint16_t)x; return u.t;
+  }
+}
+template <class T> __device__ __forceinline__ T shfl_down_t(T v, int d) {
+  if constexpr (sizeof(T) == 8) {
+    union { T t; int i[2]; } u; u.t = v;
+    u.i[0] = __shfl_down(u.i[0], d, 64); u.i[1] = __shfl_down(u.i[1], d, 64); return u.t;
+  } else if constexpr (sizeof(T) == 4) {
+    union { T t; int i; } u; u.t = v; u.i = __shfl_down(u.i, d, 64); return u.t;
+  } else {
+    union { T t; uint16_t s; } u; u.s = 0; u.t = v;
+    int x = __shfl_down((int)u.s, d, 64); u.s = (uint16_t)x; return u.t;
+  }
+}
+
+__device__ __forceinline__ unsigned long long wave_reduce_add_u64(unsigned long long v) {
+  return __builtin_amdgcn_wave_reduce_add_u64(v, 0);
+}
+
+// All-lanes monoid reduction.  Integer PLUS/MIN/MAX/LOR use the gfx950 scalar wave-reduce
+// builtins (there is no floating-point variant in this toolchain: SURVEY.md §0), everything
+// else a fixed xor-butterfly, so the combination order is identical on every run.
+template <class T, bool FULL = true> __device__ __forceinline__ T wave_reduce_op(int op, T v) {
+  if constexpr (std::is_integral<T>::value && sizeof(T) >= 4) {
+    if (op == B_PLUS) {
+      if constexpr (sizeof(T) == 8) return (T)__builtin_amdgcn_wave_reduce_add_u64((uint64_t)v, 0);
+      else return (T)__builtin_amdgcn_wave_reduce_add_u32((uint32_t)v, 0);
+    }
+    if (op == B_MIN) {
+      if constexpr (std::is_same<T, int64_t>::value) return __builtin_amdgcn_wave_reduce_min_i64(v, 0);
+      else if constexpr (std::is_same<T, uint64_t>::value) return __builtin_amdgcn_wave_reduce_min_u64(v, 0);
+      else if constexpr (std::is_same<T, int32_t>::value) return __builtin_amdgcn_wave_reduce_min_i32(v, 0);
+      else return __builtin_amdgcn_wave_reduce_min_u32(v, 0);
+    }
+    if (op == B_MAX) {
+      if constexpr (std::is_same<T, int64_t>::value) return __builtin_amdgcn_wave_reduce_max_i64(v, 0);
+      else if constexpr (std::is_same<T, uint64_t>::value) return __builtin_amdgcn_wave_reduce_max_u64(v, 0);
+      else if constexpr (std::is_same<T, int32_t>::value) return __builtin_amdgcn_wave_reduce_max_i32(v, 0);
+      else return __builtin_amdgcn_wave_reduce_max_u32(v, 0);
+    }
+  }
+  if constexpr (is_bool<T>::value) {
+    if (op == B_LOR || op == B_PLUS || op == B_MAX || op == B_ANY)
+      return bool8(__builtin_amdgcn_wave_reduce_or_b32((uint32_t)v.v, 0) != 0);
+    if (op == B_LAND || op == B_TIMES || op == B_MIN)
+      return bool8(__builtin_amdgcn_wave_reduce_and_b32((uint32_t)v.v, 0) != 0);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = apply_binop<T, FULL>(op, v, shfl_xor_t<T>(v, m));
+  return v;
+}
+
+// sub-wave (power-of-two group of G lanes) reduction; result valid in the group's lane 0
+template <class T, int G, bool FULL = true> __device__ __forceinline__ T group_reduce_op(int op, T v) {
+#pragma unroll
+  for (int d = G / 2; d >= 1; d >>= 1) v = apply_binop<T, FULL>(op, v, shfl_down_t<T>(v, d));
+  return v;
+}
+
+template <class T> __device__ __forceinline__ bool val_eq(T a, T b) {
+  if constexpr (is_bool<T>::value) return a.v == b.v; else return a == b;
+}
+#define memcmp_eq(a, b) ::grb::val_eq(a, b)
+
+// ---- a device word the host can read back (count results, flags) ------------------------------------------
+struct ScalarSlot {
+  DevBuf b;
+  ScalarSlot() : b(16) {}
+  void* dev() { return b.p; }
+  void zero() { GRB_HIP(hipMemsetAsync(b.p, 0, 16, stream())); }
+  uint64_t read_u64() {
+    uint64_t v = 0; GRB_HIP(hipMemcpyAsync(&v, b.p, 8, hipMemcpyDeviceToHost, stream()));
+    GRB_HIP(hipStreamSynchronize(stream())); return v;
+  }
+};
+
+// ---- library-backed primitives (grb_prims.hip: rocPRIM scan / radix sort) ------------------------------------
+void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n);            // out[i] = sum in[0..i)
+void sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n, int end_bit);
+void sort_pairs_u64(const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n, int end_bit);
+
+// ---- kernels in grb_vecops.hip ---------------------------------------------------------------------------------
+void vec_epilogue(int code, uint64_t n, void* wval, uint8_t* wpres, const void* tval, const uint8_t* tpres,
+                  const uint8_t* allow, int accum, bool replace);
+void reduce_values(int code, uint64_t n, const void* val, const uint8_t* pres, int op, const void* identity, void* result_host);
+void vec_ewise(int code, uint64_t n, const void* uval, const uint8_t* upres, const void* vval, const uint8_t* vpres, int op,
+               bool is_union, void* tval, uint8_t* tpres);
+void vec_apply(int code, uint64_t n, const void* uval, const uint8_t* upres, int mode, int op, const void* scalar, void* tval, uint8_t* tpres);
+void vec_assign_scalar(int code, uint64_t n, void* wval, uint8_t* wpres, const uint8_t* allow, const uint8_t* region, const void* scalar, int accum, bool replace);
+void select_value_flags(int code, uint64_t n, const void* val, const uint8_t* pres, int sel, const void* thunk, uint8_t* keep);
+
+}  // namespace grb

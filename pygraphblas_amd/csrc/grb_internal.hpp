@@ -1,0 +1,184 @@
+// grb_internal.hpp — object model of the MI355X GraphBLAS backend (not part of the C ABI).
+//
+// Layout in HBM:
+//   Matrix : CSR  rowptr u32[nrows+1] | col u32[nnz] (sorted within a row) | val T[nnz]
+//            + a lazily built, cached CSR of the transpose ("CSC view") and SpMV row-block plan.
+//   Vector : bitmap  val T[n] | present u8[n]   (+ nvals); sparse index lists are transient.
+// Host mirrors (sorted tuples) exist only for element-wise host access (setElement /
+// extractTuples) and are synchronised lazily in either direction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include <mutex>
+#include "grb_ops.hpp"
+
+typedef uint64_t GrB_Index;
+
+// GrB_Info: positive v1.3 / SuiteSparse-5 numbering (reference: pygraphblas/base.py:189-203)
+enum GrB_Info_e : int {
+  GrB_SUCCESS = 0, GrB_NO_VALUE = 1, GrB_UNINITIALIZED_OBJECT = 2, GrB_INVALID_OBJECT = 3,
+  GrB_NULL_POINTER = 4, GrB_INVALID_VALUE = 5, GrB_INVALID_INDEX = 6, GrB_DOMAIN_MISMATCH = 7,
+  GrB_DIMENSION_MISMATCH = 8, GrB_OUTPUT_NOT_EMPTY = 9, GrB_OUT_OF_MEMORY = 10,
+  GrB_INSUFFICIENT_SPACE = 11, GrB_INDEX_OUT_OF_BOUNDS = 12, GrB_PANIC = 13
+};
+typedef int GrB_Info;
+
+// descriptor fields / values (SuiteSparse v5.1 numbering)
+enum { GrB_OUTP = 0, GrB_MASK = 1, GrB_INP0 = 2, GrB_INP1 = 3,
+       GxB_DESCRIPTOR_NTHREADS = 5, GxB_DESCRIPTOR_CHUNK = 7, GxB_DESCRIPTOR_GPU_CONTROL = 21,
+       GxB_DESCRIPTOR_GPU_CHUNK = 22, GxB_AxB_METHOD = 1000, GxB_SORT = 35 };
+enum { GxB_DEFAULT = 0, GrB_REPLACE = 1, GrB_COMP = 2, GrB_TRAN = 3, GrB_STRUCTURE = 4,
+       GxB_AxB_GUSTAVSON = 1001, GxB_AxB_DOT = 1003, GxB_AxB_HASH = 1004, GxB_AxB_SAXPY = 1005 };
+
+#define GRB_MAGIC 0x72657473786f62ULL
+#define GRB_FREED 0x6c6c756e786f62ULL
+#define GRB_DIM_DEVICE_MAX 0xFFFFFFF0ULL   // device containers use 32-bit indices
+#define GXB_INDEX_MAX ((GrB_Index)1 << 60)
+
+struct GrB_Type_opaque { uint64_t magic; int code; size_t size; char name[32]; };
+struct GrB_UnaryOp_opaque { uint64_t magic; int opcode; GrB_Type_opaque* xtype; GrB_Type_opaque* ztype; char name[40]; void* fn; };
+struct GrB_BinaryOp_opaque { uint64_t magic; int opcode; GrB_Type_opaque* xtype; GrB_Type_opaque* ytype; GrB_Type_opaque* ztype; char name[40]; void* fn; };
+struct GrB_Monoid_opaque { uint64_t magic; GrB_BinaryOp_opaque* op; uint8_t identity[16]; bool has_terminal; uint8_t terminal[16]; char name[48]; bool builtin; };
+struct GrB_Semiring_opaque { uint64_t magic; GrB_Monoid_opaque* add; GrB_BinaryOp_opaque* mul; char name[56]; bool builtin; };
+struct GrB_Descriptor_opaque { uint64_t magic; int outp, mask, inp0, inp1, axb, nthreads, sort; double chunk; bool builtin; char name[16]; };
+struct GxB_SelectOp_opaque { uint64_t magic; int opcode; char name[24]; void* fn; GrB_Type_opaque* xtype; GrB_Type_opaque* ttype; };
+
+typedef GrB_Type_opaque* GrB_Type;
+typedef GrB_UnaryOp_opaque* GrB_UnaryOp;
+typedef GrB_BinaryOp_opaque* GrB_BinaryOp;
+typedef GrB_Monoid_opaque* GrB_Monoid;
+typedef GrB_Semiring_opaque* GrB_Semiring;
+typedef GrB_Descriptor_opaque* GrB_Descriptor;
+typedef GxB_SelectOp_opaque* GxB_SelectOp;
+
+enum SelectCode { SEL_TRIL = 0, SEL_TRIU, SEL_DIAG, SEL_OFFDIAG, SEL_NONZERO, SEL_EQ_ZERO, SEL_GT_ZERO,
+                  SEL_GE_ZERO, SEL_LT_ZERO, SEL_LE_ZERO, SEL_NE_THUNK, SEL_EQ_THUNK, SEL_GT_THUNK,
+                  SEL_GE_THUNK, SEL_LT_THUNK, SEL_LE_THUNK, SEL_USER };
+
+namespace grb {
+
+// ---- device memory ----------------------------------------------------------------------
+bool device_ok();                 // a HIP device was found at init
+const char* device_error();       // why not
+hipStream_t stream();             // the stream every kernel of the library is launched on
+void* dev_alloc(size_t bytes);    // pooled hipMalloc; throws GrbError(OUT_OF_MEMORY/PANIC)
+void dev_free(void* p);
+void dev_pool_release();          // return cached blocks to the driver
+size_t dev_bytes_in_use();
+
+struct GrbError { int info; std::string msg; };
+[[noreturn]] void fail(int info, const std::string& msg);
+#define GRB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+  ::grb::fail(GrB_PANIC, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+// owning device buffer
+struct DevBuf {
+  void* p = nullptr; size_t bytes = 0;
+  DevBuf() {}
+  explicit DevBuf(size_t n) { alloc(n); }
+  DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { reset(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; } return *this; }
+  ~DevBuf() { reset(); }
+  void alloc(size_t n) { reset(); if (n) { p = dev_alloc(n); bytes = n; } }
+  void reset() { if (p) dev_free(p); p = nullptr; bytes = 0; }
+  template <class T> T* as() const { return (T*)p; }
+};
+
+// ---- device CSR ---------------------------------------------------------------------------
+struct DevCSR {
+  uint32_t nrows = 0, ncols = 0; uint64_t nnz = 0;
+  DevBuf rowptr, col, val;      // u32[nrows+1], u32[nnz], T[nnz]
+  // SpMV row-block plan (grb_spmv.hip): blocks of consecutive rows holding <= SPMV_BLOCK_NNZ
+  // entries, long rows split into parts.  Built on first mxv, cached with the matrix.
+  DevBuf plan_blocks; uint32_t plan_nblocks = 0; DevBuf plan_aux; uint32_t plan_nlong = 0;
+  bool has_plan = false;
+  bool valid = false;
+  void clear() { rowptr.reset(); col.reset(); val.reset(); plan_blocks.reset(); plan_aux.reset();
+                 nnz = 0; has_plan = false; valid = false; plan_nblocks = plan_nlong = 0; }
+};
+
+}  // namespace grb
+
+struct GrB_Matrix_opaque {
+  uint64_t magic = GRB_MAGIC;
+  GrB_Type type = nullptr;
+  GrB_Index nrows = 0, ncols = 0;
+  // host mirror: tuples sorted by (i, j), values packed at type->size each
+  bool host_valid = true;
+  std::vector<GrB_Index> hi, hj; std::vector<uint8_t> hx;
+  // pending host edits (setElement / removeElement), applied in order at assemble time
+  struct Pending { GrB_Index i, j; bool del; uint8_t x[16]; };
+  std::vector<Pending> pending;
+  // device
+  bool dev_valid = false;
+  grb::DevCSR csr;          // by-row
+  grb::DevCSR csc;          // CSR of the transpose (cached; invalidated with csr)
+  int format = 0;           // GxB_BY_ROW(0) / GxB_BY_COL(1): stored option only
+  int sparsity_control = 15;
+  double hyper_switch = 0.0625;
+  std::string err;
+};
+
+struct GrB_Vector_opaque {
+  uint64_t magic = GRB_MAGIC;
+  GrB_Type type = nullptr;
+  GrB_Index n = 0;
+  bool host_valid = true;
+  std::vector<GrB_Index> hi; std::vector<uint8_t> hx;
+  struct Pending { GrB_Index i; bool del; uint8_t x[16]; };
+  std::vector<Pending> pending;
+  bool dev_valid = false;
+  grb::DevBuf dval, dpres;   // T[n], u8[n]
+  uint64_t dnvals = 0; bool dnvals_known = true;   // entry count of the device bitmap, recounted lazily
+  int sparsity_control = 15;
+  std::string err;
+};
+
+struct GxB_Scalar_opaque {
+  uint64_t magic = GRB_MAGIC;
+  GrB_Type type = nullptr; bool has = false; uint8_t x[16] = {0};
+  std::string err;
+};
+
+typedef GrB_Matrix_opaque* GrB_Matrix;
+typedef GrB_Vector_opaque* GrB_Vector;
+typedef GxB_Scalar_opaque* GxB_Scalar;
+
+namespace grb {
+
+// ---- containers (grb_container.cpp) ----------------------------------------------------------
+void mat_host_assemble(GrB_Matrix A);     // apply pending edits to the host mirror
+void mat_to_host(GrB_Matrix A);           // ensure host mirror valid (downloads if needed)
+void mat_to_device(GrB_Matrix A);         // ensure device CSR valid (assembles + uploads)
+void mat_invalidate_host(GrB_Matrix A);   // device was written
+void mat_invalidate_device(GrB_Matrix A); // host was written
+uint64_t mat_nvals(GrB_Matrix A);
+void vec_host_assemble(GrB_Vector v);
+void vec_to_host(GrB_Vector v);
+void vec_to_device(GrB_Vector v);
+void vec_invalidate_host(GrB_Vector v);
+void vec_invalidate_device(GrB_Vector v);
+uint64_t vec_nvals(GrB_Vector v);
+uint64_t vec_dev_nvals(GrB_Vector v);   // entry count of the (valid) device bitmap
+const DevCSR& mat_csc(GrB_Matrix A);      // cached CSR of A^T (device)
+
+bool check_obj(const void* p);            // magic check
+GrB_Type type_by_code(int code);
+
+// scalar conversion between any two built-in real types through host code
+void cast_scalar(int dst_code, void* dst, int src_code, const void* src);
+
+// ---- kernels launched from the op drivers (see the respective .hip files) -----------------------
+// grb_transpose.hip
+void csr_transpose(const DevCSR& A, size_t tsize, DevCSR& At);
+// grb_vecops.hip
+void vec_cast_values(int dst_code, void* dst, int src_code, const void* src, uint64_t n);
+void build_allow(uint64_t n, int mcode, const void* mval, const uint8_t* mpres, bool structural,
+                 bool complement, uint8_t* allow);
+uint64_t count_present(const uint8_t* pres, uint64_t n);
+
+}  // namespace grb

@@ -1,0 +1,89 @@
+// grb_mxv.cpp — GrB_mxv and GrB_vxm: the SpMV half of the hot path.
+//
+// Replaces lib.GrB_mxv (reference call site pygraphblas/matrix.py:2714-2725, Matrix.mxv) and
+// lib.GrB_vxm (pygraphblas/vector.py:960-970, Vector.vxm); semantics per SURVEY.md App. A:
+//   w<mask,replace> = accum(w, op(A) (+).(x) u)         mxv: multiply is A(i,j) (x) u(j),  desc.INP0 transposes A
+//   w'<mask',replace> = accum(w', u' (+).(x) op(A))     vxm: multiply is u(i) (x) A(i,j),  desc.INP1 transposes A
+// Both are executed in "mxv orientation" t = M (+).(x) u with M = op(A) (mxv) or op(A)^T (vxm);
+// whichever of CSR(A) / CSR(A^T) the chosen direction needs is taken from the matrix (the transpose
+// is built once on the device and cached).
+#include "grb_opcommon.hpp"
+#include "grb_spmv.hpp"
+
+using namespace grb;
+
+static int g_force_method = SPMV_AUTO;   // test hook: GRB_MI355X_SPMV=adaptive|rowgroup|push
+
+static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semiring semiring, GrB_Matrix A, GrB_Vector u,
+                     GrB_Descriptor desc, bool is_vxm) {
+  need_device();
+  if (!check_obj(w) || !check_obj(A) || !check_obj(u) || (mask && !check_obj(mask)))
+    fail(GrB_UNINITIALIZED_OBJECT, "mxv/vxm: uninitialised operand");
+  const DescView dv(desc);
+  const bool useT = is_vxm ? !dv.tran1 : dv.tran0;           // M = useT ? A^T : A
+  const uint64_t mr = useT ? A->ncols : A->nrows, mc = useT ? A->nrows : A->ncols;
+  if (u->n != mc || w->n != mr || (mask && mask->n != mr)) fail(GrB_DIMENSION_MISMATCH, "mxv/vxm: dimensions do not conform");
+  SemiringDesc sd = make_semiring_desc(semiring, /*swap_mult_args=*/is_vxm);
+  const char* env = getenv("GRB_MI355X_SPMV");
+  int method = g_force_method;
+  if (env) method = !strcmp(env, "adaptive") ? SPMV_ADAPTIVE : !strcmp(env, "rowgroup") ? SPMV_ROWGROUP : !strcmp(env, "push") ? SPMV_PUSH : SPMV_AUTO;
+  g_last_plan.clear();
+
+  DevBuf allow_buf; bool nothing = false;
+  const uint8_t* allow = vector_allow(mask, dv, mr, allow_buf, &nothing);
+  if (nothing) {   // no mask + complement: nothing may be written; replace clears w
+    if (dv.replace) { w->hi.clear(); w->hx.clear(); w->pending.clear(); w->host_valid = true; vec_invalidate_device(w); }
+    return;
+  }
+  mat_to_device(A); vec_to_device(u);
+  const uint64_t u_nvals = vec_dev_nvals(u);
+  const bool u_full = u_nvals == u->n;
+
+  // does the multiply read the matrix / vector values at all?
+  const bool uses_a = sd.flip ? binop_uses_y(sd.mulop) : binop_uses_x(sd.mulop);
+  const bool uses_u = sd.flip ? binop_uses_x(sd.mulop) : binop_uses_y(sd.mulop);
+
+  // direction: push when the frontier is sparse enough that its rows hold < 1/8 of the entries
+  const double avgdeg = (double)A->csr.nnz / (double)(mc ? mc : 1);   // mean length of the rows a push would walk
+  bool push = spmspv_push_supported(sd) && !u_full && (double)u_nvals * (avgdeg + 1) * 8 < (double)A->csr.nnz + 1;
+  if (method == SPMV_PUSH) push = spmspv_push_supported(sd);
+  else if (method == SPMV_ADAPTIVE || method == SPMV_ROWGROUP) push = false;
+
+  const size_t zs = type_size(sd.zcode);
+  DevBuf tval(mr * zs + 1), tpres(mr + 1), ucast, acast;
+  const void* uval = uses_u ? cast_values(sd.zcode, u->type->code, u->dval.p, u->n, ucast) : nullptr;
+
+  SpmvCall call{};
+  call.uval = uval; call.allow = allow; call.tval = tval.p; call.tpres = tpres.as<uint8_t>(); call.method = method;
+  if (push) {
+    // push walks rows of M^T:  M^T = useT ? A : A^T
+    DevCSR& P = useT ? A->csr : const_cast<DevCSR&>(mat_csc(A));
+    call.M = &P; call.upres = u->dpres.as<uint8_t>();
+    call.aval = uses_a ? cast_values(sd.zcode, A->type->code, P.val.p, P.nnz, acast) : nullptr;
+    spmspv_push(call, sd, u_nvals);
+  } else {
+    DevCSR& R = useT ? const_cast<DevCSR&>(mat_csc(A)) : A->csr;
+    call.M = &R; call.upres = u_full ? nullptr : u->dpres.as<uint8_t>();
+    call.aval = uses_a ? cast_values(sd.zcode, A->type->code, R.val.p, R.nnz, acast) : nullptr;
+    spmv_pull(call, sd);
+  }
+  vector_write_back(w, sd.zcode, tval, tpres, allow, accum, dv.replace, /*t_only_allowed=*/true);
+}
+
+extern "C" {
+
+GrB_Info GrB_mxv(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Semiring semiring,
+                 const GrB_Matrix A, const GrB_Vector u, const GrB_Descriptor desc) {
+  if (!w || !A || !u || !semiring) return GrB_NULL_POINTER;
+  if (!check_obj(w)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(w, [&] { mxv_like(w, mask, accum, semiring, A, u, desc, false); });
+}
+
+GrB_Info GrB_vxm(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Semiring semiring,
+                 const GrB_Vector u, const GrB_Matrix A, const GrB_Descriptor desc) {
+  if (!w || !A || !u || !semiring) return GrB_NULL_POINTER;
+  if (!check_obj(w)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(w, [&] { mxv_like(w, mask, accum, semiring, A, u, desc, true); });
+}
+
+}  // extern "C"

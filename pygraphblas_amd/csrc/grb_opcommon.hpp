@@ -1,0 +1,77 @@
+// grb_opcommon.hpp — pieces every GraphBLAS operation driver shares: operator validation, operand
+// typecasts into the operator's domain, mask -> allow bytes, and the final
+// C<M,replace> = accum(C, T) write-back for vectors.
+#pragma once
+#include "grb_api.hpp"
+#include "grb_device.hpp"
+#include "grb_semiring.hpp"
+
+namespace grb {
+
+inline void not_implemented(const std::string& what) { fail(GrB_INVALID_VALUE, "not implemented in the MI355X backend: " + what); }
+
+// built-in, same-type binary operator (x, y, z all one real type) or a comparison whose inputs share a type
+inline void check_binop(GrB_BinaryOp op, const char* what) {
+  if (!check_obj(op)) fail(GrB_UNINITIALIZED_OBJECT, std::string(what) + " operator is not initialised");
+  if (op->opcode >= B_FIRSTI) not_implemented(std::string("positional / user-defined operator ") + op->name);
+  if (op->xtype != op->ytype) not_implemented(std::string("mixed-type operator ") + op->name);
+}
+
+inline SemiringDesc make_semiring_desc(GrB_Semiring s, bool swap_mult_args) {
+  if (!check_obj(s)) fail(GrB_UNINITIALIZED_OBJECT, "semiring is not initialised");
+  check_binop(s->mul, "multiply"); check_binop(s->add->op, "monoid");
+  if (s->mul->xtype != s->mul->ztype) not_implemented(std::string("semiring with a comparison multiplier: ") + s->name);
+  SemiringDesc d{};
+  d.zcode = s->add->op->ztype->code; d.addop = s->add->op->opcode; d.mulop = s->mul->opcode; d.flip = false;
+  if (swap_mult_args) { int m; if (mirror_binop(d.mulop, &m)) d.mulop = m; else d.flip = true; }
+  memcpy(d.identity, s->add->identity, 16); memcpy(d.terminal, s->add->terminal, 16); d.has_terminal = s->add->has_terminal;
+  return d;
+}
+
+// values of a device array in another type: returns `src` itself when no cast is needed, else fills `tmp`
+inline const void* cast_values(int dst_code, int src_code, const void* src, uint64_t n, DevBuf& tmp) {
+  if (dst_code == src_code || n == 0) return src;
+  tmp.alloc(n * type_size(dst_code));
+  vec_cast_values(dst_code, tmp.p, src_code, src, n);
+  return tmp.p;
+}
+
+// mask vector -> allow bytes.  Returns nullptr (= everything allowed) when there is no mask and no
+// complement; sets *nothing when there is no mask but the complement flag is set.
+inline const uint8_t* vector_allow(GrB_Vector mask, const DescView& dv, uint64_t n, DevBuf& tmp, bool* nothing) {
+  *nothing = false;
+  if (!mask) { if (dv.mask_comp) *nothing = true; return nullptr; }
+  vec_to_device(mask);
+  tmp.alloc(n ? n : 1);
+  build_allow(n, mask->type->code, mask->dval.p, mask->dpres.as<uint8_t>(), dv.mask_struct, dv.mask_comp, tmp.as<uint8_t>());
+  return tmp.as<uint8_t>();
+}
+
+// Write T (bitmap tval/tpres of type tcode; buffers are consumed) into w under mask/accum/replace.
+// `t_only_allowed`: T has no entries where the mask forbids writing (true for the kernels here).
+inline void vector_write_back(GrB_Vector w, int tcode, DevBuf& tval, DevBuf& tpres, const uint8_t* allow, GrB_BinaryOp accum,
+                              bool replace, bool t_only_allowed) {
+  const uint64_t n = w->n; const int wcode = w->type->code;
+  const bool w_empty = w->host_valid ? (vec_nvals(w) == 0) : (w->dnvals_known && w->dnvals == 0);
+  if (accum) check_binop(accum, "accum");
+  if (!accum && (!allow || (t_only_allowed && (replace || w_empty)))) {
+    // w becomes exactly T: adopt the buffers (typecast the values if the output type differs)
+    if (tcode != wcode) { DevBuf c(n * w->type->size + 1); vec_cast_values(wcode, c.p, tcode, tval.p, n); tval = std::move(c); }
+    vec_invalidate_host(w);
+    w->dval = std::move(tval); w->dpres = std::move(tpres); w->dev_valid = true; w->dnvals_known = false; w->dnvals = 0;
+    return;
+  }
+  vec_to_device(w);
+  // the epilogue runs in the accumulator's domain (or w's type without one)
+  const int ecode = accum ? accum->xtype->code : wcode;
+  DevBuf tc, wc;
+  const void* tv = cast_values(ecode, tcode, tval.p, n, tc);
+  void* wv = w->dval.p;
+  if (ecode != wcode) { wc.alloc(n * type_size(ecode) + 1); vec_cast_values(ecode, wc.p, wcode, w->dval.p, n); wv = wc.p; }
+  vec_epilogue(ecode, n, wv, w->dpres.as<uint8_t>(), tv, tpres.as<uint8_t>(), allow, accum ? accum->opcode : -1, replace);
+  if (ecode != wcode) vec_cast_values(wcode, w->dval.p, ecode, wv, n);
+  vec_invalidate_host(w);
+  w->dnvals_known = false;   // temporaries return to the pool; reuse is stream-ordered
+}
+
+}  // namespace grb

@@ -1,0 +1,34 @@
+// grb_prims.hip — device-wide scan and radix sort, delegated to rocPRIM (header-only, ships with
+// ROCm).  These are support primitives for format conversion (CSR build, transpose, compaction);
+// the hot-path kernels (grb_spmv.hip, grb_spgemm.hip) are hand-written.
+#include "grb_api.hpp"
+#include "grb_device.hpp"
+#include <rocprim/rocprim.hpp>
+
+namespace grb {
+
+void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n) {
+  if (!n) return;
+  size_t tmp = 0;
+  GRB_HIP(rocprim::exclusive_scan(nullptr, tmp, in, out, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>(), stream()));
+  DevBuf t(tmp ? tmp : 16);
+  GRB_HIP(rocprim::exclusive_scan(t.p, tmp, in, out, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>(), stream()));
+}
+
+void sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n, int end_bit) {
+  if (!n) return;
+  size_t tmp = 0;
+  GRB_HIP(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)end_bit, stream()));
+  DevBuf t(tmp ? tmp : 16);
+  GRB_HIP(rocprim::radix_sort_pairs(t.p, tmp, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)end_bit, stream()));
+}
+
+void sort_pairs_u64(const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n, int end_bit) {
+  if (!n) return;
+  size_t tmp = 0;
+  GRB_HIP(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)end_bit, stream()));
+  DevBuf t(tmp ? tmp : 16);
+  GRB_HIP(rocprim::radix_sort_pairs(t.p, tmp, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)end_bit, stream()));
+}
+
+}  // namespace grb

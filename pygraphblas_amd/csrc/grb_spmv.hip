@@ -1,0 +1,102 @@
+// grb_spmv.hip — the SpMV / SpMSpV kernels behind GrB_mxv and GrB_vxm  (HBM-bound; no MFMA).
+//
+//   t(i) = (+)_j  mult(M(i,j), u(j))      M in CSR (u32 rowptr/col, sorted rows), u and t bitmap
+//
+// Three hand-written kernels, all wave64:
+//  A  k_spmv_adaptive   row-block ("CSR-adaptive" style) pull kernel — the FP64 PLUS_TIMES
+//                       north-star path.  A block of 256 threads owns a run of consecutive rows
+//                       holding <= 2048 entries: col/val are read fully coalesced (every lane a
+//                       consecutive entry, 8 independent loads in flight per lane before the
+//                       first use), u is gathered (n*8 B = 32 MiB at R-MAT-22: L2/Infinity-Cache
+//                       resident), products are staged in LDS and each row is reduced from LDS
+//                       in a fixed left-to-right order (deterministic).  Rows longer than a
+//                       block are split into 8192-entry parts; the last part to arrive combines
+//                       the partials in part order (agent-scope fence + ticket, guide §6 G16).
+//  B  k_spmv_rowgroup   G lanes per row with mask skip and monoid-terminal early exit — the
+//                       pull step of BFS (complemented visited mask, LOR terminal).
+//  C  k_spmspv_push     frontier-driven scatter with atomics — the push step when u is sparse.
+// Algorithmic bytes per call: nnz*(sizeof(T)+4) + (nrows+1)*4 + ncols*T + nrows*T.
+#include "grb_api.hpp"
+#include "grb_device.hpp"
+#include "grb_semiring.hpp"
+#include "grb_spmv.hpp"
+#include <vector>
+
+namespace grb {
+
+// per-type kernel instantiations live in grb_spmv_inst.hip (compiled once per value type, in parallel)
+template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d);
+template <class T> void run_push(const SpmvCall& c, const SemiringDesc& d, const uint32_t* fidx, uint64_t u_nvals);
+
+// ---- plan: greedy row blocking, once per matrix -------------------------------------------------------------
+void spmv_build_plan(DevCSR& M) {
+  if (M.has_plan) return;
+  std::vector<uint32_t> rp((size_t)M.nrows + 1);
+  GRB_HIP(hipMemcpyAsync(rp.data(), M.rowptr.p, rp.size() * 4, hipMemcpyDeviceToHost, stream()));
+  GRB_HIP(hipStreamSynchronize(stream()));
+  std::vector<SpmvBlock> blocks; blocks.reserve(M.nnz / SPMV_NNZ * 2 + 16);
+  uint32_t nslots = 0, nlong = 0;
+  uint32_t r = 0; const uint32_t n = M.nrows;
+  while (r < n) {
+    const uint32_t len = rp[r + 1] - rp[r];
+    if (len > (uint32_t)SPMV_NNZ) {
+      const uint32_t parts = (len + SPMV_LONG_CHUNK - 1) / SPMV_LONG_CHUNK;
+      for (uint32_t p = 0; p < parts; p++) blocks.push_back({r, p, parts, nslots});
+      if (parts > 1) { nslots += parts; nlong++; }
+      r++;
+    } else {
+      uint32_t e = r, tot = 0;
+      while (e < n && e - r < (uint32_t)SPMV_MAX_ROWS) {
+        const uint32_t l = rp[e + 1] - rp[e];
+        if (tot + l > (uint32_t)SPMV_NNZ) break;
+        tot += l; e++;
+      }
+      blocks.push_back({r, e, 0, 0});
+      r = e;
+    }
+  }
+  M.plan_nblocks = (uint32_t)blocks.size(); M.plan_nlong = nslots;
+  M.plan_blocks.alloc(blocks.size() * sizeof(SpmvBlock) + 16);
+  GRB_HIP(hipMemcpyAsync(M.plan_blocks.p, blocks.data(), blocks.size() * sizeof(SpmvBlock), hipMemcpyHostToDevice, stream()));
+  // aux: [tickets u32[nblocks]] [partials 8 B * nslots] [partial flags u8 * nslots]  (tickets indexed by `slot`)
+  const size_t aux = (size_t)(nslots + 1) * 4 + (size_t)(nslots + 1) * 8 + (size_t)(nslots + 1);
+  M.plan_aux.alloc(aux);
+  GRB_HIP(hipMemsetAsync(M.plan_aux.p, 0, aux, stream()));
+  GRB_HIP(hipStreamSynchronize(stream()));
+  M.has_plan = true;
+}
+
+void spmv_pull(const SpmvCall& c, const SemiringDesc& d) {
+  dispatch_type(d.zcode, [&]<class T>() { run_pull<T>(c, d); });
+  GRB_HIP(hipGetLastError());
+}
+
+bool spmspv_push_supported(const SemiringDesc& d) {
+  const int ts = type_size(d.zcode);
+  if (d.zcode == T_BOOL) return d.addop == B_LOR || d.addop == B_ANY || d.addop == B_PLUS || d.addop == B_MAX;
+  if (ts < 4) return false;
+  return d.addop == B_PLUS || d.addop == B_MIN || d.addop == B_MAX;
+}
+
+// gather the indices of present entries of a bitmap vector (ascending) -> fidx, returns count
+__global__ void k_flag_to_u32(const uint8_t* __restrict__ pres, uint64_t n, uint32_t* __restrict__ out) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) out[i] = pres[i] ? 1u : 0u;
+}
+__global__ void k_compact_idx(const uint8_t* __restrict__ pres, const uint32_t* __restrict__ pos, uint64_t n, uint32_t* __restrict__ out) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) if (pres[i]) out[pos[i]] = (uint32_t)i;
+}
+
+void spmspv_push(const SpmvCall& c, const SemiringDesc& d, uint64_t u_nvals) {
+  // c.M here is the CSR whose ROWS are indexed like u (i.e. the transpose of the pull operand)
+  DevCSR& M = *c.M; const uint64_t nu = M.nrows, nout = M.ncols;
+  auto grid_of = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 4096) b = 4096; return (unsigned)b; };
+  DevBuf flags(nu * 4 + 4), pos(nu * 4 + 4), fidx((u_nvals + 1) * 4);
+  hipLaunchKernelGGL(k_flag_to_u32, dim3(grid_of(nu)), dim3(256), 0, stream(), c.upres, nu, flags.as<uint32_t>());
+  exclusive_scan_u32(flags.as<uint32_t>(), pos.as<uint32_t>(), nu);
+  hipLaunchKernelGGL(k_compact_idx, dim3(grid_of(nu)), dim3(256), 0, stream(), c.upres, pos.as<uint32_t>(), nu, fidx.as<uint32_t>());
+  GRB_HIP(hipMemsetAsync(c.tpres, 0, nout ? nout : 1, stream()));
+  dispatch_type(d.zcode, [&]<class T>() { run_push<T>(c, d, fidx.as<uint32_t>(), u_nvals); });
+  GRB_HIP(hipGetLastError());
+}
+
+}  // namespace grb

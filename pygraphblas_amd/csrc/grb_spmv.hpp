@@ -1,0 +1,35 @@
+// grb_spmv.hpp — host interface of the SpMV / SpMSpV kernels (grb_spmv.hip).
+#pragma once
+#include "grb_internal.hpp"
+#include "grb_semiring.hpp"
+
+namespace grb {
+
+constexpr int SPMV_THREADS = 256;
+constexpr int SPMV_NNZ = 2048;          // entries per stream block  (LDS: 2048 * sizeof(T) <= 16 KiB)
+constexpr int SPMV_UNROLL = SPMV_NNZ / SPMV_THREADS;
+constexpr int SPMV_LONG_CHUNK = 8192;   // entries per part of a long row
+constexpr int SPMV_MAX_ROWS = 1024;     // rows per stream block (bounds runs of empty rows)
+
+struct SpmvBlock { uint32_t row, aux, nparts, slot; };
+// stream block : rows [row, aux), nparts == 0
+// long-row part: row, aux = part index, nparts >= 1, slot = first partial slot of this row
+
+enum SpmvMethod { SPMV_AUTO = 0, SPMV_ADAPTIVE = 1, SPMV_ROWGROUP = 2, SPMV_PUSH = 3 };
+
+struct SpmvCall {
+  DevCSR* M;                // pull: rows of M index the output.  push: rows of M index the input u.
+  const void* aval;         // M's values already in the semiring type (nullptr when the multiply ignores them)
+  const void* uval;         // u values in the semiring type (dense array of length ncols(M) / nrows(M) for push)
+  const uint8_t* upres;     // presence bytes, nullptr when every entry of u is present (pull only)
+  const uint8_t* allow;     // per-output "mask allows writing" bytes, nullptr = all allowed
+  void* tval; uint8_t* tpres;   // output bitmap vector (semiring type)
+  int method = SPMV_AUTO;
+};
+
+void spmv_build_plan(DevCSR& M);
+void spmv_pull(const SpmvCall& c, const SemiringDesc& d);
+bool spmspv_push_supported(const SemiringDesc& d);
+void spmspv_push(const SpmvCall& c, const SemiringDesc& d, uint64_t u_nvals);
+
+}  // namespace grb

@@ -1,0 +1,8 @@
+// grb_spmv_inst.hip — explicit instantiation of the SpMV kernels for ONE value type.
+// The Makefile compiles this file once per built-in type (-DGRB_INST_TYPE=...), in parallel.
+#include "grb_spmv_kernels.hpp"
+namespace grb {
+using std::int8_t; using std::uint8_t; using std::int16_t; using std::uint16_t; using std::int32_t; using std::uint32_t; using std::int64_t; using std::uint64_t;
+template void run_pull<GRB_INST_TYPE>(const SpmvCall&, const SemiringDesc&);
+template void run_push<GRB_INST_TYPE>(const SpmvCall&, const SemiringDesc&, const uint32_t*, uint64_t);
+}

@@ -1,0 +1,306 @@
+// grb_spmv_kernels.hpp — the SpMV / SpMSpV kernels behind GrB_mxv and GrB_vxm  (HBM-bound; no MFMA).
+//
+//   t(i) = (+)_j  mult(M(i,j), u(j))      M in CSR (u32 rowptr/col, sorted rows), u and t bitmap
+//
+// Three hand-written kernels, all wave64:
+//  A  k_spmv_adaptive   row-block ("CSR-adaptive" style) pull kernel — the FP64 PLUS_TIMES
+//                       north-star path.  A block of 256 threads owns a run of consecutive rows
+//                       holding <= 2048 entries: col/val are read fully coalesced (every lane a
+//                       consecutive entry, 8 independent loads in flight per lane before the
+//                       first use), u is gathered (n*8 B = 32 MiB at R-MAT-22: L2/Infinity-Cache
+//                       resident), products are staged in LDS and each row is reduced from LDS
+//                       in a fixed left-to-right order (deterministic).  Rows longer than a
+//                       block are split into 8192-entry parts; the last part to arrive combines
+//                       the partials in part order (agent-scope fence + ticket, guide §6 G16).
+//  B  k_spmv_rowgroup   G lanes per row with mask skip and monoid-terminal early exit — the
+//                       pull step of BFS (complemented visited mask, LOR terminal).
+//  C  k_spmspv_push     frontier-driven scatter with atomics — the push step when u is sparse.
+// Algorithmic bytes per call: nnz*(sizeof(T)+4) + (nrows+1)*4 + ncols*T + nrows*T.
+#pragma once
+#include "grb_api.hpp"
+#include "grb_device.hpp"
+#include "grb_semiring.hpp"
+#include "grb_spmv.hpp"
+
+namespace grb {
+
+template <class T> struct SpmvKArgs {
+  const uint32_t* rowptr; const uint32_t* col; const T* aval;
+  const T* uval; const uint8_t* upres; const uint8_t* allow;
+  T* tval; uint8_t* tpres;
+  const SpmvBlock* blocks; uint32_t* tickets; T* partial; uint8_t* pflag;
+  uint32_t nrows;
+};
+
+// ---- kernel A ---------------------------------------------------------------------------------------------------
+template <class T, class SR, bool U_FULL, bool HAS_ALLOW>
+__global__ __launch_bounds__(SPMV_THREADS) void k_spmv_adaptive(const SpmvKArgs<T> a, const SR sr) {
+  __shared__ T s_prod[SPMV_NNZ];
+  __shared__ uint8_t s_has[U_FULL ? 4 : SPMV_NNZ];
+  __shared__ T s_wave[SPMV_THREADS / 64];
+  __shared__ uint8_t s_whas[SPMV_THREADS / 64];
+  const int tid = threadIdx.x;
+  const SpmvBlock b = a.blocks[blockIdx.x];
+  const bool use_a = sr.uses_a(), use_u = sr.uses_u();
+
+  if (b.nparts == 0) {
+    const uint32_t r0 = b.row, r1 = b.aux;
+    if constexpr (HAS_ALLOW) {
+      int any = 0;
+      for (uint32_t r = r0 + tid; r < r1; r += SPMV_THREADS) any |= a.allow[r];
+      if (!__syncthreads_or(any)) {   // the whole block is masked out: no matrix traffic at all
+        for (uint32_t r = r0 + tid; r < r1; r += SPMV_THREADS) a.tpres[r] = 0;
+        return;
+      }
+    }
+    const uint32_t p0 = a.rowptr[r0], p1 = a.rowptr[r1];
+    // phase 1: coalesced stream of (col, val), gather u, products to LDS.  All loads of a lane are
+    // issued before the first dependent use so >= 8 requests per lane are in flight.
+    uint32_t c[SPMV_UNROLL]; T av[SPMV_UNROLL]; T uv[SPMV_UNROLL]; uint8_t up[SPMV_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SPMV_UNROLL; u++) {
+      const uint32_t p = p0 + tid + u * SPMV_THREADS;
+      c[u] = 0; av[u] = T();
+      if (p < p1) { c[u] = a.col[p]; if (use_a) av[u] = a.aval[p]; }
+    }
+#pragma unroll
+    for (int u = 0; u < SPMV_UNROLL; u++) {
+      const uint32_t p = p0 + tid + u * SPMV_THREADS;
+      uv[u] = T(); up[u] = 1;
+      if (p < p1) {
+        if (use_u) uv[u] = a.uval[c[u]];
+        if constexpr (!U_FULL) up[u] = a.upres[c[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < SPMV_UNROLL; u++) {
+      const int k = tid + u * SPMV_THREADS;
+      if (p0 + k < p1) {
+        s_prod[k] = sr.mult(av[u], uv[u]);
+        if constexpr (!U_FULL) s_has[k] = up[u];
+      }
+    }
+    __syncthreads();
+    // phase 2: one thread per row, serial in entry order (fixed order => reproducible FP sums)
+    for (uint32_t r = r0 + tid; r < r1; r += SPMV_THREADS) {
+      if constexpr (HAS_ALLOW) { if (!a.allow[r]) { a.tpres[r] = 0; continue; } }
+      const uint32_t qb = a.rowptr[r] - p0, qe = a.rowptr[r + 1] - p0;
+      T acc = sr.identity; bool has = false;
+      if constexpr (U_FULL) {
+        has = qe > qb;
+        if (has) { acc = s_prod[qb]; for (uint32_t q = qb + 1; q < qe; q++) acc = sr.add(acc, s_prod[q]); }
+      } else {
+        for (uint32_t q = qb; q < qe; q++) if (s_has[q]) { acc = has ? sr.add(acc, s_prod[q]) : s_prod[q]; has = true; }
+      }
+      if (has) a.tval[r] = acc;
+      a.tpres[r] = has ? 1 : 0;
+    }
+    return;
+  }
+
+  // ---- long row part ----
+  const uint32_t row = b.row;
+  if constexpr (HAS_ALLOW) { if (!a.allow[row]) { if (b.aux == 0 && tid == 0) a.tpres[row] = 0; return; } }
+  const uint32_t rb = a.rowptr[row], re = a.rowptr[row + 1];
+  const uint32_t pb = rb + b.aux * SPMV_LONG_CHUNK;
+  const uint32_t pe = (re - pb > (uint32_t)SPMV_LONG_CHUNK) ? pb + SPMV_LONG_CHUNK : re;
+  T acc = sr.identity; bool has = false;
+  for (uint32_t base = pb; base < pe; base += SPMV_NNZ) {
+    uint32_t c[SPMV_UNROLL]; T av[SPMV_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SPMV_UNROLL; u++) {
+      const uint32_t p = base + tid + u * SPMV_THREADS;
+      c[u] = 0; av[u] = T();
+      if (p < pe) { c[u] = a.col[p]; if (use_a) av[u] = a.aval[p]; }
+    }
+#pragma unroll
+    for (int u = 0; u < SPMV_UNROLL; u++) {
+      const uint32_t p = base + tid + u * SPMV_THREADS;
+      if (p < pe) {
+        bool pr = true;
+        if constexpr (!U_FULL) pr = a.upres[c[u]] != 0;
+        if (pr) {
+          const T x = use_u ? a.uval[c[u]] : T();
+          const T m = sr.mult(av[u], x);
+          acc = has ? sr.add(acc, m) : m; has = true;
+        }
+      }
+    }
+  }
+  // block reduction in a fixed tree: lanes (xor butterfly) -> 4 waves in order
+  const T accv = has ? acc : sr.identity;
+  const T wsum = wave_reduce_op<T, false>(sr.add_op(), accv);
+  const bool whas = __any(has);
+  if ((tid & 63) == 0) { s_wave[tid >> 6] = wsum; s_whas[tid >> 6] = whas; }
+  __syncthreads();
+  if (tid == 0) {
+    T r = sr.identity; bool h = false;
+    for (int w = 0; w < SPMV_THREADS / 64; w++) if (s_whas[w]) { r = h ? sr.add(r, s_wave[w]) : s_wave[w]; h = true; }
+    if (b.nparts == 1) {
+      if (h) a.tval[row] = r;
+      a.tpres[row] = h ? 1 : 0;
+    } else {
+      a.partial[b.slot + b.aux] = r; a.pflag[b.slot + b.aux] = h ? 1 : 0;
+      __threadfence();                                         // agent-scope release of the partial
+      const uint32_t ticket = atomicAdd(&a.tickets[b.slot], 1u);
+      if (ticket == b.nparts - 1) {                            // last part to arrive combines, in part order
+        __threadfence();                                       // agent-scope acquire
+        T tot = sr.identity; bool th = false;
+        for (uint32_t p = 0; p < b.nparts; p++) {
+          const T pv = __hip_atomic_load(&a.partial[b.slot + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint8_t pf = __hip_atomic_load(&a.pflag[b.slot + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (pf) { tot = th ? sr.add(tot, pv) : pv; th = true; }
+        }
+        if (th) a.tval[row] = tot;
+        a.tpres[row] = th ? 1 : 0;
+        a.tickets[b.slot] = 0;                                  // re-arm for the next launch
+      }
+    }
+  }
+}
+
+// ---- kernel B: G lanes per row, mask skip, terminal early exit -----------------------------------------------------
+template <class T, class SR, int G, bool U_FULL>
+__global__ __launch_bounds__(256) void k_spmv_rowgroup(const SpmvKArgs<T> a, const SR sr) {
+  const int lane = threadIdx.x & (G - 1);
+  const uint64_t group = (blockIdx.x * 256ull + threadIdx.x) / G;
+  const uint64_t ngroups = (uint64_t)gridDim.x * 256ull / G;
+  const bool use_a = sr.uses_a(), use_u = sr.uses_u();
+  for (uint64_t r = group; r < a.nrows; r += ngroups) {
+    if (a.allow && !a.allow[r]) { if (lane == 0) a.tpres[r] = 0; continue; }
+    const uint32_t pb = a.rowptr[r], pe = a.rowptr[r + 1];
+    T acc = sr.identity; bool has = false;
+    for (uint32_t p = pb + lane; p < pe; p += G) {
+      const uint32_t c = a.col[p];
+      bool pr = true;
+      if constexpr (!U_FULL) pr = a.upres[c] != 0;
+      if (pr) {
+        const T m = sr.mult(use_a ? a.aval[p] : T(), use_u ? a.uval[c] : T());
+        acc = has ? sr.add(acc, m) : m; has = true;
+        if (sr.has_terminal && memcmp_eq(acc, sr.terminal)) break;   // this lane cannot change the result any more
+      }
+    }
+    // reduce the G lanes (identity where a lane saw nothing)
+    T v = has ? acc : sr.identity;
+    unsigned long long hb = __ballot(has);
+    if constexpr (G == 64) { v = wave_reduce_op<T, false>(sr.add_op(), v); }
+    else { v = group_reduce_op<T, G, false>(sr.add_op(), v); hb = (hb >> ((threadIdx.x & 63) & ~(G - 1))) & ((G == 64) ? ~0ull : ((1ull << G) - 1)); }
+    if (lane == 0) { const bool h = hb != 0; if (h) a.tval[r] = v; a.tpres[r] = h ? 1 : 0; }
+  }
+}
+
+// ---- kernel C: push.  t is pre-initialised (tpres = 0); entries are claimed with tpres CAS-free flags ---------------
+// Scatter with one atomic combine per product.  Used only for semirings whose monoid has a
+// native atomic (PLUS on 32/64-bit ints and floats, MIN/MAX on ints, LOR/ANY): chosen by the driver.
+template <class T> __device__ __forceinline__ void atomic_combine(int op, T* addr, T v) {
+  if constexpr (is_bool<T>::value) {
+    // LOR / ANY / PLUS / MAX on BOOL: any contribution sets the byte; benign same-value race
+    if (v) addr->v = 1;
+  } else if constexpr (std::is_same<T, float>::value || std::is_same<T, double>::value) {
+    if (op == B_PLUS) atomicAdd(addr, v);
+    else {  // MIN / MAX through integer CAS
+      typedef typename std::conditional<sizeof(T) == 8, unsigned long long, unsigned int>::type U;
+      U* ua = (U*)addr; U old = *ua, assumed;
+      do {
+        assumed = old; T cur; memcpy(&cur, &assumed, sizeof(T));
+        T nv = apply_binop<T, false>(op, cur, v); U nu; memcpy(&nu, &nv, sizeof(T));
+        if (nu == assumed) break;
+        old = atomicCAS(ua, assumed, nu);
+      } while (old != assumed);
+    }
+  } else if constexpr (sizeof(T) == 4) {
+    typedef typename std::conditional<std::is_signed<T>::value, int, unsigned int>::type A;
+    if (op == B_PLUS) atomicAdd((A*)addr, (A)v); else if (op == B_MIN) atomicMin((A*)addr, (A)v);
+    else if (op == B_MAX) atomicMax((A*)addr, (A)v); else *addr = v;
+  } else if constexpr (sizeof(T) == 8) {
+    if (op == B_PLUS) atomicAdd((unsigned long long*)addr, (unsigned long long)v);
+    else if (op == B_MIN) { if constexpr (std::is_signed<T>::value) atomicMin((long long*)addr, (long long)v); else atomicMin((unsigned long long*)addr, (unsigned long long)v); }
+    else if (op == B_MAX) { if constexpr (std::is_signed<T>::value) atomicMax((long long*)addr, (long long)v); else atomicMax((unsigned long long*)addr, (unsigned long long)v); }
+    else *addr = v;
+  }
+}
+
+template <class T, class SR>
+__global__ __launch_bounds__(256) void k_spmspv_push(const uint32_t* __restrict__ fidx, uint32_t nf, const uint32_t* __restrict__ rowptr,
+                                                     const uint32_t* __restrict__ col, const T* __restrict__ aval, const T* __restrict__ uval,
+                                                     const uint8_t* __restrict__ allow, T* __restrict__ tval, uint8_t* __restrict__ tpres, const SR sr) {
+  // one wave per frontier entry: its row of M^T (= CSR row of the stored matrix) is streamed coalesced
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6;
+  const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+  const bool use_a = sr.uses_a(), use_u = sr.uses_u();
+  for (uint64_t f = wave; f < nf; f += nwaves) {
+    const uint32_t i = fidx[f];
+    const T ui = use_u ? uval[i] : T();
+    const uint32_t pb = rowptr[i], pe = rowptr[i + 1];
+    for (uint32_t p = pb + lane; p < pe; p += 64) {
+      const uint32_t j = col[p];
+      if (allow && !allow[j]) continue;
+      const T m = sr.mult(use_a ? aval[p] : T(), ui);
+      atomic_combine<T>(sr.add_op(), &tval[j], m);
+      tpres[j] = 1;
+    }
+  }
+}
+
+// ---- host drivers ---------------------------------------------------------------------------------------------------------
+template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
+  DevCSR& M = *c.M;
+  with_semiring<T>(d, [&](auto sr) {
+    typedef decltype(sr) SR;
+    SpmvKArgs<T> a{};
+    a.rowptr = M.rowptr.as<uint32_t>(); a.col = M.col.as<uint32_t>(); a.aval = (const T*)c.aval;
+    a.uval = (const T*)c.uval; a.upres = c.upres; a.allow = c.allow; a.tval = (T*)c.tval; a.tpres = c.tpres; a.nrows = M.nrows;
+    const bool full = c.upres == nullptr;
+    // masked pull with a terminal monoid (BFS) -> row-group kernel with early exit; otherwise the row-block kernel
+    const bool prefer_rowgroup = c.method == SPMV_ROWGROUP || (c.method == SPMV_AUTO && c.allow && d.has_terminal);
+    if (prefer_rowgroup) {
+      const double avg = M.nrows ? (double)M.nnz / M.nrows : 0;
+      const int G = avg > 24 ? 64 : 8;
+      uint64_t groups_per_block = 256 / G;
+      uint64_t nb = (M.nrows + groups_per_block - 1) / groups_per_block; if (nb < 1) nb = 1; if (nb > 65536) nb = 65536;
+#define GRB_LAUNCH_B(GG) \
+      if (full) hipLaunchKernelGGL((k_spmv_rowgroup<T, SR, GG, true>), dim3((unsigned)nb), dim3(256), 0, stream(), a, sr); \
+      else hipLaunchKernelGGL((k_spmv_rowgroup<T, SR, GG, false>), dim3((unsigned)nb), dim3(256), 0, stream(), a, sr);
+      if (G == 64) { GRB_LAUNCH_B(64) } else { GRB_LAUNCH_B(8) }
+#undef GRB_LAUNCH_B
+      g_last_plan += std::string("k_spmv_rowgroup<G=") + std::to_string(G) + (sr.is_static ? ",static>" : ",dynamic>") + " ";
+      return;
+    }
+    spmv_build_plan(M);
+    a.blocks = M.plan_blocks.as<SpmvBlock>();
+    uint8_t* aux = M.plan_aux.as<uint8_t>();
+    const size_t ns = (size_t)M.plan_nlong + 1;
+    a.tickets = (uint32_t*)aux; a.partial = (T*)(aux + ns * 4); a.pflag = aux + ns * 4 + ns * 8;
+    if (M.plan_nblocks == 0) return;
+    const dim3 grid(M.plan_nblocks), block(SPMV_THREADS);
+    if (full) {
+      if (c.allow) hipLaunchKernelGGL((k_spmv_adaptive<T, SR, true, true>), grid, block, 0, stream(), a, sr);
+      else hipLaunchKernelGGL((k_spmv_adaptive<T, SR, true, false>), grid, block, 0, stream(), a, sr);
+    } else {
+      if (c.allow) hipLaunchKernelGGL((k_spmv_adaptive<T, SR, false, true>), grid, block, 0, stream(), a, sr);
+      else hipLaunchKernelGGL((k_spmv_adaptive<T, SR, false, false>), grid, block, 0, stream(), a, sr);
+    }
+    g_last_plan += std::string("k_spmv_adaptive<") + (sr.is_static ? "static" : "dynamic") + (full ? ",full" : ",bitmap") + (c.allow ? ",mask> " : "> ");
+  });
+}
+
+
+template <class T> __global__ void k_fill(T* p, uint64_t n, T v) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) p[i] = v;
+}
+
+template <class T> void run_push(const SpmvCall& c, const SemiringDesc& d, const uint32_t* fidx, uint64_t u_nvals) {
+  DevCSR& M = *c.M; const uint64_t nout = M.ncols;
+  auto grid_of = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 4096) b = 4096; return (unsigned)b; };
+  with_semiring<T>(d, [&](auto sr) {
+    typedef decltype(sr) SR;
+    if (nout) hipLaunchKernelGGL((k_fill<T>), dim3(grid_of(nout)), dim3(256), 0, stream(), (T*)c.tval, nout, sr.identity);
+    uint64_t nb = (u_nvals + 3) / 4; if (nb < 1) nb = 1; if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL((k_spmspv_push<T, SR>), dim3((unsigned)nb), dim3(256), 0, stream(), fidx, (uint32_t)u_nvals,
+                       M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(), (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, sr);
+    g_last_plan += std::string("k_spmspv_push<") + (sr.is_static ? "static> " : "dynamic> ");
+  });
+}
+
+}  // namespace grb

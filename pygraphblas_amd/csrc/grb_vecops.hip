@@ -1,0 +1,222 @@
+// grb_vecops.hip — O(n) streaming kernels over the bitmap vector layout (val T[n] | present u8[n]).
+// All of them are HBM-bound: one coalesced pass, grid-stride, 256-thread blocks capped at 2048
+// blocks (guide §6 G11).  They implement typecasting, mask -> "allow" bytes, the
+// C<M,replace> = accum(C,T) epilogue of GraphBLAS, monoid
+// reductions and the element-wise companions of the hot path.
+#include "grb_api.hpp"
+#include "grb_device.hpp"
+
+namespace grb {
+
+static inline int grid_for(uint64_t n, int per_thread = 1) {
+  uint64_t b = (n + 256ull * per_thread - 1) / (256ull * per_thread);
+  if (b < 1) b = 1; if (b > 2048) b = 2048; return (int)b;
+}
+
+// ---- typecast ---------------------------------------------------------------------------------------
+template <class D, class S> __global__ void k_cast(D* __restrict__ dst, const S* __restrict__ src, uint64_t n) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) dst[i] = cast_to<D, S>(src[i]);
+}
+void vec_cast_values(int dst_code, void* dst, int src_code, const void* src, uint64_t n) {
+  if (!n) return;
+  dispatch_type(src_code, [&]<class S>() {
+    dispatch_type(dst_code, [&]<class D>() {
+      hipLaunchKernelGGL((k_cast<D, S>), dim3(grid_for(n)), dim3(256), 0, stream(), (D*)dst, (const S*)src, n);
+    });
+  });
+}
+
+// ---- mask -> allow bytes ------------------------------------------------------------------------------
+template <class M> __global__ void k_allow(uint64_t n, const M* __restrict__ mval, const uint8_t* __restrict__ mpres,
+                                           bool structural, bool complement, uint8_t* __restrict__ allow) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {
+    bool m = mpres[i] != 0;
+    if (m && !structural) m = (bool)cast_to<bool8, M>(mval[i]);
+    allow[i] = (uint8_t)(m != complement);
+  }
+}
+void build_allow(uint64_t n, int mcode, const void* mval, const uint8_t* mpres, bool structural, bool complement, uint8_t* allow) {
+  if (!n) return;
+  dispatch_type(mcode, [&]<class M>() {
+    hipLaunchKernelGGL((k_allow<M>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (const M*)mval, mpres, structural, complement, allow);
+  });
+}
+
+// ---- count present ------------------------------------------------------------------------------------
+__global__ void k_count(const uint8_t* __restrict__ pres, uint64_t n, unsigned long long* out) {
+  unsigned long long c = 0;
+  // 16 bytes per lane per step
+  const uint64_t n16 = n / 16;
+  const uint4* p4 = (const uint4*)pres;
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += gridDim.x * 256ull) {
+    uint4 v = p4[i];
+    c += __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) + __popc(v.w & 0x01010101u);
+  }
+  for (uint64_t i = n16 * 16 + blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) c += pres[i] != 0;
+  c = wave_reduce_add_u64(c);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+uint64_t count_present(const uint8_t* pres, uint64_t n) {
+  if (!n) return 0;
+  ScalarSlot slot; slot.zero();
+  hipLaunchKernelGGL(k_count, dim3(grid_for(n, 16)), dim3(256), 0, stream(), pres, n, (unsigned long long*)slot.dev());
+  return slot.read_u64();
+}
+
+// ---- C<M,replace> = accum(C, T) for vectors, in place on (wval, wpres) ---------------------------------
+template <class T> __global__ void k_vec_epilogue(uint64_t n, T* __restrict__ wval, uint8_t* __restrict__ wpres,
+                                                  const T* __restrict__ tval, const uint8_t* __restrict__ tpres,
+                                                  const uint8_t* __restrict__ allow, int accum, bool replace) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {
+    const bool ok = allow ? allow[i] != 0 : true;
+    if (ok) {
+      const bool tp = tpres[i] != 0;
+      if (accum >= 0) {
+        if (tp) {
+          if (wpres[i]) wval[i] = apply_binop<T>(accum, wval[i], tval[i]);
+          else { wval[i] = tval[i]; wpres[i] = 1; }
+        }
+      } else {
+        if (tp) wval[i] = tval[i];
+        wpres[i] = tp ? 1 : 0;
+      }
+    } else if (replace) {
+      wpres[i] = 0;
+    }
+  }
+}
+void vec_epilogue(int code, uint64_t n, void* wval, uint8_t* wpres, const void* tval, const uint8_t* tpres,
+                  const uint8_t* allow, int accum, bool replace) {
+  if (!n) return;
+  dispatch_type(code, [&]<class T>() {
+    hipLaunchKernelGGL((k_vec_epilogue<T>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (T*)wval, wpres, (const T*)tval, tpres, allow, accum, replace);
+  });
+}
+
+// ---- monoid reduction of present entries to one scalar -----------------------------------------------------
+// pres == nullptr means "all n entries present" (matrix value arrays).
+template <class T> __global__ void k_reduce(uint64_t n, const T* __restrict__ val, const uint8_t* __restrict__ pres, int op,
+                                            T identity, T* __restrict__ partial) {
+  __shared__ T sh[4];
+  T acc = identity;
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull)
+    if (!pres || pres[i]) acc = apply_binop<T>(op, acc, val[i]);
+  acc = wave_reduce_op<T>(op, acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    T r = sh[0];
+    for (int w = 1; w < 4; w++) r = apply_binop<T>(op, r, sh[w]);
+    partial[blockIdx.x] = r;
+  }
+}
+// fixed-shape two-level tree: results are run-to-run deterministic for floating point as well
+void reduce_values(int code, uint64_t n, const void* val, const uint8_t* pres, int op, const void* identity, void* result_host) {
+  dispatch_type(code, [&]<class T>() {
+    T id; memcpy(&id, identity, sizeof(T));
+    if (!n) { memcpy(result_host, &id, sizeof(T)); return; }
+    const int g = grid_for(n, 4);
+    DevBuf part((size_t)g * sizeof(T)), fin(sizeof(T) * 1);
+    hipLaunchKernelGGL((k_reduce<T>), dim3(g), dim3(256), 0, stream(), n, (const T*)val, pres, op, id, part.as<T>());
+    hipLaunchKernelGGL((k_reduce<T>), dim3(1), dim3(256), 0, stream(), (uint64_t)g, (const T*)part.as<T>(), (const uint8_t*)nullptr, op, id, fin.as<T>());
+    T r; GRB_HIP(hipMemcpyAsync(&r, fin.p, sizeof(T), hipMemcpyDeviceToHost, stream()));
+    GRB_HIP(hipStreamSynchronize(stream()));
+    memcpy(result_host, &r, sizeof(T));
+  });
+}
+
+// ---- element-wise union / intersection of two bitmap vectors ----------------------------------------------------
+template <class T> __global__ void k_vec_ewise(uint64_t n, const T* __restrict__ uval, const uint8_t* __restrict__ upres,
+                                               const T* __restrict__ vval, const uint8_t* __restrict__ vpres, int op, bool is_union,
+                                               T* __restrict__ tval, uint8_t* __restrict__ tpres) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {
+    const bool a = upres[i] != 0, b = vpres[i] != 0;
+    if (a && b) { tval[i] = apply_binop<T>(op, uval[i], vval[i]); tpres[i] = 1; }
+    else if (is_union && a) { tval[i] = uval[i]; tpres[i] = 1; }
+    else if (is_union && b) { tval[i] = vval[i]; tpres[i] = 1; }
+    else tpres[i] = 0;
+  }
+}
+void vec_ewise(int code, uint64_t n, const void* uval, const uint8_t* upres, const void* vval, const uint8_t* vpres, int op,
+               bool is_union, void* tval, uint8_t* tpres) {
+  if (!n) return;
+  dispatch_type(code, [&]<class T>() {
+    hipLaunchKernelGGL((k_vec_ewise<T>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (const T*)uval, upres, (const T*)vval, vpres, op, is_union, (T*)tval, tpres);
+  });
+}
+
+// ---- apply: unary op, or binary op with one bound scalar (mode 1: z=f(s,x)  mode 2: z=f(x,s)) ----------------------
+template <class T> __global__ void k_vec_apply(uint64_t n, const T* __restrict__ uval, const uint8_t* __restrict__ upres, int mode, int op,
+                                               T s, T* __restrict__ tval, uint8_t* __restrict__ tpres) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {
+    const bool a = upres ? upres[i] != 0 : true;
+    if (a) {
+      T x = uval[i];
+      tval[i] = mode == 0 ? apply_unop<T>(op, x) : (mode == 1 ? apply_binop<T>(op, s, x) : apply_binop<T>(op, x, s));
+    }
+    if (tpres) tpres[i] = a ? 1 : 0;
+  }
+}
+void vec_apply(int code, uint64_t n, const void* uval, const uint8_t* upres, int mode, int op, const void* scalar, void* tval, uint8_t* tpres) {
+  if (!n) return;
+  dispatch_type(code, [&]<class T>() {
+    T s{}; if (scalar) memcpy(&s, scalar, sizeof(T));
+    hipLaunchKernelGGL((k_vec_apply<T>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (const T*)uval, upres, mode, op, s, (T*)tval, tpres);
+  });
+}
+
+// ---- w<allow>(:) = accum(w, scalar) over all indices (GrB_Vector_assign_<T> with GrB_ALL) ---------------------------------
+template <class T> __global__ void k_vec_assign_scalar(uint64_t n, T* __restrict__ wval, uint8_t* __restrict__ wpres,
+                                                       const uint8_t* __restrict__ allow, const uint8_t* __restrict__ region, T s, int accum, bool replace) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {
+    const bool ok = allow ? allow[i] != 0 : true;
+    const bool in = region ? region[i] != 0 : true;
+    if (ok && in) {
+      if (accum >= 0 && wpres[i]) wval[i] = apply_binop<T>(accum, wval[i], s); else wval[i] = s;
+      wpres[i] = 1;
+    } else if (!ok && replace) wpres[i] = 0;
+  }
+}
+void vec_assign_scalar(int code, uint64_t n, void* wval, uint8_t* wpres, const uint8_t* allow, const uint8_t* region, const void* scalar, int accum, bool replace) {
+  if (!n) return;
+  dispatch_type(code, [&]<class T>() {
+    T s; memcpy(&s, scalar, sizeof(T));
+    hipLaunchKernelGGL((k_vec_assign_scalar<T>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (T*)wval, wpres, allow, region, s, accum, replace);
+  });
+}
+
+// ---- value-based select on a bitmap vector / value array: keep[i] = pred(val[i]) --------------------------------------------
+template <class T> __global__ void k_select_value(uint64_t n, const T* __restrict__ val, const uint8_t* __restrict__ pres, int sel, T thunk,
+                                                  uint8_t* __restrict__ keep) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {
+    bool k = pres ? pres[i] != 0 : true;
+    if (k) {
+      const T x = val[i]; const T z = T();
+      switch (sel) {
+        case SEL_NONZERO: k = (bool)cast_to<bool8, T>(x); break;
+        case SEL_EQ_ZERO: k = !(bool)cast_to<bool8, T>(x); break;
+        case SEL_GT_ZERO: k = apply_binop<T>(B_ISGT, x, z); break;
+        case SEL_GE_ZERO: k = apply_binop<T>(B_ISGE, x, z); break;
+        case SEL_LT_ZERO: k = apply_binop<T>(B_ISLT, x, z); break;
+        case SEL_LE_ZERO: k = apply_binop<T>(B_ISLE, x, z); break;
+        case SEL_NE_THUNK: k = apply_binop<T>(B_ISNE, x, thunk); break;
+        case SEL_EQ_THUNK: k = apply_binop<T>(B_ISEQ, x, thunk); break;
+        case SEL_GT_THUNK: k = apply_binop<T>(B_ISGT, x, thunk); break;
+        case SEL_GE_THUNK: k = apply_binop<T>(B_ISGE, x, thunk); break;
+        case SEL_LT_THUNK: k = apply_binop<T>(B_ISLT, x, thunk); break;
+        case SEL_LE_THUNK: k = apply_binop<T>(B_ISLE, x, thunk); break;
+        default: break;
+      }
+    }
+    keep[i] = k ? 1 : 0;
+  }
+}
+void select_value_flags(int code, uint64_t n, const void* val, const uint8_t* pres, int sel, const void* thunk, uint8_t* keep) {
+  if (!n) return;
+  dispatch_type(code, [&]<class T>() {
+    T t{}; if (thunk) memcpy(&t, thunk, sizeof(T));
+    hipLaunchKernelGGL((k_select_value<T>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (const T*)val, pres, sel, t, keep);
+  });
+}
+
+}  // namespace grb

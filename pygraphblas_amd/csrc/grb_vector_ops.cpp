@@ -1,0 +1,193 @@
+// grb_vector_ops.cpp — the O(n) vector operations the reference's BFS / PageRank loops wrap around
+// the hot path, kept in HBM so an iteration never leaves the device:
+//   GrB_Vector_reduce_<T>            <- Vector.reduce_bool/int/float   (pygraphblas/vector.py:1101-1202)
+//   GrB_Matrix_reduce_<T>            <- Matrix.reduce_int              (pygraphblas/matrix.py:1782-1804)
+//   GrB_Vector_assign_<T>            <- Vector.assign_scalar           (pygraphblas/vector.py:1494-1524)
+//   GrB_Vector_eWiseAdd/eWiseMult_*  <- Vector.eadd / emult            (pygraphblas/vector.py:604-833)
+//   GrB_Vector_apply, GxB_Vector_apply_BinaryOp1st/2nd, GxB_Vector_select  (pygraphblas/vector.py:1204-1340)
+#include "grb_opcommon.hpp"
+
+using namespace grb;
+
+// scalar c = accum ? accum(c, s) : s, with s in type scode and c in type ccode (host)
+static void scalar_accum(void* c, int ccode, const void* s, int scode, GrB_BinaryOp accum) {
+  if (!accum) { cast_scalar(ccode, c, scode, s); return; }
+  check_binop(accum, "accum");
+  const int ac = accum->xtype->code; uint8_t a[16], b[16], z[16];
+  cast_scalar(ac, a, ccode, c); cast_scalar(ac, b, scode, s);
+  dispatch_type(ac, [&]<class T>() { T x, y; memcpy(&x, a, sizeof(T)); memcpy(&y, b, sizeof(T)); T r = apply_binop<T>(accum->opcode, x, y); memcpy(z, &r, sizeof(T)); });
+  cast_scalar(ccode, c, ac, z);
+}
+
+static void reduce_common(void* c, int ccode, GrB_BinaryOp accum, GrB_Monoid monoid, int vcode, const void* val, const uint8_t* pres, uint64_t n) {
+  need_device();
+  if (!check_obj(monoid)) fail(GrB_UNINITIALIZED_OBJECT, "monoid is not initialised");
+  check_binop(monoid->op, "monoid");
+  const int mc = monoid->op->ztype->code;
+  DevBuf tmp; const void* v = cast_values(mc, vcode, val, n, tmp);
+  uint8_t r[16];
+  reduce_values(mc, n, v, pres, monoid->op->opcode, monoid->identity, r);
+  scalar_accum(c, ccode, r, mc, accum);
+}
+
+static GrB_Info vec_reduce(void* c, int ccode, GrB_BinaryOp accum, GrB_Monoid monoid, GrB_Vector u) {
+  if (!c || !u || !monoid) return GrB_NULL_POINTER; if (!check_obj(u)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(u, [&] { vec_to_device(u); reduce_common(c, ccode, accum, monoid, u->type->code, u->dval.p, u->dpres.as<uint8_t>(), u->n); });
+}
+static GrB_Info mat_reduce(void* c, int ccode, GrB_BinaryOp accum, GrB_Monoid monoid, GrB_Matrix A) {
+  if (!c || !A || !monoid) return GrB_NULL_POINTER; if (!check_obj(A)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(A, [&] { mat_to_device(A); reduce_common(c, ccode, accum, monoid, A->type->code, A->csr.val.p, nullptr, A->csr.nnz); });
+}
+
+static void vec_assign(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const void* x, int xcode, const GrB_Index* I, GrB_Index ni, GrB_Descriptor desc) {
+  need_device();
+  if (mask && !check_obj(mask)) fail(GrB_UNINITIALIZED_OBJECT, "assign: mask is not initialised");
+  const DescView dv(desc);
+  if (mask && mask->n != w->n) fail(GrB_DIMENSION_MISMATCH, "assign: mask size");
+  if (accum) check_binop(accum, "accum");
+  const uint64_t n = w->n;
+  DevBuf allow_buf, region; bool nothing = false;
+  const uint8_t* allow = vector_allow(mask, dv, n, allow_buf, &nothing);
+  if (nothing) { if (dv.replace) { GrB_Vector_clear(w); } return; }
+  vec_to_device(w);
+  const uint8_t* reg = nullptr;
+  if (I != GrB_ALL) {
+    if (!I && ni) fail(GrB_NULL_POINTER, "assign: index list is NULL");
+    std::vector<uint8_t> h(n ? n : 1, 0);
+    for (GrB_Index k = 0; k < ni; k++) { if (I[k] >= n) fail(GrB_INDEX_OUT_OF_BOUNDS, "assign: index out of bounds"); h[I[k]] = 1; }
+    region.alloc(n ? n : 1);
+    GRB_HIP(hipMemcpyAsync(region.p, h.data(), n, hipMemcpyHostToDevice, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+    reg = region.as<uint8_t>();
+  }
+  const int wcode = w->type->code;
+  const int ecode = accum ? accum->xtype->code : wcode;
+  uint8_t s[16]; cast_scalar(ecode, s, xcode, x);
+  if (ecode == wcode) {
+    vec_assign_scalar(wcode, n, w->dval.p, w->dpres.as<uint8_t>(), allow, reg, s, accum ? accum->opcode : -1, dv.replace);
+  } else {
+    DevBuf wc(n * type_size(ecode) + 1);
+    vec_cast_values(ecode, wc.p, wcode, w->dval.p, n);
+    vec_assign_scalar(ecode, n, wc.p, w->dpres.as<uint8_t>(), allow, reg, s, accum->opcode, dv.replace);
+    vec_cast_values(wcode, w->dval.p, ecode, wc.p, n);
+  }
+  vec_invalidate_host(w); w->dnvals_known = false;
+}
+
+static void vec_ewise_op(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_BinaryOp op, GrB_Vector u, GrB_Vector v,
+                         GrB_Descriptor desc, bool is_union) {
+  need_device();
+  if (!check_obj(u) || !check_obj(v) || (mask && !check_obj(mask))) fail(GrB_UNINITIALIZED_OBJECT, "eWise: uninitialised operand");
+  check_binop(op, "eWise");
+  const DescView dv(desc); const uint64_t n = w->n;
+  if (u->n != n || v->n != n || (mask && mask->n != n)) fail(GrB_DIMENSION_MISMATCH, "eWise: vector sizes differ");
+  DevBuf allow_buf; bool nothing = false;
+  const uint8_t* allow = vector_allow(mask, dv, n, allow_buf, &nothing);
+  if (nothing) { if (dv.replace) GrB_Vector_clear(w); return; }
+  vec_to_device(u); vec_to_device(v);
+  const int xc = op->xtype->code;
+  DevBuf uc, vc, tval(n * type_size(xc) + 1), tpres(n + 1);
+  const void* uv = cast_values(xc, u->type->code, u->dval.p, n, uc);
+  const void* vv = cast_values(xc, v->type->code, v->dval.p, n, vc);
+  vec_ewise(xc, n, uv, u->dpres.as<uint8_t>(), vv, v->dpres.as<uint8_t>(), op->opcode, is_union, tval.p, tpres.as<uint8_t>());
+  // a comparison yields 0/1 in the operand type: identical to BOOL after the typecast into w
+  vector_write_back(w, xc, tval, tpres, allow, accum, dv.replace, /*t_only_allowed=*/false);
+}
+
+// mode 0: unary op; 1: z = f(s, x); 2: z = f(x, s)
+static void vec_apply_op(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, int mode, int opcode, int opxcode, const void* scalar, int scode,
+                         GrB_Vector u, GrB_Descriptor desc) {
+  need_device();
+  if (!check_obj(u) || (mask && !check_obj(mask))) fail(GrB_UNINITIALIZED_OBJECT, "apply: uninitialised operand");
+  const DescView dv(desc); const uint64_t n = w->n;
+  if (u->n != n || (mask && mask->n != n)) fail(GrB_DIMENSION_MISMATCH, "apply: vector sizes differ");
+  DevBuf allow_buf; bool nothing = false;
+  const uint8_t* allow = vector_allow(mask, dv, n, allow_buf, &nothing);
+  if (nothing) { if (dv.replace) GrB_Vector_clear(w); return; }
+  vec_to_device(u);
+  DevBuf uc, tval(n * type_size(opxcode) + 1), tpres(n + 1);
+  const void* uv = cast_values(opxcode, u->type->code, u->dval.p, n, uc);
+  uint8_t s[16] = {0}; if (scalar) cast_scalar(opxcode, s, scode, scalar);
+  vec_apply(opxcode, n, uv, u->dpres.as<uint8_t>(), mode, opcode, s, tval.p, tpres.as<uint8_t>());
+  vector_write_back(w, opxcode, tval, tpres, allow, accum, dv.replace, false);
+}
+
+#define VEC_GUARD(w) if (!(w)) return GrB_NULL_POINTER; if (!check_obj(w)) return GrB_UNINITIALIZED_OBJECT
+
+extern "C" {
+
+GrB_Info GrB_Vector_eWiseAdd_BinaryOp(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Vector u, const GrB_Vector v, const GrB_Descriptor desc) {
+  VEC_GUARD(w); if (!op || !u || !v) return GrB_NULL_POINTER; return guarded(w, [&] { vec_ewise_op(w, mask, accum, op, u, v, desc, true); }); }
+GrB_Info GrB_Vector_eWiseAdd_Monoid(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Monoid op, const GrB_Vector u, const GrB_Vector v, const GrB_Descriptor desc) {
+  VEC_GUARD(w); if (!op || !u || !v) return GrB_NULL_POINTER; if (!check_obj(op)) return GrB_UNINITIALIZED_OBJECT; return guarded(w, [&] { vec_ewise_op(w, mask, accum, op->op, u, v, desc, true); }); }
+GrB_Info GrB_Vector_eWiseAdd_Semiring(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Semiring op, const GrB_Vector u, const GrB_Vector v, const GrB_Descriptor desc) {
+  VEC_GUARD(w); if (!op || !u || !v) return GrB_NULL_POINTER; if (!check_obj(op)) return GrB_UNINITIALIZED_OBJECT; return guarded(w, [&] { vec_ewise_op(w, mask, accum, op->add->op, u, v, desc, true); }); }
+GrB_Info GrB_Vector_eWiseMult_BinaryOp(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Vector u, const GrB_Vector v, const GrB_Descriptor desc) {
+  VEC_GUARD(w); if (!op || !u || !v) return GrB_NULL_POINTER; return guarded(w, [&] { vec_ewise_op(w, mask, accum, op, u, v, desc, false); }); }
+GrB_Info GrB_Vector_eWiseMult_Monoid(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Monoid op, const GrB_Vector u, const GrB_Vector v, const GrB_Descriptor desc) {
+  VEC_GUARD(w); if (!op || !u || !v) return GrB_NULL_POINTER; if (!check_obj(op)) return GrB_UNINITIALIZED_OBJECT; return guarded(w, [&] { vec_ewise_op(w, mask, accum, op->op, u, v, desc, false); }); }
+GrB_Info GrB_Vector_eWiseMult_Semiring(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Semiring op, const GrB_Vector u, const GrB_Vector v, const GrB_Descriptor desc) {
+  VEC_GUARD(w); if (!op || !u || !v) return GrB_NULL_POINTER; if (!check_obj(op)) return GrB_UNINITIALIZED_OBJECT; return guarded(w, [&] { vec_ewise_op(w, mask, accum, op->mul, u, v, desc, false); }); }
+
+GrB_Info GrB_Vector_apply(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_UnaryOp op, const GrB_Vector u, const GrB_Descriptor desc) {
+  VEC_GUARD(w); if (!op || !u) return GrB_NULL_POINTER; if (!check_obj(op)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(w, [&] { if (op->opcode >= U_POSITIONI) not_implemented("positional / user-defined unary operator");
+    vec_apply_op(w, mask, accum, 0, op->opcode, op->xtype->code, nullptr, 0, u, desc); });
+}
+
+GrB_Info GxB_Vector_select(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GxB_SelectOp op, const GrB_Vector u, const GxB_Scalar thunk, const GrB_Descriptor desc) {
+  VEC_GUARD(w); if (!op || !u) return GrB_NULL_POINTER; if (!check_obj(op) || !check_obj(u)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(w, [&] {
+    need_device();
+    const DescView dv(desc); const uint64_t n = w->n;
+    if (u->n != n || (mask && mask->n != n)) fail(GrB_DIMENSION_MISMATCH, "select: vector sizes differ");
+    if (op->opcode == SEL_USER) not_implemented("user-defined select operator");
+    DevBuf allow_buf; bool nothing = false;
+    const uint8_t* allow = vector_allow(mask, dv, n, allow_buf, &nothing);
+    if (nothing) { if (dv.replace) GrB_Vector_clear(w); return; }
+    vec_to_device(u);
+    const int uc = u->type->code; const size_t ts = u->type->size;
+    DevBuf tval(n * ts + 1), tpres(n + 1);
+    GRB_HIP(hipMemcpyAsync(tval.p, u->dval.p, n * ts, hipMemcpyDeviceToDevice, stream()));
+    int64_t k = 0; uint8_t th[16] = {0};
+    if (thunk && check_obj(thunk) && thunk->has) { cast_scalar(T_INT64, &k, thunk->type->code, thunk->x); cast_scalar(uc, th, thunk->type->code, thunk->x); }
+    if (op->opcode <= SEL_OFFDIAG) {
+      // positional on an n x 1 column: entry (i, 0);  tril: 0 <= i + k ... keep iff j - i <= k etc.
+      std::vector<uint8_t> up(n), keep(n);
+      GRB_HIP(hipMemcpyAsync(up.data(), u->dpres.p, n, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+      for (uint64_t i = 0; i < n; i++) { const int64_t d = 0 - (int64_t)i; bool kp = false;
+        switch (op->opcode) { case SEL_TRIL: kp = d <= k; break; case SEL_TRIU: kp = d >= k; break; case SEL_DIAG: kp = d == k; break; default: kp = d != k; }
+        keep[i] = up[i] && kp; }
+      GRB_HIP(hipMemcpyAsync(tpres.p, keep.data(), n, hipMemcpyHostToDevice, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+    } else {
+      select_value_flags(uc, n, u->dval.p, u->dpres.as<uint8_t>(), op->opcode, th, tpres.as<uint8_t>());
+    }
+    vector_write_back(w, uc, tval, tpres, allow, accum, dv.replace, false);
+  });
+}
+
+#define GRB_TYPED_VECOPS(SUF, CT, CODE) \
+  GrB_Info GrB_Vector_reduce_##SUF(CT* c, const GrB_BinaryOp accum, const GrB_Monoid monoid, const GrB_Vector u, const GrB_Descriptor desc) { (void)desc; return vec_reduce(c, CODE, accum, monoid, u); } \
+  GrB_Info GrB_Matrix_reduce_##SUF(CT* c, const GrB_BinaryOp accum, const GrB_Monoid monoid, const GrB_Matrix A, const GrB_Descriptor desc) { (void)desc; return mat_reduce(c, CODE, accum, monoid, A); } \
+  GrB_Info GrB_Vector_assign_##SUF(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, CT x, const GrB_Index* I, GrB_Index ni, const GrB_Descriptor desc) { \
+    VEC_GUARD(w); return guarded(w, [&] { vec_assign(w, mask, accum, &x, CODE, I, ni, desc); }); } \
+  GrB_Info GxB_Vector_apply_BinaryOp1st_##SUF(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, CT x, const GrB_Vector u, const GrB_Descriptor desc) { \
+    VEC_GUARD(w); if (!op || !u) return GrB_NULL_POINTER; return guarded(w, [&] { check_binop(op, "apply"); vec_apply_op(w, mask, accum, 1, op->opcode, op->xtype->code, &x, CODE, u, desc); }); } \
+  GrB_Info GxB_Vector_apply_BinaryOp2nd_##SUF(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Vector u, CT y, const GrB_Descriptor desc) { \
+    VEC_GUARD(w); if (!op || !u) return GrB_NULL_POINTER; return guarded(w, [&] { check_binop(op, "apply"); vec_apply_op(w, mask, accum, 2, op->opcode, op->xtype->code, &y, CODE, u, desc); }); }
+GRB_TYPED_VECOPS(BOOL, bool, T_BOOL) GRB_TYPED_VECOPS(INT8, int8_t, T_INT8) GRB_TYPED_VECOPS(UINT8, uint8_t, T_UINT8)
+GRB_TYPED_VECOPS(INT16, int16_t, T_INT16) GRB_TYPED_VECOPS(UINT16, uint16_t, T_UINT16) GRB_TYPED_VECOPS(INT32, int32_t, T_INT32)
+GRB_TYPED_VECOPS(UINT32, uint32_t, T_UINT32) GRB_TYPED_VECOPS(INT64, int64_t, T_INT64) GRB_TYPED_VECOPS(UINT64, uint64_t, T_UINT64)
+GRB_TYPED_VECOPS(FP32, float, T_FP32) GRB_TYPED_VECOPS(FP64, double, T_FP64)
+
+GrB_Info GxB_Vector_fprint(GrB_Vector v, const char* name, int pr, FILE* f) {
+  if (!v) return GrB_NULL_POINTER; if (!check_obj(v)) return GrB_UNINITIALIZED_OBJECT; if (pr <= 0) return GrB_SUCCESS;
+  return guarded(v, [&] { fprintf(f ? f : stdout, "\n  GraphBLAS vector: %s  type %s  size %llu  nvals %llu  (MI355X bitmap layout)\n", name ? name : "",
+                                 v->type->name, (unsigned long long)v->n, (unsigned long long)vec_nvals(v)); });
+}
+GrB_Info GxB_Matrix_fprint(GrB_Matrix A, const char* name, int pr, FILE* f) {
+  if (!A) return GrB_NULL_POINTER; if (!check_obj(A)) return GrB_UNINITIALIZED_OBJECT; if (pr <= 0) return GrB_SUCCESS;
+  return guarded(A, [&] { fprintf(f ? f : stdout, "\n  GraphBLAS matrix: %s  type %s  %llu-by-%llu  nvals %llu  (MI355X CSR layout)\n", name ? name : "",
+                                 A->type->name, (unsigned long long)A->nrows, (unsigned long long)A->ncols, (unsigned long long)mat_nvals(A)); });
+}
+
+}  // extern "C"

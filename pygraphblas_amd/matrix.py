@@ -1,0 +1,417 @@
+"""`Matrix` — the host-side mirror of pygraphblas.Matrix for the mxm / mxv hot path.
+
+Same names, argument meaning and error behaviour as the reference class
+(pygraphblas/matrix.py): `Matrix.sparse/dense/from_lists/random/identity`, `nrows/ncols/nvals`,
+`mxm` (:2401-2584), `mxv` (:2586-2726), `@`, `@=`, `A.plus_times(B)` (:1607-1613), `iseq` (:1436-1453),
+`reduce_int/float/bool` (:1759-1804), `transpose`, `tril/triu/offdiag/select`, `eadd/emult`, `apply`.
+Every method is a thin call into the C ABI (include/grb_mi355x.h); arithmetic happens in HIP kernels.
+Bulk constructors `from_arrays` / `from_csr` exist because the reference's per-element
+`from_lists` loop (:325-330) cannot load benchmark-sized graphs.
+"""
+import ctypes as C
+import random as _random
+from functools import partial
+
+import numpy as np
+
+from . import _capi, types, descriptor as _d
+from ._capi import lib, u64
+from .base import check, NoValue
+from .types import current_semiring, current_accum, current_binop, current_monoid
+
+NULL = None
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def get_args(mask, accum, desc):
+    """mask handle, accum op handle, descriptor handle from arguments or context
+    (reference: Matrix._get_args, pygraphblas/matrix.py:2380-2399)."""
+    mh = C.c_void_p(mask._h.value) if mask is not None else None
+    if accum is None:
+        accum = current_accum.get(None)
+    ah = C.c_void_p(accum.get_op()) if accum is not None else None
+    if desc is None:
+        desc = _d.current_desc.get(None)
+    dh = C.c_void_p(desc.get_desc()) if desc is not None else None
+    return mh, ah, dh
+
+
+class Matrix:
+    _kind = "matrix"
+
+    def __init__(self, handle, typ=None):
+        self._h = handle  # ctypes c_void_p owning a GrB_Matrix
+        if typ is None:
+            t = C.c_void_p()
+            check(lib.GxB_Matrix_type(C.byref(t), self._h))
+            typ = types.type_of_handle(t.value)
+        self.type = typ
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and lib is not None:
+            lib.GrB_Matrix_free(C.byref(h))
+
+    # ---- construction ---------------------------------------------------------------------------------
+    @classmethod
+    def sparse(cls, typ, nrows=None, ncols=None):
+        imax = _capi.constants["GxB_INDEX_MAX"]
+        h = C.c_void_p()
+        check(lib.GrB_Matrix_new(C.byref(h), C.c_void_p(typ._h), u64(imax if nrows is None else nrows),
+                                 u64(imax if ncols is None else ncols)))
+        return cls(h, typ)
+
+    @classmethod
+    def dense(cls, typ, nrows, ncols, fill=None):
+        if fill is None:
+            fill = typ.default_zero
+        I, J = np.divmod(np.arange(nrows * ncols, dtype=np.uint64), np.uint64(ncols))
+        return cls.from_arrays(I, J, np.full(nrows * ncols, fill, dtype=typ._np), nrows, ncols, typ)
+
+    @classmethod
+    def from_lists(cls, I, J, V=None, nrows=None, ncols=None, typ=None):
+        """Build from coordinate lists; the type is inferred from V[0] when not given."""
+        if V is None:
+            V = [True] * len(I)
+        elif not hasattr(V, "__len__"):
+            V = [V] * len(I)
+        if typ is None:
+            typ = types.from_python_value(V[0])
+        if nrows is None:
+            nrows = max(I) + 1
+        if ncols is None:
+            ncols = max(J) + 1
+        return cls.from_arrays(np.asarray(I, np.uint64), np.asarray(J, np.uint64), np.asarray(V, typ._np), nrows, ncols, typ)
+
+    @classmethod
+    def from_arrays(cls, I, J, V, nrows, ncols, typ, dup=None):
+        """Bulk build through GrB_Matrix_build_<T> (duplicates combined with `dup`, default: error)."""
+        m = cls.sparse(typ, nrows, ncols)
+        I = np.ascontiguousarray(I, np.uint64); J = np.ascontiguousarray(J, np.uint64); V = np.ascontiguousarray(V, typ._np)
+        fn = getattr(lib, "GrB_Matrix_build_" + typ.__name__)
+        check(fn(m._h, _p(I), _p(J), _p(V), u64(len(I)), C.c_void_p(dup.get_op()) if dup is not None else None), m)
+        return m
+
+    @classmethod
+    def from_csr(cls, typ, nrows, ncols, rowptr, colidx, values, device=False):
+        """Import CSR arrays (u32 rowptr/colidx).  `device=True`: the arguments are raw HBM addresses (ints)."""
+        h = C.c_void_p()
+        if device:
+            rp, ci, vv, nvals = C.c_void_p(rowptr), C.c_void_p(colidx), C.c_void_p(values[0]), values[1]
+        else:
+            rowptr = np.ascontiguousarray(rowptr, np.uint32); colidx = np.ascontiguousarray(colidx, np.uint32)
+            values = np.ascontiguousarray(values, typ._np)
+            rp, ci, vv, nvals = _p(rowptr), _p(colidx), _p(values), len(colidx)
+        check(lib.GrBX_Matrix_import_CSR(C.byref(h), C.c_void_p(typ._h), u64(nrows), u64(ncols), u64(nvals), rp, ci, vv,
+                                         C.c_int(1 if device else 0)))
+        return cls(h, typ)
+
+    @classmethod
+    def from_scipy_sparse(cls, m, typ=None):
+        m = m.tocsr(); m.sort_indices()
+        typ = typ or {np.dtype(np.float64): types.FP64, np.dtype(np.float32): types.FP32, np.dtype(np.int64): types.INT64,
+                      np.dtype(np.int32): types.INT32, np.dtype(np.bool_): types.BOOL}[m.dtype]
+        return cls.from_csr(typ, m.shape[0], m.shape[1], m.indptr, m.indices, m.data)
+
+    @classmethod
+    def identity(cls, typ, nrows, one=None):
+        idx = np.arange(nrows, dtype=np.uint64)
+        return cls.from_arrays(idx, idx, np.full(nrows, typ.default_one if one is None else one, typ._np), nrows, nrows, typ)
+
+    @classmethod
+    def random(cls, typ, nvals, nrows=None, ncols=None, make_symmetric=False, no_diagonal=False, seed=None):
+        """Random matrix from Python's `random` like the reference generator (pygraphblas/matrix.py:499-571):
+        later duplicates overwrite, so nvals is an upper bound."""
+        if seed is not None:
+            _random.seed(seed)
+        m = cls.sparse(typ, nrows, ncols)
+        for _ in range(nvals):
+            i, j = _random.randrange(nrows), _random.randrange(ncols)
+            if no_diagonal and i == j:
+                continue
+            if typ is types.BOOL:
+                v = True
+            elif typ in (types.FP32, types.FP64):
+                v = _random.random()
+            else:
+                info = np.iinfo(typ._np)
+                v = _random.randint(info.min, info.max)
+            m[i, j] = v
+            if make_symmetric:
+                m[j, i] = v
+        return m
+
+    def dup(self):
+        h = C.c_void_p()
+        check(lib.GrB_Matrix_dup(C.byref(h), self._h), self)
+        return Matrix(h, self.type)
+
+    # ---- properties -----------------------------------------------------------------------------------
+    def _index(self, fn):
+        n = u64()
+        check(fn(C.byref(n), self._h), self)
+        return n.value
+
+    @property
+    def nrows(self):
+        return self._index(lib.GrB_Matrix_nrows)
+
+    @property
+    def ncols(self):
+        return self._index(lib.GrB_Matrix_ncols)
+
+    @property
+    def shape(self):
+        return (self.nrows, self.ncols)
+
+    @property
+    def nvals(self):
+        return self._index(lib.GrB_Matrix_nvals)
+
+    @property
+    def T(self):
+        return self.transpose()
+
+    def __len__(self):
+        return self.nvals
+
+    def clear(self):
+        check(lib.GrB_Matrix_clear(self._h), self)
+
+    def wait(self):
+        check(lib.GrB_Matrix_wait(C.byref(self._h)), self)
+
+    # ---- element access ---------------------------------------------------------------------------------
+    def to_arrays(self):
+        n = self.nvals
+        I, J, X = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, self.type._np)
+        nn = u64(n)
+        fn = getattr(lib, "GrB_Matrix_extractTuples_" + self.type.__name__)
+        check(fn(_p(I), _p(J), _p(X), C.byref(nn), self._h), self)
+        return I, J, X
+
+    def to_lists(self):
+        I, J, X = self.to_arrays()
+        return [I.tolist(), J.tolist(), X.tolist()]
+
+    def to_csr(self):
+        n = self.nvals
+        rp, ci, x = np.zeros(self.nrows + 1, np.uint32), np.zeros(n, np.uint32), np.zeros(n, self.type._np)
+        check(lib.GrBX_Matrix_export_CSR(self._h, _p(rp), _p(ci), _p(x), C.c_int(0)), self)
+        return rp, ci, x
+
+    def to_scipy_sparse(self):
+        import scipy.sparse as sp
+        rp, ci, x = self.to_csr()
+        return sp.csr_matrix((x, ci.astype(np.int64), rp.astype(np.int64)), shape=self.shape)
+
+    def __iter__(self):
+        I, J, X = self.to_arrays()
+        return iter(zip(I.tolist(), J.tolist(), X.tolist()))
+
+    def __setitem__(self, index, value):
+        i, j = index
+        fn = getattr(lib, "GrB_Matrix_setElement_" + self.type.__name__)
+        check(fn(self._h, self.type._c(value), u64(i), u64(j)), self)
+
+    def __getitem__(self, index):
+        i, j = index
+        out = self.type._c()
+        fn = getattr(lib, "GrB_Matrix_extractElement_" + self.type.__name__)
+        check(fn(C.byref(out), self._h, u64(i), u64(j)), self)
+        return out.value
+
+    def get(self, i, j, default=None):
+        try:
+            return self[i, j]
+        except NoValue:
+            return default
+
+    def __delitem__(self, index):
+        i, j = index
+        check(lib.GrB_Matrix_removeElement(self._h, u64(i), u64(j)), self)
+
+    def __contains__(self, index):
+        return self.get(*index) is not None
+
+    # ---- the hot path -------------------------------------------------------------------------------------
+    def mxm(self, other, semiring=None, cast=None, out=None, mask=None, accum=None, desc=None):
+        """Matrix-matrix multiply `C<mask> = accum(C, self (+).(x) other)`  (reference: matrix.py:2401-2584)."""
+        if semiring is None:
+            semiring = current_semiring.get(None)
+        if out is None:
+            if cast is not None:
+                typ = cast
+            elif semiring is not None:
+                typ = semiring.ztype
+            else:
+                typ = types.promote(self.type, other.type)
+            out = Matrix.sparse(typ, self.nrows, other.ncols)
+        if semiring is None:
+            semiring = out.type._default_semiring()
+        mh, ah, dh = get_args(mask, accum, desc)
+        check(lib.GrB_mxm(out._h, mh, ah, C.c_void_p(semiring.get_op()), self._h, other._h, dh), out)
+        return out
+
+    def mxv(self, other, semiring=None, cast=None, out=None, mask=None, accum=None, desc=None):
+        """Matrix-vector multiply `w<mask> = accum(w, self (+).(x) other)`  (reference: matrix.py:2586-2726)."""
+        from .vector import Vector
+        if semiring is None:
+            semiring = current_semiring.get(None)
+        if out is None:
+            # the reference sizes by ncols whenever *any* explicit descriptor is passed
+            # (Descriptor.__contains__ quirk); only a transposing one should
+            transposed = desc is not None and _d.T0 in desc
+            if cast is not None:
+                typ = cast
+            elif semiring is not None:
+                typ = semiring.ztype
+            else:
+                typ = types.promote(self.type, other.type)
+            out = Vector.sparse(typ, self.ncols if transposed else self.nrows)
+        if semiring is None:
+            semiring = out.type._default_semiring()
+        mh, ah, dh = get_args(mask, accum, desc)
+        check(lib.GrB_mxv(out._h, mh, ah, C.c_void_p(semiring.get_op()), self._h, other._h, dh), out)
+        return out
+
+    def __matmul__(self, other):
+        from .vector import Vector
+        if isinstance(other, Matrix):
+            return self.mxm(other)
+        if isinstance(other, Vector):
+            return self.mxv(other)
+        raise TypeError("Right argument to @ must be Matrix or Vector.")
+
+    def __imatmul__(self, other):
+        return self.mxm(other, out=self)
+
+    def __getattr__(self, name):
+        # A.plus_times(B) -> FP64.plus_times(A, B)   (reference: matrix.py:1607-1613)
+        if name.startswith("_"):
+            raise AttributeError(name)
+        typ = self.__dict__.get("type")
+        op = getattr(typ, name, None) if typ is not None else None
+        if isinstance(op, (types.Semiring, types.BinaryOp)):
+            return partial(op, self)
+        raise AttributeError(name)
+
+    # ---- reductions -----------------------------------------------------------------------------------------
+    def _reduce_scalar(self, suffix, ctype, default_type, mon, accum, desc):
+        if mon is None:
+            mon = current_monoid.get(getattr(default_type, "LOR_MONOID" if default_type is types.BOOL else "PLUS_MONOID"))
+        out = ctype(0)
+        _, ah, dh = get_args(None, accum, desc)
+        fn = getattr(lib, "GrB_Matrix_reduce_" + suffix)
+        check(fn(C.byref(out), ah, C.c_void_p(mon.get_op()), self._h, dh), self)
+        return out.value
+
+    def reduce_bool(self, mon=None, accum=None, desc=None):
+        return self._reduce_scalar("BOOL", C.c_bool, types.BOOL, mon, accum, desc)
+
+    def reduce_int(self, mon=None, accum=None, desc=None):
+        """Reduce to a Python int with INT64.PLUS_MONOID by default (reference: matrix.py:1782-1804)."""
+        return self._reduce_scalar("INT64", C.c_int64, types.INT64, mon, accum, desc)
+
+    def reduce_float(self, mon=None, accum=None, desc=None):
+        return self._reduce_scalar("FP64", C.c_double, types.FP64, mon, accum, desc)
+
+    def reduce_vector(self, mon=None, out=None, mask=None, accum=None, desc=None):
+        from .vector import Vector
+        if mon is None:
+            mon = current_monoid.get(self.type.PLUS_MONOID if self.type is not types.BOOL else types.BOOL.LOR_MONOID)
+        if out is None:
+            out = Vector.sparse(self.type, self.nrows)
+        mh, ah, dh = get_args(mask, accum, desc)
+        check(lib.GrB_Matrix_reduce_Monoid(out._h, mh, ah, C.c_void_p(mon.get_op()), self._h, dh), out)
+        return out
+
+    # ---- companions of the hot path -------------------------------------------------------------------------
+    def transpose(self, cast=None, out=None, mask=None, accum=None, desc=None):
+        if out is None:
+            out = Matrix.sparse(cast or self.type, self.ncols, self.nrows)
+        mh, ah, dh = get_args(mask, accum, desc)
+        check(lib.GrB_transpose(out._h, mh, ah, self._h, dh), out)
+        return out
+
+    def _ewise(self, fn_stem, other, op, cast, out, mask, accum, desc, default):
+        if op is None:
+            op = current_binop.get(None) or default(types.promote(self.type, other.type))
+        if out is None:
+            out = Matrix.sparse(cast or types.promote(self.type, other.type), self.nrows, self.ncols)
+        kind = {"BinaryOp": "BinaryOp", "Monoid": "Monoid", "Semiring": "Semiring"}[op.kind]
+        mh, ah, dh = get_args(mask, accum, desc)
+        fn = getattr(lib, f"GrB_Matrix_{fn_stem}_{kind}")
+        check(fn(out._h, mh, ah, C.c_void_p(op.get_op()), self._h, other._h, dh), out)
+        return out
+
+    def eadd(self, other, add_op=None, cast=None, out=None, mask=None, accum=None, desc=None):
+        """Element-wise union (reference: matrix.py:1103-1262)."""
+        return self._ewise("eWiseAdd", other, add_op, cast, out, mask, accum, desc, lambda t: t._default_addop())
+
+    def emult(self, other, mult_op=None, cast=None, out=None, mask=None, accum=None, desc=None):
+        """Element-wise intersection (reference: matrix.py:1264-1413)."""
+        return self._ewise("eWiseMult", other, mult_op, cast, out, mask, accum, desc, lambda t: t._default_multop())
+
+    def iseq(self, other, eq_op=None):
+        """True when both matrices have the same pattern and equal values (reference: matrix.py:1436-1453)."""
+        if self.nrows != other.nrows or self.ncols != other.ncols or self.nvals != other.nvals:
+            return False
+        if eq_op is None:
+            eq_op = types.promote(self.type, other.type).EQ
+        c = self.emult(other, eq_op, cast=types.BOOL)
+        if c.nvals != self.nvals:
+            return False
+        return c.reduce_bool(types.BOOL.LAND_MONOID)
+
+    def apply(self, op, out=None, mask=None, accum=None, desc=None):
+        if out is None:
+            out = Matrix.sparse(self.type, self.nrows, self.ncols)
+        mh, ah, dh = get_args(mask, accum, desc)
+        check(lib.GrB_Matrix_apply(out._h, mh, ah, C.c_void_p(op.get_op()), self._h, dh), out)
+        return out
+
+    def select(self, op, thunk=None, out=None, mask=None, accum=None, desc=None):
+        """`GxB_Matrix_select` with a built-in select operator name ("TRIL", ">0", ...) (reference: matrix.py:2042-2140)."""
+        opname = {"tril": "TRIL", "triu": "TRIU", "diag": "DIAG", "offdiag": "OFFDIAG", "nonzero": "NONZERO",
+                  "!=0": "NONZERO", "==0": "EQ_ZERO", ">0": "GT_ZERO", ">=0": "GE_ZERO", "<0": "LT_ZERO", "<=0": "LE_ZERO",
+                  "!=": "NE_THUNK", "==": "EQ_THUNK", ">": "GT_THUNK", ">=": "GE_THUNK", "<": "LT_THUNK", "<=": "LE_THUNK"}.get(op, op)
+        if out is None:
+            out = Matrix.sparse(self.type, self.nrows, self.ncols)
+        th = None
+        if thunk is not None:
+            th = C.c_void_p()
+            ttyp = types.INT64 if opname in ("TRIL", "TRIU", "DIAG", "OFFDIAG") else self.type
+            check(lib.GxB_Scalar_new(C.byref(th), C.c_void_p(ttyp._h)))
+            check(getattr(lib, "GxB_Scalar_setElement_" + ttyp.__name__)(th, ttyp._c(thunk)))
+        mh, ah, dh = get_args(mask, accum, desc)
+        try:
+            check(lib.GxB_Matrix_select(out._h, mh, ah, C.c_void_p(_capi.handle("GxB_" + opname)), self._h, th, dh), out)
+        finally:
+            if th is not None:
+                lib.GxB_Scalar_free(C.byref(th))
+        return out
+
+    def tril(self, thunk=None):
+        return self.select("TRIL", thunk)
+
+    def triu(self, thunk=None):
+        return self.select("TRIU", thunk)
+
+    def offdiag(self, thunk=None):
+        return self.select("OFFDIAG", thunk)
+
+    def nonzero(self):
+        return self.select("NONZERO")
+
+    def pattern(self, typ=types.BOOL):
+        """The structure of the matrix as a matrix of ones (reference: matrix.py:887-922)."""
+        out = Matrix.sparse(typ, self.nrows, self.ncols)
+        check(lib.GrB_Matrix_apply(out._h, None, None, C.c_void_p(typ.ONE.get_op()), self._h, None), out)
+        return out
+
+    def __repr__(self):
+        return f"<Matrix ({self.nrows}x{self.ncols} : {self.nvals}:{self.type.__name__})>"
