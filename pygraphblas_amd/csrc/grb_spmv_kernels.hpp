@@ -24,6 +24,19 @@
 
 namespace grb {
 
+// Load flavours (experiment knobs GRB_MI355X_GATHER / GRB_MI355X_STREAM): 0 plain, 1 nontemporal, 2 sc1 (L1 bypass)
+template <int MODE, class T> __device__ __forceinline__ T ld(const T* p) {
+  if constexpr (MODE == 0) return *p;
+  else {
+    typedef typename std::conditional<sizeof(T) == 8, uint64_t, typename std::conditional<sizeof(T) == 4, uint32_t,
+            typename std::conditional<sizeof(T) == 2, uint16_t, uint8_t>::type>::type>::type W;
+    W w;
+    if constexpr (MODE == 1) w = __builtin_nontemporal_load((const W*)p);
+    else w = __hip_atomic_load((const W*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    T t; __builtin_memcpy(&t, &w, sizeof(T)); return t;
+  }
+}
+
 template <class T> struct SpmvKArgs {
   const uint32_t* rowptr; const uint32_t* col; const T* aval;
   const T* uval; const uint8_t* upres; const uint8_t* allow;
@@ -33,7 +46,7 @@ template <class T> struct SpmvKArgs {
 };
 
 // ---- kernel A ---------------------------------------------------------------------------------------------------
-template <class T, class SR, bool U_FULL, bool HAS_ALLOW>
+template <class T, class SR, bool U_FULL, bool HAS_ALLOW, int GM = 0, int SM = 0>
 __global__ __launch_bounds__(SPMV_THREADS) void k_spmv_adaptive(const SpmvKArgs<T> a, const SR sr) {
   __shared__ T s_prod[SPMV_NNZ];
   __shared__ uint8_t s_has[U_FULL ? 4 : SPMV_NNZ];
@@ -54,46 +67,65 @@ __global__ __launch_bounds__(SPMV_THREADS) void k_spmv_adaptive(const SpmvKArgs<
       }
     }
     const uint32_t p0 = a.rowptr[r0], p1 = a.rowptr[r1];
-    // phase 1: coalesced stream of (col, val), gather u, products to LDS.  All loads of a lane are
-    // issued before the first dependent use so >= 8 requests per lane are in flight.
-    uint32_t c[SPMV_UNROLL]; T av[SPMV_UNROLL]; T uv[SPMV_UNROLL]; uint8_t up[SPMV_UNROLL];
+    const uint32_t cnt = p1 - p0;
+    // phase 1: coalesced stream of (col, val), gather u, products to LDS.  Every load is
+    // unconditional (tail lanes re-read the block's last entry) so the compiler keeps them
+    // branch-free: 16 streaming loads, then 8 gathers, are in flight per lane before the first use.
+    if (cnt) {
+      uint32_t c[SPMV_UNROLL]; T av[SPMV_UNROLL]; T uv[SPMV_UNROLL]; uint8_t up[SPMV_UNROLL];
 #pragma unroll
-    for (int u = 0; u < SPMV_UNROLL; u++) {
-      const uint32_t p = p0 + tid + u * SPMV_THREADS;
-      c[u] = 0; av[u] = T();
-      if (p < p1) { c[u] = a.col[p]; if (use_a) av[u] = a.aval[p]; }
-    }
-#pragma unroll
-    for (int u = 0; u < SPMV_UNROLL; u++) {
-      const uint32_t p = p0 + tid + u * SPMV_THREADS;
-      uv[u] = T(); up[u] = 1;
-      if (p < p1) {
-        if (use_u) uv[u] = a.uval[c[u]];
-        if constexpr (!U_FULL) up[u] = a.upres[c[u]];
+      for (int u = 0; u < SPMV_UNROLL; u++) {
+        const uint32_t k = tid + u * SPMV_THREADS;
+        const uint32_t p = p0 + (k < cnt ? k : cnt - 1);
+        c[u] = ld<SM>(&a.col[p]);
+        av[u] = use_a ? ld<SM>(&a.aval[p]) : T();
       }
-    }
 #pragma unroll
-    for (int u = 0; u < SPMV_UNROLL; u++) {
-      const int k = tid + u * SPMV_THREADS;
-      if (p0 + k < p1) {
-        s_prod[k] = sr.mult(av[u], uv[u]);
-        if constexpr (!U_FULL) s_has[k] = up[u];
+      for (int u = 0; u < SPMV_UNROLL; u++) {
+        uv[u] = use_u ? ld<GM>(&a.uval[c[u]]) : T();
+        if constexpr (!U_FULL) up[u] = ld<GM>(&a.upres[c[u]]); else up[u] = 1;
+      }
+#pragma unroll
+      for (int u = 0; u < SPMV_UNROLL; u++) {
+        const uint32_t k = tid + u * SPMV_THREADS;
+        if (k < cnt) {
+          s_prod[k] = sr.mult(av[u], uv[u]);
+          if constexpr (!U_FULL) s_has[k] = up[u];
+        }
       }
     }
     __syncthreads();
-    // phase 2: one thread per row, serial in entry order (fixed order => reproducible FP sums)
-    for (uint32_t r = r0 + tid; r < r1; r += SPMV_THREADS) {
-      if constexpr (HAS_ALLOW) { if (!a.allow[r]) { a.tpres[r] = 0; continue; } }
-      const uint32_t qb = a.rowptr[r] - p0, qe = a.rowptr[r + 1] - p0;
+    // phase 2: G lanes per row, G = the largest power of two with rows*G <= 256 (block-uniform).
+    // Each lane sums a G-strided slice of the row from LDS (conflict-free), then a fixed
+    // shuffle tree combines the G partials: the order is a function of the row block only,
+    // so floating-point results are reproducible run to run.
+    const uint32_t nr = r1 - r0;
+    const uint32_t G = nr >= SPMV_THREADS / 2 ? 1u : (nr <= 4 ? 64u : (1u << (31 - __builtin_clz(SPMV_THREADS / nr))));
+    const uint32_t lane = tid & (G - 1), grp = tid / G, ngrp = SPMV_THREADS / G;
+    for (uint32_t rb = 0; rb < nr; rb += ngrp) {
+      const uint32_t r = r0 + rb + grp;
+      const bool live = rb + grp < nr;
+      bool ok = live;
+      if constexpr (HAS_ALLOW) { if (live) ok = a.allow[r] != 0; }
+      uint32_t qb = 0, qe = 0;
+      if (ok) { qb = a.rowptr[r] - p0; qe = a.rowptr[r + 1] - p0; }
       T acc = sr.identity; bool has = false;
-      if constexpr (U_FULL) {
-        has = qe > qb;
-        if (has) { acc = s_prod[qb]; for (uint32_t q = qb + 1; q < qe; q++) acc = sr.add(acc, s_prod[q]); }
-      } else {
-        for (uint32_t q = qb; q < qe; q++) if (s_has[q]) { acc = has ? sr.add(acc, s_prod[q]) : s_prod[q]; has = true; }
+      for (uint32_t q = qb + lane; q < qe; q += G) {
+        if constexpr (U_FULL) { acc = has ? sr.add(acc, s_prod[q]) : s_prod[q]; has = true; }
+        else if (s_has[q]) { acc = has ? sr.add(acc, s_prod[q]) : s_prod[q]; has = true; }
       }
-      if (has) a.tval[r] = acc;
-      a.tpres[r] = has ? 1 : 0;
+      if (G > 1) {
+        // lanes without a contribution carry the identity; `has` travels with the value
+        for (uint32_t d = G >> 1; d >= 1; d >>= 1) {
+          const T ov = shfl_down_t<T>(acc, (int)d);
+          const int oh = __shfl_down((int)has, (int)d, 64);
+          if (oh) { acc = has ? sr.add(acc, ov) : ov; has = true; }
+        }
+      }
+      if (live && lane == 0) {
+        if (has) a.tval[r] = acc;
+        a.tpres[r] = has ? 1 : 0;
+      }
     }
     return;
   }
@@ -106,24 +138,25 @@ __global__ __launch_bounds__(SPMV_THREADS) void k_spmv_adaptive(const SpmvKArgs<
   const uint32_t pe = (re - pb > (uint32_t)SPMV_LONG_CHUNK) ? pb + SPMV_LONG_CHUNK : re;
   T acc = sr.identity; bool has = false;
   for (uint32_t base = pb; base < pe; base += SPMV_NNZ) {
-    uint32_t c[SPMV_UNROLL]; T av[SPMV_UNROLL];
+    uint32_t c[SPMV_UNROLL]; T av[SPMV_UNROLL]; T uv[SPMV_UNROLL]; uint8_t up[SPMV_UNROLL];
 #pragma unroll
     for (int u = 0; u < SPMV_UNROLL; u++) {
-      const uint32_t p = base + tid + u * SPMV_THREADS;
-      c[u] = 0; av[u] = T();
-      if (p < pe) { c[u] = a.col[p]; if (use_a) av[u] = a.aval[p]; }
+      uint32_t p = base + tid + u * SPMV_THREADS;
+      p = p < pe ? p : pe - 1;                       // unconditional loads: tail lanes re-read the last entry
+      c[u] = ld<SM>(&a.col[p]);
+      av[u] = use_a ? ld<SM>(&a.aval[p]) : T();
+    }
+#pragma unroll
+    for (int u = 0; u < SPMV_UNROLL; u++) {
+      uv[u] = use_u ? ld<GM>(&a.uval[c[u]]) : T();
+      if constexpr (!U_FULL) up[u] = ld<GM>(&a.upres[c[u]]); else up[u] = 1;
     }
 #pragma unroll
     for (int u = 0; u < SPMV_UNROLL; u++) {
       const uint32_t p = base + tid + u * SPMV_THREADS;
-      if (p < pe) {
-        bool pr = true;
-        if constexpr (!U_FULL) pr = a.upres[c[u]] != 0;
-        if (pr) {
-          const T x = use_u ? a.uval[c[u]] : T();
-          const T m = sr.mult(av[u], x);
-          acc = has ? sr.add(acc, m) : m; has = true;
-        }
+      if (p < pe && up[u]) {
+        const T m = sr.mult(av[u], uv[u]);
+        acc = has ? sr.add(acc, m) : m; has = true;
       }
     }
   }
@@ -274,6 +307,15 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
     a.tickets = (uint32_t*)aux; a.partial = (T*)(aux + ns * 4); a.pflag = aux + ns * 4 + ns * 8;
     if (M.plan_nblocks == 0) return;
     const dim3 grid(M.plan_nblocks), block(SPMV_THREADS);
+    if constexpr (std::is_same<T, double>::value && SR::is_static) {
+      const char* eg = getenv("GRB_MI355X_GATHER"); const char* es = getenv("GRB_MI355X_STREAM");
+      const int gm = eg ? atoi(eg) : 0, sm = es ? atoi(es) : 0;
+      if (full && !c.allow && (gm || sm)) {
+#define GRB_EXP(G_, S_) if (gm == G_ && sm == S_) { hipLaunchKernelGGL((k_spmv_adaptive<T, SR, true, false, G_, S_>), grid, block, 0, stream(), a, sr); g_last_plan += "k_spmv_adaptive<exp g" #G_ " s" #S_ "> "; return; }
+        GRB_EXP(0, 1) GRB_EXP(1, 0) GRB_EXP(1, 1) GRB_EXP(2, 0) GRB_EXP(2, 1)
+#undef GRB_EXP
+      }
+    }
     if (full) {
       if (c.allow) hipLaunchKernelGGL((k_spmv_adaptive<T, SR, true, true>), grid, block, 0, stream(), a, sr);
       else hipLaunchKernelGGL((k_spmv_adaptive<T, SR, true, false>), grid, block, 0, stream(), a, sr);

@@ -1,0 +1,161 @@
+"""GPU parity of GrB_mxv / GrB_vxm (HIP kernels, through the C ABI) against the CPU oracle.
+
+Bit-exact for BOOL / integer types; floating point is compared at rtol 1e-6 (the tolerance
+BASELINE.json's north_star states) — and exactly where the test data sits on a 1/8 grid.
+Cases cover what the reference's tests cover for this path (tests/test_vector.py:298-315,
+tests/test_matrix.py:293-306, tests/test_descriptor.py:13-30): masks (valued / structural /
+complemented / empty), replace, accum, transposed inputs, output aliasing an input, typecast of
+operands and output, empty and ragged inputs, rows longer than one kernel block.
+"""
+import itertools
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+import pygraphblas_amd as gb
+from pygraphblas_amd import descriptor as D
+from helpers import TYPE, rand_matrix, rand_vector, to_matrix, to_vector, vector_pairs, assert_same
+
+pytestmark = pytest.mark.gpu
+
+SEMIRINGS = {
+    "BOOL": ["LOR_LAND", "ANY_PAIR", "LXOR_LAND", "LAND_LOR", "EQ_LOR"],
+    "INT": ["PLUS_TIMES", "MIN_PLUS", "PLUS_PAIR", "PLUS_SECOND", "PLUS_FIRST", "MAX_MIN", "MIN_FIRST", "PLUS_PLUS", "TIMES_PLUS",
+            "PLUS_LAND", "MAX_MINUS", "MIN_RDIV", "PLUS_ISGT", "ANY_PAIR"],
+    "FP": ["PLUS_TIMES", "MIN_PLUS", "PLUS_PAIR", "PLUS_SECOND", "PLUS_FIRST", "MAX_TIMES", "MIN_MAX", "PLUS_MINUS", "PLUS_DIV"],
+}
+
+
+def family(t):
+    return "BOOL" if t == "BOOL" else ("FP" if t.startswith("FP") else "INT")
+
+
+def run_case(rng, typ, sr_name, nrows, ncols, dens, udens, *, vxm=False, tran=False, mask=None, accum=None, replace=False,
+             out_typ=None, a_typ=None, u_typ=None, method=None):
+    add, mul = sr_name.split("_")
+    a_typ, u_typ, out_typ = a_typ or typ, u_typ or typ, out_typ or typ
+    # stored matrix A is (nrows x ncols); the effective operand may be transposed
+    A = rand_matrix(rng, a_typ, nrows, ncols, dens)
+    eff_r, eff_c = (ncols, nrows) if tran else (nrows, ncols)
+    n_in, n_out = (eff_r, eff_c) if vxm else (eff_c, eff_r)
+    ui, ux = rand_vector(rng, u_typ, n_in, udens)
+    wi, wx = rand_vector(rng, out_typ, n_out, 0.4)
+    mi = mx = None
+    mtyp = None
+    if mask is not None:
+        mtyp = mask["typ"]
+        mi, mx = rand_vector(rng, mtyp, n_out, mask.get("dens", 0.5))
+    sr = getattr(TYPE[typ], sr_name)
+    gA, gu, gw = to_matrix(A), to_vector(u_typ, n_in, ui, ux), to_vector(out_typ, n_out, wi, wx)
+    gm = to_vector(mtyp, n_out, mi, mx) if mask is not None else None
+    flags = []
+    if replace:
+        flags.append("R")
+    if mask is not None and mask.get("struct"):
+        flags.append("S")
+    if mask is not None and mask.get("comp"):
+        flags.append("C")
+    if tran:
+        flags.append("T1" if vxm else "T0")
+    desc = getattr(D, "".join(flags)) if flags else None
+    acc = getattr(TYPE[out_typ], accum) if accum else None
+    if method:
+        os.environ["GRB_MI355X_SPMV"] = method
+    try:
+        if vxm:
+            gu.vxm(gA, semiring=sr, out=gw, mask=gm, accum=acc, desc=desc)
+        else:
+            gA.mxv(gu, semiring=sr, out=gw, mask=gm, accum=acc, desc=desc)
+    finally:
+        os.environ.pop("GRB_MI355X_SPMV", None)
+    kw = dict(accum=accum, accum_type=out_typ, replace=replace, mask_comp=bool(mask and mask.get("comp")),
+              mask_struct=bool(mask and mask.get("struct")))
+    if vxm:
+        exp = O.vxm(O.row_vector(out_typ, n_out, wi, wx), O.row_vector(u_typ, n_in, ui, ux), A, add, mul, typ,
+                    mask=O.row_vector(mtyp, n_out, mi, mx) if mask is not None else None, tran_a=tran, **kw)
+        exp_idx = exp.J
+    else:
+        exp = O.mxv(O.col_vector(out_typ, n_out, wi, wx), A, O.col_vector(u_typ, n_in, ui, ux), add, mul, typ,
+                    mask=O.col_vector(mtyp, n_out, mi, mx) if mask is not None else None, tran_a=tran, **kw)
+        exp_idx = exp.I
+    gi, gx = vector_pairs(gw)
+    assert_same(out_typ, gi, gx, exp_idx, exp.X, what=f"{typ}.{sr_name} vxm={vxm} tran={tran} mask={mask} accum={accum} plan={gb.last_kernel_plan()}")
+
+
+ALL = ["BOOL", "INT8", "UINT8", "INT16", "UINT16", "INT32", "UINT32", "INT64", "UINT64", "FP32", "FP64"]
+
+
+@pytest.mark.parametrize("typ", ALL)
+def test_every_type_default_semirings(gpu, typ):
+    rng = np.random.default_rng(hash(typ) % 2**32)
+    for sr in SEMIRINGS[family(typ)]:
+        for vxm in (False, True):
+            run_case(rng, typ, sr, 37, 53, 0.15, 0.6, vxm=vxm)
+            run_case(rng, typ, sr, 41, 29, 0.2, 1.0, vxm=vxm, tran=True)
+
+
+@pytest.mark.parametrize("typ", ["BOOL", "INT64", "FP64", "UINT8", "FP32"])
+@pytest.mark.parametrize("method", ["adaptive", "rowgroup", "push"])
+def test_masks_accum_replace_all_kernels(gpu, typ, method):
+    rng = np.random.default_rng(7)
+    sr = {"BOOL": "LOR_LAND", "FP64": "PLUS_TIMES", "FP32": "PLUS_TIMES"}.get(typ, "MIN_PLUS" if method == "push" else "PLUS_TIMES")
+    acc = {"BOOL": "LOR"}.get(typ, "PLUS")
+    masks = [None, {"typ": "BOOL"}, {"typ": "BOOL", "comp": True}, {"typ": "INT32", "struct": True}, {"typ": "FP64", "comp": True, "struct": True},
+             {"typ": "UINT8", "dens": 0.0, "comp": True}, {"typ": "BOOL", "dens": 1.0}]
+    for mask, accum, replace, vxm in itertools.product(masks, [None, acc], [False, True], [False, True]):
+        run_case(rng, typ, sr, 64, 48, 0.12, 0.3, vxm=vxm, mask=mask, accum=accum, replace=replace, method=method)
+
+
+def test_typecasts(gpu):
+    rng = np.random.default_rng(3)
+    # operands of other types are cast into the semiring's domain; the result into the output's type
+    run_case(rng, "BOOL", "LOR_LAND", 30, 30, 0.2, 0.5, a_typ="INT64", u_typ="UINT8", out_typ="BOOL", vxm=True)   # the BFS step
+    run_case(rng, "FP64", "PLUS_TIMES", 30, 40, 0.2, 0.7, a_typ="FP32", u_typ="INT8", out_typ="FP32")
+    run_case(rng, "INT64", "PLUS_TIMES", 30, 40, 0.2, 0.7, a_typ="UINT8", u_typ="INT16", out_typ="FP64", accum="PLUS")
+    run_case(rng, "INT32", "MIN_PLUS", 25, 25, 0.3, 0.5, out_typ="INT8", mask={"typ": "FP32"}, accum="MIN")
+    run_case(rng, "FP32", "PLUS_SECOND", 50, 50, 0.1, 1.0, a_typ="BOOL", accum="PLUS", tran=True)                  # the PageRank step
+
+
+def test_edge_shapes(gpu):
+    rng = np.random.default_rng(11)
+    run_case(rng, "INT64", "PLUS_TIMES", 1, 1, 1.0, 1.0)
+    run_case(rng, "INT64", "PLUS_TIMES", 5, 7, 0.0, 1.0)            # empty matrix
+    run_case(rng, "INT64", "PLUS_TIMES", 5, 7, 0.5, 0.0)            # empty vector
+    run_case(rng, "FP64", "PLUS_TIMES", 3, 9000, 0.9, 1.0)          # rows longer than one block (2048) and one part (8192)
+    run_case(rng, "FP64", "PLUS_TIMES", 2, 30000, 0.95, 0.9)        # multi-part long rows with a bitmap operand
+    run_case(rng, "INT32", "MIN_PLUS", 3000, 3, 0.5, 1.0)           # many short rows
+    run_case(rng, "UINT16", "PLUS_TIMES", 2500, 2500, 0.002, 1.0)   # mostly empty rows
+    run_case(rng, "BOOL", "LOR_LAND", 4, 20000, 0.9, 0.5, mask={"typ": "BOOL", "comp": True})
+
+
+def test_output_aliases_input(gpu):
+    # reference: tests/test_descriptor.py:13-30 (test_RCT0 / test_RC): out=w aliases the operand, empty mask complemented, replace
+    M = gb.Matrix.from_lists([0, 1, 2], [1, 2, 0], [True, True, True])
+    w = gb.Vector.sparse(gb.BOOL, 3); v = gb.Vector.sparse(gb.BOOL, 3)
+    w[0] = True
+    M.mxv(w, out=w, mask=v, desc=D.RCT0)
+    assert w.iseq(gb.Vector.from_lists([1], [True], 3))
+    w = gb.Vector.sparse(gb.BOOL, 3); w[0] = True
+    M.mxv(w, out=w, mask=v, desc=D.RC)
+    assert w.iseq(gb.Vector.from_lists([2], [True], 3))
+
+
+def test_dimension_mismatch_raises(gpu):
+    A = gb.Matrix.from_lists([0, 1], [1, 2], [1, 2], nrows=3, ncols=4)
+    with pytest.raises(gb.DimensionMismatch):
+        A.mxv(gb.Vector.from_lists([0], [1], size=3))
+    with pytest.raises(gb.DimensionMismatch):
+        gb.Vector.from_lists([0], [1], size=4).vxm(A)
+
+
+def test_fp64_random_values_within_1e6(gpu):
+    # unstructured double values: order of summation differs from the oracle's, tolerance 1e-6 relative
+    rng = np.random.default_rng(5)
+    A = rand_matrix(rng, "FP64", 2000, 2000, 0.01, small=False)
+    ui, ux = rand_vector(rng, "FP64", 2000, 1.0, small=False)
+    w = to_matrix(A).mxv(to_vector("FP64", 2000, ui, ux), semiring=gb.FP64.PLUS_TIMES)
+    exp = O.mxv(O.col_vector("FP64", 2000), A, O.col_vector("FP64", 2000, ui, ux), "PLUS", "TIMES", "FP64")
+    gi, gx = vector_pairs(w)
+    assert_same("FP64", gi, gx, exp.I, exp.X, rtol=1e-6)
