@@ -1,0 +1,29 @@
+// grb_matops.hpp — host interface of the O(nnz) matrix kernels (grb_matops.hip) and SpGEMM (grb_spgemm.hip).
+#pragma once
+#include "grb_internal.hpp"
+#include "grb_semiring.hpp"
+
+namespace grb {
+
+// out = C<M,replace> (+accum) T  — all three in one value type `code`; M may be nullptr
+void csr_writeback(int code, uint32_t nrows, const DevCSR& C, const DevCSR& Tm, const DevCSR* M, int mcode, bool mstruct, bool mcomp,
+                   bool replace, int accum, DevCSR& out);
+void csr_ewise(int code, const DevCSR& A, const void* aval, const DevCSR& B, const void* bval, int op, bool is_union, DevCSR& out);
+void csr_compact(const DevCSR& A, const void* aval, size_t ts, const uint8_t* keep, DevCSR& out);
+void select_positional_flags(const DevCSR& A, int sel, int64_t k, uint8_t* keep);
+void mask_flags(const DevCSR& Tm, const DevCSR& M, int mcode, bool mstruct, bool mcomp, uint8_t* keep);
+void csr_reduce_rows(int code, const DevCSR& A, const void* aval, int op, void* tval, uint8_t* tpres);
+void csr_row_indices(const DevCSR& A, uint32_t* rowidx);
+
+// ---- SpGEMM ----------------------------------------------------------------------------------------------
+struct SpgemmCall {
+  const DevCSR* A; const void* aval;     // values already in the semiring type (nullptr: multiply ignores them)
+  const DevCSR* B; const void* bval;
+  const DevCSR* M; int mcode; bool mstruct;   // non-complemented mask for the masked kernel (nullptr otherwise)
+};
+// T<M> = A (+).(x) B restricted to the entries the mask allows; T's pattern is a subset of M's
+void spgemm_masked(const SpgemmCall& c, const SemiringDesc& d, DevCSR& out);
+// T = A (+).(x) B by expand / sort / compress
+void spgemm_esc(const SpgemmCall& c, const SemiringDesc& d, DevCSR& out);
+
+}  // namespace grb

@@ -1,0 +1,334 @@
+// grb_spgemm_kernels.hpp — the SpGEMM kernels behind GrB_mxm  (irregular gather; no MFMA).
+//
+// (1) Masked Gustavson,  T<M> = A (+).(x) B  with a non-complemented mask — the triangle-counting
+//     path  L.mxm(L, PLUS_PAIR, mask=L)  (reference caller: demo/TriangleCentrality.ipynb cell 17).
+//     One team of threads owns output row i.  The allowed columns of M(i,:) are hashed into an
+//     LDS table (open addressing, load <= 1/2); 16-lane groups walk the entries k of A(i,:) and
+//     stream row B(k,:) coalesced; every product probes the table and, on a hit, combines into
+//     the LDS accumulator of that mask position.  Only masked products ever touch memory beyond the
+//     B stream, and nothing is written outside nnz(M) slots.  Rows are binned by mask-row length so
+//     the table (64 ... 8192 slots) and the team (1 wave ... 4 waves) fit the row; rows whose mask
+//     row exceeds 4096 entries use a dense position map in HBM and global atomics.
+// (2) Expand / sort / compress for the unmasked (or complement-masked) product: every product is
+//     emitted with key (i,j), a stable radix sort brings equal keys together in k order, and a
+//     segmented in-order reduction compresses them — deterministic for floating point too.
+// Algorithmic work: F = 2 * sum_{(i,k) in A} nnz(B(k,:)) flops,
+//   bytes = 2*(nnz(A)*4 + (n+1)*4) + (F/2)*4 [+ (F/2)*sizeof(T) when the multiply reads B's values] + nnz(C)*(4+sizeof(T)).
+#pragma once
+#include "grb_api.hpp"
+#include "grb_device.hpp"
+#include "grb_semiring.hpp"
+#include "grb_atomics.hpp"
+#include "grb_matops.hpp"
+
+namespace grb {
+
+constexpr uint32_t HASH_EMPTY = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t hash_col(uint32_t j, uint32_t mask) { return (j * 2654435761u >> 7) & mask; }
+
+template <class T> struct SpgemmKArgs {
+  const uint32_t* arp; const uint32_t* acol; const T* aval;
+  const uint32_t* brp; const uint32_t* bcol; const T* bval;
+  const uint32_t* mrp; const uint32_t* mcol; const void* mval; int mcode; bool mstruct;
+  typename acc_word<T>::type* cacc; uint8_t* cflag;      // one slot per mask entry
+};
+
+__device__ __forceinline__ bool spgemm_mask_truth(const void* mval, int mcode, uint32_t p, bool structural) {
+  if (structural || !mval) return true;
+  switch (type_size(mcode)) {
+    case 1: return ((const uint8_t*)mval)[p] != 0;
+    case 2: return ((const uint16_t*)mval)[p] != 0;
+    case 4: return mcode == T_FP32 ? ((const float*)mval)[p] != 0.0f : ((const uint32_t*)mval)[p] != 0;
+    default: return mcode == T_FP64 ? ((const double*)mval)[p] != 0.0 : ((const uint64_t*)mval)[p] != 0;
+  }
+}
+
+// ---- (1a) LDS-hash masked Gustavson: TEAM threads per row, 256 / TEAM rows per block -----------------------------
+template <class T, class SR, int SLOTS, int TEAM>
+__global__ __launch_bounds__(256) void k_spgemm_masked_lds(const SpgemmKArgs<T> a, const uint32_t* __restrict__ rows, uint32_t nrows_bin, const SR sr) {
+  typedef typename acc_word<T>::type W;
+  constexpr int TEAMS = 256 / TEAM;
+  __shared__ uint32_t s_key[TEAMS][SLOTS];
+  __shared__ W s_acc[TEAMS][SLOTS];
+  __shared__ uint16_t s_pos[TEAMS][SLOTS];
+  __shared__ uint8_t s_flag[TEAMS][SLOTS];
+  const int team = threadIdx.x / TEAM, t = threadIdx.x % TEAM;
+  const int lane16 = t & 15, grp = t >> 4;
+  constexpr int NG = TEAM / 16;
+  const bool use_a = sr.uses_a(), use_b = sr.uses_u();
+  const W idw = to_word<T>(sr.identity);
+  uint32_t* key = s_key[team]; W* acc = s_acc[team]; uint16_t* pos = s_pos[team]; uint8_t* flag = s_flag[team];
+  const uint32_t nblk_rows = (nrows_bin + TEAMS - 1) / TEAMS * TEAMS;     // every team runs the same trip count
+  for (uint32_t rbase = blockIdx.x * TEAMS; rbase < nblk_rows; rbase += gridDim.x * TEAMS) {
+    const uint32_t ridx = rbase + team;
+    const bool live = ridx < nrows_bin;
+    const uint32_t i = live ? rows[ridx] : 0;
+    for (int s = t; s < SLOTS; s += TEAM) { key[s] = HASH_EMPTY; acc[s] = idw; flag[s] = 0; }
+    __syncthreads();
+    const uint32_t mb = live ? a.mrp[i] : 0, me = live ? a.mrp[i + 1] : 0;
+    for (uint32_t p = mb + t; p < me; p += TEAM) {
+      if (!spgemm_mask_truth(a.mval, a.mcode, p, a.mstruct)) continue;
+      const uint32_t j = a.mcol[p];
+      uint32_t h = hash_col(j, SLOTS - 1);
+      while (atomicCAS(&key[h], HASH_EMPTY, j) != HASH_EMPTY) h = (h + 1) & (SLOTS - 1);
+      pos[h] = (uint16_t)(p - mb);
+    }
+    __syncthreads();
+    const uint32_t ab = live ? a.arp[i] : 0, ae = live ? a.arp[i + 1] : 0;
+    for (uint32_t pa = ab + grp; pa < ae; pa += NG) {
+      const uint32_t k = a.acol[pa];
+      const T av = use_a ? a.aval[pa] : T();
+      const uint32_t bb = a.brp[k], be = a.brp[k + 1];
+      for (uint32_t pb = bb + lane16; pb < be; pb += 16) {
+        const uint32_t j = a.bcol[pb];
+        uint32_t h = hash_col(j, SLOTS - 1);
+        uint32_t kk = key[h];
+        while (kk != j && kk != HASH_EMPTY) { h = (h + 1) & (SLOTS - 1); kk = key[h]; }
+        if (kk == j) {
+          const T m = sr.mult(av, use_b ? a.bval[pb] : T());
+          word_combine<T>(sr.add_op(), &acc[h], m);
+          flag[h] = 1;
+        }
+      }
+    }
+    __syncthreads();
+    for (int s = t; s < SLOTS; s += TEAM) {
+      if (key[s] != HASH_EMPTY && flag[s]) { a.cacc[mb + pos[s]] = acc[s]; a.cflag[mb + pos[s]] = 1; }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- (1b) huge mask rows: dense position map in HBM, one persistent block per map ----------------------------------
+template <class T, class SR>
+__global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T> a, const uint32_t* __restrict__ rows, uint32_t nrows_bin,
+                                                            uint32_t* __restrict__ maps, uint32_t ncols, const SR sr) {
+  uint32_t* map = maps + (size_t)blockIdx.x * ncols;       // zero-initialised; entry = mask position + 1
+  const int t = threadIdx.x, lane16 = t & 15, grp = t >> 4; constexpr int NG = 1024 / 16;
+  const bool use_a = sr.uses_a(), use_b = sr.uses_u();
+  for (uint32_t ridx = blockIdx.x; ridx < nrows_bin; ridx += gridDim.x) {
+    const uint32_t i = rows[ridx];
+    const uint32_t mb = a.mrp[i], me = a.mrp[i + 1];
+    for (uint32_t p = mb + t; p < me; p += 1024) if (spgemm_mask_truth(a.mval, a.mcode, p, a.mstruct)) map[a.mcol[p]] = p - mb + 1;
+    __threadfence_block(); __syncthreads();
+    const uint32_t ab = a.arp[i], ae = a.arp[i + 1];
+    for (uint32_t pa = ab + grp; pa < ae; pa += NG) {
+      const uint32_t k = a.acol[pa];
+      const T av = use_a ? a.aval[pa] : T();
+      const uint32_t bb = a.brp[k], be = a.brp[k + 1];
+      for (uint32_t pb = bb + lane16; pb < be; pb += 16) {
+        const uint32_t s = map[a.bcol[pb]];
+        if (s) {
+          const T m = sr.mult(av, use_b ? a.bval[pb] : T());
+          word_combine<T>(sr.add_op(), &a.cacc[mb + s - 1], m);
+          a.cflag[mb + s - 1] = 1;
+        }
+      }
+    }
+    __syncthreads();
+    for (uint32_t p = mb + t; p < me; p += 1024) map[a.mcol[p]] = 0;
+    __threadfence_block(); __syncthreads();
+  }
+}
+
+template <class W> __global__ void k_fill_words(W* p, uint64_t n, W v) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) p[i] = v;
+}
+
+// compaction of the per-mask-entry accumulators into CSR values
+template <class T> __global__ void k_compact_acc(uint32_t nrows, const uint32_t* __restrict__ mrp, const uint32_t* __restrict__ mcol,
+                                                 const typename acc_word<T>::type* __restrict__ cacc, const uint8_t* __restrict__ cflag,
+                                                 const uint32_t* __restrict__ orp, uint32_t* __restrict__ ocol, T* __restrict__ oval) {
+  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nrows; r += (uint64_t)gridDim.x * 256ull) {
+    uint32_t w = orp[r];
+    for (uint32_t p = mrp[r]; p < mrp[r + 1]; p++) if (cflag[p]) { ocol[w] = mcol[p]; oval[w] = from_word<T>(cacc[p]); w++; }
+  }
+}
+
+static __global__ void k_bin_rows(uint32_t nrows, const uint32_t* __restrict__ mrp, const uint32_t* __restrict__ arp, uint32_t* __restrict__ counts,
+                           uint32_t* __restrict__ lists /* 5 x nrows */) {
+  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nrows; r += (uint64_t)gridDim.x * 256ull) {
+    const uint32_t ml = mrp[r + 1] - mrp[r], al = arp[r + 1] - arp[r];
+    if (!ml || !al) continue;
+    const int b = ml <= 32 ? 0 : (ml <= 256 ? 1 : (ml <= 1024 ? 2 : (ml <= 4096 ? 3 : 4)));
+    const uint32_t pos = atomicAdd(&counts[b], 1u);
+    lists[(size_t)b * nrows + pos] = (uint32_t)r;
+  }
+}
+static __global__ void k_count_flags_rows(uint32_t nrows, const uint32_t* __restrict__ rp, const uint8_t* __restrict__ flag, uint32_t* __restrict__ cnt) {
+  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nrows; r += (uint64_t)gridDim.x * 256ull) {
+    uint32_t c = 0; for (uint32_t p = rp[r]; p < rp[r + 1]; p++) c += flag[p] != 0; cnt[r] = c;
+  }
+}
+
+template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDesc& d, DevCSR& out) {
+  typedef typename acc_word<T>::type W;
+  const DevCSR& A = *c.A; const DevCSR& B = *c.B; const DevCSR& M = *c.M;
+  const uint32_t nrows = A.nrows; const uint64_t mnz = M.nnz;
+  out.clear(); out.nrows = nrows; out.ncols = B.ncols;
+  out.rowptr.alloc(((size_t)nrows + 1) * 4);
+  if (!mnz || !A.nnz || !B.nnz) { GRB_HIP(hipMemsetAsync(out.rowptr.p, 0, ((size_t)nrows + 1) * 4, stream())); out.nnz = 0; out.valid = true; return; }
+  auto grid_rows = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 65535u * 16) b = 65535u * 16; return (unsigned)b; };
+  DevBuf cacc(mnz * sizeof(W)), cflag(mnz), counts(32), lists((size_t)5 * nrows * 4 + 4);
+  GRB_HIP(hipMemsetAsync(cflag.p, 0, mnz, stream()));
+  GRB_HIP(hipMemsetAsync(counts.p, 0, 32, stream()));
+  hipLaunchKernelGGL(k_bin_rows, dim3(grid_rows(nrows)), dim3(256), 0, stream(), nrows, M.rowptr.as<uint32_t>(), A.rowptr.as<uint32_t>(), counts.as<uint32_t>(), lists.as<uint32_t>());
+  uint32_t hc[8];
+  GRB_HIP(hipMemcpyAsync(hc, counts.p, 32, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+  with_semiring<T>(d, [&](auto sr) {
+    typedef decltype(sr) SR;
+    SpgemmKArgs<T> a{A.rowptr.as<uint32_t>(), A.col.as<uint32_t>(), (const T*)c.aval, B.rowptr.as<uint32_t>(), B.col.as<uint32_t>(), (const T*)c.bval,
+                     M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(), M.val.p, c.mcode, c.mstruct, cacc.as<W>(), cflag.as<uint8_t>()};
+    const uint32_t* L = lists.as<uint32_t>();
+    auto nblocks = [](uint32_t rows, int teams) { uint64_t b = ((uint64_t)rows + teams - 1) / teams; if (b > 256u * 64) b = 256u * 64; if (b < 1) b = 1; return (unsigned)b; };
+    // the HBM-map kernel accumulates straight into cacc: start those slots at the identity (before any kernel writes results)
+    if (hc[4]) hipLaunchKernelGGL((k_fill_words<W>), dim3(4096), dim3(256), 0, stream(), cacc.as<W>(), mnz, to_word<T>(sr.identity));
+    if (hc[0]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 64, 64>), dim3(nblocks(hc[0], 4)), dim3(256), 0, stream(), a, L, hc[0], sr);
+    if (hc[1]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 512, 256>), dim3(nblocks(hc[1], 1)), dim3(256), 0, stream(), a, L + (size_t)nrows, hc[1], sr);
+    if (hc[2]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 2048, 256>), dim3(nblocks(hc[2], 1)), dim3(256), 0, stream(), a, L + (size_t)2 * nrows, hc[2], sr);
+    if (hc[3]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 8192, 256>), dim3(nblocks(hc[3], 1)), dim3(256), 0, stream(), a, L + (size_t)3 * nrows, hc[3], sr);
+    if (hc[4]) {
+      const unsigned nb = hc[4] < 64 ? hc[4] : 64;
+      DevBuf maps((size_t)nb * B.ncols * 4);
+      GRB_HIP(hipMemsetAsync(maps.p, 0, (size_t)nb * B.ncols * 4, stream()));
+      hipLaunchKernelGGL((k_spgemm_masked_map<T, SR>), dim3(nb), dim3(1024), 0, stream(), a, L + (size_t)4 * nrows, hc[4], maps.as<uint32_t>(), B.ncols, sr);
+      GRB_HIP(hipStreamSynchronize(stream()));
+    }
+    g_last_plan += std::string("k_spgemm_masked<") + (sr.is_static ? "static" : "dynamic") + "> bins " + std::to_string(hc[0]) + "/" + std::to_string(hc[1]) + "/" +
+                   std::to_string(hc[2]) + "/" + std::to_string(hc[3]) + "/" + std::to_string(hc[4]) + " ";
+  });
+  GRB_HIP(hipGetLastError());
+  // compaction
+  DevBuf cnt(((size_t)nrows + 1) * 4);
+  GRB_HIP(hipMemsetAsync(cnt.p, 0, ((size_t)nrows + 1) * 4, stream()));
+  hipLaunchKernelGGL(k_count_flags_rows, dim3(grid_rows(nrows)), dim3(256), 0, stream(), nrows, M.rowptr.as<uint32_t>(), cflag.as<uint8_t>(), cnt.as<uint32_t>());
+  exclusive_scan_u32(cnt.as<uint32_t>(), out.rowptr.as<uint32_t>(), (uint64_t)nrows + 1);
+  uint32_t total = 0;
+  GRB_HIP(hipMemcpyAsync(&total, out.rowptr.as<uint32_t>() + nrows, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+  out.nnz = total; out.col.alloc((size_t)total * 4); out.val.alloc((size_t)total * sizeof(T));
+  hipLaunchKernelGGL((k_compact_acc<T>), dim3(grid_rows(nrows)), dim3(256), 0, stream(), nrows, M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(), cacc.as<W>(),
+                     cflag.as<uint8_t>(), out.rowptr.as<uint32_t>(), out.col.as<uint32_t>(), out.val.as<T>());
+  GRB_HIP(hipGetLastError());
+  GRB_HIP(hipStreamSynchronize(stream()));
+  out.valid = true;
+}
+
+// ---- (2) expand / sort / compress ------------------------------------------------------------------------------------------
+static __global__ void k_row_upper_bound(uint32_t nrows, const uint32_t* __restrict__ arp, const uint32_t* __restrict__ acol, const uint32_t* __restrict__ brp,
+                                  unsigned long long* __restrict__ ub) {
+  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nrows; r += (uint64_t)gridDim.x * 256ull) {
+    unsigned long long s = 0;
+    for (uint32_t p = arp[r]; p < arp[r + 1]; p++) { const uint32_t k = acol[p]; s += brp[k + 1] - brp[k]; }
+    ub[r] = s;
+  }
+}
+
+// one wave per row of the chunk: products of row i are written at off[i - r0] in (k, then B-row) order
+template <class T, class SR>
+__global__ __launch_bounds__(256) void k_expand(uint32_t r0, uint32_t r1, const uint32_t* __restrict__ arp, const uint32_t* __restrict__ acol, const T* __restrict__ aval,
+                                                const uint32_t* __restrict__ brp, const uint32_t* __restrict__ bcol, const T* __restrict__ bval,
+                                                const unsigned long long* __restrict__ off, unsigned long long* __restrict__ keys, T* __restrict__ vals, const SR sr) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = (uint64_t)gridDim.x * 4;
+  const bool use_a = sr.uses_a(), use_b = sr.uses_u();
+  for (uint64_t r = r0 + wave; r < r1; r += nwaves) {
+    unsigned long long o = off[r - r0];
+    for (uint32_t pa = arp[r]; pa < arp[r + 1]; pa++) {
+      const uint32_t k = acol[pa]; const T av = use_a ? aval[pa] : T();
+      const uint32_t bb = brp[k], be = brp[k + 1];
+      for (uint32_t pb = bb + lane; pb < be; pb += 64) {
+        keys[o + (pb - bb)] = ((unsigned long long)(r - r0) << 32) | bcol[pb];
+        vals[o + (pb - bb)] = sr.mult(av, use_b ? bval[pb] : T());
+      }
+      o += be - bb;
+    }
+  }
+}
+static __global__ void k_iota32(uint32_t* p, uint64_t n) { for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) p[i] = (uint32_t)i; }
+static __global__ void k_heads(const unsigned long long* __restrict__ keys, uint64_t n, uint32_t* __restrict__ head) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+// each segment head reduces its run in sorted (== k) order and appends the entry; rows are counted with atomics
+template <class T, class SR>
+__global__ void k_compress(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ perm, const T* __restrict__ vals, uint64_t n,
+                           const uint32_t* __restrict__ head, const uint32_t* __restrict__ pos, uint32_t out_base, uint32_t r0,
+                           uint32_t* __restrict__ ocol, T* __restrict__ oval, uint32_t* __restrict__ rowcount, const SR sr) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {
+    if (!head[i]) continue;
+    const unsigned long long key = keys[i];
+    T acc = vals[perm[i]];
+    for (uint64_t q = i + 1; q < n && keys[q] == key; q++) acc = sr.add(acc, vals[perm[q]]);
+    const uint32_t w = out_base + pos[i];
+    ocol[w] = (uint32_t)(key & 0xFFFFFFFFull); oval[w] = acc;
+    atomicAdd(&rowcount[r0 + (uint32_t)(key >> 32)], 1u);
+  }
+}
+
+template <class T> void run_spgemm_esc(const SpgemmCall& c, const SemiringDesc& d, DevCSR& out) {
+  const DevCSR& A = *c.A; const DevCSR& B = *c.B;
+  const uint32_t nrows = A.nrows;
+  out.clear(); out.nrows = nrows; out.ncols = B.ncols;
+  out.rowptr.alloc(((size_t)nrows + 1) * 4);
+  DevBuf rowcount(((size_t)nrows + 1) * 4);
+  GRB_HIP(hipMemsetAsync(rowcount.p, 0, ((size_t)nrows + 1) * 4, stream()));
+  auto grid_n = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 8192) b = 8192; return (unsigned)b; };
+  // per-row product counts on the host decide the chunking (bounded temporary memory)
+  DevBuf ub((size_t)nrows * 8 + 8);
+  hipLaunchKernelGGL(k_row_upper_bound, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, A.rowptr.as<uint32_t>(), A.col.as<uint32_t>(), B.rowptr.as<uint32_t>(), ub.as<unsigned long long>());
+  std::vector<unsigned long long> hub(nrows);
+  if (nrows) GRB_HIP(hipMemcpyAsync(hub.data(), ub.p, (size_t)nrows * 8, hipMemcpyDeviceToHost, stream()));
+  GRB_HIP(hipStreamSynchronize(stream()));
+  const unsigned long long BUDGET = 1ull << 27;      // products per chunk (~3.5 GB of temporaries at 8-byte values)
+  struct Piece { DevBuf col, val; uint32_t n; };
+  std::vector<Piece> pieces; uint64_t total = 0;
+  with_semiring<T>(d, [&](auto sr) {
+    typedef decltype(sr) SR;
+    uint32_t r0 = 0;
+    while (r0 < nrows) {
+      uint32_t r1 = r0; unsigned long long P = 0;
+      std::vector<unsigned long long> off;
+      while (r1 < nrows && (P == 0 || P + hub[r1] <= BUDGET)) { off.push_back(P); P += hub[r1]; r1++; }
+      if (P > 0xFFFFFFF0ull) fail(GrB_OUT_OF_MEMORY, "mxm: one output row needs more than 2^32 products; not supported by the expand/sort/compress path");
+      if (P) {
+        DevBuf doff(off.size() * 8), keys(P * 8), keys2(P * 8), vals(P * sizeof(T)), perm0(P * 4), perm(P * 4), head(P * 4 + 4), pos(P * 4 + 4);
+        GRB_HIP(hipMemcpyAsync(doff.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, stream()));
+        uint64_t nb = ((uint64_t)(r1 - r0) + 3) / 4; if (nb > 65535u * 4) nb = 65535u * 4; if (nb < 1) nb = 1;
+        hipLaunchKernelGGL((k_expand<T, SR>), dim3((unsigned)nb), dim3(256), 0, stream(), r0, r1, A.rowptr.as<uint32_t>(), A.col.as<uint32_t>(), (const T*)c.aval,
+                           B.rowptr.as<uint32_t>(), B.col.as<uint32_t>(), (const T*)c.bval, doff.as<unsigned long long>(), keys.as<unsigned long long>(), vals.as<T>(), sr);
+        hipLaunchKernelGGL(k_iota32, dim3(grid_n(P)), dim3(256), 0, stream(), perm0.as<uint32_t>(), P);
+        int rbits = 1; while ((1ull << rbits) < (unsigned long long)(r1 - r0)) rbits++;
+        sort_pairs_u64((const uint64_t*)keys.p, (uint64_t*)keys2.p, perm0.as<uint32_t>(), perm.as<uint32_t>(), P, 32 + rbits);
+        hipLaunchKernelGGL(k_heads, dim3(grid_n(P)), dim3(256), 0, stream(), keys2.as<unsigned long long>(), P, head.as<uint32_t>());
+        exclusive_scan_u32(head.as<uint32_t>(), pos.as<uint32_t>(), P);
+        uint32_t lastpos = 0, lasthead = 0;
+        GRB_HIP(hipMemcpyAsync(&lastpos, pos.as<uint32_t>() + (P - 1), 4, hipMemcpyDeviceToHost, stream()));
+        GRB_HIP(hipMemcpyAsync(&lasthead, head.as<uint32_t>() + (P - 1), 4, hipMemcpyDeviceToHost, stream()));
+        GRB_HIP(hipStreamSynchronize(stream()));
+        const uint32_t uniq = lastpos + lasthead;
+        Piece pc; pc.n = uniq; pc.col.alloc((size_t)uniq * 4 + 4); pc.val.alloc((size_t)uniq * sizeof(T) + 8);
+        hipLaunchKernelGGL((k_compress<T, SR>), dim3(grid_n(P)), dim3(256), 0, stream(), keys2.as<unsigned long long>(), perm.as<uint32_t>(), vals.as<T>(), P,
+                           head.as<uint32_t>(), pos.as<uint32_t>(), 0u, r0, (uint32_t*)pc.col.p, (T*)pc.val.p, rowcount.as<uint32_t>(), sr);
+        GRB_HIP(hipStreamSynchronize(stream()));
+        total += uniq; pieces.push_back(std::move(pc));
+      }
+      r0 = r1;
+    }
+    g_last_plan += std::string("spgemm_esc<") + (sr.is_static ? "static" : "dynamic") + "> chunks " + std::to_string(pieces.size()) + " ";
+  });
+  GRB_HIP(hipGetLastError());
+  if (total > 0xFFFFFFF0ull) fail(GrB_INSUFFICIENT_SPACE, "mxm: result has more than 2^32 entries");
+  exclusive_scan_u32(rowcount.as<uint32_t>(), out.rowptr.as<uint32_t>(), (uint64_t)nrows + 1);
+  out.nnz = total; out.col.alloc(total * 4 + 4); out.val.alloc(total * sizeof(T) + 8);
+  uint64_t w = 0;
+  for (auto& pc : pieces) {
+    if (pc.n) {
+      GRB_HIP(hipMemcpyAsync(out.col.as<uint32_t>() + w, pc.col.p, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, stream()));
+      GRB_HIP(hipMemcpyAsync(out.val.as<T>() + w, pc.val.p, (size_t)pc.n * sizeof(T), hipMemcpyDeviceToDevice, stream()));
+    }
+    w += pc.n;
+  }
+  GRB_HIP(hipStreamSynchronize(stream()));
+  out.valid = true;
+}
+
+}  // namespace grb

@@ -61,4 +61,7 @@ def assert_same(typ, got_idx, got_val, exp_idx, exp_val, rtol=0.0, what=""):
         assert np.allclose(got_val, exp_val, rtol=rtol, atol=0.0, equal_nan=True), f"values differ {what}"
     else:
         eq = np.array_equal(got_val, exp_val, equal_nan=True) if got_val.dtype.kind == 'f' else np.array_equal(got_val, exp_val)
+        if not eq:
+            bad = np.flatnonzero(~((got_val == exp_val) | ((got_val != got_val) & (exp_val != exp_val))))
+            what = f"{what} first diffs at {bad[:6].tolist()}: got {got_val[bad[:6]]} expected {exp_val[bad[:6]]}"
         assert eq, f"values differ (bit-exact required) {what}: {got_val[:8]} vs {exp_val[:8]}"

@@ -81,7 +81,9 @@ def run_case(rng, typ, sr_name, nrows, ncols, dens, udens, *, vxm=False, tran=Fa
                     mask=O.col_vector(mtyp, n_out, mi, mx) if mask is not None else None, tran_a=tran, **kw)
         exp_idx = exp.I
     gi, gx = vector_pairs(gw)
-    assert_same(out_typ, gi, gx, exp_idx, exp.X, what=f"{typ}.{sr_name} vxm={vxm} tran={tran} mask={mask} accum={accum} plan={gb.last_kernel_plan()}")
+    # quotients are not on the 1/8 grid: the order of summation matters in the last bit -> 1e-6 relative
+    rtol = 1e-6 if ("DIV" in sr_name and out_typ.startswith("FP")) else 0.0
+    assert_same(out_typ, gi, gx, exp_idx, exp.X, rtol=rtol, what=f"{typ}.{sr_name} vxm={vxm} tran={tran} mask={mask} accum={accum} plan={gb.last_kernel_plan()}")
 
 
 ALL = ["BOOL", "INT8", "UINT8", "INT16", "UINT16", "INT32", "UINT32", "INT64", "UINT64", "FP32", "FP64"]
