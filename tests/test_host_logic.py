@@ -1,0 +1,132 @@
+"""Host-side logic of the backend that needs no GPU: the object model behind the C ABI (build / setElement /
+extract / remove / resize / dup on the host mirror), descriptors, the type registry and promotion table,
+context managers, the R-MAT generator (numpy == torch) and the row-block partitioner."""
+import numpy as np
+import pytest
+
+from pygraphblas_amd_rmat import rmat
+
+
+def test_matrix_container_roundtrip(gb):
+    from pygraphblas_amd import Matrix, INT64, FP64, NoValue, InvalidIndex, OutputNotEmpty
+    m = Matrix.from_lists([2, 0, 1], [0, 1, 2], [3, 1, 2])
+    assert (m.nrows, m.ncols, m.nvals) == (3, 3, 3) and m.type is INT64
+    assert m.to_lists() == [[0, 1, 2], [1, 2, 0], [1, 2, 3]]            # row-major order
+    assert m[0, 1] == 1 and m.get(0, 0) is None
+    with pytest.raises(NoValue):
+        m[0, 0]
+    m[0, 0] = 7; m[0, 0] = 9                                             # last write wins
+    assert m[0, 0] == 9 and m.nvals == 4
+    del m[0, 0]; del m[1, 2]
+    assert m.to_lists() == [[0, 2], [1, 0], [1, 3]]
+    with pytest.raises(InvalidIndex):
+        m[5, 0] = 1
+    d = m.dup(); d[1, 1] = 5
+    assert m.nvals == 2 and d.nvals == 3
+    d.clear(); assert d.nvals == 0
+    f = Matrix.from_lists([0], [0], [1.5]); assert f.type is FP64 and f[0, 0] == 1.5
+    with pytest.raises(OutputNotEmpty):
+        gb.lib.GrB_Matrix_build_INT64.restype = int
+        from pygraphblas_amd.base import check
+        import ctypes as C
+        I = np.array([0], np.uint64); X = np.array([1], np.int64)
+        check(gb.lib.GrB_Matrix_build_INT64(m._h, I.ctypes.data_as(C.c_void_p), I.ctypes.data_as(C.c_void_p), X.ctypes.data_as(C.c_void_p), C.c_uint64(1), None), m)
+
+
+def test_build_combines_duplicates_with_dup_op(gb):
+    from pygraphblas_amd import Matrix, Vector, INT64, InvalidValue
+    I = np.array([0, 0, 1, 0], np.uint64); J = np.array([1, 1, 2, 1], np.uint64); X = np.array([5, 7, 1, 2], np.int64)
+    assert Matrix.from_arrays(I, J, X, 2, 3, INT64, dup=INT64.PLUS).to_lists() == [[0, 1], [1, 2], [14, 1]]
+    assert Matrix.from_arrays(I, J, X, 2, 3, INT64, dup=INT64.MIN).to_lists() == [[0, 1], [1, 2], [2, 1]]
+    assert Matrix.from_arrays(I, J, X, 2, 3, INT64, dup=INT64.SECOND).to_lists() == [[0, 1], [1, 2], [2, 1]]
+    with pytest.raises(InvalidValue):
+        Matrix.from_arrays(I, J, X, 2, 3, INT64)
+    assert Vector.from_arrays(I, X, 4, INT64, dup=INT64.PLUS).to_lists() == [[0, 1], [14, 1]]
+
+
+def test_vector_container_and_casts(gb):
+    from pygraphblas_amd import Vector, UINT8, BOOL, FP32, INT8
+    v = Vector.from_lists([3, 1], [2, 4], size=5)
+    assert v.size == 5 and v.nvals == 2 and v.to_lists() == [[1, 3], [4, 2]]
+    v[4] = 9; del v[1]
+    assert list(v) == [(3, 2), (4, 9)] and 3 in v and 1 not in v
+    u = Vector.sparse(UINT8, 4); u[0] = 300 % 256; assert u[0] == 44
+    b = Vector.sparse(BOOL, 4); b[2] = True; assert b.to_lists() == [[2], [True]]
+    # extractElement typecasts like C with float->int saturation
+    import ctypes as C
+    f = Vector.sparse(FP32, 2); f[0] = 1e10
+    out = C.c_int8(0); gb.lib.GrB_Vector_extractElement_INT8(C.byref(out), f._h, C.c_uint64(0)); assert out.value == 127
+    assert Vector.sparse(INT8).size == gb.GxB_INDEX_MAX                      # default dimension (pygraphblas/__init__.py:366-367)
+
+
+def test_resize_and_huge_dimensions(gb):
+    from pygraphblas_amd import Matrix, INT64
+    m = Matrix.sparse(INT64)                                                  # 2^60 x 2^60 host-only hypersparse container
+    m[2 ** 40, 5] = 1; m[3, 2 ** 50] = 2
+    assert m.nvals == 2 and m[2 ** 40, 5] == 1
+    import ctypes as C
+    from pygraphblas_amd.base import check
+    check(gb.lib.GrB_Matrix_resize(m._h, C.c_uint64(10), C.c_uint64(10)), m)
+    assert (m.nrows, m.ncols, m.nvals) == (10, 10, 0)
+
+
+def test_descriptors(gb):
+    from pygraphblas_amd import descriptor as D
+    assert D.T1 in D.CT1 and D.C in D.CT1 and D.T0 not in D.CT1 and D.T0 not in D.RC
+    assert D.CT1 == (D.C & D.T1) and D.RSCT0T1 == (D.R & D.S & D.C & D.T0 & D.T1)
+    assert D.T1 != D.T0 and repr(D.RC) == "<Descriptor RC>"
+    with D.T0:
+        assert D.current_desc.get() is D.T0
+    assert D.current_desc.get(None) is None
+
+
+def test_type_registry_and_promotion(gb):
+    from pygraphblas_amd import BOOL, INT8, UINT8, INT16, UINT16, INT32, UINT32, INT64, UINT64, FP32, FP64, promote
+    assert INT64.PLUS_TIMES is INT64.plus_times and INT64.PLUS_TIMES.ztype is INT64 and BOOL.LOR_LAND.ztype is BOOL
+    assert FP32.PLUS_SECOND.ztype is FP32 and UINT8.MIN_PLUS.ztype is UINT8
+    assert INT64._default_semiring() is INT64.PLUS_TIMES and BOOL._default_semiring() is BOOL.LOR_LAND
+    order = [FP64, FP32, INT64, UINT64, INT32, UINT32, INT16, UINT16, INT8, UINT8]   # pygraphblas/types.py:465-482
+    for i, a in enumerate(order):
+        for j, b in enumerate(order):
+            assert promote(a, b) is order[min(i, j)]
+        assert promote(a, BOOL) is a and promote(BOOL, a) is a
+    assert promote(BOOL, BOOL) is BOOL
+
+
+def test_context_managers(gb):
+    from pygraphblas_amd import INT64, Accum, types
+    with INT64.MIN_PLUS:
+        assert types.current_semiring.get() is INT64.MIN_PLUS
+    assert types.current_semiring.get(None) is None
+    with Accum(INT64.MIN):
+        assert types.current_accum.get() is INT64.MIN
+    assert types.current_accum.get(None) is None
+
+
+def test_rmat_numpy_equals_torch_and_is_sliceable():
+    import torch
+    s, d = rmat.edges_numpy(11, seed=7)
+    s2, d2 = rmat.edges_torch(11, "cpu", seed=7)
+    assert np.array_equal(s.astype(np.int64), s2.numpy()) and np.array_equal(d.astype(np.int64), d2.numpy())
+    s3, d3 = rmat.edges_numpy(11, seed=7, first=1000, count=500)
+    assert np.array_equal(s3, s[1000:1500]) and np.array_equal(d3, d[1000:1500])
+    for kw in (dict(), dict(symmetric=True, drop_self_loops=True), dict(symmetric=True, drop_self_loops=True, lower=True), dict(row_range=(256, 1024))):
+        rp, c = rmat.csr_numpy(11, **kw); rp2, c2 = rmat.csr_torch(11, "cpu", **kw)
+        assert np.array_equal(rp, rp2.numpy().view(np.uint32)) and np.array_equal(c, c2.numpy().view(np.uint32))
+        rows = np.repeat(np.arange(len(rp) - 1), np.diff(rp.astype(np.int64)))
+        assert np.all(np.diff(rows * (1 << 32) + c.astype(np.int64)) > 0)       # sorted, no duplicates
+    assert np.array_equal(rmat.values_numpy(100), rmat.values_torch(100, "cpu").numpy())
+    # skew sanity: (a+b)=0.76 of the edges land in the top half of the rows
+    assert abs((s < 1024).mean() - 0.76) < 0.01
+
+
+def test_balanced_row_blocks(gb):
+    from pygraphblas_amd.dist import balanced_row_blocks, rmat_expected_row_prefix
+    rp, _ = rmat.csr_numpy(12)
+    b = balanced_row_blocks(rp.astype(np.int64), 8)
+    assert b[0] == 0 and b[-1] == 4096 and all(x <= y for x, y in zip(b, b[1:]))
+    per = np.diff(rp.astype(np.int64)[b]); assert per.max() < 1.35 * per.mean()
+    # the analytic prefix every rank can compute without the graph gives nearly the same split
+    b2 = balanced_row_blocks(rmat_expected_row_prefix(12), 8)
+    per2 = np.diff(rp.astype(np.int64)[b2]); assert per2.max() < 1.6 * per2.mean()
+    assert balanced_row_blocks(rp.astype(np.int64), 1) == [0, 4096]
