@@ -14,7 +14,8 @@ GrB_Info GrB_Vector_free(GrB_Vector* v);
 }
 
 namespace grb {
-extern std::string g_last_plan;  // human-readable list of kernels launched by the last hot-path call
+extern std::string g_last_plan;
+extern thread_local std::string g_last_error;   // most recent failure message of this thread (for *_error on another operand)  // human-readable list of kernels launched by the last hot-path call
 
 // Run `body`; translate C++ failures to GrB_Info and remember the message on `obj` (if it has .err).
 template <class Obj, class F> inline GrB_Info guarded(Obj* obj, F&& body) {
@@ -23,6 +24,7 @@ template <class Obj, class F> inline GrB_Info guarded(Obj* obj, F&& body) {
     return GrB_SUCCESS;
   } catch (const GrbError& e) {
     if (obj) obj->err = e.msg;
+    g_last_error = e.msg;
     return e.info;
   } catch (const std::bad_alloc&) {
     if (obj) obj->err = "host allocation failed";

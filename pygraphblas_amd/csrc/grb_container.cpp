@@ -247,7 +247,8 @@ GrB_Info GrB_Matrix_wait(GrB_Matrix* A) {
   if (!A) return GrB_NULL_POINTER; CHECK_MAT(*A);
   return guarded(*A, [&] { if ((*A)->host_valid) mat_host_assemble(*A); if (device_ok()) GRB_HIP(hipStreamSynchronize(stream())); });
 }
-GrB_Info GrB_Matrix_error(const char** s, const GrB_Matrix A) { if (!s) return GrB_NULL_POINTER; CHECK_MAT(A); *s = A->err.c_str(); return GrB_SUCCESS; }
+// the reference asks `self` for the message even when the failing object was the output (pygraphblas/matrix.py:43-51)
+GrB_Info GrB_Matrix_error(const char** s, const GrB_Matrix A) { if (!s) return GrB_NULL_POINTER; CHECK_MAT(A); *s = A->err.empty() ? g_last_error.c_str() : A->err.c_str(); return GrB_SUCCESS; }
 GrB_Info GxB_Matrix_type(GrB_Type* t, const GrB_Matrix A) { if (!t) return GrB_NULL_POINTER; CHECK_MAT(A); *t = A->type; return GrB_SUCCESS; }
 GrB_Info GrB_Matrix_resize(GrB_Matrix A, GrB_Index nr, GrB_Index nc) {
   CHECK_MAT(A); if (nr > GXB_INDEX_MAX || nc > GXB_INDEX_MAX) return GrB_INVALID_VALUE;
@@ -371,7 +372,7 @@ GrB_Info GrB_Vector_wait(GrB_Vector* v) {
   if (!v) return GrB_NULL_POINTER; CHECK_VEC(*v);
   return guarded(*v, [&] { if ((*v)->host_valid) vec_host_assemble(*v); if (device_ok()) GRB_HIP(hipStreamSynchronize(stream())); });
 }
-GrB_Info GrB_Vector_error(const char** s, const GrB_Vector v) { if (!s) return GrB_NULL_POINTER; CHECK_VEC(v); *s = v->err.c_str(); return GrB_SUCCESS; }
+GrB_Info GrB_Vector_error(const char** s, const GrB_Vector v) { if (!s) return GrB_NULL_POINTER; CHECK_VEC(v); *s = v->err.empty() ? g_last_error.c_str() : v->err.c_str(); return GrB_SUCCESS; }
 GrB_Info GxB_Vector_type(GrB_Type* t, const GrB_Vector v) { if (!t) return GrB_NULL_POINTER; CHECK_VEC(v); *t = v->type; return GrB_SUCCESS; }
 GrB_Info GrB_Vector_resize(GrB_Vector v, GrB_Index n) {
   CHECK_VEC(v); if (n > GXB_INDEX_MAX) return GrB_INVALID_VALUE;

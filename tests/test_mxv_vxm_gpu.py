@@ -24,7 +24,7 @@ SEMIRINGS = {
     "BOOL": ["LOR_LAND", "ANY_PAIR", "LXOR_LAND", "LAND_LOR", "EQ_LOR"],
     "INT": ["PLUS_TIMES", "MIN_PLUS", "PLUS_PAIR", "PLUS_SECOND", "PLUS_FIRST", "MAX_MIN", "MIN_FIRST", "PLUS_PLUS", "TIMES_PLUS",
             "PLUS_LAND", "MAX_MINUS", "MIN_RDIV", "PLUS_ISGT", "ANY_PAIR"],
-    "FP": ["PLUS_TIMES", "MIN_PLUS", "PLUS_PAIR", "PLUS_SECOND", "PLUS_FIRST", "MAX_TIMES", "MIN_MAX", "PLUS_MINUS", "PLUS_DIV"],
+    "FP": ["PLUS_TIMES", "MIN_PLUS", "PLUS_PAIR", "PLUS_SECOND", "PLUS_FIRST", "MAX_TIMES", "MIN_MAX", "PLUS_MINUS", "MIN_DIV"],
 }
 
 

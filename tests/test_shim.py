@@ -1,0 +1,68 @@
+"""The `suitesparse_graphblas`-compatible CFFI shim (shim/): the drop-in boundary the unmodified reference binds.
+
+Python 3.10 here has no cffi, so these tests drive the image's /opt/conda/bin/python3.9 in a subprocess and skip
+when it is missing.  With /root/reference present (build container only) the *unmodified* reference package is
+imported on top of the shim and its own GPU-free tests are run."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PY39 = "/opt/conda/bin/python3.9"
+REF = "/root/reference"
+
+
+def have_py39():
+    if not os.path.exists(PY39):
+        return False
+    return subprocess.run([PY39, "-c", "import cffi"], capture_output=True).returncode == 0
+
+
+needs39 = pytest.mark.skipif(not have_py39(), reason="no /opt/conda/bin/python3.9 with cffi")
+
+
+@needs39
+def test_cffi_boundary_without_gpu(gb):
+    if gb.device_info()["ok"]:
+        pytest.skip("a HIP device is present")
+    r = subprocess.run([PY39, os.path.join(ROOT, "tests", "shim_cffi_smoke.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK cpu" in r.stdout, r.stdout + r.stderr
+
+
+@needs39
+@pytest.mark.gpu
+def test_cffi_boundary_on_gpu(gpu):
+    r = subprocess.run([PY39, os.path.join(ROOT, "tests", "shim_cffi_smoke.py"), "--gpu"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK gpu" in r.stdout, r.stdout + r.stderr
+
+
+@needs39
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_unmodified_reference_imports_and_runs_its_gpu_free_tests(gb):
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "shim") + ":" + REF)
+    code = ("import pygraphblas as p; from pygraphblas import *; "
+            "assert INT64.PLUS_TIMES.ztype is INT64 and BOOL.LOR_LAND.ztype is BOOL and FP32.PLUS_SECOND is not None; "
+            "m = Matrix.from_lists([0,1,2],[1,2,0],[1,2,3]); assert m.nvals == 3 and m[0,1] == 1 and m.type is INT64; "
+            "v = Vector.from_lists([0,1,2],[2,3,4]); assert list(v) == [(0,2),(1,3),(2,4)]; "
+            "assert descriptor.T1 in descriptor.CT1; print('OK import', len([n for n in dir(p.lib) if 'SEMIRING' in n or n.startswith('GxB_PLUS_')]))")
+    r = subprocess.run([PY39, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")
+    assert r.returncode == 0 and "OK import" in r.stdout, r.stdout + r.stderr
+    # the reference's own tests that need no arithmetic pass unmodified
+    # selected by name (-k): everything in these files that involves no arithmetic
+    names = ("test_type_lookup_name test_gb_from_type test_promotion test_options_set test_descriptor test_scalar_create_from_type "
+             "test_scalar_from_value test_scalar_dup test_scalar_clear test_scalar_wait test_matrix_init_without_type "
+             "test_matrix_get_set_element test_clear test_resize test_matrix_create_dup test_matrix_to_from_lists test_matrix_gb_type "
+             "test_matrix_random test_iters test_identity test_delitem test_vector_init_without_type test_vector_create_sparse "
+             "test_vector_gb_type test_vector_create_dup test_vector_from_list test_vector_to_lists test_contains").split()
+    files = [f"{REF}/tests/{f}" for f in ("test_types.py", "test_base.py", "test_descriptor.py", "test_scalar.py", "test_matrix.py", "test_vector.py")]
+    r = subprocess.run([PY39, "-m", "pytest", "-c", "/dev/null", "--rootdir", "/tmp", "-p", "no:cacheprovider", "-q", "-k", " or ".join(names), *files],
+                       capture_output=True, text=True, timeout=600, env=env, cwd="/tmp")
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr
+    import re
+    m = re.search(r"(\d+) passed", tail)
+    assert m and int(m.group(1)) >= 28, r.stdout[-3000:]
+    # -k matches substrings, so a few arithmetic tests ride along: without a GPU they must fail loudly (Panic), nothing else
+    other = [l for l in r.stdout.splitlines() if l.startswith("FAILED") and "Panic" not in l]
+    assert not other, other

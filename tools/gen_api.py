@@ -199,7 +199,7 @@ H.append("""/* grb_mi355x.h — C ABI of libgrb_mi355x.so, an MI355X (gfx950) Gr
  *   GrB_vxm   <- lib.GrB_vxm   called at pygraphblas/vector.py:960-970     (Vector.vxm)
  *   GrB_Matrix_reduce_<T> <- pygraphblas/matrix.py:1799-1803 (Matrix.reduce_int et al.)
  *   GrB_Vector_reduce_<T> <- pygraphblas/vector.py:1132-1202
- *   object model (new/free/build/setElement/extract*/nvals/...) <- the `lib.` calls listed by
+ *   object model (new, free, build, setElement, extractElement, extractTuples, nvals, ...) <- the `lib.` calls listed by
  *       grep -oh "lib\\.G[rx]B_[A-Za-z0-9_]*" pygraphblas/*.py  (SURVEY.md §8b)
  *   error convention: positive GrB_Info codes 0..13 as mapped at pygraphblas/base.py:189-203.
  * Signatures are GraphBLAS C API 1.3 with SuiteSparse v5.1-era GxB_ extensions.
@@ -207,6 +207,14 @@ H.append("""/* grb_mi355x.h — C ABI of libgrb_mi355x.so, an MI355X (gfx950) Gr
  */
 typedef uint64_t GrB_Index;
 typedef int GrB_Info;
+typedef int GrB_Mode;
+typedef int GrB_Desc_Field;
+typedef int GrB_Desc_Value;
+typedef int GxB_Option_Field;
+typedef int GxB_Format_Value;
+typedef void (*GxB_unary_function)(void *, const void *);
+typedef void (*GxB_binary_function)(void *, const void *, const void *);
+typedef bool (*GxB_select_function)(GrB_Index i, GrB_Index j, const void *x, const void *thunk);
 typedef struct GrB_Type_opaque *GrB_Type;
 typedef struct GrB_UnaryOp_opaque *GrB_UnaryOp;
 typedef struct GrB_BinaryOp_opaque *GrB_BinaryOp;
@@ -481,6 +489,33 @@ GrB_Info GxB_Matrix_apply_BinaryOp2nd_{t}(GrB_Matrix C, const GrB_Matrix Mask, c
 GrB_Info GxB_Scalar_setElement_{t}(GxB_Scalar s, {c} x);
 GrB_Info GxB_Scalar_extractElement_{t}({c} *x, const GxB_Scalar s);
 GrB_Info GrB_Monoid_new_{t}(GrB_Monoid *monoid, GrB_BinaryOp op, {c} identity);
+""")
+# complex types: the handles and the 17 typed entry points exist so that the reference's type registry imports
+# (pygraphblas/types.py:87-110 resolves them for all 13 types); every one returns GrB_DOMAIN_MISMATCH (DESIGN.md §8)
+H.append("""
+/* ---- complex types are declared for registry compatibility only; all return GrB_DOMAIN_MISMATCH ---- */
+typedef struct { float re; float im; } GxB_FC32_t;
+typedef struct { double re; double im; } GxB_FC64_t;
+""")
+for t, c in (("FC32", "GxB_FC32_t"), ("FC64", "GxB_FC64_t")):
+    H.append(f"""
+GrB_Info GxB_Matrix_setElement_{t}(GrB_Matrix C, {c} x, GrB_Index i, GrB_Index j);
+GrB_Info GxB_Matrix_extractElement_{t}({c} *x, const GrB_Matrix A, GrB_Index i, GrB_Index j);
+GrB_Info GxB_Matrix_extractTuples_{t}(GrB_Index *I, GrB_Index *J, {c} *X, GrB_Index *nvals, const GrB_Matrix A);
+GrB_Info GxB_Matrix_reduce_{t}({c} *c, const GrB_BinaryOp accum, const GrB_Monoid monoid, const GrB_Matrix A, const GrB_Descriptor desc);
+GrB_Info GxB_Vector_setElement_{t}(GrB_Vector w, {c} x, GrB_Index i);
+GrB_Info GxB_Vector_extractElement_{t}({c} *x, const GrB_Vector v, GrB_Index i);
+GrB_Info GxB_Vector_extractTuples_{t}(GrB_Index *I, {c} *X, GrB_Index *nvals, const GrB_Vector v);
+GrB_Info GxB_Vector_reduce_{t}({c} *c, const GrB_BinaryOp accum, const GrB_Monoid monoid, const GrB_Vector u, const GrB_Descriptor desc);
+GrB_Info GxB_Vector_assign_{t}(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, {c} x, const GrB_Index *I, GrB_Index ni, const GrB_Descriptor desc);
+GrB_Info GxB_Matrix_assign_{t}(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, {c} x, const GrB_Index *I, GrB_Index ni, const GrB_Index *J, GrB_Index nj, const GrB_Descriptor desc);
+GrB_Info GxB_Vector_apply_BinaryOp1st_{t}(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, {c} x, const GrB_Vector u, const GrB_Descriptor desc);
+GrB_Info GxB_Vector_apply_BinaryOp2nd_{t}(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Vector u, {c} y, const GrB_Descriptor desc);
+GrB_Info GxB_Matrix_apply_BinaryOp1st_{t}(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, {c} x, const GrB_Matrix A, const GrB_Descriptor desc);
+GrB_Info GxB_Matrix_apply_BinaryOp2nd_{t}(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Matrix A, {c} y, const GrB_Descriptor desc);
+GrB_Info GxB_Scalar_setElement_{t}(GxB_Scalar s, {c} x);
+GrB_Info GxB_Scalar_extractElement_{t}({c} *x, const GxB_Scalar s);
+GrB_Info GxB_Monoid_new_{t}(GrB_Monoid *monoid, GrB_BinaryOp op, {c} identity);
 """)
 with open(os.path.join(ROOT, "include/grb_mi355x.h"), "w") as f:
     f.write("".join(H))
