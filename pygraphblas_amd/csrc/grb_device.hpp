@@ -29,6 +29,18 @@ template <class T> __device__ __forceinline__ T shfl_down_t(T v, int d) {
   }
 }
 
+template <class T> __device__ __forceinline__ T shfl_t(T v, int src) {
+  if constexpr (sizeof(T) == 8) {
+    union { T t; int i[2]; } u; u.t = v;
+    u.i[0] = __shfl(u.i[0], src, 64); u.i[1] = __shfl(u.i[1], src, 64); return u.t;
+  } else if constexpr (sizeof(T) == 4) {
+    union { T t; int i; } u; u.t = v; u.i = __shfl(u.i, src, 64); return u.t;
+  } else {
+    union { T t; uint16_t s; } u; u.s = 0; u.t = v;
+    int x = __shfl((int)u.s, src, 64); u.s = (uint16_t)x; return u.t;
+  }
+}
+
 __device__ __forceinline__ unsigned long long wave_reduce_add_u64(unsigned long long v) {
   return __builtin_amdgcn_wave_reduce_add_u64(v, 0);
 }

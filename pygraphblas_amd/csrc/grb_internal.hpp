@@ -68,6 +68,7 @@ void* dev_alloc(size_t bytes);    // pooled hipMalloc; throws GrbError(OUT_OF_ME
 void dev_free(void* p);
 void dev_pool_release();          // return cached blocks to the driver
 size_t dev_bytes_in_use();
+int device_cus();                 // compute units of the device (256 on MI355X)
 
 struct GrbError { int info; std::string msg; };
 [[noreturn]] void fail(int info, const std::string& msg);
@@ -96,8 +97,11 @@ struct DevCSR {
   // entries, long rows split into parts.  Built on first mxv, cached with the matrix.
   DevBuf plan_blocks; uint32_t plan_nblocks = 0; DevBuf plan_aux; uint32_t plan_nlong = 0;
   bool has_plan = false;
+  // kernel-W plan (grb_spmv_wavepipe.hpp): per-task first row, hot-column list, remapped column array, per-wave carries
+  DevBuf wp_rs, wp_hot, wp_pcol, wp_carry; uint32_t wp_nhot = 0, wp_ntasks = 0; int wp_tsize = 0;
   bool valid = false;
   void clear() { rowptr.reset(); col.reset(); val.reset(); plan_blocks.reset(); plan_aux.reset();
+                 wp_rs.reset(); wp_hot.reset(); wp_pcol.reset(); wp_carry.reset(); wp_nhot = wp_ntasks = 0; wp_tsize = 0;
                  nnz = 0; has_plan = false; valid = false; plan_nblocks = plan_nlong = 0; }
 };
 

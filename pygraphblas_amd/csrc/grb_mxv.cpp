@@ -26,7 +26,7 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   SemiringDesc sd = make_semiring_desc(semiring, /*swap_mult_args=*/is_vxm);
   const char* env = getenv("GRB_MI355X_SPMV");
   int method = g_force_method;
-  if (env) method = !strcmp(env, "adaptive") ? SPMV_ADAPTIVE : !strcmp(env, "rowgroup") ? SPMV_ROWGROUP : !strcmp(env, "push") ? SPMV_PUSH : SPMV_AUTO;
+  if (env) method = !strcmp(env, "adaptive") ? SPMV_ADAPTIVE : !strcmp(env, "rowgroup") ? SPMV_ROWGROUP : !strcmp(env, "push") ? SPMV_PUSH : !strcmp(env, "wavepipe") ? SPMV_WAVEPIPE : SPMV_AUTO;
   g_last_plan.clear();
 
   DevBuf allow_buf; bool nothing = false;
@@ -47,7 +47,7 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   const double avgdeg = (double)A->csr.nnz / (double)(mc ? mc : 1);   // mean length of the rows a push would walk
   bool push = spmspv_push_supported(sd) && !u_full && (double)u_nvals * (avgdeg + 1) * 8 < (double)A->csr.nnz + 1;
   if (method == SPMV_PUSH) push = spmspv_push_supported(sd);
-  else if (method == SPMV_ADAPTIVE || method == SPMV_ROWGROUP) push = false;
+  else if (method == SPMV_ADAPTIVE || method == SPMV_ROWGROUP || method == SPMV_WAVEPIPE) push = false;
 
   const size_t zs = type_size(sd.zcode);
   DevBuf tval(mr * zs + 1), tpres(mr + 1), ucast, acast;

@@ -21,6 +21,7 @@ static bool g_inited = false, g_device_ok = false;
 static std::string g_device_err = "GrB_init has not been called";
 static hipStream_t g_stream = 0;
 static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+static int g_cus = 0;
 static int g_nthreads = 1; static double g_chunk = 65536; static int g_burble = 0;
 static double g_hyper_switch = 0.0625; static int g_format = 0;
 static double g_bitmap_switch[8] = {0.04, 0.05, 0.06, 0.08, 0.10, 0.20, 0.30, 0.40};
@@ -85,6 +86,7 @@ void dev_pool_release() {
   g_free.clear(); g_cached = 0;
 }
 size_t dev_bytes_in_use() { return g_in_use; }
+int device_cus() { return g_cus; }
 
 bool check_obj(const void* p) { return p && *(const uint64_t*)p == GRB_MAGIC; }
 GrB_Type type_by_code(int code) {
@@ -127,6 +129,7 @@ static GrB_Info do_init() {
     e = hipSetDevice(dev);
     if (e == hipSuccess) e = hipEventCreate(&g_ev0);
     if (e == hipSuccess) e = hipEventCreate(&g_ev1);
+    if (e == hipSuccess) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) g_cus = pr.multiProcessorCount; }
     g_device_ok = (e == hipSuccess);
     if (!g_device_ok) { g_device_err = hipGetErrorString(e); (void)hipGetLastError(); }
     else g_device_err.clear();

@@ -37,6 +37,10 @@ template <int MODE, class T> __device__ __forceinline__ T ld(const T* p) {
   }
 }
 
+}  // namespace grb
+#include "grb_spmv_wavepipe.hpp"
+namespace grb {
+
 template <class T> struct SpmvKArgs {
   const uint32_t* rowptr; const uint32_t* col; const T* aval;
   const T* uval; const uint8_t* upres; const uint8_t* allow;
@@ -299,6 +303,14 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
 #undef GRB_LAUNCH_B
       g_last_plan += std::string("k_spmv_rowgroup<G=") + std::to_string(G) + (sr.is_static ? ",static>" : ",dynamic>") + " ";
       return;
+    }
+    // kernel W: full operand, no mask, large matrix
+    if constexpr (sizeof(T) >= 4) {
+      const bool want = c.method == SPMV_WAVEPIPE || (c.method == SPMV_AUTO && M.nnz >= (1u << 20));
+      if (want && full && !c.allow && M.ncols < 0x7FFFFFFFu && M.nnz >= (uint64_t)WP_ENT && device_cus() > 0) {
+        run_wavepipe<T>(c, d, device_cus());
+        return;
+      }
     }
     spmv_build_plan(M);
     a.blocks = M.plan_blocks.as<SpmvBlock>();

@@ -18,6 +18,8 @@ dev = torch.device("cuda", 0)
 n = 1 << args.scale
 rowptr, col = rmat.csr_torch(args.scale, dev, seed=42)
 nnz = col.numel()
+if args.relabel.startswith("mod"):
+    col = ((col.to(torch.int64) & 0xFFFFFFFF) % int(args.relabel[3:])).to(torch.int32)
 if args.relabel == "degree":
     cl = col.to(torch.int64) & 0xFFFFFFFF
     cnt = torch.bincount(cl, minlength=n)
