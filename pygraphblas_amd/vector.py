@@ -281,5 +281,54 @@ class Vector:
         check(fn(out._h, mh, ah, C.c_void_p(op.get_op()), self.type._c(first), self._h, dh), out)
         return out
 
+    # ---- operators (reference: pygraphblas/vector.py:982-1076): vector operands -> eadd / emult, scalars -> bound apply
+    def _binop(self, other, opname, union, out=None, reverse=False):
+        op = getattr(self.type, opname)
+        if isinstance(other, Vector):
+            return (self.eadd if union else self.emult)(other, op, out=out)
+        return self.apply_first(other, op, out=out) if reverse else self.apply_second(op, other, out=out)
+
+    def __add__(self, other):
+        return self._binop(other, "PLUS", True)
+
+    def __radd__(self, other):
+        return self._binop(other, "PLUS", True, reverse=True)
+
+    def __iadd__(self, other):
+        return self._binop(other, "PLUS", True, out=self)
+
+    def __sub__(self, other):
+        return self._binop(other, "MINUS", True)
+
+    def __rsub__(self, other):
+        return self._binop(other, "MINUS", True, reverse=True)
+
+    def __isub__(self, other):
+        return self._binop(other, "MINUS", True, out=self)
+
+    def __mul__(self, other):
+        return self._binop(other, "TIMES", False)
+
+    def __rmul__(self, other):
+        return self._binop(other, "TIMES", False, reverse=True)
+
+    def __imul__(self, other):
+        return self._binop(other, "TIMES", False, out=self)
+
+    def __truediv__(self, other):
+        return self._binop(other, "DIV", False)
+
+    def __rtruediv__(self, other):
+        return self._binop(other, "DIV", False, reverse=True)
+
+    def __itruediv__(self, other):
+        return self._binop(other, "DIV", False, out=self)
+
+    def __abs__(self):
+        return self.apply(self.type.ABS)
+
+    def __neg__(self):
+        return self.apply(self.type.AINV)
+
     def __repr__(self):
         return f"<Vector ({self.size} : {self.nvals}:{self.type.__name__})>"
