@@ -43,27 +43,35 @@ __device__ __forceinline__ bool spgemm_mask_truth(const void* mval, int mcode, u
   }
 }
 
-// ---- (1a) LDS-hash masked Gustavson: TEAM threads per row, 256 / TEAM rows per block -----------------------------
-template <class T, class SR, int SLOTS, int TEAM>
-__global__ __launch_bounds__(256) void k_spgemm_masked_lds(const SpgemmKArgs<T> a, const uint32_t* __restrict__ rows, uint32_t nrows_bin, const SR sr) {
+// ---- (1a) LDS-hash masked Gustavson: TEAM threads per row, BLOCK / TEAM rows per block -----------------------------
+// Work inside a row is wildly uneven (R-MAT: B rows of 1 ... 40 000 entries), so the entries k of A(i,:) are first
+// sorted into two LDS work lists by the length of B(k,:): short rows (< 64 entries) are walked by 16-lane groups,
+// four at a time per wave; long rows by a whole wave each, 64 coalesced entries per step.
+constexpr int SPG_LIST = 512;       // k's staged per round (per team)
+template <class T, class SR, int SLOTS, int TEAM, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T> a, const uint32_t* __restrict__ rows, uint32_t nrows_bin, const SR sr) {
   typedef typename acc_word<T>::type W;
-  constexpr int TEAMS = 256 / TEAM;
+  constexpr int TEAMS = BLOCK / TEAM;
+  constexpr int LCAP = TEAM >= 256 ? SPG_LIST : 64;
   __shared__ uint32_t s_key[TEAMS][SLOTS];
   __shared__ W s_acc[TEAMS][SLOTS];
   __shared__ uint16_t s_pos[TEAMS][SLOTS];
   __shared__ uint8_t s_flag[TEAMS][SLOTS];
+  __shared__ uint32_t s_lpa[TEAMS][LCAP], s_lbb[TEAMS][LCAP], s_lbe[TEAMS][LCAP];     // work list: A-entry position, B row begin / end
+  __shared__ uint32_t s_cnt[TEAMS][2];                                                  // [0] short rows fill from the front, [1] long rows from the back
   const int team = threadIdx.x / TEAM, t = threadIdx.x % TEAM;
-  const int lane16 = t & 15, grp = t >> 4;
-  constexpr int NG = TEAM / 16;
+  const int lane16 = t & 15, grp = t >> 4, lane64 = t & 63, wv = t >> 6;
+  constexpr int NG = TEAM / 16, NW = TEAM / 64;
   const bool use_a = sr.uses_a(), use_b = sr.uses_u();
   const W idw = to_word<T>(sr.identity);
   uint32_t* key = s_key[team]; W* acc = s_acc[team]; uint16_t* pos = s_pos[team]; uint8_t* flag = s_flag[team];
+  uint32_t* lpa = s_lpa[team]; uint32_t* lbb = s_lbb[team]; uint32_t* lbe = s_lbe[team]; uint32_t* cnt = s_cnt[team];
   const uint32_t nblk_rows = (nrows_bin + TEAMS - 1) / TEAMS * TEAMS;     // every team runs the same trip count
   for (uint32_t rbase = blockIdx.x * TEAMS; rbase < nblk_rows; rbase += gridDim.x * TEAMS) {
     const uint32_t ridx = rbase + team;
     const bool live = ridx < nrows_bin;
     const uint32_t i = live ? rows[ridx] : 0;
-    for (int s = t; s < SLOTS; s += TEAM) { key[s] = HASH_EMPTY; acc[s] = idw; flag[s] = 0; }
+    for (int s2 = t; s2 < SLOTS; s2 += TEAM) { key[s2] = HASH_EMPTY; acc[s2] = idw; flag[s2] = 0; }
     __syncthreads();
     const uint32_t mb = live ? a.mrp[i] : 0, me = live ? a.mrp[i + 1] : 0;
     for (uint32_t p = mb + t; p < me; p += TEAM) {
@@ -73,27 +81,60 @@ __global__ __launch_bounds__(256) void k_spgemm_masked_lds(const SpgemmKArgs<T> 
       while (atomicCAS(&key[h], HASH_EMPTY, j) != HASH_EMPTY) h = (h + 1) & (SLOTS - 1);
       pos[h] = (uint16_t)(p - mb);
     }
-    __syncthreads();
     const uint32_t ab = live ? a.arp[i] : 0, ae = live ? a.arp[i + 1] : 0;
-    for (uint32_t pa = ab + grp; pa < ae; pa += NG) {
-      const uint32_t k = a.acol[pa];
-      const T av = use_a ? a.aval[pa] : T();
-      const uint32_t bb = a.brp[k], be = a.brp[k + 1];
-      for (uint32_t pb = bb + lane16; pb < be; pb += 16) {
-        const uint32_t j = a.bcol[pb];
-        uint32_t h = hash_col(j, SLOTS - 1);
-        uint32_t kk = key[h];
-        while (kk != j && kk != HASH_EMPTY) { h = (h + 1) & (SLOTS - 1); kk = key[h]; }
-        if (kk == j) {
-          const T m = sr.mult(av, use_b ? a.bval[pb] : T());
-          word_combine<T>(sr.add_op(), &acc[h], m);
-          flag[h] = 1;
+    // the longest A row of the block decides the number of rounds, so every team reaches every barrier
+    uint32_t maxlen = ae - ab;
+    if constexpr (TEAMS > 1) {
+      __shared__ uint32_t s_max;
+      if (threadIdx.x == 0) s_max = 0;
+      __syncthreads();
+      if (t == 0) atomicMax(&s_max, maxlen);
+      __syncthreads();
+      maxlen = s_max;
+    }
+    for (uint32_t r0 = 0; r0 < maxlen; r0 += LCAP) {
+      if (t < 2) cnt[t] = 0;
+      __syncthreads();
+      // stage the next LCAP entries of A(i,:) into the short / long lists
+      for (uint32_t q = r0 + t; q < r0 + LCAP && ab + q < ae; q += TEAM) {
+        const uint32_t pa = ab + q, k = a.acol[pa];
+        const uint32_t bb = a.brp[k], be = a.brp[k + 1];
+        if (be == bb) continue;
+        const bool lng = be - bb >= 64;
+        const uint32_t slot = lng ? (LCAP - 1 - atomicAdd(&cnt[1], 1u)) : atomicAdd(&cnt[0], 1u);
+        lpa[slot] = pa; lbb[slot] = bb; lbe[slot] = be;
+      }
+      __syncthreads();
+      const uint32_t nshort = cnt[0], nlong = cnt[1];
+      // short rows: one 16-lane group each
+      for (uint32_t q = grp; q < nshort; q += NG) {
+        const T av = use_a ? a.aval[lpa[q]] : T();
+        const uint32_t be = lbe[q];
+        for (uint32_t pb = lbb[q] + lane16; pb < be; pb += 16) {
+          const uint32_t j = a.bcol[pb];
+          uint32_t h = hash_col(j, SLOTS - 1);
+          uint32_t kk = key[h];
+          while (kk != j && kk != HASH_EMPTY) { h = (h + 1) & (SLOTS - 1); kk = key[h]; }
+          if (kk == j) { word_combine<T>(sr.add_op(), &acc[h], sr.mult(av, use_b ? a.bval[pb] : T())); flag[h] = 1; }
         }
       }
+      // long rows: one wave each
+      for (uint32_t q = wv; q < nlong; q += NW) {
+        const uint32_t sl = LCAP - 1 - q;
+        const T av = use_a ? a.aval[lpa[sl]] : T();
+        const uint32_t be = lbe[sl];
+        for (uint32_t pb = lbb[sl] + lane64; pb < be; pb += 64) {
+          const uint32_t j = a.bcol[pb];
+          uint32_t h = hash_col(j, SLOTS - 1);
+          uint32_t kk = key[h];
+          while (kk != j && kk != HASH_EMPTY) { h = (h + 1) & (SLOTS - 1); kk = key[h]; }
+          if (kk == j) { word_combine<T>(sr.add_op(), &acc[h], sr.mult(av, use_b ? a.bval[pb] : T())); flag[h] = 1; }
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    for (int s = t; s < SLOTS; s += TEAM) {
-      if (key[s] != HASH_EMPTY && flag[s]) { a.cacc[mb + pos[s]] = acc[s]; a.cflag[mb + pos[s]] = 1; }
+    for (int s2 = t; s2 < SLOTS; s2 += TEAM) {
+      if (key[s2] != HASH_EMPTY && flag[s2]) { a.cacc[mb + pos[s2]] = acc[s2]; a.cflag[mb + pos[s2]] = 1; }
     }
     __syncthreads();
   }
@@ -104,7 +145,7 @@ template <class T, class SR>
 __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T> a, const uint32_t* __restrict__ rows, uint32_t nrows_bin,
                                                             uint32_t* __restrict__ maps, uint32_t ncols, const SR sr) {
   uint32_t* map = maps + (size_t)blockIdx.x * ncols;       // zero-initialised; entry = mask position + 1
-  const int t = threadIdx.x, lane16 = t & 15, grp = t >> 4; constexpr int NG = 1024 / 16;
+  const int t = threadIdx.x;
   const bool use_a = sr.uses_a(), use_b = sr.uses_u();
   for (uint32_t ridx = blockIdx.x; ridx < nrows_bin; ridx += gridDim.x) {
     const uint32_t i = rows[ridx];
@@ -112,16 +153,17 @@ __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T>
     for (uint32_t p = mb + t; p < me; p += 1024) if (spgemm_mask_truth(a.mval, a.mcode, p, a.mstruct)) map[a.mcol[p]] = p - mb + 1;
     __threadfence_block(); __syncthreads();
     const uint32_t ab = a.arp[i], ae = a.arp[i + 1];
-    for (uint32_t pa = ab + grp; pa < ae; pa += NG) {
+    // one wave per entry k of A(i,:): these rows have thousands of k's, most with long B rows
+    for (uint32_t pa = ab + (t >> 6); pa < ae; pa += 16) {
       const uint32_t k = a.acol[pa];
       const T av = use_a ? a.aval[pa] : T();
       const uint32_t bb = a.brp[k], be = a.brp[k + 1];
-      for (uint32_t pb = bb + lane16; pb < be; pb += 16) {
-        const uint32_t s = map[a.bcol[pb]];
-        if (s) {
+      for (uint32_t pb = bb + (t & 63); pb < be; pb += 64) {
+        const uint32_t s2 = map[a.bcol[pb]];
+        if (s2) {
           const T m = sr.mult(av, use_b ? a.bval[pb] : T());
-          word_combine<T>(sr.add_op(), &a.cacc[mb + s - 1], m);
-          a.cflag[mb + s - 1] = 1;
+          word_combine<T>(sr.add_op(), &a.cacc[mb + s2 - 1], m);
+          a.cflag[mb + s2 - 1] = 1;
         }
       }
     }
@@ -146,14 +188,40 @@ template <class T> __global__ void k_compact_acc(uint32_t nrows, const uint32_t*
 }
 
 static __global__ void k_bin_rows(uint32_t nrows, const uint32_t* __restrict__ mrp, const uint32_t* __restrict__ arp, uint32_t* __restrict__ counts,
-                           uint32_t* __restrict__ lists /* 5 x nrows */) {
-  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nrows; r += (uint64_t)gridDim.x * 256ull) {
-    const uint32_t ml = mrp[r + 1] - mrp[r], al = arp[r + 1] - arp[r];
-    if (!ml || !al) continue;
-    const int b = ml <= 32 ? 0 : (ml <= 256 ? 1 : (ml <= 1024 ? 2 : (ml <= 4096 ? 3 : 4)));
-    const uint32_t pos = atomicAdd(&counts[b], 1u);
-    lists[(size_t)b * nrows + pos] = (uint32_t)r;
+                                  uint32_t* __restrict__ lists /* 5 x nrows */) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t nround = ((uint64_t)nrows + 63) / 64 * 64;
+  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nround; r += (uint64_t)gridDim.x * 256ull) {
+    int b = -1;
+    if (r < nrows) {
+      const uint32_t ml = mrp[r + 1] - mrp[r], al = arp[r + 1] - arp[r];
+      if (ml && al) b = ml <= 32 ? 0 : (ml <= 256 ? 1 : (ml <= 1024 ? 2 : (ml <= 4096 ? 3 : 4)));
+    }
+    // one atomic per wave per bin instead of one per row
+    for (int bb = 0; bb < 5; bb++) {
+      const unsigned long long m = __ballot(b == bb);
+      if (!m) continue;
+      const int leader = __builtin_ctzll(m);
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(&counts[bb], (uint32_t)__popcll(m));
+      base = __shfl(base, leader, 64);
+      if (b == bb) lists[(size_t)bb * nrows + base + __popcll(m & ((1ull << lane) - 1))] = (uint32_t)r;
+    }
   }
+}
+// entry-parallel compaction of the per-mask-entry accumulators: pos = exclusive scan of the flags
+static __global__ void k_flags_to_u32(const uint8_t* __restrict__ flag, uint64_t n, uint32_t* __restrict__ out) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) out[i] = flag[i] ? 1u : 0u;
+}
+static __global__ void k_rowptr_from_scan(uint32_t nrows, const uint32_t* __restrict__ mrp, const uint32_t* __restrict__ pos, uint32_t total, uint64_t mnz, uint32_t* __restrict__ orp) {
+  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r <= nrows; r += (uint64_t)gridDim.x * 256ull) {
+    const uint32_t p = mrp[r]; orp[r] = p < mnz ? pos[p] : total;
+  }
+}
+template <class T> __global__ void k_scatter_acc(uint64_t mnz, const uint32_t* __restrict__ mcol, const typename acc_word<T>::type* __restrict__ cacc,
+                                                 const uint8_t* __restrict__ cflag, const uint32_t* __restrict__ pos, uint32_t* __restrict__ ocol, T* __restrict__ oval) {
+  for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < mnz; p += gridDim.x * 256ull)
+    if (cflag[p]) { const uint32_t w = pos[p]; ocol[w] = mcol[p]; oval[w] = from_word<T>(cacc[p]); }
 }
 static __global__ void k_count_flags_rows(uint32_t nrows, const uint32_t* __restrict__ rp, const uint8_t* __restrict__ flag, uint32_t* __restrict__ cnt) {
   for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nrows; r += (uint64_t)gridDim.x * 256ull) {
@@ -183,12 +251,12 @@ template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDes
     auto nblocks = [](uint32_t rows, int teams) { uint64_t b = ((uint64_t)rows + teams - 1) / teams; if (b > 256u * 64) b = 256u * 64; if (b < 1) b = 1; return (unsigned)b; };
     // the HBM-map kernel accumulates straight into cacc: start those slots at the identity (before any kernel writes results)
     if (hc[4]) hipLaunchKernelGGL((k_fill_words<W>), dim3(4096), dim3(256), 0, stream(), cacc.as<W>(), mnz, to_word<T>(sr.identity));
-    if (hc[0]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 64, 64>), dim3(nblocks(hc[0], 4)), dim3(256), 0, stream(), a, L, hc[0], sr);
-    if (hc[1]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 512, 256>), dim3(nblocks(hc[1], 1)), dim3(256), 0, stream(), a, L + (size_t)nrows, hc[1], sr);
-    if (hc[2]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 2048, 256>), dim3(nblocks(hc[2], 1)), dim3(256), 0, stream(), a, L + (size_t)2 * nrows, hc[2], sr);
-    if (hc[3]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 8192, 256>), dim3(nblocks(hc[3], 1)), dim3(256), 0, stream(), a, L + (size_t)3 * nrows, hc[3], sr);
+    if (hc[0]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 64, 64, 256>), dim3(nblocks(hc[0], 4)), dim3(256), 0, stream(), a, L, hc[0], sr);
+    if (hc[1]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 512, 256, 256>), dim3(nblocks(hc[1], 1)), dim3(256), 0, stream(), a, L + (size_t)nrows, hc[1], sr);
+    if (hc[2]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 2048, 512, 512>), dim3(nblocks(hc[2], 1)), dim3(512), 0, stream(), a, L + (size_t)2 * nrows, hc[2], sr);
+    if (hc[3]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 8192, 1024, 1024>), dim3(nblocks(hc[3], 1)), dim3(1024), 0, stream(), a, L + (size_t)3 * nrows, hc[3], sr);
     if (hc[4]) {
-      const unsigned nb = hc[4] < 64 ? hc[4] : 64;
+      const unsigned nb = hc[4] < 256 ? hc[4] : 256;
       DevBuf maps((size_t)nb * B.ncols * 4);
       GRB_HIP(hipMemsetAsync(maps.p, 0, (size_t)nb * B.ncols * 4, stream()));
       hipLaunchKernelGGL((k_spgemm_masked_map<T, SR>), dim3(nb), dim3(1024), 0, stream(), a, L + (size_t)4 * nrows, hc[4], maps.as<uint32_t>(), B.ncols, sr);
@@ -198,16 +266,22 @@ template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDes
                    std::to_string(hc[2]) + "/" + std::to_string(hc[3]) + "/" + std::to_string(hc[4]) + " ";
   });
   GRB_HIP(hipGetLastError());
-  // compaction
-  DevBuf cnt(((size_t)nrows + 1) * 4);
-  GRB_HIP(hipMemsetAsync(cnt.p, 0, ((size_t)nrows + 1) * 4, stream()));
-  hipLaunchKernelGGL(k_count_flags_rows, dim3(grid_rows(nrows)), dim3(256), 0, stream(), nrows, M.rowptr.as<uint32_t>(), cflag.as<uint8_t>(), cnt.as<uint32_t>());
-  exclusive_scan_u32(cnt.as<uint32_t>(), out.rowptr.as<uint32_t>(), (uint64_t)nrows + 1);
-  uint32_t total = 0;
-  GRB_HIP(hipMemcpyAsync(&total, out.rowptr.as<uint32_t>() + nrows, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
-  out.nnz = total; out.col.alloc((size_t)total * 4); out.val.alloc((size_t)total * sizeof(T));
-  hipLaunchKernelGGL((k_compact_acc<T>), dim3(grid_rows(nrows)), dim3(256), 0, stream(), nrows, M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(), cacc.as<W>(),
-                     cflag.as<uint8_t>(), out.rowptr.as<uint32_t>(), out.col.as<uint32_t>(), out.val.as<T>());
+  // compaction (entry-parallel): position of every kept mask entry = exclusive scan of the flags
+  {
+    auto grid_n = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 8192) b = 8192; return (unsigned)b; };
+    DevBuf f32(mnz * 4 + 4), pos(mnz * 4 + 4);
+    hipLaunchKernelGGL(k_flags_to_u32, dim3(grid_n(mnz)), dim3(256), 0, stream(), cflag.as<uint8_t>(), mnz, f32.as<uint32_t>());
+    exclusive_scan_u32(f32.as<uint32_t>(), pos.as<uint32_t>(), mnz);
+    uint32_t lastp = 0; uint8_t lastf = 0;
+    GRB_HIP(hipMemcpyAsync(&lastp, pos.as<uint32_t>() + (mnz - 1), 4, hipMemcpyDeviceToHost, stream()));
+    GRB_HIP(hipMemcpyAsync(&lastf, cflag.as<uint8_t>() + (mnz - 1), 1, hipMemcpyDeviceToHost, stream()));
+    GRB_HIP(hipStreamSynchronize(stream()));
+    const uint32_t total = lastp + (lastf ? 1u : 0u);
+    out.nnz = total; out.col.alloc((size_t)total * 4 + 4); out.val.alloc((size_t)total * sizeof(T) + 8);
+    hipLaunchKernelGGL(k_rowptr_from_scan, dim3(grid_n(nrows + 1)), dim3(256), 0, stream(), nrows, M.rowptr.as<uint32_t>(), pos.as<uint32_t>(), total, mnz, out.rowptr.as<uint32_t>());
+    hipLaunchKernelGGL((k_scatter_acc<T>), dim3(grid_n(mnz)), dim3(256), 0, stream(), mnz, M.col.as<uint32_t>(), cacc.as<W>(), cflag.as<uint8_t>(), pos.as<uint32_t>(),
+                       out.col.as<uint32_t>(), out.val.as<T>());
+  }
   GRB_HIP(hipGetLastError());
   GRB_HIP(hipStreamSynchronize(stream()));
   out.valid = true;
