@@ -20,6 +20,7 @@
 #include "grb_semiring.hpp"
 #include "grb_atomics.hpp"
 #include "grb_matops.hpp"
+#include "grb_spgemm_kernels_fwd.hpp"
 
 namespace grb {
 
@@ -123,12 +124,21 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
         const uint32_t sl = LCAP - 1 - q;
         const T av = use_a ? a.aval[lpa[sl]] : T();
         const uint32_t be = lbe[sl];
-        for (uint32_t pb = lbb[sl] + lane64; pb < be; pb += 64) {
-          const uint32_t j = a.bcol[pb];
-          uint32_t h = hash_col(j, SLOTS - 1);
-          uint32_t kk = key[h];
-          while (kk != j && kk != HASH_EMPTY) { h = (h + 1) & (SLOTS - 1); kk = key[h]; }
-          if (kk == j) { word_combine<T>(sr.add_op(), &acc[h], sr.mult(av, use_b ? a.bval[pb] : T())); flag[h] = 1; }
+        for (uint32_t pb0 = lbb[sl] + lane64; pb0 < be; pb0 += 256) {
+          uint32_t jj[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const uint32_t pb = pb0 + 64 * u; jj[u] = a.bcol[pb < be ? pb : be - 1]; }   // 4 loads in flight
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint32_t pb = pb0 + 64 * u;
+            if (pb < be) {
+              const uint32_t j = jj[u];
+              uint32_t h = hash_col(j, SLOTS - 1);
+              uint32_t kk = key[h];
+              while (kk != j && kk != HASH_EMPTY) { h = (h + 1) & (SLOTS - 1); kk = key[h]; }
+              if (kk == j) { word_combine<T>(sr.add_op(), &acc[h], sr.mult(av, use_b ? a.bval[pb] : T())); flag[h] = 1; }
+            }
+          }
         }
       }
       __syncthreads();
@@ -158,12 +168,20 @@ __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T>
       const uint32_t k = a.acol[pa];
       const T av = use_a ? a.aval[pa] : T();
       const uint32_t bb = a.brp[k], be = a.brp[k + 1];
-      for (uint32_t pb = bb + (t & 63); pb < be; pb += 64) {
-        const uint32_t s2 = map[a.bcol[pb]];
-        if (s2) {
-          const T m = sr.mult(av, use_b ? a.bval[pb] : T());
-          word_combine<T>(sr.add_op(), &a.cacc[mb + s2 - 1], m);
-          a.cflag[mb + s2 - 1] = 1;
+      for (uint32_t pb0 = bb + (t & 63); pb0 < be; pb0 += 256) {
+        uint32_t ss[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t pb = pb0 + 64 * u; ss[u] = a.bcol[pb < be ? pb : be - 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) ss[u] = map[ss[u]];                   // 4 independent map lookups in flight
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t pb = pb0 + 64 * u;
+          if (pb < be && ss[u]) {
+            const T m = sr.mult(av, use_b ? a.bval[pb] : T());
+            word_combine<T>(sr.add_op(), &a.cacc[mb + ss[u] - 1], m);
+            a.cflag[mb + ss[u] - 1] = 1;
+          }
         }
       }
     }
@@ -251,17 +269,22 @@ template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDes
     auto nblocks = [](uint32_t rows, int teams) { uint64_t b = ((uint64_t)rows + teams - 1) / teams; if (b > 256u * 64) b = 256u * 64; if (b < 1) b = 1; return (unsigned)b; };
     // the HBM-map kernel accumulates straight into cacc: start those slots at the identity (before any kernel writes results)
     if (hc[4]) hipLaunchKernelGGL((k_fill_words<W>), dim3(4096), dim3(256), 0, stream(), cacc.as<W>(), mnz, to_word<T>(sr.identity));
-    if (hc[0]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 64, 64, 256>), dim3(nblocks(hc[0], 4)), dim3(256), 0, stream(), a, L, hc[0], sr);
-    if (hc[1]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 512, 256, 256>), dim3(nblocks(hc[1], 1)), dim3(256), 0, stream(), a, L + (size_t)nrows, hc[1], sr);
-    if (hc[2]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 2048, 512, 512>), dim3(nblocks(hc[2], 1)), dim3(512), 0, stream(), a, L + (size_t)2 * nrows, hc[2], sr);
-    if (hc[3]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 8192, 1024, 1024>), dim3(nblocks(hc[3], 1)), dim3(1024), 0, stream(), a, L + (size_t)3 * nrows, hc[3], sr);
+    // the bins write disjoint accumulator slots and each is dominated by a few heavy rows: run them concurrently on
+    // auxiliary streams (forked from / joined back into the library stream with events) so their tails overlap
+    AuxStreams& ax = aux_streams();
+    ax.fork(stream());
+    if (hc[0]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 64, 64, 256>), dim3(nblocks(hc[0], 4)), dim3(256), 0, ax.s[0], a, L, hc[0], sr);
+    if (hc[1]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 512, 256, 256>), dim3(nblocks(hc[1], 1)), dim3(256), 0, ax.s[1], a, L + (size_t)nrows, hc[1], sr);
+    if (hc[2]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 2048, 512, 512>), dim3(nblocks(hc[2], 1)), dim3(512), 0, ax.s[2], a, L + (size_t)2 * nrows, hc[2], sr);
+    if (hc[3]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 8192, 1024, 1024>), dim3(nblocks(hc[3], 1)), dim3(1024), 0, ax.s[3], a, L + (size_t)3 * nrows, hc[3], sr);
     if (hc[4]) {
       const unsigned nb = hc[4] < 256 ? hc[4] : 256;
       DevBuf maps((size_t)nb * B.ncols * 4);
       GRB_HIP(hipMemsetAsync(maps.p, 0, (size_t)nb * B.ncols * 4, stream()));
       hipLaunchKernelGGL((k_spgemm_masked_map<T, SR>), dim3(nb), dim3(1024), 0, stream(), a, L + (size_t)4 * nrows, hc[4], maps.as<uint32_t>(), B.ncols, sr);
+      ax.join(stream());
       GRB_HIP(hipStreamSynchronize(stream()));
-    }
+    } else ax.join(stream());
     g_last_plan += std::string("k_spgemm_masked<") + (sr.is_static ? "static" : "dynamic") + "> bins " + std::to_string(hc[0]) + "/" + std::to_string(hc[1]) + "/" +
                    std::to_string(hc[2]) + "/" + std::to_string(hc[3]) + "/" + std::to_string(hc[4]) + " ";
   });

@@ -26,7 +26,7 @@ namespace grb {
 
 // per-type kernel instantiations live in grb_spmv_inst.hip (compiled once per value type, in parallel)
 template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d);
-template <class T> void run_push(const SpmvCall& c, const SemiringDesc& d, const uint32_t* fidx, uint64_t u_nvals);
+template <class T> void run_push(const SpmvCall& c, const SemiringDesc& d, const uint32_t* fidx, uint64_t u_nvals, uint32_t* longlist);
 
 // ---- plan: greedy row blocking, once per matrix -------------------------------------------------------------
 void spmv_build_plan(DevCSR& M) {
@@ -90,12 +90,13 @@ void spmspv_push(const SpmvCall& c, const SemiringDesc& d, uint64_t u_nvals) {
   // c.M here is the CSR whose ROWS are indexed like u (i.e. the transpose of the pull operand)
   DevCSR& M = *c.M; const uint64_t nu = M.nrows, nout = M.ncols;
   auto grid_of = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 4096) b = 4096; return (unsigned)b; };
-  DevBuf flags(nu * 4 + 4), pos(nu * 4 + 4), fidx((u_nvals + 1) * 4);
+  DevBuf flags(nu * 4 + 4), pos(nu * 4 + 4), fidx((u_nvals + 1) * 4), longlist((u_nvals + 2) * 4);
+  GRB_HIP(hipMemsetAsync(longlist.p, 0, 4, stream()));
   hipLaunchKernelGGL(k_flag_to_u32, dim3(grid_of(nu)), dim3(256), 0, stream(), c.upres, nu, flags.as<uint32_t>());
   exclusive_scan_u32(flags.as<uint32_t>(), pos.as<uint32_t>(), nu);
   hipLaunchKernelGGL(k_compact_idx, dim3(grid_of(nu)), dim3(256), 0, stream(), c.upres, pos.as<uint32_t>(), nu, fidx.as<uint32_t>());
   GRB_HIP(hipMemsetAsync(c.tpres, 0, nout ? nout : 1, stream()));
-  dispatch_type(d.zcode, [&]<class T>() { run_push<T>(c, d, fidx.as<uint32_t>(), u_nvals); });
+  dispatch_type(d.zcode, [&]<class T>() { run_push<T>(c, d, fidx.as<uint32_t>(), u_nvals, longlist.as<uint32_t>()); });
   GRB_HIP(hipGetLastError());
 }
 

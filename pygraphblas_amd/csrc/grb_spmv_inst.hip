@@ -4,5 +4,5 @@
 namespace grb {
 using std::int8_t; using std::uint8_t; using std::int16_t; using std::uint16_t; using std::int32_t; using std::uint32_t; using std::int64_t; using std::uint64_t;
 template void run_pull<GRB_INST_TYPE>(const SpmvCall&, const SemiringDesc&);
-template void run_push<GRB_INST_TYPE>(const SpmvCall&, const SemiringDesc&, const uint32_t*, uint64_t);
+template void run_push<GRB_INST_TYPE>(const SpmvCall&, const SemiringDesc&, const uint32_t*, uint64_t, uint32_t*);
 }

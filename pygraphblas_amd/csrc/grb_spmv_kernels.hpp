@@ -257,10 +257,12 @@ template <class T> __device__ __forceinline__ void atomic_combine(int op, T* add
   }
 }
 
+constexpr int PUSH_LONG = 4096;
 template <class T, class SR>
 __global__ __launch_bounds__(256) void k_spmspv_push(const uint32_t* __restrict__ fidx, uint32_t nf, const uint32_t* __restrict__ rowptr,
                                                      const uint32_t* __restrict__ col, const T* __restrict__ aval, const T* __restrict__ uval,
-                                                     const uint8_t* __restrict__ allow, T* __restrict__ tval, uint8_t* __restrict__ tpres, const SR sr) {
+                                                     const uint8_t* __restrict__ allow, T* __restrict__ tval, uint8_t* __restrict__ tpres,
+                                                     uint32_t* __restrict__ longlist, const SR sr) {
   // one wave per frontier entry: its row of M^T (= CSR row of the stored matrix) is streamed coalesced
   const int lane = threadIdx.x & 63;
   const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6;
@@ -270,7 +272,32 @@ __global__ __launch_bounds__(256) void k_spmspv_push(const uint32_t* __restrict_
     const uint32_t i = fidx[f];
     const T ui = use_u ? uval[i] : T();
     const uint32_t pb = rowptr[i], pe = rowptr[i + 1];
+    if (pe - pb > (uint32_t)PUSH_LONG) {          // hub row: handed to the all-blocks kernel below (one wave would take ms)
+      if (lane == 0) longlist[1 + atomicAdd(&longlist[0], 1u)] = i;
+      continue;
+    }
     for (uint32_t p = pb + lane; p < pe; p += 64) {
+      const uint32_t j = col[p];
+      if (allow && !allow[j]) continue;
+      const T m = sr.mult(use_a ? aval[p] : T(), ui);
+      atomic_combine<T>(sr.add_op(), &tval[j], m);
+      tpres[j] = 1;
+    }
+  }
+}
+
+// frontier rows longer than PUSH_LONG: every block of the grid takes a slice of each (the list is short: hubs only)
+template <class T, class SR>
+__global__ __launch_bounds__(256) void k_spmspv_push_long(const uint32_t* __restrict__ longlist, const uint32_t* __restrict__ rowptr,
+                                                          const uint32_t* __restrict__ col, const T* __restrict__ aval, const T* __restrict__ uval,
+                                                          const uint8_t* __restrict__ allow, T* __restrict__ tval, uint8_t* __restrict__ tpres, const SR sr) {
+  const uint32_t nl = longlist[0];
+  const bool use_a = sr.uses_a(), use_u = sr.uses_u();
+  for (uint32_t l = 0; l < nl; l++) {
+    const uint32_t i = longlist[1 + l];
+    const T ui = use_u ? uval[i] : T();
+    const uint32_t pb = rowptr[i], pe = rowptr[i + 1];
+    for (uint64_t p = (uint64_t)pb + blockIdx.x * 256ull + threadIdx.x; p < pe; p += (uint64_t)gridDim.x * 256ull) {
       const uint32_t j = col[p];
       if (allow && !allow[j]) continue;
       const T m = sr.mult(use_a ? aval[p] : T(), ui);
@@ -293,7 +320,8 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
     const bool prefer_rowgroup = c.method == SPMV_ROWGROUP || (c.method == SPMV_AUTO && c.allow && d.has_terminal);
     if (prefer_rowgroup) {
       const double avg = M.nrows ? (double)M.nnz / M.nrows : 0;
-      const int G = avg > 24 ? 64 : 8;
+      const int G = avg > 96 ? 64 : 8;        // 8 lanes per row unless rows are long on average: most rows of a power-law graph are short
+
       uint64_t groups_per_block = 256 / G;
       uint64_t nb = (M.nrows + groups_per_block - 1) / groups_per_block; if (nb < 1) nb = 1; if (nb > 65536) nb = 65536;
 #define GRB_LAUNCH_B(GG) \
@@ -344,7 +372,7 @@ template <class T> __global__ void k_fill(T* p, uint64_t n, T v) {
   for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) p[i] = v;
 }
 
-template <class T> void run_push(const SpmvCall& c, const SemiringDesc& d, const uint32_t* fidx, uint64_t u_nvals) {
+template <class T> void run_push(const SpmvCall& c, const SemiringDesc& d, const uint32_t* fidx, uint64_t u_nvals, uint32_t* longlist) {
   DevCSR& M = *c.M; const uint64_t nout = M.ncols;
   auto grid_of = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 4096) b = 4096; return (unsigned)b; };
   with_semiring<T>(d, [&](auto sr) {
@@ -352,7 +380,9 @@ template <class T> void run_push(const SpmvCall& c, const SemiringDesc& d, const
     if (nout) hipLaunchKernelGGL((k_fill<T>), dim3(grid_of(nout)), dim3(256), 0, stream(), (T*)c.tval, nout, sr.identity);
     uint64_t nb = (u_nvals + 3) / 4; if (nb < 1) nb = 1; if (nb > 16384) nb = 16384;
     hipLaunchKernelGGL((k_spmspv_push<T, SR>), dim3((unsigned)nb), dim3(256), 0, stream(), fidx, (uint32_t)u_nvals,
-                       M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(), (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, sr);
+                       M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(), (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, longlist, sr);
+    hipLaunchKernelGGL((k_spmspv_push_long<T, SR>), dim3(1024), dim3(256), 0, stream(), longlist, M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(),
+                       (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, sr);
     g_last_plan += std::string("k_spmspv_push<") + (sr.is_static ? "static> " : "dynamic> ");
   });
 }
