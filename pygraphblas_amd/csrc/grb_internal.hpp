@@ -184,5 +184,6 @@ void vec_cast_values(int dst_code, void* dst, int src_code, const void* src, uin
 void build_allow(uint64_t n, int mcode, const void* mval, const uint8_t* mpres, bool structural,
                  bool complement, uint8_t* allow);
 uint64_t count_present(const uint8_t* pres, uint64_t n);
+uint64_t frontier_edges(const uint8_t* pres, const uint32_t* rowptr, uint64_t n);
 
 }  // namespace grb

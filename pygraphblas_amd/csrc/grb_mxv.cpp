@@ -43,11 +43,15 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   const bool uses_a = sd.flip ? binop_uses_y(sd.mulop) : binop_uses_x(sd.mulop);
   const bool uses_u = sd.flip ? binop_uses_x(sd.mulop) : binop_uses_y(sd.mulop);
 
-  // direction: push when the frontier is sparse enough that its rows hold < 1/8 of the entries
-  const double avgdeg = (double)A->csr.nnz / (double)(mc ? mc : 1);   // mean length of the rows a push would walk
-  bool push = spmspv_push_supported(sd) && !u_full && (double)u_nvals * (avgdeg + 1) * 8 < (double)A->csr.nnz + 1;
+  // direction (Beamer-style): push walks the rows of the frontier, pull scans the rows of the output.  Push is
+  // considered only for a sparse operand and a monoid with a native atomic; it is taken when the edges leaving the
+  // frontier (an exact count on the device) are < 1/16 of all entries.
+  bool push = false;
   if (method == SPMV_PUSH) push = spmspv_push_supported(sd);
-  else if (method == SPMV_ADAPTIVE || method == SPMV_ROWGROUP || method == SPMV_WAVEPIPE) push = false;
+  else if (method == SPMV_AUTO && spmspv_push_supported(sd) && !u_full && u_nvals * 16 < (uint64_t)A->csr.nnz + 16) {
+    const DevCSR& P = useT ? A->csr : mat_csc(A);
+    push = frontier_edges(u->dpres.as<uint8_t>(), P.rowptr.as<uint32_t>(), u->n) * 16 < P.nnz + 16;
+  }
 
   const size_t zs = type_size(sd.zcode);
   DevBuf tval(mr * zs + 1), tpres(mr + 1), ucast, acast;

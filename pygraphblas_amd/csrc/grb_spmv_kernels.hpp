@@ -293,11 +293,13 @@ __global__ __launch_bounds__(256) void k_spmspv_push_long(const uint32_t* __rest
                                                           const uint8_t* __restrict__ allow, T* __restrict__ tval, uint8_t* __restrict__ tpres, const SR sr) {
   const uint32_t nl = longlist[0];
   const bool use_a = sr.uses_a(), use_u = sr.uses_u();
-  for (uint32_t l = 0; l < nl; l++) {
+  // few long rows: every block takes a slice of each; many: one block per row
+  const bool split = nl < gridDim.x / 8;
+  for (uint32_t l = split ? 0 : blockIdx.x; l < nl; l += split ? 1 : gridDim.x) {
     const uint32_t i = longlist[1 + l];
     const T ui = use_u ? uval[i] : T();
     const uint32_t pb = rowptr[i], pe = rowptr[i + 1];
-    for (uint64_t p = (uint64_t)pb + blockIdx.x * 256ull + threadIdx.x; p < pe; p += (uint64_t)gridDim.x * 256ull) {
+    for (uint64_t p = (uint64_t)pb + (split ? blockIdx.x * 256ull : 0ull) + threadIdx.x; p < pe; p += split ? (uint64_t)gridDim.x * 256ull : 256ull) {
       const uint32_t j = col[p];
       if (allow && !allow[j]) continue;
       const T m = sr.mult(use_a ? aval[p] : T(), ui);

@@ -63,6 +63,20 @@ uint64_t count_present(const uint8_t* pres, uint64_t n) {
   return slot.read_u64();
 }
 
+// ---- sum of the row lengths of the present entries (how many edges a push from this frontier would walk) ----------------
+__global__ void k_frontier_edges(const uint8_t* __restrict__ pres, const uint32_t* __restrict__ rowptr, uint64_t n, unsigned long long* out) {
+  unsigned long long c = 0;
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) if (pres[i]) c += rowptr[i + 1] - rowptr[i];
+  c = wave_reduce_add_u64(c);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+uint64_t frontier_edges(const uint8_t* pres, const uint32_t* rowptr, uint64_t n) {
+  if (!n) return 0;
+  ScalarSlot slot; slot.zero();
+  hipLaunchKernelGGL(k_frontier_edges, dim3(grid_for(n, 4)), dim3(256), 0, stream(), pres, rowptr, n, (unsigned long long*)slot.dev());
+  return slot.read_u64();
+}
+
 // ---- C<M,replace> = accum(C, T) for vectors, in place on (wval, wpres) ---------------------------------
 template <class T> __global__ void k_vec_epilogue(uint64_t n, T* __restrict__ wval, uint8_t* __restrict__ wpres,
                                                   const T* __restrict__ tval, const uint8_t* __restrict__ tpres,
