@@ -41,7 +41,10 @@ def main():
         if args.gpus != 1 or world != 1:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
             sys.exit(2)
-    os.environ.setdefault("GRB_MI355X_DEVICE", str(local_rank))
+    # test hook: BENCH_DEVICE_OVERRIDE puts every rank on one GPU (with BENCH_BACKEND=gloo) to exercise the N>1 code path on a 1-GPU box
+    if "BENCH_DEVICE_OVERRIDE" in os.environ:
+        local_rank = int(os.environ["BENCH_DEVICE_OVERRIDE"])
+    os.environ["GRB_MI355X_DEVICE"] = str(local_rank)
 
     import numpy as np
     import torch
@@ -50,7 +53,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import pygraphblas_amd as gb
     from pygraphblas_amd import rmat

@@ -78,6 +78,46 @@ template <class T, bool FULL = true> __device__ __forceinline__ T wave_reduce_op
   return v;
 }
 
+// ---- DPP wave reduction (no LDS crossbar): quad swaps, row rotates, then the two row broadcasts of gfx9.
+// The combination order is fixed, so floating-point results are reproducible.  Lanes that have nothing to add must
+// pass the monoid identity.  Returns the total in every lane (read back from lane 63).
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_mov(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+template <class T, int CTRL, int ROW_MASK> __device__ __forceinline__ T dpp_move_t(T v) {
+  // lanes that are not written (row_mask) or have no valid source keep their own value as `old`
+  if constexpr (sizeof(T) == 8) {
+    union { T t; uint32_t u[2]; } a, r; a.t = v;
+    r.u[0] = dpp_mov<CTRL, ROW_MASK>(a.u[0], a.u[0]); r.u[1] = dpp_mov<CTRL, ROW_MASK>(a.u[1], a.u[1]); return r.t;
+  } else {
+    union { T t; uint32_t u; } a, r; a.u = 0; a.t = v; r.u = dpp_mov<CTRL, ROW_MASK>(a.u, a.u); return r.t;
+  }
+}
+template <class T, bool FULL = true> __device__ __forceinline__ T wave_reduce_dpp(int op, T v, T identity) {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "DPP reduction handles 4- and 8-byte types");
+  v = apply_binop<T, FULL>(op, dpp_move_t<T, 0xB1, 0xf>(v), v);     // quad_perm [1,0,3,2]
+  v = apply_binop<T, FULL>(op, dpp_move_t<T, 0x4E, 0xf>(v), v);     // quad_perm [2,3,0,1]
+  v = apply_binop<T, FULL>(op, dpp_move_t<T, 0x124, 0xf>(v), v);    // row_ror:4
+  v = apply_binop<T, FULL>(op, dpp_move_t<T, 0x128, 0xf>(v), v);    // row_ror:8   -> every lane of a 16-lane row holds the row total
+  {                                                                 // row_bcast:15 into rows 1 and 3 (others must not change)
+    const T m = dpp_move_t<T, 0x142, 0xa>(v);
+    const int row = (threadIdx.x >> 4) & 3;
+    if (row == 1 || row == 3) v = apply_binop<T, FULL>(op, m, v);
+  }
+  {                                                                 // row_bcast:31 into rows 2 and 3
+    const T m = dpp_move_t<T, 0x143, 0xc>(v);
+    const int row = (threadIdx.x >> 4) & 3;
+    if (row >= 2) v = apply_binop<T, FULL>(op, m, v);
+  }
+  (void)identity;
+  if constexpr (sizeof(T) == 8) {
+    union { T t; uint32_t u[2]; } a, r; a.t = v;
+    r.u[0] = (uint32_t)__builtin_amdgcn_readlane((int)a.u[0], 63); r.u[1] = (uint32_t)__builtin_amdgcn_readlane((int)a.u[1], 63); return r.t;
+  } else {
+    union { T t; uint32_t u; } a, r; a.u = 0; a.t = v; r.u = (uint32_t)__builtin_amdgcn_readlane((int)a.u, 63); return r.t;
+  }
+}
+
 // sub-wave (power-of-two group of G lanes) reduction; result valid in the group's lane 0
 template <class T, int G, bool FULL = true> __device__ __forceinline__ T group_reduce_op(int op, T v) {
 #pragma unroll

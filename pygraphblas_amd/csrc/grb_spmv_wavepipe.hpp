@@ -5,9 +5,10 @@
 // a 128-byte L2->L1 line fill for 8 useful bytes (66 M L1->L2 requests per launch), and kernel A's phases add up
 // instead of overlapping (stream-only 0.22 ms + gather 0.36 ms).  Kernel W attacks both:
 //   * hot table: columns are ranked by how often they occur; the H most frequent (H*sizeof(T) = 96 KiB of the CU's
-//     160 KiB LDS) are staged in LDS once per workgroup.  The plan keeps a remapped column array
-//     pcol = rank (< H) for hot columns, H + col otherwise, so a hot gather is one ds_read and never reaches L1/L2
-//     (≈ 40 % of all gathers at R-MAT-22).  u itself is not permuted.
+//     160 KiB LDS) are staged in LDS once per workgroup.  The plan keeps the column array re-labelled by rank
+//     (pcol = rank of the column) and every call first writes u in rank order (one 3n-word pass, ~4 % of the
+//     kernel): a hot gather is one ds_read and never reaches L1/L2 (≈ 40 % of all gathers at R-MAT-22), and the
+//     remaining gathers find frequently used entries packed into the same 128-byte lines (-25 % L2 misses).
 //   * one 1024-thread workgroup per CU, each WAVE runs its own software pipeline over a contiguous range of
 //     512-entry tasks (merge-style: tasks split the entry range evenly, rows are found with a per-task row index):
 //     the coalesced col/val loads of task t+1 are in flight while task t gathers, multiplies into the wave's
@@ -31,6 +32,10 @@ constexpr int WP_LDS_BYTES = 160 * 1024;
 template <class T> struct wp_hot { static constexpr int H = (WP_LDS_BYTES - WP_WAVES * WP_ENT * (int)sizeof(T)) / (int)sizeof(T); };   // 12288 (8 B) / 24576 (4 B)
 constexpr uint32_t WP_NONE = 0xFFFFFFFFu;
 
+template <class T> __device__ __forceinline__ T wp_wave_total(int op, T v, T identity) {
+  if constexpr (sizeof(T) >= 4) return wave_reduce_dpp<T, false>(op, v, identity); else return wave_reduce_op<T, false>(op, v);
+}
+
 template <class T> struct WpCarry {           // per wave: partial of the row it entered in the middle of / left open
   uint32_t head_row, tail_row; uint8_t head_has, head_done, tail_has, pad; T head_val, tail_val;
 };
@@ -52,7 +57,7 @@ __global__ __launch_bounds__(WP_WAVES * 64, 1) void k_spmv_wavepipe(const WpArgs
   __shared__ T s_prod[WP_WAVES][WP_ENT];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const bool use_a = sr.uses_a(), use_u = sr.uses_u();
-  if (use_u) for (uint32_t h = threadIdx.x; h < a.nhot; h += WP_WAVES * 64) s_hot[h] = a.x[a.hot_cols[h]];
+  if (use_u) for (uint32_t h = threadIdx.x; h < a.nhot; h += WP_WAVES * 64) s_hot[h] = a.x[h];      // x is the rank-permuted copy of u
   __syncthreads();
   T* prod = s_prod[wv];
   const uint32_t gw = blockIdx.x * WP_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane(wv);
@@ -102,12 +107,9 @@ __global__ __launch_bounds__(WP_WAVES * 64, 1) void k_spmv_wavepipe(const WpArgs
 #pragma unroll
       for (int u = 0; u < WP_PER; u++) {
         if (use_u) {
-          const uint32_t c = cA[u];
-          const uint32_t cc = c & 0x7FFFFFFFu;
-          const uint32_t cg = cc >= (uint32_t)H ? cc - H : 0u;        // not hot: original column index
-          T g;
-          if (c >> 31) g = ld<1>(&a.x[cg]); else g = a.x[cg];         // rare columns: non-temporal, do not displace warm lines of u in L2
-          uv[u] = cc < (uint32_t)H ? s_hot[cc < (uint32_t)H ? cc : 0] : g;
+          const uint32_t c = cA[u];                                   // column RANK (0 = most frequent)
+          const T g = a.x[c >= (uint32_t)H ? c : 0u];                 // not hot: gather from the rank-ordered copy of u (L2 / HBM)
+          uv[u] = c < (uint32_t)H ? s_hot[c < (uint32_t)H ? c : 0] : g;
         } else uv[u] = T();
       }
 #pragma unroll
@@ -126,14 +128,18 @@ __global__ __launch_bounds__(WP_WAVES * 64, 1) void k_spmv_wavepipe(const WpArgs
         const uint32_t qs = rs_ - e0, qe = re_ - e0;
         const bool longrow = qe - qs > (uint32_t)WP_SHORT;
         T acc = sr.identity; bool has = false;
-        if (!longrow) for (uint32_t q = qs; q < qe; q++) { acc = has ? sr.add(acc, prod[q]) : prod[q]; has = true; }
+        if (!longrow && qe > qs) {                               // entry order kept; 4 LDS reads in flight per step
+          uint32_t q = qs; acc = prod[q++]; has = true;
+          for (; q + 4 <= qe; q += 4) { const T p0 = prod[q], p1 = prod[q + 1], p2 = prod[q + 2], p3 = prod[q + 3]; acc = sr.add(sr.add(sr.add(sr.add(acc, p0), p1), p2), p3); }
+          for (; q < qe; q++) acc = sr.add(acc, prod[q]);
+        }
         unsigned long long lm = __ballot(longrow);
         while (lm) {
           const int j = __builtin_ctzll(lm); lm &= lm - 1;
           const uint32_t js = __shfl(qs, j, 64), je = __shfl(qe, j, 64);
           T pa = sr.identity; bool ph = false;
           for (uint32_t q = js + lane; q < je; q += 64) { pa = ph ? sr.add(pa, prod[q]) : prod[q]; ph = true; }
-          const T tot = wave_reduce_op<T, false>(sr.add_op(), ph ? pa : sr.identity);
+          const T tot = wp_wave_total<T>(sr.add_op(), ph ? pa : sr.identity, sr.identity);
           if (lane == j) { acc = tot; has = true; }
         }
         if (rbase == 0 && lane == 0 && carry_has) { acc = has ? sr.add(carry, acc) : carry; has = true; }   // carried part comes first
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(WP_WAVES * 64, 1) void k_spmv_wavepipe(const WpArgs
       if (tail_start < cnt) {
         T pa = sr.identity; bool ph = false;
         for (uint32_t q = tail_start + lane; q < cnt; q += 64) { pa = ph ? sr.add(pa, prod[q]) : prod[q]; ph = true; }
-        const T tot = wave_reduce_op<T, false>(sr.add_op(), ph ? pa : sr.identity);
+        const T tot = wp_wave_total<T>(sr.add_op(), ph ? pa : sr.identity, sr.identity);
         carry = carry_has ? sr.add(carry, tot) : tot; carry_has = true;
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_wave_barrier();   // LDS slice is free for the next task
@@ -210,11 +216,9 @@ static __global__ void k_wp_neg_keys(const uint32_t* __restrict__ cnt, uint32_t 
 static __global__ void k_wp_rank(const uint32_t* __restrict__ sorted_id, uint32_t n, uint32_t* __restrict__ rank) {
   for (uint32_t h = blockIdx.x * 256 + threadIdx.x; h < n; h += gridDim.x * 256) rank[sorted_id[h]] = h;
 }
-static __global__ void k_wp_remap(const uint32_t* __restrict__ col, uint64_t nnz, const uint32_t* __restrict__ rank, uint32_t H, uint32_t cold_rank, uint32_t* __restrict__ pcol) {
+static __global__ void k_wp_remap(const uint32_t* __restrict__ col, uint64_t nnz, const uint32_t* __restrict__ rank, uint32_t* __restrict__ pcol) {
   for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < nnz; p += gridDim.x * 256ull) {
-    const uint32_t c = col[p]; const uint32_t r = rank[c];
-    // hot: the rank itself; otherwise H + column, with the top bit set for columns too rare to be worth an L2 line
-    pcol[p] = r < H ? r : ((c + H) | (r >= cold_rank ? 0x80000000u : 0u));
+    pcol[p] = rank[col[p]];
   }
 }
 
@@ -231,26 +235,31 @@ template <class T> void build_wavepipe_plan(DevCSR& M) {
   hipLaunchKernelGGL(k_wp_neg_keys, dim3(grid_n(n)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, key.as<uint32_t>(), id.as<uint32_t>());
   sort_pairs_u32(key.as<uint32_t>(), key2.as<uint32_t>(), id.as<uint32_t>(), id2.as<uint32_t>(), n, 32);
   const uint32_t nhot = n < H ? n : H;
-  M.wp_hot.alloc((size_t)H * 4);
-  GRB_HIP(hipMemcpyAsync(M.wp_hot.p, id2.p, (size_t)nhot * 4, hipMemcpyDeviceToDevice, stream()));
+  M.wp_hot.alloc((size_t)n * 4 + 4);                  // order[rank] = original column, all n ranks
+  GRB_HIP(hipMemcpyAsync(M.wp_hot.p, id2.p, (size_t)n * 4, hipMemcpyDeviceToDevice, stream()));
   GRB_HIP(hipMemsetAsync(rank.p, 0xFF, (size_t)n * 4 + 4, stream()));
   hipLaunchKernelGGL(k_wp_rank, dim3(grid_n(n)), dim3(256), 0, stream(), id2.as<uint32_t>(), n, rank.as<uint32_t>());
-  // columns ranked beyond what one XCD's 4 MiB L2 can hold of u are gathered with a non-temporal hint
-  const char* ecr = getenv("GRB_MI355X_COLD_RANK");
-  const uint32_t cold_rank = ecr ? (uint32_t)atoll(ecr) : (uint32_t)((3u << 20) / sizeof(T));
   M.wp_pcol.alloc(M.nnz * 4 + 4);
-  hipLaunchKernelGGL(k_wp_remap, dim3(grid_n(M.nnz)), dim3(256), 0, stream(), M.col.as<uint32_t>(), M.nnz, rank.as<uint32_t>(), H, cold_rank, M.wp_pcol.as<uint32_t>());
+  hipLaunchKernelGGL(k_wp_remap, dim3(grid_n(M.nnz)), dim3(256), 0, stream(), M.col.as<uint32_t>(), M.nnz, rank.as<uint32_t>(), M.wp_pcol.as<uint32_t>());
   M.wp_nhot = nhot; M.wp_ntasks = ntasks; M.wp_tsize = (int)sizeof(T);
   GRB_HIP(hipStreamSynchronize(stream()));
+}
+
+template <class T> __global__ void k_wp_permute(const T* __restrict__ x, const uint32_t* __restrict__ order, uint32_t n, T* __restrict__ xp) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) xp[i] = x[order[i]];
 }
 
 template <class T> bool run_wavepipe(const SpmvCall& c, const SemiringDesc& d, int ncu) {
   DevCSR& M = *c.M;
   if (M.wp_tsize != (int)sizeof(T)) build_wavepipe_plan<T>(M);
+  // u in column-rank order: frequently used entries share cache lines (and the first H of them are the LDS table)
+  DevBuf xp((size_t)M.ncols * sizeof(T) + 8);
+  const bool uses_u = d.flip ? binop_uses_x(d.mulop) : binop_uses_y(d.mulop);
+  if (uses_u) hipLaunchKernelGGL((k_wp_permute<T>), dim3(2048), dim3(256), 0, stream(), (const T*)c.uval, M.wp_hot.as<uint32_t>(), M.ncols, xp.as<T>());
   const uint32_t nwaves = (uint32_t)ncu * WP_WAVES;
   const uint32_t tpw = (M.wp_ntasks + nwaves - 1) / nwaves;
   if (M.wp_carry.bytes < (size_t)nwaves * sizeof(WpCarry<T>)) M.wp_carry.alloc((size_t)nwaves * sizeof(WpCarry<T>));
-  WpArgs<T> a{M.rowptr.as<uint32_t>(), M.wp_pcol.as<uint32_t>(), (const T*)c.aval, (const T*)c.uval, M.wp_hot.as<uint32_t>(), M.wp_rs.as<uint32_t>(), M.wp_rs.as<uint32_t>() + (M.wp_ntasks + 1),
+  WpArgs<T> a{M.rowptr.as<uint32_t>(), M.wp_pcol.as<uint32_t>(), (const T*)c.aval, (const T*)xp.p, M.wp_hot.as<uint32_t>(), M.wp_rs.as<uint32_t>(), M.wp_rs.as<uint32_t>() + (M.wp_ntasks + 1),
               (T*)c.tval, c.tpres, M.wp_carry.as<WpCarry<T>>(), M.nrows, M.wp_ntasks, (uint32_t)M.nnz, tpw, M.wp_nhot};
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;

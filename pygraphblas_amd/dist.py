@@ -40,10 +40,19 @@ def rmat_expected_row_prefix(scale, nparts_hint=0):
     return (prefix * (1 << 40)).astype(np.int64)
 
 
-def allgatherv_into(full, mine, bounds, rank, world, dist):
-    """full[bounds[p]:bounds[p+1]] <- rank p's `mine` for every p (tensors on this rank's device)."""
+def allgatherv_into(full, mine, bounds, rank, world, dist, mode=None):
+    """full[bounds[p]:bounds[p+1]] <- rank p's `mine` for every p (tensors on this rank's device).
+
+    mode "p2p" (default): grouped isend/irecv — every pair of ranks exchanges directly (one xGMI hop on MI355X).
+    mode "broadcast": one broadcast per rank — slower, but available on every backend (used for the gloo smoke runs)."""
+    import os
+    mode = mode or os.environ.get("GRB_DIST_ALLGATHER", "p2p")
     full[bounds[rank]:bounds[rank + 1]].copy_(mine)
     if world == 1:
+        return
+    if mode == "broadcast":
+        for p in range(world):
+            dist.broadcast(full[bounds[p]:bounds[p + 1]], src=p)
         return
     ops = []
     for peer in range(world):

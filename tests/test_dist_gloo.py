@@ -27,6 +27,9 @@ def _worker(rank, world, port, q):
     full = torch.zeros(n, dtype=torch.float64)
     gdist.allgatherv_into(full, x_all[r0:r1].clone(), bounds, rank, world, dist)
     assert torch.equal(full, x_all)
+    full2 = torch.zeros(n, dtype=torch.float64)
+    gdist.allgatherv_into(full2, x_all[r0:r1].clone(), bounds, rank, world, dist, mode="broadcast")
+    assert torch.equal(full2, x_all)
     # local row block times the gathered vector == the matching rows of the global product
     val = rmat.values_numpy(len(col), seed=43 + rank)
     import scipy.sparse as sp
