@@ -98,7 +98,7 @@ struct DevCSR {
   DevBuf plan_blocks; uint32_t plan_nblocks = 0; DevBuf plan_aux; uint32_t plan_nlong = 0;
   bool has_plan = false;
   // kernel-W plan (grb_spmv_wavepipe.hpp): per-task first row, hot-column list, remapped column array, per-wave carries
-  DevBuf wp_rs, wp_hot, wp_pcol, wp_carry; uint32_t wp_nhot = 0, wp_ntasks = 0; int wp_tsize = 0;
+  DevBuf wp_rs, wp_hot, wp_pcol, wp_carry; uint32_t wp_nhot = 0, wp_ntasks = 0, wp_nwarm = 0; int wp_tsize = 0;
   bool valid = false;
   void clear() { rowptr.reset(); col.reset(); val.reset(); plan_blocks.reset(); plan_aux.reset();
                  wp_rs.reset(); wp_hot.reset(); wp_pcol.reset(); wp_carry.reset(); wp_nhot = wp_ntasks = 0; wp_tsize = 0;

@@ -41,9 +41,9 @@ template <class T> struct WpCarry {           // per wave: partial of the row it
 };
 
 template <class T> struct WpArgs {
-  const uint32_t* rowptr; const uint32_t* pcol; const T* aval; const T* x; const uint32_t* hot_cols;
+  const uint32_t* rowptr; const uint32_t* pcol; const T* aval; const T* x; const T* xorig; const uint32_t* hot_cols;
   const uint32_t* trow; const uint32_t* tent;      // merge-path task starts: task t begins at (row trow[t], entry tent[t]); [ntasks+1]
-  T* y; uint8_t* ypres; WpCarry<T>* carry; uint32_t nrows, ntasks, nnz, tasks_per_wave, nhot;
+  T* y; uint8_t* ypres; WpCarry<T>* carry; uint32_t nrows, ntasks, nnz, tasks_per_wave, nhot, nwarm;
 };
 
 // Tasks are equal slices of the merge of {entries} and {row ends} (WP_ENT items each), so a task holds at most WP_ENT
@@ -107,8 +107,9 @@ __global__ __launch_bounds__(WP_WAVES * 64, 1) void k_spmv_wavepipe(const WpArgs
 #pragma unroll
       for (int u = 0; u < WP_PER; u++) {
         if (use_u) {
-          const uint32_t c = cA[u];                                   // column RANK (0 = most frequent)
-          const T g = a.x[c >= (uint32_t)H ? c : 0u];                 // not hot: gather from the rank-ordered copy of u (L2 / HBM)
+          const uint32_t c = cA[u];                                   // rank of the column if < nwarm (0 = most frequent), else nwarm + column
+          const T* base = c < a.nwarm ? a.x : a.xorig - a.nwarm;      // warm: rank-ordered copy of the top of u; cold: u itself
+          const T g = base[c >= (uint32_t)H ? c : 0u];
           uv[u] = c < (uint32_t)H ? s_hot[c < (uint32_t)H ? c : 0] : g;
         } else uv[u] = T();
       }
@@ -216,9 +217,10 @@ static __global__ void k_wp_neg_keys(const uint32_t* __restrict__ cnt, uint32_t 
 static __global__ void k_wp_rank(const uint32_t* __restrict__ sorted_id, uint32_t n, uint32_t* __restrict__ rank) {
   for (uint32_t h = blockIdx.x * 256 + threadIdx.x; h < n; h += gridDim.x * 256) rank[sorted_id[h]] = h;
 }
-static __global__ void k_wp_remap(const uint32_t* __restrict__ col, uint64_t nnz, const uint32_t* __restrict__ rank, uint32_t* __restrict__ pcol) {
+static __global__ void k_wp_remap(const uint32_t* __restrict__ col, uint64_t nnz, const uint32_t* __restrict__ rank, uint32_t nwarm, uint32_t* __restrict__ pcol) {
   for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < nnz; p += gridDim.x * 256ull) {
-    pcol[p] = rank[col[p]];
+    const uint32_t c = col[p], r = rank[c];
+    pcol[p] = r < nwarm ? r : nwarm + c;
   }
 }
 
@@ -234,13 +236,18 @@ template <class T> void build_wavepipe_plan(DevCSR& M) {
   hipLaunchKernelGGL(k_wp_col_hist, dim3(grid_n(M.nnz)), dim3(256), 0, stream(), M.col.as<uint32_t>(), M.nnz, cnt.as<uint32_t>());
   hipLaunchKernelGGL(k_wp_neg_keys, dim3(grid_n(n)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, key.as<uint32_t>(), id.as<uint32_t>());
   sort_pairs_u32(key.as<uint32_t>(), key2.as<uint32_t>(), id.as<uint32_t>(), id2.as<uint32_t>(), n, 32);
-  const uint32_t nhot = n < H ? n : H;
-  M.wp_hot.alloc((size_t)n * 4 + 4);                  // order[rank] = original column, all n ranks
-  GRB_HIP(hipMemcpyAsync(M.wp_hot.p, id2.p, (size_t)n * 4, hipMemcpyDeviceToDevice, stream()));
+  const uint32_t nhot = n < H ? n : H;   // (nwarm >= nhot always: H*sizeof(T) <= 96 KiB)
+  // the `nwarm` most frequent columns (two XCD-L2s' worth of u) are gathered from a rank-ordered copy made per call;
+  // rarer ones straight from u
+  const uint32_t nwarm_cap = (uint32_t)((8u << 20) / sizeof(T));
+  const uint32_t nwarm = n < nwarm_cap ? n : nwarm_cap;
+  M.wp_hot.alloc((size_t)nwarm * 4 + 4);               // order[rank] = original column for rank < nwarm
+  GRB_HIP(hipMemcpyAsync(M.wp_hot.p, id2.p, (size_t)nwarm * 4, hipMemcpyDeviceToDevice, stream()));
+  M.wp_nwarm = nwarm;
   GRB_HIP(hipMemsetAsync(rank.p, 0xFF, (size_t)n * 4 + 4, stream()));
   hipLaunchKernelGGL(k_wp_rank, dim3(grid_n(n)), dim3(256), 0, stream(), id2.as<uint32_t>(), n, rank.as<uint32_t>());
   M.wp_pcol.alloc(M.nnz * 4 + 4);
-  hipLaunchKernelGGL(k_wp_remap, dim3(grid_n(M.nnz)), dim3(256), 0, stream(), M.col.as<uint32_t>(), M.nnz, rank.as<uint32_t>(), M.wp_pcol.as<uint32_t>());
+  hipLaunchKernelGGL(k_wp_remap, dim3(grid_n(M.nnz)), dim3(256), 0, stream(), M.col.as<uint32_t>(), M.nnz, rank.as<uint32_t>(), nwarm, M.wp_pcol.as<uint32_t>());
   M.wp_nhot = nhot; M.wp_ntasks = ntasks; M.wp_tsize = (int)sizeof(T);
   GRB_HIP(hipStreamSynchronize(stream()));
 }
@@ -253,14 +260,14 @@ template <class T> bool run_wavepipe(const SpmvCall& c, const SemiringDesc& d, i
   DevCSR& M = *c.M;
   if (M.wp_tsize != (int)sizeof(T)) build_wavepipe_plan<T>(M);
   // u in column-rank order: frequently used entries share cache lines (and the first H of them are the LDS table)
-  DevBuf xp((size_t)M.ncols * sizeof(T) + 8);
+  DevBuf xp((size_t)M.wp_nwarm * sizeof(T) + 8);
   const bool uses_u = d.flip ? binop_uses_x(d.mulop) : binop_uses_y(d.mulop);
-  if (uses_u) hipLaunchKernelGGL((k_wp_permute<T>), dim3(2048), dim3(256), 0, stream(), (const T*)c.uval, M.wp_hot.as<uint32_t>(), M.ncols, xp.as<T>());
+  if (uses_u) hipLaunchKernelGGL((k_wp_permute<T>), dim3(2048), dim3(256), 0, stream(), (const T*)c.uval, M.wp_hot.as<uint32_t>(), M.wp_nwarm, xp.as<T>());
   const uint32_t nwaves = (uint32_t)ncu * WP_WAVES;
   const uint32_t tpw = (M.wp_ntasks + nwaves - 1) / nwaves;
   if (M.wp_carry.bytes < (size_t)nwaves * sizeof(WpCarry<T>)) M.wp_carry.alloc((size_t)nwaves * sizeof(WpCarry<T>));
-  WpArgs<T> a{M.rowptr.as<uint32_t>(), M.wp_pcol.as<uint32_t>(), (const T*)c.aval, (const T*)xp.p, M.wp_hot.as<uint32_t>(), M.wp_rs.as<uint32_t>(), M.wp_rs.as<uint32_t>() + (M.wp_ntasks + 1),
-              (T*)c.tval, c.tpres, M.wp_carry.as<WpCarry<T>>(), M.nrows, M.wp_ntasks, (uint32_t)M.nnz, tpw, M.wp_nhot};
+  WpArgs<T> a{M.rowptr.as<uint32_t>(), M.wp_pcol.as<uint32_t>(), (const T*)c.aval, (const T*)xp.p, (const T*)c.uval, M.wp_hot.as<uint32_t>(), M.wp_rs.as<uint32_t>(), M.wp_rs.as<uint32_t>() + (M.wp_ntasks + 1),
+              (T*)c.tval, c.tpres, M.wp_carry.as<WpCarry<T>>(), M.nrows, M.wp_ntasks, (uint32_t)M.nnz, tpw, M.wp_nhot, M.wp_nwarm};
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;
     hipLaunchKernelGGL((k_spmv_wavepipe<T, SR>), dim3(ncu), dim3(WP_WAVES * 64), 0, stream(), a, sr);
