@@ -1,0 +1,152 @@
+"""GPU tests of the O(n) / O(nnz) operations around the hot path (SURVEY.md §8f "next" rows 1-3): eWiseAdd/eWiseMult,
+apply, select (tril/triu/offdiag/value tests), transpose, reduce to vector / scalar, assign_scalar, bulk CSR import/export,
+typecasts — against numpy / scipy computed on the host.  Integer results bit-exact; FP on a 1/8 grid (exact)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import pygraphblas_amd as gb
+from pygraphblas_amd import descriptor as D
+from helpers import TYPE, rand_matrix, rand_vector, to_matrix, to_vector
+
+pytestmark = pytest.mark.gpu
+
+
+def dense_m(t):
+    d = np.zeros((t.nrows, t.ncols), dtype=t.X.dtype); p = np.zeros((t.nrows, t.ncols), bool)
+    d[t.I.astype(int), t.J.astype(int)] = t.X; p[t.I.astype(int), t.J.astype(int)] = True
+    return d, p
+
+
+def got_m(m):
+    I, J, X = m.to_arrays()
+    d = np.zeros(m.shape, dtype=X.dtype); p = np.zeros(m.shape, bool)
+    d[I.astype(int), J.astype(int)] = X; p[I.astype(int), J.astype(int)] = True
+    return d, p
+
+
+def got_v(v):
+    return v.to_dense_arrays()
+
+
+@pytest.mark.parametrize("typ", ["INT64", "FP64", "INT8", "UINT16", "FP32", "BOOL"])
+def test_matrix_ewise_union_and_intersection(gpu, typ):
+    rng = np.random.default_rng(1)
+    A, B = rand_matrix(rng, typ, 40, 30, 0.3), rand_matrix(rng, typ, 40, 30, 0.3)
+    da, pa = dense_m(A); db, pb = dense_m(B)
+    T = TYPE[typ]
+    add = T.LOR if typ == "BOOL" else T.PLUS
+    mul = T.LAND if typ == "BOOL" else T.TIMES
+    with np.errstate(over="ignore"):
+        u = np.where(pa & pb, (da | db) if typ == "BOOL" else (da + db).astype(da.dtype), np.where(pa, da, db))
+        i = (da & db) if typ == "BOOL" else (da * db).astype(da.dtype)
+    g, p = got_m(to_matrix(A).eadd(to_matrix(B), add))
+    assert np.array_equal(p, pa | pb) and np.array_equal(g[p], u[p])
+    g, p = got_m(to_matrix(A).emult(to_matrix(B), mul))
+    assert np.array_equal(p, pa & pb) and np.array_equal(g[p], i[p])
+    # masked, complemented, with accum into an existing matrix
+    Cm, M = rand_matrix(rng, typ, 40, 30, 0.3), rand_matrix(rng, "BOOL", 40, 30, 0.5)
+    dc, pc = dense_m(Cm); dm, pm = dense_m(M)
+    out = to_matrix(Cm)
+    to_matrix(A).emult(to_matrix(B), mul, out=out, mask=to_matrix(M), accum=add, desc=D.C)
+    allow = ~(pm & dm.astype(bool))
+    tp = pa & pb
+    with np.errstate(over="ignore"):
+        z = np.where(pc & tp, (dc | i) if typ == "BOOL" else (dc + i).astype(dc.dtype), np.where(tp, i, dc))
+    zp = pc | tp
+    exp_p = np.where(allow, zp, pc); exp = np.where(allow, z, dc)
+    g, p = got_m(out)
+    assert np.array_equal(p, exp_p) and np.array_equal(g[p], exp[p])
+
+
+def test_select_transpose_pattern_reduce_vector(gpu):
+    rng = np.random.default_rng(2)
+    A = rand_matrix(rng, "INT64", 50, 50, 0.2)
+    d, p = dense_m(A); m = to_matrix(A)
+    for name, keep in (("tril", np.tril(np.ones((50, 50), bool))), ("triu", np.triu(np.ones((50, 50), bool))), ("offdiag", ~np.eye(50, dtype=bool))):
+        g, gp = got_m(getattr(m, name)())
+        assert np.array_equal(gp, p & keep) and np.array_equal(g[gp], d[gp])
+    g, gp = got_m(m.tril(-1)); assert np.array_equal(gp, p & np.tril(np.ones((50, 50), bool), -1))
+    g, gp = got_m(m.select(">", 10)); assert np.array_equal(gp, p & (d > 10))
+    g, gp = got_m(m.select("==0")); assert np.array_equal(gp, p & (d == 0))
+    g, gp = got_m(m.nonzero()); assert np.array_equal(gp, p & (d != 0))
+    g, gp = got_m(m.transpose()); assert np.array_equal(gp, p.T) and np.array_equal(g[gp], d.T[gp])
+    g, gp = got_m(m.T.T); assert np.array_equal(gp, p) and np.array_equal(g[gp], d[gp])
+    g, gp = got_m(m.pattern()); assert np.array_equal(gp, p) and g[gp].all()
+    rv, rp = got_v(m.reduce_vector())
+    assert np.array_equal(rp.astype(bool), p.any(1)) and np.array_equal(rv[rp != 0], np.where(p, d, 0).sum(1)[p.any(1)])
+    rv, rp = got_v(m.reduce_vector(gb.INT64.MAX_MONOID, desc=D.T0))
+    assert np.array_equal(rp.astype(bool), p.any(0)) and np.array_equal(rv[rp != 0], np.where(p, d, -2**62).max(0)[p.any(0)])
+    assert m.reduce_int() == int(np.where(p, d, 0).sum()) and m.reduce_int(gb.INT64.MIN_MONOID) == int(d[p].min())
+    assert gb.Matrix.sparse(gb.INT64, 5, 5).reduce_int() == 0
+
+
+def test_matrix_apply_and_bound_scalars(gpu):
+    rng = np.random.default_rng(3)
+    A = rand_matrix(rng, "FP64", 30, 20, 0.3); d, p = dense_m(A); m = to_matrix(A)
+    g, gp = got_m(m.apply(gb.FP64.AINV)); assert np.array_equal(gp, p) and np.array_equal(g[gp], -d[gp])
+    g, gp = got_m(m.apply(gb.FP64.ABS)); assert np.array_equal(g[gp], np.abs(d[gp]))
+    import ctypes as C
+    out = gb.Matrix.sparse(gb.FP64, 30, 20)
+    gb.base.check(gb.lib.GxB_Matrix_apply_BinaryOp2nd_FP64(out._h, None, None, C.c_void_p(gb.FP64.TIMES.get_op()), m._h, C.c_double(2.5), None), out)
+    g, gp = got_m(out); assert np.array_equal(g[gp], d[gp] * 2.5)
+    gb.base.check(gb.lib.GxB_Matrix_apply_BinaryOp1st_FP64(out._h, None, None, C.c_void_p(gb.FP64.MINUS.get_op()), C.c_double(1.0), m._h, None), out)
+    g, gp = got_m(out); assert np.array_equal(g[gp], 1.0 - d[gp])
+    # GrB_Matrix_assign_<T> over a row/column block, no mask
+    I = np.array([1, 3], np.uint64); J = np.array([0, 2, 4], np.uint64)
+    gb.base.check(gb.lib.GrB_Matrix_assign_FP64(m._h, None, None, C.c_double(9.0), I.ctypes.data_as(C.c_void_p), C.c_uint64(2), J.ctypes.data_as(C.c_void_p), C.c_uint64(3), None), m)
+    e = d.copy(); ep = p.copy(); e[np.ix_([1, 3], [0, 2, 4])] = 9.0; ep[np.ix_([1, 3], [0, 2, 4])] = True
+    g, gp = got_m(m); assert np.array_equal(gp, ep) and np.array_equal(g[gp], e[gp])
+
+
+@pytest.mark.parametrize("typ", ["INT32", "FP32", "UINT8"])
+def test_vector_ops(gpu, typ):
+    rng = np.random.default_rng(4); n = 5000; T = TYPE[typ]
+    ui, ux = rand_vector(rng, typ, n, 0.5); vi, vx = rand_vector(rng, typ, n, 0.5)
+    u, v = to_vector(typ, n, ui, ux), to_vector(typ, n, vi, vx)
+    du = np.zeros(n, ux.dtype); pu = np.zeros(n, bool); du[ui.astype(int)] = ux; pu[ui.astype(int)] = True
+    dv = np.zeros(n, vx.dtype); pv = np.zeros(n, bool); dv[vi.astype(int)] = vx; pv[vi.astype(int)] = True
+    with np.errstate(over="ignore"):
+        s = (du + dv).astype(du.dtype); dmm = (du - dv).astype(du.dtype); pr = (du * dv).astype(du.dtype)
+    g, p = got_v(u + v); assert np.array_equal(p.astype(bool), pu | pv) and np.array_equal(g[p != 0], np.where(pu & pv, s, np.where(pu, du, dv))[pu | pv])
+    g, p = got_v(u - v); assert np.array_equal(g[p != 0], np.where(pu & pv, dmm, np.where(pu, du, dv))[pu | pv])
+    g, p = got_v(u * v); assert np.array_equal(p.astype(bool), pu & pv) and np.array_equal(g[p != 0], pr[pu & pv])
+    g, p = got_v(u.emult(v, T.MIN)); assert np.array_equal(g[p != 0], np.minimum(du, dv)[pu & pv])
+    w = u.dup(); w -= v
+    g, p = got_v(w); assert np.array_equal(g[p != 0], np.where(pu & pv, dmm, np.where(pu, du, dv))[pu | pv])
+    g, p = got_v(abs(u)); assert np.array_equal(g[p != 0], np.abs(du[pu]))
+    g, p = got_v(u.apply_second(T.PLUS, 3)); assert np.array_equal(g[p != 0], (du[pu] + du.dtype.type(3)).astype(du.dtype))
+    # assign_scalar: all, masked (valued mask), with accum
+    w = u.dup(); w.assign_scalar(7); g, p = got_v(w); assert p.all() and (g == 7).all()
+    w = u.dup(); w.assign_scalar(5, mask=v)
+    g, p = got_v(w); m = pv & (dv != 0)
+    assert np.array_equal(p.astype(bool), pu | m) and np.array_equal(g[p != 0], np.where(m, 5, du)[pu | m])
+    w = u.dup(); w.assign_scalar(2, accum=T.PLUS)
+    g, p = got_v(w); assert p.all() and np.array_equal(g, np.where(pu, (du + du.dtype.type(2)).astype(du.dtype), 2))
+    w = u.dup(); w.assign_scalar(1, index=[3, 4, 5])
+    g, p = got_v(w); e = du.copy(); ep = pu.copy(); e[3:6] = 1; ep[3:6] = True
+    assert np.array_equal(p.astype(bool), ep) and np.array_equal(g[p != 0], e[ep])
+    # reductions
+    if typ != "UINT8":
+        assert u.reduce_int() == int(du[pu].astype(np.int64).sum()) if typ == "INT32" else abs(u.reduce_float() - float(du[pu].astype(np.float64).sum())) < 1e-3
+    assert u.reduce_bool() == bool((du[pu] != 0).any())
+    assert gb.Vector.sparse(T, 10).reduce_bool() is False
+
+
+def test_bulk_csr_roundtrip_and_scipy(gpu):
+    rng = np.random.default_rng(6)
+    S = sp.random(300, 200, density=0.05, format="csr", random_state=7, dtype=np.float64)
+    S.sort_indices()
+    m = gb.Matrix.from_scipy_sparse(S)
+    assert m.nvals == S.nnz and m.type is gb.FP64
+    rp, ci, x = m.to_csr()
+    assert np.array_equal(rp, S.indptr.astype(np.uint32)) and np.array_equal(ci, S.indices.astype(np.uint32)) and np.array_equal(x, S.data)
+    x0 = rng.random(200)
+    y = m.mxv(gb.Vector.from_dense_array(x0, gb.FP64), semiring=gb.FP64.PLUS_TIMES)
+    yv, yp = y.to_dense_arrays()
+    assert np.allclose(yv[yp != 0], (S @ x0)[yp != 0], rtol=1e-12) and np.array_equal(yp.astype(bool), np.diff(S.indptr) > 0)
+    assert (m.to_scipy_sparse() != S).nnz == 0
+    # build with tuples given in arbitrary order == import of the sorted CSR
+    perm = rng.permutation(S.nnz); coo = S.tocoo()
+    m2 = gb.Matrix.from_arrays(coo.row[perm].astype(np.uint64), coo.col[perm].astype(np.uint64), coo.data[perm], 300, 200, gb.FP64)
+    assert m2.iseq(m)
