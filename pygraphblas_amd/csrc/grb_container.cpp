@@ -48,7 +48,7 @@ void mat_invalidate_host(GrB_Matrix A) {
   A->host_valid = false; A->hi.clear(); A->hj.clear(); A->hx.clear(); A->pending.clear();
   A->hi.shrink_to_fit(); A->hj.shrink_to_fit(); A->hx.shrink_to_fit();
   A->csc.clear(); A->csr.has_plan = false; A->csr.plan_blocks.reset(); A->csr.plan_aux.reset();
-  A->csr.wp_rs.reset(); A->csr.wp_hot.reset(); A->csr.wp_pcol.reset(); A->csr.wp_tsize = 0;
+  A->csr.wp_rs.reset(); A->csr.wp_hot.reset(); A->csr.wp_pcol.reset(); A->csr.wp_tsize = 0; A->csr.xcd.reset();
 }
 
 void mat_to_host(GrB_Matrix A) {

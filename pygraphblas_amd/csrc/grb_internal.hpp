@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <memory>
 #include "grb_ops.hpp"
 
 typedef uint64_t GrB_Index;
@@ -99,9 +100,10 @@ struct DevCSR {
   bool has_plan = false;
   // kernel-W plan (grb_spmv_wavepipe.hpp): per-task first row, hot-column list, remapped column array, per-wave carries
   DevBuf wp_rs, wp_hot, wp_pcol, wp_carry; uint32_t wp_nhot = 0, wp_ntasks = 0, wp_nwarm = 0; int wp_tsize = 0;
+  std::shared_ptr<void> xcd;    // kernel-X plan (grb_spmv_xcd.hpp: XcdPlan), panel-major copy of the matrix
   bool valid = false;
   void clear() { rowptr.reset(); col.reset(); val.reset(); plan_blocks.reset(); plan_aux.reset();
-                 wp_rs.reset(); wp_hot.reset(); wp_pcol.reset(); wp_carry.reset(); wp_nhot = wp_ntasks = 0; wp_tsize = 0;
+                 wp_rs.reset(); wp_hot.reset(); wp_pcol.reset(); wp_carry.reset(); wp_nhot = wp_ntasks = 0; wp_tsize = 0; xcd.reset();
                  nnz = 0; has_plan = false; valid = false; plan_nblocks = plan_nlong = 0; }
 };
 

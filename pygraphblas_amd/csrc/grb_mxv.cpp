@@ -26,7 +26,7 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   SemiringDesc sd = make_semiring_desc(semiring, /*swap_mult_args=*/is_vxm);
   const char* env = getenv("GRB_MI355X_SPMV");
   int method = g_force_method;
-  if (env) method = !strcmp(env, "adaptive") ? SPMV_ADAPTIVE : !strcmp(env, "rowgroup") ? SPMV_ROWGROUP : !strcmp(env, "push") ? SPMV_PUSH : !strcmp(env, "wavepipe") ? SPMV_WAVEPIPE : SPMV_AUTO;
+  if (env) method = !strcmp(env, "adaptive") ? SPMV_ADAPTIVE : !strcmp(env, "rowgroup") ? SPMV_ROWGROUP : !strcmp(env, "push") ? SPMV_PUSH : !strcmp(env, "wavepipe") ? SPMV_WAVEPIPE : !strcmp(env, "xcd") ? SPMV_XCD : SPMV_AUTO;
   g_last_plan.clear();
 
   DevBuf allow_buf; bool nothing = false;

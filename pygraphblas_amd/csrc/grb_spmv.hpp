@@ -15,7 +15,7 @@ struct SpmvBlock { uint32_t row, aux, nparts, slot; };
 // stream block : rows [row, aux), nparts == 0
 // long-row part: row, aux = part index, nparts >= 1, slot = first partial slot of this row
 
-enum SpmvMethod { SPMV_AUTO = 0, SPMV_ADAPTIVE = 1, SPMV_ROWGROUP = 2, SPMV_PUSH = 3, SPMV_WAVEPIPE = 4 };
+enum SpmvMethod { SPMV_AUTO = 0, SPMV_ADAPTIVE = 1, SPMV_ROWGROUP = 2, SPMV_PUSH = 3, SPMV_WAVEPIPE = 4, SPMV_XCD = 5 };
 
 struct SpmvCall {
   DevCSR* M;                // pull: rows of M index the output.  push: rows of M index the input u.

@@ -39,6 +39,7 @@ template <int MODE, class T> __device__ __forceinline__ T ld(const T* p) {
 
 }  // namespace grb
 #include "grb_spmv_wavepipe.hpp"
+#include "grb_spmv_xcd.hpp"
 namespace grb {
 
 template <class T> struct SpmvKArgs {
@@ -336,7 +337,12 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
     }
     // kernel W: full operand, no mask, large matrix
     if constexpr (sizeof(T) >= 4) {
-      const bool want = c.method == SPMV_WAVEPIPE || (c.method == SPMV_AUTO && M.nnz >= (1u << 20));
+      // kernel X (one column panel per XCD) for the big ones; it keeps a panel-major copy of the matrix
+      const bool want_x = c.method == SPMV_XCD || (c.method == SPMV_AUTO && M.nnz >= (1u << 22));
+      if (want_x && full && !c.allow && M.ncols < 0x7FFFFFFFu && M.nnz >= (uint64_t)WP_ENT * 64 && device_cus() > 0) {
+        if (run_xcd<T>(c, d, device_cus())) return;
+      }
+      const bool want = c.method == SPMV_WAVEPIPE || c.method == SPMV_XCD || (c.method == SPMV_AUTO && M.nnz >= (1u << 20));
       if (want && full && !c.allow && M.ncols < 0x7FFFFFFFu && M.nnz >= (uint64_t)WP_ENT && device_cus() > 0) {
         run_wavepipe<T>(c, d, device_cus());
         return;

@@ -24,11 +24,12 @@
 
 namespace grb {
 
-constexpr int WP_ENT = 512;                 // entries per task = 8 per lane
+constexpr int WP_ENT = 512;                 // merge items per task = 8 per lane
 constexpr int WP_PER = WP_ENT / 64;
 constexpr int WP_SHORT = 24;                // rows longer than this (within one task) are reduced by the whole wave
-constexpr int WP_WAVES = 16;                // waves per workgroup (1024 threads, one workgroup per CU)
-constexpr int WP_LDS_BYTES = 160 * 1024;
+constexpr int WP_WAVES = 16;                // waves per workgroup (1024 threads)
+constexpr int WP_WGS_PER_CU = 1;            // one workgroup per CU (measured: 2 x 768 threads with 256-item tasks spills registers and is slower)
+constexpr int WP_LDS_BYTES = 160 * 1024 / WP_WGS_PER_CU;
 template <class T> struct wp_hot { static constexpr int H = (WP_LDS_BYTES - WP_WAVES * WP_ENT * (int)sizeof(T)) / (int)sizeof(T); };   // 12288 (8 B) / 24576 (4 B)
 constexpr uint32_t WP_NONE = 0xFFFFFFFFu;
 
@@ -51,7 +52,9 @@ template <class T> struct WpArgs {
 // 10^5-entry rows and long runs of empty rows).  Task t owns entries [tent[t], tent[t+1]) and completes rows
 // [trow[t], trow[t+1]); the entries of row trow[t+1] seen so far are carried to the next task.
 template <class T, class SR>
-__global__ __launch_bounds__(WP_WAVES * 64, 1) void k_spmv_wavepipe(const WpArgs<T> a, const SR sr) {
+__global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k_spmv_wavepipe(const WpArgs<T> a0, const WpArgs<T>* __restrict__ panels, const SR sr) {
+  // panel mode (kernel X, grb_spmv_xcd.hpp): workgroup b works on column panel b % 8 — the XCD it is observed to run on
+  const WpArgs<T> a = panels ? panels[blockIdx.x & 7] : a0;
   constexpr int H = wp_hot<T>::H;
   __shared__ T s_hot[H];
   __shared__ T s_prod[WP_WAVES][WP_ENT];
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(WP_WAVES * 64, 1) void k_spmv_wavepipe(const WpArgs
   if (use_u) for (uint32_t h = threadIdx.x; h < a.nhot; h += WP_WAVES * 64) s_hot[h] = a.x[h];      // x is the rank-permuted copy of u
   __syncthreads();
   T* prod = s_prod[wv];
-  const uint32_t gw = blockIdx.x * WP_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane(wv);
+  const uint32_t gw = (panels ? (blockIdx.x >> 3) : blockIdx.x) * WP_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane(wv);
   const uint32_t t0 = gw * a.tasks_per_wave;
   uint32_t t1 = t0 + a.tasks_per_wave; if (t1 > a.ntasks) t1 = a.ntasks;
   WpCarry<T> cr; cr.head_row = cr.tail_row = WP_NONE; cr.head_has = cr.head_done = cr.tail_has = cr.pad = 0; cr.head_val = cr.tail_val = sr.identity;
@@ -180,7 +183,10 @@ __global__ __launch_bounds__(WP_WAVES * 64, 1) void k_spmv_wavepipe(const WpArgs
 
 // combine the partials of rows that span several waves' ranges, in wave order
 template <class T, class SR>
-__global__ void k_spmv_wavepipe_fixup(const WpCarry<T>* __restrict__ carry, uint32_t nwaves, T* __restrict__ y, uint8_t* __restrict__ ypres, const SR sr) {
+__global__ void k_spmv_wavepipe_fixup(const WpCarry<T>* __restrict__ carry0, uint32_t nwaves, T* __restrict__ y0, uint8_t* __restrict__ ypres0,
+                                      const WpArgs<T>* __restrict__ panels, const SR sr) {
+  const WpCarry<T>* carry = panels ? panels[blockIdx.y].carry : carry0;
+  T* y = panels ? panels[blockIdx.y].y : y0; uint8_t* ypres = panels ? panels[blockIdx.y].ypres : ypres0;
   for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < nwaves; w += gridDim.x * blockDim.x) {
     const WpCarry<T> c = carry[w];
     if (c.head_row == WP_NONE || !c.head_done) continue;
@@ -208,6 +214,7 @@ static __global__ void k_wp_task_starts(const uint32_t* __restrict__ rowptr, uin
     trow[t] = lo; tent[t] = (uint32_t)(D - lo);
   }
 }
+static __global__ void k_iota_u32_wp(uint32_t* p, uint64_t n) { for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) p[i] = (uint32_t)i; }
 static __global__ void k_wp_col_hist(const uint32_t* __restrict__ col, uint64_t nnz, uint32_t* __restrict__ cnt) {
   for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < nnz; p += gridDim.x * 256ull) atomicAdd(&cnt[col[p]], 1u);
 }
@@ -263,15 +270,16 @@ template <class T> bool run_wavepipe(const SpmvCall& c, const SemiringDesc& d, i
   DevBuf xp((size_t)M.wp_nwarm * sizeof(T) + 8);
   const bool uses_u = d.flip ? binop_uses_x(d.mulop) : binop_uses_y(d.mulop);
   if (uses_u) hipLaunchKernelGGL((k_wp_permute<T>), dim3(2048), dim3(256), 0, stream(), (const T*)c.uval, M.wp_hot.as<uint32_t>(), M.wp_nwarm, xp.as<T>());
-  const uint32_t nwaves = (uint32_t)ncu * WP_WAVES;
+  const uint32_t nwaves = (uint32_t)ncu * WP_WGS_PER_CU * WP_WAVES;
   const uint32_t tpw = (M.wp_ntasks + nwaves - 1) / nwaves;
   if (M.wp_carry.bytes < (size_t)nwaves * sizeof(WpCarry<T>)) M.wp_carry.alloc((size_t)nwaves * sizeof(WpCarry<T>));
   WpArgs<T> a{M.rowptr.as<uint32_t>(), M.wp_pcol.as<uint32_t>(), (const T*)c.aval, (const T*)xp.p, (const T*)c.uval, M.wp_hot.as<uint32_t>(), M.wp_rs.as<uint32_t>(), M.wp_rs.as<uint32_t>() + (M.wp_ntasks + 1),
               (T*)c.tval, c.tpres, M.wp_carry.as<WpCarry<T>>(), M.nrows, M.wp_ntasks, (uint32_t)M.nnz, tpw, M.wp_nhot, M.wp_nwarm};
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;
-    hipLaunchKernelGGL((k_spmv_wavepipe<T, SR>), dim3(ncu), dim3(WP_WAVES * 64), 0, stream(), a, sr);
-    hipLaunchKernelGGL((k_spmv_wavepipe_fixup<T, SR>), dim3((nwaves + 255) / 256), dim3(256), 0, stream(), M.wp_carry.as<WpCarry<T>>(), nwaves, (T*)c.tval, c.tpres, sr);
+    hipLaunchKernelGGL((k_spmv_wavepipe<T, SR>), dim3(ncu * WP_WGS_PER_CU), dim3(WP_WAVES * 64), 0, stream(), a, (const WpArgs<T>*)nullptr, sr);
+    hipLaunchKernelGGL((k_spmv_wavepipe_fixup<T, SR>), dim3((nwaves + 255) / 256), dim3(256), 0, stream(), M.wp_carry.as<WpCarry<T>>(), nwaves, (T*)c.tval, c.tpres,
+                       (const WpArgs<T>*)nullptr, sr);
     g_last_plan += std::string("k_spmv_wavepipe<") + (sr.is_static ? "static" : "dynamic") + ",hot=" + std::to_string(M.wp_nhot) + "> ";
   });
   return true;

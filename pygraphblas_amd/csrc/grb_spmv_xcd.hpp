@@ -1,0 +1,213 @@
+// grb_spmv_xcd.hpp — SpMV kernel "X": kernel W run on eight column panels at once, one panel per XCD.
+//
+// Why (profiles/spmv_pmc_traffic.json): kernel W's time is its memory-side read traffic at ~5.2 TB/s, and 60 % of that
+// traffic is 128-byte line fills for gathers of u that miss the 4 MiB per-XCD L2 — every XCD sees all 32 MiB of u, so
+// the eight L2s cache eight copies of the same hot 4 MiB.  Kernel X gives each XCD its own eighth of the columns:
+//   * columns are ranked by frequency (as in W); column of rank r belongs to panel r & 7 with local index r >> 3, so
+//     every panel gets an equal share of hot, warm and cold columns and of the entries;
+//   * the plan stores the matrix panel-major: for each panel a CSR over its non-empty *sub-rows* (row fragments),
+//     a local-index column array and the values in that order;
+//   * per call u is written panel-major in rank order (xp[panel][local]); workgroup b (observed to run on XCD b % 8)
+//     runs W's wave pipeline on panel b & 7: its LDS table holds the panel's hottest 12 288 entries (= the global top
+//     98 304 columns spread over the XCDs) and every other gather falls in the panel's own 4 MiB window of xp, which
+//     its XCD's L2 keeps — so the aggregate 32 MiB of L2 holds all of u once;
+//   * each sub-row's sum goes to a partial array; a merge kernel adds the <= 8 partials of every row in panel order
+//     (fixed order => reproducible) and writes y.
+// Extra algorithmic cost: one partial (8 B written + read) and one index per sub-row (~12 M at R-MAT-22, ~0.3 GB)
+// against ~1.3 GB of avoided line fills.  Placement is used for speed only: any other block->XCD mapping is still correct.
+#pragma once
+#include "grb_spmv_wavepipe.hpp"
+#include "grb_matops.hpp"
+
+namespace grb {
+
+constexpr int XP = 8;      // panels = XCDs
+
+struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per matrix and value type
+  DevBuf order;           // u32[n]      original column of rank r
+  DevBuf pcol, pval;      // u32[nnz], T[nnz] panel-major entries (local column index, value)
+  DevBuf rowptr;          // u32[F + XP] per-panel sub-row pointers, relative to the panel's first entry (F_k + 1 each)
+  DevBuf tasks;           // u32 per-panel merge-path task starts: trow then tent, (ntasks_k + 1) each
+  DevBuf rowsub_ptr, rowsub_idx;   // u32[nrows+1], u32[F]: sub-rows of every row, in panel order
+  DevBuf args;            // WpArgs<T>[XP] in HBM (pointers into the per-call buffers are patched every call)
+  DevBuf carry;           // WpCarry<T>[XP * waves_per_panel]
+  DevBuf xp, partial, scratch;     // per-call work buffers kept with the plan so the argument block never changes
+  uint64_t eoff[XP + 1], soff[XP + 1], toff[XP + 1]; uint32_t ntasks[XP]; uint32_t wn = 0; uint64_t F = 0; int tsize = 0;
+};
+
+static __global__ void k_xp_panel_keys(const uint32_t* __restrict__ col, uint64_t nnz, const uint32_t* __restrict__ rank, uint32_t* __restrict__ key, uint32_t* __restrict__ idx) {
+  for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < nnz; p += gridDim.x * 256ull) { key[p] = rank[col[p]] & 7u; idx[p] = (uint32_t)p; }
+}
+static __global__ void k_xp_hist8(const uint32_t* __restrict__ key, uint64_t nnz, unsigned long long* __restrict__ cnt) {
+  __shared__ unsigned int s[XP];
+  if (threadIdx.x < XP) s[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < nnz; p += gridDim.x * 256ull) atomicAdd(&s[key[p]], 1u);
+  __syncthreads();
+  if (threadIdx.x < XP && s[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], (unsigned long long)s[threadIdx.x]);
+}
+template <class T> __global__ void k_xp_gather_entries(const uint32_t* __restrict__ perm, uint64_t nnz, const uint32_t* __restrict__ col, const T* __restrict__ val,
+                                                       const uint32_t* __restrict__ rank, const uint32_t* __restrict__ rowidx,
+                                                       uint32_t* __restrict__ pcol, T* __restrict__ pval, uint32_t* __restrict__ prow) {
+  for (uint64_t q = blockIdx.x * 256ull + threadIdx.x; q < nnz; q += gridDim.x * 256ull) {
+    const uint32_t p = perm[q];
+    pcol[q] = rank[col[p]] >> 3; pval[q] = val[p]; prow[q] = rowidx[p];
+  }
+}
+// head[q] = 1 where a new sub-row starts (first entry of a panel, or the row changes)
+static __global__ void k_xp_heads(const uint32_t* __restrict__ prow, uint64_t nnz, uint64_t e0, uint64_t e1, uint64_t e2, uint64_t e3, uint64_t e4, uint64_t e5, uint64_t e6, uint64_t e7,
+                                  uint32_t* __restrict__ head) {
+  for (uint64_t q = blockIdx.x * 256ull + threadIdx.x; q < nnz; q += gridDim.x * 256ull) {
+    const bool pstart = q == e0 || q == e1 || q == e2 || q == e3 || q == e4 || q == e5 || q == e6 || q == e7;
+    head[q] = (pstart || prow[q] != prow[q - 1]) ? 1u : 0u;
+  }
+}
+// sub-row s (global numbering, panel-major) starts at entry q: rowptr slot s + panel, value relative to the panel
+static __global__ void k_xp_subrows(const uint32_t* __restrict__ head, const uint32_t* __restrict__ sidx, const uint32_t* __restrict__ prow, uint64_t q0, uint64_t q1,
+                                    uint32_t panel, uint32_t* __restrict__ rowptr, uint32_t* __restrict__ subrow_row) {
+  for (uint64_t q = q0 + blockIdx.x * 256ull + threadIdx.x; q < q1; q += gridDim.x * 256ull)
+    if (head[q]) { const uint32_t s = sidx[q]; rowptr[s + panel] = (uint32_t)(q - q0); subrow_row[s] = prow[q]; }
+}
+static __global__ void k_xp_set(uint32_t* p, uint32_t v) { *p = v; }
+template <class T> __global__ void k_xp_permute(const T* __restrict__ x, const uint32_t* __restrict__ order, uint32_t n, uint32_t wn, T* __restrict__ xp) {
+  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) xp[(size_t)(r & 7u) * wn + (r >> 3)] = x[order[r]];
+}
+// y(i) = sum of the partials of row i's sub-rows, in panel order.  All (<= 8) index and partial loads of a row are
+// issued before the first add.
+template <class T, class SR>
+__global__ void k_xp_combine(uint32_t nrows, const uint32_t* __restrict__ rsp, const uint32_t* __restrict__ rsi, const T* __restrict__ partial,
+                             T* __restrict__ y, uint8_t* __restrict__ ypres, const SR sr) {
+  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nrows; r += (uint64_t)gridDim.x * 256ull) {
+    const uint32_t b = rsp[r], e = rsp[r + 1], cnt = e - b;
+    uint32_t ix[XP]; T v[XP];
+#pragma unroll
+    for (int j = 0; j < XP; j++) ix[j] = rsi[(uint32_t)j < cnt ? b + j : (cnt ? b : 0)];
+#pragma unroll
+    for (int j = 0; j < XP; j++) v[j] = partial[ix[j]];
+    if (cnt) {
+      T acc = v[0];
+#pragma unroll
+      for (int j = 1; j < XP; j++) if ((uint32_t)j < cnt) acc = sr.add(acc, v[j]);
+      y[r] = acc;
+    }
+    ypres[r] = cnt ? 1 : 0;
+  }
+}
+
+template <class T> void build_xcd_plan(DevCSR& M, int ncu) {
+  auto grid_n = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 8192) b = 8192; return (unsigned)b; };
+  auto* P = new XcdPlan(); M.xcd.reset(P);
+  const uint32_t n = M.ncols; const uint64_t nnz = M.nnz;
+  // 1. rank the columns by frequency (descending; ties by index)
+  DevBuf cnt((size_t)n * 4 + 4), key((size_t)n * 4 + 4), id((size_t)n * 4 + 4), key2((size_t)n * 4 + 4), rank((size_t)n * 4 + 4);
+  P->order.alloc((size_t)n * 4 + 4);
+  GRB_HIP(hipMemsetAsync(cnt.p, 0, (size_t)n * 4 + 4, stream()));
+  hipLaunchKernelGGL(k_wp_col_hist, dim3(grid_n(nnz)), dim3(256), 0, stream(), M.col.as<uint32_t>(), nnz, cnt.as<uint32_t>());
+  hipLaunchKernelGGL(k_wp_neg_keys, dim3(grid_n(n)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, key.as<uint32_t>(), id.as<uint32_t>());
+  sort_pairs_u32(key.as<uint32_t>(), key2.as<uint32_t>(), id.as<uint32_t>(), P->order.as<uint32_t>(), n, 32);
+  hipLaunchKernelGGL(k_wp_rank, dim3(grid_n(n)), dim3(256), 0, stream(), P->order.as<uint32_t>(), n, rank.as<uint32_t>());
+  // 2. entries grouped by panel (stable: row-major order is kept inside a panel)
+  DevBuf pk(nnz * 4 + 4), pidx(nnz * 4 + 4), pk2(nnz * 4 + 4), perm(nnz * 4 + 4), rowidx(nnz * 4 + 4), prow(nnz * 4 + 4), hc(XP * 8);
+  hipLaunchKernelGGL(k_xp_panel_keys, dim3(grid_n(nnz)), dim3(256), 0, stream(), M.col.as<uint32_t>(), nnz, rank.as<uint32_t>(), pk.as<uint32_t>(), pidx.as<uint32_t>());
+  GRB_HIP(hipMemsetAsync(hc.p, 0, XP * 8, stream()));
+  hipLaunchKernelGGL(k_xp_hist8, dim3(1024), dim3(256), 0, stream(), pk.as<uint32_t>(), nnz, hc.as<unsigned long long>());
+  sort_pairs_u32(pk.as<uint32_t>(), pk2.as<uint32_t>(), pidx.as<uint32_t>(), perm.as<uint32_t>(), nnz, 3);
+  unsigned long long hcnt[XP];
+  GRB_HIP(hipMemcpyAsync(hcnt, hc.p, XP * 8, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+  P->eoff[0] = 0; for (int k = 0; k < XP; k++) P->eoff[k + 1] = P->eoff[k] + hcnt[k];
+  csr_row_indices(M, rowidx.as<uint32_t>());
+  P->pcol.alloc(nnz * 4 + 4); P->pval.alloc(nnz * sizeof(T) + 8);
+  hipLaunchKernelGGL((k_xp_gather_entries<T>), dim3(grid_n(nnz)), dim3(256), 0, stream(), perm.as<uint32_t>(), nnz, M.col.as<uint32_t>(), M.val.as<T>(),
+                     rank.as<uint32_t>(), rowidx.as<uint32_t>(), P->pcol.as<uint32_t>(), P->pval.as<T>(), prow.as<uint32_t>());
+  // 3. sub-rows
+  DevBuf head(nnz * 4 + 4), sidx(nnz * 4 + 4);
+  hipLaunchKernelGGL(k_xp_heads, dim3(grid_n(nnz)), dim3(256), 0, stream(), prow.as<uint32_t>(), nnz, P->eoff[0], P->eoff[1], P->eoff[2], P->eoff[3], P->eoff[4], P->eoff[5],
+                     P->eoff[6], P->eoff[7], head.as<uint32_t>());
+  exclusive_scan_u32(head.as<uint32_t>(), sidx.as<uint32_t>(), nnz);
+  for (int k = 0; k <= XP; k++) {
+    if (P->eoff[k] >= nnz) { uint32_t lp = 0, lh = 0;
+      GRB_HIP(hipMemcpyAsync(&lp, sidx.as<uint32_t>() + (nnz - 1), 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipMemcpyAsync(&lh, head.as<uint32_t>() + (nnz - 1), 4, hipMemcpyDeviceToHost, stream()));
+      GRB_HIP(hipStreamSynchronize(stream())); P->soff[k] = (uint64_t)lp + lh; }
+    else { uint32_t v = 0; GRB_HIP(hipMemcpyAsync(&v, sidx.as<uint32_t>() + P->eoff[k], 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream())); P->soff[k] = v; }
+  }
+  P->F = P->soff[XP];
+  DevBuf subrow_row(P->F * 4 + 4);
+  P->rowptr.alloc((P->F + XP) * 4 + 4);
+  for (int k = 0; k < XP; k++) {
+    if (P->eoff[k + 1] > P->eoff[k])
+      hipLaunchKernelGGL(k_xp_subrows, dim3(grid_n(P->eoff[k + 1] - P->eoff[k])), dim3(256), 0, stream(), head.as<uint32_t>(), sidx.as<uint32_t>(), prow.as<uint32_t>(),
+                         P->eoff[k], P->eoff[k + 1], (uint32_t)k, P->rowptr.as<uint32_t>(), subrow_row.as<uint32_t>());
+    hipLaunchKernelGGL(k_xp_set, dim3(1), dim3(1), 0, stream(), P->rowptr.as<uint32_t>() + P->soff[k + 1] + k, (uint32_t)(P->eoff[k + 1] - P->eoff[k]));   // end sentinel of panel k
+  }
+  // 4. row -> its sub-rows, in panel order (stable sort of the sub-row ids by row)
+  {
+    DevBuf sid(P->F * 4 + 4), rkey(P->F * 4 + 4), rcnt(((size_t)M.nrows + 1) * 4);
+    P->rowsub_idx.alloc(P->F * 4 + 4); P->rowsub_ptr.alloc(((size_t)M.nrows + 1) * 4);
+    hipLaunchKernelGGL(k_iota_u32_wp, dim3(grid_n(P->F)), dim3(256), 0, stream(), sid.as<uint32_t>(), P->F);
+    int bits = 1; while (bits < 32 && (1ull << bits) < (uint64_t)M.nrows) bits++;
+    sort_pairs_u32(subrow_row.as<uint32_t>(), rkey.as<uint32_t>(), sid.as<uint32_t>(), P->rowsub_idx.as<uint32_t>(), P->F, bits);
+    GRB_HIP(hipMemsetAsync(rcnt.p, 0, ((size_t)M.nrows + 1) * 4, stream()));
+    hipLaunchKernelGGL(k_wp_col_hist, dim3(grid_n(P->F)), dim3(256), 0, stream(), subrow_row.as<uint32_t>(), P->F, rcnt.as<uint32_t>());
+    exclusive_scan_u32(rcnt.as<uint32_t>(), P->rowsub_ptr.as<uint32_t>(), (uint64_t)M.nrows + 1);
+  }
+  // 5. merge-path tasks per panel
+  P->toff[0] = 0;
+  for (int k = 0; k < XP; k++) {
+    const uint64_t fk = P->soff[k + 1] - P->soff[k], ek = P->eoff[k + 1] - P->eoff[k];
+    P->ntasks[k] = (uint32_t)((fk + ek + WP_ENT - 1) / WP_ENT);
+    P->toff[k + 1] = P->toff[k] + 2 * ((uint64_t)P->ntasks[k] + 1);
+  }
+  P->tasks.alloc(P->toff[XP] * 4 + 4);
+  for (int k = 0; k < XP; k++) {
+    const uint64_t fk = P->soff[k + 1] - P->soff[k], ek = P->eoff[k + 1] - P->eoff[k];
+    uint32_t* tr = P->tasks.as<uint32_t>() + P->toff[k];
+    hipLaunchKernelGGL(k_wp_task_starts, dim3(grid_n(P->ntasks[k] + 1)), dim3(256), 0, stream(), P->rowptr.as<uint32_t>() + P->soff[k] + k, (uint32_t)fk, (uint32_t)ek, P->ntasks[k],
+                       tr, tr + (P->ntasks[k] + 1));
+  }
+  P->wn = (n + XP - 1) / XP;
+  const uint32_t wpp = (uint32_t)(ncu / XP) * WP_WGS_PER_CU * WP_WAVES;       // waves per panel
+  constexpr uint32_t H = wp_hot<T>::H;
+  P->args.alloc(XP * sizeof(WpArgs<T>)); P->carry.alloc((size_t)XP * wpp * sizeof(WpCarry<T>));
+  P->xp.alloc((size_t)XP * P->wn * sizeof(T) + 8); P->partial.alloc(P->F * sizeof(T) + 8); P->scratch.alloc(P->F + 8);
+  WpArgs<T> ha[XP];
+  for (int k = 0; k < XP; k++) {
+    WpArgs<T>& a = ha[k];
+    const uint32_t fk = (uint32_t)(P->soff[k + 1] - P->soff[k]), ek = (uint32_t)(P->eoff[k + 1] - P->eoff[k]);
+    a.rowptr = P->rowptr.as<uint32_t>() + P->soff[k] + k; a.pcol = P->pcol.as<uint32_t>() + P->eoff[k];
+    a.aval = P->pval.as<T>() + P->eoff[k];
+    a.x = P->xp.as<T>() + (size_t)k * P->wn; a.xorig = a.x; a.hot_cols = nullptr;
+    a.trow = P->tasks.as<uint32_t>() + P->toff[k]; a.tent = a.trow + (P->ntasks[k] + 1);
+    a.y = P->partial.as<T>() + P->soff[k]; a.ypres = P->scratch.as<uint8_t>() + P->soff[k];
+    a.carry = P->carry.as<WpCarry<T>>() + (size_t)k * wpp;
+    a.nrows = fk; a.ntasks = P->ntasks[k]; a.nnz = ek; a.tasks_per_wave = (P->ntasks[k] + wpp - 1) / wpp;
+    a.nhot = P->wn < H ? P->wn : H; a.nwarm = 0xFFFFFFFFu;      // every gather of the panel falls in its window of xp
+  }
+  GRB_HIP(hipMemcpyAsync(P->args.p, ha, sizeof(ha), hipMemcpyHostToDevice, stream()));
+  P->tsize = (int)sizeof(T);
+  GRB_HIP(hipStreamSynchronize(stream()));
+}
+
+template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int ncu) {
+  DevCSR& M = *c.M;
+  if (ncu < XP || ncu % XP) return false;
+  if (c.aval && c.aval != M.val.p) return false;      // the plan's panel-major values are a copy of the stored ones (no typecast)
+  auto* P = static_cast<XcdPlan*>(M.xcd.get());
+  if (!P || P->tsize != (int)sizeof(T)) { build_xcd_plan<T>(M, ncu); P = static_cast<XcdPlan*>(M.xcd.get()); }
+  const uint32_t wpp = (uint32_t)(ncu / XP) * WP_WGS_PER_CU * WP_WAVES;
+  const bool uses_u = d.flip ? binop_uses_x(d.mulop) : binop_uses_y(d.mulop);
+  if (uses_u) hipLaunchKernelGGL((k_xp_permute<T>), dim3(2048), dim3(256), 0, stream(), (const T*)c.uval, P->order.as<uint32_t>(), M.ncols, P->wn, P->xp.as<T>());
+  WpArgs<T> a0{};
+  with_semiring<T>(d, [&](auto sr) {
+    typedef decltype(sr) SR;
+    hipLaunchKernelGGL((k_spmv_wavepipe<T, SR>), dim3(ncu * WP_WGS_PER_CU), dim3(WP_WAVES * 64), 0, stream(), a0, (const WpArgs<T>*)P->args.p, sr);
+    hipLaunchKernelGGL((k_spmv_wavepipe_fixup<T, SR>), dim3((wpp + 255) / 256, XP), dim3(256), 0, stream(), (const WpCarry<T>*)nullptr, wpp, (T*)nullptr, (uint8_t*)nullptr,
+                       (const WpArgs<T>*)P->args.p, sr);
+    uint64_t nb = ((uint64_t)M.nrows + 255) / 256; if (nb > 65535u * 8) nb = 65535u * 8; if (nb < 1) nb = 1;
+    hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3((unsigned)nb), dim3(256), 0, stream(), M.nrows, P->rowsub_ptr.as<uint32_t>(), P->rowsub_idx.as<uint32_t>(), P->partial.as<T>(),
+                       (T*)c.tval, c.tpres, sr);
+    g_last_plan += std::string("k_spmv_xcd<") + (sr.is_static ? "static" : "dynamic") + ",subrows=" + std::to_string(P->F) + "> ";
+  });
+  return true;
+}
+
+}  // namespace grb

@@ -163,9 +163,10 @@ def test_fp64_random_values_within_1e6(gpu):
     assert_same("FP64", gi, gx, exp.I, exp.X, rtol=1e-6)
 
 
+@pytest.mark.parametrize("method", ["wavepipe", "xcd"])
 @pytest.mark.parametrize("typ,sr", [("FP64", "PLUS_TIMES"), ("FP32", "PLUS_SECOND"), ("INT64", "MIN_PLUS"), ("INT32", "PLUS_PAIR"), ("UINT32", "MAX_MIN")])
-def test_wavepipe_kernel_shapes(gpu, typ, sr):
-    """Kernel W (persistent merge-path pipeline + LDS hot table) forced on shapes that stress its carries: rows that span
+def test_wavepipe_kernel_shapes(gpu, typ, sr, method):
+    """Kernels W / X (persistent merge-path pipeline + LDS hot table; X = one column panel per XCD) forced on shapes that stress the carries: rows that span
     tasks and whole waves' ranges, runs of empty rows, a single row, fewer tasks than waves, hot and cold columns."""
     rng = np.random.default_rng(17)
     shapes = [(3, 40000, 0.9),        # three rows of ~36000 entries: each spans ~70 tasks and several waves
@@ -175,15 +176,17 @@ def test_wavepipe_kernel_shapes(gpu, typ, sr):
               (40, 30000, 0.3),       # rows of ~9000
               (2000, 2000, 0.001)]    # very sparse: barely more than one task
     for nrows, ncols, dens in shapes:
-        run_case(rng, typ, sr, nrows, ncols, dens, 1.0, method="wavepipe")
-        assert "wavepipe" in gb.last_kernel_plan(), gb.last_kernel_plan()
+        run_case(rng, typ, sr, nrows, ncols, dens, 1.0, method=method)
+        assert ("wavepipe" in gb.last_kernel_plan()) or ("xcd" in gb.last_kernel_plan()), gb.last_kernel_plan()
+        if method == "xcd" and nrows * ncols * dens > 40000:
+            assert "xcd" in gb.last_kernel_plan(), gb.last_kernel_plan()      # kernel X: one column panel per XCD
     # skewed columns (a few very hot ones) + a transposed operand through the cached CSC
     A = rand_matrix(rng, typ, 3000, 5000, 0.01)
     A.J[: len(A.J) // 2] = rng.integers(0, 7, len(A.J) // 2).astype(np.uint64)
     key = np.unique(A.I * np.uint64(5000) + A.J, return_index=True)[1]
     A = O.Tuples(typ, 3000, 5000, A.I[key], A.J[key], A.X[key])
     ui, ux = rand_vector(rng, typ, 5000, 1.0)
-    os.environ["GRB_MI355X_SPMV"] = "wavepipe"
+    os.environ["GRB_MI355X_SPMV"] = method
     try:
         w = to_matrix(A).mxv(to_vector(typ, 5000, ui, ux), semiring=getattr(TYPE[typ], sr))
     finally:
