@@ -26,7 +26,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
-        if "k_spm" not in k: continue
+        if "k_spm" not in k and "k_xp_" not in k and "k_wp_permute" not in k: continue
         short = k.split("(")[0].replace("void grb::", "")
         agg[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 with open(out + "/summary.txt", "w") as fo:
