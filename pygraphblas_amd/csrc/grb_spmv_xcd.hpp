@@ -25,6 +25,7 @@ constexpr int XP = 8;      // panels = XCDs
 
 struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per matrix and value type
   DevBuf order;           // u32[n]      original column of rank r
+  DevBuf order_pm;        // u32[8*wn]   the same, laid out like xp (panel-major)
   DevBuf pcol, pval;      // u32[nnz], T[nnz] panel-major entries (local column index, value)
   DevBuf rowptr;          // u32[F + XP] per-panel sub-row pointers, relative to the panel's first entry (F_k + 1 each)
   DevBuf tasks;           // u32 per-panel merge-path task starts: trow then tent, (ntasks_k + 1) each
@@ -35,6 +36,23 @@ struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per 
   uint64_t eoff[XP + 1], soff[XP + 1], toff[XP + 1]; uint32_t ntasks[XP]; uint32_t wn = 0; uint64_t F = 0; int tsize = 0;
 };
 
+// key = panel | (local < H ? local : H) | (local < H ? 0 : column): hot entries keep their frequency order, the rest sort by column
+static __global__ void k_xp_window_keys(const uint32_t* __restrict__ order, uint32_t n, uint32_t H, unsigned long long* __restrict__ key, uint32_t* __restrict__ colv) {
+  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
+    const uint32_t c = order[r], k = r & 7u, l = r >> 3;
+    key[r] = ((unsigned long long)k << 56) | ((unsigned long long)(l < H ? l : H) << 32) | (l < H ? 0u : c);
+    colv[r] = c;
+  }
+}
+// sorted position i holds column cols[i] of panel k = key >> 56; panel k has ceil((n - k) / 8) columns and starts after panels < k
+static __global__ void k_xp_window_rank(const unsigned long long* __restrict__ key, const uint32_t* __restrict__ cols, uint32_t n, uint32_t* __restrict__ rank, uint32_t* __restrict__ order) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint32_t k = (uint32_t)(key[i] >> 56);
+    uint32_t start = 0; for (uint32_t j = 0; j < k; j++) start += (n - j + 7) / 8;
+    const uint32_t r = (i - start) * 8 + k;
+    rank[cols[i]] = r; order[r] = cols[i];
+  }
+}
 static __global__ void k_xp_panel_keys(const uint32_t* __restrict__ col, uint64_t nnz, const uint32_t* __restrict__ rank, uint32_t* __restrict__ key, uint32_t* __restrict__ idx) {
   for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < nnz; p += gridDim.x * 256ull) { key[p] = rank[col[p]] & 7u; idx[p] = (uint32_t)p; }
 }
@@ -69,28 +87,59 @@ static __global__ void k_xp_subrows(const uint32_t* __restrict__ head, const uin
     if (head[q]) { const uint32_t s = sidx[q]; rowptr[s + panel] = (uint32_t)(q - q0); subrow_row[s] = prow[q]; }
 }
 static __global__ void k_xp_set(uint32_t* p, uint32_t v) { *p = v; }
-template <class T> __global__ void k_xp_permute(const T* __restrict__ x, const uint32_t* __restrict__ order, uint32_t n, uint32_t wn, T* __restrict__ xp) {
-  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) xp[(size_t)(r & 7u) * wn + (r >> 3)] = x[order[r]];
+// xp[d] = u[order_pm[d]] with order_pm the rank order laid out panel-major (d = panel * wn + local): coalesced index
+// reads and stores, 4 independent gathers in flight per thread
+template <class T> __global__ void k_xp_permute(const T* __restrict__ x, const uint32_t* __restrict__ order_pm, uint32_t total, T* __restrict__ xp) {
+  const uint32_t stride = gridDim.x * 256;
+  for (uint32_t d0 = blockIdx.x * 256 + threadIdx.x; d0 < total; d0 += 4 * stride) {
+    uint32_t o[4]; T v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const uint32_t d = d0 + u * stride; o[u] = order_pm[d < total ? d : total - 1]; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = x[o[u]];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const uint32_t d = d0 + u * stride; if (d < total) xp[d] = v[u]; }
+  }
+}
+static __global__ void k_xp_order_pm(const uint32_t* __restrict__ order, uint32_t n, uint32_t wn, uint32_t* __restrict__ order_pm) {
+  for (uint32_t d = blockIdx.x * 256 + threadIdx.x; d < XP * wn; d += gridDim.x * 256) {
+    const uint32_t k = d / wn, l = d - k * wn, r = l * XP + k;
+    order_pm[d] = order[r < n ? r : n - 1];          // padding slots of the last window re-read a valid column
+  }
 }
 // y(i) = sum of the partials of row i's sub-rows, in panel order.  All (<= 8) index and partial loads of a row are
 // issued before the first add.
 template <class T, class SR>
 __global__ void k_xp_combine(uint32_t nrows, const uint32_t* __restrict__ rsp, const uint32_t* __restrict__ rsi, const T* __restrict__ partial,
                              T* __restrict__ y, uint8_t* __restrict__ ypres, const SR sr) {
-  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nrows; r += (uint64_t)gridDim.x * 256ull) {
-    const uint32_t b = rsp[r], e = rsp[r + 1], cnt = e - b;
-    uint32_t ix[XP]; T v[XP];
+  // two rows per thread (half a grid apart), every load of both rows issued before the first add: the chain
+  // rowsub_ptr -> rowsub_idx -> partial is three dependent memory round trips
+  const uint64_t half = ((uint64_t)nrows + 1) / 2;
+  for (uint64_t t = blockIdx.x * 256ull + threadIdx.x; t < half; t += (uint64_t)gridDim.x * 256ull) {
+    const uint64_t r[2] = {t, t + half};
+    uint32_t b[2], cnt[2];
 #pragma unroll
-    for (int j = 0; j < XP; j++) ix[j] = rsi[(uint32_t)j < cnt ? b + j : (cnt ? b : 0)];
+    for (int q = 0; q < 2; q++) { const uint64_t rr = r[q] < nrows ? r[q] : nrows - 1; b[q] = rsp[rr]; cnt[q] = r[q] < nrows ? rsp[rr + 1] - b[q] : 0; }
+    uint32_t ix[2][XP]; T v[2][XP];
 #pragma unroll
-    for (int j = 0; j < XP; j++) v[j] = partial[ix[j]];
-    if (cnt) {
-      T acc = v[0];
+    for (int q = 0; q < 2; q++)
 #pragma unroll
-      for (int j = 1; j < XP; j++) if ((uint32_t)j < cnt) acc = sr.add(acc, v[j]);
-      y[r] = acc;
+      for (int j = 0; j < XP; j++) ix[q][j] = rsi[(uint32_t)j < cnt[q] ? b[q] + j : (cnt[q] ? b[q] : 0)];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int j = 0; j < XP; j++) v[q][j] = partial[ix[q][j]];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      if (r[q] >= nrows) continue;
+      if (cnt[q]) {
+        T acc = v[q][0];
+#pragma unroll
+        for (int j = 1; j < XP; j++) if ((uint32_t)j < cnt[q]) acc = sr.add(acc, v[q][j]);
+        y[r[q]] = acc;
+      }
+      ypres[r[q]] = cnt[q] ? 1 : 0;
     }
-    ypres[r] = cnt ? 1 : 0;
   }
 }
 
@@ -106,6 +155,16 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu) {
   hipLaunchKernelGGL(k_wp_neg_keys, dim3(grid_n(n)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, key.as<uint32_t>(), id.as<uint32_t>());
   sort_pairs_u32(key.as<uint32_t>(), key2.as<uint32_t>(), id.as<uint32_t>(), P->order.as<uint32_t>(), n, 32);
   hipLaunchKernelGGL(k_wp_rank, dim3(grid_n(n)), dim3(256), 0, stream(), P->order.as<uint32_t>(), n, rank.as<uint32_t>());
+  // 1b. inside a panel only the first H local indices (the LDS table) need to be in frequency order; the rest of the
+  //     window is re-ordered by column index so that the per-call operand copy reads u almost sequentially
+  {
+    constexpr uint32_t HH = wp_hot<T>::H;
+    DevBuf k64((size_t)n * 8 + 8), k64o((size_t)n * 8 + 8), cin((size_t)n * 4 + 4), cout((size_t)n * 4 + 4);
+    hipLaunchKernelGGL(k_xp_window_keys, dim3(grid_n(n)), dim3(256), 0, stream(), P->order.as<uint32_t>(), n, HH, (unsigned long long*)k64.p, cin.as<uint32_t>());
+    sort_pairs_u64((const uint64_t*)k64.p, (uint64_t*)k64o.p, cin.as<uint32_t>(), cout.as<uint32_t>(), n, 60);
+    // position i of the sorted sequence -> panel k = key >> 56, local = i - first position of panel k
+    hipLaunchKernelGGL(k_xp_window_rank, dim3(grid_n(n)), dim3(256), 0, stream(), (const unsigned long long*)k64o.p, cout.as<uint32_t>(), n, rank.as<uint32_t>(), P->order.as<uint32_t>());
+  }
   // 2. entries grouped by panel (stable: row-major order is kept inside a panel)
   DevBuf pk(nnz * 4 + 4), pidx(nnz * 4 + 4), pk2(nnz * 4 + 4), perm(nnz * 4 + 4), rowidx(nnz * 4 + 4), prow(nnz * 4 + 4), hc(XP * 8);
   hipLaunchKernelGGL(k_xp_panel_keys, dim3(grid_n(nnz)), dim3(256), 0, stream(), M.col.as<uint32_t>(), nnz, rank.as<uint32_t>(), pk.as<uint32_t>(), pidx.as<uint32_t>());
@@ -165,6 +224,8 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu) {
                        tr, tr + (P->ntasks[k] + 1));
   }
   P->wn = (n + XP - 1) / XP;
+  P->order_pm.alloc((size_t)XP * P->wn * 4 + 4);
+  hipLaunchKernelGGL(k_xp_order_pm, dim3(grid_n((uint64_t)XP * P->wn)), dim3(256), 0, stream(), P->order.as<uint32_t>(), n, P->wn, P->order_pm.as<uint32_t>());
   const uint32_t wpp = (uint32_t)(ncu / XP) * WP_WGS_PER_CU * WP_WAVES;       // waves per panel
   constexpr uint32_t H = wp_hot<T>::H;
   P->args.alloc(XP * sizeof(WpArgs<T>)); P->carry.alloc((size_t)XP * wpp * sizeof(WpCarry<T>));
@@ -195,14 +256,14 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
   if (!P || P->tsize != (int)sizeof(T)) { build_xcd_plan<T>(M, ncu); P = static_cast<XcdPlan*>(M.xcd.get()); }
   const uint32_t wpp = (uint32_t)(ncu / XP) * WP_WGS_PER_CU * WP_WAVES;
   const bool uses_u = d.flip ? binop_uses_x(d.mulop) : binop_uses_y(d.mulop);
-  if (uses_u) hipLaunchKernelGGL((k_xp_permute<T>), dim3(2048), dim3(256), 0, stream(), (const T*)c.uval, P->order.as<uint32_t>(), M.ncols, P->wn, P->xp.as<T>());
+  if (uses_u) hipLaunchKernelGGL((k_xp_permute<T>), dim3(2048), dim3(256), 0, stream(), (const T*)c.uval, P->order_pm.as<uint32_t>(), (uint32_t)(XP * P->wn), P->xp.as<T>());
   WpArgs<T> a0{};
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;
     hipLaunchKernelGGL((k_spmv_wavepipe<T, SR>), dim3(ncu * WP_WGS_PER_CU), dim3(WP_WAVES * 64), 0, stream(), a0, (const WpArgs<T>*)P->args.p, sr);
     hipLaunchKernelGGL((k_spmv_wavepipe_fixup<T, SR>), dim3((wpp + 255) / 256, XP), dim3(256), 0, stream(), (const WpCarry<T>*)nullptr, wpp, (T*)nullptr, (uint8_t*)nullptr,
                        (const WpArgs<T>*)P->args.p, sr);
-    uint64_t nb = ((uint64_t)M.nrows + 255) / 256; if (nb > 65535u * 8) nb = 65535u * 8; if (nb < 1) nb = 1;
+    uint64_t nb = ((uint64_t)M.nrows / 2 + 256) / 256; if (nb > 65535u * 8) nb = 65535u * 8; if (nb < 1) nb = 1;
     hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3((unsigned)nb), dim3(256), 0, stream(), M.nrows, P->rowsub_ptr.as<uint32_t>(), P->rowsub_idx.as<uint32_t>(), P->partial.as<T>(),
                        (T*)c.tval, c.tpres, sr);
     g_last_plan += std::string("k_spmv_xcd<") + (sr.is_static ? "static" : "dynamic") + ",subrows=" + std::to_string(P->F) + "> ";
