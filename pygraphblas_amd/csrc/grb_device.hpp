@@ -29,6 +29,18 @@ template <class T> __device__ __forceinline__ T shfl_down_t(T v, int d) {
   }
 }
 
+template <class T> __device__ __forceinline__ T shfl_up_t(T v, int d) {
+  if constexpr (sizeof(T) == 8) {
+    union { T t; int i[2]; } u; u.t = v;
+    u.i[0] = __shfl_up(u.i[0], d, 64); u.i[1] = __shfl_up(u.i[1], d, 64); return u.t;
+  } else if constexpr (sizeof(T) == 4) {
+    union { T t; int i; } u; u.t = v; u.i = __shfl_up(u.i, d, 64); return u.t;
+  } else {
+    union { T t; uint16_t s; } u; u.s = 0; u.t = v;
+    int x = __shfl_up((int)u.s, d, 64); u.s = (uint16_t)x; return u.t;
+  }
+}
+
 template <class T> __device__ __forceinline__ T shfl_t(T v, int src) {
   if constexpr (sizeof(T) == 8) {
     union { T t; int i[2]; } u; u.t = v;

@@ -6,3 +6,12 @@ using std::int8_t; using std::uint8_t; using std::int16_t; using std::uint16_t; 
 template void run_pull<GRB_INST_TYPE>(const SpmvCall&, const SemiringDesc&);
 template void run_push<GRB_INST_TYPE>(const SpmvCall&, const SemiringDesc&, const uint32_t*, uint64_t, uint32_t*);
 }
+
+#ifdef WP_PROFILE
+// experiment only: read and reset the phase counters of kernel W (this TU's copy)
+extern "C" int GrBX_wp_prof_read(unsigned long long* out8) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out8, HIP_SYMBOL(grb::g_wp_prof), 8192 * 8);
+  return 0;
+}
+#endif

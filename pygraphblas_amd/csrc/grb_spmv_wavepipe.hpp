@@ -24,168 +24,282 @@
 
 namespace grb {
 
-constexpr int WP_ENT = 512;                 // merge items per task = 8 per lane
+constexpr int WP_ENT = 256;                 // merge items per task = 8 per lane
 constexpr int WP_PER = WP_ENT / 64;
 constexpr int WP_SHORT = 24;                // rows longer than this (within one task) are reduced by the whole wave
 constexpr int WP_WAVES = 16;                // waves per workgroup (1024 threads)
 constexpr int WP_WGS_PER_CU = 1;            // one workgroup per CU (measured: 2 x 768 threads with 256-item tasks spills registers and is slower)
 constexpr int WP_LDS_BYTES = 160 * 1024 / WP_WGS_PER_CU;
-template <class T> struct wp_hot { static constexpr int H = (WP_LDS_BYTES - WP_WAVES * WP_ENT * (int)sizeof(T)) / (int)sizeof(T); };   // 12288 (8 B) / 24576 (4 B)
+template <class T> struct wp_hot { static constexpr int H = (WP_LDS_BYTES - WP_WAVES * WP_ENT * ((int)sizeof(T) + 1) - 16) / (int)sizeof(T); };   // what the scan slices and row-start maps leave: 15870 (8 B) / 35836 (4 B)
 constexpr uint32_t WP_NONE = 0xFFFFFFFFu;
+constexpr uint32_t WP_CHUNK = 4;              // tasks per chunk (the unit handed out dynamically; one carry record each)
+constexpr uint32_t WP_STATIC_PCT = 40;        // share of the chunks that is split statically
+inline uint32_t wp_env(const char* name, uint32_t dflt) { const char* e = getenv(name); return e && *e ? (uint32_t)atoi(e) : dflt; }   // tuning hooks
+constexpr uint32_t WP_MAX_STATIC = 64;        // a static range owns at most this many chunk ids (one lane writes each empty record)
 
 template <class T> __device__ __forceinline__ T wp_wave_total(int op, T v, T identity) {
   if constexpr (sizeof(T) >= 4) return wave_reduce_dpp<T, false>(op, v, identity); else return wave_reduce_op<T, false>(op, v);
 }
 
+#ifdef WP_PROFILE
+static __device__ unsigned long long g_wp_prof[8192];   // experiment: cycles of every wave of the last launch, then its task count
+#define WP_CLK() __builtin_amdgcn_s_memtime()
+#endif
 template <class T> struct WpCarry {           // per wave: partial of the row it entered in the middle of / left open
   uint32_t head_row, tail_row; uint8_t head_has, head_done, tail_has, pad; T head_val, tail_val;
 };
 
+template <class T> __device__ __forceinline__ void wp_st_carry(WpCarry<T>* p, const WpCarry<T>& c);
 template <class T> struct WpArgs {
   const uint32_t* rowptr; const uint32_t* pcol; const T* aval; const T* x; const T* xorig; const uint32_t* hot_cols;
   const uint32_t* trow; const uint32_t* tent;      // merge-path task starts: task t begins at (row trow[t], entry tent[t]); [ntasks+1]
-  T* y; uint8_t* ypres; WpCarry<T>* carry; uint32_t nrows, ntasks, nnz, tasks_per_wave, nhot, nwarm;
+  T* y; uint8_t* ypres; WpCarry<T>* carry; uint32_t nrows, ntasks, nnz, tasks_per_chunk, static_pct, nhot, nwarm;
 };
 
 // Tasks are equal slices of the merge of {entries} and {row ends} (WP_ENT items each), so a task holds at most WP_ENT
 // entries AND completes at most WP_ENT rows: runs of empty or tiny rows cannot unbalance the waves (R-MAT has both
 // 10^5-entry rows and long runs of empty rows).  Task t owns entries [tent[t], tent[t+1]) and completes rows
 // [trow[t], trow[t+1]); the entries of row trow[t+1] seen so far are carried to the next task.
+//
+// A lane owns WP_PER *consecutive* entries of the task (one wide load per stream).  The row sums are a segmented
+// inclusive scan of the products in entry order: the lanes that look at rows mark every row start in a byte map in LDS,
+// the entry lanes scan their own entries, a 6-step wave scan carries sums across lanes, the scanned values go to LDS
+// once (conflict-free) and every row reads the value at its last entry.  The cost of a task does not depend on how its
+// entries are split into rows (measured before: per-row serial sums spent half of every wave's time in divergent,
+// bank-conflicting LDS reads).
+// The argument block of panel mode is read from memory, so the compiler cannot tell that the pointers in it are global
+// and would emit FLAT loads — which count on lgkmcnt as well as vmcnt, so every wait for an LDS operation would also
+// drain the loads the pipeline wants to keep in flight.  All HBM traffic of the kernel goes through these helpers.
+#define WP_G __attribute__((address_space(1)))
+template <int B> struct wp_word;
+template <> struct wp_word<1> { typedef uint8_t type; };
+template <> struct wp_word<2> { typedef uint16_t type; };
+template <> struct wp_word<4> { typedef uint32_t type; };
+template <> struct wp_word<8> { typedef uint64_t type; };
+template <class E> __device__ __forceinline__ E wp_ld(const E* p) {
+  typedef typename wp_word<sizeof(E)>::type W;
+  const W w = *(const WP_G W*)(uintptr_t)p;
+  E e; __builtin_memcpy(&e, &w, sizeof(E)); return e;
+}
+template <class E> __device__ __forceinline__ void wp_st(E* p, E v) {
+  typedef typename wp_word<sizeof(E)>::type W;
+  W w; __builtin_memcpy(&w, &v, sizeof(E));
+  *(WP_G W*)(uintptr_t)p = w;
+}
+typedef uint32_t wp_u32x4 __attribute__((ext_vector_type(4)));
+typedef wp_u32x4 wp_u32x4_u __attribute__((aligned(4)));
+template <class T> __device__ __forceinline__ void wp_st_carry(WpCarry<T>* p, const WpCarry<T>& c) {
+  wp_st(&p->head_row, c.head_row); wp_st(&p->tail_row, c.tail_row);
+  wp_st(&p->head_has, c.head_has); wp_st(&p->head_done, c.head_done); wp_st(&p->tail_has, c.tail_has);
+  wp_st(&p->head_val, c.head_val); wp_st(&p->tail_val, c.tail_val);
+}
+template <class E, int N> __device__ __forceinline__ void wp_load_run(const E* __restrict__ arr, uint32_t first, uint32_t len, bool fast, E (&out)[N]) {
+  if (fast) {
+    if constexpr (sizeof(E) >= 4 && (sizeof(E) * N) % 16 == 0) {                // 16-byte loads, element-aligned
+      wp_u32x4 tmp[sizeof(E) * N / 16];
+#pragma unroll
+      for (int j = 0; j < (int)(sizeof(E) * N / 16); j++) tmp[j] = ((const WP_G wp_u32x4_u*)(uintptr_t)(arr + first))[j];
+      __builtin_memcpy(&out[0], &tmp[0], sizeof(E) * N);
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; i++) out[i] = wp_ld(arr + first + i);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; i++) { const uint32_t k = first + i; out[i] = wp_ld(arr + (k < len ? k : len - 1)); }
+  }
+}
+
 template <class T, class SR>
 __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k_spmv_wavepipe(const WpArgs<T> a0, const WpArgs<T>* __restrict__ panels, const SR sr) {
   // panel mode (kernel X, grb_spmv_xcd.hpp): workgroup b works on column panel b % 8 — the XCD it is observed to run on
   const WpArgs<T> a = panels ? panels[blockIdx.x & 7] : a0;
   constexpr int H = wp_hot<T>::H;
   __shared__ T s_hot[H];
-  __shared__ T s_prod[WP_WAVES][WP_ENT];
+  __shared__ __attribute__((aligned(16))) T s_scan[WP_WAVES][WP_ENT];
+  __shared__ uint32_t s_flag[WP_WAVES][WP_ENT / 4];
+  __shared__ uint32_t s_next;                                         // next dynamic chunk of this workgroup
+  if (threadIdx.x == 0) s_next = 0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const bool use_a = sr.uses_a(), use_u = sr.uses_u();
-  if (use_u) for (uint32_t h = threadIdx.x; h < a.nhot; h += WP_WAVES * 64) s_hot[h] = a.x[h];      // x is the rank-permuted copy of u
+  if (use_u) for (uint32_t h = threadIdx.x; h < a.nhot; h += WP_WAVES * 64) s_hot[h] = wp_ld(a.x + h);      // x is the rank-permuted copy of u
   __syncthreads();
-  T* prod = s_prod[wv];
-  const uint32_t gw = (panels ? (blockIdx.x >> 3) : blockIdx.x) * WP_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane(wv);
-  const uint32_t t0 = gw * a.tasks_per_wave;
-  uint32_t t1 = t0 + a.tasks_per_wave; if (t1 > a.ntasks) t1 = a.ntasks;
+  T* scan = s_scan[wv]; uint32_t* flagw = s_flag[wv]; uint8_t* flagb = (uint8_t*)flagw;
+#ifdef WP_PROFILE
+  const unsigned long long pf_t0 = WP_CLK();
+#endif
+  // Work split.  Waves do not run at the same speed (measured: per-wave times of one launch spread +-30 % around the
+  // mean whatever the static split — the sum of ~70 tasks of randomly stalled gathers), so with equal shares most of the
+  // chip idles while the slowest wave finishes.  The chunks (`tasks_per_chunk` tasks each) are split evenly between the
+  // workgroups; inside a workgroup every wave first takes a contiguous static range (40 % of the chunks) and then the
+  // rest one chunk at a time from a counter in LDS.  (Counters in HBM were measured and rejected: same-address atomics
+  // complete one per ~80 ns per address, which made the whole kernel 1.5-2x slower.)  Every chunk id has a carry
+  // record; a static range uses the record of its first chunk and leaves the others empty.
+  const uint32_t K = a.tasks_per_chunk, nchunks = (K + a.ntasks - 1) / K;
+  const uint32_t nwg = panels ? (gridDim.x >> 3) : gridDim.x, jwg = panels ? (blockIdx.x >> 3) : blockIdx.x;
+  // chunk ids [0, dyn0) are static ranges of s0 chunks, dealt to (workgroup, wave) so that every workgroup samples the
+  // whole matrix (its parts differ in cost); ids >= dyn0 are dynamic, workgroup j owning those congruent to j
+  uint32_t s0 = (uint32_t)((uint64_t)nchunks * a.static_pct / 100 / (nwg * WP_WAVES)); if (s0 > WP_MAX_STATIC) s0 = WP_MAX_STATIC;
+  const uint32_t dyn0 = s0 * nwg * WP_WAVES;
+  auto grab = [&]() { uint32_t v = 0; if (lane == 0) v = atomicAdd(&s_next, 1u); return v; };
+  uint32_t rec = ((uint32_t)__builtin_amdgcn_readfirstlane(wv) * nwg + jwg) * s0, nrec = s0;
+  if (nrec == 0) { rec = dyn0 + (uint32_t)__builtin_amdgcn_readfirstlane(grab()) * nwg + jwg; nrec = 1; }
+  while (rec < nchunks) {
+  const uint32_t t0 = rec * K;
+  uint32_t t1 = t0 + nrec * K; if (t1 > a.ntasks) t1 = a.ntasks;
+  uint32_t next_raw = 0;
+  uint32_t end_r = 0;                                                    // row the range ends in
   WpCarry<T> cr; cr.head_row = cr.tail_row = WP_NONE; cr.head_has = cr.head_done = cr.tail_has = cr.pad = 0; cr.head_val = cr.tail_val = sr.identity;
-  if (t0 >= t1) { if (lane == 0) a.carry[gw] = cr; return; }
 
   T carry = sr.identity; bool carry_has = false, owned = true;        // partial of the row the current task starts in (wave-uniform)
-  // stage 1: the coalesced loads of a task (tail lanes re-read its last entry: branch-free) + the row pointers of the
-  // first 64 rows it completes
-  auto load_task = [&](uint32_t e0, uint32_t cnt, uint32_t r0, uint32_t (&c)[WP_PER], T (&v)[WP_PER], uint32_t& rpa, uint32_t& rpb) {
-    const uint32_t last = cnt ? cnt - 1 : 0; const uint32_t base = e0 < a.nnz ? e0 : a.nnz - 1;
+  // stage 1: the column indices of a task + the row pointers of the first 64 rows it completes.
+  // stage 2: its values and the gathers of u that the LDS table does not serve.
+  // Lanes past the end of a task read the next task's entries (in bounds; only the very last task takes the clamped path).
+  auto load_cols = [&](uint32_t e0, uint32_t r0, uint32_t (&c)[WP_PER], uint32_t& rpa, uint32_t& rpb) {
+    wp_load_run<uint32_t, WP_PER>(a.pcol, e0 + lane * WP_PER, a.nnz, a.nnz - e0 >= (uint32_t)WP_ENT, c);
+    const uint32_t rq = r0 + lane;
+    rpa = wp_ld(a.rowptr + (rq < a.nrows ? rq : a.nrows)); rpb = wp_ld(a.rowptr + (rq + 1 < a.nrows ? rq + 1 : a.nrows));
+  };
+  auto issue_gather = [&](uint32_t e0, uint32_t cnt, const uint32_t (&c)[WP_PER], T (&v)[WP_PER], T (&g)[WP_PER]) {
+    if (use_a) wp_load_run<T, WP_PER>(a.aval, e0 + lane * WP_PER, a.nnz, a.nnz - e0 >= (uint32_t)WP_ENT, v);
+    else {
+#pragma unroll
+      for (int u = 0; u < WP_PER; u++) v[u] = T();
+    }
 #pragma unroll
     for (int u = 0; u < WP_PER; u++) {
-      const uint32_t k = lane + u * 64; const uint32_t p = base + (k < cnt ? k : last);
-      c[u] = a.pcol[p]; v[u] = use_a ? a.aval[p] : T();
+      const uint32_t cc = (uint32_t)(lane * WP_PER + u) < cnt ? c[u] : 0u;   // rank of the column if < nwarm (0 = most frequent), else nwarm + column
+      const T* xb = cc < a.nwarm ? a.x : a.xorig - a.nwarm;          // warm: rank-ordered copy of the top of u; cold: u itself
+      g[u] = use_u ? wp_ld(xb + (cc >= (uint32_t)H ? cc : 0u)) : T();          // LDS-resident ranks read element 0 (always cached) and are replaced below
     }
-    const uint32_t rq = r0 + lane;
-    rpa = a.rowptr[rq < a.nrows ? rq : a.nrows]; rpb = a.rowptr[rq + 1 < a.nrows ? rq + 1 : a.nrows];
   };
-  // task descriptors live in registers, one task per lane, 63 tasks + 1 look-ahead at a time: the steady state
+  // task descriptors live in registers, one task per lane, 61 tasks + 3 look-ahead at a time: the steady state
   // issues no dependent global load
-  for (uint32_t tc = t0; tc < t1; tc += 63) {
+  for (uint32_t tc = t0; tc < t1; tc += 61) {
     const uint32_t tl = tc + lane <= a.ntasks ? tc + lane : a.ntasks;
-    const uint32_t d_r = a.trow[tl], d_e = a.tent[tl];
-    const uint32_t nin = t1 - tc < 63u ? t1 - tc : 63u;
-    uint32_t cA[WP_PER]; T vA[WP_PER]; uint32_t rpA, rpB;
+    const uint32_t d_r = wp_ld(a.trow + tl), d_e = wp_ld(a.tent + tl);
+    const uint32_t nin = t1 - tc < 61u ? t1 - tc : 61u;
+    if (tc + 61 >= t1) { next_raw = grab(); end_r = __builtin_amdgcn_readlane(d_r, (int)nin); }   // last window: ask for the next chunk now
+    // three tasks are in flight per wave: task i (values + gathers issued, being reduced), task i+1 (column indices
+    // loaded, gathers issued during iteration i) and task i+2 (column indices issued)
+    uint32_t cA[WP_PER]; T vA[WP_PER], gA[WP_PER]; uint32_t rpA, rpB;
+    uint32_t cB[WP_PER]; uint32_t rpAn = 0, rpBn = 0;
     {
       const uint32_t r00 = __builtin_amdgcn_readlane(d_r, 0), e00 = __builtin_amdgcn_readlane(d_e, 0), e01 = __builtin_amdgcn_readlane(d_e, 1);
-      if (tc == t0) owned = a.rowptr[r00 < a.nrows ? r00 : a.nrows] == e00;   // does this wave see the start of its first row?
-      load_task(e00, e01 - e00, r00, cA, vA, rpA, rpB);
+      if (tc == t0) owned = wp_ld(a.rowptr + (r00 < a.nrows ? r00 : a.nrows)) == e00;   // does this wave see the start of its first row?
+      load_cols(e00, r00, cA, rpA, rpB);
+      if (nin > 1) load_cols(e01, __builtin_amdgcn_readlane(d_r, 1), cB, rpAn, rpBn);
+      issue_gather(e00, e01 - e00, cA, vA, gA);
     }
     for (uint32_t i = 0; i < nin; i++) {
       const int iu = (int)__builtin_amdgcn_readfirstlane(i);
       const uint32_t r0 = __builtin_amdgcn_readlane(d_r, iu), e0 = __builtin_amdgcn_readlane(d_e, iu);
       const uint32_t r1 = __builtin_amdgcn_readlane(d_r, iu + 1), e1 = __builtin_amdgcn_readlane(d_e, iu + 1);
-      const uint32_t cnt = e1 - e0;
-      uint32_t cB[WP_PER]; T vB[WP_PER]; uint32_t rpAn = 0, rpBn = 0;
-      const bool more = i + 1 < nin;
-      if (more) {                                              // next task's loads are in flight while this one gathers and reduces
-        const uint32_t e2 = __builtin_amdgcn_readlane(d_e, iu + 2 < 64 ? iu + 2 : 63);
-        load_task(e1, e2 - e1, r1, cB, vB, rpAn, rpBn);
-      }
-      // stage 2: gathers (LDS for hot columns, L2/HBM otherwise), products into the wave's LDS slice
-      T uv[WP_PER];
+      const uint32_t cnt = e1 - e0, nr = r1 - r0;
+      const bool more = i + 1 < nin, more2 = i + 2 < nin;
+      // ---- rows, pass 1: mark the first entry of every row that starts in this task (and of the row that follows them)
 #pragma unroll
-      for (int u = 0; u < WP_PER; u++) {
-        if (use_u) {
-          const uint32_t c = cA[u];                                   // rank of the column if < nwarm (0 = most frequent), else nwarm + column
-          const T* base = c < a.nwarm ? a.x : a.xorig - a.nwarm;      // warm: rank-ordered copy of the top of u; cold: u itself
-          const T g = base[c >= (uint32_t)H ? c : 0u];
-          uv[u] = c < (uint32_t)H ? s_hot[c < (uint32_t)H ? c : 0] : g;
-        } else uv[u] = T();
-      }
-#pragma unroll
-      for (int u = 0; u < WP_PER; u++) { const uint32_t k = lane + u * 64; if (k < cnt) prod[k] = sr.mult(vA[u], uv[u]); }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-      // stage 3: rows [r0, r1) end inside this task.  Short segments are summed by one lane in entry order, long ones
-      // by the whole wave (64-strided partials + fixed butterfly).  Row r0 first absorbs the carried partial.
-      const uint32_t nr = r1 - r0;
-      uint32_t tail_start = 0;                                  // task-local offset where the entries of row r1 begin
+      for (int w = lane; w < WP_ENT / 4; w += 64) flagw[w] = 0;
+      uint32_t qs0 = 0, qe0 = 0, tail_start = 0;                  // tail_start: task-local offset where the entries of row r1 begin
       for (uint32_t rbase = 0; rbase < nr; rbase += 64) {
         const uint32_t ri = rbase + lane; const bool live = ri < nr; const uint32_t r = r0 + ri;
         uint32_t rs_, re_;
-        if (rbase == 0) { rs_ = rpA; re_ = rpB; } else { rs_ = live ? a.rowptr[r] : e1; re_ = live ? a.rowptr[r + 1] : e1; }
-        if (rs_ < e0) rs_ = e0;                                 // only row r0 can have started in an earlier task
+        if (rbase == 0) { rs_ = rpA; re_ = rpB; } else { rs_ = live ? wp_ld(a.rowptr + r) : e1; re_ = live ? wp_ld(a.rowptr + r + 1) : e1; }
+        const bool before = rs_ < e0;                           // only row r0 can have started in an earlier task
+        if (before) rs_ = e0;
         if (!live) { rs_ = re_ = e0; }
         const uint32_t qs = rs_ - e0, qe = re_ - e0;
-        const bool longrow = qe - qs > (uint32_t)WP_SHORT;
+        if (live && qe > qs && !before) flagb[qs] = 1;
+        if (live && ri == nr - 1 && qe < cnt) flagb[qe] = 1;
+        if (rbase + 64 >= nr) tail_start = __shfl(qe, (int)(nr - 1 - rbase), 64);
+        if (rbase == 0) { qs0 = qs; qe0 = qe; }
+      }
+      if (!carry_has && lane == 0) flagb[0] = 1;                // nothing carried in: entry 0 starts a segment
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();   // LDS ops of one wave execute in order; keep the compiler from reordering
+      uint32_t fbits = 0;                                       // bit u: my entry u is the first of its row
+#pragma unroll
+      for (int w = 0; w < WP_PER / 4; w++) {
+        const uint32_t x = flagw[lane * (WP_PER / 4) + w];
+        fbits |= (((x & 1u) | ((x >> 7) & 2u) | ((x >> 14) & 4u) | ((x >> 21) & 8u)) << (4 * w));
+      }
+      // ---- entries: products (LDS table for the hottest ranks) and their segmented scan in entry order
+      T p[WP_PER];
+#pragma unroll
+      for (int u = 0; u < WP_PER; u++) {
+        const uint32_t cc = cA[u];
+        const T uvv = use_u ? (cc < (uint32_t)H ? s_hot[cc < (uint32_t)H ? cc : 0] : gA[u]) : T();
+        p[u] = sr.mult(vA[u], uvv);                             // entries past cnt hold junk: a forward scan never lets it reach a live position
+      }
+      uint32_t cC[WP_PER]; uint32_t rpAnn = 0, rpBnn = 0; T vB[WP_PER], gB[WP_PER];
+      if (more) issue_gather(e1, __builtin_amdgcn_readlane(d_e, iu + 2) - e1, cB, vB, gB);                          // stage 2 of task i+1
+      if (more2) load_cols(__builtin_amdgcn_readlane(d_e, iu + 2), __builtin_amdgcn_readlane(d_r, iu + 2), cC, rpAnn, rpBnn);   // stage 1 of task i+2
+      {
+        T agg = p[0];
+#pragma unroll
+        for (int u = 1; u < WP_PER; u++) agg = ((fbits >> u) & 1u) ? p[u] : sr.add(agg, p[u]);
+        if (lane == 0 && fbits == 0) agg = sr.add(carry, agg);    // the carried partial flows through lane 0 (entry 0 is marked when there is none)
+        T v = agg; int f = fbits != 0;                          // sum since the last row start at or before my last entry
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const T vu = shfl_up_t<T>(v, d); const int fu = __shfl_up(f, d, 64);
+          if (lane >= d) { if (!f) v = sr.add(vu, v); f |= fu; }
+        }
+        T run = shfl_up_t<T>(v, 1); if (lane == 0) run = carry;   // what flows into my first entry (unused when it starts a row)
+#pragma unroll
+        for (int u = 0; u < WP_PER; u++) { run = ((fbits >> u) & 1u) ? p[u] : sr.add(run, p[u]); p[u] = run; }
+        __builtin_memcpy(&scan[lane * WP_PER], &p[0], sizeof(T) * WP_PER);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();
+      // ---- rows, pass 2: a row's sum is the scanned value at its last entry; row r0 also owns what was carried in
+      for (uint32_t rbase = 0; rbase < nr; rbase += 64) {
+        const uint32_t ri = rbase + lane; const bool live = ri < nr; const uint32_t r = r0 + ri;
+        uint32_t qs = qs0, qe = qe0;
+        if (rbase) { const uint32_t rs_ = live ? wp_ld(a.rowptr + r) : e0, re_ = live ? wp_ld(a.rowptr + r + 1) : e0; qs = rs_ - e0; qe = re_ - e0; }
         T acc = sr.identity; bool has = false;
-        if (!longrow && qe > qs) {                               // entry order kept; 4 LDS reads in flight per step
-          uint32_t q = qs; acc = prod[q++]; has = true;
-          for (; q + 4 <= qe; q += 4) { const T p0 = prod[q], p1 = prod[q + 1], p2 = prod[q + 2], p3 = prod[q + 3]; acc = sr.add(sr.add(sr.add(sr.add(acc, p0), p1), p2), p3); }
-          for (; q < qe; q++) acc = sr.add(acc, prod[q]);
-        }
-        unsigned long long lm = __ballot(longrow);
-        while (lm) {
-          const int j = __builtin_ctzll(lm); lm &= lm - 1;
-          const uint32_t js = __shfl(qs, j, 64), je = __shfl(qe, j, 64);
-          T pa = sr.identity; bool ph = false;
-          for (uint32_t q = js + lane; q < je; q += 64) { pa = ph ? sr.add(pa, prod[q]) : prod[q]; ph = true; }
-          const T tot = wp_wave_total<T>(sr.add_op(), ph ? pa : sr.identity, sr.identity);
-          if (lane == j) { acc = tot; has = true; }
-        }
-        if (rbase == 0 && lane == 0 && carry_has) { acc = has ? sr.add(carry, acc) : carry; has = true; }   // carried part comes first
+        if (live && qe > qs) { acc = scan[qe - 1]; has = true; }
+        else if (rbase == 0 && lane == 0 && carry_has) { acc = carry; has = true; }   // row r0 ended exactly where this task starts
         const bool to_fixup = rbase == 0 && lane == 0 && !owned;      // the row began in another wave's range
-        if (live && !to_fixup) { if (has) a.y[r] = acc; a.ypres[r] = has ? 1 : 0; }
+        if (live && !to_fixup) { if (has) wp_st(a.y + r, acc); wp_st(a.ypres + r, (uint8_t)(has ? 1 : 0)); }
         if (rbase == 0 && !owned) {
           cr.head_row = r0; cr.head_val = shfl_t<T>(acc, 0); cr.head_has = (uint8_t)__shfl((int)has, 0, 64); cr.head_done = 1;
         }
-        if (rbase + 64 >= nr) tail_start = __shfl(qe, (int)(nr - 1 - rbase), 64);
       }
-      if (nr) { carry = sr.identity; carry_has = false; owned = true; }
-      // entries [tail_start, cnt) belong to row r1, which ends in a later task: fold them into the carry
-      if (tail_start < cnt) {
-        T pa = sr.identity; bool ph = false;
-        for (uint32_t q = tail_start + lane; q < cnt; q += 64) { pa = ph ? sr.add(pa, prod[q]) : prod[q]; ph = true; }
-        const T tot = wp_wave_total<T>(sr.add_op(), ph ? pa : sr.identity, sr.identity);
-        carry = carry_has ? sr.add(carry, tot) : tot; carry_has = true;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_wave_barrier();   // LDS slice is free for the next task
+      // entries [tail_start, cnt) belong to row r1, which ends in a later task: they become the carry
+      if (nr) {
+        owned = true;
+        if (tail_start < cnt) { carry = scan[cnt - 1]; carry_has = true; } else { carry = sr.identity; carry_has = false; }
+      } else if (cnt) { carry = scan[cnt - 1]; carry_has = true; }           // still inside row r0 (includes what was carried in)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();   // LDS slices are free for the next task
       if (more) {
 #pragma unroll
-        for (int u = 0; u < WP_PER; u++) { cA[u] = cB[u]; vA[u] = vB[u]; }
-        rpA = rpAn; rpB = rpBn;
+        for (int u = 0; u < WP_PER; u++) { cA[u] = cB[u]; vA[u] = vB[u]; gA[u] = gB[u]; cB[u] = cC[u]; }
+        rpA = rpAn; rpB = rpBn; rpAn = rpAnn; rpBn = rpBnn;
       }
     }
   }
-  // the row this wave's range ends in (if the range ends strictly inside it, or at its very end without its end marker)
-  {
-    const uint32_t rend = a.trow[t1], eend = a.tent[t1];
-    if (rend < a.nrows && (carry_has || eend > a.rowptr[rend] || !owned)) {
-      if (owned) { cr.tail_row = rend; cr.tail_val = carry; cr.tail_has = carry_has; }
-      else { cr.head_row = rend; cr.head_val = carry; cr.head_has = carry_has; cr.head_done = 0; }   // the whole range lies inside one row
-    }
+  // the row the range ends in, if it ends strictly inside it or at its very end without its end marker
+  if (end_r < a.nrows && (carry_has || !owned)) {
+    if (owned) { cr.tail_row = end_r; cr.tail_val = carry; cr.tail_has = carry_has; }
+    else { cr.head_row = end_r; cr.head_val = carry; cr.head_has = carry_has; cr.head_done = 0; }   // the whole range lies inside one row
   }
-  if (lane == 0) a.carry[gw] = cr;
+  if (lane == 0) wp_st_carry(a.carry + rec, cr);
+  if (lane > 0 && (uint32_t)lane < nrec) {       // the other chunk ids of a static range: empty records
+    WpCarry<T> e; e.head_row = e.tail_row = WP_NONE; e.head_has = e.head_done = e.tail_has = e.pad = 0; e.head_val = e.tail_val = sr.identity;
+    wp_st_carry(a.carry + rec + lane, e);
+  }
+  rec = dyn0 + (uint32_t)__builtin_amdgcn_readfirstlane(next_raw) * nwg + jwg; nrec = 1;
+  }
+#ifdef WP_PROFILE
+  if (lane == 0) { const unsigned long long t = WP_CLK(); g_wp_prof[blockIdx.x * WP_WAVES + wv] = t - pf_t0; g_wp_prof[4096 + blockIdx.x * WP_WAVES + wv] = 1ull; }
+#endif
 }
 
 // combine the partials of rows that span several waves' ranges, in wave order
 template <class T, class SR>
-__global__ void k_spmv_wavepipe_fixup(const WpCarry<T>* __restrict__ carry0, uint32_t nwaves, T* __restrict__ y0, uint8_t* __restrict__ ypres0,
+__global__ void k_spmv_wavepipe_fixup(const WpCarry<T>* __restrict__ carry0, uint32_t nwaves /* records */, T* __restrict__ y0, uint8_t* __restrict__ ypres0,
                                       const WpArgs<T>* __restrict__ panels, const SR sr) {
   const WpCarry<T>* carry = panels ? panels[blockIdx.y].carry : carry0;
+  if (panels) nwaves = (panels[blockIdx.y].ntasks + panels[blockIdx.y].tasks_per_chunk - 1) / panels[blockIdx.y].tasks_per_chunk;   // records = chunks of this panel
   T* y = panels ? panels[blockIdx.y].y : y0; uint8_t* ypres = panels ? panels[blockIdx.y].ypres : ypres0;
   for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < nwaves; w += gridDim.x * blockDim.x) {
     const WpCarry<T> c = carry[w];
@@ -203,6 +317,12 @@ __global__ void k_spmv_wavepipe_fixup(const WpCarry<T>* __restrict__ carry0, uin
   }
 }
 
+// tasks per chunk: about 16 chunks per wave, at least WP_CHUNK tasks each
+inline uint32_t wp_chunk_tasks(uint32_t ntasks, uint32_t nwaves) {
+  const uint32_t k = ntasks / ((nwaves ? nwaves : 1) * wp_env("GRB_MI355X_WP_CHUNKS", 16u));
+  const uint32_t lo = wp_env("GRB_MI355X_WP_MINCHUNK", WP_CHUNK);
+  return k > lo ? k : lo;
+}
 // ---- plan pieces -------------------------------------------------------------------------------------------------------
 static __global__ void k_wp_task_starts(const uint32_t* __restrict__ rowptr, uint32_t nrows, uint32_t nnz, uint32_t ntasks,
                                          uint32_t* __restrict__ trow, uint32_t* __restrict__ tent) {
@@ -270,11 +390,10 @@ template <class T> bool run_wavepipe(const SpmvCall& c, const SemiringDesc& d, i
   DevBuf xp((size_t)M.wp_nwarm * sizeof(T) + 8);
   const bool uses_u = d.flip ? binop_uses_x(d.mulop) : binop_uses_y(d.mulop);
   if (uses_u) hipLaunchKernelGGL((k_wp_permute<T>), dim3(2048), dim3(256), 0, stream(), (const T*)c.uval, M.wp_hot.as<uint32_t>(), M.wp_nwarm, xp.as<T>());
-  const uint32_t nwaves = (uint32_t)ncu * WP_WGS_PER_CU * WP_WAVES;
-  const uint32_t tpw = (M.wp_ntasks + nwaves - 1) / nwaves;
+  const uint32_t tpw = wp_chunk_tasks(M.wp_ntasks, (uint32_t)ncu * WP_WGS_PER_CU * WP_WAVES), nwaves = (M.wp_ntasks + tpw - 1) / tpw;      // one record per chunk
   if (M.wp_carry.bytes < (size_t)nwaves * sizeof(WpCarry<T>)) M.wp_carry.alloc((size_t)nwaves * sizeof(WpCarry<T>));
   WpArgs<T> a{M.rowptr.as<uint32_t>(), M.wp_pcol.as<uint32_t>(), (const T*)c.aval, (const T*)xp.p, (const T*)c.uval, M.wp_hot.as<uint32_t>(), M.wp_rs.as<uint32_t>(), M.wp_rs.as<uint32_t>() + (M.wp_ntasks + 1),
-              (T*)c.tval, c.tpres, M.wp_carry.as<WpCarry<T>>(), M.nrows, M.wp_ntasks, (uint32_t)M.nnz, tpw, M.wp_nhot, M.wp_nwarm};
+              (T*)c.tval, c.tpres, M.wp_carry.as<WpCarry<T>>(), M.nrows, M.wp_ntasks, (uint32_t)M.nnz, tpw, wp_env("GRB_MI355X_WP_STATIC", WP_STATIC_PCT), M.wp_nhot, M.wp_nwarm};
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;
     hipLaunchKernelGGL((k_spmv_wavepipe<T, SR>), dim3(ncu * WP_WGS_PER_CU), dim3(WP_WAVES * 64), 0, stream(), a, (const WpArgs<T>*)nullptr, sr);

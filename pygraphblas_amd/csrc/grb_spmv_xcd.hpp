@@ -31,9 +31,9 @@ struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per 
   DevBuf tasks;           // u32 per-panel merge-path task starts: trow then tent, (ntasks_k + 1) each
   DevBuf rowsub_ptr, rowsub_idx;   // u32[nrows+1], u32[F]: sub-rows of every row, in panel order
   DevBuf args;            // WpArgs<T>[XP] in HBM (pointers into the per-call buffers are patched every call)
-  DevBuf carry;           // WpCarry<T>[XP * waves_per_panel]
+  DevBuf carry;           // WpCarry<T>, one per chunk of tasks, panel after panel
   DevBuf xp, partial, scratch;     // per-call work buffers kept with the plan so the argument block never changes
-  uint64_t eoff[XP + 1], soff[XP + 1], toff[XP + 1]; uint32_t ntasks[XP]; uint32_t wn = 0; uint64_t F = 0; int tsize = 0;
+  uint64_t eoff[XP + 1], soff[XP + 1], toff[XP + 1]; uint32_t ntasks[XP]; uint32_t maxchunks = 1; uint32_t wn = 0; uint64_t F = 0; int tsize = 0;
 };
 
 // key = panel | (local < H ? local : H) | (local < H ? 0 : column): hot entries keep their frequency order, the rest sort by column
@@ -226,9 +226,14 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu) {
   P->wn = (n + XP - 1) / XP;
   P->order_pm.alloc((size_t)XP * P->wn * 4 + 4);
   hipLaunchKernelGGL(k_xp_order_pm, dim3(grid_n((uint64_t)XP * P->wn)), dim3(256), 0, stream(), P->order.as<uint32_t>(), n, P->wn, P->order_pm.as<uint32_t>());
-  const uint32_t wpp = (uint32_t)(ncu / XP) * WP_WGS_PER_CU * WP_WAVES;       // waves per panel
   constexpr uint32_t H = wp_hot<T>::H;
-  P->args.alloc(XP * sizeof(WpArgs<T>)); P->carry.alloc((size_t)XP * wpp * sizeof(WpCarry<T>));
+  P->args.alloc(XP * sizeof(WpArgs<T>));
+  size_t coff[XP + 1]; coff[0] = 0;
+  const uint32_t wpp = (uint32_t)(ncu / XP) * WP_WGS_PER_CU * WP_WAVES;       // waves per panel
+  uint32_t kt[XP];
+  for (int k = 0; k < XP; k++) { kt[k] = wp_chunk_tasks(P->ntasks[k], wpp); coff[k + 1] = coff[k] + (P->ntasks[k] + kt[k] - 1) / kt[k]; }
+  P->carry.alloc((coff[XP] + 1) * sizeof(WpCarry<T>)); P->maxchunks = 1;
+  for (int k = 0; k < XP; k++) if (coff[k + 1] - coff[k] > P->maxchunks) P->maxchunks = (uint32_t)(coff[k + 1] - coff[k]);
   P->xp.alloc((size_t)XP * P->wn * sizeof(T) + 8); P->partial.alloc(P->F * sizeof(T) + 8); P->scratch.alloc(P->F + 8);
   WpArgs<T> ha[XP];
   for (int k = 0; k < XP; k++) {
@@ -239,8 +244,8 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu) {
     a.x = P->xp.as<T>() + (size_t)k * P->wn; a.xorig = a.x; a.hot_cols = nullptr;
     a.trow = P->tasks.as<uint32_t>() + P->toff[k]; a.tent = a.trow + (P->ntasks[k] + 1);
     a.y = P->partial.as<T>() + P->soff[k]; a.ypres = P->scratch.as<uint8_t>() + P->soff[k];
-    a.carry = P->carry.as<WpCarry<T>>() + (size_t)k * wpp;
-    a.nrows = fk; a.ntasks = P->ntasks[k]; a.nnz = ek; a.tasks_per_wave = (P->ntasks[k] + wpp - 1) / wpp;
+    a.carry = P->carry.as<WpCarry<T>>() + coff[k];
+    a.nrows = fk; a.ntasks = P->ntasks[k]; a.nnz = ek; a.tasks_per_chunk = kt[k]; a.static_pct = wp_env("GRB_MI355X_WP_STATIC", WP_STATIC_PCT);
     a.nhot = P->wn < H ? P->wn : H; a.nwarm = 0xFFFFFFFFu;      // every gather of the panel falls in its window of xp
   }
   GRB_HIP(hipMemcpyAsync(P->args.p, ha, sizeof(ha), hipMemcpyHostToDevice, stream()));
@@ -254,14 +259,13 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
   if (c.aval && c.aval != M.val.p) return false;      // the plan's panel-major values are a copy of the stored ones (no typecast)
   auto* P = static_cast<XcdPlan*>(M.xcd.get());
   if (!P || P->tsize != (int)sizeof(T)) { build_xcd_plan<T>(M, ncu); P = static_cast<XcdPlan*>(M.xcd.get()); }
-  const uint32_t wpp = (uint32_t)(ncu / XP) * WP_WGS_PER_CU * WP_WAVES;
   const bool uses_u = d.flip ? binop_uses_x(d.mulop) : binop_uses_y(d.mulop);
   if (uses_u) hipLaunchKernelGGL((k_xp_permute<T>), dim3(2048), dim3(256), 0, stream(), (const T*)c.uval, P->order_pm.as<uint32_t>(), (uint32_t)(XP * P->wn), P->xp.as<T>());
   WpArgs<T> a0{};
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;
     hipLaunchKernelGGL((k_spmv_wavepipe<T, SR>), dim3(ncu * WP_WGS_PER_CU), dim3(WP_WAVES * 64), 0, stream(), a0, (const WpArgs<T>*)P->args.p, sr);
-    hipLaunchKernelGGL((k_spmv_wavepipe_fixup<T, SR>), dim3((wpp + 255) / 256, XP), dim3(256), 0, stream(), (const WpCarry<T>*)nullptr, wpp, (T*)nullptr, (uint8_t*)nullptr,
+    hipLaunchKernelGGL((k_spmv_wavepipe_fixup<T, SR>), dim3((P->maxchunks + 255) / 256, XP), dim3(256), 0, stream(), (const WpCarry<T>*)nullptr, P->maxchunks, (T*)nullptr, (uint8_t*)nullptr,
                        (const WpArgs<T>*)P->args.p, sr);
     uint64_t nb = ((uint64_t)M.nrows / 2 + 256) / 256; if (nb > 65535u * 8) nb = 65535u * 8; if (nb < 1) nb = 1;
     hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3((unsigned)nb), dim3(256), 0, stream(), M.nrows, P->rowsub_ptr.as<uint32_t>(), P->rowsub_idx.as<uint32_t>(), P->partial.as<T>(),
