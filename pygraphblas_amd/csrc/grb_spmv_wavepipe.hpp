@@ -30,8 +30,9 @@ constexpr int WP_SHORT = 24;                // rows longer than this (within one
 constexpr int WP_WAVES = 16;                // waves per workgroup (1024 threads)
 constexpr int WP_WGS_PER_CU = 1;            // one workgroup per CU (measured: 2 x 768 threads with 256-item tasks spills registers and is slower)
 constexpr int WP_LDS_BYTES = 160 * 1024 / WP_WGS_PER_CU;
-template <class T> struct wp_hot { static constexpr int H = (WP_LDS_BYTES - WP_WAVES * WP_ENT * ((int)sizeof(T) + 1) - 16) / (int)sizeof(T); };   // what the scan slices and row-start maps leave: 15870 (8 B) / 35836 (4 B)
+template <class T> struct wp_hot { static constexpr int H = (WP_LDS_BYTES - WP_WAVES * WP_ENT * (int)sizeof(T) - 16) / (int)sizeof(T); };   // what the scan slices leave: 16382 (8 B) / 36860 (4 B)
 constexpr uint32_t WP_NONE = 0xFFFFFFFFu;
+constexpr uint32_t WP_ROWSTART = 0x80000000u, WP_COLMASK = 0x7FFFFFFFu;   // plan column words: bit 31 marks the first entry of a row
 constexpr uint32_t WP_CHUNK = 4;              // tasks per chunk (the unit handed out dynamically; one carry record each)
 constexpr uint32_t WP_STATIC_PCT = 40;        // share of the chunks that is split statically
 inline uint32_t wp_env(const char* name, uint32_t dflt) { const char* e = getenv(name); return e && *e ? (uint32_t)atoi(e) : dflt; }   // tuning hooks
@@ -62,9 +63,9 @@ template <class T> struct WpArgs {
 // [trow[t], trow[t+1]); the entries of row trow[t+1] seen so far are carried to the next task.
 //
 // A lane owns WP_PER *consecutive* entries of the task (one wide load per stream).  The row sums are a segmented
-// inclusive scan of the products in entry order: the lanes that look at rows mark every row start in a byte map in LDS,
-// the entry lanes scan their own entries, a 6-step wave scan carries sums across lanes, the scanned values go to LDS
-// once (conflict-free) and every row reads the value at its last entry.  The cost of a task does not depend on how its
+// inclusive scan of the products in entry order: the plan marks the first entry of every row in bit 31 of its column
+// word, the entry lanes scan their own entries, a 6-step wave scan carries sums across lanes, the scanned values go to
+// LDS once (conflict-free) and every row reads the value at its last entry.  The cost of a task does not depend on how its
 // entries are split into rows (measured before: per-row serial sums spent half of every wave's time in divergent,
 // bank-conflicting LDS reads).
 // The argument block of panel mode is read from memory, so the compiler cannot tell that the pointers in it are global
@@ -80,6 +81,12 @@ template <class E> __device__ __forceinline__ E wp_ld(const E* p) {
   typedef typename wp_word<sizeof(E)>::type W;
   const W w = *(const WP_G W*)(uintptr_t)p;
   E e; __builtin_memcpy(&e, &w, sizeof(E)); return e;
+}
+// a wave-uniform value kept in scalar registers (the carried partials live across the whole task loop)
+template <class E> __device__ __forceinline__ E wp_uniform(E v) {
+  if constexpr (sizeof(E) == 8) { union { E e; int i[2]; } u; u.e = v; u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]); u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]); return u.e; }
+  else if constexpr (sizeof(E) == 4) { union { E e; int i; } u; u.e = v; u.i = __builtin_amdgcn_readfirstlane(u.i); return u.e; }
+  else { union { E e; uint16_t s; } u; u.s = 0; u.e = v; const int x = __builtin_amdgcn_readfirstlane((int)u.s); u.s = (uint16_t)x; return u.e; }
 }
 template <class E> __device__ __forceinline__ void wp_st(E* p, E v) {
   typedef typename wp_word<sizeof(E)>::type W;
@@ -110,21 +117,22 @@ template <class E, int N> __device__ __forceinline__ void wp_load_run(const E* _
   }
 }
 
-template <class T, class SR>
+template <class T> struct WpStage { uint32_t c[WP_PER]; T v[WP_PER], g[WP_PER]; uint32_t rpa, rpb; };   // what one task has in flight
+
+template <class T, class SR, bool PANEL>
 __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k_spmv_wavepipe(const WpArgs<T> a0, const WpArgs<T>* __restrict__ panels, const SR sr) {
   // panel mode (kernel X, grb_spmv_xcd.hpp): workgroup b works on column panel b % 8 — the XCD it is observed to run on
-  const WpArgs<T> a = panels ? panels[blockIdx.x & 7] : a0;
+  const WpArgs<T> a = PANEL ? panels[blockIdx.x & 7] : a0;
   constexpr int H = wp_hot<T>::H;
   __shared__ T s_hot[H];
   __shared__ __attribute__((aligned(16))) T s_scan[WP_WAVES][WP_ENT];
-  __shared__ uint32_t s_flag[WP_WAVES][WP_ENT / 4];
   __shared__ uint32_t s_next;                                         // next dynamic chunk of this workgroup
   if (threadIdx.x == 0) s_next = 0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const bool use_a = sr.uses_a(), use_u = sr.uses_u();
   if (use_u) for (uint32_t h = threadIdx.x; h < a.nhot; h += WP_WAVES * 64) s_hot[h] = wp_ld(a.x + h);      // x is the rank-permuted copy of u
   __syncthreads();
-  T* scan = s_scan[wv]; uint32_t* flagw = s_flag[wv]; uint8_t* flagb = (uint8_t*)flagw;
+  T* scan = s_scan[wv];
 #ifdef WP_PROFILE
   const unsigned long long pf_t0 = WP_CLK();
 #endif
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
   // complete one per ~80 ns per address, which made the whole kernel 1.5-2x slower.)  Every chunk id has a carry
   // record; a static range uses the record of its first chunk and leaves the others empty.
   const uint32_t K = a.tasks_per_chunk, nchunks = (K + a.ntasks - 1) / K;
-  const uint32_t nwg = panels ? (gridDim.x >> 3) : gridDim.x, jwg = panels ? (blockIdx.x >> 3) : blockIdx.x;
+  const uint32_t nwg = PANEL ? (gridDim.x >> 3) : gridDim.x, jwg = PANEL ? (blockIdx.x >> 3) : blockIdx.x;
   // chunk ids [0, dyn0) are static ranges of s0 chunks, dealt to (workgroup, wave) so that every workgroup samples the
   // whole matrix (its parts differ in cost); ids >= dyn0 are dynamic, workgroup j owning those congruent to j
   uint32_t s0 = (uint32_t)((uint64_t)nchunks * a.static_pct / 100 / (nwg * WP_WAVES)); if (s0 > WP_MAX_STATIC) s0 = WP_MAX_STATIC;
@@ -168,8 +176,8 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
     }
 #pragma unroll
     for (int u = 0; u < WP_PER; u++) {
-      const uint32_t cc = (uint32_t)(lane * WP_PER + u) < cnt ? c[u] : 0u;   // rank of the column if < nwarm (0 = most frequent), else nwarm + column
-      const T* xb = cc < a.nwarm ? a.x : a.xorig - a.nwarm;          // warm: rank-ordered copy of the top of u; cold: u itself
+      const uint32_t cc = (uint32_t)(lane * WP_PER + u) < cnt ? (c[u] & WP_COLMASK) : 0u;   // rank of the column if < nwarm (0 = most frequent), else nwarm + column
+      const T* xb = PANEL || cc < a.nwarm ? a.x : a.xorig - a.nwarm;   // warm: rank-ordered copy of the top of u; cold: u itself (a panel's window is all warm)
       g[u] = use_u ? wp_ld(xb + (cc >= (uint32_t)H ? cc : 0u)) : T();          // LDS-resident ranks read element 0 (always cached) and are replaced below
     }
   };
@@ -182,63 +190,42 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
     if (tc + 61 >= t1) { next_raw = grab(); end_r = __builtin_amdgcn_readlane(d_r, (int)nin); }   // last window: ask for the next chunk now
     // three tasks are in flight per wave: task i (values + gathers issued, being reduced), task i+1 (column indices
     // loaded, gathers issued during iteration i) and task i+2 (column indices issued)
-    uint32_t cA[WP_PER]; T vA[WP_PER], gA[WP_PER]; uint32_t rpA, rpB;
-    uint32_t cB[WP_PER]; uint32_t rpAn = 0, rpBn = 0;
+    WpStage<T> S0, S1, S2;
     {
       const uint32_t r00 = __builtin_amdgcn_readlane(d_r, 0), e00 = __builtin_amdgcn_readlane(d_e, 0), e01 = __builtin_amdgcn_readlane(d_e, 1);
       if (tc == t0) owned = wp_ld(a.rowptr + (r00 < a.nrows ? r00 : a.nrows)) == e00;   // does this wave see the start of its first row?
-      load_cols(e00, r00, cA, rpA, rpB);
-      if (nin > 1) load_cols(e01, __builtin_amdgcn_readlane(d_r, 1), cB, rpAn, rpBn);
-      issue_gather(e00, e01 - e00, cA, vA, gA);
+      load_cols(e00, r00, S0.c, S0.rpa, S0.rpb);
+      if (nin > 1) load_cols(e01, __builtin_amdgcn_readlane(d_r, 1), S1.c, S1.rpa, S1.rpb);
+      issue_gather(e00, e01 - e00, S0.c, S0.v, S0.g);
     }
-    for (uint32_t i = 0; i < nin; i++) {
+    // one task: A is reduced while the gathers of B and the column indices of C are issued.  The loop below is unrolled
+    // three times so that the three register sets swap roles without being copied.
+    auto step = [&](uint32_t i, WpStage<T>& A, WpStage<T>& B, WpStage<T>& C) __attribute__((always_inline)) {
       const int iu = (int)__builtin_amdgcn_readfirstlane(i);
       const uint32_t r0 = __builtin_amdgcn_readlane(d_r, iu), e0 = __builtin_amdgcn_readlane(d_e, iu);
       const uint32_t r1 = __builtin_amdgcn_readlane(d_r, iu + 1), e1 = __builtin_amdgcn_readlane(d_e, iu + 1);
       const uint32_t cnt = e1 - e0, nr = r1 - r0;
       const bool more = i + 1 < nin, more2 = i + 2 < nin;
-      // ---- rows, pass 1: mark the first entry of every row that starts in this task (and of the row that follows them)
-#pragma unroll
-      for (int w = lane; w < WP_ENT / 4; w += 64) flagw[w] = 0;
-      uint32_t qs0 = 0, qe0 = 0, tail_start = 0;                  // tail_start: task-local offset where the entries of row r1 begin
-      for (uint32_t rbase = 0; rbase < nr; rbase += 64) {
-        const uint32_t ri = rbase + lane; const bool live = ri < nr; const uint32_t r = r0 + ri;
-        uint32_t rs_, re_;
-        if (rbase == 0) { rs_ = rpA; re_ = rpB; } else { rs_ = live ? wp_ld(a.rowptr + r) : e1; re_ = live ? wp_ld(a.rowptr + r + 1) : e1; }
-        const bool before = rs_ < e0;                           // only row r0 can have started in an earlier task
-        if (before) rs_ = e0;
-        if (!live) { rs_ = re_ = e0; }
-        const uint32_t qs = rs_ - e0, qe = re_ - e0;
-        if (live && qe > qs && !before) flagb[qs] = 1;
-        if (live && ri == nr - 1 && qe < cnt) flagb[qe] = 1;
-        if (rbase + 64 >= nr) tail_start = __shfl(qe, (int)(nr - 1 - rbase), 64);
-        if (rbase == 0) { qs0 = qs; qe0 = qe; }
-      }
-      if (!carry_has && lane == 0) flagb[0] = 1;                // nothing carried in: entry 0 starts a segment
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();   // LDS ops of one wave execute in order; keep the compiler from reordering
-      uint32_t fbits = 0;                                       // bit u: my entry u is the first of its row
-#pragma unroll
-      for (int w = 0; w < WP_PER / 4; w++) {
-        const uint32_t x = flagw[lane * (WP_PER / 4) + w];
-        fbits |= (((x & 1u) | ((x >> 7) & 2u) | ((x >> 14) & 4u) | ((x >> 21) & 8u)) << (4 * w));
-      }
       // ---- entries: products (LDS table for the hottest ranks) and their segmented scan in entry order
       T p[WP_PER];
 #pragma unroll
       for (int u = 0; u < WP_PER; u++) {
-        const uint32_t cc = cA[u];
-        const T uvv = use_u ? (cc < (uint32_t)H ? s_hot[cc < (uint32_t)H ? cc : 0] : gA[u]) : T();
-        p[u] = sr.mult(vA[u], uvv);                             // entries past cnt hold junk: a forward scan never lets it reach a live position
+        const uint32_t cc = A.c[u] & WP_COLMASK;
+        const T uvv = use_u ? (cc < (uint32_t)H ? s_hot[cc < (uint32_t)H ? cc : 0] : A.g[u]) : T();
+        p[u] = sr.mult(A.v[u], uvv);                             // entries past cnt hold junk: a forward scan never lets it reach a live position
       }
-      uint32_t cC[WP_PER]; uint32_t rpAnn = 0, rpBnn = 0; T vB[WP_PER], gB[WP_PER];
-      if (more) issue_gather(e1, __builtin_amdgcn_readlane(d_e, iu + 2) - e1, cB, vB, gB);                          // stage 2 of task i+1
-      if (more2) load_cols(__builtin_amdgcn_readlane(d_e, iu + 2), __builtin_amdgcn_readlane(d_r, iu + 2), cC, rpAnn, rpBnn);   // stage 1 of task i+2
+      if (more) issue_gather(e1, __builtin_amdgcn_readlane(d_e, iu + 2) - e1, B.c, B.v, B.g);                          // stage 2 of task i+1
+      if (more2) load_cols(__builtin_amdgcn_readlane(d_e, iu + 2), __builtin_amdgcn_readlane(d_r, iu + 2), C.c, C.rpa, C.rpb);   // stage 1 of task i+2
       {
-        T agg = p[0];
+        bool st[WP_PER];                                        // my entry u is the first of its row (bit 31 of the column word, set by the plan)
 #pragma unroll
-        for (int u = 1; u < WP_PER; u++) agg = ((fbits >> u) & 1u) ? p[u] : sr.add(agg, p[u]);
-        if (lane == 0 && fbits == 0) agg = sr.add(carry, agg);    // the carried partial flows through lane 0 (entry 0 is marked when there is none)
-        T v = agg; int f = fbits != 0;                          // sum since the last row start at or before my last entry
+        for (int u = 0; u < WP_PER; u++) st[u] = (int32_t)A.c[u] < 0;
+        if (lane == 0 && !carry_has) st[0] = true;              // nothing carried in: entry 0 starts a segment whatever it is
+        T agg = p[0]; bool anyf = st[0];
+#pragma unroll
+        for (int u = 1; u < WP_PER; u++) { agg = st[u] ? p[u] : sr.add(agg, p[u]); anyf = anyf || st[u]; }
+        if (lane == 0 && !anyf) agg = sr.add(carry, agg);       // the carried partial flows through lane 0
+        T v = agg; int f = anyf;                                // sum since the last row start at or before my last entry
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
           const T vu = shfl_up_t<T>(v, d); const int fu = __shfl_up(f, d, 64);
@@ -246,35 +233,40 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
         }
         T run = shfl_up_t<T>(v, 1); if (lane == 0) run = carry;   // what flows into my first entry (unused when it starts a row)
 #pragma unroll
-        for (int u = 0; u < WP_PER; u++) { run = ((fbits >> u) & 1u) ? p[u] : sr.add(run, p[u]); p[u] = run; }
+        for (int u = 0; u < WP_PER; u++) { run = st[u] ? p[u] : sr.add(run, p[u]); p[u] = run; }
         __builtin_memcpy(&scan[lane * WP_PER], &p[0], sizeof(T) * WP_PER);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();
-      // ---- rows, pass 2: a row's sum is the scanned value at its last entry; row r0 also owns what was carried in
+      // ---- rows: a row's sum is the scanned value at its last entry; row r0 also owns what was carried in
+      uint32_t tail_start = 0;                                  // task-local offset where the entries of row r1 begin
       for (uint32_t rbase = 0; rbase < nr; rbase += 64) {
         const uint32_t ri = rbase + lane; const bool live = ri < nr; const uint32_t r = r0 + ri;
-        uint32_t qs = qs0, qe = qe0;
-        if (rbase) { const uint32_t rs_ = live ? wp_ld(a.rowptr + r) : e0, re_ = live ? wp_ld(a.rowptr + r + 1) : e0; qs = rs_ - e0; qe = re_ - e0; }
+        uint32_t rs_, re_;
+        if (rbase == 0) { rs_ = A.rpa; re_ = A.rpb; } else { rs_ = live ? wp_ld(a.rowptr + r) : e0; re_ = live ? wp_ld(a.rowptr + r + 1) : e0; }
+        if (rs_ < e0) rs_ = e0;                                 // only row r0 can have started in an earlier task
+        if (!live) { rs_ = re_ = e0; }
+        const uint32_t qs = rs_ - e0, qe = re_ - e0;
+        if (rbase + 64 >= nr) tail_start = __shfl(qe, (int)(nr - 1 - rbase), 64);
         T acc = sr.identity; bool has = false;
         if (live && qe > qs) { acc = scan[qe - 1]; has = true; }
         else if (rbase == 0 && lane == 0 && carry_has) { acc = carry; has = true; }   // row r0 ended exactly where this task starts
         const bool to_fixup = rbase == 0 && lane == 0 && !owned;      // the row began in another wave's range
         if (live && !to_fixup) { if (has) wp_st(a.y + r, acc); wp_st(a.ypres + r, (uint8_t)(has ? 1 : 0)); }
         if (rbase == 0 && !owned) {
-          cr.head_row = r0; cr.head_val = shfl_t<T>(acc, 0); cr.head_has = (uint8_t)__shfl((int)has, 0, 64); cr.head_done = 1;
+          cr.head_row = r0; cr.head_val = wp_uniform(acc); cr.head_has = (uint8_t)__builtin_amdgcn_readfirstlane((int)has); cr.head_done = 1;
         }
       }
       // entries [tail_start, cnt) belong to row r1, which ends in a later task: they become the carry
       if (nr) {
         owned = true;
-        if (tail_start < cnt) { carry = scan[cnt - 1]; carry_has = true; } else { carry = sr.identity; carry_has = false; }
-      } else if (cnt) { carry = scan[cnt - 1]; carry_has = true; }           // still inside row r0 (includes what was carried in)
+        if (tail_start < cnt) { carry = wp_uniform(scan[cnt - 1]); carry_has = true; } else { carry = sr.identity; carry_has = false; }
+      } else if (cnt) { carry = wp_uniform(scan[cnt - 1]); carry_has = true; }           // still inside row r0 (includes what was carried in)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();   // LDS slices are free for the next task
-      if (more) {
-#pragma unroll
-        for (int u = 0; u < WP_PER; u++) { cA[u] = cB[u]; vA[u] = vB[u]; gA[u] = gB[u]; cB[u] = cC[u]; }
-        rpA = rpAn; rpB = rpBn; rpAn = rpAnn; rpBn = rpBnn;
-      }
+    };
+    for (uint32_t i = 0; i < nin; i += 3) {
+      step(i, S0, S1, S2);
+      if (i + 1 < nin) step(i + 1, S1, S2, S0);
+      if (i + 2 < nin) step(i + 2, S2, S0, S1);
     }
   }
   // the row the range ends in, if it ends strictly inside it or at its very end without its end marker
@@ -351,6 +343,11 @@ static __global__ void k_wp_remap(const uint32_t* __restrict__ col, uint64_t nnz
   }
 }
 
+// bit 31 of the column word of the first entry of every non-empty row
+static __global__ void k_wp_mark_row_starts(const uint32_t* __restrict__ rowptr, uint32_t nrows, uint32_t* __restrict__ pcol) {
+  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < nrows; r += gridDim.x * 256) { const uint32_t s = rowptr[r]; if (rowptr[r + 1] > s) pcol[s] |= WP_ROWSTART; }
+}
+
 template <class T> void build_wavepipe_plan(DevCSR& M) {
   constexpr uint32_t H = wp_hot<T>::H;
   auto grid_n = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 8192) b = 8192; return (unsigned)b; };
@@ -375,6 +372,7 @@ template <class T> void build_wavepipe_plan(DevCSR& M) {
   hipLaunchKernelGGL(k_wp_rank, dim3(grid_n(n)), dim3(256), 0, stream(), id2.as<uint32_t>(), n, rank.as<uint32_t>());
   M.wp_pcol.alloc(M.nnz * 4 + 4);
   hipLaunchKernelGGL(k_wp_remap, dim3(grid_n(M.nnz)), dim3(256), 0, stream(), M.col.as<uint32_t>(), M.nnz, rank.as<uint32_t>(), nwarm, M.wp_pcol.as<uint32_t>());
+  hipLaunchKernelGGL(k_wp_mark_row_starts, dim3(grid_n(M.nrows)), dim3(256), 0, stream(), M.rowptr.as<uint32_t>(), M.nrows, M.wp_pcol.as<uint32_t>());
   M.wp_nhot = nhot; M.wp_ntasks = ntasks; M.wp_tsize = (int)sizeof(T);
   GRB_HIP(hipStreamSynchronize(stream()));
 }
@@ -396,7 +394,7 @@ template <class T> bool run_wavepipe(const SpmvCall& c, const SemiringDesc& d, i
               (T*)c.tval, c.tpres, M.wp_carry.as<WpCarry<T>>(), M.nrows, M.wp_ntasks, (uint32_t)M.nnz, tpw, wp_env("GRB_MI355X_WP_STATIC", WP_STATIC_PCT), M.wp_nhot, M.wp_nwarm};
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;
-    hipLaunchKernelGGL((k_spmv_wavepipe<T, SR>), dim3(ncu * WP_WGS_PER_CU), dim3(WP_WAVES * 64), 0, stream(), a, (const WpArgs<T>*)nullptr, sr);
+    hipLaunchKernelGGL((k_spmv_wavepipe<T, SR, false>), dim3(ncu * WP_WGS_PER_CU), dim3(WP_WAVES * 64), 0, stream(), a, (const WpArgs<T>*)nullptr, sr);
     hipLaunchKernelGGL((k_spmv_wavepipe_fixup<T, SR>), dim3((nwaves + 255) / 256), dim3(256), 0, stream(), M.wp_carry.as<WpCarry<T>>(), nwaves, (T*)c.tval, c.tpres,
                        (const WpArgs<T>*)nullptr, sr);
     g_last_plan += std::string("k_spmv_wavepipe<") + (sr.is_static ? "static" : "dynamic") + ",hot=" + std::to_string(M.wp_nhot) + "> ";

@@ -222,6 +222,7 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu) {
     uint32_t* tr = P->tasks.as<uint32_t>() + P->toff[k];
     hipLaunchKernelGGL(k_wp_task_starts, dim3(grid_n(P->ntasks[k] + 1)), dim3(256), 0, stream(), P->rowptr.as<uint32_t>() + P->soff[k] + k, (uint32_t)fk, (uint32_t)ek, P->ntasks[k],
                        tr, tr + (P->ntasks[k] + 1));
+    hipLaunchKernelGGL(k_wp_mark_row_starts, dim3(grid_n(fk)), dim3(256), 0, stream(), P->rowptr.as<uint32_t>() + P->soff[k] + k, (uint32_t)fk, P->pcol.as<uint32_t>() + P->eoff[k]);
   }
   P->wn = (n + XP - 1) / XP;
   P->order_pm.alloc((size_t)XP * P->wn * 4 + 4);
@@ -264,7 +265,7 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
   WpArgs<T> a0{};
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;
-    hipLaunchKernelGGL((k_spmv_wavepipe<T, SR>), dim3(ncu * WP_WGS_PER_CU), dim3(WP_WAVES * 64), 0, stream(), a0, (const WpArgs<T>*)P->args.p, sr);
+    hipLaunchKernelGGL((k_spmv_wavepipe<T, SR, true>), dim3(ncu * WP_WGS_PER_CU), dim3(WP_WAVES * 64), 0, stream(), a0, (const WpArgs<T>*)P->args.p, sr);
     hipLaunchKernelGGL((k_spmv_wavepipe_fixup<T, SR>), dim3((P->maxchunks + 255) / 256, XP), dim3(256), 0, stream(), (const WpCarry<T>*)nullptr, P->maxchunks, (T*)nullptr, (uint8_t*)nullptr,
                        (const WpArgs<T>*)P->args.p, sr);
     uint64_t nb = ((uint64_t)M.nrows / 2 + 256) / 256; if (nb > 65535u * 8) nb = 65535u * 8; if (nb < 1) nb = 1;
