@@ -130,7 +130,8 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
   if (threadIdx.x == 0) s_next = 0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const bool use_a = sr.uses_a(), use_u = sr.uses_u();
-  if (use_u) for (uint32_t h = threadIdx.x; h < a.nhot; h += WP_WAVES * 64) s_hot[h] = wp_ld(a.x + h);      // x is the rank-permuted copy of u
+  const T* const u_ptr = PANEL ? a0.xorig : a.xorig;                     // panel mode: u comes with the launch, the rest of `a` is the plan's
+  if (use_u) for (uint32_t h = threadIdx.x; h < a.nhot; h += WP_WAVES * 64) s_hot[h] = wp_ld(a.x + h);      // the table's contents, gathered from u once per call
   __syncthreads();
   T* scan = s_scan[wv];
 #ifdef WP_PROFILE
@@ -177,8 +178,12 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
 #pragma unroll
     for (int u = 0; u < WP_PER; u++) {
       const uint32_t cc = (uint32_t)(lane * WP_PER + u) < cnt ? (c[u] & WP_COLMASK) : 0u;   // rank of the column if < nwarm (0 = most frequent), else nwarm + column
-      const T* xb = PANEL || cc < a.nwarm ? a.x : a.xorig - a.nwarm;   // warm: rank-ordered copy of the top of u; cold: u itself (a panel's window is all warm)
-      g[u] = use_u ? wp_ld(xb + (cc >= (uint32_t)H ? cc : 0u)) : T();          // LDS-resident ranks read element 0 (always cached) and are replaced below
+      if constexpr (PANEL) {
+        g[u] = use_u ? wp_ld(u_ptr + (cc >= (uint32_t)H ? cc - (uint32_t)H : 0u)) : T();   // column word = H + column; LDS-resident ones read u[0] (cached) and are replaced below
+      } else {
+        const T* xb = cc < a.nwarm ? a.x : a.xorig - a.nwarm;           // warm: rank-ordered copy of the top of u; cold: u itself
+        g[u] = use_u ? wp_ld(xb + (cc >= (uint32_t)H ? cc : 0u)) : T();  // LDS-resident ranks read element 0 (always cached) and are replaced below
+      }
     }
   };
   // task descriptors live in registers, one task per lane, 61 tasks + 3 look-ahead at a time: the steady state

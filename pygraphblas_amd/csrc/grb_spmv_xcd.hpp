@@ -1,19 +1,19 @@
 // grb_spmv_xcd.hpp — SpMV kernel "X": kernel W run on eight column panels at once, one panel per XCD.
 //
-// Why (profiles/spmv_pmc_traffic.json): kernel W's time is its memory-side read traffic at ~5.2 TB/s, and 60 % of that
-// traffic is 128-byte line fills for gathers of u that miss the 4 MiB per-XCD L2 — every XCD sees all 32 MiB of u, so
-// the eight L2s cache eight copies of the same hot 4 MiB.  Kernel X gives each XCD its own eighth of the columns:
-//   * columns are ranked by frequency (as in W); column of rank r belongs to panel r & 7 with local index r >> 3, so
-//     every panel gets an equal share of hot, warm and cold columns and of the entries;
-//   * the plan stores the matrix panel-major: for each panel a CSR over its non-empty *sub-rows* (row fragments),
-//     a local-index column array and the values in that order;
-//   * per call u is written panel-major in rank order (xp[panel][local]); workgroup b (observed to run on XCD b % 8)
-//     runs W's wave pipeline on panel b & 7: its LDS table holds the panel's hottest 12 288 entries (= the global top
-//     98 304 columns spread over the XCDs) and every other gather falls in the panel's own 4 MiB window of xp, which
-//     its XCD's L2 keeps — so the aggregate 32 MiB of L2 holds all of u once;
+// Why (profiles/spmv_pmc_traffic.json): kernel W's time is its memory-side read traffic, and 60 % of that traffic is
+// 128-byte line fills for gathers of u that miss the 4 MiB per-XCD L2 — every XCD sees all 32 MiB of u, so the eight
+// L2s cache eight copies of the same hot 4 MiB.  Kernel X gives each XCD its own eighth of u:
+//   * u is cut into 128-byte lines; every line (16 FP64 columns) belongs to one panel.  Lines are dealt to the panels so
+//     that the panels hold the same number of entries (heaviest lines first to the lightest panel, then in snake order);
+//   * the plan stores the matrix panel-major: for each panel a CSR over its non-empty *sub-rows* (row fragments), the
+//     column words and the values in that order.  A column word is the slot in the panel's LDS table for the panel's
+//     H most frequent columns, H + column for the others (bit 31: first entry of a sub-row);
+//   * workgroup b (observed to run on XCD b % 8) runs W's wave pipeline on panel b & 7: its LDS table is filled from u
+//     through the panel's hot-column list, every other gather reads u itself and touches only the panel's lines, which
+//     its XCD's L2 keeps — so the aggregate 32 MiB of L2 holds u once and u is never copied or re-ordered per call;
 //   * each sub-row's sum goes to a partial array; a merge kernel adds the <= 8 partials of every row in panel order
 //     (fixed order => reproducible) and writes y.
-// Extra algorithmic cost: one partial (8 B written + read) and one index per sub-row (~12 M at R-MAT-22, ~0.3 GB)
+// Extra algorithmic cost: one partial (8 B written + read) and one index per sub-row (~7.7 M at R-MAT-22, ~0.2 GB)
 // against ~1.3 GB of avoided line fills.  Placement is used for speed only: any other block->XCD mapping is still correct.
 #pragma once
 #include "grb_spmv_wavepipe.hpp"
@@ -24,33 +24,53 @@ namespace grb {
 constexpr int XP = 8;      // panels = XCDs
 
 struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per matrix and value type
-  DevBuf order;           // u32[n]      original column of rank r
-  DevBuf order_pm;        // u32[8*wn]   the same, laid out like xp (panel-major)
+  DevBuf hot_cols;        // u32[8*H]    column held by slot h of panel k's LDS table
   DevBuf pcol, pval;      // u32[nnz], T[nnz] panel-major entries (local column index, value)
   DevBuf rowptr;          // u32[F + XP] per-panel sub-row pointers, relative to the panel's first entry (F_k + 1 each)
   DevBuf tasks;           // u32 per-panel merge-path task starts: trow then tent, (ntasks_k + 1) each
   DevBuf rowsub_ptr, rowsub_idx;   // u32[nrows+1], u32[F]: sub-rows of every row, in panel order
   DevBuf args;            // WpArgs<T>[XP] in HBM (pointers into the per-call buffers are patched every call)
   DevBuf carry;           // WpCarry<T>, one per chunk of tasks, panel after panel
-  DevBuf xp, partial, scratch;     // per-call work buffers kept with the plan so the argument block never changes
-  uint64_t eoff[XP + 1], soff[XP + 1], toff[XP + 1]; uint32_t ntasks[XP]; uint32_t maxchunks = 1; uint32_t wn = 0; uint64_t F = 0; int tsize = 0;
+  DevBuf xhot, partial, scratch;   // per-call work buffers kept with the plan so the argument block never changes (xhot: T[8*H], the LDS tables' contents)
+  uint64_t eoff[XP + 1], soff[XP + 1], toff[XP + 1]; uint32_t ntasks[XP]; uint32_t maxchunks = 1; uint32_t nhot[XP]; uint64_t F = 0; int tsize = 0;
 };
 
-// key = panel | (local < H ? local : H) | (local < H ? 0 : column): hot entries keep their frequency order, the rest sort by column
-static __global__ void k_xp_window_keys(const uint32_t* __restrict__ order, uint32_t n, uint32_t H, unsigned long long* __restrict__ key, uint32_t* __restrict__ colv) {
-  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
-    const uint32_t c = order[r], k = r & 7u, l = r >> 3;
-    key[r] = ((unsigned long long)k << 56) | ((unsigned long long)(l < H ? l : H) << 32) | (l < H ? 0u : c);
-    colv[r] = c;
+// weight of a line of u = entries in its columns
+static __global__ void k_xp_line_weights(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t line, uint32_t nlines, uint32_t* __restrict__ negw, uint32_t* __restrict__ id) {
+  for (uint32_t l = blockIdx.x * 256 + threadIdx.x; l < nlines; l += gridDim.x * 256) {
+    uint64_t w = 0; for (uint32_t j = 0; j < line; j++) { const uint64_t c = (uint64_t)l * line + j; if (c < n) w += cnt[c]; }
+    negw[l] = 0xFFFFFFFFu - (uint32_t)(w > 0xFFFFFFFEull ? 0xFFFFFFFEull : w); id[l] = l;
   }
 }
-// sorted position i holds column cols[i] of panel k = key >> 56; panel k has ceil((n - k) / 8) columns and starts after panels < k
-static __global__ void k_xp_window_rank(const unsigned long long* __restrict__ key, const uint32_t* __restrict__ cols, uint32_t n, uint32_t* __restrict__ rank, uint32_t* __restrict__ order) {
+// lines in descending weight: the first `ntop` take the panel the host balanced for them, the others are dealt in snake order
+static __global__ void k_xp_deal_lines(const uint32_t* __restrict__ sorted_line, uint32_t nlines, const uint8_t* __restrict__ top_panel, uint32_t ntop, uint8_t* __restrict__ panel_of_line) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nlines; i += gridDim.x * 256) {
+    uint32_t k;
+    if (i < ntop) k = top_panel[i]; else { const uint32_t m = (i - ntop) % (2 * XP); k = m < XP ? m : 2 * XP - 1 - m; }
+    panel_of_line[sorted_line[i]] = (uint8_t)k;
+  }
+}
+// key = panel | descending count | column: a panel's columns in frequency order (ties by index)
+static __global__ void k_xp_column_keys(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t line, const uint8_t* __restrict__ panel_of_line, unsigned long long* __restrict__ key, uint32_t* __restrict__ colv) {
+  for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) {
+    key[c] = ((unsigned long long)panel_of_line[c / line] << 60) | ((unsigned long long)(0xFFFFFFFFu - cnt[c]) << 28) | c;
+    colv[c] = c;
+  }
+}
+static __global__ void k_xp_panel_starts(const unsigned long long* __restrict__ key, uint32_t n, uint32_t* __restrict__ start) {
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const uint32_t k = (uint32_t)(key[i] >> 56);
-    uint32_t start = 0; for (uint32_t j = 0; j < k; j++) start += (n - j + 7) / 8;
-    const uint32_t r = (i - start) * 8 + k;
-    rank[cols[i]] = r; order[r] = cols[i];
+    const uint32_t k = (uint32_t)(key[i] >> 60);
+    if (i == 0 || (uint32_t)(key[i - 1] >> 60) != k) start[k] = i;
+  }
+}
+// code word of a column: (slot or H + column) << 3 | panel; the panel's hot-column list
+static __global__ void k_xp_column_codes(const unsigned long long* __restrict__ key, const uint32_t* __restrict__ cols, uint32_t n, uint32_t H, uint32_t s0, uint32_t s1, uint32_t s2,
+                                         uint32_t s3, uint32_t s4, uint32_t s5, uint32_t s6, uint32_t s7, uint32_t* __restrict__ code, uint32_t* __restrict__ hot_cols) {
+  const uint32_t st[XP] = {s0, s1, s2, s3, s4, s5, s6, s7};
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint32_t k = (uint32_t)(key[i] >> 60), c = cols[i], local = i - st[k];
+    code[c] = ((local < H ? local : H + c) << 3) | k;
+    if (local < H) hot_cols[(size_t)k * H + local] = c;
   }
 }
 static __global__ void k_xp_panel_keys(const uint32_t* __restrict__ col, uint64_t nnz, const uint32_t* __restrict__ rank, uint32_t* __restrict__ key, uint32_t* __restrict__ idx) {
@@ -87,25 +107,10 @@ static __global__ void k_xp_subrows(const uint32_t* __restrict__ head, const uin
     if (head[q]) { const uint32_t s = sidx[q]; rowptr[s + panel] = (uint32_t)(q - q0); subrow_row[s] = prow[q]; }
 }
 static __global__ void k_xp_set(uint32_t* p, uint32_t v) { *p = v; }
-// xp[d] = u[order_pm[d]] with order_pm the rank order laid out panel-major (d = panel * wn + local): coalesced index
-// reads and stores, 4 independent gathers in flight per thread
-template <class T> __global__ void k_xp_permute(const T* __restrict__ x, const uint32_t* __restrict__ order_pm, uint32_t total, T* __restrict__ xp) {
-  const uint32_t stride = gridDim.x * 256;
-  for (uint32_t d0 = blockIdx.x * 256 + threadIdx.x; d0 < total; d0 += 4 * stride) {
-    uint32_t o[4]; T v[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) { const uint32_t d = d0 + u * stride; o[u] = order_pm[d < total ? d : total - 1]; }
-#pragma unroll
-    for (int u = 0; u < 4; u++) v[u] = x[o[u]];
-#pragma unroll
-    for (int u = 0; u < 4; u++) { const uint32_t d = d0 + u * stride; if (d < total) xp[d] = v[u]; }
-  }
-}
-static __global__ void k_xp_order_pm(const uint32_t* __restrict__ order, uint32_t n, uint32_t wn, uint32_t* __restrict__ order_pm) {
-  for (uint32_t d = blockIdx.x * 256 + threadIdx.x; d < XP * wn; d += gridDim.x * 256) {
-    const uint32_t k = d / wn, l = d - k * wn, r = l * XP + k;
-    order_pm[d] = order[r < n ? r : n - 1];          // padding slots of the last window re-read a valid column
-  }
+// xhot[k*H + h] = u[hot column h of panel k]: the eight LDS tables' contents, gathered once per call (every workgroup of a
+// panel then loads its table with coalesced reads; gathering in each of the 32 workgroups cost 7-16 us of L2 traffic)
+template <class T> __global__ void k_xp_hot_gather(const T* __restrict__ u, const uint32_t* __restrict__ hot_cols, uint32_t total, T* __restrict__ xhot) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) xhot[i] = u[hot_cols[i]];
 }
 // y(i) = sum of the partials of row i's sub-rows, in panel order.  All (<= 8) index and partial loads of a row are
 // issued before the first add.
@@ -147,24 +152,40 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu) {
   auto grid_n = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 8192) b = 8192; return (unsigned)b; };
   auto* P = new XcdPlan(); M.xcd.reset(P);
   const uint32_t n = M.ncols; const uint64_t nnz = M.nnz;
-  // 1. rank the columns by frequency (descending; ties by index)
-  DevBuf cnt((size_t)n * 4 + 4), key((size_t)n * 4 + 4), id((size_t)n * 4 + 4), key2((size_t)n * 4 + 4), rank((size_t)n * 4 + 4);
-  P->order.alloc((size_t)n * 4 + 4);
+  // 1. deal the 128-byte lines of u to the panels (equal entry counts), rank every panel's columns by frequency
+  constexpr uint32_t HH = wp_hot<T>::H;
+  const uint32_t line = 128 / (uint32_t)sizeof(T), nlines = (n + line - 1) / line;
+  DevBuf cnt((size_t)n * 4 + 4), rank((size_t)n * 4 + 4);
+  P->hot_cols.alloc((size_t)XP * HH * 4 + 4);
   GRB_HIP(hipMemsetAsync(cnt.p, 0, (size_t)n * 4 + 4, stream()));
+  GRB_HIP(hipMemsetAsync(P->hot_cols.p, 0, (size_t)XP * HH * 4 + 4, stream()));
   hipLaunchKernelGGL(k_wp_col_hist, dim3(grid_n(nnz)), dim3(256), 0, stream(), M.col.as<uint32_t>(), nnz, cnt.as<uint32_t>());
-  hipLaunchKernelGGL(k_wp_neg_keys, dim3(grid_n(n)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, key.as<uint32_t>(), id.as<uint32_t>());
-  sort_pairs_u32(key.as<uint32_t>(), key2.as<uint32_t>(), id.as<uint32_t>(), P->order.as<uint32_t>(), n, 32);
-  hipLaunchKernelGGL(k_wp_rank, dim3(grid_n(n)), dim3(256), 0, stream(), P->order.as<uint32_t>(), n, rank.as<uint32_t>());
-  // 1b. inside a panel only the first H local indices (the LDS table) need to be in frequency order; the rest of the
-  //     window is re-ordered by column index so that the per-call operand copy reads u almost sequentially
+  uint32_t cstart[XP + 1];
   {
-    constexpr uint32_t HH = wp_hot<T>::H;
-    DevBuf k64((size_t)n * 8 + 8), k64o((size_t)n * 8 + 8), cin((size_t)n * 4 + 4), cout((size_t)n * 4 + 4);
-    hipLaunchKernelGGL(k_xp_window_keys, dim3(grid_n(n)), dim3(256), 0, stream(), P->order.as<uint32_t>(), n, HH, (unsigned long long*)k64.p, cin.as<uint32_t>());
-    sort_pairs_u64((const uint64_t*)k64.p, (uint64_t*)k64o.p, cin.as<uint32_t>(), cout.as<uint32_t>(), n, 60);
-    // position i of the sorted sequence -> panel k = key >> 56, local = i - first position of panel k
-    hipLaunchKernelGGL(k_xp_window_rank, dim3(grid_n(n)), dim3(256), 0, stream(), (const unsigned long long*)k64o.p, cout.as<uint32_t>(), n, rank.as<uint32_t>(), P->order.as<uint32_t>());
+    DevBuf negw((size_t)nlines * 4 + 4), lid((size_t)nlines * 4 + 4), negw2((size_t)nlines * 4 + 4), lsorted((size_t)nlines * 4 + 4), pol((size_t)nlines + 8);
+    hipLaunchKernelGGL(k_xp_line_weights, dim3(grid_n(nlines)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, line, nlines, negw.as<uint32_t>(), lid.as<uint32_t>());
+    sort_pairs_u32(negw.as<uint32_t>(), negw2.as<uint32_t>(), lid.as<uint32_t>(), lsorted.as<uint32_t>(), nlines, 32);
+    const uint32_t ntop = nlines < 4096u ? nlines : 4096u;                 // the heavy head of the distribution is balanced exactly
+    std::vector<uint32_t> topw(ntop); std::vector<uint8_t> topk(ntop);
+    GRB_HIP(hipMemcpyAsync(topw.data(), negw2.p, (size_t)ntop * 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+    uint64_t load[XP] = {0};
+    for (uint32_t i = 0; i < ntop; i++) { int best = 0; for (int k = 1; k < XP; k++) if (load[k] < load[best]) best = k; topk[i] = (uint8_t)best; load[best] += 0xFFFFFFFFu - topw[i]; }
+    DevBuf dtop((size_t)ntop + 8);
+    GRB_HIP(hipMemcpyAsync(dtop.p, topk.data(), ntop, hipMemcpyHostToDevice, stream()));
+    hipLaunchKernelGGL(k_xp_deal_lines, dim3(grid_n(nlines)), dim3(256), 0, stream(), lsorted.as<uint32_t>(), nlines, (const uint8_t*)dtop.p, ntop, (uint8_t*)pol.p);
+    DevBuf k64((size_t)n * 8 + 8), k64o((size_t)n * 8 + 8), cin((size_t)n * 4 + 4), cout((size_t)n * 4 + 4), dstart(XP * 4);
+    hipLaunchKernelGGL(k_xp_column_keys, dim3(grid_n(n)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, line, (const uint8_t*)pol.p, (unsigned long long*)k64.p, cin.as<uint32_t>());
+    sort_pairs_u64((const uint64_t*)k64.p, (uint64_t*)k64o.p, cin.as<uint32_t>(), cout.as<uint32_t>(), n, 64);
+    GRB_HIP(hipMemsetAsync(dstart.p, 0xFF, XP * 4, stream()));
+    hipLaunchKernelGGL(k_xp_panel_starts, dim3(grid_n(n)), dim3(256), 0, stream(), (const unsigned long long*)k64o.p, n, dstart.as<uint32_t>());
+    GRB_HIP(hipMemcpyAsync(cstart, dstart.p, XP * 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));   // (also orders the host buffers above)
+    cstart[XP] = n;
+    for (int k = XP - 1; k >= 0; k--) if (cstart[k] == 0xFFFFFFFFu) cstart[k] = cstart[k + 1];      // a panel without columns
+    hipLaunchKernelGGL(k_xp_column_codes, dim3(grid_n(n)), dim3(256), 0, stream(), (const unsigned long long*)k64o.p, cout.as<uint32_t>(), n, HH, cstart[0], cstart[1], cstart[2], cstart[3],
+                       cstart[4], cstart[5], cstart[6], cstart[7], rank.as<uint32_t>(), P->hot_cols.as<uint32_t>());
+    GRB_HIP(hipStreamSynchronize(stream()));
   }
+  for (int k = 0; k < XP; k++) { const uint32_t nk = cstart[k + 1] - cstart[k]; P->nhot[k] = nk < HH ? nk : HH; }
   // 2. entries grouped by panel (stable: row-major order is kept inside a panel)
   DevBuf pk(nnz * 4 + 4), pidx(nnz * 4 + 4), pk2(nnz * 4 + 4), perm(nnz * 4 + 4), rowidx(nnz * 4 + 4), prow(nnz * 4 + 4), hc(XP * 8);
   hipLaunchKernelGGL(k_xp_panel_keys, dim3(grid_n(nnz)), dim3(256), 0, stream(), M.col.as<uint32_t>(), nnz, rank.as<uint32_t>(), pk.as<uint32_t>(), pidx.as<uint32_t>());
@@ -224,9 +245,6 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu) {
                        tr, tr + (P->ntasks[k] + 1));
     hipLaunchKernelGGL(k_wp_mark_row_starts, dim3(grid_n(fk)), dim3(256), 0, stream(), P->rowptr.as<uint32_t>() + P->soff[k] + k, (uint32_t)fk, P->pcol.as<uint32_t>() + P->eoff[k]);
   }
-  P->wn = (n + XP - 1) / XP;
-  P->order_pm.alloc((size_t)XP * P->wn * 4 + 4);
-  hipLaunchKernelGGL(k_xp_order_pm, dim3(grid_n((uint64_t)XP * P->wn)), dim3(256), 0, stream(), P->order.as<uint32_t>(), n, P->wn, P->order_pm.as<uint32_t>());
   constexpr uint32_t H = wp_hot<T>::H;
   P->args.alloc(XP * sizeof(WpArgs<T>));
   size_t coff[XP + 1]; coff[0] = 0;
@@ -235,19 +253,19 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu) {
   for (int k = 0; k < XP; k++) { kt[k] = wp_chunk_tasks(P->ntasks[k], wpp); coff[k + 1] = coff[k] + (P->ntasks[k] + kt[k] - 1) / kt[k]; }
   P->carry.alloc((coff[XP] + 1) * sizeof(WpCarry<T>)); P->maxchunks = 1;
   for (int k = 0; k < XP; k++) if (coff[k + 1] - coff[k] > P->maxchunks) P->maxchunks = (uint32_t)(coff[k + 1] - coff[k]);
-  P->xp.alloc((size_t)XP * P->wn * sizeof(T) + 8); P->partial.alloc(P->F * sizeof(T) + 8); P->scratch.alloc(P->F + 8);
+  P->xhot.alloc((size_t)XP * H * sizeof(T) + 8); P->partial.alloc(P->F * sizeof(T) + 8); P->scratch.alloc(P->F + 8);
   WpArgs<T> ha[XP];
   for (int k = 0; k < XP; k++) {
     WpArgs<T>& a = ha[k];
     const uint32_t fk = (uint32_t)(P->soff[k + 1] - P->soff[k]), ek = (uint32_t)(P->eoff[k + 1] - P->eoff[k]);
     a.rowptr = P->rowptr.as<uint32_t>() + P->soff[k] + k; a.pcol = P->pcol.as<uint32_t>() + P->eoff[k];
     a.aval = P->pval.as<T>() + P->eoff[k];
-    a.x = P->xp.as<T>() + (size_t)k * P->wn; a.xorig = a.x; a.hot_cols = nullptr;
+    a.x = P->xhot.as<T>() + (size_t)k * H; a.xorig = nullptr; a.hot_cols = P->hot_cols.as<uint32_t>() + (size_t)k * H;      // u comes with the launch
     a.trow = P->tasks.as<uint32_t>() + P->toff[k]; a.tent = a.trow + (P->ntasks[k] + 1);
     a.y = P->partial.as<T>() + P->soff[k]; a.ypres = P->scratch.as<uint8_t>() + P->soff[k];
     a.carry = P->carry.as<WpCarry<T>>() + coff[k];
     a.nrows = fk; a.ntasks = P->ntasks[k]; a.nnz = ek; a.tasks_per_chunk = kt[k]; a.static_pct = wp_env("GRB_MI355X_WP_STATIC", WP_STATIC_PCT);
-    a.nhot = P->wn < H ? P->wn : H; a.nwarm = 0xFFFFFFFFu;      // every gather of the panel falls in its window of xp
+    a.nhot = P->nhot[k]; a.nwarm = H;
   }
   GRB_HIP(hipMemcpyAsync(P->args.p, ha, sizeof(ha), hipMemcpyHostToDevice, stream()));
   P->tsize = (int)sizeof(T);
@@ -261,8 +279,9 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
   auto* P = static_cast<XcdPlan*>(M.xcd.get());
   if (!P || P->tsize != (int)sizeof(T)) { build_xcd_plan<T>(M, ncu); P = static_cast<XcdPlan*>(M.xcd.get()); }
   const bool uses_u = d.flip ? binop_uses_x(d.mulop) : binop_uses_y(d.mulop);
-  if (uses_u) hipLaunchKernelGGL((k_xp_permute<T>), dim3(2048), dim3(256), 0, stream(), (const T*)c.uval, P->order_pm.as<uint32_t>(), (uint32_t)(XP * P->wn), P->xp.as<T>());
-  WpArgs<T> a0{};
+  WpArgs<T> a0{}; a0.xorig = (const T*)c.uval;        // the only per-call pointer of the pipeline: u itself
+  constexpr uint32_t H = wp_hot<T>::H;
+  if (uses_u) hipLaunchKernelGGL((k_xp_hot_gather<T>), dim3((XP * H + 255) / 256), dim3(256), 0, stream(), (const T*)c.uval, P->hot_cols.as<uint32_t>(), (uint32_t)(XP * H), P->xhot.as<T>());
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;
     hipLaunchKernelGGL((k_spmv_wavepipe<T, SR, true>), dim3(ncu * WP_WGS_PER_CU), dim3(WP_WAVES * 64), 0, stream(), a0, (const WpArgs<T>*)P->args.p, sr);
