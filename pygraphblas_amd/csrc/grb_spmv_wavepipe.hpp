@@ -105,7 +105,7 @@ template <class E, int N> __device__ __forceinline__ void wp_load_run(const E* _
     if constexpr (sizeof(E) >= 4 && (sizeof(E) * N) % 16 == 0) {                // 16-byte loads, element-aligned
       wp_u32x4 tmp[sizeof(E) * N / 16];
 #pragma unroll
-      for (int j = 0; j < (int)(sizeof(E) * N / 16); j++) tmp[j] = ((const WP_G wp_u32x4_u*)(uintptr_t)(arr + first))[j];
+      for (int j = 0; j < (int)(sizeof(E) * N / 16); j++) tmp[j] = __builtin_nontemporal_load(&((const WP_G wp_u32x4_u*)(uintptr_t)(arr + first))[j]);   // streamed once: keep the L2 for the lines of u
       __builtin_memcpy(&out[0], &tmp[0], sizeof(E) * N);
     } else {
 #pragma unroll

@@ -28,7 +28,7 @@ struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per 
   DevBuf pcol, pval;      // u32[nnz], T[nnz] panel-major entries (local column index, value)
   DevBuf rowptr;          // u32[F + XP] per-panel sub-row pointers, relative to the panel's first entry (F_k + 1 each)
   DevBuf tasks;           // u32 per-panel merge-path task starts: trow then tent, (ntasks_k + 1) each
-  DevBuf rowsub_ptr, rowsub_idx;   // u32[nrows+1], u32[F]: sub-rows of every row, in panel order
+  DevBuf subrow_row, blockptr;     // u32[F]: row of every sub-row (panel-major, ascending inside a panel); u32[(nblocks+1)*8]: first sub-row of panel k in row block b
   DevBuf args;            // WpArgs<T>[XP] in HBM (pointers into the per-call buffers are patched every call)
   DevBuf carry;           // WpCarry<T>, one per chunk of tasks, panel after panel
   DevBuf xhot, partial, scratch;   // per-call work buffers kept with the plan so the argument block never changes (xhot: T[8*H], the LDS tables' contents)
@@ -112,39 +112,43 @@ static __global__ void k_xp_set(uint32_t* p, uint32_t v) { *p = v; }
 template <class T> __global__ void k_xp_hot_gather(const T* __restrict__ u, const uint32_t* __restrict__ hot_cols, uint32_t total, T* __restrict__ xhot) {
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) xhot[i] = u[hot_cols[i]];
 }
-// y(i) = sum of the partials of row i's sub-rows, in panel order.  All (<= 8) index and partial loads of a row are
-// issued before the first add.
+// y(i) = sum of the partials of row i's sub-rows, in panel order.  A workgroup owns XP_RB consecutive rows: their
+// sub-rows are one contiguous run in each panel (sub-rows are in row order inside a panel), so the eight runs are read
+// with coalesced loads and accumulated panel after panel in LDS — no per-row index chain, fixed order => reproducible.
+constexpr uint32_t XP_RB = 2048;
+static __global__ void k_xp_block_starts(const uint32_t* __restrict__ subrow_row, uint32_t nblocks, uint64_t s0, uint64_t s1, uint64_t s2, uint64_t s3, uint64_t s4, uint64_t s5,
+                                         uint64_t s6, uint64_t s7, uint64_t s8, uint32_t* __restrict__ blockptr) {
+  const uint64_t so[XP + 1] = {s0, s1, s2, s3, s4, s5, s6, s7, s8};
+  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < (nblocks + 1) * XP; t += gridDim.x * 256) {
+    const uint32_t b = t / XP, k = t % XP; const uint64_t target = (uint64_t)b * XP_RB;
+    uint64_t lo = so[k], hi = so[k + 1];                       // first sub-row of panel k whose row is >= target
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (subrow_row[mid] < target) lo = mid + 1; else hi = mid; }
+    blockptr[t] = (uint32_t)lo;
+  }
+}
 template <class T, class SR>
-__global__ void k_xp_combine(uint32_t nrows, const uint32_t* __restrict__ rsp, const uint32_t* __restrict__ rsi, const T* __restrict__ partial,
-                             T* __restrict__ y, uint8_t* __restrict__ ypres, const SR sr) {
-  // two rows per thread (half a grid apart), every load of both rows issued before the first add: the chain
-  // rowsub_ptr -> rowsub_idx -> partial is three dependent memory round trips
-  const uint64_t half = ((uint64_t)nrows + 1) / 2;
-  for (uint64_t t = blockIdx.x * 256ull + threadIdx.x; t < half; t += (uint64_t)gridDim.x * 256ull) {
-    const uint64_t r[2] = {t, t + half};
-    uint32_t b[2], cnt[2];
+__global__ __launch_bounds__(512) void k_xp_combine(uint32_t nrows, const uint32_t* __restrict__ blockptr, const uint32_t* __restrict__ subrow_row, const T* __restrict__ partial,
+                                                    T* __restrict__ y, uint8_t* __restrict__ ypres, const SR sr) {
+  __shared__ T acc[XP_RB];
+  __shared__ uint8_t has[XP_RB];
+  const uint32_t b = blockIdx.x, r0 = b * XP_RB;
+  for (uint32_t i = threadIdx.x; i < XP_RB; i += 512) has[i] = 0;
+  // the loads of all eight runs are independent of the LDS phase: first sub-row of every panel is fetched up front
+  uint32_t lo[XP], hi[XP];
 #pragma unroll
-    for (int q = 0; q < 2; q++) { const uint64_t rr = r[q] < nrows ? r[q] : nrows - 1; b[q] = rsp[rr]; cnt[q] = r[q] < nrows ? rsp[rr + 1] - b[q] : 0; }
-    uint32_t ix[2][XP]; T v[2][XP];
+  for (int k = 0; k < XP; k++) { lo[k] = blockptr[b * XP + k]; hi[k] = blockptr[(b + 1) * XP + k]; }
+  __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 2; q++)
-#pragma unroll
-      for (int j = 0; j < XP; j++) ix[q][j] = rsi[(uint32_t)j < cnt[q] ? b[q] + j : (cnt[q] ? b[q] : 0)];
-#pragma unroll
-    for (int q = 0; q < 2; q++)
-#pragma unroll
-      for (int j = 0; j < XP; j++) v[q][j] = partial[ix[q][j]];
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-      if (r[q] >= nrows) continue;
-      if (cnt[q]) {
-        T acc = v[q][0];
-#pragma unroll
-        for (int j = 1; j < XP; j++) if ((uint32_t)j < cnt[q]) acc = sr.add(acc, v[q][j]);
-        y[r[q]] = acc;
-      }
-      ypres[r[q]] = cnt[q] ? 1 : 0;
+  for (int k = 0; k < XP; k++) {
+    for (uint32_t s = lo[k] + threadIdx.x; s < hi[k]; s += 512) {         // one sub-row of a row per panel: no two threads meet on a row
+      const uint32_t r = subrow_row[s] - r0; const T v = partial[s];
+      if (has[r]) acc[r] = sr.add(acc[r], v); else { acc[r] = v; has[r] = 1; }
     }
+    __syncthreads();
+  }
+  for (uint32_t i = threadIdx.x; i < XP_RB; i += 512) {
+    const uint32_t r = r0 + i;
+    if (r < nrows) { if (has[i]) y[r] = acc[i]; ypres[r] = has[i]; }
   }
 }
 
@@ -211,24 +215,20 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu) {
     else { uint32_t v = 0; GRB_HIP(hipMemcpyAsync(&v, sidx.as<uint32_t>() + P->eoff[k], 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream())); P->soff[k] = v; }
   }
   P->F = P->soff[XP];
-  DevBuf subrow_row(P->F * 4 + 4);
+  P->subrow_row.alloc(P->F * 4 + 4);
   P->rowptr.alloc((P->F + XP) * 4 + 4);
   for (int k = 0; k < XP; k++) {
     if (P->eoff[k + 1] > P->eoff[k])
       hipLaunchKernelGGL(k_xp_subrows, dim3(grid_n(P->eoff[k + 1] - P->eoff[k])), dim3(256), 0, stream(), head.as<uint32_t>(), sidx.as<uint32_t>(), prow.as<uint32_t>(),
-                         P->eoff[k], P->eoff[k + 1], (uint32_t)k, P->rowptr.as<uint32_t>(), subrow_row.as<uint32_t>());
+                         P->eoff[k], P->eoff[k + 1], (uint32_t)k, P->rowptr.as<uint32_t>(), P->subrow_row.as<uint32_t>());
     hipLaunchKernelGGL(k_xp_set, dim3(1), dim3(1), 0, stream(), P->rowptr.as<uint32_t>() + P->soff[k + 1] + k, (uint32_t)(P->eoff[k + 1] - P->eoff[k]));   // end sentinel of panel k
   }
-  // 4. row -> its sub-rows, in panel order (stable sort of the sub-row ids by row)
+  // 4. row blocks of the merge kernel: where each block's run of sub-rows starts in every panel
   {
-    DevBuf sid(P->F * 4 + 4), rkey(P->F * 4 + 4), rcnt(((size_t)M.nrows + 1) * 4);
-    P->rowsub_idx.alloc(P->F * 4 + 4); P->rowsub_ptr.alloc(((size_t)M.nrows + 1) * 4);
-    hipLaunchKernelGGL(k_iota_u32_wp, dim3(grid_n(P->F)), dim3(256), 0, stream(), sid.as<uint32_t>(), P->F);
-    int bits = 1; while (bits < 32 && (1ull << bits) < (uint64_t)M.nrows) bits++;
-    sort_pairs_u32(subrow_row.as<uint32_t>(), rkey.as<uint32_t>(), sid.as<uint32_t>(), P->rowsub_idx.as<uint32_t>(), P->F, bits);
-    GRB_HIP(hipMemsetAsync(rcnt.p, 0, ((size_t)M.nrows + 1) * 4, stream()));
-    hipLaunchKernelGGL(k_wp_col_hist, dim3(grid_n(P->F)), dim3(256), 0, stream(), subrow_row.as<uint32_t>(), P->F, rcnt.as<uint32_t>());
-    exclusive_scan_u32(rcnt.as<uint32_t>(), P->rowsub_ptr.as<uint32_t>(), (uint64_t)M.nrows + 1);
+    const uint32_t nblocks = (uint32_t)(((uint64_t)M.nrows + XP_RB - 1) / XP_RB);
+    P->blockptr.alloc(((size_t)nblocks + 1) * XP * 4 + 4);
+    hipLaunchKernelGGL(k_xp_block_starts, dim3(grid_n(((uint64_t)nblocks + 1) * XP)), dim3(256), 0, stream(), P->subrow_row.as<uint32_t>(), nblocks, P->soff[0], P->soff[1], P->soff[2],
+                       P->soff[3], P->soff[4], P->soff[5], P->soff[6], P->soff[7], P->soff[8], P->blockptr.as<uint32_t>());
   }
   // 5. merge-path tasks per panel
   P->toff[0] = 0;
@@ -287,8 +287,8 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
     hipLaunchKernelGGL((k_spmv_wavepipe<T, SR, true>), dim3(ncu * WP_WGS_PER_CU), dim3(WP_WAVES * 64), 0, stream(), a0, (const WpArgs<T>*)P->args.p, sr);
     hipLaunchKernelGGL((k_spmv_wavepipe_fixup<T, SR>), dim3((P->maxchunks + 255) / 256, XP), dim3(256), 0, stream(), (const WpCarry<T>*)nullptr, P->maxchunks, (T*)nullptr, (uint8_t*)nullptr,
                        (const WpArgs<T>*)P->args.p, sr);
-    uint64_t nb = ((uint64_t)M.nrows / 2 + 256) / 256; if (nb > 65535u * 8) nb = 65535u * 8; if (nb < 1) nb = 1;
-    hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3((unsigned)nb), dim3(256), 0, stream(), M.nrows, P->rowsub_ptr.as<uint32_t>(), P->rowsub_idx.as<uint32_t>(), P->partial.as<T>(),
+    const uint32_t nblocks = (uint32_t)(((uint64_t)M.nrows + XP_RB - 1) / XP_RB);
+    hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3(nblocks), dim3(512), 0, stream(), M.nrows, P->blockptr.as<uint32_t>(), P->subrow_row.as<uint32_t>(), P->partial.as<T>(),
                        (T*)c.tval, c.tpres, sr);
     g_last_plan += std::string("k_spmv_xcd<") + (sr.is_static ? "static" : "dynamic") + ",subrows=" + std::to_string(P->F) + "> ";
   });
