@@ -31,6 +31,12 @@ constexpr int WP_WAVES = 16;                // waves per workgroup (1024 threads
 constexpr int WP_WGS_PER_CU = 1;            // one workgroup per CU (measured: 2 x 768 threads with 256-item tasks spills registers and is slower)
 constexpr int WP_LDS_BYTES = 160 * 1024 / WP_WGS_PER_CU;
 template <class T> struct wp_hot { static constexpr int H = (WP_LDS_BYTES - WP_WAVES * WP_ENT * (int)sizeof(T) - 16) / (int)sizeof(T); };   // what the scan slices leave: 16382 (8 B) / 36860 (4 B)
+#ifndef WP_NT_COLS
+#define WP_NT_COLS false
+#endif
+#ifndef WP_NT_VALS
+#define WP_NT_VALS false
+#endif
 constexpr uint32_t WP_NONE = 0xFFFFFFFFu;
 constexpr uint32_t WP_ROWSTART = 0x80000000u, WP_COLMASK = 0x7FFFFFFFu;   // plan column words: bit 31 marks the first entry of a row
 constexpr uint32_t WP_CHUNK = 4;              // tasks per chunk (the unit handed out dynamically; one carry record each)
@@ -100,12 +106,15 @@ template <class T> __device__ __forceinline__ void wp_st_carry(WpCarry<T>* p, co
   wp_st(&p->head_has, c.head_has); wp_st(&p->head_done, c.head_done); wp_st(&p->tail_has, c.tail_has);
   wp_st(&p->head_val, c.head_val); wp_st(&p->tail_val, c.tail_val);
 }
-template <class E, int N> __device__ __forceinline__ void wp_load_run(const E* __restrict__ arr, uint32_t first, uint32_t len, bool fast, E (&out)[N]) {
+template <class E, int N, bool NT = false> __device__ __forceinline__ void wp_load_run(const E* __restrict__ arr, uint32_t first, uint32_t len, bool fast, E (&out)[N]) {
   if (fast) {
     if constexpr (sizeof(E) >= 4 && (sizeof(E) * N) % 16 == 0) {                // 16-byte loads, element-aligned
       wp_u32x4 tmp[sizeof(E) * N / 16];
 #pragma unroll
-      for (int j = 0; j < (int)(sizeof(E) * N / 16); j++) tmp[j] = __builtin_nontemporal_load(&((const WP_G wp_u32x4_u*)(uintptr_t)(arr + first))[j]);   // streamed once: keep the L2 for the lines of u
+      for (int j = 0; j < (int)(sizeof(E) * N / 16); j++) {
+        const WP_G wp_u32x4_u* q = &((const WP_G wp_u32x4_u*)(uintptr_t)(arr + first))[j];
+        tmp[j] = NT ? __builtin_nontemporal_load(q) : *q;
+      }
       __builtin_memcpy(&out[0], &tmp[0], sizeof(E) * N);
     } else {
 #pragma unroll
@@ -165,12 +174,12 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
   // stage 2: its values and the gathers of u that the LDS table does not serve.
   // Lanes past the end of a task read the next task's entries (in bounds; only the very last task takes the clamped path).
   auto load_cols = [&](uint32_t e0, uint32_t r0, uint32_t (&c)[WP_PER], uint32_t& rpa, uint32_t& rpb) {
-    wp_load_run<uint32_t, WP_PER>(a.pcol, e0 + lane * WP_PER, a.nnz, a.nnz - e0 >= (uint32_t)WP_ENT, c);
+    wp_load_run<uint32_t, WP_PER, WP_NT_COLS>(a.pcol, e0 + lane * WP_PER, a.nnz, a.nnz - e0 >= (uint32_t)WP_ENT, c);
     const uint32_t rq = r0 + lane;
     rpa = wp_ld(a.rowptr + (rq < a.nrows ? rq : a.nrows)); rpb = wp_ld(a.rowptr + (rq + 1 < a.nrows ? rq + 1 : a.nrows));
   };
   auto issue_gather = [&](uint32_t e0, uint32_t cnt, const uint32_t (&c)[WP_PER], T (&v)[WP_PER], T (&g)[WP_PER]) {
-    if (use_a) wp_load_run<T, WP_PER>(a.aval, e0 + lane * WP_PER, a.nnz, a.nnz - e0 >= (uint32_t)WP_ENT, v);
+    if (use_a) wp_load_run<T, WP_PER, WP_NT_VALS>(a.aval, e0 + lane * WP_PER, a.nnz, a.nnz - e0 >= (uint32_t)WP_ENT, v);
     else {
 #pragma unroll
       for (int u = 0; u < WP_PER; u++) v[u] = T();
