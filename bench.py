@@ -138,7 +138,7 @@ def main():
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "spmv_pmc_traffic.json")
-    if os.path.exists(pmc_file):
+    if os.path.exists(pmc_file) and world == 1 and args.scale == 22:     # the PMC passes were collected on this exact workload
         try:
             traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
         except Exception:
