@@ -24,9 +24,9 @@
 
 namespace grb {
 
-constexpr int WP_ENT = 256;                 // merge items per task = 8 per lane
+constexpr int WP_ENT = 256;                 // merge items per task = 4 per lane (measured: 512 with 16 waves spills for 8-byte types; 8 waves x 512 is 6 % slower;
+                                            // a fourth stage — values two, column words three tasks ahead — spills too and is 4 % slower)
 constexpr int WP_PER = WP_ENT / 64;
-constexpr int WP_SHORT = 24;                // rows longer than this (within one task) are reduced by the whole wave
 constexpr int WP_WAVES = 16;                // waves per workgroup (1024 threads)
 constexpr int WP_WGS_PER_CU = 1;            // one workgroup per CU (measured: 2 x 768 threads with 256-item tasks spills registers and is slower)
 constexpr int WP_LDS_BYTES = 160 * 1024 / WP_WGS_PER_CU;
@@ -123,6 +123,30 @@ template <class E, int N, bool NT = false> __device__ __forceinline__ void wp_lo
   } else {
 #pragma unroll
     for (int i = 0; i < N; i++) { const uint32_t k = first + i; out[i] = wp_ld(arr + (k < len ? k : len - 1)); }
+  }
+}
+
+// Inclusive segmented scan of (v, f) over the 64 lanes with DPP moves (no LDS crossbar round trips: the 6-step chain is
+// on every task's critical path): 4 shifts inside the 16-lane rows, then the two row broadcasts of gfx9.  f = "a segment
+// starts at or before this lane (within what has been scanned)".
+template <class T, class SR> __device__ __forceinline__ void wp_seg_scan(T& v, int& f, int lane, const SR& sr) {
+  if constexpr (sizeof(T) == 4 || sizeof(T) == 8) {
+    const int l16 = lane & 15, row = (lane >> 4) & 3;
+#define WP_SCAN_STEP(CTRL, MASK, COND) { const T vu = dpp_move_t<T, CTRL, MASK>(v); const int fu = (int)dpp_mov<CTRL, MASK>((uint32_t)f, (uint32_t)f); \
+                                         if (COND) { if (!f) v = sr.add(vu, v); f |= fu; } }
+    WP_SCAN_STEP(0x111, 0xf, l16 >= 1)      // row_shr:1
+    WP_SCAN_STEP(0x112, 0xf, l16 >= 2)      // row_shr:2
+    WP_SCAN_STEP(0x114, 0xf, l16 >= 4)      // row_shr:4
+    WP_SCAN_STEP(0x118, 0xf, l16 >= 8)      // row_shr:8
+    WP_SCAN_STEP(0x142, 0xa, row == 1 || row == 3)   // row_bcast:15: the total of row r reaches row r+1 (rows 1 and 3)
+    WP_SCAN_STEP(0x143, 0xc, row >= 2)               // row_bcast:31: lane 31 (rows 0-1 scanned) reaches rows 2 and 3
+#undef WP_SCAN_STEP
+  } else {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const T vu = shfl_up_t<T>(v, d); const int fu = __shfl_up(f, d, 64);
+      if (lane >= d) { if (!f) v = sr.add(vu, v); f |= fu; }
+    }
   }
 }
 
@@ -240,11 +264,7 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
         for (int u = 1; u < WP_PER; u++) { agg = st[u] ? p[u] : sr.add(agg, p[u]); anyf = anyf || st[u]; }
         if (lane == 0 && !anyf) agg = sr.add(carry, agg);       // the carried partial flows through lane 0
         T v = agg; int f = anyf;                                // sum since the last row start at or before my last entry
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const T vu = shfl_up_t<T>(v, d); const int fu = __shfl_up(f, d, 64);
-          if (lane >= d) { if (!f) v = sr.add(vu, v); f |= fu; }
-        }
+        wp_seg_scan<T, SR>(v, f, lane, sr);
         T run = shfl_up_t<T>(v, 1); if (lane == 0) run = carry;   // what flows into my first entry (unused when it starts a row)
 #pragma unroll
         for (int u = 0; u < WP_PER; u++) { run = st[u] ? p[u] : sr.add(run, p[u]); p[u] = run; }
@@ -265,7 +285,7 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
         if (live && qe > qs) { acc = scan[qe - 1]; has = true; }
         else if (rbase == 0 && lane == 0 && carry_has) { acc = carry; has = true; }   // row r0 ended exactly where this task starts
         const bool to_fixup = rbase == 0 && lane == 0 && !owned;      // the row began in another wave's range
-        if (live && !to_fixup) { if (has) wp_st(a.y + r, acc); wp_st(a.ypres + r, (uint8_t)(has ? 1 : 0)); }
+        if (live && !to_fixup) { if (has) wp_st(a.y + r, acc); if constexpr (!PANEL) wp_st(a.ypres + r, (uint8_t)(has ? 1 : 0)); }   // sub-rows are never empty: the merge kernel needs no presence bytes
         if (rbase == 0 && !owned) {
           cr.head_row = r0; cr.head_val = wp_uniform(acc); cr.head_has = (uint8_t)__builtin_amdgcn_readfirstlane((int)has); cr.head_done = 1;
         }

@@ -267,6 +267,10 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu) {
     a.nrows = fk; a.ntasks = P->ntasks[k]; a.nnz = ek; a.tasks_per_chunk = kt[k]; a.static_pct = wp_env("GRB_MI355X_WP_STATIC", WP_STATIC_PCT);
     a.nhot = P->nhot[k]; a.nwarm = H;
   }
+  if (getenv("GRB_MI355X_VERBOSE"))
+    for (int k = 0; k < XP; k++)
+      fprintf(stderr, "[grb] xcd plan panel %d: entries %llu sub-rows %llu tasks %u chunk %u columns %u hot %u\n", k, (unsigned long long)(P->eoff[k + 1] - P->eoff[k]),
+              (unsigned long long)(P->soff[k + 1] - P->soff[k]), P->ntasks[k], kt[k], cstart[k + 1] - cstart[k], P->nhot[k]);
   GRB_HIP(hipMemcpyAsync(P->args.p, ha, sizeof(ha), hipMemcpyHostToDevice, stream()));
   P->tsize = (int)sizeof(T);
   GRB_HIP(hipStreamSynchronize(stream()));
