@@ -16,7 +16,7 @@
 // Extra algorithmic cost: one partial (8 B written + read) and one index per sub-row (~7.7 M at R-MAT-22, ~0.2 GB)
 // against ~1.3 GB of avoided line fills.  Placement is used for speed only: any other block->XCD mapping is still correct.
 #pragma once
-#include "grb_spmv_wavepipe.hpp"
+#include "grb_spmv_tiles.hpp"
 #include "grb_matops.hpp"
 
 namespace grb {
@@ -27,7 +27,7 @@ struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per 
   DevBuf hot_cols;        // u32[8*H]    column held by slot h of panel k's LDS table
   DevBuf pcol, pval;      // u32[nnz], T[nnz] panel-major entries (local column index, value)
   DevBuf rowptr;          // u32[F + XP] per-panel sub-row pointers, relative to the panel's first entry (F_k + 1 each)
-  DevBuf tasks;           // u32 per-panel merge-path task starts: trow then tent, (ntasks_k + 1) each
+  DevBuf tasks;           // u32 per panel: first sub-row of every 256-entry tile, (ntiles_k + 1) each
   DevBuf subrow_row, blockptr;     // u32[F]: row of every sub-row (panel-major, ascending inside a panel); u32[(nblocks+1)*8]: first sub-row of panel k in row block b
   DevBuf args;            // WpArgs<T>[XP] in HBM (pointers into the per-call buffers are patched every call)
   DevBuf carry;           // WpCarry<T>, one per chunk of tasks, panel after panel
@@ -157,7 +157,7 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu) {
   auto* P = new XcdPlan(); M.xcd.reset(P);
   const uint32_t n = M.ncols; const uint64_t nnz = M.nnz;
   // 1. deal the 128-byte lines of u to the panels (equal entry counts), rank every panel's columns by frequency
-  constexpr uint32_t HH = wp_hot<T>::H;
+  constexpr uint32_t HH = xt_hot<T>::H;
   const uint32_t line = 128 / (uint32_t)sizeof(T), nlines = (n + line - 1) / line;
   DevBuf cnt((size_t)n * 4 + 4), rank((size_t)n * 4 + 4);
   P->hot_cols.alloc((size_t)XP * HH * 4 + 4);
@@ -230,22 +230,21 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu) {
     hipLaunchKernelGGL(k_xp_block_starts, dim3(grid_n(((uint64_t)nblocks + 1) * XP)), dim3(256), 0, stream(), P->subrow_row.as<uint32_t>(), nblocks, P->soff[0], P->soff[1], P->soff[2],
                        P->soff[3], P->soff[4], P->soff[5], P->soff[6], P->soff[7], P->soff[8], P->blockptr.as<uint32_t>());
   }
-  // 5. merge-path tasks per panel
+  // 5. tiles of 256 entries per panel and the sub-row each begins in; row-start flags into the column words
   P->toff[0] = 0;
   for (int k = 0; k < XP; k++) {
-    const uint64_t fk = P->soff[k + 1] - P->soff[k], ek = P->eoff[k + 1] - P->eoff[k];
-    P->ntasks[k] = (uint32_t)((fk + ek + WP_ENT - 1) / WP_ENT);
-    P->toff[k + 1] = P->toff[k] + 2 * ((uint64_t)P->ntasks[k] + 1);
+    const uint64_t ek = P->eoff[k + 1] - P->eoff[k];
+    P->ntasks[k] = (uint32_t)((ek + WP_ENT - 1) / WP_ENT);
+    P->toff[k + 1] = P->toff[k] + (uint64_t)P->ntasks[k] + 1;
   }
   P->tasks.alloc(P->toff[XP] * 4 + 4);
   for (int k = 0; k < XP; k++) {
-    const uint64_t fk = P->soff[k + 1] - P->soff[k], ek = P->eoff[k + 1] - P->eoff[k];
-    uint32_t* tr = P->tasks.as<uint32_t>() + P->toff[k];
-    hipLaunchKernelGGL(k_wp_task_starts, dim3(grid_n(P->ntasks[k] + 1)), dim3(256), 0, stream(), P->rowptr.as<uint32_t>() + P->soff[k] + k, (uint32_t)fk, (uint32_t)ek, P->ntasks[k],
-                       tr, tr + (P->ntasks[k] + 1));
+    const uint64_t fk = P->soff[k + 1] - P->soff[k];
+    hipLaunchKernelGGL(k_xt_tile_rows, dim3(grid_n(P->ntasks[k] + 1)), dim3(256), 0, stream(), P->rowptr.as<uint32_t>() + P->soff[k] + k, (uint32_t)fk, P->ntasks[k],
+                       P->tasks.as<uint32_t>() + P->toff[k]);
     hipLaunchKernelGGL(k_wp_mark_row_starts, dim3(grid_n(fk)), dim3(256), 0, stream(), P->rowptr.as<uint32_t>() + P->soff[k] + k, (uint32_t)fk, P->pcol.as<uint32_t>() + P->eoff[k]);
   }
-  constexpr uint32_t H = wp_hot<T>::H;
+  constexpr uint32_t H = xt_hot<T>::H;
   P->args.alloc(XP * sizeof(WpArgs<T>));
   size_t coff[XP + 1]; coff[0] = 0;
   const uint32_t wpp = (uint32_t)(ncu / XP) * WP_WGS_PER_CU * WP_WAVES;       // waves per panel
@@ -261,7 +260,7 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu) {
     a.rowptr = P->rowptr.as<uint32_t>() + P->soff[k] + k; a.pcol = P->pcol.as<uint32_t>() + P->eoff[k];
     a.aval = P->pval.as<T>() + P->eoff[k];
     a.x = P->xhot.as<T>() + (size_t)k * H; a.xorig = nullptr; a.hot_cols = P->hot_cols.as<uint32_t>() + (size_t)k * H;      // u comes with the launch
-    a.trow = P->tasks.as<uint32_t>() + P->toff[k]; a.tent = a.trow + (P->ntasks[k] + 1);
+    a.trow = P->tasks.as<uint32_t>() + P->toff[k]; a.tent = a.trow;      // first sub-row of every tile
     a.y = P->partial.as<T>() + P->soff[k]; a.ypres = P->scratch.as<uint8_t>() + P->soff[k];
     a.carry = P->carry.as<WpCarry<T>>() + coff[k];
     a.nrows = fk; a.ntasks = P->ntasks[k]; a.nnz = ek; a.tasks_per_chunk = kt[k]; a.static_pct = wp_env("GRB_MI355X_WP_STATIC", WP_STATIC_PCT);
@@ -284,11 +283,11 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
   if (!P || P->tsize != (int)sizeof(T)) { build_xcd_plan<T>(M, ncu); P = static_cast<XcdPlan*>(M.xcd.get()); }
   const bool uses_u = d.flip ? binop_uses_x(d.mulop) : binop_uses_y(d.mulop);
   WpArgs<T> a0{}; a0.xorig = (const T*)c.uval;        // the only per-call pointer of the pipeline: u itself
-  constexpr uint32_t H = wp_hot<T>::H;
+  constexpr uint32_t H = xt_hot<T>::H;
   if (uses_u) hipLaunchKernelGGL((k_xp_hot_gather<T>), dim3((XP * H + 255) / 256), dim3(256), 0, stream(), (const T*)c.uval, P->hot_cols.as<uint32_t>(), (uint32_t)(XP * H), P->xhot.as<T>());
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;
-    hipLaunchKernelGGL((k_spmv_wavepipe<T, SR, true>), dim3(ncu * WP_WGS_PER_CU), dim3(WP_WAVES * 64), 0, stream(), a0, (const WpArgs<T>*)P->args.p, sr);
+    hipLaunchKernelGGL((k_spmv_tiles<T, SR>), dim3(ncu * WP_WGS_PER_CU), dim3(WP_WAVES * 64), 0, stream(), a0, (const WpArgs<T>*)P->args.p, sr);
     hipLaunchKernelGGL((k_spmv_wavepipe_fixup<T, SR>), dim3((P->maxchunks + 255) / 256, XP), dim3(256), 0, stream(), (const WpCarry<T>*)nullptr, P->maxchunks, (T*)nullptr, (uint8_t*)nullptr,
                        (const WpArgs<T>*)P->args.p, sr);
     const uint32_t nblocks = (uint32_t)(((uint64_t)M.nrows + XP_RB - 1) / XP_RB);
