@@ -32,7 +32,9 @@ struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per 
   DevBuf args;            // WpArgs<T>[XP] in HBM (pointers into the per-call buffers are patched every call)
   DevBuf carry;           // WpCarry<T>, one per chunk of tasks, panel after panel
   DevBuf xhot, partial, scratch;   // per-call work buffers kept with the plan so the argument block never changes (xhot: T[8*H], the LDS tables' contents)
-  uint64_t eoff[XP + 1], soff[XP + 1], toff[XP + 1]; uint32_t ntasks[XP]; uint32_t maxchunks = 1; uint32_t nhot[XP]; uint64_t F = 0; int tsize = 0;
+  uint64_t eoff[XP + 1], soff[XP + 1], toff[XP + 1];
+  uint64_t ebase[XP + 1];   // where a panel's entries are stored (eoff padded to 64-entry boundaries: aligned 16-byte loads)
+  uint32_t ntasks[XP]; uint32_t maxchunks = 1; uint32_t nhot[XP]; uint64_t F = 0; int tsize = 0;
 };
 
 // weight of a line of u = entries in its columns
@@ -86,10 +88,18 @@ static __global__ void k_xp_hist8(const uint32_t* __restrict__ key, uint64_t nnz
 }
 template <class T> __global__ void k_xp_gather_entries(const uint32_t* __restrict__ perm, uint64_t nnz, const uint32_t* __restrict__ col, const T* __restrict__ val,
                                                        const uint32_t* __restrict__ rank, const uint32_t* __restrict__ rowidx,
-                                                       uint32_t* __restrict__ pcol, T* __restrict__ pval, uint32_t* __restrict__ prow) {
+                                                       uint32_t* __restrict__ pcol, T* __restrict__ pval, uint32_t* __restrict__ prow,
+                                                       uint64_t e1, uint64_t e2, uint64_t e3, uint64_t e4, uint64_t e5, uint64_t e6, uint64_t e7) {
   for (uint64_t q = blockIdx.x * 256ull + threadIdx.x; q < nnz; q += gridDim.x * 256ull) {
     const uint32_t p = perm[q];
-    pcol[q] = rank[col[p]] >> 3; pval[q] = val[p]; prow[q] = rowidx[p];
+    // panel k is stored from eoff[k] rounded up to a multiple of 64 entries: every panel adds < 64 entries of padding
+    uint64_t d = q;
+    if (q >= e1) d = q - e1 + ((e1 + 63) & ~63ull);
+    const uint64_t b1 = (e1 + 63) & ~63ull, b2 = (b1 + (e2 - e1) + 63) & ~63ull, b3 = (b2 + (e3 - e2) + 63) & ~63ull, b4 = (b3 + (e4 - e3) + 63) & ~63ull,
+                   b5 = (b4 + (e5 - e4) + 63) & ~63ull, b6 = (b5 + (e6 - e5) + 63) & ~63ull, b7 = (b6 + (e7 - e6) + 63) & ~63ull;
+    if (q >= e7) d = q - e7 + b7; else if (q >= e6) d = q - e6 + b6; else if (q >= e5) d = q - e5 + b5; else if (q >= e4) d = q - e4 + b4;
+    else if (q >= e3) d = q - e3 + b3; else if (q >= e2) d = q - e2 + b2; else if (q >= e1) d = q - e1 + b1;
+    pcol[d] = rank[col[p]] >> 3; pval[d] = val[p]; prow[q] = rowidx[p];
   }
 }
 // head[q] = 1 where a new sub-row starts (first entry of a panel, or the row changes)
@@ -200,9 +210,11 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu) {
   GRB_HIP(hipMemcpyAsync(hcnt, hc.p, XP * 8, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
   P->eoff[0] = 0; for (int k = 0; k < XP; k++) P->eoff[k + 1] = P->eoff[k] + hcnt[k];
   csr_row_indices(M, rowidx.as<uint32_t>());
-  P->pcol.alloc(nnz * 4 + 4); P->pval.alloc(nnz * sizeof(T) + 8);
+  P->ebase[0] = 0; for (int k = 0; k < XP; k++) P->ebase[k + 1] = (P->ebase[k] + (P->eoff[k + 1] - P->eoff[k]) + 63) & ~63ull;
+  P->pcol.alloc((P->ebase[XP] + 64) * 4 + 4); P->pval.alloc((P->ebase[XP] + 64) * sizeof(T) + 8);
   hipLaunchKernelGGL((k_xp_gather_entries<T>), dim3(grid_n(nnz)), dim3(256), 0, stream(), perm.as<uint32_t>(), nnz, M.col.as<uint32_t>(), M.val.as<T>(),
-                     rank.as<uint32_t>(), rowidx.as<uint32_t>(), P->pcol.as<uint32_t>(), P->pval.as<T>(), prow.as<uint32_t>());
+                     rank.as<uint32_t>(), rowidx.as<uint32_t>(), P->pcol.as<uint32_t>(), P->pval.as<T>(), prow.as<uint32_t>(),
+                     P->eoff[1], P->eoff[2], P->eoff[3], P->eoff[4], P->eoff[5], P->eoff[6], P->eoff[7]);
   // 3. sub-rows
   DevBuf head(nnz * 4 + 4), sidx(nnz * 4 + 4);
   hipLaunchKernelGGL(k_xp_heads, dim3(grid_n(nnz)), dim3(256), 0, stream(), prow.as<uint32_t>(), nnz, P->eoff[0], P->eoff[1], P->eoff[2], P->eoff[3], P->eoff[4], P->eoff[5],
@@ -242,7 +254,7 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu) {
     const uint64_t fk = P->soff[k + 1] - P->soff[k];
     hipLaunchKernelGGL(k_xt_tile_rows, dim3(grid_n(P->ntasks[k] + 1)), dim3(256), 0, stream(), P->rowptr.as<uint32_t>() + P->soff[k] + k, (uint32_t)fk, P->ntasks[k],
                        P->tasks.as<uint32_t>() + P->toff[k]);
-    hipLaunchKernelGGL(k_wp_mark_row_starts, dim3(grid_n(fk)), dim3(256), 0, stream(), P->rowptr.as<uint32_t>() + P->soff[k] + k, (uint32_t)fk, P->pcol.as<uint32_t>() + P->eoff[k]);
+    hipLaunchKernelGGL(k_wp_mark_row_starts, dim3(grid_n(fk)), dim3(256), 0, stream(), P->rowptr.as<uint32_t>() + P->soff[k] + k, (uint32_t)fk, P->pcol.as<uint32_t>() + P->ebase[k]);
   }
   constexpr uint32_t H = xt_hot<T>::H;
   P->args.alloc(XP * sizeof(WpArgs<T>));
@@ -257,8 +269,8 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu) {
   for (int k = 0; k < XP; k++) {
     WpArgs<T>& a = ha[k];
     const uint32_t fk = (uint32_t)(P->soff[k + 1] - P->soff[k]), ek = (uint32_t)(P->eoff[k + 1] - P->eoff[k]);
-    a.rowptr = P->rowptr.as<uint32_t>() + P->soff[k] + k; a.pcol = P->pcol.as<uint32_t>() + P->eoff[k];
-    a.aval = P->pval.as<T>() + P->eoff[k];
+    a.rowptr = P->rowptr.as<uint32_t>() + P->soff[k] + k; a.pcol = P->pcol.as<uint32_t>() + P->ebase[k];
+    a.aval = P->pval.as<T>() + P->ebase[k];
     a.x = P->xhot.as<T>() + (size_t)k * H; a.xorig = nullptr; a.hot_cols = P->hot_cols.as<uint32_t>() + (size_t)k * H;      // u comes with the launch
     a.trow = P->tasks.as<uint32_t>() + P->toff[k]; a.tent = a.trow;      // first sub-row of every tile
     a.y = P->partial.as<T>() + P->soff[k]; a.ypres = P->scratch.as<uint8_t>() + P->soff[k];
