@@ -32,6 +32,17 @@ template <class E> __device__ __forceinline__ E xt_readlane(E v, int src) {     
   else { union { E e; uint16_t s; } u; u.s = 0; u.e = v; const int x = __builtin_amdgcn_readlane((int)u.s, src); u.s = (uint16_t)x; return u.e; }
 }
 
+// a gather through a buffer descriptor: lanes whose offset is out of range (0xFFFFFFFF) return 0 and make no memory
+// request at all.  The lanes served by the LDS table (3 in 4) and the lanes behind the end of a tile use that: a plain
+// global load costs the texture path a cycle per lane even when most lanes read the same dummy address.
+typedef uint32_t xt_v2u __attribute__((ext_vector_type(2)));
+template <class E> __device__ __forceinline__ E xt_buf_load(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+  if constexpr (sizeof(E) == 8) { union { xt_v2u w; E e; } x; x.w = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0); return x.e; }
+  else if constexpr (sizeof(E) == 4) { union { uint32_t w; E e; } x; x.w = __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0); return x.e; }
+  else if constexpr (sizeof(E) == 2) { union { uint16_t w; E e; } x; x.w = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, (int)off, 0, 0); return x.e; }
+  else { union { uint8_t w; E e; } x; x.w = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(r, (int)off, 0, 0); return x.e; }
+}
+
 template <class T> struct XtStage { uint32_t c[WP_PER]; T v[WP_PER], g[WP_PER]; uint32_t rf; };   // what one tile has in flight (rf: sub-row of its first entry)
 
 // a.trow = first sub-row of every tile [ntiles + 1]; a.ntasks = tiles; a.rowptr / a.tent / a.ypres are not used
@@ -44,7 +55,8 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
   if (threadIdx.x == 0) s_next = 0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const bool use_a = sr.uses_a(), use_u = sr.uses_u();
-  const T* const u_ptr = a0.xorig;                      // u comes with the launch, the rest of `a` is the plan's
+  // u comes with the launch (a0.xorig, a0.nrows = its length), the rest of `a` is the plan's
+  const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a0.xorig, (short)0, (int)(a0.nrows * (uint32_t)sizeof(T)), 0x00020000);
   if (use_u) for (uint32_t h = threadIdx.x; h < a.nhot; h += WP_WAVES * 64) s_hot[h] = wp_ld(a.x + h);      // the table's contents, gathered from u once per call
   __syncthreads();
   // work split: see k_spmv_wavepipe
@@ -71,7 +83,7 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
 #pragma unroll
     for (int u = 0; u < WP_PER; u++) {
       const uint32_t cc = (uint32_t)(lane * WP_PER + u) < cnt ? (c[u] & WP_COLMASK) : 0u;   // slot in the LDS table, or H + column
-      g[u] = use_u ? wp_ld(u_ptr + (cc >= (uint32_t)H ? cc - (uint32_t)H : 0u)) : T();      // LDS-resident ones read u[0] (cached) and are replaced below
+      g[u] = use_u ? xt_buf_load<T>(u_rsrc, cc >= (uint32_t)H ? (cc - (uint32_t)H) * (uint32_t)sizeof(T) : 0xFFFFFFFFu) : T();   // only the columns the table does not hold are fetched
     }
   };
 

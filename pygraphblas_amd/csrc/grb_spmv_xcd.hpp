@@ -294,7 +294,7 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
   auto* P = static_cast<XcdPlan*>(M.xcd.get());
   if (!P || P->tsize != (int)sizeof(T)) { build_xcd_plan<T>(M, ncu); P = static_cast<XcdPlan*>(M.xcd.get()); }
   const bool uses_u = d.flip ? binop_uses_x(d.mulop) : binop_uses_y(d.mulop);
-  WpArgs<T> a0{}; a0.xorig = (const T*)c.uval;        // the only per-call pointer of the pipeline: u itself
+  WpArgs<T> a0{}; a0.xorig = (const T*)c.uval; a0.nrows = M.ncols;       // the only per-call pointer of the pipeline: u itself (and its length)
   constexpr uint32_t H = xt_hot<T>::H;
   if (uses_u) hipLaunchKernelGGL((k_xp_hot_gather<T>), dim3((XP * H + 255) / 256), dim3(256), 0, stream(), (const T*)c.uval, P->hot_cols.as<uint32_t>(), (uint32_t)(XP * H), P->xhot.as<T>());
   with_semiring<T>(d, [&](auto sr) {
