@@ -59,6 +59,9 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
   const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a0.xorig, (short)0, (int)(a0.nrows * (uint32_t)sizeof(T)), 0x00020000);
   if (use_u) for (uint32_t h = threadIdx.x; h < a.nhot; h += WP_WAVES * 64) s_hot[h] = wp_ld(a.x + h);      // the table's contents, gathered from u once per call
   __syncthreads();
+#ifdef WP_PROFILE
+  const unsigned long long pf_t0 = WP_CLK();
+#endif
   // work split: see k_spmv_wavepipe
   const uint32_t K = a.tasks_per_chunk, nchunks = (K + a.ntasks - 1) / K;
   const uint32_t nwg = gridDim.x >> 3, jwg = blockIdx.x >> 3;
@@ -192,6 +195,9 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
     }
     rec = dyn0 + (uint32_t)__builtin_amdgcn_readfirstlane(next_raw) * nwg + jwg; nrec = 1;
   }
+#ifdef WP_PROFILE
+  if (lane == 0) { const unsigned long long t = WP_CLK(); g_wp_prof[blockIdx.x * WP_WAVES + wv] = t - pf_t0; g_wp_prof[4096 + blockIdx.x * WP_WAVES + wv] = 1ull; }
+#endif
 }
 
 // first sub-row of every tile: the largest s with rowptr[s] <= 256 t (sub-rows are never empty)
