@@ -43,6 +43,17 @@ void build_allow(uint64_t n, int mcode, const void* mval, const uint8_t* mpres, 
 }
 
 // ---- count present ------------------------------------------------------------------------------------
+// One atomic per workgroup and at most 512 workgroups: same-address atomics complete one after the other (~10-80 ns each on
+// this part), so a counter bumped by every wave of a 4096-block grid cost 40-80 us for a 4 MB bitmap.
+__device__ __forceinline__ void block_add_u64(unsigned long long c, unsigned long long* out) {
+  __shared__ unsigned long long sh[4];
+  c = wave_reduce_add_u64(c);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { const unsigned long long t = sh[0] + sh[1] + sh[2] + sh[3]; if (t) atomicAdd(out, t); }
+}
+static inline int grid_capped(uint64_t n, int per_thread, int cap = 512) { const int g = grid_for(n, per_thread); return g < cap ? g : cap; }
+
 __global__ void k_count(const uint8_t* __restrict__ pres, uint64_t n, unsigned long long* out) {
   unsigned long long c = 0;
   // 16 bytes per lane per step
@@ -53,27 +64,35 @@ __global__ void k_count(const uint8_t* __restrict__ pres, uint64_t n, unsigned l
     c += __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) + __popc(v.w & 0x01010101u);
   }
   for (uint64_t i = n16 * 16 + blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) c += pres[i] != 0;
-  c = wave_reduce_add_u64(c);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+  block_add_u64(c, out);
 }
 uint64_t count_present(const uint8_t* pres, uint64_t n) {
   if (!n) return 0;
   ScalarSlot slot; slot.zero();
-  hipLaunchKernelGGL(k_count, dim3(grid_for(n, 16)), dim3(256), 0, stream(), pres, n, (unsigned long long*)slot.dev());
+  hipLaunchKernelGGL(k_count, dim3(grid_capped(n, 16)), dim3(256), 0, stream(), pres, n, (unsigned long long*)slot.dev());
   return slot.read_u64();
 }
 
 // ---- sum of the row lengths of the present entries (how many edges a push from this frontier would walk) ----------------
 __global__ void k_frontier_edges(const uint8_t* __restrict__ pres, const uint32_t* __restrict__ rowptr, uint64_t n, unsigned long long* out) {
   unsigned long long c = 0;
-  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) if (pres[i]) c += rowptr[i + 1] - rowptr[i];
-  c = wave_reduce_add_u64(c);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+  // four presence bytes per lane per step; the row pointers are only read for present entries
+  const uint64_t n4 = n / 4;
+  const uint32_t* p4 = (const uint32_t*)pres;
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n4; i += gridDim.x * 256ull) {
+    const uint32_t v = p4[i];
+    if (v) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) if ((v >> (8 * j)) & 0xFFu) c += rowptr[i * 4 + j + 1] - rowptr[i * 4 + j];
+    }
+  }
+  for (uint64_t i = n4 * 4 + blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) if (pres[i]) c += rowptr[i + 1] - rowptr[i];
+  block_add_u64(c, out);
 }
 uint64_t frontier_edges(const uint8_t* pres, const uint32_t* rowptr, uint64_t n) {
   if (!n) return 0;
   ScalarSlot slot; slot.zero();
-  hipLaunchKernelGGL(k_frontier_edges, dim3(grid_for(n, 4)), dim3(256), 0, stream(), pres, rowptr, n, (unsigned long long*)slot.dev());
+  hipLaunchKernelGGL(k_frontier_edges, dim3(grid_capped(n, 16)), dim3(256), 0, stream(), pres, rowptr, n, (unsigned long long*)slot.dev());
   return slot.read_u64();
 }
 
