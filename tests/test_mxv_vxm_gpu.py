@@ -174,7 +174,10 @@ def test_wavepipe_kernel_shapes(gpu, typ, sr, method):
               (6000, 300, 0.4),       # many medium rows
               (50000, 64, 0.02),      # mostly empty / tiny rows: row-marker dominated tasks
               (40, 30000, 0.3),       # rows of ~9000
-              (2000, 2000, 0.001)]    # very sparse: barely more than one task
+              (2000, 2000, 0.001),    # very sparse: barely more than one task
+              (20000, 16, 0.9),       # every column in one 128-byte line of u: kernel X puts all entries in one panel, seven panels are empty
+              (3000, 40, 1.0),        # three lines of u: five empty panels, every entry served by the LDS tables
+              (257, 4100, 0.25)]      # panels of ~32 000 entries: last tiles are partial
     for nrows, ncols, dens in shapes:
         run_case(rng, typ, sr, nrows, ncols, dens, 1.0, method=method)
         assert ("wavepipe" in gb.last_kernel_plan()) or ("xcd" in gb.last_kernel_plan()), gb.last_kernel_plan()
