@@ -151,16 +151,26 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
 }
 
 // ---- (1b) huge mask rows: dense position map in HBM, one persistent block per map ----------------------------------
+// Nearly every product misses the mask, and a lookup in the 4-bytes-per-column map is a random HBM access.  A bit filter
+// in LDS (1 Mbit, column mod 2^20: a mask row of 30 000 entries lets ~2 % of the misses through) answers most products
+// without leaving the CU; only the survivors read the map for their exact position.
+constexpr uint32_t SPG_FILTER_WORDS = 32768;        // 2^20 bits = 128 KiB of LDS
 template <class T, class SR>
 __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T> a, const uint32_t* __restrict__ rows, uint32_t nrows_bin,
                                                             uint32_t* __restrict__ maps, uint32_t ncols, const SR sr) {
+  __shared__ uint32_t s_filter[SPG_FILTER_WORDS];
   uint32_t* map = maps + (size_t)blockIdx.x * ncols;       // zero-initialised; entry = mask position + 1
   const int t = threadIdx.x;
   const bool use_a = sr.uses_a(), use_b = sr.uses_u();
   for (uint32_t ridx = blockIdx.x; ridx < nrows_bin; ridx += gridDim.x) {
     const uint32_t i = rows[ridx];
     const uint32_t mb = a.mrp[i], me = a.mrp[i + 1];
-    for (uint32_t p = mb + t; p < me; p += 1024) if (spgemm_mask_truth(a.mval, a.mcode, p, a.mstruct)) map[a.mcol[p]] = p - mb + 1;
+    for (uint32_t w = t; w < SPG_FILTER_WORDS; w += 1024) s_filter[w] = 0;
+    __syncthreads();
+    for (uint32_t p = mb + t; p < me; p += 1024) if (spgemm_mask_truth(a.mval, a.mcode, p, a.mstruct)) {
+      const uint32_t j = a.mcol[p];
+      map[j] = p - mb + 1; atomicOr(&s_filter[(j >> 5) & (SPG_FILTER_WORDS - 1)], 1u << (j & 31));
+    }
     __threadfence_block(); __syncthreads();
     const uint32_t ab = a.arp[i], ae = a.arp[i + 1];
     // one wave per entry k of A(i,:): these rows have thousands of k's, most with long B rows
@@ -173,11 +183,15 @@ __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T>
 #pragma unroll
         for (int u = 0; u < 4; u++) { const uint32_t pb = pb0 + 64 * u; ss[u] = a.bcol[pb < be ? pb : be - 1]; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) ss[u] = map[ss[u]];                   // 4 independent map lookups in flight
+        for (int u = 0; u < 4; u++) {
+          const uint32_t pb = pb0 + 64 * u; const uint32_t j = ss[u];
+          const bool maybe = pb < be && ((s_filter[(j >> 5) & (SPG_FILTER_WORDS - 1)] >> (j & 31)) & 1u);
+          ss[u] = maybe ? map[j] : 0u;                                     // the rare survivors: exact position from the map
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const uint32_t pb = pb0 + 64 * u;
-          if (pb < be && ss[u]) {
+          if (ss[u]) {
             const T m = sr.mult(av, use_b ? a.bval[pb] : T());
             word_combine<T>(sr.add_op(), &a.cacc[mb + ss[u] - 1], m);
             a.cflag[mb + ss[u] - 1] = 1;
@@ -273,10 +287,12 @@ template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDes
     // auxiliary streams (forked from / joined back into the library stream with events) so their tails overlap
     AuxStreams& ax = aux_streams();
     ax.fork(stream());
-    if (hc[0]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 64, 64, 256>), dim3(nblocks(hc[0], 4)), dim3(256), 0, ax.s[0], a, L, hc[0], sr);
-    if (hc[1]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 512, 256, 256>), dim3(nblocks(hc[1], 1)), dim3(256), 0, ax.s[1], a, L + (size_t)nrows, hc[1], sr);
-    if (hc[2]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 2048, 512, 512>), dim3(nblocks(hc[2], 1)), dim3(512), 0, ax.s[2], a, L + (size_t)2 * nrows, hc[2], sr);
-    if (hc[3]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 8192, 1024, 1024>), dim3(nblocks(hc[3], 1)), dim3(1024), 0, ax.s[3], a, L + (size_t)3 * nrows, hc[3], sr);
+    const bool serial = getenv("GRB_MI355X_SPGEMM_SERIAL") != nullptr;      // experiment hook: run the bins one after the other
+    hipStream_t bs[4]; for (int q = 0; q < 4; q++) bs[q] = serial ? stream() : ax.s[q];
+    if (hc[0]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 64, 64, 256>), dim3(nblocks(hc[0], 4)), dim3(256), 0, bs[0], a, L, hc[0], sr);
+    if (hc[1]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 512, 256, 256>), dim3(nblocks(hc[1], 1)), dim3(256), 0, bs[1], a, L + (size_t)nrows, hc[1], sr);
+    if (hc[2]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 2048, 512, 512>), dim3(nblocks(hc[2], 1)), dim3(512), 0, bs[2], a, L + (size_t)2 * nrows, hc[2], sr);
+    if (hc[3]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 8192, 1024, 1024>), dim3(nblocks(hc[3], 1)), dim3(1024), 0, bs[3], a, L + (size_t)3 * nrows, hc[3], sr);
     if (hc[4]) {
       const unsigned nb = hc[4] < 256 ? hc[4] : 256;
       DevBuf maps((size_t)nb * B.ncols * 4);
