@@ -43,6 +43,27 @@ template <class E> __device__ __forceinline__ E xt_buf_load(__amdgpu_buffer_rsrc
   else { union { uint8_t w; E e; } x; x.w = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(r, (int)off, 0, 0); return x.e; }
 }
 
+// the two streams of a tile through buffer descriptors; lanes behind the end of the panel read zeros.  XT_STREAM_AUX = the
+// cache-policy bits of these loads (1 sc0, 2 nt, 16 sc1).  Measured on R-MAT-22 FP64 (ms per mxv, stream-only variant in
+// brackets): 0: 0.300 (0.226), sc0: 0.300 (0.227), nt: 0.292 (0.212), sc1: 0.318 (0.240), sc0+sc1+nt: 0.293 (0.213).
+#ifndef XT_STREAM_AUX
+#define XT_STREAM_AUX 2
+#endif
+typedef uint32_t xt_v4u __attribute__((ext_vector_type(4)));
+template <class E, int N> __device__ __forceinline__ void xt_stream_load(__amdgpu_buffer_rsrc_t r, uint32_t first, E (&out)[N]) {
+  static_assert((sizeof(E) * N) % 16 == 0 || sizeof(E) * N == 4 || sizeof(E) * N == 8, "tile slice per lane");
+  if constexpr ((sizeof(E) * N) % 16 == 0) {
+    xt_v4u tmp[sizeof(E) * N / 16];
+#pragma unroll
+    for (int j = 0; j < (int)(sizeof(E) * N / 16); j++) tmp[j] = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(first * (uint32_t)sizeof(E) + 16u * j), 0, XT_STREAM_AUX);
+    __builtin_memcpy(&out[0], &tmp[0], sizeof(E) * N);
+  } else if constexpr (sizeof(E) * N == 8) {
+    xt_v2u tmp = __builtin_amdgcn_raw_buffer_load_b64(r, (int)(first * (uint32_t)sizeof(E)), 0, XT_STREAM_AUX); __builtin_memcpy(&out[0], &tmp, 8);
+  } else {
+    uint32_t tmp = __builtin_amdgcn_raw_buffer_load_b32(r, (int)(first * (uint32_t)sizeof(E)), 0, XT_STREAM_AUX); __builtin_memcpy(&out[0], &tmp, 4);
+  }
+}
+
 template <class T> struct XtStage { uint32_t c[WP_PER]; T v[WP_PER], g[WP_PER]; uint32_t rf; };   // what one tile has in flight (rf: sub-row of its first entry)
 
 // a.trow = first sub-row of every tile [ntiles + 1]; a.ntasks = tiles; a.rowptr / a.tent / a.ypres are not used
@@ -58,6 +79,8 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
   // u comes with the launch (a0.xorig, a0.nrows = its length), the rest of `a` is the plan's
   const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a0.xorig, (short)0, (int)(a0.nrows * (uint32_t)sizeof(T)), 0x00020000);
   if (use_u) for (uint32_t h = threadIdx.x; h < a.nhot; h += WP_WAVES * 64) s_hot[h] = wp_ld(a.x + h);      // the table's contents, gathered from u once per call
+  const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.pcol, (short)0, (int)(a.nnz * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.aval, (short)0, (int)(a.nnz * (uint32_t)sizeof(T)), 0x00020000);
   __syncthreads();
 #ifdef WP_PROFILE
   const unsigned long long pf_t0 = WP_CLK();
@@ -73,12 +96,12 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
 
   auto load_cols = [&](uint32_t t, uint32_t (&c)[WP_PER], uint32_t& rf) {
     const uint32_t e0 = t * (uint32_t)WP_ENT;
-    wp_load_run<uint32_t, WP_PER, WP_NT_COLS>(a.pcol, e0 + lane * WP_PER, a.nnz, a.nnz - e0 >= (uint32_t)WP_ENT, c);
+    xt_stream_load<uint32_t, WP_PER>(c_rsrc, e0 + lane * WP_PER, c);
     rf = wp_ld(a.trow + t);
   };
   auto issue_gather = [&](uint32_t t, const uint32_t (&c)[WP_PER], T (&v)[WP_PER], T (&g)[WP_PER]) {
     const uint32_t e0 = t * (uint32_t)WP_ENT, cnt = a.nnz - e0 < (uint32_t)WP_ENT ? a.nnz - e0 : (uint32_t)WP_ENT;
-    if (use_a) wp_load_run<T, WP_PER, WP_NT_VALS>(a.aval, e0 + lane * WP_PER, a.nnz, cnt == (uint32_t)WP_ENT, v);
+    if (use_a) xt_stream_load<T, WP_PER>(v_rsrc, e0 + lane * WP_PER, v);
     else {
 #pragma unroll
       for (int u = 0; u < WP_PER; u++) v[u] = T();
@@ -171,7 +194,7 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
 #pragma unroll
         for (int u = 0; u < WP_PER; u++) {
           row += (rs[u] && (u > 0 || lane > 0)) ? 1u : 0u;
-          if (end[u]) wp_st(a.y + row, p[u]);
+          if (end[u]) wp_st(a.y + row, p[u]);        // (non-temporal stores here: 0.286 -> 0.312 ms)
         }
       }
       last_row = rf + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);     // (junk entries behind the panel's end only follow its last row)
