@@ -35,10 +35,15 @@ template <class E> __device__ __forceinline__ E xt_readlane(E v, int src) {     
 // a gather through a buffer descriptor: lanes whose offset is out of range (0xFFFFFFFF) return 0 and make no memory
 // request at all.  The lanes served by the LDS table (3 in 4) and the lanes behind the end of a tile use that: a plain
 // global load costs the texture path a cycle per lane even when most lanes read the same dummy address.
+// Cache policy: default.  (Measured: sc0 or sc1 on these loads change nothing; nt makes them leave the L2 and the whole
+// product 0.285 -> 0.392 ms — the L2 residency of the panel's lines is what the design lives on.)
 typedef uint32_t xt_v2u __attribute__((ext_vector_type(2)));
+#ifndef XT_GATHER_AUX
+#define XT_GATHER_AUX 0
+#endif
 template <class E> __device__ __forceinline__ E xt_buf_load(__amdgpu_buffer_rsrc_t r, uint32_t off) {
-  if constexpr (sizeof(E) == 8) { union { xt_v2u w; E e; } x; x.w = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0); return x.e; }
-  else if constexpr (sizeof(E) == 4) { union { uint32_t w; E e; } x; x.w = __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0); return x.e; }
+  if constexpr (sizeof(E) == 8) { union { xt_v2u w; E e; } x; x.w = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, XT_GATHER_AUX); return x.e; }
+  else if constexpr (sizeof(E) == 4) { union { uint32_t w; E e; } x; x.w = __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, XT_GATHER_AUX); return x.e; }
   else if constexpr (sizeof(E) == 2) { union { uint16_t w; E e; } x; x.w = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, (int)off, 0, 0); return x.e; }
   else { union { uint8_t w; E e; } x; x.w = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(r, (int)off, 0, 0); return x.e; }
 }
