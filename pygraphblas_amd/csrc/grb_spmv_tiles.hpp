@@ -8,14 +8,15 @@
 //     the sub-row of the tile's first entry (one word per tile) plus the number of row starts before it, a 6-step integer
 //     wave scan.  The kernel never reads row pointers and has no per-row pass;
 //   * row sums leave from the lanes that hold a row's last entry (the next entry starts a row), straight from registers:
-//     no scan buffer in LDS, so the LDS table grows from 16 382 to 20 478 FP64 columns per panel.
+//     no scan buffer in LDS (only 64 staging slots per wave for the outgoing sums), so the LDS table grows from 16 382 to
+//     19 454 FP64 columns per panel.
 // Work split, carry records and fix-up are W's (chunks of tiles; wp_* helpers).
 #pragma once
 #include "grb_spmv_wavepipe.hpp"
 
 namespace grb {
 
-template <class T> struct xt_hot { static constexpr int H = (WP_LDS_BYTES - 16) / (int)sizeof(T); };   // the whole LDS is the table: 20478 (8 B) / 40956 (4 B)
+template <class T> struct xt_hot { static constexpr int H = (WP_LDS_BYTES - 16 - WP_WAVES * 64 * (int)sizeof(T)) / (int)sizeof(T); };   // all of the LDS but the staging slots is the table: 19454 (8 B) / 39932 (4 B)
 
 // inclusive prefix sum over the 64 lanes (DPP; same shape as wp_seg_scan)
 __device__ __forceinline__ uint32_t xt_scan_add(uint32_t x, int lane) {
@@ -77,9 +78,11 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
   const WpArgs<T> a = panels[blockIdx.x & 7];          // workgroup b works on column panel b % 8 — the XCD it is observed to run on
   constexpr int H = xt_hot<T>::H;
   __shared__ T s_hot[H];
+  __shared__ T s_stage[WP_WAVES][64];                   // per wave: sub-row sums on their way out
   __shared__ uint32_t s_next;                           // next dynamic chunk of this workgroup
   if (threadIdx.x == 0) s_next = 0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  T* const stage = s_stage[wv];
   const bool use_a = sr.uses_a(), use_u = sr.uses_u();
   // u comes with the launch (a0.xorig, a0.nrows = its length), the rest of `a` is the plan's
   const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a0.xorig, (short)0, (int)(a0.nrows * (uint32_t)sizeof(T)), 0x00020000);
@@ -184,25 +187,30 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
         const bool nx = u + 1 < WP_PER ? rs[u + 1 < WP_PER ? u + 1 : u] : nxt0 != 0;
         end[u] = pos + 1 < cnt ? nx : (pos + 1 == cnt ? last_end : false);
       }
-      if (!owned) {                                              // the first row end of the range closes a row that began in another range
-        const unsigned long long m = __ballot(end[0] || end[1] || end[2] || end[3]);
-        if (m) {
-          const int L = (int)__builtin_ctzll(m);
-          const T hv = end[0] ? p[0] : end[1] ? p[1] : end[2] ? p[2] : p[3];
-          cr.head_row = rf; cr.head_val = xt_readlane<T>(hv, L); cr.head_has = 1; cr.head_done = 1;
-          if (lane == L) { if (end[0]) end[0] = false; else if (end[1]) end[1] = false; else if (end[2]) end[2] = false; else end[3] = false; }
-          owned = true;
-        }
-      }
-      {
-        uint32_t row = rf + incl - mine;
+      // ---- the sums of the sub-rows that end in this tile leave through the wave's staging slots: the ends are ranked by
+      // sub-row (rf, rf+1, ... — consecutive), so 64 of them at a time become one coalesced store.  (Storing from the
+      // owning lanes, 8 scattered bytes per sub-row in four sparse store instructions, cost 25-30 us per product.)
+      const uint32_t starts = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);      // row starts behind the tile's first entry
+      const uint32_t nends = starts + (last_end ? 1u : 0u);
+      bool skip_first = false;
+      for (uint32_t base = 0; base < nends; base += 64) {
+        uint32_t row = incl - mine;
 #pragma unroll
         for (int u = 0; u < WP_PER; u++) {
           row += (rs[u] && (u > 0 || lane > 0)) ? 1u : 0u;
-          if (end[u]) wp_st(a.y + row, p[u]);        // (non-temporal stores here: 0.286 -> 0.312 ms)
+          const uint32_t k = row - base;
+          if (end[u] && k < 64u) stage[k] = p[u];
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();
+        if (base == 0 && !owned) {                               // the first row end of the range closes a row that began in another range
+          cr.head_row = rf; cr.head_val = wp_uniform(stage[0]); cr.head_has = 1; cr.head_done = 1;
+          owned = true; skip_first = true;
+        }
+        const uint32_t k = base + (uint32_t)lane;
+        if (k < nends && !(skip_first && k == 0)) wp_st(a.y + rf + k, stage[lane]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();   // the slots are free again
       }
-      last_row = rf + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);     // (junk entries behind the panel's end only follow its last row)
+      last_row = rf + starts;
       if (cnt == (uint32_t)WP_ENT && !last_end) { carry = xt_readlane<T>(p[WP_PER - 1], 63); carry_has = true; }
       else { carry = sr.identity; carry_has = false; }
     };
