@@ -144,14 +144,22 @@ template <class T> __device__ __forceinline__ bool val_eq(T a, T b) {
 
 // ---- a device word the host can read back (count results, flags) ------------------------------------------
 struct ScalarSlot {
-  DevBuf b;
-  ScalarSlot() : b(16) {}
-  void* dev() { return b.p; }
-  void zero() { GRB_HIP(hipMemsetAsync(b.p, 0, 16, stream())); }
-  uint64_t read_u64() {
-    uint64_t v = 0; GRB_HIP(hipMemcpyAsync(&v, b.p, 8, hipMemcpyDeviceToHost, stream()));
-    GRB_HIP(hipStreamSynchronize(stream())); return v;
+  // two 64-bit counters that are zero between uses: the reader re-zeroes them right behind its copy, so the memset is
+  // dispatched while the host waits for the result instead of in front of the next counting kernel
+  static DevBuf& buf() {
+    static thread_local DevBuf b;
+    if (!b.p) { b.alloc(16); GRB_HIP(hipMemsetAsync(b.p, 0, 16, stream())); }
+    return b;
   }
+  void* dev() { return buf().p; }
+  void zero() {}
+  void read(uint64_t out[2]) {
+    out[0] = out[1] = 0;
+    GRB_HIP(hipMemcpyAsync(out, buf().p, 16, hipMemcpyDeviceToHost, stream()));
+    GRB_HIP(hipMemsetAsync(buf().p, 0, 16, stream()));
+    GRB_HIP(hipStreamSynchronize(stream()));
+  }
+  uint64_t read_u64() { uint64_t v[2]; read(v); return v[0]; }
 };
 
 // ---- library-backed primitives (grb_prims.hip: rocPRIM scan / radix sort) ------------------------------------

@@ -187,5 +187,6 @@ void build_allow(uint64_t n, int mcode, const void* mval, const uint8_t* mpres, 
                  bool complement, uint8_t* allow);
 uint64_t count_present(const uint8_t* pres, uint64_t n);
 uint64_t frontier_edges(const uint8_t* pres, const uint32_t* rowptr, uint64_t n);
+uint64_t frontier_edges_and_count(const uint8_t* pres, const uint32_t* rowptr, uint64_t n, uint64_t* count);
 
 }  // namespace grb

@@ -36,6 +36,15 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
     return;
   }
   mat_to_device(A); vec_to_device(u);
+  // the entry count of u and (for the direction choice below) the edges leaving it come from one kernel and one round
+  // trip when the count is not known yet — the usual state inside a BFS loop, where u was just updated under a mask
+  uint64_t fe_cached = ~0ull;
+  if (!u->dnvals_known && method == SPMV_AUTO && spmspv_push_supported(sd) && u->n && (useT || A->csc.valid)) {      // (never build a transpose just for this)
+    const DevCSR& P0 = useT ? A->csr : mat_csc(A);
+    uint64_t cnt = 0;
+    fe_cached = frontier_edges_and_count(u->dpres.as<uint8_t>(), P0.rowptr.as<uint32_t>(), u->n, &cnt);
+    u->dnvals = cnt; u->dnvals_known = true;
+  }
   const uint64_t u_nvals = vec_dev_nvals(u);
   const bool u_full = u_nvals == u->n;
 
@@ -50,7 +59,8 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   if (method == SPMV_PUSH) push = spmspv_push_supported(sd);
   else if (method == SPMV_AUTO && spmspv_push_supported(sd) && !u_full && u_nvals * 16 < (uint64_t)A->csr.nnz + 16) {
     const DevCSR& P = useT ? A->csr : mat_csc(A);
-    push = frontier_edges(u->dpres.as<uint8_t>(), P.rowptr.as<uint32_t>(), u->n) * 16 < P.nnz + 16;
+    const uint64_t fe = fe_cached != ~0ull ? fe_cached : frontier_edges(u->dpres.as<uint8_t>(), P.rowptr.as<uint32_t>(), u->n);
+    push = fe * 16 < P.nnz + 16;
   }
 
   const size_t zs = type_size(sd.zcode);

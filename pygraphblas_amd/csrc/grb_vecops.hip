@@ -74,8 +74,8 @@ uint64_t count_present(const uint8_t* pres, uint64_t n) {
 }
 
 // ---- sum of the row lengths of the present entries (how many edges a push from this frontier would walk) ----------------
-__global__ void k_frontier_edges(const uint8_t* __restrict__ pres, const uint32_t* __restrict__ rowptr, uint64_t n, unsigned long long* out) {
-  unsigned long long c = 0;
+__global__ void k_frontier_edges(const uint8_t* __restrict__ pres, const uint32_t* __restrict__ rowptr, uint64_t n, unsigned long long* out, unsigned long long* out_count) {
+  unsigned long long c = 0, np = 0;
   // four presence bytes per lane per step; the row pointers are only read for present entries
   const uint64_t n4 = n / 4;
   const uint32_t* p4 = (const uint32_t*)pres;
@@ -83,17 +83,26 @@ __global__ void k_frontier_edges(const uint8_t* __restrict__ pres, const uint32_
     const uint32_t v = p4[i];
     if (v) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) if ((v >> (8 * j)) & 0xFFu) c += rowptr[i * 4 + j + 1] - rowptr[i * 4 + j];
+      for (int j = 0; j < 4; j++) if ((v >> (8 * j)) & 0xFFu) { c += rowptr[i * 4 + j + 1] - rowptr[i * 4 + j]; np++; }
     }
   }
-  for (uint64_t i = n4 * 4 + blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) if (pres[i]) c += rowptr[i + 1] - rowptr[i];
+  for (uint64_t i = n4 * 4 + blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) if (pres[i]) { c += rowptr[i + 1] - rowptr[i]; np++; }
   block_add_u64(c, out);
+  if (out_count) { __syncthreads(); block_add_u64(np, out_count); }
 }
 uint64_t frontier_edges(const uint8_t* pres, const uint32_t* rowptr, uint64_t n) {
   if (!n) return 0;
   ScalarSlot slot; slot.zero();
-  hipLaunchKernelGGL(k_frontier_edges, dim3(grid_capped(n, 16)), dim3(256), 0, stream(), pres, rowptr, n, (unsigned long long*)slot.dev());
+  hipLaunchKernelGGL(k_frontier_edges, dim3(grid_capped(n, 16)), dim3(256), 0, stream(), pres, rowptr, n, (unsigned long long*)slot.dev(), (unsigned long long*)nullptr);
   return slot.read_u64();
+}
+// the same with the number of present entries as a second result: one kernel, one round trip to the host
+uint64_t frontier_edges_and_count(const uint8_t* pres, const uint32_t* rowptr, uint64_t n, uint64_t* count) {
+  *count = 0;
+  if (!n) return 0;
+  ScalarSlot slot; slot.zero();
+  hipLaunchKernelGGL(k_frontier_edges, dim3(grid_capped(n, 16)), dim3(256), 0, stream(), pres, rowptr, n, (unsigned long long*)slot.dev(), (unsigned long long*)slot.dev() + 1);
+  uint64_t v[2]; slot.read(v); *count = v[1]; return v[0];
 }
 
 // ---- C<M,replace> = accum(C, T) for vectors, in place on (wval, wpres) ---------------------------------
