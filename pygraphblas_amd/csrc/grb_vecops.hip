@@ -152,8 +152,33 @@ template <class T> __global__ void k_reduce(uint64_t n, const T* __restrict__ va
     partial[blockIdx.x] = r;
   }
 }
+// BOOL with LOR / LAND (the `while q.reduce_bool()` of a BFS loop): "is any present value true / false" — one kernel, 16 bytes
+// per lane per step, one atomic per workgroup into the self-cleaning counter slot
+__global__ void k_any_byte(uint64_t n, const uint8_t* __restrict__ val, const uint8_t* __restrict__ pres, uint8_t want, unsigned long long* out) {
+  unsigned long long c = 0;
+  const uint64_t n16 = n / 16;
+  const uint4* v4 = (const uint4*)val; const uint4* p4 = (const uint4*)pres;
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += gridDim.x * 256ull) {
+    const uint4 v = v4[i]; uint4 p = pres ? p4[i] : make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+    const uint32_t m = want ? 0u : 0x01010101u;          // count present bytes whose value (0/1) equals `want`
+    c += __popc(((v.x ^ m) & 0x01010101u) & ((p.x | (p.x >> 1) | (p.x >> 2) | (p.x >> 3) | (p.x >> 4) | (p.x >> 5) | (p.x >> 6) | (p.x >> 7)) & 0x01010101u));
+    c += __popc(((v.y ^ m) & 0x01010101u) & ((p.y | (p.y >> 1) | (p.y >> 2) | (p.y >> 3) | (p.y >> 4) | (p.y >> 5) | (p.y >> 6) | (p.y >> 7)) & 0x01010101u));
+    c += __popc(((v.z ^ m) & 0x01010101u) & ((p.z | (p.z >> 1) | (p.z >> 2) | (p.z >> 3) | (p.z >> 4) | (p.z >> 5) | (p.z >> 6) | (p.z >> 7)) & 0x01010101u));
+    c += __popc(((v.w ^ m) & 0x01010101u) & ((p.w | (p.w >> 1) | (p.w >> 2) | (p.w >> 3) | (p.w >> 4) | (p.w >> 5) | (p.w >> 6) | (p.w >> 7)) & 0x01010101u));
+  }
+  for (uint64_t i = n16 * 16 + blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) c += (!pres || pres[i]) && ((val[i] != 0) == (want != 0));
+  block_add_u64(c, out);
+}
 // fixed-shape two-level tree: results are run-to-run deterministic for floating point as well
 void reduce_values(int code, uint64_t n, const void* val, const uint8_t* pres, int op, const void* identity, void* result_host) {
+  if (code == T_BOOL && n && (op == B_LOR || op == B_LAND) && ((uintptr_t)val % 16 == 0) && (!pres || (uintptr_t)pres % 16 == 0)) {
+    ScalarSlot slot; slot.zero();
+    hipLaunchKernelGGL(k_any_byte, dim3(grid_capped(n, 16)), dim3(256), 0, stream(), n, (const uint8_t*)val, pres, (uint8_t)(op == B_LOR ? 1 : 0), (unsigned long long*)slot.dev());
+    const uint64_t hits = slot.read_u64();
+    const uint8_t r = op == B_LOR ? (hits != 0) : (hits == 0);        // LOR: some present value is true; LAND: no present value is false
+    memcpy(result_host, &r, 1);
+    return;
+  }
   dispatch_type(code, [&]<class T>() {
     T id; memcpy(&id, identity, sizeof(T));
     if (!n) { memcpy(result_host, &id, sizeof(T)); return; }

@@ -133,6 +133,20 @@ def test_vector_ops(gpu, typ):
     assert gb.Vector.sparse(T, 10).reduce_bool() is False
 
 
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 1000, 4099, 70001])
+def test_bool_reduce_lor_land(gpu, n):
+    """BOOL vectors reduce with LOR (the BFS loop condition) and LAND in one counting kernel: present/absent x true/false."""
+    rng = np.random.default_rng(n)
+    for dens, ptrue in [(0.5, 0.5), (0.3, 0.0), (0.3, 1.0), (1.0, 0.5), (1.0, 1.0), (0.02, 0.5)]:
+        idx = np.flatnonzero(rng.random(n) < dens).astype(np.uint64)
+        if len(idx) == 0: idx = np.array([n - 1], np.uint64)
+        val = rng.random(len(idx)) < ptrue
+        u = to_vector("BOOL", n, idx, val)
+        d, _ = got_v(u)                      # moves it to the device
+        assert u.reduce_bool() == bool(val.any()), (n, dens, ptrue)
+        assert u.reduce_bool(mon=gb.BOOL.LAND_MONOID) == bool(val.all()), (n, dens, ptrue)
+
+
 def test_bulk_csr_roundtrip_and_scipy(gpu):
     rng = np.random.default_rng(6)
     S = sp.random(300, 200, density=0.05, format="csr", random_state=7, dtype=np.float64)
