@@ -39,7 +39,7 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   // the entry count of u and (for the direction choice below) the edges leaving it come from one kernel and one round
   // trip when the count is not known yet — the usual state inside a BFS loop, where u was just updated under a mask
   uint64_t fe_cached = ~0ull;
-  if (!u->dnvals_known && method == SPMV_AUTO && spmspv_push_supported(sd) && u->n && (useT || A->csc.valid)) {      // (never build a transpose just for this)
+  if (!u->dnvals_known && mask && method == SPMV_AUTO && spmspv_push_supported(sd) && u->n && (useT || A->csc.valid)) {      // (a masked product: frontier-like operand; never build a transpose just for this)
     const DevCSR& P0 = useT ? A->csr : mat_csc(A);
     uint64_t cnt = 0;
     fe_cached = frontier_edges_and_count(u->dpres.as<uint8_t>(), P0.rowptr.as<uint32_t>(), u->n, &cnt);

@@ -147,7 +147,10 @@ template <class T> GRB_HD T wrap_mul(T a, T b) {
 // ---- the binary operator switch, same-type ops (x, y, z all T) ----------------------------
 // Comparison ops (B_EQ..B_LE) are returned as T-valued 0/1 here; callers that need the BOOL
 // ztype cast the result.  i/j are the row/col coordinates for the positional ops.
-template <class T, bool FULL = true> GRB_HD T apply_binop(int op, T x, T y) {
+// FULL = false: the multipliers and monoids of the semiring kernels (FIRST..LXOR) only.  MATH = false: everything but the
+// operators that call into the math library (POW, ATAN2, HYPOT, ...): the O(n) kernels instantiate both and pick per call —
+// one kernel carrying the whole switch ran a 4 M-element ABS in 133 us instead of 9.
+template <class T, bool FULL = true, bool MATH = FULL> GRB_HD T apply_binop(int op, T x, T y) {
   if constexpr (is_bool<T>::value) {
     const bool a = x, b = y;
     switch (op) {
@@ -182,7 +185,7 @@ template <class T, bool FULL = true> GRB_HD T apply_binop(int op, T x, T y) {
       case B_RDIV:
         if constexpr (std::is_floating_point<T>::value) return y / x; else return int_div(y, x);
       case B_POW:
-        if constexpr (!FULL) return (T)0;
+        if constexpr (!MATH) return (T)0;
         else if constexpr (std::is_floating_point<T>::value) return (T)pow((double)x, (double)y);
         else return int_pow(x, y);
       case B_ISEQ: case B_EQ: return (T)(x == y);
@@ -210,7 +213,8 @@ template <class T, bool FULL = true> GRB_HD T apply_binop(int op, T x, T y) {
         case B_BCLR: { int64_t k = (int64_t)y; return (k >= 1 && k <= bits) ? (T)((U)x & ~((U)1 << (k - 1))) : x; }
         default: return (T)0;
       }
-    } else {
+    } else if constexpr (!MATH) return (T)0;
+    else {
       switch (op) {
         case B_ATAN2: return (T)atan2((double)x, (double)y);
         case B_HYPOT: return (T)hypot((double)x, (double)y);
@@ -225,12 +229,13 @@ template <class T, bool FULL = true> GRB_HD T apply_binop(int op, T x, T y) {
 }
 
 GRB_HD bool binop_is_compare(int op) { return op >= B_EQ && op <= B_LE; }
+GRB_HD bool binop_needs_math(int op) { return op == B_POW || (op >= B_ATAN2 && op <= B_LDEXP); }
 GRB_HD bool binop_is_positional(int op) { return op >= B_FIRSTI && op <= B_SECONDJ1; }
 // which inputs does the multiplier actually read?  (SURVEY.md App. C "kernel consequences")
 GRB_HD bool binop_uses_x(int op) { return !(op == B_SECOND || op == B_PAIR || op == B_ANY || binop_is_positional(op)); }
 GRB_HD bool binop_uses_y(int op) { return !(op == B_FIRST || op == B_PAIR || binop_is_positional(op)); }
 
-template <class T> GRB_HD T apply_unop(int op, T x) {
+template <class T, bool MATH = true> GRB_HD T apply_unop(int op, T x) {
   if constexpr (is_bool<T>::value) {
     switch (op) {
       case U_LNOT: return bool8(!(bool)x);
@@ -253,7 +258,8 @@ template <class T> GRB_HD T apply_unop(int op, T x) {
         if constexpr (std::is_integral<T>::value) return (T)~x; else return x;
       default: break;
     }
-    if constexpr (std::is_floating_point<T>::value) {
+    if constexpr (!MATH) return x;
+    else if constexpr (std::is_floating_point<T>::value) {
       const double d = (double)x;
       switch (op) {
         case U_SQRT: return (T)sqrt(d);  case U_LOG: return (T)log(d);   case U_EXP: return (T)exp(d);

@@ -42,6 +42,8 @@ void build_allow(uint64_t n, int mcode, const void* mval, const uint8_t* mpres, 
   });
 }
 
+static inline bool unop_needs_math(int op) { return op >= U_SQRT && op <= U_ISFINITE; }
+
 // ---- count present ------------------------------------------------------------------------------------
 // One atomic per workgroup and at most 512 workgroups: same-address atomics complete one after the other (~10-80 ns each on
 // this part), so a counter bumped by every wave of a 4096-block grid cost 40-80 us for a 4 MB bitmap.
@@ -106,7 +108,7 @@ uint64_t frontier_edges_and_count(const uint8_t* pres, const uint32_t* rowptr, u
 }
 
 // ---- C<M,replace> = accum(C, T) for vectors, in place on (wval, wpres) ---------------------------------
-template <class T> __global__ void k_vec_epilogue(uint64_t n, T* __restrict__ wval, uint8_t* __restrict__ wpres,
+template <class T, bool MATH> __global__ void k_vec_epilogue(uint64_t n, T* __restrict__ wval, uint8_t* __restrict__ wpres,
                                                   const T* __restrict__ tval, const uint8_t* __restrict__ tpres,
                                                   const uint8_t* __restrict__ allow, int accum, bool replace) {
   for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {
@@ -115,7 +117,7 @@ template <class T> __global__ void k_vec_epilogue(uint64_t n, T* __restrict__ wv
       const bool tp = tpres[i] != 0;
       if (accum >= 0) {
         if (tp) {
-          if (wpres[i]) wval[i] = apply_binop<T>(accum, wval[i], tval[i]);
+          if (wpres[i]) wval[i] = apply_binop<T, true, MATH>(accum, wval[i], tval[i]);
           else { wval[i] = tval[i]; wpres[i] = 1; }
         }
       } else {
@@ -131,7 +133,8 @@ void vec_epilogue(int code, uint64_t n, void* wval, uint8_t* wpres, const void* 
                   const uint8_t* allow, int accum, bool replace) {
   if (!n) return;
   dispatch_type(code, [&]<class T>() {
-    hipLaunchKernelGGL((k_vec_epilogue<T>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (T*)wval, wpres, (const T*)tval, tpres, allow, accum, replace);
+    if (accum >= 0 && binop_needs_math(accum)) hipLaunchKernelGGL((k_vec_epilogue<T, true>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (T*)wval, wpres, (const T*)tval, tpres, allow, accum, replace);
+    else hipLaunchKernelGGL((k_vec_epilogue<T, false>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (T*)wval, wpres, (const T*)tval, tpres, allow, accum, replace);
   });
 }
 
@@ -142,13 +145,13 @@ template <class T> __global__ void k_reduce(uint64_t n, const T* __restrict__ va
   __shared__ T sh[4];
   T acc = identity;
   for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull)
-    if (!pres || pres[i]) acc = apply_binop<T>(op, acc, val[i]);
+    if (!pres || pres[i]) acc = apply_binop<T, true, false>(op, acc, val[i]);
   acc = wave_reduce_op<T>(op, acc);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
     T r = sh[0];
-    for (int w = 1; w < 4; w++) r = apply_binop<T>(op, r, sh[w]);
+    for (int w = 1; w < 4; w++) r = apply_binop<T, true, false>(op, r, sh[w]);
     partial[blockIdx.x] = r;
   }
 }
@@ -193,12 +196,12 @@ void reduce_values(int code, uint64_t n, const void* val, const uint8_t* pres, i
 }
 
 // ---- element-wise union / intersection of two bitmap vectors ----------------------------------------------------
-template <class T> __global__ void k_vec_ewise(uint64_t n, const T* __restrict__ uval, const uint8_t* __restrict__ upres,
+template <class T, bool MATH> __global__ void k_vec_ewise(uint64_t n, const T* __restrict__ uval, const uint8_t* __restrict__ upres,
                                                const T* __restrict__ vval, const uint8_t* __restrict__ vpres, int op, bool is_union,
                                                T* __restrict__ tval, uint8_t* __restrict__ tpres) {
   for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {
     const bool a = upres[i] != 0, b = vpres[i] != 0;
-    if (a && b) { tval[i] = apply_binop<T>(op, uval[i], vval[i]); tpres[i] = 1; }
+    if (a && b) { tval[i] = apply_binop<T, true, MATH>(op, uval[i], vval[i]); tpres[i] = 1; }
     else if (is_union && a) { tval[i] = uval[i]; tpres[i] = 1; }
     else if (is_union && b) { tval[i] = vval[i]; tpres[i] = 1; }
     else tpres[i] = 0;
@@ -208,18 +211,19 @@ void vec_ewise(int code, uint64_t n, const void* uval, const uint8_t* upres, con
                bool is_union, void* tval, uint8_t* tpres) {
   if (!n) return;
   dispatch_type(code, [&]<class T>() {
-    hipLaunchKernelGGL((k_vec_ewise<T>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (const T*)uval, upres, (const T*)vval, vpres, op, is_union, (T*)tval, tpres);
+    if (binop_needs_math(op)) hipLaunchKernelGGL((k_vec_ewise<T, true>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (const T*)uval, upres, (const T*)vval, vpres, op, is_union, (T*)tval, tpres);
+    else hipLaunchKernelGGL((k_vec_ewise<T, false>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (const T*)uval, upres, (const T*)vval, vpres, op, is_union, (T*)tval, tpres);
   });
 }
 
 // ---- apply: unary op, or binary op with one bound scalar (mode 1: z=f(s,x)  mode 2: z=f(x,s)) ----------------------
-template <class T> __global__ void k_vec_apply(uint64_t n, const T* __restrict__ uval, const uint8_t* __restrict__ upres, int mode, int op,
+template <class T, bool MATH> __global__ void k_vec_apply(uint64_t n, const T* __restrict__ uval, const uint8_t* __restrict__ upres, int mode, int op,
                                                T s, T* __restrict__ tval, uint8_t* __restrict__ tpres) {
   for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {
     const bool a = upres ? upres[i] != 0 : true;
     if (a) {
       T x = uval[i];
-      tval[i] = mode == 0 ? apply_unop<T>(op, x) : (mode == 1 ? apply_binop<T>(op, s, x) : apply_binop<T>(op, x, s));
+      tval[i] = mode == 0 ? apply_unop<T, MATH>(op, x) : (mode == 1 ? apply_binop<T, true, MATH>(op, s, x) : apply_binop<T, true, MATH>(op, x, s));
     }
     if (tpres) tpres[i] = a ? 1 : 0;
   }
@@ -228,18 +232,19 @@ void vec_apply(int code, uint64_t n, const void* uval, const uint8_t* upres, int
   if (!n) return;
   dispatch_type(code, [&]<class T>() {
     T s{}; if (scalar) memcpy(&s, scalar, sizeof(T));
-    hipLaunchKernelGGL((k_vec_apply<T>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (const T*)uval, upres, mode, op, s, (T*)tval, tpres);
+    if (mode == 0 ? unop_needs_math(op) : binop_needs_math(op)) hipLaunchKernelGGL((k_vec_apply<T, true>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (const T*)uval, upres, mode, op, s, (T*)tval, tpres);
+    else hipLaunchKernelGGL((k_vec_apply<T, false>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (const T*)uval, upres, mode, op, s, (T*)tval, tpres);
   });
 }
 
 // ---- w<allow>(:) = accum(w, scalar) over all indices (GrB_Vector_assign_<T> with GrB_ALL) ---------------------------------
-template <class T> __global__ void k_vec_assign_scalar(uint64_t n, T* __restrict__ wval, uint8_t* __restrict__ wpres,
+template <class T, bool MATH> __global__ void k_vec_assign_scalar(uint64_t n, T* __restrict__ wval, uint8_t* __restrict__ wpres,
                                                        const uint8_t* __restrict__ allow, const uint8_t* __restrict__ region, T s, int accum, bool replace) {
   for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {
     const bool ok = allow ? allow[i] != 0 : true;
     const bool in = region ? region[i] != 0 : true;
     if (ok && in) {
-      if (accum >= 0 && wpres[i]) wval[i] = apply_binop<T>(accum, wval[i], s); else wval[i] = s;
+      if (accum >= 0 && wpres[i]) wval[i] = apply_binop<T, true, MATH>(accum, wval[i], s); else wval[i] = s;
       wpres[i] = 1;
     } else if (!ok && replace) wpres[i] = 0;
   }
@@ -248,7 +253,8 @@ void vec_assign_scalar(int code, uint64_t n, void* wval, uint8_t* wpres, const u
   if (!n) return;
   dispatch_type(code, [&]<class T>() {
     T s; memcpy(&s, scalar, sizeof(T));
-    hipLaunchKernelGGL((k_vec_assign_scalar<T>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (T*)wval, wpres, allow, region, s, accum, replace);
+    if (accum >= 0 && binop_needs_math(accum)) hipLaunchKernelGGL((k_vec_assign_scalar<T, true>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (T*)wval, wpres, allow, region, s, accum, replace);
+    else hipLaunchKernelGGL((k_vec_assign_scalar<T, false>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (T*)wval, wpres, allow, region, s, accum, replace);
   });
 }
 
