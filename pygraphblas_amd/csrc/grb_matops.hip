@@ -29,7 +29,7 @@ __device__ __forceinline__ bool mask_truth(const void* mval, int mcode, uint32_t
 
 // ---- write-back merge:  out(i,:) from C(i,:), T(i,:), M(i,:) -------------------------------------------------------
 // FILL = false: count entries of each output row.  FILL = true: write them at orow[i].
-template <class T, bool FILL>
+template <class T, bool FILL, bool MATH = false>
 __global__ void k_writeback(uint32_t nrows, const uint32_t* __restrict__ crp, const uint32_t* __restrict__ ccol, const T* __restrict__ cval,
                             const uint32_t* __restrict__ trp, const uint32_t* __restrict__ tcol, const T* __restrict__ tval,
                             const uint32_t* __restrict__ mrp, const uint32_t* __restrict__ mcol, const void* __restrict__ mval, int mcode,
@@ -52,7 +52,7 @@ __global__ void k_writeback(uint32_t nrows, const uint32_t* __restrict__ crp, co
       bool outp; T outv = T();
       if (m) {
         if (accum >= 0) {
-          if (inc && intt) { outp = true; if (FILL) outv = apply_binop<T>(accum, cval[pc], tval[pt]); }
+          if (inc && intt) { outp = true; if (FILL) outv = apply_binop<T, true, MATH>(accum, cval[pc], tval[pt]); }
           else if (intt) { outp = true; if (FILL) outv = tval[pt]; }
           else { outp = true; if (FILL) outv = cval[pc]; }
         } else { outp = intt; if (FILL && intt) outv = tval[pt]; }
@@ -80,16 +80,18 @@ void csr_writeback(int code, uint32_t nrows, const DevCSR& C, const DevCSR& Tm, 
     uint32_t total = 0;
     GRB_HIP(hipMemcpyAsync(&total, out.rowptr.as<uint32_t>() + nrows, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
     out.nnz = total; out.col.alloc((size_t)total * 4); out.val.alloc((size_t)total * sizeof(T));
-    hipLaunchKernelGGL((k_writeback<T, true>), dim3(grid_rows(nrows)), dim3(256), 0, stream(), nrows, C.rowptr.as<uint32_t>(), C.col.as<uint32_t>(), C.val.as<T>(),
-                       Tm.rowptr.as<uint32_t>(), Tm.col.as<uint32_t>(), Tm.val.as<T>(), M ? M->rowptr.as<uint32_t>() : nullptr, M ? M->col.as<uint32_t>() : nullptr,
-                       M ? M->val.p : nullptr, mcode, M != nullptr, mstruct, mcomp, replace, accum, (uint32_t*)nullptr, out.rowptr.as<uint32_t>(), out.col.as<uint32_t>(), out.val.as<T>());
+#define GRB_WB_FILL(MATH) hipLaunchKernelGGL((k_writeback<T, true, MATH>), dim3(grid_rows(nrows)), dim3(256), 0, stream(), nrows, C.rowptr.as<uint32_t>(), C.col.as<uint32_t>(), C.val.as<T>(), \
+                       Tm.rowptr.as<uint32_t>(), Tm.col.as<uint32_t>(), Tm.val.as<T>(), M ? M->rowptr.as<uint32_t>() : nullptr, M ? M->col.as<uint32_t>() : nullptr, \
+                       M ? M->val.p : nullptr, mcode, M != nullptr, mstruct, mcomp, replace, accum, (uint32_t*)nullptr, out.rowptr.as<uint32_t>(), out.col.as<uint32_t>(), out.val.as<T>())
+    if (accum >= 0 && binop_needs_math(accum)) GRB_WB_FILL(true); else GRB_WB_FILL(false);
+#undef GRB_WB_FILL
   });
   GRB_HIP(hipGetLastError());
   out.valid = true;
 }
 
 // ---- element-wise union / intersection -----------------------------------------------------------------------------
-template <class T, bool FILL>
+template <class T, bool FILL, bool MATH = false>      // MATH: the operator may call into the math library (see grb_ops.hpp)
 __global__ void k_ewise(uint32_t nrows, const uint32_t* __restrict__ arp, const uint32_t* __restrict__ acol, const T* __restrict__ aval,
                         const uint32_t* __restrict__ brp, const uint32_t* __restrict__ bcol, const T* __restrict__ bval, int op, bool is_union,
                         uint32_t* __restrict__ ocount, const uint32_t* __restrict__ orp, uint32_t* __restrict__ ocol, T* __restrict__ oval) {
@@ -98,7 +100,7 @@ __global__ void k_ewise(uint32_t nrows, const uint32_t* __restrict__ arp, const 
     uint32_t w = FILL ? orp[i] : 0, cnt = 0;
     while (pa < ea || pb < eb) {
       const uint32_t ja = pa < ea ? acol[pa] : 0xFFFFFFFFu, jb = pb < eb ? bcol[pb] : 0xFFFFFFFFu;
-      if (ja == jb) { if (FILL) { ocol[w] = ja; oval[w] = apply_binop<T>(op, aval[pa], bval[pb]); w++; } cnt++; pa++; pb++; }
+      if (ja == jb) { if (FILL) { ocol[w] = ja; oval[w] = apply_binop<T, true, MATH>(op, aval[pa], bval[pb]); w++; } cnt++; pa++; pb++; }
       else if (ja < jb) { if (is_union) { if (FILL) { ocol[w] = ja; oval[w] = aval[pa]; w++; } cnt++; } pa++; }
       else { if (is_union) { if (FILL) { ocol[w] = jb; oval[w] = bval[pb]; w++; } cnt++; } pb++; }
     }
@@ -119,8 +121,10 @@ void csr_ewise(int code, const DevCSR& A, const void* aval, const DevCSR& B, con
     uint32_t total = 0;
     GRB_HIP(hipMemcpyAsync(&total, out.rowptr.as<uint32_t>() + nrows, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
     out.nnz = total; out.col.alloc((size_t)total * 4); out.val.alloc((size_t)total * sizeof(T));
-    hipLaunchKernelGGL((k_ewise<T, true>), dim3(grid_rows(nrows)), dim3(256), 0, stream(), nrows, A.rowptr.as<uint32_t>(), A.col.as<uint32_t>(), (const T*)aval,
-                       B.rowptr.as<uint32_t>(), B.col.as<uint32_t>(), (const T*)bval, op, is_union, (uint32_t*)nullptr, out.rowptr.as<uint32_t>(), out.col.as<uint32_t>(), out.val.as<T>());
+#define GRB_EW_FILL(MATH) hipLaunchKernelGGL((k_ewise<T, true, MATH>), dim3(grid_rows(nrows)), dim3(256), 0, stream(), nrows, A.rowptr.as<uint32_t>(), A.col.as<uint32_t>(), (const T*)aval, \
+                       B.rowptr.as<uint32_t>(), B.col.as<uint32_t>(), (const T*)bval, op, is_union, (uint32_t*)nullptr, out.rowptr.as<uint32_t>(), out.col.as<uint32_t>(), out.val.as<T>())
+    if (binop_needs_math(op)) GRB_EW_FILL(true); else GRB_EW_FILL(false);
+#undef GRB_EW_FILL
   });
   GRB_HIP(hipGetLastError());
   out.valid = true;
@@ -207,10 +211,10 @@ template <class T> __global__ void k_reduce_rows(uint32_t nrows, const uint32_t*
   for (uint64_t r = grp; r < nrows; r += ngrp) {
     const uint32_t b = rp[r], e = rp[r + 1];
     T acc = T(); bool has = false;
-    for (uint32_t p = b + lane; p < e; p += 16) { acc = has ? apply_binop<T>(op, acc, val[p]) : val[p]; has = true; }
+    for (uint32_t p = b + lane; p < e; p += 16) { acc = has ? apply_binop<T, true, false>(op, acc, val[p]) : val[p]; has = true; }
     for (int d = 8; d >= 1; d >>= 1) {
       const T ov = shfl_down_t<T>(acc, d); const int oh = __shfl_down((int)has, d, 64);
-      if (oh) { acc = has ? apply_binop<T>(op, acc, ov) : ov; has = true; }
+      if (oh) { acc = has ? apply_binop<T, true, false>(op, acc, ov) : ov; has = true; }
     }
     if (lane == 0) { if (has) tval[r] = acc; tpres[r] = has ? 1 : 0; }
   }

@@ -133,6 +133,23 @@ def test_vector_ops(gpu, typ):
     assert gb.Vector.sparse(T, 10).reduce_bool() is False
 
 
+def test_math_library_operators(gpu):
+    """The O(n) kernels exist in two variants (with / without the operators that call the math library): exercise the heavy one."""
+    rng = np.random.default_rng(9); n = 3000
+    ui, ux = rand_vector(rng, "FP64", n, 0.6); vi, vx = rand_vector(rng, "FP64", n, 0.6)
+    ux = np.abs(ux) + 0.5; vx = np.abs(vx) * 0.25
+    u, v = to_vector("FP64", n, ui, ux), to_vector("FP64", n, vi, vx)
+    du = np.zeros(n); pu = np.zeros(n, bool); du[ui.astype(int)] = ux; pu[ui.astype(int)] = True
+    dv = np.zeros(n); pv = np.zeros(n, bool); dv[vi.astype(int)] = vx; pv[vi.astype(int)] = True
+    g, p = got_v(u.emult(v, gb.FP64.POW)); assert np.array_equal(p.astype(bool), pu & pv) and np.allclose(g[p != 0], np.power(du, dv)[pu & pv], rtol=1e-12)
+    g, p = got_v(u.eadd(v, gb.FP64.ATAN2)); both = pu & pv
+    assert np.allclose(g[both], np.arctan2(du, dv)[both], rtol=1e-12) and np.array_equal(g[pu & ~pv], du[pu & ~pv])
+    g, p = got_v(u.apply(gb.FP64.EXP)); assert np.allclose(g[p != 0], np.exp(du[pu]), rtol=1e-12)
+    g, p = got_v(u.apply(gb.FP64.LOG)); assert np.allclose(g[p != 0], np.log(du[pu]), rtol=1e-12)
+    w = u.dup(); w.assign_scalar(2.0, accum=gb.FP64.POW); g, p = got_v(w)
+    assert p.all() and np.allclose(g, np.where(pu, du ** 2.0, 2.0), rtol=1e-12)
+
+
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 1000, 4099, 70001])
 def test_bool_reduce_lor_land(gpu, n):
     """BOOL vectors reduce with LOR (the BFS loop condition) and LAND in one counting kernel: present/absent x true/false."""
