@@ -49,8 +49,10 @@ inline const uint8_t* vector_allow(GrB_Vector mask, const DescView& dv, uint64_t
 
 // Write T (bitmap tval/tpres of type tcode; buffers are consumed) into w under mask/accum/replace.
 // `t_only_allowed`: T has no entries where the mask forbids writing (true for the kernels here).
+// `t_nvals`: the entry count of T when the caller knows it (~0 otherwise) — carried into w where the result's count follows
+// from it, so that the next product does not have to count on the device and wait for the answer.
 inline void vector_write_back(GrB_Vector w, int tcode, DevBuf& tval, DevBuf& tpres, const uint8_t* allow, GrB_BinaryOp accum,
-                              bool replace, bool t_only_allowed) {
+                              bool replace, bool t_only_allowed, uint64_t t_nvals = ~0ull) {
   const uint64_t n = w->n; const int wcode = w->type->code;
   const bool w_empty = w->host_valid ? (vec_nvals(w) == 0) : (w->dnvals_known && w->dnvals == 0);
   if (accum) check_binop(accum, "accum");
@@ -58,10 +60,13 @@ inline void vector_write_back(GrB_Vector w, int tcode, DevBuf& tval, DevBuf& tpr
     // w becomes exactly T: adopt the buffers (typecast the values if the output type differs)
     if (tcode != wcode) { DevBuf c(n * w->type->size + 1); vec_cast_values(wcode, c.p, tcode, tval.p, n); tval = std::move(c); }
     vec_invalidate_host(w);
-    w->dval = std::move(tval); w->dpres = std::move(tpres); w->dev_valid = true; w->dnvals_known = false; w->dnvals = 0;
+    w->dval = std::move(tval); w->dpres = std::move(tpres); w->dev_valid = true;
+    w->dnvals_known = t_nvals != ~0ull; w->dnvals = w->dnvals_known ? t_nvals : 0;
     return;
   }
   vec_to_device(w);
+  // no mask + accum: the result is the union of w and T — still full when w or T was
+  const bool stays_full = !allow && accum && ((w->dnvals_known && w->dnvals == n) || t_nvals == n);
   // the epilogue runs in the accumulator's domain (or w's type without one)
   const int ecode = accum ? accum->xtype->code : wcode;
   DevBuf tc, wc;
@@ -71,7 +76,7 @@ inline void vector_write_back(GrB_Vector w, int tcode, DevBuf& tval, DevBuf& tpr
   vec_epilogue(ecode, n, wv, w->dpres.as<uint8_t>(), tv, tpres.as<uint8_t>(), allow, accum ? accum->opcode : -1, replace);
   if (ecode != wcode) vec_cast_values(wcode, w->dval.p, ecode, wv, n);
   vec_invalidate_host(w);
-  w->dnvals_known = false;   // temporaries return to the pool; reuse is stream-ordered
+  w->dnvals_known = stays_full; w->dnvals = stays_full ? n : 0;   // (temporaries return to the pool; reuse is stream-ordered)
 }
 
 }  // namespace grb

@@ -70,7 +70,8 @@ static void vec_assign(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const 
     vec_assign_scalar(ecode, n, wc.p, w->dpres.as<uint8_t>(), allow, reg, s, accum->opcode, dv.replace);
     vec_cast_values(wcode, w->dval.p, ecode, wc.p, n);
   }
-  vec_invalidate_host(w); w->dnvals_known = false;
+  vec_invalidate_host(w);
+  w->dnvals_known = !allow && !reg; w->dnvals = w->dnvals_known ? n : 0;       // every index, no mask: the vector is full now
 }
 
 static void vec_ewise_op(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_BinaryOp op, GrB_Vector u, GrB_Vector v,
@@ -90,7 +91,9 @@ static void vec_ewise_op(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_
   const void* vv = cast_values(xc, v->type->code, v->dval.p, n, vc);
   vec_ewise(xc, n, uv, u->dpres.as<uint8_t>(), vv, v->dpres.as<uint8_t>(), op->opcode, is_union, tval.p, tpres.as<uint8_t>());
   // a comparison yields 0/1 in the operand type: identical to BOOL after the typecast into w
-  vector_write_back(w, xc, tval, tpres, allow, accum, dv.replace, /*t_only_allowed=*/false);
+  const bool uf = u->dnvals_known && u->dnvals == n, vf = v->dnvals_known && v->dnvals == n;
+  const uint64_t tn = (is_union ? (uf || vf) : (uf && vf)) ? n : ~0ull;          // a full operand makes the union full, two make the intersection full
+  vector_write_back(w, xc, tval, tpres, allow, accum, dv.replace, /*t_only_allowed=*/false, tn);
 }
 
 // mode 0: unary op; 1: z = f(s, x); 2: z = f(x, s)
@@ -108,7 +111,7 @@ static void vec_apply_op(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, int 
   const void* uv = cast_values(opxcode, u->type->code, u->dval.p, n, uc);
   uint8_t s[16] = {0}; if (scalar) cast_scalar(opxcode, s, scode, scalar);
   vec_apply(opxcode, n, uv, u->dpres.as<uint8_t>(), mode, opcode, s, tval.p, tpres.as<uint8_t>());
-  vector_write_back(w, opxcode, tval, tpres, allow, accum, dv.replace, false);
+  vector_write_back(w, opxcode, tval, tpres, allow, accum, dv.replace, false, u->dnvals_known ? u->dnvals : ~0ull);     // apply keeps the pattern
 }
 
 #define VEC_GUARD(w) if (!(w)) return GrB_NULL_POINTER; if (!check_obj(w)) return GrB_UNINITIALIZED_OBJECT
