@@ -67,13 +67,19 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
   const W idw = to_word<T>(sr.identity);
   uint32_t* key = s_key[team]; W* acc = s_acc[team]; uint16_t* pos = s_pos[team]; uint8_t* flag = s_flag[team];
   uint32_t* lpa = s_lpa[team]; uint32_t* lbb = s_lbb[team]; uint32_t* lbe = s_lbe[team]; uint32_t* cnt = s_cnt[team];
+  // a team of one wave (the bin of the shortest mask rows: four rows per block) needs no block barrier: its LDS slices are
+  // private and LDS operations of a wave execute in order, so every row runs exactly its own number of rounds
+  auto team_sync = [&]() {
+    if constexpr (TEAM == 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+  };
   const uint32_t nblk_rows = (nrows_bin + TEAMS - 1) / TEAMS * TEAMS;     // every team runs the same trip count
   for (uint32_t rbase = blockIdx.x * TEAMS; rbase < nblk_rows; rbase += gridDim.x * TEAMS) {
     const uint32_t ridx = rbase + team;
     const bool live = ridx < nrows_bin;
     const uint32_t i = live ? rows[ridx] : 0;
     for (int s2 = t; s2 < SLOTS; s2 += TEAM) { key[s2] = HASH_EMPTY; acc[s2] = idw; flag[s2] = 0; }
-    __syncthreads();
+    team_sync();
     const uint32_t mb = live ? a.mrp[i] : 0, me = live ? a.mrp[i + 1] : 0;
     for (uint32_t p = mb + t; p < me; p += TEAM) {
       if (!spgemm_mask_truth(a.mval, a.mcode, p, a.mstruct)) continue;
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
     const uint32_t ab = live ? a.arp[i] : 0, ae = live ? a.arp[i + 1] : 0;
     // the longest A row of the block decides the number of rounds, so every team reaches every barrier
     uint32_t maxlen = ae - ab;
-    if constexpr (TEAMS > 1) {
+    if constexpr (TEAMS > 1 && TEAM != 64) {
       __shared__ uint32_t s_max;
       if (threadIdx.x == 0) s_max = 0;
       __syncthreads();
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
     }
     for (uint32_t r0 = 0; r0 < maxlen; r0 += LCAP) {
       if (t < 2) cnt[t] = 0;
-      __syncthreads();
+      team_sync();
       // stage the next LCAP entries of A(i,:) into the short / long lists
       for (uint32_t q = r0 + t; q < r0 + LCAP && ab + q < ae; q += TEAM) {
         const uint32_t pa = ab + q, k = a.acol[pa];
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
         const uint32_t slot = lng ? (LCAP - 1 - atomicAdd(&cnt[1], 1u)) : atomicAdd(&cnt[0], 1u);
         lpa[slot] = pa; lbb[slot] = bb; lbe[slot] = be;
       }
-      __syncthreads();
+      team_sync();
       const uint32_t nshort = cnt[0], nlong = cnt[1];
       // short rows: one 16-lane group each
       for (uint32_t q = grp; q < nshort; q += NG) {
@@ -141,12 +147,12 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
           }
         }
       }
-      __syncthreads();
+      team_sync();
     }
     for (int s2 = t; s2 < SLOTS; s2 += TEAM) {
       if (key[s2] != HASH_EMPTY && flag[s2]) { a.cacc[mb + pos[s2]] = acc[s2]; a.cflag[mb + pos[s2]] = 1; }
     }
-    __syncthreads();
+    team_sync();
   }
 }
 
