@@ -49,6 +49,7 @@ __device__ __forceinline__ bool spgemm_mask_truth(const void* mval, int mcode, u
 // sorted into two LDS work lists by the length of B(k,:): short rows (< 64 entries) are walked by 16-lane groups,
 // four at a time per wave; long rows by a whole wave each, 64 coalesced entries per step.
 constexpr int SPG_LIST = 512;       // k's staged per round (per team)
+constexpr uint32_t SPG_HUGE = 2048; // B rows at least this long are shared by the whole team
 template <class T, class SR, int SLOTS, int TEAM, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T> a, const uint32_t* __restrict__ rows, uint32_t nrows_bin, const SR sr) {
   typedef typename acc_word<T>::type W;
@@ -59,7 +60,9 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
   __shared__ uint16_t s_pos[TEAMS][SLOTS];
   __shared__ uint8_t s_flag[TEAMS][SLOTS];
   __shared__ uint32_t s_lpa[TEAMS][LCAP], s_lbb[TEAMS][LCAP], s_lbe[TEAMS][LCAP];     // work list: A-entry position, B row begin / end
-  __shared__ uint32_t s_cnt[TEAMS][2];                                                  // [0] short rows fill from the front, [1] long rows from the back
+  __shared__ uint32_t s_cnt[TEAMS][3];                                                  // [0] short rows fill from the front, [1] long rows from the back, [2] huge rows
+  constexpr int HCAP = TEAM > 64 ? 64 : 1;                                              // B rows of >= SPG_HUGE entries are walked by the whole team (one wave would hold the others at the barrier)
+  __shared__ uint32_t s_hpa[TEAMS][HCAP], s_hbb[TEAMS][HCAP], s_hbe[TEAMS][HCAP];
   const int team = threadIdx.x / TEAM, t = threadIdx.x % TEAM;
   const int lane16 = t & 15, grp = t >> 4, lane64 = t & 63, wv = t >> 6;
   constexpr int NG = TEAM / 16, NW = TEAM / 64;
@@ -100,19 +103,23 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
       maxlen = s_max;
     }
     for (uint32_t r0 = 0; r0 < maxlen; r0 += LCAP) {
-      if (t < 2) cnt[t] = 0;
+      if (t < 3) cnt[t] = 0;
       team_sync();
       // stage the next LCAP entries of A(i,:) into the short / long lists
       for (uint32_t q = r0 + t; q < r0 + LCAP && ab + q < ae; q += TEAM) {
         const uint32_t pa = ab + q, k = a.acol[pa];
         const uint32_t bb = a.brp[k], be = a.brp[k + 1];
         if (be == bb) continue;
+        if (TEAM > 64 && be - bb >= SPG_HUGE) {
+          const uint32_t hs = atomicAdd(&cnt[2], 1u);
+          if (hs < (uint32_t)HCAP) { s_hpa[team][hs] = pa; s_hbb[team][hs] = bb; s_hbe[team][hs] = be; continue; }
+        }
         const bool lng = be - bb >= 64;
         const uint32_t slot = lng ? (LCAP - 1 - atomicAdd(&cnt[1], 1u)) : atomicAdd(&cnt[0], 1u);
         lpa[slot] = pa; lbb[slot] = bb; lbe[slot] = be;
       }
       team_sync();
-      const uint32_t nshort = cnt[0], nlong = cnt[1];
+      const uint32_t nshort = cnt[0], nlong = cnt[1], nhuge = cnt[2] < (uint32_t)HCAP ? cnt[2] : (uint32_t)HCAP;
       // short rows: one 16-lane group each
       for (uint32_t q = grp; q < nshort; q += NG) {
         const T av = use_a ? a.aval[lpa[q]] : T();
@@ -143,6 +150,29 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
               uint32_t kk = key[h];
               while (kk != j && kk != HASH_EMPTY) { h = (h + 1) & (SLOTS - 1); kk = key[h]; }
               if (kk == j) { word_combine<T>(sr.add_op(), &acc[h], sr.mult(av, use_b ? a.bval[pb] : T())); flag[h] = 1; }
+            }
+          }
+        }
+      }
+      // huge rows: the whole team, TEAM coalesced entries per step, 4 loads in flight per lane
+      if constexpr (TEAM > 64) {
+        for (uint32_t q = 0; q < nhuge; q++) {
+          const T av = use_a ? a.aval[s_hpa[team][q]] : T();
+          const uint32_t be = s_hbe[team][q];
+          for (uint32_t pb0 = s_hbb[team][q] + t; pb0 < be; pb0 += 4 * TEAM) {
+            uint32_t jj[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t pb = pb0 + TEAM * u; jj[u] = a.bcol[pb < be ? pb : be - 1]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const uint32_t pb = pb0 + TEAM * u;
+              if (pb < be) {
+                const uint32_t j = jj[u];
+                uint32_t h = hash_col(j, SLOTS - 1);
+                uint32_t kk = key[h];
+                while (kk != j && kk != HASH_EMPTY) { h = (h + 1) & (SLOTS - 1); kk = key[h]; }
+                if (kk == j) { word_combine<T>(sr.add_op(), &acc[h], sr.mult(av, use_b ? a.bval[pb] : T())); flag[h] = 1; }
+              }
             }
           }
         }
