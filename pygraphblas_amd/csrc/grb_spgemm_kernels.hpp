@@ -195,13 +195,41 @@ template <class T, class SR>
 __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T> a, const uint32_t* __restrict__ rows, uint32_t nrows_bin,
                                                             uint32_t* __restrict__ maps, uint32_t ncols, const SR sr) {
   __shared__ uint32_t s_filter[SPG_FILTER_WORDS];
+  constexpr uint32_t HL = 4096;                            // A-entries whose B row is huge: set aside by the waves, then walked by the whole block
+  __shared__ uint32_t s_hl[HL];
+  __shared__ uint32_t s_nh;
   uint32_t* map = maps + (size_t)blockIdx.x * ncols;       // zero-initialised; entry = mask position + 1
   const int t = threadIdx.x;
   const bool use_a = sr.uses_a(), use_b = sr.uses_u();
+  // one B row against the filter and the map: `step` lanes apart, 4 loads in flight per lane
+  auto walk = [&](uint32_t pa, uint32_t first, uint32_t be, uint32_t step, uint32_t mb) {
+    const T av = use_a ? a.aval[pa] : T();
+    for (uint32_t pb0 = first; pb0 < be; pb0 += 4 * step) {
+      uint32_t ss[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const uint32_t pb = pb0 + step * u; ss[u] = a.bcol[pb < be ? pb : be - 1]; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t pb = pb0 + step * u; const uint32_t j = ss[u];
+        const bool maybe = pb < be && ((s_filter[(j >> 5) & (SPG_FILTER_WORDS - 1)] >> (j & 31)) & 1u);
+        ss[u] = maybe ? map[j] : 0u;                                     // the rare survivors: exact position from the map
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t pb = pb0 + step * u;
+        if (ss[u]) {
+          const T m = sr.mult(av, use_b ? a.bval[pb] : T());
+          word_combine<T>(sr.add_op(), &a.cacc[mb + ss[u] - 1], m);
+          a.cflag[mb + ss[u] - 1] = 1;
+        }
+      }
+    }
+  };
   for (uint32_t ridx = blockIdx.x; ridx < nrows_bin; ridx += gridDim.x) {
     const uint32_t i = rows[ridx];
     const uint32_t mb = a.mrp[i], me = a.mrp[i + 1];
     for (uint32_t w = t; w < SPG_FILTER_WORDS; w += 1024) s_filter[w] = 0;
+    if (t == 0) s_nh = 0;
     __syncthreads();
     for (uint32_t p = mb + t; p < me; p += 1024) if (spgemm_mask_truth(a.mval, a.mcode, p, a.mstruct)) {
       const uint32_t j = a.mcol[p];
@@ -209,31 +237,24 @@ __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T>
     }
     __threadfence_block(); __syncthreads();
     const uint32_t ab = a.arp[i], ae = a.arp[i + 1];
-    // one wave per entry k of A(i,:): these rows have thousands of k's, most with long B rows
+    // one wave per entry k of A(i,:): these rows have thousands of k's, most with long B rows; the longest ones are kept
+    // for the whole block (a wave alone on a 30 000-entry row leaves the other fifteen waiting at the end of the row)
     for (uint32_t pa = ab + (t >> 6); pa < ae; pa += 16) {
       const uint32_t k = a.acol[pa];
-      const T av = use_a ? a.aval[pa] : T();
       const uint32_t bb = a.brp[k], be = a.brp[k + 1];
-      for (uint32_t pb0 = bb + (t & 63); pb0 < be; pb0 += 256) {
-        uint32_t ss[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t pb = pb0 + 64 * u; ss[u] = a.bcol[pb < be ? pb : be - 1]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const uint32_t pb = pb0 + 64 * u; const uint32_t j = ss[u];
-          const bool maybe = pb < be && ((s_filter[(j >> 5) & (SPG_FILTER_WORDS - 1)] >> (j & 31)) & 1u);
-          ss[u] = maybe ? map[j] : 0u;                                     // the rare survivors: exact position from the map
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const uint32_t pb = pb0 + 64 * u;
-          if (ss[u]) {
-            const T m = sr.mult(av, use_b ? a.bval[pb] : T());
-            word_combine<T>(sr.add_op(), &a.cacc[mb + ss[u] - 1], m);
-            a.cflag[mb + ss[u] - 1] = 1;
-          }
-        }
+      if (be - bb >= 4 * SPG_HUGE) {
+        uint32_t slot = HL;
+        if ((t & 63) == 0) slot = atomicAdd(&s_nh, 1u);
+        slot = (uint32_t)__shfl((int)slot, 0, 64);
+        if (slot < HL) { if ((t & 63) == 0) s_hl[slot] = pa; continue; }
       }
+      walk(pa, bb + (t & 63), be, 64, mb);
+    }
+    __syncthreads();
+    const uint32_t nh = s_nh < HL ? s_nh : HL;
+    for (uint32_t q = 0; q < nh; q++) {
+      const uint32_t pa = s_hl[q], k = a.acol[pa];
+      walk(pa, a.brp[k] + t, a.brp[k + 1], 1024, mb);
     }
     __syncthreads();
     for (uint32_t p = mb + t; p < me; p += 1024) map[a.mcol[p]] = 0;
