@@ -29,6 +29,7 @@ struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per 
   DevBuf rowptr;          // u32[F + XP] per-panel sub-row pointers, relative to the panel's first entry (F_k + 1 each)
   DevBuf tasks;           // u32 per panel: first sub-row of every 256-entry tile, (ntiles_k + 1) each
   DevBuf subrow_row, blockptr;     // u32[F]: row of every sub-row (panel-major, ascending inside a panel); u32[(nblocks+1)*8]: first sub-row of panel k in row block b
+  DevBuf subrow_lrow;              // u16[F]: the same row relative to its block of XP_RB rows — what the merge kernel streams (2 bytes per sub-row instead of 4)
   DevBuf args;            // WpArgs<T>[XP] in HBM (pointers into the per-call buffers are patched every call)
   DevBuf carry;           // WpCarry<T>, one per chunk of tasks, panel after panel
   DevBuf xhot, partial, scratch;   // per-call work buffers kept with the plan so the argument block never changes (xhot: T[8*H], the LDS tables' contents)
@@ -126,6 +127,9 @@ template <class T> __global__ void k_xp_hot_gather(const T* __restrict__ u, cons
 // sub-rows are one contiguous run in each panel (sub-rows are in row order inside a panel), so the eight runs are read
 // with coalesced loads and accumulated panel after panel in LDS — no per-row index chain, fixed order => reproducible.
 constexpr uint32_t XP_RB = 2048;
+static __global__ void k_xp_local_rows(const uint32_t* __restrict__ subrow_row, uint64_t F, uint16_t* __restrict__ lrow) {
+  for (uint64_t s = blockIdx.x * 256ull + threadIdx.x; s < F; s += gridDim.x * 256ull) lrow[s] = (uint16_t)(subrow_row[s] % XP_RB);
+}
 static __global__ void k_xp_block_starts(const uint32_t* __restrict__ subrow_row, uint32_t nblocks, uint64_t s0, uint64_t s1, uint64_t s2, uint64_t s3, uint64_t s4, uint64_t s5,
                                          uint64_t s6, uint64_t s7, uint64_t s8, uint32_t* __restrict__ blockptr) {
   const uint64_t so[XP + 1] = {s0, s1, s2, s3, s4, s5, s6, s7, s8};
@@ -137,7 +141,7 @@ static __global__ void k_xp_block_starts(const uint32_t* __restrict__ subrow_row
   }
 }
 template <class T, class SR>
-__global__ __launch_bounds__(512) void k_xp_combine(uint32_t nrows, const uint32_t* __restrict__ blockptr, const uint32_t* __restrict__ subrow_row, const T* __restrict__ partial,
+__global__ __launch_bounds__(512) void k_xp_combine(uint32_t nrows, const uint32_t* __restrict__ blockptr, const uint16_t* __restrict__ subrow_lrow, const T* __restrict__ partial,
                                                     T* __restrict__ y, uint8_t* __restrict__ ypres, const SR sr) {
   __shared__ T acc[XP_RB];
   __shared__ uint8_t has[XP_RB];
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(512) void k_xp_combine(uint32_t nrows, const uint32
 #pragma unroll
   for (int k = 0; k < XP; k++) {
     for (uint32_t s = lo[k] + threadIdx.x; s < hi[k]; s += 512) {         // one sub-row of a row per panel: no two threads meet on a row
-      const uint32_t r = subrow_row[s] - r0; const T v = partial[s];
+      const uint32_t r = subrow_lrow[s]; const T v = partial[s];
       if (has[r]) acc[r] = sr.add(acc[r], v); else { acc[r] = v; has[r] = 1; }
     }
     __syncthreads();
@@ -239,6 +243,8 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu) {
   {
     const uint32_t nblocks = (uint32_t)(((uint64_t)M.nrows + XP_RB - 1) / XP_RB);
     P->blockptr.alloc(((size_t)nblocks + 1) * XP * 4 + 4);
+    P->subrow_lrow.alloc(P->F * 2 + 4);
+    hipLaunchKernelGGL(k_xp_local_rows, dim3(grid_n(P->F)), dim3(256), 0, stream(), P->subrow_row.as<uint32_t>(), P->F, P->subrow_lrow.as<uint16_t>());
     hipLaunchKernelGGL(k_xp_block_starts, dim3(grid_n(((uint64_t)nblocks + 1) * XP)), dim3(256), 0, stream(), P->subrow_row.as<uint32_t>(), nblocks, P->soff[0], P->soff[1], P->soff[2],
                        P->soff[3], P->soff[4], P->soff[5], P->soff[6], P->soff[7], P->soff[8], P->blockptr.as<uint32_t>());
   }
@@ -303,7 +309,7 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
     hipLaunchKernelGGL((k_spmv_wavepipe_fixup<T, SR>), dim3((P->maxchunks + 255) / 256, XP), dim3(256), 0, stream(), (const WpCarry<T>*)nullptr, P->maxchunks, (T*)nullptr, (uint8_t*)nullptr,
                        (const WpArgs<T>*)P->args.p, sr);
     const uint32_t nblocks = (uint32_t)(((uint64_t)M.nrows + XP_RB - 1) / XP_RB);
-    hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3(nblocks), dim3(512), 0, stream(), M.nrows, P->blockptr.as<uint32_t>(), P->subrow_row.as<uint32_t>(), P->partial.as<T>(),
+    hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3(nblocks), dim3(512), 0, stream(), M.nrows, P->blockptr.as<uint32_t>(), P->subrow_lrow.as<uint16_t>(), P->partial.as<T>(),
                        (T*)c.tval, c.tpres, sr);
     g_last_plan += std::string("k_spmv_xcd<") + (sr.is_static ? "static" : "dynamic") + ",subrows=" + std::to_string(P->F) + "> ";
   });
