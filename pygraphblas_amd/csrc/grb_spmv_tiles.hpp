@@ -27,6 +27,23 @@ __device__ __forceinline__ uint32_t xt_scan_add(uint32_t x, int lane) {
 #undef XT_STEP
   return x;
 }
+// the segmented scan of the sums and the prefix count of the row starts in one pass: x = flag << 31 | count
+template <class T, class SR> __device__ __forceinline__ void xt_seg_scan_count(T& v, uint32_t& x, int lane, const SR& sr) {
+  if constexpr (sizeof(T) == 4 || sizeof(T) == 8) {
+    const int l16 = lane & 15, row = (lane >> 4) & 3;
+#define XT_SC_STEP(CTRL, MASK, COND) { const T vu = dpp_move_t<T, CTRL, MASK>(v); const uint32_t xu = dpp_mov<CTRL, MASK>(x, x); \
+                                       if (COND) { if (!(x >> 31)) v = sr.add(vu, v); x = (x + (xu & 0x7FFFFFFFu)) | (xu & 0x80000000u); } }
+    XT_SC_STEP(0x111, 0xf, l16 >= 1) XT_SC_STEP(0x112, 0xf, l16 >= 2) XT_SC_STEP(0x114, 0xf, l16 >= 4) XT_SC_STEP(0x118, 0xf, l16 >= 8)
+    XT_SC_STEP(0x142, 0xa, row == 1 || row == 3) XT_SC_STEP(0x143, 0xc, row >= 2)
+#undef XT_SC_STEP
+  } else {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const T vu = shfl_up_t<T>(v, d); const uint32_t xu = (uint32_t)__shfl_up((int)x, d, 64);
+      if (lane >= d) { if (!(x >> 31)) v = sr.add(vu, v); x = (x + (xu & 0x7FFFFFFFu)) | (xu & 0x80000000u); }
+    }
+  }
+}
 template <class E> __device__ __forceinline__ E xt_readlane(E v, int src) {          // src wave-uniform
   if constexpr (sizeof(E) == 8) { union { E e; int i[2]; } u; u.e = v; u.i[0] = __builtin_amdgcn_readlane(u.i[0], src); u.i[1] = __builtin_amdgcn_readlane(u.i[1], src); return u.e; }
   else if constexpr (sizeof(E) == 4) { union { E e; int i; } u; u.e = v; u.i = __builtin_amdgcn_readlane(u.i, src); return u.e; }
@@ -159,25 +176,26 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
       // what follows the tile's last entry: a row start, or the end of the panel?
       const uint32_t nextw = more ? (uint32_t)__builtin_amdgcn_readfirstlane(B.c[0]) : (uint32_t)__builtin_amdgcn_readfirstlane(behind_w);
       const bool last_end = e0 + cnt >= a.nnz || (int32_t)nextw < 0;
-      // ---- segmented inclusive scan of the products in entry order
+      // ---- segmented inclusive scan of the products in entry order, and in the same wave scan the number of row starts
+      // behind the tile's first entry (sub-row of an entry = rf + that count, up to and including the entry)
+      uint32_t mine = 0;
+#pragma unroll
+      for (int u = 0; u < WP_PER; u++) mine += (rs[u] && (u > 0 || lane > 0)) ? 1u : 0u;
+      uint32_t incl;
       {
         bool st0 = rs[0] || (lane == 0 && !carry_has);           // nothing carried in: entry 0 starts a segment whatever it is
         T agg = p[0]; bool anyf = st0;
 #pragma unroll
         for (int u = 1; u < WP_PER; u++) { agg = rs[u] ? p[u] : sr.add(agg, p[u]); anyf = anyf || rs[u]; }
         if (lane == 0 && !anyf) agg = sr.add(carry, agg);        // the carried partial flows through lane 0
-        T v = agg; int f = anyf;
-        wp_seg_scan<T, SR>(v, f, lane, sr);
+        T v = agg; uint32_t x = (anyf ? 0x80000000u : 0u) | mine;
+        xt_seg_scan_count<T, SR>(v, x, lane, sr);
+        incl = x & 0x7FFFFFFFu;
         T run = shfl_up_t<T>(v, 1); if (lane == 0) run = carry;  // what flows into my first entry (unused when it starts a row)
         run = st0 ? p[0] : sr.add(run, p[0]); p[0] = run;
 #pragma unroll
         for (int u = 1; u < WP_PER; u++) { run = rs[u] ? p[u] : sr.add(run, p[u]); p[u] = run; }
       }
-      // ---- sub-row of every entry: rf + row starts behind the tile's first entry, up to and including the entry
-      uint32_t mine = 0;
-#pragma unroll
-      for (int u = 0; u < WP_PER; u++) mine += (rs[u] && (u > 0 || lane > 0)) ? 1u : 0u;
-      const uint32_t incl = xt_scan_add(mine, lane);
       // ---- an entry ends its sub-row when the next entry starts one
       const int nxt0 = __shfl_down((int)rs[0], 1, 64);           // first flag of the next lane
       bool end[WP_PER];
