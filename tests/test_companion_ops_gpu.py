@@ -133,6 +133,28 @@ def test_vector_ops(gpu, typ):
     assert gb.Vector.sparse(T, 10).reduce_bool() is False
 
 
+def test_entry_counts_follow_the_ops(gpu):
+    """Vector ops carry known entry counts into their results (so the next product need not count on the device): the
+    counts they carry must be the true ones."""
+    rng = np.random.default_rng(11); n = 4000
+    fi = np.arange(n, dtype=np.uint64); fx = rng.random(n) + 0.5
+    si, sx = rand_vector(rng, "FP64", n, 0.3)
+    full, full2, sp = to_vector("FP64", n, fi, fx), to_vector("FP64", n, fi, fx[::-1].copy()), to_vector("FP64", n, si, sx)
+    for v in (full, full2, sp): got_v(v)                              # on the device, counts known
+    def cnt(v):
+        g, p = got_v(v); return int((p != 0).sum())
+    for expr, expect in [(lambda: full * full2, n), (lambda: full + sp, n), (lambda: sp + full, n), (lambda: full * sp, len(si)),
+                         (lambda: sp * sp, len(si)), (lambda: sp + sp, len(si)), (lambda: abs(full), n), (lambda: abs(sp), len(si)),
+                         (lambda: full.apply_second(gb.FP64.PLUS, 1.0), n)]:
+        r = expr(); assert r.nvals == expect == cnt(r)
+    w = sp.dup(); w.assign_scalar(3.0); assert w.nvals == n == cnt(w)
+    w = sp.dup(); w.assign_scalar(3.0, mask=sp); assert w.nvals == cnt(w)
+    w = full.dup(); w.assign_scalar(2.0, accum=gb.FP64.PLUS); assert w.nvals == n == cnt(w)
+    w = full.dup(); sp.apply(gb.FP64.ABS, out=w, accum=gb.FP64.PLUS); assert w.nvals == n == cnt(w)        # union with a full w stays full
+    w = sp.dup(); full.apply(gb.FP64.ABS, out=w, accum=gb.FP64.PLUS); assert w.nvals == n == cnt(w)        # ... or with a full T
+    w = sp.dup(); sp.apply(gb.FP64.ABS, out=w, accum=gb.FP64.PLUS); assert w.nvals == len(si) == cnt(w)
+
+
 def test_math_library_operators(gpu):
     """The O(n) kernels exist in two variants (with / without the operators that call the math library): exercise the heavy one."""
     rng = np.random.default_rng(9); n = 3000
