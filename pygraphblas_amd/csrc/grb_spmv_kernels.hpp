@@ -339,7 +339,8 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
     if constexpr (sizeof(T) >= 4) {
       // kernel X (one column panel per XCD) for the big ones; it keeps a panel-major copy of the matrix
       const bool want_x = c.method == SPMV_XCD || (c.method == SPMV_AUTO && M.nnz >= (1u << 22));
-      if (want_x && full && !c.allow && M.ncols < 0x0F000000u && M.nnz >= (uint64_t)WP_ENT * 64 && device_cus() > 0) {
+      // (32-bit byte offsets into a panel's streams and into u: a panel holds ~nnz/8 entries)
+      if (want_x && full && !c.allow && M.ncols < 0x0F000000u && M.nnz >= (uint64_t)WP_ENT * 64 && M.nnz * sizeof(T) < (7ull << 30) && device_cus() > 0) {
         if (run_xcd<T>(c, d, device_cus())) return;
       }
       const bool want = c.method == SPMV_WAVEPIPE || c.method == SPMV_XCD || (c.method == SPMV_AUTO && M.nnz >= (1u << 20));

@@ -5,11 +5,11 @@
 //   * a task is a *tile* of 256 consecutive entries (W: 256 items of the entry/row-end merge, i.e. ~227 entries): every
 //     lane slot carries an entry and the kernel needs no task descriptors;
 //   * the sub-row an entry belongs to follows from the row-start flags that come with the column words (bit 31): it is
-//     the sub-row of the tile's first entry (one word per tile) plus the number of row starts before it, a 6-step integer
-//     wave scan.  The kernel never reads row pointers and has no per-row pass;
-//   * row sums leave from the lanes that hold a row's last entry (the next entry starts a row), straight from registers:
-//     no scan buffer in LDS (only 64 staging slots per wave for the outgoing sums), so the LDS table grows from 16 382 to
-//     19 454 FP64 columns per panel.
+//     the sub-row of the tile's first entry (one word per tile) plus the number of row starts before it, which rides in
+//     the flag word of the segmented wave scan.  The kernel never reads row pointers and has no per-row pass;
+//   * a sub-row ends where the next entry starts one; the sums of the sub-rows that end in a tile are consecutive
+//     sub-rows, so they pass through 64 staging slots per wave and leave as coalesced stores.  There is no scan buffer in
+//     LDS: the LDS table grows from 16 382 to 19 454 FP64 columns per panel.
 // Work split, carry records and fix-up are W's (chunks of tiles; wp_* helpers).
 #pragma once
 #include "grb_spmv_wavepipe.hpp"
@@ -18,15 +18,6 @@ namespace grb {
 
 template <class T> struct xt_hot { static constexpr int H = (WP_LDS_BYTES - 16 - WP_WAVES * 64 * (int)sizeof(T)) / (int)sizeof(T); };   // all of the LDS but the staging slots is the table: 19454 (8 B) / 39932 (4 B)
 
-// inclusive prefix sum over the 64 lanes (DPP; same shape as wp_seg_scan)
-__device__ __forceinline__ uint32_t xt_scan_add(uint32_t x, int lane) {
-  const int l16 = lane & 15, row = (lane >> 4) & 3;
-#define XT_STEP(CTRL, MASK, COND) { const uint32_t t = dpp_mov<CTRL, MASK>(x, x); if (COND) x += t; }
-  XT_STEP(0x111, 0xf, l16 >= 1) XT_STEP(0x112, 0xf, l16 >= 2) XT_STEP(0x114, 0xf, l16 >= 4) XT_STEP(0x118, 0xf, l16 >= 8)
-  XT_STEP(0x142, 0xa, row == 1 || row == 3) XT_STEP(0x143, 0xc, row >= 2)
-#undef XT_STEP
-  return x;
-}
 // the segmented scan of the sums and the prefix count of the row starts in one pass: x = flag << 31 | count
 template <class T, class SR> __device__ __forceinline__ void xt_seg_scan_count(T& v, uint32_t& x, int lane, const SR& sr) {
   if constexpr (sizeof(T) == 4 || sizeof(T) == 8) {
