@@ -285,31 +285,55 @@ void oracle_reduce(int type, uint64_t n, const void* X, int op, void* out) {
 
 /* ============================ typed fast paths: the timed CPU baseline ============================ */
 /* y = A x over PLUS_TIMES, CSR u32; ypres[i] = row i non-empty.  One OpenMP thread per row chunk. */
+/* rows [*r0, *r1) of piece q of P pieces holding about the same number of entries each: R-MAT rows differ by five orders
+   of magnitude in length, so equal row counts per thread leave one thread with the hub rows (measured: 82 ms per pass on
+   128 threads with 1024-row chunks, 10x slower than this) */
+static void spmv_piece(const uint32_t* rp, uint32_t nrows, int q, int P, uint32_t* r0, uint32_t* r1) {
+  const uint64_t nnz = rp[nrows], lo_t = nnz * (uint64_t)q / (uint64_t)P, hi_t = nnz * (uint64_t)(q + 1) / (uint64_t)P;
+  uint32_t lo = 0, hi = nrows;                       /* first row whose start is >= lo_t */
+  while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (rp[mid] < lo_t) lo = mid + 1; else hi = mid; }
+  *r0 = q == 0 ? 0 : lo;
+  lo = 0; hi = nrows;
+  while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (rp[mid] < hi_t) lo = mid + 1; else hi = mid; }
+  *r1 = q == P - 1 ? nrows : lo;
+}
 void fast_spmv_plus_times_fp64(uint32_t nrows, const uint32_t* rp, const uint32_t* col, const double* val, const double* x,
                                double* y, uint8_t* ypres) {
-#pragma omp parallel for schedule(dynamic, 1024)
-  for (int64_t i = 0; i < (int64_t)nrows; i++) {
-    double s = 0.0; const uint32_t b = rp[i], e = rp[i + 1];
-    for (uint32_t p = b; p < e; p++) s += val[p] * x[col[p]];
-    y[i] = s; ypres[i] = e > b;
+  const int P = omp_get_max_threads() * 8;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int q = 0; q < P; q++) {
+    uint32_t r0, r1; spmv_piece(rp, nrows, q, P, &r0, &r1);
+    for (uint32_t i = r0; i < r1; i++) {
+      double s = 0.0; const uint32_t b = rp[i], e = rp[i + 1];
+      for (uint32_t p = b; p < e; p++) s += val[p] * x[col[p]];
+      y[i] = s; ypres[i] = e > b;
+    }
   }
 }
 void fast_spmv_plus_times_fp32(uint32_t nrows, const uint32_t* rp, const uint32_t* col, const float* val, const float* x,
                                float* y, uint8_t* ypres) {
-#pragma omp parallel for schedule(dynamic, 1024)
-  for (int64_t i = 0; i < (int64_t)nrows; i++) {
-    float s = 0.0f; const uint32_t b = rp[i], e = rp[i + 1];
-    for (uint32_t p = b; p < e; p++) s += val[p] * x[col[p]];
-    y[i] = s; ypres[i] = e > b;
+  const int P = omp_get_max_threads() * 8;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int q = 0; q < P; q++) {
+    uint32_t r0, r1; spmv_piece(rp, nrows, q, P, &r0, &r1);
+    for (uint32_t i = r0; i < r1; i++) {
+      float s = 0.0f; const uint32_t b = rp[i], e = rp[i + 1];
+      for (uint32_t p = b; p < e; p++) s += val[p] * x[col[p]];
+      y[i] = s; ypres[i] = e > b;
+    }
   }
 }
 /* y = A x over PLUS_SECOND on a pattern (PageRank inner product, gap/prmark.py:22) */
 void fast_spmv_plus_second_fp32(uint32_t nrows, const uint32_t* rp, const uint32_t* col, const float* x, float* y, uint8_t* ypres) {
-#pragma omp parallel for schedule(dynamic, 1024)
-  for (int64_t i = 0; i < (int64_t)nrows; i++) {
-    float s = 0.0f; const uint32_t b = rp[i], e = rp[i + 1];
-    for (uint32_t p = b; p < e; p++) s += x[col[p]];
-    y[i] = s; ypres[i] = e > b;
+  const int P = omp_get_max_threads() * 8;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int q = 0; q < P; q++) {
+    uint32_t r0, r1; spmv_piece(rp, nrows, q, P, &r0, &r1);
+    for (uint32_t i = r0; i < r1; i++) {
+      float s = 0.0f; const uint32_t b = rp[i], e = rp[i + 1];
+      for (uint32_t p = b; p < e; p++) s += x[col[p]];
+      y[i] = s; ypres[i] = e > b;
+    }
   }
 }
 /* sum over (i,k) in L, of |L(k,:) ∩ L(i,:)|  ==  reduce(L.mxm(L, PLUS_PAIR, mask=L))  (demo/TriangleCentrality.ipynb cell 17) */
