@@ -377,3 +377,10 @@ int oracle_num_threads(void) {
   return 1;
 #endif
 }
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}

@@ -40,7 +40,23 @@ def lib():
         _lib.fast_tricount_LL_maskL.restype = C.c_int64
         _lib.fast_bfs_levels.restype = C.c_int
         _lib.oracle_num_threads.restype = C.c_int
+        # a container's CPU quota (cgroup v2 cpu.max) can be far below the number of visible CPUs: more OpenMP threads than
+        # the quota pays for get throttled (measured on the GPU box: 256 CPUs visible, quota 16 -> 128 threads run the
+        # scale-22 SpMV at 2 GFLOP/s)
+        if "OMP_NUM_THREADS" not in os.environ:
+            q = cpu_quota()
+            if q and q < _lib.oracle_num_threads():
+                _lib.oracle_set_num_threads(C.c_int(q))
     return _lib
+
+
+def cpu_quota():
+    """CPUs' worth of time the cgroup may use (None if unlimited / unknown)."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else max(1, int(int(quota) / int(period)))
+    except Exception:
+        return None
 
 
 def tcode(t):
