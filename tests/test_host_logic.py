@@ -1,6 +1,7 @@
 """Host-side logic of the backend that needs no GPU: the object model behind the C ABI (build / setElement /
 extract / remove / resize / dup on the host mirror), descriptors, the type registry and promotion table,
 context managers, the R-MAT generator (numpy == torch) and the row-block partitioner."""
+import os
 import numpy as np
 import pytest
 
@@ -130,3 +131,55 @@ def test_balanced_row_blocks(gb):
     b2 = balanced_row_blocks(rmat_expected_row_prefix(12), 8)
     per2 = np.diff(rp.astype(np.int64)[b2]); assert per2.max() < 1.6 * per2.mean()
     assert balanced_row_blocks(rp.astype(np.int64), 1) == [0, 4096]
+
+
+# ---- text readers ---------------------------------------------------------------------------------
+import pygraphblas_amd as gb
+
+# the 7x7 matrix of the reference's doctests (pygraphblas/matrix.py:381-394 from_mm, :415-425 from_tsv): entries 0..11
+_DOC_I = [0, 0, 1, 1, 2, 3, 3, 4, 5, 6, 6, 6]
+_DOC_J = [1, 3, 4, 6, 5, 0, 2, 5, 2, 2, 3, 4]
+_DOC_V = list(range(12))
+
+
+def _doc_lines(sep):
+    return "".join(f"{i + 1}{sep}{j + 1}{sep}{v}\n" for i, j, v in zip(_DOC_I, _DOC_J, _DOC_V))
+
+
+def test_from_mm_matches_reference_doctest(tmp_path):
+    p = tmp_path / "t.mm"
+    p.write_text("%%MatrixMarket matrix coordinate integer general\n%%GraphBLAS GrB_INT64\n7 7 12\n" + _doc_lines(" "))
+    M = gb.Matrix.from_mm(p)
+    assert M.type is gb.INT64 and (M.nrows, M.ncols, M.nvals) == (7, 7, 12)
+    I, J, V = M.to_lists()
+    assert (list(I), list(J), list(V)) == (_DOC_I, _DOC_J, _DOC_V)
+
+
+def test_from_mm_symmetric_pattern_and_real(tmp_path):
+    p = tmp_path / "s.mm"
+    p.write_text("%%MatrixMarket matrix coordinate real symmetric\n% a comment\n3 3 3\n1 1 2.5\n2 1 -1.0\n3 2 4.0\n")
+    M = gb.Matrix.from_mm(p)
+    assert M.type is gb.FP64 and M.nvals == 5
+    I, J, V = M.to_lists()
+    assert sorted(zip(I, J, V)) == [(0, 0, 2.5), (0, 1, -1.0), (1, 0, -1.0), (1, 2, 4.0), (2, 1, 4.0)]
+    q = tmp_path / "p.mm"
+    q.write_text("%%MatrixMarket matrix coordinate pattern general\n2 3 2\n1 3\n2 1\n")
+    P = gb.Matrix.from_mm(q)
+    assert P.type is gb.BOOL and sorted(zip(*P.to_lists())) == [(0, 2, True), (1, 0, True)]
+
+
+def test_from_tsv_matches_reference_doctest(tmp_path):
+    p = tmp_path / "t.tsv"
+    p.write_text(_doc_lines("\t"))
+    M = gb.Matrix.from_tsv(p, gb.INT32, 7, 7)
+    assert M.type is gb.INT32
+    I, J, V = M.to_lists()
+    assert (list(I), list(J), list(V)) == (_DOC_I, _DOC_J, _DOC_V)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/docs/test_mm.mm"), reason="reference checkout not mounted (GPU box)")
+def test_readers_on_the_reference_fixture_files():
+    M = gb.Matrix.from_mm("/root/reference/docs/test_mm.mm")
+    assert M.type is gb.INT64 and [list(x) for x in M.to_lists()] == [_DOC_I, _DOC_J, _DOC_V]
+    T = gb.Matrix.from_tsv("/root/reference/docs/test_tsvfile.tsv", gb.INT32, 7, 7)
+    assert [list(x) for x in T.to_lists()] == [_DOC_I, _DOC_J, _DOC_V]
