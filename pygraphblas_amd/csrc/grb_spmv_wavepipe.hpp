@@ -74,7 +74,7 @@ template <class T> struct WpArgs {
 // LDS once (conflict-free) and every row reads the value at its last entry.  The cost of a task does not depend on how its
 // entries are split into rows (measured before: per-row serial sums spent half of every wave's time in divergent,
 // bank-conflicting LDS reads).
-// The argument block of panel mode is read from memory, so the compiler cannot tell that the pointers in it are global
+// The panel pipeline (grb_spmv_tiles.hpp) reads its argument block from memory, so the compiler cannot tell that the pointers in it are global
 // and would emit FLAT loads — which count on lgkmcnt as well as vmcnt, so every wait for an LDS operation would also
 // drain the loads the pipeline wants to keep in flight.  All HBM traffic of the kernel goes through these helpers.
 #define WP_G __attribute__((address_space(1)))
@@ -152,10 +152,8 @@ template <class T, class SR> __device__ __forceinline__ void wp_seg_scan(T& v, i
 
 template <class T> struct WpStage { uint32_t c[WP_PER]; T v[WP_PER], g[WP_PER]; uint32_t rpa, rpb; };   // what one task has in flight
 
-template <class T, class SR, bool PANEL>
-__global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k_spmv_wavepipe(const WpArgs<T> a0, const WpArgs<T>* __restrict__ panels, const SR sr) {
-  // panel mode (kernel X, grb_spmv_xcd.hpp): workgroup b works on column panel b % 8 — the XCD it is observed to run on
-  const WpArgs<T> a = PANEL ? panels[blockIdx.x & 7] : a0;
+template <class T, class SR>
+__global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k_spmv_wavepipe(const WpArgs<T> a, const SR sr) {
   constexpr int H = wp_hot<T>::H;
   __shared__ T s_hot[H];
   __shared__ __attribute__((aligned(16))) T s_scan[WP_WAVES][WP_ENT];
@@ -163,7 +161,6 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
   if (threadIdx.x == 0) s_next = 0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const bool use_a = sr.uses_a(), use_u = sr.uses_u();
-  const T* const u_ptr = PANEL ? a0.xorig : a.xorig;                     // panel mode: u comes with the launch, the rest of `a` is the plan's
   if (use_u) for (uint32_t h = threadIdx.x; h < a.nhot; h += WP_WAVES * 64) s_hot[h] = wp_ld(a.x + h);      // the table's contents, gathered from u once per call
   __syncthreads();
   T* scan = s_scan[wv];
@@ -178,7 +175,7 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
   // complete one per ~80 ns per address, which made the whole kernel 1.5-2x slower.)  Every chunk id has a carry
   // record; a static range uses the record of its first chunk and leaves the others empty.
   const uint32_t K = a.tasks_per_chunk, nchunks = (K + a.ntasks - 1) / K;
-  const uint32_t nwg = PANEL ? (gridDim.x >> 3) : gridDim.x, jwg = PANEL ? (blockIdx.x >> 3) : blockIdx.x;
+  const uint32_t nwg = gridDim.x, jwg = blockIdx.x;
   // chunk ids [0, dyn0) are static ranges of s0 chunks, dealt to (workgroup, wave) so that every workgroup samples the
   // whole matrix (its parts differ in cost); ids >= dyn0 are dynamic, workgroup j owning those congruent to j
   uint32_t s0 = (uint32_t)((uint64_t)nchunks * a.static_pct / 100 / (nwg * WP_WAVES)); if (s0 > WP_MAX_STATIC) s0 = WP_MAX_STATIC;
@@ -211,12 +208,8 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
 #pragma unroll
     for (int u = 0; u < WP_PER; u++) {
       const uint32_t cc = (uint32_t)(lane * WP_PER + u) < cnt ? (c[u] & WP_COLMASK) : 0u;   // rank of the column if < nwarm (0 = most frequent), else nwarm + column
-      if constexpr (PANEL) {
-        g[u] = use_u ? wp_ld(u_ptr + (cc >= (uint32_t)H ? cc - (uint32_t)H : 0u)) : T();   // column word = H + column; LDS-resident ones read u[0] (cached) and are replaced below
-      } else {
-        const T* xb = cc < a.nwarm ? a.x : a.xorig - a.nwarm;           // warm: rank-ordered copy of the top of u; cold: u itself
-        g[u] = use_u ? wp_ld(xb + (cc >= (uint32_t)H ? cc : 0u)) : T();  // LDS-resident ranks read element 0 (always cached) and are replaced below
-      }
+      const T* xb = cc < a.nwarm ? a.x : a.xorig - a.nwarm;           // warm: rank-ordered copy of the top of u; cold: u itself
+      g[u] = use_u ? wp_ld(xb + (cc >= (uint32_t)H ? cc : 0u)) : T();  // LDS-resident ranks read element 0 (always cached) and are replaced below
     }
   };
   // task descriptors live in registers, one task per lane, 61 tasks + 3 look-ahead at a time: the steady state
@@ -285,7 +278,7 @@ __global__ __launch_bounds__(WP_WAVES * 64, WP_WGS_PER_CU * WP_WAVES / 4) void k
         if (live && qe > qs) { acc = scan[qe - 1]; has = true; }
         else if (rbase == 0 && lane == 0 && carry_has) { acc = carry; has = true; }   // row r0 ended exactly where this task starts
         const bool to_fixup = rbase == 0 && lane == 0 && !owned;      // the row began in another wave's range
-        if (live && !to_fixup) { if (has) wp_st(a.y + r, acc); if constexpr (!PANEL) wp_st(a.ypres + r, (uint8_t)(has ? 1 : 0)); }   // sub-rows are never empty: the merge kernel needs no presence bytes
+        if (live && !to_fixup) { if (has) wp_st(a.y + r, acc); wp_st(a.ypres + r, (uint8_t)(has ? 1 : 0)); }
         if (rbase == 0 && !owned) {
           cr.head_row = r0; cr.head_val = wp_uniform(acc); cr.head_has = (uint8_t)__builtin_amdgcn_readfirstlane((int)has); cr.head_done = 1;
         }
@@ -428,7 +421,7 @@ template <class T> bool run_wavepipe(const SpmvCall& c, const SemiringDesc& d, i
               (T*)c.tval, c.tpres, M.wp_carry.as<WpCarry<T>>(), M.nrows, M.wp_ntasks, (uint32_t)M.nnz, tpw, wp_env("GRB_MI355X_WP_STATIC", WP_STATIC_PCT), M.wp_nhot, M.wp_nwarm};
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;
-    hipLaunchKernelGGL((k_spmv_wavepipe<T, SR, false>), dim3(ncu * WP_WGS_PER_CU), dim3(WP_WAVES * 64), 0, stream(), a, (const WpArgs<T>*)nullptr, sr);
+    hipLaunchKernelGGL((k_spmv_wavepipe<T, SR>), dim3(ncu * WP_WGS_PER_CU), dim3(WP_WAVES * 64), 0, stream(), a, sr);
     hipLaunchKernelGGL((k_spmv_wavepipe_fixup<T, SR>), dim3((nwaves + 255) / 256), dim3(256), 0, stream(), M.wp_carry.as<WpCarry<T>>(), nwaves, (T*)c.tval, c.tpres,
                        (const WpArgs<T>*)nullptr, sr);
     g_last_plan += std::string("k_spmv_wavepipe<") + (sr.is_static ? "static" : "dynamic") + ",hot=" + std::to_string(M.wp_nhot) + "> ";
