@@ -8,11 +8,13 @@
 //   * the plan stores the matrix panel-major: for each panel a CSR over its non-empty *sub-rows* (row fragments), the
 //     column words and the values in that order.  A column word is the slot in the panel's LDS table for the panel's
 //     H most frequent columns, H + column for the others (bit 31: first entry of a sub-row);
-//   * workgroup b (observed to run on XCD b % 8) runs W's wave pipeline on panel b & 7: its LDS table is filled from u
-//     through the panel's hot-column list, every other gather reads u itself and touches only the panel's lines, which
-//     its XCD's L2 keeps — so the aggregate 32 MiB of L2 holds u once and u is never copied or re-ordered per call;
-//   * each sub-row's sum goes to a partial array; a merge kernel adds the <= 8 partials of every row in panel order
-//     (fixed order => reproducible) and writes y.
+//   * a small kernel gathers the contents of the eight LDS tables from u once per call (through the panels' hot-column
+//     lists); workgroup b (observed to run on XCD b % 8) runs the tile pipeline (grb_spmv_tiles.hpp) on panel b & 7:
+//     table for the hot columns, every other gather reads u itself and touches only the panel's lines, which its XCD's L2
+//     keeps — so the aggregate 32 MiB of L2 holds u once and u is never copied or re-ordered per call;
+//   * each sub-row's sum goes to a partial array; a merge kernel (2048 rows per workgroup, the eight contiguous runs of
+//     their partials accumulated panel after panel in LDS) adds the <= 8 partials of every row in a fixed order
+//     (=> reproducible) and writes y.
 // Extra algorithmic cost: one partial (8 B written + read) and one index per sub-row (~7.7 M at R-MAT-22, ~0.2 GB)
 // against ~1.3 GB of avoided line fills.  Placement is used for speed only: any other block->XCD mapping is still correct.
 #pragma once
@@ -25,12 +27,12 @@ constexpr int XP = 8;      // panels = XCDs
 
 struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per matrix and value type
   DevBuf hot_cols;        // u32[8*H]    column held by slot h of panel k's LDS table
-  DevBuf pcol, pval;      // u32[nnz], T[nnz] panel-major entries (local column index, value)
+  DevBuf pcol, pval;      // u32[.], T[.] panel-major entries (column word, value); panel k starts at ebase[k]
   DevBuf rowptr;          // u32[F + XP] per-panel sub-row pointers, relative to the panel's first entry (F_k + 1 each)
   DevBuf tasks;           // u32 per panel: first sub-row of every 256-entry tile, (ntiles_k + 1) each
   DevBuf subrow_row, blockptr;     // u32[F]: row of every sub-row (panel-major, ascending inside a panel); u32[(nblocks+1)*8]: first sub-row of panel k in row block b
   DevBuf subrow_lrow;              // u16[F]: the same row relative to its block of XP_RB rows — what the merge kernel streams (2 bytes per sub-row instead of 4)
-  DevBuf args;            // WpArgs<T>[XP] in HBM (pointers into the per-call buffers are patched every call)
+  DevBuf args;            // WpArgs<T>[XP] in HBM; never changes between calls (u and the output arrive as kernel arguments)
   DevBuf carry;           // WpCarry<T>, one per chunk of tasks, panel after panel
   DevBuf xhot, partial, scratch;   // per-call work buffers kept with the plan so the argument block never changes (xhot: T[8*H], the LDS tables' contents)
   uint64_t eoff[XP + 1], soff[XP + 1], toff[XP + 1];
