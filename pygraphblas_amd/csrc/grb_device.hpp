@@ -171,6 +171,7 @@ void sort_pairs_u64(const uint64_t* kin, uint64_t* kout, const uint32_t* vin, ui
 void vec_epilogue(int code, uint64_t n, void* wval, uint8_t* wpres, const void* tval, const uint8_t* tpres,
                   const uint8_t* allow, int accum, bool replace);
 void reduce_values(int code, uint64_t n, const void* val, const uint8_t* pres, int op, const void* identity, void* result_host);
+void reduce_values_f32_f64(uint64_t n, const void* val_f32, const uint8_t* pres, int op, const void* identity_f64, void* result_host);
 void vec_ewise(int code, uint64_t n, const void* uval, const uint8_t* upres, const void* vval, const uint8_t* vpres, int op,
                bool is_union, void* tval, uint8_t* tpres);
 void vec_apply(int code, uint64_t n, const void* uval, const uint8_t* upres, int mode, int op, const void* scalar, void* tval, uint8_t* tpres);

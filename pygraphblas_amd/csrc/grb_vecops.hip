@@ -155,6 +155,18 @@ template <class T> __global__ void k_reduce(uint64_t n, const T* __restrict__ va
     partial[blockIdx.x] = r;
   }
 }
+// FP32 values reduced in an FP64 monoid (`reduce_float` of an FP32 vector: the convergence test of a PageRank loop): the first
+// level reads the floats and widens on the fly instead of a cast pass over the vector; same fixed two-level tree
+__global__ void k_reduce_f32_f64(uint64_t n, const float* __restrict__ val, const uint8_t* __restrict__ pres, int op, double identity, double* __restrict__ partial) {
+  __shared__ double sh[4];
+  double acc = identity;
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull)
+    if (!pres || pres[i]) acc = apply_binop<double, true, false>(op, acc, (double)val[i]);
+  acc = wave_reduce_op<double>(op, acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) { double r = sh[0]; for (int w = 1; w < 4; w++) r = apply_binop<double, true, false>(op, r, sh[w]); partial[blockIdx.x] = r; }
+}
 // BOOL with LOR / LAND (the `while q.reduce_bool()` of a BFS loop): "is any present value true / false" — one kernel, 16 bytes
 // per lane per step, one atomic per workgroup into the self-cleaning counter slot
 __global__ void k_any_byte(uint64_t n, const uint8_t* __restrict__ val, const uint8_t* __restrict__ pres, uint8_t want, unsigned long long* out) {
@@ -193,6 +205,18 @@ void reduce_values(int code, uint64_t n, const void* val, const uint8_t* pres, i
     GRB_HIP(hipStreamSynchronize(stream()));
     memcpy(result_host, &r, sizeof(T));
   });
+}
+
+void reduce_values_f32_f64(uint64_t n, const void* val_f32, const uint8_t* pres, int op, const void* identity_f64, void* result_host) {
+  double id; memcpy(&id, identity_f64, 8);
+  if (!n) { memcpy(result_host, &id, 8); return; }
+  const int g = grid_for(n, 4);
+  DevBuf part((size_t)g * 8), fin(8);
+  hipLaunchKernelGGL(k_reduce_f32_f64, dim3(g), dim3(256), 0, stream(), n, (const float*)val_f32, pres, op, id, part.as<double>());
+  hipLaunchKernelGGL((k_reduce<double>), dim3(1), dim3(256), 0, stream(), (uint64_t)g, (const double*)part.as<double>(), (const uint8_t*)nullptr, op, id, fin.as<double>());
+  double r; GRB_HIP(hipMemcpyAsync(&r, fin.p, 8, hipMemcpyDeviceToHost, stream()));
+  GRB_HIP(hipStreamSynchronize(stream()));
+  memcpy(result_host, &r, 8);
 }
 
 // ---- element-wise union / intersection of two bitmap vectors ----------------------------------------------------

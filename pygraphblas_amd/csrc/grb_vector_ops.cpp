@@ -24,9 +24,14 @@ static void reduce_common(void* c, int ccode, GrB_BinaryOp accum, GrB_Monoid mon
   if (!check_obj(monoid)) fail(GrB_UNINITIALIZED_OBJECT, "monoid is not initialised");
   check_binop(monoid->op, "monoid");
   const int mc = monoid->op->ztype->code;
-  DevBuf tmp; const void* v = cast_values(mc, vcode, val, n, tmp);
   uint8_t r[16];
-  reduce_values(mc, n, v, pres, monoid->op->opcode, monoid->identity, r);
+  const int mop = monoid->op->opcode;
+  if (mc == T_FP64 && vcode == T_FP32 && (mop == B_PLUS || mop == B_MIN || mop == B_MAX || mop == B_TIMES)) {
+    reduce_values_f32_f64(n, val, pres, mop, monoid->identity, r);          // no cast pass: the first reduction level widens on the fly
+  } else {
+    DevBuf tmp; const void* v = cast_values(mc, vcode, val, n, tmp);
+    reduce_values(mc, n, v, pres, mop, monoid->identity, r);
+  }
   scalar_accum(c, ccode, r, mc, accum);
 }
 
