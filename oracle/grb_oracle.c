@@ -336,6 +336,21 @@ void fast_spmv_plus_second_fp32(uint32_t nrows, const uint32_t* rp, const uint32
     }
   }
 }
+/* the same product with the row sums formed in double and rounded to float once: the "compensated" form SURVEY.md §8c asks FP
+ * comparisons to be made against (the reference's own summation order is unspecified; a sequential float sum over a hub's
+ * 1.6e5 terms is itself off by ~1e-5 relative) */
+void fast_spmv_plus_second_fp32_wide(uint32_t nrows, const uint32_t* rp, const uint32_t* col, const float* x, float* y, uint8_t* ypres) {
+  const int P = omp_get_max_threads() * 8;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int q = 0; q < P; q++) {
+    uint32_t r0, r1; spmv_piece(rp, nrows, q, P, &r0, &r1);
+    for (uint32_t i = r0; i < r1; i++) {
+      double s = 0.0; const uint32_t b = rp[i], e = rp[i + 1];
+      for (uint32_t p = b; p < e; p++) s += (double)x[col[p]];
+      y[i] = (float)s; ypres[i] = e > b;
+    }
+  }
+}
 /* sum over (i,k) in L, of |L(k,:) ∩ L(i,:)|  ==  reduce(L.mxm(L, PLUS_PAIR, mask=L))  (demo/TriangleCentrality.ipynb cell 17) */
 int64_t fast_tricount_LL_maskL(uint32_t n, const uint32_t* rp, const uint32_t* col) {
   int64_t total = 0;

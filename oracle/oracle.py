@@ -168,6 +168,9 @@ def fast_spmv(rowptr, col, val, x, semiring="PLUS_TIMES"):
     elif semiring == "PLUS_SECOND":
         x = _arr(x, np.float32); y = np.zeros(n, np.float32)
         L.fast_spmv_plus_second_fp32(C.c_uint32(n), _p(rowptr), _p(col), _p(x), _p(y), _p(pres))
+    elif semiring == "PLUS_SECOND_WIDE":      # row sums formed in double, rounded to float once
+        x = _arr(x, np.float32); y = np.zeros(n, np.float32)
+        L.fast_spmv_plus_second_fp32_wide(C.c_uint32(n), _p(rowptr), _p(col), _p(x), _p(y), _p(pres))
     else:
         raise ValueError(semiring)
     return y, pres

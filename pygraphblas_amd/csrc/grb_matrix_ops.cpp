@@ -191,13 +191,9 @@ void do_assign_scalar(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, const void
   const DescView dv(desc);
   if (M && (M->nrows != C->nrows || M->ncols != C->ncols)) fail(GrB_DIMENSION_MISMATCH, "assign: mask dimensions");
   if (C->nrows > GRB_DIM_DEVICE_MAX || C->ncols > GRB_DIM_DEVICE_MAX) fail(GrB_INSUFFICIENT_SPACE, "assign: matrix too large for the device layout");
-  std::vector<uint32_t> rows, cols;
-  if (I == GrB_ALL) { rows.resize(C->nrows); for (uint64_t i = 0; i < C->nrows; i++) rows[i] = (uint32_t)i; }
-  else { rows.assign(I, I + ni); }
-  if (J == GrB_ALL) { cols.resize(C->ncols); for (uint64_t j = 0; j < C->ncols; j++) cols[j] = (uint32_t)j; }
-  else { cols.assign(J, J + nj); }
-  for (auto r : rows) if (r >= C->nrows) fail(GrB_INDEX_OUT_OF_BOUNDS, "assign: row index out of bounds");
-  for (auto c : cols) if (c >= C->ncols) fail(GrB_INDEX_OUT_OF_BOUNDS, "assign: column index out of bounds");
+  // (indices are validated as 64-bit values before they are narrowed to the device layout's 32 bits)
+  const std::vector<uint64_t> rows64 = expand_index_list(I, ni, C->nrows, "assign (rows)"), cols64 = expand_index_list(J, nj, C->ncols, "assign (columns)");
+  std::vector<uint32_t> rows(rows64.begin(), rows64.end()), cols(cols64.begin(), cols64.end());
   std::sort(cols.begin(), cols.end()); cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
   std::vector<uint8_t> inrow(C->nrows ? C->nrows : 1, 0); for (auto r : rows) inrow[r] = 1;
   const uint64_t total = 0; (void)total;

@@ -5,6 +5,7 @@
 #include "grb_api.hpp"
 #include "grb_device.hpp"
 #include "grb_semiring.hpp"
+#include <vector>
 
 namespace grb {
 
@@ -21,11 +22,35 @@ inline SemiringDesc make_semiring_desc(GrB_Semiring s, bool swap_mult_args) {
   if (!check_obj(s)) fail(GrB_UNINITIALIZED_OBJECT, "semiring is not initialised");
   check_binop(s->mul, "multiply"); check_binop(s->add->op, "monoid");
   if (s->mul->xtype != s->mul->ztype) not_implemented(std::string("semiring with a comparison multiplier: ") + s->name);
+  if (!semiring_op_supported(s->mul->opcode, s->mul->ztype->code)) not_implemented(std::string("semiring multiplier ") + s->mul->name + " (math-library and bit-index operators run only in apply / eWise)");
+  if (!semiring_op_supported(s->add->op->opcode, s->add->op->ztype->code)) not_implemented(std::string("semiring monoid ") + s->add->op->name);
   SemiringDesc d{};
   d.zcode = s->add->op->ztype->code; d.addop = s->add->op->opcode; d.mulop = s->mul->opcode; d.flip = false;
   if (swap_mult_args) { int m; if (mirror_binop(d.mulop, &m)) d.mulop = m; else d.flip = true; }
   memcpy(d.identity, s->add->identity, 16); memcpy(d.terminal, s->add->terminal, 16); d.has_terminal = s->add->has_terminal;
   return d;
+}
+
+// An index list argument (I, ni) of extract / assign as explicit 64-bit indices, validated against `dim` BEFORE any
+// narrowing: GrB_ALL, an explicit list, or SuiteSparse's GxB_RANGE / GxB_STRIDE / GxB_BACKWARDS encodings of ni
+// (I = {begin, end[, stride]}, `end` inclusive).
+constexpr uint64_t GXB_RANGE = 0x7FFFFFFFFFFFFFFFull, GXB_STRIDE = GXB_RANGE - 1, GXB_BACKWARDS = GXB_RANGE - 2;
+inline std::vector<uint64_t> expand_index_list(const GrB_Index* I, GrB_Index ni, uint64_t dim, const char* what) {
+  std::vector<uint64_t> out;
+  if (I == GrB_ALL) { out.resize(dim); for (uint64_t i = 0; i < dim; i++) out[i] = i; return out; }
+  if (!I) fail(GrB_NULL_POINTER, std::string(what) + ": index list is NULL");
+  auto oob = [&]() { fail(GrB_INDEX_OUT_OF_BOUNDS, std::string(what) + ": index out of bounds"); };
+  if (ni == GXB_RANGE || ni == GXB_STRIDE || ni == GXB_BACKWARDS) {
+    const uint64_t b = I[0], e = I[1], st = ni == GXB_RANGE ? 1 : I[2];
+    if (st == 0) return out;
+    if (ni == GXB_BACKWARDS) { if (b >= dim && b >= e) oob(); for (uint64_t i = b; i + 1 > e; i -= st) { if (i >= dim) oob(); out.push_back(i); if (i < st) break; } }
+    else for (uint64_t i = b; i <= e; i += st) { if (i >= dim) oob(); out.push_back(i); }
+    return out;
+  }
+  if (ni > (1ull << 40)) fail(GrB_INVALID_VALUE, std::string(what) + ": index count is not plausible");
+  out.assign(I, I + ni);
+  for (uint64_t v : out) if (v >= dim) oob();
+  return out;
 }
 
 // values of a device array in another type: returns `src` itself when no cast is needed, else fills `tmp`

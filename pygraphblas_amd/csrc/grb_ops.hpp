@@ -199,8 +199,9 @@ template <class T, bool FULL = true, bool MATH = FULL> GRB_HD T apply_binop(int 
       case B_LXOR: return (T)((x != 0) != (y != 0));
       default: break;
     }
-    if constexpr (!FULL) return (T)0;   // semiring kernels: multipliers are FIRST..LXOR only
-    else if constexpr (std::is_integral<T>::value) {
+    // semiring kernels (FULL = false): FIRST..LXOR plus the integer bitwise operators; everything else is refused by
+    // make_semiring_desc before a kernel is chosen (semiring_op_supported below)
+    if constexpr (std::is_integral<T>::value) {
       typedef typename std::make_unsigned<T>::type U;
       constexpr int bits = (int)sizeof(T) * 8;
       switch (op) {
@@ -208,6 +209,10 @@ template <class T, bool FULL = true, bool MATH = FULL> GRB_HD T apply_binop(int 
         case B_BAND: return (T)((U)x & (U)y);
         case B_BXOR: return (T)((U)x ^ (U)y);
         case B_BXNOR: return (T)~((U)x ^ (U)y);
+        default: break;
+      }
+      if constexpr (!FULL) return (T)0;
+      else switch (op) {
         case B_BGET: { int64_t k = (int64_t)y; return (k >= 1 && k <= bits) ? (T)(((U)x >> (k - 1)) & 1) : (T)0; }
         case B_BSET: { int64_t k = (int64_t)y; return (k >= 1 && k <= bits) ? (T)((U)x | ((U)1 << (k - 1))) : x; }
         case B_BCLR: { int64_t k = (int64_t)y; return (k >= 1 && k <= bits) ? (T)((U)x & ~((U)1 << (k - 1))) : x; }
@@ -228,6 +233,12 @@ template <class T, bool FULL = true, bool MATH = FULL> GRB_HD T apply_binop(int 
   }
 }
 
+// can the semiring kernels (apply_binop<T, false>) evaluate this operator on values of type `code`?
+GRB_HD bool semiring_op_supported(int op, int code) {
+  if (op <= B_LXOR) return op != B_POW || code == T_BOOL;
+  if (op >= B_BOR && op <= B_BXNOR) return code >= T_INT8 && code <= T_UINT64;
+  return code == T_BOOL && (op <= B_LXNOR);
+}
 GRB_HD bool binop_is_compare(int op) { return op >= B_EQ && op <= B_LE; }
 GRB_HD bool binop_needs_math(int op) { return op == B_POW || (op >= B_ATAN2 && op <= B_LDEXP); }
 GRB_HD bool binop_is_positional(int op) { return op >= B_FIRSTI && op <= B_SECONDJ1; }

@@ -21,6 +21,7 @@
 #include "grb_atomics.hpp"
 #include "grb_matops.hpp"
 #include "grb_spgemm_kernels_fwd.hpp"
+#include <algorithm>
 
 namespace grb {
 
@@ -342,7 +343,19 @@ template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDes
     if (hc[4]) hipLaunchKernelGGL((k_fill_words<W>), dim3(4096), dim3(256), 0, stream(), cacc.as<W>(), mnz, to_word<T>(sr.identity));
     // the bins write disjoint accumulator slots and each is dominated by a few heavy rows: run them concurrently on
     // auxiliary streams (forked from / joined back into the library stream with events) so their tails overlap
+    // everything that can throw (allocation of the position maps of the HBM-map bin) happens before the fork; between fork and
+    // join only kernel launches are issued, and the guard joins the side streams again if anything unwinds past it — the
+    // accumulators return to the pool only after every bin kernel has been ordered before the library stream
+    DevBuf maps; unsigned nb_map = 0;
+    if (hc[4]) {
+      const uint64_t per_map = (uint64_t)B.ncols * 4, budget = 4ull << 30;          // position maps: at most 4 GiB in all
+      uint64_t fit = per_map ? budget / per_map : 256; if (fit < 1) fit = 1;
+      nb_map = (unsigned)std::min<uint64_t>(std::min<uint64_t>(hc[4], 256), fit);
+      maps.alloc((size_t)nb_map * per_map);
+      GRB_HIP(hipMemsetAsync(maps.p, 0, (size_t)nb_map * per_map, stream()));
+    }
     AuxStreams& ax = aux_streams();
+    struct ForkGuard { AuxStreams& a; bool joined = false; ~ForkGuard() { if (!joined) { try { a.join(stream()); } catch (...) {} (void)hipStreamSynchronize(stream()); } } } guard{ax};
     ax.fork(stream());
     const bool serial = getenv("GRB_MI355X_SPGEMM_SERIAL") != nullptr;      // experiment hook: run the bins one after the other
     hipStream_t bs[4]; for (int q = 0; q < 4; q++) bs[q] = serial ? stream() : ax.s[q];
@@ -350,14 +363,9 @@ template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDes
     if (hc[1]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 512, 256, 256>), dim3(nblocks(hc[1], 1)), dim3(256), 0, bs[1], a, L + (size_t)nrows, hc[1], sr);
     if (hc[2]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 2048, 512, 512>), dim3(nblocks(hc[2], 1)), dim3(512), 0, bs[2], a, L + (size_t)2 * nrows, hc[2], sr);
     if (hc[3]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 8192, 1024, 1024>), dim3(nblocks(hc[3], 1)), dim3(1024), 0, bs[3], a, L + (size_t)3 * nrows, hc[3], sr);
-    if (hc[4]) {
-      const unsigned nb = hc[4] < 256 ? hc[4] : 256;
-      DevBuf maps((size_t)nb * B.ncols * 4);
-      GRB_HIP(hipMemsetAsync(maps.p, 0, (size_t)nb * B.ncols * 4, stream()));
-      hipLaunchKernelGGL((k_spgemm_masked_map<T, SR>), dim3(nb), dim3(1024), 0, stream(), a, L + (size_t)4 * nrows, hc[4], maps.as<uint32_t>(), B.ncols, sr);
-      ax.join(stream());
-      GRB_HIP(hipStreamSynchronize(stream()));
-    } else ax.join(stream());
+    if (hc[4]) hipLaunchKernelGGL((k_spgemm_masked_map<T, SR>), dim3(nb_map), dim3(1024), 0, stream(), a, L + (size_t)4 * nrows, hc[4], maps.as<uint32_t>(), B.ncols, sr);
+    ax.join(stream()); guard.joined = true;
+    if (hc[4]) GRB_HIP(hipStreamSynchronize(stream()));       // the maps go back to the pool when this scope ends
     g_last_plan += std::string("k_spgemm_masked<") + (sr.is_static ? "static" : "dynamic") + "> bins " + std::to_string(hc[0]) + "/" + std::to_string(hc[1]) + "/" +
                    std::to_string(hc[2]) + "/" + std::to_string(hc[3]) + "/" + std::to_string(hc[4]) + " ";
   });

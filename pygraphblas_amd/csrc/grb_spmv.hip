@@ -24,6 +24,8 @@
 
 namespace grb {
 
+float g_xcd_plan_build_ms = 0;
+
 // per-type kernel instantiations live in grb_spmv_inst.hip (compiled once per value type, in parallel)
 template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d);
 template <class T> void run_push(const SpmvCall& c, const SemiringDesc& d, const uint32_t* fidx, uint64_t u_nvals, uint32_t* longlist);
@@ -58,8 +60,9 @@ void spmv_build_plan(DevCSR& M) {
   M.plan_nblocks = (uint32_t)blocks.size(); M.plan_nlong = nslots;
   M.plan_blocks.alloc(blocks.size() * sizeof(SpmvBlock) + 16);
   GRB_HIP(hipMemcpyAsync(M.plan_blocks.p, blocks.data(), blocks.size() * sizeof(SpmvBlock), hipMemcpyHostToDevice, stream()));
-  // aux: [tickets u32[nblocks]] [partials 8 B * nslots] [partial flags u8 * nslots]  (tickets indexed by `slot`)
-  const size_t aux = (size_t)(nslots + 1) * 4 + (size_t)(nslots + 1) * 8 + (size_t)(nslots + 1);
+  // aux: [partials 8 B * nslots] [tickets u32 * nslots] [partial flags u8 * nslots]  (tickets indexed by `slot`; the 8-byte
+  // partials come first so that they are 8-byte aligned whatever nslots is)
+  const size_t aux = (size_t)(nslots + 1) * 8 + (size_t)(nslots + 1) * 4 + (size_t)(nslots + 1);
   M.plan_aux.alloc(aux);
   GRB_HIP(hipMemsetAsync(M.plan_aux.p, 0, aux, stream()));
   GRB_HIP(hipStreamSynchronize(stream()));
@@ -101,3 +104,39 @@ void spmspv_push(const SpmvCall& c, const SemiringDesc& d, uint64_t u_nvals) {
 }
 
 }  // namespace grb
+
+// ---- how a full-chip launch maps workgroups to XCDs ------------------------------------------------------------------------
+// Kernel X gives workgroup b the column panel b % 8 and is fast when that workgroup runs on XCD b % 8 (every XCD's L2 then
+// holds one eighth of the operand).  The round-robin dispatch is observed, not documented, and other partition modes deal
+// differently — so it is probed once (XCC_ID of every workgroup of a one-workgroup-per-CU launch) and reported with the plan.
+namespace grb {
+static __global__ __launch_bounds__(1024) void k_xcc_probe(uint32_t* __restrict__ out) {
+  uint32_t x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  if (threadIdx.x == 0) out[blockIdx.x] = x & 0xFu;
+}
+const std::string& xcd_mapping() {
+  static std::string res;
+  if (!res.empty() || !device_ok()) return res;
+  const int ncu = device_cus();
+  if (ncu <= 0) { res = "unknown"; return res; }
+  DevBuf d((size_t)ncu * 4);
+  hipLaunchKernelGGL(k_xcc_probe, dim3(ncu), dim3(1024), 0, stream(), d.as<uint32_t>());
+  std::vector<uint32_t> h(ncu);
+  if (hipMemcpyAsync(h.data(), d.p, (size_t)ncu * 4, hipMemcpyDeviceToHost, stream()) != hipSuccess || hipStreamSynchronize(stream()) != hipSuccess) { (void)hipGetLastError(); res = "unknown"; return res; }
+  int match = 0; uint32_t seen = 0;
+  for (int b = 0; b < ncu; b++) { match += (h[b] == (uint32_t)(b & 7)); seen |= 1u << h[b]; }
+  const int nx = __builtin_popcount(seen);
+  if (match == ncu) res = "roundrobin8";
+  else res = "xcds=" + std::to_string(nx) + ",workgroups_on_xcd_b%8=" + std::to_string(match) + "/" + std::to_string(ncu);
+  return res;
+}
+}  // namespace grb
+
+extern "C" GrB_Info GrBX_last_plan_build_ms(float* ms) { if (!ms) return GrB_NULL_POINTER; *ms = grb::g_xcd_plan_build_ms; return GrB_SUCCESS; }
+extern "C" GrB_Info GrBX_xcd_mapping(char* buf, int len) {
+  if (!buf || len <= 0) return GrB_NULL_POINTER;
+  if (!grb::device_ok()) { snprintf(buf, len, "no device"); return GrB_NO_VALUE; }
+  try { snprintf(buf, len, "%s", grb::xcd_mapping().c_str()); } catch (...) { snprintf(buf, len, "unknown"); }
+  return GrB_SUCCESS;
+}

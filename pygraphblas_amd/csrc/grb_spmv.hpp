@@ -27,6 +27,7 @@ struct SpmvCall {
   int method = SPMV_AUTO;
 };
 
+const std::string& xcd_mapping();   // "roundrobin8" when workgroup b of a full-chip launch runs on XCD b % 8 (probed once)
 void spmv_build_plan(DevCSR& M);
 void spmv_pull(const SpmvCall& c, const SemiringDesc& d);
 bool spmspv_push_supported(const SemiringDesc& d);

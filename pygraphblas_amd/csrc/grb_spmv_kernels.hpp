@@ -378,7 +378,7 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
     a.blocks = M.plan_blocks.as<SpmvBlock>();
     uint8_t* aux = M.plan_aux.as<uint8_t>();
     const size_t ns = (size_t)M.plan_nlong + 1;
-    a.tickets = (uint32_t*)aux; a.partial = (T*)(aux + ns * 4); a.pflag = aux + ns * 4 + ns * 8;
+    a.partial = (T*)aux; a.tickets = (uint32_t*)(aux + ns * 8); a.pflag = aux + ns * 8 + ns * 4;
     if (M.plan_nblocks == 0) return;
     const dim3 grid(M.plan_nblocks), block(SPMV_THREADS);
     if constexpr (std::is_same<T, double>::value && SR::is_static) {

@@ -5,41 +5,78 @@
 // L2s cache eight copies of the same hot 4 MiB.  Kernel X gives each XCD its own eighth of u:
 //   * u is cut into 128-byte lines; every line (16 FP64 columns) belongs to one panel.  Lines are dealt to the panels so
 //     that the panels hold the same number of entries (heaviest lines first to the lightest panel, then in snake order);
-//   * the plan stores the matrix panel-major: for each panel a CSR over its non-empty *sub-rows* (row fragments), the
-//     column words and the values in that order.  A column word is the slot in the panel's LDS table for the panel's
-//     H most frequent columns, H + column for the others (bit 31: first entry of a sub-row);
+//   * the plan stores the matrix panel-major: for each panel the column words and the values of its entries in row-major
+//     order, cut into tiles of 256 entries.  A column word is the slot in the panel's LDS table for the panel's H most
+//     frequent columns, H + column for the others; bit 31 marks the first entry of a *sub-row* (the entries of one row
+//     in one panel; a sub-row also ends at every chunk boundary, so no sub-row spans two chunks of tiles);
 //   * a small kernel gathers the contents of the eight LDS tables from u once per call (through the panels' hot-column
 //     lists); workgroup b (observed to run on XCD b % 8) runs the tile pipeline (grb_spmv_tiles.hpp) on panel b & 7:
 //     table for the hot columns, every other gather reads u itself and touches only the panel's lines, which its XCD's L2
 //     keeps — so the aggregate 32 MiB of L2 holds u once and u is never copied or re-ordered per call;
 //   * each sub-row's sum goes to a partial array; a merge kernel (2048 rows per workgroup, the eight contiguous runs of
-//     their partials accumulated panel after panel in LDS) adds the <= 8 partials of every row in a fixed order
+//     their partials accumulated panel after panel in LDS) adds the partials of every row in a fixed order
 //     (=> reproducible) and writes y.
-// Extra algorithmic cost: one partial (8 B written + read) and one index per sub-row (~7.7 M at R-MAT-22, ~0.2 GB)
+// Extra algorithmic cost: one partial (8 B written + read) and one 16-bit row id per sub-row (~7.8 M at R-MAT-22)
 // against ~1.3 GB of avoided line fills.  Placement is used for speed only: any other block->XCD mapping is still correct.
+//
+// The plan (round 2) is built in a handful of passes over the entries, with no full-size sort and two host round trips
+// (sizes for the allocations): column counts (LDS-aggregated atomics), the line deal and the per-panel column ranking
+// (sorts of `nlines` and `ncols` 32-bit keys), then two sweeps over units of 16384 entries in row-major order — a
+// counting sweep (entries per unit and panel) and, after a scan, a scattering sweep that writes every entry to its
+// place in its panel (wave ballots rank the entries of a panel inside a step; the order inside a panel stays row-major,
+// so the plan is a deterministic function of the matrix) — and two passes over the tiles that number the sub-rows.
 #pragma once
 #include "grb_spmv_tiles.hpp"
 #include "grb_matops.hpp"
 
 namespace grb {
 
-constexpr int XP = 8;      // panels = XCDs
+constexpr int XP = 8;                 // panels = XCDs
+constexpr uint32_t XP_RB = 2048;      // rows per workgroup of the merge kernel
+constexpr uint32_t XP_UNIT = 16384;   // entries per unit of the plan-building sweeps
+constexpr int XP_ST = 512;            // threads of a sweep workgroup
+constexpr int XP_SW = XP_ST / 64;     // its waves
 
 struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per matrix and value type
-  DevBuf hot_cols;        // u32[8*H]    column held by slot h of panel k's LDS table
-  DevBuf pcol, pval;      // u32[.], T[.] panel-major entries (column word, value); panel k starts at ebase[k]
-  DevBuf rowptr;          // u32[F + XP] per-panel sub-row pointers, relative to the panel's first entry (F_k + 1 each)
-  DevBuf tasks;           // u32 per panel: first sub-row of every 256-entry tile, (ntiles_k + 1) each
-  DevBuf subrow_row, blockptr;     // u32[F]: row of every sub-row (panel-major, ascending inside a panel); u32[(nblocks+1)*8]: first sub-row of panel k in row block b
-  DevBuf subrow_lrow;              // u16[F]: the same row relative to its block of XP_RB rows — what the merge kernel streams (2 bytes per sub-row instead of 4)
-  DevBuf args;            // WpArgs<T>[XP] in HBM; never changes between calls (u and the output arrive as kernel arguments)
-  DevBuf carry;           // WpCarry<T>, one per chunk of tasks, panel after panel
-  DevBuf xhot, partial, scratch;   // per-call work buffers kept with the plan so the argument block never changes (xhot: T[8*H], the LDS tables' contents)
-  uint64_t eoff[XP + 1], soff[XP + 1], toff[XP + 1];
-  uint64_t ebase[XP + 1];   // where a panel's entries are stored (eoff padded to 64-entry boundaries: aligned 16-byte loads)
-  uint32_t ntasks[XP]; uint32_t maxchunks = 1; uint32_t nhot[XP]; uint64_t F = 0; int tsize = 0;
+  DevBuf hot_cols;        // u32[XP*H]   column held by slot h of panel k's LDS table
+  DevBuf pcol, pval;      // u32[.], T[.] panel-major entries (column word, value); panel k starts at tile tbase[k]
+  DevBuf trow;            // u32[tiles]  sub-row (numbered over all panels, panel after panel) of every tile's first entry
+  DevBuf lrow;            // u16[F]      row of every sub-row relative to its block of XP_RB rows — what the merge kernel streams
+  DevBuf blockptr;        // u32[(nblocks+1)*XP] first sub-row of panel k in row block b
+  DevBuf args;            // XtPanel<T>[XP] in HBM; never changes between calls (u and the partial array arrive as kernel arguments)
+  DevBuf xhot, partial;   // per-call work buffers kept with the plan (xhot: T[XP*H], the LDS tables' contents)
+  uint64_t ne[XP]; uint32_t tbase[XP + 1]; uint32_t ntiles[XP], nhot[XP];
+  uint64_t F = 0; int tsize = 0; bool has_vals = false; float build_ms = 0;
 };
+extern float g_xcd_plan_build_ms;     // duration of the most recent plan build (grb_spmv.hip; read by GrBX_last_plan_build_ms)
 
+// ---- plan pieces ----------------------------------------------------------------------------------------------------------
+// column counts.  A hub column of R-MAT-22 occurs 1.6e5 times, and atomics on one address complete one per ~80 ns: counting
+// straight into HBM took 13 ms.  Every workgroup aggregates its slice in an LDS table first (the hot columns claim their
+// slots early) and only columns that find no slot go to HBM directly.
+static __global__ __launch_bounds__(1024) void k_xp_col_hist(const uint32_t* __restrict__ col, uint64_t nnz, uint32_t* __restrict__ cnt) {
+  constexpr uint32_t S = 8192;
+  __shared__ uint32_t key[S], val[S];
+  for (uint32_t i = threadIdx.x; i < S; i += 1024) { key[i] = 0xFFFFFFFFu; val[i] = 0; }
+  __syncthreads();
+  const uint64_t per = (nnz + gridDim.x - 1) / gridDim.x, b = blockIdx.x * per, e = b + per < nnz ? b + per : nnz;
+  for (uint64_t p = b + threadIdx.x; p < e; p += 1024) {
+    const uint32_t c = col[p]; uint32_t h = (c * 2654435761u) >> 19;
+    bool done = false;
+#pragma unroll
+    for (int probe = 0; probe < 2; probe++) {
+      if (!done) {
+        uint32_t k = key[h];
+        if (k == 0xFFFFFFFFu) k = atomicCAS(&key[h], 0xFFFFFFFFu, c) == 0xFFFFFFFFu ? c : key[h];
+        if (k == c) { atomicAdd(&val[h], 1u); done = true; }
+        h = (h + 1) & (S - 1);
+      }
+    }
+    if (!done) atomicAdd(&cnt[c], 1u);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < S; i += 1024) if (val[i]) atomicAdd(&cnt[key[i]], val[i]);
+}
 // weight of a line of u = entries in its columns
 static __global__ void k_xp_line_weights(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t line, uint32_t nlines, uint32_t* __restrict__ negw, uint32_t* __restrict__ id) {
   for (uint32_t l = blockIdx.x * 256 + threadIdx.x; l < nlines; l += gridDim.x * 256) {
@@ -47,7 +84,26 @@ static __global__ void k_xp_line_weights(const uint32_t* __restrict__ cnt, uint3
     negw[l] = 0xFFFFFFFFu - (uint32_t)(w > 0xFFFFFFFEull ? 0xFFFFFFFEull : w); id[l] = l;
   }
 }
-// lines in descending weight: the first `ntop` take the panel the host balanced for them, the others are dealt in snake order
+// the heavy head of the weight distribution (<= 4096 lines, heaviest first) is balanced exactly: each line to the panel with
+// the least load so far (LPT).  One workgroup; the loop itself is serial.
+static __global__ __launch_bounds__(256) void k_xp_lpt(const uint32_t* __restrict__ negw_sorted, uint32_t ntop, uint8_t* __restrict__ top_panel) {
+  __shared__ uint32_t w[4096];
+  for (uint32_t i = threadIdx.x; i < ntop; i += 256) w[i] = 0xFFFFFFFFu - negw_sorted[i];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long load[XP];
+    for (int k = 0; k < XP; k++) load[k] = 0;
+    for (uint32_t i = 0; i < ntop; i++) {
+      int best = 0;
+#pragma unroll
+      for (int k = 1; k < XP; k++) if (load[k] < load[best]) best = k;
+#pragma unroll
+      for (int k = 0; k < XP; k++) if (k == best) load[k] += w[i];
+      top_panel[i] = (uint8_t)best;
+    }
+  }
+}
+// lines in descending weight: the first `ntop` take the panel the LPT chose for them, the others are dealt in snake order
 static __global__ void k_xp_deal_lines(const uint32_t* __restrict__ sorted_line, uint32_t nlines, const uint8_t* __restrict__ top_panel, uint32_t ntop, uint8_t* __restrict__ panel_of_line) {
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nlines; i += gridDim.x * 256) {
     uint32_t k;
@@ -55,71 +111,155 @@ static __global__ void k_xp_deal_lines(const uint32_t* __restrict__ sorted_line,
     panel_of_line[sorted_line[i]] = (uint8_t)k;
   }
 }
-// key = panel | descending count | column: a panel's columns in frequency order (ties by index)
-static __global__ void k_xp_column_keys(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t line, const uint8_t* __restrict__ panel_of_line, unsigned long long* __restrict__ key, uint32_t* __restrict__ colv) {
+// key = panel | descending count (clamped to 20 bits: ties among the rarest and among the very hottest columns do not matter),
+// stable sort => a panel's columns in frequency order, ties by index
+static __global__ void k_xp_column_keys(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t line, const uint8_t* __restrict__ panel_of_line, uint32_t* __restrict__ key, uint32_t* __restrict__ colv) {
   for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) {
-    key[c] = ((unsigned long long)panel_of_line[c / line] << 60) | ((unsigned long long)(0xFFFFFFFFu - cnt[c]) << 28) | c;
+    const uint32_t w = cnt[c] < 0xFFFFFu ? cnt[c] : 0xFFFFFu;
+    key[c] = ((uint32_t)panel_of_line[c / line] << 20) | (0xFFFFFu - w);
     colv[c] = c;
   }
 }
-static __global__ void k_xp_panel_starts(const unsigned long long* __restrict__ key, uint32_t n, uint32_t* __restrict__ start) {
+static __global__ void k_xp_panel_starts(const uint32_t* __restrict__ key, uint32_t n, uint32_t* __restrict__ start) {
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const uint32_t k = (uint32_t)(key[i] >> 60);
-    if (i == 0 || (uint32_t)(key[i - 1] >> 60) != k) start[k] = i;
+    const uint32_t k = key[i] >> 20;
+    if (i == 0 || (key[i - 1] >> 20) != k) start[k] = i;
   }
 }
+static __global__ void k_xp_fix_starts(uint32_t* __restrict__ start, uint32_t n) {      // a panel without columns starts where the next one does
+  if (blockIdx.x == 0 && threadIdx.x == 0) { start[XP] = n; for (int k = XP - 1; k >= 0; k--) if (start[k] == 0xFFFFFFFFu) start[k] = start[k + 1]; }
+}
 // code word of a column: (slot or H + column) << 3 | panel; the panel's hot-column list
-static __global__ void k_xp_column_codes(const unsigned long long* __restrict__ key, const uint32_t* __restrict__ cols, uint32_t n, uint32_t H, uint32_t s0, uint32_t s1, uint32_t s2,
-                                         uint32_t s3, uint32_t s4, uint32_t s5, uint32_t s6, uint32_t s7, uint32_t* __restrict__ code, uint32_t* __restrict__ hot_cols) {
-  const uint32_t st[XP] = {s0, s1, s2, s3, s4, s5, s6, s7};
+static __global__ void k_xp_column_codes(const uint32_t* __restrict__ key, const uint32_t* __restrict__ cols, uint32_t n, uint32_t H, const uint32_t* __restrict__ start,
+                                         uint32_t* __restrict__ code, uint32_t* __restrict__ hot_cols) {
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const uint32_t k = (uint32_t)(key[i] >> 60), c = cols[i], local = i - st[k];
+    const uint32_t k = key[i] >> 20, c = cols[i], local = i - start[k];
     code[c] = ((local < H ? local : H + c) << 3) | k;
     if (local < H) hot_cols[(size_t)k * H + local] = c;
   }
 }
-static __global__ void k_xp_panel_keys(const uint32_t* __restrict__ col, uint64_t nnz, const uint32_t* __restrict__ rank, uint32_t* __restrict__ key, uint32_t* __restrict__ idx) {
-  for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < nnz; p += gridDim.x * 256ull) { key[p] = rank[col[p]] & 7u; idx[p] = (uint32_t)p; }
+// row of every entry: the non-empty rows mark their first entry, an inclusive max-scan fills the rest
+static __global__ void k_xp_mark_rows(const uint32_t* __restrict__ rowptr, uint32_t nrows, uint32_t* __restrict__ rowidx) {
+  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < nrows; r += gridDim.x * 256) { const uint32_t s = rowptr[r]; if (rowptr[r + 1] > s) rowidx[s] = r; }
 }
-static __global__ void k_xp_hist8(const uint32_t* __restrict__ key, uint64_t nnz, unsigned long long* __restrict__ cnt) {
-  __shared__ unsigned int s[XP];
-  if (threadIdx.x < XP) s[threadIdx.x] = 0;
+
+// The two sweeps over the entries in row-major order, one workgroup per unit of XP_UNIT entries, XP_ST entries per step.
+// In a step every wave ballots its lanes panel by panel: the rank of an entry among the entries of its panel in the unit
+// follows from the ballots, the counts of the waves before it and the running count of the unit; the row of the entry
+// that precedes it in its panel (same wave: a shuffle; earlier: the waves' last rows of the step, then the running
+// last row) tells whether it starts a sub-row.
+//   SCATTER = false: entries per (panel, unit) -> ne, and the row of the unit's last entry per panel -> lastkey
+//                    (index + 1 in the high word, so that an exclusive max-scan finds the nearest earlier unit that has one)
+//   SCATTER = true : every entry goes to its place in its panel; bit 31 of the column word = first entry of a sub-row
+//                    (the row changes, or a chunk of tiles begins); the rows of those entries go to rowtmp.
+template <class T> struct XpSweep {
+  const uint32_t* col; const uint32_t* rowidx; const uint32_t* code; const T* val; uint64_t nnz; uint32_t nunits;
+  uint32_t* ne; unsigned long long* lastkey;
+  const uint32_t* escan; const unsigned long long* carry; uint64_t ebase[XP]; uint32_t chunk_entries[XP];
+  uint32_t* pcol; T* pval; uint32_t* rowtmp;
+};
+template <class T, bool SCATTER>
+__global__ __launch_bounds__(XP_ST) void k_xp_sweep(const XpSweep<T> a) {
+  __shared__ uint32_t s_cnt[XP_SW][XP], s_last[XP_SW][XP], s_cursor[XP], s_carry[XP];
+  const uint32_t u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid < XP) {
+    s_cursor[tid] = 0; uint32_t cr = WP_NONE;
+    if constexpr (SCATTER) {
+      const unsigned long long key = a.carry[(size_t)tid * a.nunits + u];
+      if (key != 0 && (key >> 32) - 1 >= (unsigned long long)tid * a.nunits) cr = (uint32_t)key;       // the last entry of this panel before the unit
+    }
+    s_carry[tid] = cr;
+  }
   __syncthreads();
-  for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < nnz; p += gridDim.x * 256ull) atomicAdd(&s[key[p]], 1u);
-  __syncthreads();
-  if (threadIdx.x < XP && s[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], (unsigned long long)s[threadIdx.x]);
-}
-template <class T> __global__ void k_xp_gather_entries(const uint32_t* __restrict__ perm, uint64_t nnz, const uint32_t* __restrict__ col, const T* __restrict__ val,
-                                                       const uint32_t* __restrict__ rank, const uint32_t* __restrict__ rowidx,
-                                                       uint32_t* __restrict__ pcol, T* __restrict__ pval, uint32_t* __restrict__ prow,
-                                                       uint64_t e1, uint64_t e2, uint64_t e3, uint64_t e4, uint64_t e5, uint64_t e6, uint64_t e7) {
-  for (uint64_t q = blockIdx.x * 256ull + threadIdx.x; q < nnz; q += gridDim.x * 256ull) {
-    const uint32_t p = perm[q];
-    // panel k is stored from eoff[k] rounded up to a multiple of 64 entries: every panel adds < 64 entries of padding
-    uint64_t d = q;
-    if (q >= e1) d = q - e1 + ((e1 + 63) & ~63ull);
-    const uint64_t b1 = (e1 + 63) & ~63ull, b2 = (b1 + (e2 - e1) + 63) & ~63ull, b3 = (b2 + (e3 - e2) + 63) & ~63ull, b4 = (b3 + (e4 - e3) + 63) & ~63ull,
-                   b5 = (b4 + (e5 - e4) + 63) & ~63ull, b6 = (b5 + (e6 - e5) + 63) & ~63ull, b7 = (b6 + (e7 - e6) + 63) & ~63ull;
-    if (q >= e7) d = q - e7 + b7; else if (q >= e6) d = q - e6 + b6; else if (q >= e5) d = q - e5 + b5; else if (q >= e4) d = q - e4 + b4;
-    else if (q >= e3) d = q - e3 + b3; else if (q >= e2) d = q - e2 + b2; else if (q >= e1) d = q - e1 + b1;
-    pcol[d] = rank[col[p]] >> 3; pval[d] = val[p]; prow[q] = rowidx[p];
+  const uint64_t base = (uint64_t)u * XP_UNIT, end = base + XP_UNIT < a.nnz ? base + XP_UNIT : a.nnz;
+  for (uint64_t sb = base; sb < end; sb += XP_ST) {
+    const uint64_t p = sb + tid; const bool valid = p < end;
+    const uint32_t c = valid ? a.col[p] : 0u, code = valid ? a.code[c] : 0u, r = valid ? a.rowidx[p] : 0u;
+    const uint32_t k = valid ? (code & 7u) : 8u;
+    uint32_t myrank = 0; int plane = (int)lane; bool has_prev = false;
+#pragma unroll
+    for (uint32_t kk = 0; kk < XP; kk++) {
+      const unsigned long long m = __ballot(k == kk);
+      if (lane == 0) { s_cnt[w][kk] = (uint32_t)__popcll(m); }
+      const int top = m ? 63 - __builtin_clzll(m) : 0;
+      const uint32_t lastr = (uint32_t)__builtin_amdgcn_readlane((int)r, top);
+      if (lane == 0) s_last[w][kk] = m ? lastr : WP_NONE;
+      if (k == kk) {
+        const unsigned long long below = m & ((1ull << lane) - 1ull);
+        myrank = (uint32_t)__popcll(below);
+        if (below) { plane = 63 - __builtin_clzll(below); has_prev = true; }
+      }
+    }
+    const uint32_t prevrow = (uint32_t)__shfl((int)r, plane, 64);
+    __syncthreads();
+    if (valid) {
+      uint32_t off = s_cursor[k], prow = has_prev ? prevrow : s_carry[k];
+      for (uint32_t w2 = 0; w2 < w; w2++) { off += s_cnt[w2][k]; if (!has_prev && s_last[w2][k] != WP_NONE) prow = s_last[w2][k]; }
+      if constexpr (SCATTER) {
+        const uint32_t rel = (a.escan[(size_t)k * a.nunits + u] - a.escan[(size_t)k * a.nunits]) + off + myrank;     // position in the panel
+        const bool flag = prow != r || rel % a.chunk_entries[k] == 0;       // (prow == WP_NONE is never a row)
+        const uint64_t dest = a.ebase[k] + rel;
+        a.pcol[dest] = (code >> 3) | (flag ? WP_ROWSTART : 0u);
+        if (a.pval) a.pval[dest] = a.val[p];
+        if (flag) a.rowtmp[dest] = r;
+      }
+    }
+    __syncthreads();
+    if (tid < XP) {
+      uint32_t add = 0, cr = s_carry[tid];
+      for (int w2 = 0; w2 < XP_SW; w2++) { add += s_cnt[w2][tid]; if (s_last[w2][tid] != WP_NONE) cr = s_last[w2][tid]; }
+      s_cursor[tid] += add; s_carry[tid] = cr;
+    }
+    __syncthreads();
+  }
+  if constexpr (!SCATTER) {
+    if (tid < XP) {
+      a.ne[(size_t)tid * a.nunits + u] = s_cursor[tid];
+      a.lastkey[(size_t)tid * a.nunits + u] = s_carry[tid] != WP_NONE ? (((unsigned long long)tid * a.nunits + u + 1) << 32) | s_carry[tid] : 0ull;
+    }
   }
 }
-// head[q] = 1 where a new sub-row starts (first entry of a panel, or the row changes)
-static __global__ void k_xp_heads(const uint32_t* __restrict__ prow, uint64_t nnz, uint64_t e0, uint64_t e1, uint64_t e2, uint64_t e3, uint64_t e4, uint64_t e5, uint64_t e6, uint64_t e7,
-                                  uint32_t* __restrict__ head) {
-  for (uint64_t q = blockIdx.x * 256ull + threadIdx.x; q < nnz; q += gridDim.x * 256ull) {
-    const bool pstart = q == e0 || q == e1 || q == e2 || q == e3 || q == e4 || q == e5 || q == e6 || q == e7;
-    head[q] = (pstart || prow[q] != prow[q - 1]) ? 1u : 0u;
+static __global__ void k_xp_pick(const uint32_t* __restrict__ escan, uint32_t nunits, const uint32_t* __restrict__ cstart, uint32_t* __restrict__ out) {
+  if (threadIdx.x <= XP) { out[threadIdx.x] = escan[(size_t)threadIdx.x * nunits]; out[XP + 1 + threadIdx.x] = cstart[threadIdx.x]; }
+}
+// sub-row starts per tile (one wave per tile; the panels' streams are stored back to back in whole tiles, padding is zero)
+static __global__ __launch_bounds__(256) void k_xp_tile_flags(const uint32_t* __restrict__ pcol, uint32_t ntiles, uint32_t* __restrict__ tflags) {
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6); g < ntiles; g += gridDim.x * 4) {
+    const uint4 wd = *(const uint4*)(pcol + (size_t)g * WP_ENT + lane * 4);
+    const uint32_t c = (wd.x >> 31) + (wd.y >> 31) + (wd.z >> 31) + (wd.w >> 31);
+    const uint32_t tot = __builtin_amdgcn_wave_reduce_add_u32(c, 0);
+    if (lane == 0) tflags[g] = tot;
   }
 }
-// sub-row s (global numbering, panel-major) starts at entry q: rowptr slot s + panel, value relative to the panel
-static __global__ void k_xp_subrows(const uint32_t* __restrict__ head, const uint32_t* __restrict__ sidx, const uint32_t* __restrict__ prow, uint64_t q0, uint64_t q1,
-                                    uint32_t panel, uint32_t* __restrict__ rowptr, uint32_t* __restrict__ subrow_row) {
-  for (uint64_t q = q0 + blockIdx.x * 256ull + threadIdx.x; q < q1; q += gridDim.x * 256ull)
-    if (head[q]) { const uint32_t s = sidx[q]; rowptr[s + panel] = (uint32_t)(q - q0); subrow_row[s] = prow[q]; }
+// number the sub-rows: sub-row s (panel after panel, in entry order) starts at the s-th flagged entry
+static __global__ __launch_bounds__(256) void k_xp_subrows(const uint32_t* __restrict__ pcol, const uint32_t* __restrict__ rowtmp, const uint32_t* __restrict__ E, uint32_t ntiles,
+                                                           uint32_t* __restrict__ trow, uint32_t* __restrict__ subrow_row, uint16_t* __restrict__ lrow) {
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6); g < ntiles; g += gridDim.x * 4) {
+    const size_t q0 = (size_t)g * WP_ENT + lane * 4;
+    const uint4 wd = *(const uint4*)(pcol + q0);
+    const uint32_t f[4] = {wd.x >> 31, wd.y >> 31, wd.z >> 31, wd.w >> 31};
+    const uint32_t mine = f[0] + f[1] + f[2] + f[3];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += o; }
+    uint32_t s = E[g] + incl - mine;            // flagged entries before my first one
+    if (lane == 0) trow[g] = E[g] - (f[0] ? 0u : 1u);
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (f[j]) { const uint32_t r = rowtmp[q0 + j]; subrow_row[s] = r; lrow[s] = (uint16_t)(r % XP_RB); s++; }
+  }
 }
-static __global__ void k_xp_set(uint32_t* p, uint32_t v) { *p = v; }
+static __global__ void k_xp_block_starts(const uint32_t* __restrict__ subrow_row, uint32_t nblocks, const uint32_t* __restrict__ E, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3,
+                                         uint32_t t4, uint32_t t5, uint32_t t6, uint32_t t7, uint32_t t8, uint32_t* __restrict__ blockptr) {
+  const uint32_t tb[XP + 1] = {t0, t1, t2, t3, t4, t5, t6, t7, t8};
+  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < (nblocks + 1) * XP; t += gridDim.x * 256) {
+    const uint32_t b = t / XP, k = t % XP; const uint64_t target = (uint64_t)b * XP_RB;
+    uint32_t lo = E[tb[k]], hi = E[tb[k + 1]];                 // panel k's sub-rows; first one whose row is >= target
+    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (subrow_row[mid] < target) lo = mid + 1; else hi = mid; }
+    blockptr[t] = lo;
+  }
+}
 // xhot[k*H + h] = u[hot column h of panel k]: the eight LDS tables' contents, gathered once per call (every workgroup of a
 // panel then loads its table with coalesced reads; gathering in each of the 32 workgroups cost 7-16 us of L2 traffic)
 template <class T> __global__ void k_xp_hot_gather(const T* __restrict__ u, const uint32_t* __restrict__ hot_cols, uint32_t total, T* __restrict__ xhot) {
@@ -128,20 +268,7 @@ template <class T> __global__ void k_xp_hot_gather(const T* __restrict__ u, cons
 // y(i) = sum of the partials of row i's sub-rows, in panel order.  A workgroup owns XP_RB consecutive rows: their
 // sub-rows are one contiguous run in each panel (sub-rows are in row order inside a panel), so the eight runs are read
 // with coalesced loads and accumulated panel after panel in LDS — no per-row index chain, fixed order => reproducible.
-constexpr uint32_t XP_RB = 2048;
-static __global__ void k_xp_local_rows(const uint32_t* __restrict__ subrow_row, uint64_t F, uint16_t* __restrict__ lrow) {
-  for (uint64_t s = blockIdx.x * 256ull + threadIdx.x; s < F; s += gridDim.x * 256ull) lrow[s] = (uint16_t)(subrow_row[s] % XP_RB);
-}
-static __global__ void k_xp_block_starts(const uint32_t* __restrict__ subrow_row, uint32_t nblocks, uint64_t s0, uint64_t s1, uint64_t s2, uint64_t s3, uint64_t s4, uint64_t s5,
-                                         uint64_t s6, uint64_t s7, uint64_t s8, uint32_t* __restrict__ blockptr) {
-  const uint64_t so[XP + 1] = {s0, s1, s2, s3, s4, s5, s6, s7, s8};
-  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < (nblocks + 1) * XP; t += gridDim.x * 256) {
-    const uint32_t b = t / XP, k = t % XP; const uint64_t target = (uint64_t)b * XP_RB;
-    uint64_t lo = so[k], hi = so[k + 1];                       // first sub-row of panel k whose row is >= target
-    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (subrow_row[mid] < target) lo = mid + 1; else hi = mid; }
-    blockptr[t] = (uint32_t)lo;
-  }
-}
+// A row that crosses a chunk boundary inside a panel has consecutive sub-rows there: the first of them adds the others.
 template <class T, class SR>
 __global__ __launch_bounds__(512) void k_xp_combine(uint32_t nrows, const uint32_t* __restrict__ blockptr, const uint16_t* __restrict__ subrow_lrow, const T* __restrict__ partial,
                                                     T* __restrict__ y, uint8_t* __restrict__ ypres, const SR sr) {
@@ -149,15 +276,17 @@ __global__ __launch_bounds__(512) void k_xp_combine(uint32_t nrows, const uint32
   __shared__ uint8_t has[XP_RB];
   const uint32_t b = blockIdx.x, r0 = b * XP_RB;
   for (uint32_t i = threadIdx.x; i < XP_RB; i += 512) has[i] = 0;
-  // the loads of all eight runs are independent of the LDS phase: first sub-row of every panel is fetched up front
   uint32_t lo[XP], hi[XP];
 #pragma unroll
   for (int k = 0; k < XP; k++) { lo[k] = blockptr[b * XP + k]; hi[k] = blockptr[(b + 1) * XP + k]; }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < XP; k++) {
-    for (uint32_t s = lo[k] + threadIdx.x; s < hi[k]; s += 512) {         // one sub-row of a row per panel: no two threads meet on a row
-      const uint32_t r = subrow_lrow[s]; const T v = partial[s];
+    for (uint32_t s = lo[k] + threadIdx.x; s < hi[k]; s += 512) {         // one thread per row and panel: no two threads meet on a row
+      const uint32_t r = subrow_lrow[s];
+      if (s > lo[k] && subrow_lrow[s - 1] == r) continue;                 // a continuation: its row's first sub-row of the panel takes it
+      T v = partial[s];
+      for (uint32_t q = s + 1; q < hi[k] && subrow_lrow[q] == r; q++) v = sr.add(v, partial[q]);
       if (has[r]) acc[r] = sr.add(acc[r], v); else { acc[r] = v; has[r] = 1; }
     }
     __syncthreads();
@@ -168,152 +297,157 @@ __global__ __launch_bounds__(512) void k_xp_combine(uint32_t nrows, const uint32
   }
 }
 
-template <class T> void build_xcd_plan(DevCSR& M, int ncu) {
+// which instantiation of the tile pipeline runs.  The product uses the defaults; GRB_MI355X_XT=d<depth>w<waves>[e<exp>] picks
+// one of the others in builds with -DXT_VARIANTS (measurement harness, FP64 static semirings only).
+struct XtVariant { int depth, waves, exp; };
+inline XtVariant xt_variant() {
+  XtVariant v{XT_DEPTH, XT_WAVES, 0};
+#ifdef XT_VARIANTS
+  const char* e = getenv("GRB_MI355X_XT");
+  if (e) { int d = v.depth, w = v.waves, x = 0; if (sscanf(e, "d%dw%de%d", &d, &w, &x) >= 2) { v.depth = d; v.waves = w; v.exp = x; } }
+#endif
+  return v;
+}
+
+template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals) {
   auto grid_n = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 8192) b = 8192; return (unsigned)b; };
+  hipEvent_t ev0, ev1; GRB_HIP(hipEventCreate(&ev0)); GRB_HIP(hipEventCreate(&ev1)); GRB_HIP(hipEventRecord(ev0, stream()));
   auto* P = new XcdPlan(); M.xcd.reset(P);
   const uint32_t n = M.ncols; const uint64_t nnz = M.nnz;
-  // 1. deal the 128-byte lines of u to the panels (equal entry counts), rank every panel's columns by frequency
-  constexpr uint32_t HH = xt_hot<T>::H;
+  constexpr uint32_t H = xt_hot<T>::H;
+  // 1. column counts; the 128-byte lines of u dealt to the panels (equal entry counts); every panel's columns ranked by frequency
   const uint32_t line = 128 / (uint32_t)sizeof(T), nlines = (n + line - 1) / line;
-  DevBuf cnt((size_t)n * 4 + 4), rank((size_t)n * 4 + 4);
-  P->hot_cols.alloc((size_t)XP * HH * 4 + 4);
+  DevBuf cnt((size_t)n * 4 + 4), code((size_t)n * 4 + 4), cstart((XP + 1) * 4);
+  P->hot_cols.alloc((size_t)XP * H * 4 + 4);
   GRB_HIP(hipMemsetAsync(cnt.p, 0, (size_t)n * 4 + 4, stream()));
-  GRB_HIP(hipMemsetAsync(P->hot_cols.p, 0, (size_t)XP * HH * 4 + 4, stream()));
-  hipLaunchKernelGGL(k_wp_col_hist, dim3(grid_n(nnz)), dim3(256), 0, stream(), M.col.as<uint32_t>(), nnz, cnt.as<uint32_t>());
-  uint32_t cstart[XP + 1];
+  GRB_HIP(hipMemsetAsync(P->hot_cols.p, 0, (size_t)XP * H * 4 + 4, stream()));
+  { uint64_t nb = (nnz + 65535) / 65536; if (nb < 1) nb = 1; if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_xp_col_hist, dim3((unsigned)nb), dim3(1024), 0, stream(), M.col.as<uint32_t>(), nnz, cnt.as<uint32_t>()); }
   {
     DevBuf negw((size_t)nlines * 4 + 4), lid((size_t)nlines * 4 + 4), negw2((size_t)nlines * 4 + 4), lsorted((size_t)nlines * 4 + 4), pol((size_t)nlines + 8);
     hipLaunchKernelGGL(k_xp_line_weights, dim3(grid_n(nlines)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, line, nlines, negw.as<uint32_t>(), lid.as<uint32_t>());
     sort_pairs_u32(negw.as<uint32_t>(), negw2.as<uint32_t>(), lid.as<uint32_t>(), lsorted.as<uint32_t>(), nlines, 32);
-    const uint32_t ntop = nlines < 4096u ? nlines : 4096u;                 // the heavy head of the distribution is balanced exactly
-    std::vector<uint32_t> topw(ntop); std::vector<uint8_t> topk(ntop);
-    GRB_HIP(hipMemcpyAsync(topw.data(), negw2.p, (size_t)ntop * 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
-    uint64_t load[XP] = {0};
-    for (uint32_t i = 0; i < ntop; i++) { int best = 0; for (int k = 1; k < XP; k++) if (load[k] < load[best]) best = k; topk[i] = (uint8_t)best; load[best] += 0xFFFFFFFFu - topw[i]; }
+    const uint32_t ntop = nlines < 4096u ? nlines : 4096u;
     DevBuf dtop((size_t)ntop + 8);
-    GRB_HIP(hipMemcpyAsync(dtop.p, topk.data(), ntop, hipMemcpyHostToDevice, stream()));
+    hipLaunchKernelGGL(k_xp_lpt, dim3(1), dim3(256), 0, stream(), negw2.as<uint32_t>(), ntop, (uint8_t*)dtop.p);
     hipLaunchKernelGGL(k_xp_deal_lines, dim3(grid_n(nlines)), dim3(256), 0, stream(), lsorted.as<uint32_t>(), nlines, (const uint8_t*)dtop.p, ntop, (uint8_t*)pol.p);
-    DevBuf k64((size_t)n * 8 + 8), k64o((size_t)n * 8 + 8), cin((size_t)n * 4 + 4), cout((size_t)n * 4 + 4), dstart(XP * 4);
-    hipLaunchKernelGGL(k_xp_column_keys, dim3(grid_n(n)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, line, (const uint8_t*)pol.p, (unsigned long long*)k64.p, cin.as<uint32_t>());
-    sort_pairs_u64((const uint64_t*)k64.p, (uint64_t*)k64o.p, cin.as<uint32_t>(), cout.as<uint32_t>(), n, 64);
-    GRB_HIP(hipMemsetAsync(dstart.p, 0xFF, XP * 4, stream()));
-    hipLaunchKernelGGL(k_xp_panel_starts, dim3(grid_n(n)), dim3(256), 0, stream(), (const unsigned long long*)k64o.p, n, dstart.as<uint32_t>());
-    GRB_HIP(hipMemcpyAsync(cstart, dstart.p, XP * 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));   // (also orders the host buffers above)
-    cstart[XP] = n;
-    for (int k = XP - 1; k >= 0; k--) if (cstart[k] == 0xFFFFFFFFu) cstart[k] = cstart[k + 1];      // a panel without columns
-    hipLaunchKernelGGL(k_xp_column_codes, dim3(grid_n(n)), dim3(256), 0, stream(), (const unsigned long long*)k64o.p, cout.as<uint32_t>(), n, HH, cstart[0], cstart[1], cstart[2], cstart[3],
-                       cstart[4], cstart[5], cstart[6], cstart[7], rank.as<uint32_t>(), P->hot_cols.as<uint32_t>());
-    GRB_HIP(hipStreamSynchronize(stream()));
-  }
-  for (int k = 0; k < XP; k++) { const uint32_t nk = cstart[k + 1] - cstart[k]; P->nhot[k] = nk < HH ? nk : HH; }
-  // 2. entries grouped by panel (stable: row-major order is kept inside a panel)
-  DevBuf pk(nnz * 4 + 4), pidx(nnz * 4 + 4), pk2(nnz * 4 + 4), perm(nnz * 4 + 4), rowidx(nnz * 4 + 4), prow(nnz * 4 + 4), hc(XP * 8);
-  hipLaunchKernelGGL(k_xp_panel_keys, dim3(grid_n(nnz)), dim3(256), 0, stream(), M.col.as<uint32_t>(), nnz, rank.as<uint32_t>(), pk.as<uint32_t>(), pidx.as<uint32_t>());
-  GRB_HIP(hipMemsetAsync(hc.p, 0, XP * 8, stream()));
-  hipLaunchKernelGGL(k_xp_hist8, dim3(1024), dim3(256), 0, stream(), pk.as<uint32_t>(), nnz, hc.as<unsigned long long>());
-  sort_pairs_u32(pk.as<uint32_t>(), pk2.as<uint32_t>(), pidx.as<uint32_t>(), perm.as<uint32_t>(), nnz, 3);
-  unsigned long long hcnt[XP];
-  GRB_HIP(hipMemcpyAsync(hcnt, hc.p, XP * 8, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
-  P->eoff[0] = 0; for (int k = 0; k < XP; k++) P->eoff[k + 1] = P->eoff[k] + hcnt[k];
-  csr_row_indices(M, rowidx.as<uint32_t>());
-  P->ebase[0] = 0; for (int k = 0; k < XP; k++) P->ebase[k + 1] = (P->ebase[k] + (P->eoff[k + 1] - P->eoff[k]) + 63) & ~63ull;
-  P->pcol.alloc((P->ebase[XP] + 64) * 4 + 4); P->pval.alloc((P->ebase[XP] + 64) * sizeof(T) + 8);
-  hipLaunchKernelGGL((k_xp_gather_entries<T>), dim3(grid_n(nnz)), dim3(256), 0, stream(), perm.as<uint32_t>(), nnz, M.col.as<uint32_t>(), M.val.as<T>(),
-                     rank.as<uint32_t>(), rowidx.as<uint32_t>(), P->pcol.as<uint32_t>(), P->pval.as<T>(), prow.as<uint32_t>(),
-                     P->eoff[1], P->eoff[2], P->eoff[3], P->eoff[4], P->eoff[5], P->eoff[6], P->eoff[7]);
-  // 3. sub-rows
-  DevBuf head(nnz * 4 + 4), sidx(nnz * 4 + 4);
-  hipLaunchKernelGGL(k_xp_heads, dim3(grid_n(nnz)), dim3(256), 0, stream(), prow.as<uint32_t>(), nnz, P->eoff[0], P->eoff[1], P->eoff[2], P->eoff[3], P->eoff[4], P->eoff[5],
-                     P->eoff[6], P->eoff[7], head.as<uint32_t>());
-  exclusive_scan_u32(head.as<uint32_t>(), sidx.as<uint32_t>(), nnz);
-  for (int k = 0; k <= XP; k++) {
-    if (P->eoff[k] >= nnz) { uint32_t lp = 0, lh = 0;
-      GRB_HIP(hipMemcpyAsync(&lp, sidx.as<uint32_t>() + (nnz - 1), 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipMemcpyAsync(&lh, head.as<uint32_t>() + (nnz - 1), 4, hipMemcpyDeviceToHost, stream()));
-      GRB_HIP(hipStreamSynchronize(stream())); P->soff[k] = (uint64_t)lp + lh; }
-    else { uint32_t v = 0; GRB_HIP(hipMemcpyAsync(&v, sidx.as<uint32_t>() + P->eoff[k], 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream())); P->soff[k] = v; }
-  }
-  P->F = P->soff[XP];
-  P->subrow_row.alloc(P->F * 4 + 4);
-  P->rowptr.alloc((P->F + XP) * 4 + 4);
+    DevBuf k32((size_t)n * 4 + 4), k32o((size_t)n * 4 + 4), cin((size_t)n * 4 + 4), cout((size_t)n * 4 + 4);
+    hipLaunchKernelGGL(k_xp_column_keys, dim3(grid_n(n)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, line, (const uint8_t*)pol.p, k32.as<uint32_t>(), cin.as<uint32_t>());
+    sort_pairs_u32(k32.as<uint32_t>(), k32o.as<uint32_t>(), cin.as<uint32_t>(), cout.as<uint32_t>(), n, 23);
+    GRB_HIP(hipMemsetAsync(cstart.p, 0xFF, (XP + 1) * 4, stream()));
+    hipLaunchKernelGGL(k_xp_panel_starts, dim3(grid_n(n)), dim3(256), 0, stream(), k32o.as<uint32_t>(), n, cstart.as<uint32_t>());
+    hipLaunchKernelGGL(k_xp_fix_starts, dim3(1), dim3(1), 0, stream(), cstart.as<uint32_t>(), n);
+    hipLaunchKernelGGL(k_xp_column_codes, dim3(grid_n(n)), dim3(256), 0, stream(), k32o.as<uint32_t>(), cout.as<uint32_t>(), n, H, cstart.as<uint32_t>(), code.as<uint32_t>(), P->hot_cols.as<uint32_t>());
+  }   // (the temporaries return to the pool; reuse is stream-ordered)
+  // 2. row of every entry
+  DevBuf rowidx(nnz * 4 + 4);
+  GRB_HIP(hipMemsetAsync(rowidx.p, 0, nnz * 4 + 4, stream()));
+  hipLaunchKernelGGL(k_xp_mark_rows, dim3(grid_n(M.nrows)), dim3(256), 0, stream(), M.rowptr.as<uint32_t>(), M.nrows, rowidx.as<uint32_t>());
+  inclusive_scan_max_u32(rowidx.as<uint32_t>(), rowidx.as<uint32_t>(), nnz);
+  // 3. counting sweep, scans, the sizes (first host round trip)
+  const uint32_t nunits = (uint32_t)((nnz + XP_UNIT - 1) / XP_UNIT);
+  const size_t nslots = (size_t)XP * nunits;
+  DevBuf ne((nslots + 1) * 4), escan((nslots + 1) * 4), lastkey(nslots * 8 + 8), carry(nslots * 8 + 8), picked(2 * (XP + 1) * 4);
+  XpSweep<T> sw{};
+  sw.col = M.col.as<uint32_t>(); sw.rowidx = rowidx.as<uint32_t>(); sw.code = code.as<uint32_t>(); sw.val = with_vals ? M.val.as<T>() : nullptr; sw.nnz = nnz; sw.nunits = nunits;
+  sw.ne = ne.as<uint32_t>(); sw.lastkey = (unsigned long long*)lastkey.p; sw.escan = escan.as<uint32_t>(); sw.carry = (const unsigned long long*)carry.p;
+  GRB_HIP(hipMemsetAsync(ne.as<uint32_t>() + nslots, 0, 4, stream()));
+  hipLaunchKernelGGL((k_xp_sweep<T, false>), dim3(nunits), dim3(XP_ST), 0, stream(), sw);
+  exclusive_scan_u32(ne.as<uint32_t>(), escan.as<uint32_t>(), nslots + 1);
+  exclusive_scan_max_u64((const uint64_t*)lastkey.p, (uint64_t*)carry.p, nslots);
+  hipLaunchKernelGGL(k_xp_pick, dim3(1), dim3(64), 0, stream(), escan.as<uint32_t>(), nunits, cstart.as<uint32_t>(), picked.as<uint32_t>());
+  uint32_t hp[2 * (XP + 1)];
+  GRB_HIP(hipMemcpyAsync(hp, picked.p, sizeof(hp), hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+  const uint32_t wpp = (uint32_t)(ncu / XP) * xt_variant().waves;       // waves per panel
+  uint32_t kt[XP]; uint64_t nchunks_total = 0;
+  P->tbase[0] = 0;
   for (int k = 0; k < XP; k++) {
-    if (P->eoff[k + 1] > P->eoff[k])
-      hipLaunchKernelGGL(k_xp_subrows, dim3(grid_n(P->eoff[k + 1] - P->eoff[k])), dim3(256), 0, stream(), head.as<uint32_t>(), sidx.as<uint32_t>(), prow.as<uint32_t>(),
-                         P->eoff[k], P->eoff[k + 1], (uint32_t)k, P->rowptr.as<uint32_t>(), P->subrow_row.as<uint32_t>());
-    hipLaunchKernelGGL(k_xp_set, dim3(1), dim3(1), 0, stream(), P->rowptr.as<uint32_t>() + P->soff[k + 1] + k, (uint32_t)(P->eoff[k + 1] - P->eoff[k]));   // end sentinel of panel k
+    P->ne[k] = hp[k + 1] - hp[k];
+    P->ntiles[k] = (uint32_t)((P->ne[k] + WP_ENT - 1) / WP_ENT);
+    P->tbase[k + 1] = P->tbase[k] + P->ntiles[k];
+    const uint32_t nk = hp[XP + 1 + k + 1] - hp[XP + 1 + k]; P->nhot[k] = nk < H ? nk : H;
+    kt[k] = wp_chunk_tasks(P->ntiles[k], wpp); sw.chunk_entries[k] = kt[k] * (uint32_t)WP_ENT; sw.ebase[k] = (uint64_t)P->tbase[k] * WP_ENT;
+    nchunks_total += (P->ntiles[k] + kt[k] - 1) / kt[k];
   }
-  // 4. row blocks of the merge kernel: where each block's run of sub-rows starts in every panel
-  {
-    const uint32_t nblocks = (uint32_t)(((uint64_t)M.nrows + XP_RB - 1) / XP_RB);
-    P->blockptr.alloc(((size_t)nblocks + 1) * XP * 4 + 4);
-    P->subrow_lrow.alloc(P->F * 2 + 4);
-    hipLaunchKernelGGL(k_xp_local_rows, dim3(grid_n(P->F)), dim3(256), 0, stream(), P->subrow_row.as<uint32_t>(), P->F, P->subrow_lrow.as<uint16_t>());
-    hipLaunchKernelGGL(k_xp_block_starts, dim3(grid_n(((uint64_t)nblocks + 1) * XP)), dim3(256), 0, stream(), P->subrow_row.as<uint32_t>(), nblocks, P->soff[0], P->soff[1], P->soff[2],
-                       P->soff[3], P->soff[4], P->soff[5], P->soff[6], P->soff[7], P->soff[8], P->blockptr.as<uint32_t>());
-  }
-  // 5. tiles of 256 entries per panel and the sub-row each begins in; row-start flags into the column words
-  P->toff[0] = 0;
+  const uint32_t ntiles = P->tbase[XP];
+  const size_t nstore = (size_t)ntiles * WP_ENT + 64;
+  // 4. scattering sweep
+  DevBuf rowtmp(nstore * 4);
+  P->pcol.alloc(nstore * 4);
+  if (with_vals) P->pval.alloc(nstore * sizeof(T));
+  GRB_HIP(hipMemsetAsync(P->pcol.p, 0, nstore * 4, stream()));
+  sw.pcol = P->pcol.as<uint32_t>(); sw.pval = with_vals ? P->pval.as<T>() : nullptr; sw.rowtmp = rowtmp.as<uint32_t>();
+  hipLaunchKernelGGL((k_xp_sweep<T, true>), dim3(nunits), dim3(XP_ST), 0, stream(), sw);
+  // 5. sub-rows: starts per tile, scan, the total (second host round trip), then their numbering
+  DevBuf tflags(((size_t)ntiles + 1) * 4), E(((size_t)ntiles + 1) * 4);
+  GRB_HIP(hipMemsetAsync(tflags.as<uint32_t>() + ntiles, 0, 4, stream()));
+  { unsigned nb = (ntiles + 3) / 4; if (nb < 1) nb = 1; if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(k_xp_tile_flags, dim3(nb), dim3(256), 0, stream(), P->pcol.as<uint32_t>(), ntiles, tflags.as<uint32_t>()); }
+  exclusive_scan_u32(tflags.as<uint32_t>(), E.as<uint32_t>(), (uint64_t)ntiles + 1);
+  uint32_t F32 = 0;
+  GRB_HIP(hipMemcpyAsync(&F32, E.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+  P->F = F32;
+  DevBuf subrow_row(P->F * 4 + 4);
+  P->trow.alloc(((size_t)ntiles + 1) * 4); P->lrow.alloc(P->F * 2 + 4);
+  { unsigned nb = (ntiles + 3) / 4; if (nb < 1) nb = 1; if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(k_xp_subrows, dim3(nb), dim3(256), 0, stream(), P->pcol.as<uint32_t>(), rowtmp.as<uint32_t>(), E.as<uint32_t>(), ntiles, P->trow.as<uint32_t>(),
+                       subrow_row.as<uint32_t>(), P->lrow.as<uint16_t>()); }
+  // 6. row blocks of the merge kernel: where each block's run of sub-rows starts in every panel
+  const uint32_t nblocks = (uint32_t)(((uint64_t)M.nrows + XP_RB - 1) / XP_RB);
+  P->blockptr.alloc(((size_t)nblocks + 1) * XP * 4 + 4);
+  hipLaunchKernelGGL(k_xp_block_starts, dim3(grid_n(((uint64_t)nblocks + 1) * XP)), dim3(256), 0, stream(), subrow_row.as<uint32_t>(), nblocks, E.as<uint32_t>(), P->tbase[0], P->tbase[1],
+                     P->tbase[2], P->tbase[3], P->tbase[4], P->tbase[5], P->tbase[6], P->tbase[7], P->tbase[8], P->blockptr.as<uint32_t>());
+  // 7. the panels' argument block and the per-call buffers
+  P->args.alloc(XP * sizeof(XtPanel<T>));
+  P->xhot.alloc((size_t)XP * H * sizeof(T) + 8); P->partial.alloc(P->F * sizeof(T) + 8);
+  XtPanel<T> ha[XP];
   for (int k = 0; k < XP; k++) {
-    const uint64_t ek = P->eoff[k + 1] - P->eoff[k];
-    P->ntasks[k] = (uint32_t)((ek + WP_ENT - 1) / WP_ENT);
-    P->toff[k + 1] = P->toff[k] + (uint64_t)P->ntasks[k] + 1;
-  }
-  P->tasks.alloc(P->toff[XP] * 4 + 4);
-  for (int k = 0; k < XP; k++) {
-    const uint64_t fk = P->soff[k + 1] - P->soff[k];
-    hipLaunchKernelGGL(k_xt_tile_rows, dim3(grid_n(P->ntasks[k] + 1)), dim3(256), 0, stream(), P->rowptr.as<uint32_t>() + P->soff[k] + k, (uint32_t)fk, P->ntasks[k],
-                       P->tasks.as<uint32_t>() + P->toff[k]);
-    hipLaunchKernelGGL(k_wp_mark_row_starts, dim3(grid_n(fk)), dim3(256), 0, stream(), P->rowptr.as<uint32_t>() + P->soff[k] + k, (uint32_t)fk, P->pcol.as<uint32_t>() + P->ebase[k]);
-  }
-  constexpr uint32_t H = xt_hot<T>::H;
-  P->args.alloc(XP * sizeof(WpArgs<T>));
-  size_t coff[XP + 1]; coff[0] = 0;
-  const uint32_t wpp = (uint32_t)(ncu / XP) * WP_WGS_PER_CU * WP_WAVES;       // waves per panel
-  uint32_t kt[XP];
-  for (int k = 0; k < XP; k++) { kt[k] = wp_chunk_tasks(P->ntasks[k], wpp); coff[k + 1] = coff[k] + (P->ntasks[k] + kt[k] - 1) / kt[k]; }
-  P->carry.alloc((coff[XP] + 1) * sizeof(WpCarry<T>)); P->maxchunks = 1;
-  for (int k = 0; k < XP; k++) if (coff[k + 1] - coff[k] > P->maxchunks) P->maxchunks = (uint32_t)(coff[k + 1] - coff[k]);
-  P->xhot.alloc((size_t)XP * H * sizeof(T) + 8); P->partial.alloc(P->F * sizeof(T) + 8); P->scratch.alloc(P->F + 8);
-  WpArgs<T> ha[XP];
-  for (int k = 0; k < XP; k++) {
-    WpArgs<T>& a = ha[k];
-    const uint32_t fk = (uint32_t)(P->soff[k + 1] - P->soff[k]), ek = (uint32_t)(P->eoff[k + 1] - P->eoff[k]);
-    a.rowptr = P->rowptr.as<uint32_t>() + P->soff[k] + k; a.pcol = P->pcol.as<uint32_t>() + P->ebase[k];
-    a.aval = P->pval.as<T>() + P->ebase[k];
-    a.x = P->xhot.as<T>() + (size_t)k * H; a.xorig = nullptr; a.hot_cols = P->hot_cols.as<uint32_t>() + (size_t)k * H;      // u comes with the launch
-    a.trow = P->tasks.as<uint32_t>() + P->toff[k]; a.tent = a.trow;      // first sub-row of every tile
-    a.y = P->partial.as<T>() + P->soff[k]; a.ypres = P->scratch.as<uint8_t>() + P->soff[k];
-    a.carry = P->carry.as<WpCarry<T>>() + coff[k];
-    a.nrows = fk; a.ntasks = P->ntasks[k]; a.nnz = ek; a.tasks_per_chunk = kt[k]; a.static_pct = wp_env("GRB_MI355X_WP_STATIC", WP_STATIC_PCT);
-    a.nhot = P->nhot[k]; a.nwarm = H;
+    XtPanel<T>& a = ha[k];
+    a.pcol = P->pcol.as<uint32_t>() + (size_t)P->tbase[k] * WP_ENT; a.aval = with_vals ? P->pval.as<T>() + (size_t)P->tbase[k] * WP_ENT : nullptr;
+    a.trow = P->trow.as<uint32_t>() + P->tbase[k]; a.xhot = P->xhot.as<T>() + (size_t)k * H;
+    a.nnz = (uint32_t)P->ne[k]; a.ntiles = P->ntiles[k]; a.tiles_per_chunk = kt[k]; a.nhot = P->nhot[k];
+    a.static_pct = wp_env("GRB_MI355X_WP_STATIC", WP_STATIC_PCT); a.pad = 0;
   }
   if (getenv("GRB_MI355X_VERBOSE"))
     for (int k = 0; k < XP; k++)
-      fprintf(stderr, "[grb] xcd plan panel %d: entries %llu sub-rows %llu tasks %u chunk %u columns %u hot %u\n", k, (unsigned long long)(P->eoff[k + 1] - P->eoff[k]),
-              (unsigned long long)(P->soff[k + 1] - P->soff[k]), P->ntasks[k], kt[k], cstart[k + 1] - cstart[k], P->nhot[k]);
+      fprintf(stderr, "[grb] xcd plan panel %d: entries %llu tiles %u chunk %u hot %u (sub-rows in all %llu, chunks %llu)\n", k, (unsigned long long)P->ne[k], P->ntiles[k], kt[k], P->nhot[k],
+              (unsigned long long)P->F, (unsigned long long)nchunks_total);
   GRB_HIP(hipMemcpyAsync(P->args.p, ha, sizeof(ha), hipMemcpyHostToDevice, stream()));
-  P->tsize = (int)sizeof(T);
+  P->tsize = (int)sizeof(T); P->has_vals = with_vals;
+  GRB_HIP(hipEventRecord(ev1, stream()));
   GRB_HIP(hipStreamSynchronize(stream()));
+  GRB_HIP(hipEventElapsedTime(&P->build_ms, ev0, ev1)); g_xcd_plan_build_ms = P->build_ms;
+  (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
 }
 
 template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int ncu) {
   DevCSR& M = *c.M;
   if (ncu < XP || ncu % XP) return false;
-  if (c.aval && c.aval != M.val.p) return false;      // the plan's panel-major values are a copy of the stored ones (no typecast)
+  const bool need_vals = c.aval != nullptr;
+  if (need_vals && c.aval != M.val.p) return false;   // the plan's panel-major values are a copy of the stored ones (no typecast)
   auto* P = static_cast<XcdPlan*>(M.xcd.get());
-  if (!P || P->tsize != (int)sizeof(T)) { build_xcd_plan<T>(M, ncu); P = static_cast<XcdPlan*>(M.xcd.get()); }
+  if (!P || P->tsize != (int)sizeof(T) || (need_vals && !P->has_vals)) { build_xcd_plan<T>(M, ncu, need_vals); P = static_cast<XcdPlan*>(M.xcd.get()); }
   const bool uses_u = d.flip ? binop_uses_x(d.mulop) : binop_uses_y(d.mulop);
-  WpArgs<T> a0{}; a0.xorig = (const T*)c.uval; a0.nrows = M.ncols;       // the only per-call pointer of the pipeline: u itself (and its length)
   constexpr uint32_t H = xt_hot<T>::H;
+  XtCall<T> call{(const T*)c.uval, M.ncols, 0u, P->partial.as<T>()};
   if (uses_u) hipLaunchKernelGGL((k_xp_hot_gather<T>), dim3((XP * H + 255) / 256), dim3(256), 0, stream(), (const T*)c.uval, P->hot_cols.as<uint32_t>(), (uint32_t)(XP * H), P->xhot.as<T>());
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;
-    hipLaunchKernelGGL((k_spmv_tiles<T, SR>), dim3(ncu * WP_WGS_PER_CU), dim3(WP_WAVES * 64), 0, stream(), a0, (const WpArgs<T>*)P->args.p, sr);
-    hipLaunchKernelGGL((k_spmv_wavepipe_fixup<T, SR>), dim3((P->maxchunks + 255) / 256, XP), dim3(256), 0, stream(), (const WpCarry<T>*)nullptr, P->maxchunks, (T*)nullptr, (uint8_t*)nullptr,
-                       (const WpArgs<T>*)P->args.p, sr);
+    bool launched = false;
+#ifdef XT_VARIANTS
+    if constexpr (std::is_same<SR, StaticSR<double, B_PLUS, B_TIMES>>::value) {
+      const XtVariant v = xt_variant();
+#define XT_TRY(D_, W_, E_) if (!launched && v.depth == D_ && v.waves == W_ && v.exp == E_) { \
+        hipLaunchKernelGGL((k_spmv_tiles<T, SR, D_, W_, E_>), dim3(ncu), dim3(W_ * 64), 0, stream(), call, (const XtPanel<T>*)P->args.p, sr); launched = true; }
+      XT_TRY(1, 16, 1) XT_TRY(1, 16, 2) XT_TRY(2, 16, 0) XT_TRY(1, 8, 0) XT_TRY(2, 8, 0) XT_TRY(3, 8, 0) XT_TRY(2, 8, 2) XT_TRY(3, 8, 2) XT_TRY(4, 8, 0)
+#undef XT_TRY
+    }
+#endif
+    if (!launched) hipLaunchKernelGGL((k_spmv_tiles<T, SR>), dim3(ncu), dim3(XT_WAVES * 64), 0, stream(), call, (const XtPanel<T>*)P->args.p, sr);
     const uint32_t nblocks = (uint32_t)(((uint64_t)M.nrows + XP_RB - 1) / XP_RB);
-    hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3(nblocks), dim3(512), 0, stream(), M.nrows, P->blockptr.as<uint32_t>(), P->subrow_lrow.as<uint16_t>(), P->partial.as<T>(),
+    hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3(nblocks), dim3(512), 0, stream(), M.nrows, P->blockptr.as<uint32_t>(), P->lrow.as<uint16_t>(), P->partial.as<T>(),
                        (T*)c.tval, c.tpres, sr);
-    g_last_plan += std::string("k_spmv_xcd<") + (sr.is_static ? "static" : "dynamic") + ",subrows=" + std::to_string(P->F) + "> ";
+    g_last_plan += std::string("k_spmv_xcd<") + (sr.is_static ? "static" : "dynamic") + ",subrows=" + std::to_string(P->F) + "," + xcd_mapping() + "> ";
   });
   return true;
 }

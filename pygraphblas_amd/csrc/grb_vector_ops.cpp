@@ -57,9 +57,8 @@ static void vec_assign(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const 
   vec_to_device(w);
   const uint8_t* reg = nullptr;
   if (I != GrB_ALL) {
-    if (!I && ni) fail(GrB_NULL_POINTER, "assign: index list is NULL");
     std::vector<uint8_t> h(n ? n : 1, 0);
-    for (GrB_Index k = 0; k < ni; k++) { if (I[k] >= n) fail(GrB_INDEX_OUT_OF_BOUNDS, "assign: index out of bounds"); h[I[k]] = 1; }
+    if (ni) for (uint64_t i : expand_index_list(I, ni, n, "assign")) h[i] = 1;
     region.alloc(n ? n : 1);
     GRB_HIP(hipMemcpyAsync(region.p, h.data(), n, hipMemcpyHostToDevice, stream())); GRB_HIP(hipStreamSynchronize(stream()));
     reg = region.as<uint8_t>();

@@ -186,26 +186,32 @@ class Matrix:
         return cls.from_arrays(idx, idx, np.full(nrows, typ.default_one if one is None else one, typ._np), nrows, nrows, typ)
 
     @classmethod
-    def random(cls, typ, nvals, nrows=None, ncols=None, make_symmetric=False, no_diagonal=False, seed=None):
-        """Random matrix from Python's `random` like the reference generator (pygraphblas/matrix.py:499-571):
-        later duplicates overwrite, so nvals is an upper bound."""
+    def random(cls, typ, nvals, nrows=None, ncols=None, make_pattern=False, make_symmetric=False, make_skew_symmetric=False,
+               make_hermitian=True, no_diagonal=False, seed=None):
+        """The reference's generator, call for call (pygraphblas/matrix.py:499-571): Python's `random`, seeded if asked;
+        per entry `randint(0, nrows-1)`, `randint(0, ncols-1)`, then the value draw of the type (signed integers
+        from -(2^(b-1))+1, floats from `random()`); a repeated coordinate overwrites, so nvals is an upper bound.
+        The make_* / no_diagonal flags are accepted and — as in the reference's loop (:567-570) — do not change
+        what is generated.  `Matrix.random(INT8, 4, 10, 10, seed=42)` holds [62, 46, -70, 24]
+        (reference tests/test_matrix.py:1060-1064)."""
+        nrows = _capi.constants["GxB_INDEX_MAX"] if nrows is None else nrows
+        ncols = _capi.constants["GxB_INDEX_MAX"] if ncols is None else ncols
+        m = cls.sparse(typ, nrows, ncols)
         if seed is not None:
             _random.seed(seed)
-        m = cls.sparse(typ, nrows, ncols)
+        if nrows == 0 or ncols == 0:
+            nvals = 0
+        if typ is types.BOOL:
+            f = partial(_random.randint, 0, 1)
+        elif typ in (types.FP32, types.FP64):
+            f = _random.random
+        else:
+            info = np.iinfo(typ._np)
+            f = partial(_random.randint, 0 if info.min == 0 else int(info.min) + 1, int(info.max))
         for _ in range(nvals):
-            i, j = _random.randrange(nrows), _random.randrange(ncols)
-            if no_diagonal and i == j:
-                continue
-            if typ is types.BOOL:
-                v = True
-            elif typ in (types.FP32, types.FP64):
-                v = _random.random()
-            else:
-                info = np.iinfo(typ._np)
-                v = _random.randint(info.min, info.max)
-            m[i, j] = v
-            if make_symmetric:
-                m[j, i] = v
+            i = _random.randint(0, nrows - 1)
+            j = _random.randint(0, ncols - 1)
+            m[i, j] = f()
         return m
 
     def dup(self):

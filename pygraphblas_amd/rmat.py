@@ -98,21 +98,54 @@ def _finish_numpy(src, dst, n, symmetric, drop_self_loops, lower, row_range):
     return np.cumsum(rowptr).astype(np.uint32), cols
 
 
-def csr_numpy(scale, seed=42, edgefactor=16, symmetric=False, drop_self_loops=False, lower=False, row_range=None):
-    """Pattern CSR (rowptr u32, col u32) of the de-duplicated R-MAT graph (rows in row_range if given)."""
+def permutation_numpy(scale, seed):
+    """A pseudo-random relabelling of the 2^scale vertices (Graph500 permutes vertex labels; BASELINE's recipe does not):
+    vertex i gets the rank of hash(seed, i).  Same permutation as permutation_torch."""
+    with np.errstate(over="ignore"):
+        i = np.arange(1 << scale, dtype=np.uint64)
+        h = _mix64_np(i * np.uint64(_K1) + np.uint64((seed * _K3) & _MASK))
+    order = np.argsort(h, kind="stable")
+    perm = np.empty(1 << scale, np.uint64)
+    perm[order] = np.arange(1 << scale, dtype=np.uint64)
+    return perm
+
+
+def permutation_torch(scale, device, seed):
+    import torch
+    i = torch.arange(1 << scale, dtype=torch.int64, device=device)
+    z = i * _s64(_K1) + _s64(seed * _K3)
+    z = (z ^ _lsr(z, 30)) * _s64(_K2)
+    z = (z ^ _lsr(z, 27)) * _s64(_K3)
+    h = z ^ _lsr(z, 31)
+    # unsigned order of the 64-bit hash: flip the sign bit
+    order = torch.argsort(h ^ _s64(1 << 63), stable=True)
+    perm = torch.empty(1 << scale, dtype=torch.int64, device=device)
+    perm[order] = torch.arange(1 << scale, dtype=torch.int64, device=device)
+    return perm
+
+
+def csr_numpy(scale, seed=42, edgefactor=16, symmetric=False, drop_self_loops=False, lower=False, row_range=None, permute_seed=None):
+    """Pattern CSR (rowptr u32, col u32) of the de-duplicated R-MAT graph (rows in row_range if given).
+    permute_seed: relabel the vertices pseudo-randomly first (None = keep the generator's labels)."""
     src, dst = edges_numpy(scale, seed, edgefactor)
+    if permute_seed is not None:
+        perm = permutation_numpy(scale, permute_seed)
+        src, dst = perm[src], perm[dst]
     return _finish_numpy(src, dst, 1 << scale, symmetric, drop_self_loops, lower, row_range)
 
 
 def csr_torch(scale, device, seed=42, edgefactor=16, symmetric=False, drop_self_loops=False, lower=False, row_range=None,
-              chunk=1 << 26):
+              chunk=1 << 26, permute_seed=None):
     """Same CSR as csr_numpy, built in HBM: returns (rowptr int32-as-uint32 tensor, col tensor) on `device`."""
     import torch
     n = 1 << scale
     m = edgefactor << scale
     keys = []
+    perm = permutation_torch(scale, device, permute_seed) if permute_seed is not None else None
     for first in range(0, m, chunk):
         s, d = edges_torch(scale, device, seed, edgefactor, first, min(chunk, m - first))
+        if perm is not None:
+            s, d = perm[s], perm[d]
         if symmetric:
             s, d = torch.cat([s, d]), torch.cat([d, s])
         keep = torch.ones_like(s, dtype=torch.bool)

@@ -1,0 +1,158 @@
+"""BASELINE.json configs[0..3] (+ the single-GPU step of configs[4]) at their STATED sizes, through the C ABI on the MI355X,
+against the oracle (oracle/grb_oracle.c) — and scipy as a second opinion where it applies.
+
+  configs[0]  1000x1000 `Matrix.random(FP64, 10 000, seed=42)` mxv PLUS_TIMES_FP64   (reference generator: pygraphblas/matrix.py:499-571)
+  configs[1]  R-MAT scale-22 FP64 PLUS_TIMES SpMV                                     (also what bench.py times)
+  configs[2]  R-MAT scale-22 BOOL LOR_LAND BFS, the reference's loop                  (demo/Introduction-to-GraphBLAS-with-Python.ipynb:4301-4313)
+  configs[3]  triangle count L.mxm(L, PLUS_PAIR, mask=L).reduce_int() on R-MAT-22     (demo/TriangleCentrality.ipynb:1446-1449)
+  configs[4]  one FP32 PageRank step (PLUS_SECOND, T0, accum PLUS) on R-MAT-22        (gap/prmark.py:17-29); the BOOL-pattern
+              matrix of the reference's driver (gap/prmark.py:47 `.pattern()`) with an FP32 semiring at nnz >= 2^22
+Tolerances: bit-exact for BOOL / integer results, 1e-6 relative for FP64 / FP32 (BASELINE.json north_star).
+The scale-22 graphs are generated in HBM by pygraphblas_amd.rmat (counter-based R-MAT) and the oracle's typed
+OpenMP loops run on the same CSR arrays; every case finishes in seconds.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from helpers import TYPE
+
+pytestmark = pytest.mark.gpu
+
+SCALE = 22
+
+
+@pytest.fixture(scope="module")
+def torch_dev(gpu):
+    import torch
+    return torch, torch.device("cuda", 0)
+
+
+# ---- configs[0] ---------------------------------------------------------------------------------------------------------
+def test_config0_reference_random_1000_mxv(gb, gpu):
+    """`Matrix.random` reproduces the reference's draw sequence (tests/test_matrix.py:1060-1064), then the 1000x1000 FP64 mxv."""
+    import random
+    v = gb.Matrix.random(gb.INT8, 4, 10, 10, seed=42)
+    assert len(v) == 4
+    assert v.to_scipy_sparse().data.tolist() == [62, 46, -70, 24]
+    A = gb.Matrix.random(gb.FP64, 10_000, 1000, 1000, seed=42)
+    assert 9_000 < A.nvals <= 10_000                               # repeated coordinates overwrite
+    x = np.array([random.random() for _ in range(1000)])           # continues the same Python stream, as a caller of the reference would
+    u = gb.Vector.from_arrays(np.arange(1000, dtype=np.uint64), x, 1000, gb.FP64)
+    w = A.mxv(u, semiring=gb.FP64.PLUS_TIMES)
+    gi, gx = w.to_arrays()
+    I, J, X = A.to_arrays()
+    exp = O.mxv(O.col_vector("FP64", 1000), O.Tuples("FP64", 1000, 1000, I, J, X), O.col_vector("FP64", 1000, np.arange(1000), x), "PLUS", "TIMES", "FP64")
+    assert np.array_equal(gi, exp.I)
+    assert np.allclose(gx, exp.X, rtol=1e-6, atol=0.0)
+    S = A.to_scipy_sparse().tocsr()
+    y = S @ x
+    rows = np.flatnonzero(np.diff(S.indptr))
+    assert np.array_equal(gi.astype(np.int64), rows)
+    assert np.allclose(gx, y[rows], rtol=1e-6, atol=0.0)
+
+
+# ---- configs[1] ---------------------------------------------------------------------------------------------------------
+def test_config1_rmat22_fp64_spmv(gb, torch_dev):
+    torch, dev = torch_dev
+    from pygraphblas_amd import rmat
+    n = 1 << SCALE
+    rowptr, col = rmat.csr_torch(SCALE, dev, seed=42)
+    nnz = int(col.numel())
+    vals = rmat.values_torch(nnz, dev, seed=43)
+    xs = rmat.values_torch(n, dev, seed=44)
+    A = gb.Matrix.from_csr(gb.FP64, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+    x = gb.Vector.from_dense_array((xs.data_ptr(), n), gb.FP64, device=True)
+    w = A.mxv(x, semiring=gb.FP64.PLUS_TIMES)
+    assert "k_spmv_xcd" in gb.last_kernel_plan()                   # the north-star kernel is the one that ran
+    gy, gp = w.to_dense_arrays()
+    y, pres = O.fast_spmv(rowptr.cpu().numpy().view(np.uint32), col.cpu().numpy().view(np.uint32), vals.cpu().numpy(), xs.cpu().numpy())
+    assert np.array_equal(gp != 0, pres != 0)
+    assert np.allclose(gy[pres != 0], y[pres != 0], rtol=1e-6, atol=0.0)
+    # a second call reuses the plan and must give the same bits (fixed summation order)
+    w2 = A.mxv(x, semiring=gb.FP64.PLUS_TIMES)
+    gy2, _ = w2.to_dense_arrays()
+    assert np.array_equal(gy2[pres != 0], gy[pres != 0])
+
+
+# ---- configs[2] ---------------------------------------------------------------------------------------------------------
+def _bfs(gb, A, start):
+    from pygraphblas_amd import descriptor as D
+    v = gb.Vector.sparse(gb.UINT8, A.nrows)
+    q = gb.Vector.sparse(gb.BOOL, A.nrows)
+    q[start] = True
+    level = 1
+    while q.reduce_bool() and level <= A.nrows:
+        v.assign_scalar(level, mask=q)
+        v.vxm(A, mask=v, out=q, desc=D.RC)
+        level += 1
+    return v, level - 1
+
+
+def test_config2_rmat22_bfs_levels(gb, torch_dev):
+    torch, dev = torch_dev
+    from pygraphblas_amd import rmat
+    n = 1 << SCALE
+    rowptr, col = rmat.csr_torch(SCALE, dev, seed=42, symmetric=True, drop_self_loops=True)
+    nnz = int(col.numel())
+    vals = torch.ones(nnz, dtype=torch.bool, device=dev)
+    A = gb.Matrix.from_csr(gb.BOOL, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+    src = int(torch.argmax(rowptr[1:] - rowptr[:-1]))              # the vertex of maximum degree
+    v, depth = _bfs(gb, A, src)
+    lev, _ = v.to_dense_arrays()
+    olev, odepth = O.fast_bfs(rowptr.cpu().numpy().view(np.uint32), col.cpu().numpy().view(np.uint32), src)
+    assert depth == odepth
+    assert np.array_equal(lev, olev)                               # bit-exact level vector (unreached vertices hold 0 on both sides)
+    assert int((lev > 0).sum()) > n // 4
+
+
+# ---- configs[3] ---------------------------------------------------------------------------------------------------------
+def test_config3_rmat22_triangle_count(gb, torch_dev):
+    torch, dev = torch_dev
+    from pygraphblas_amd import rmat
+    n = 1 << SCALE
+    rowptr, col = rmat.csr_torch(SCALE, dev, seed=42, symmetric=True, drop_self_loops=True, lower=True)
+    nnz = int(col.numel())
+    vals = torch.ones(nnz, dtype=torch.int64, device=dev)
+    L = gb.Matrix.from_csr(gb.INT64, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+    tri = L.mxm(L, semiring=gb.INT64.PLUS_PAIR, mask=L).reduce_int()
+    otri = O.fast_tricount(rowptr.cpu().numpy().view(np.uint32), col.cpu().numpy().view(np.uint32))
+    assert tri == otri                                              # INT64, bit-exact
+    assert tri > 10**9
+
+
+# ---- configs[4], single-GPU step ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mtype", ["FP32", "BOOL"])
+def test_config4_rmat22_pagerank_step_fp32(gb, torch_dev, mtype):
+    """r<accum PLUS> += A' (PLUS_SECOND) w — the product of gap/prmark.py:22-23.  With mtype BOOL the matrix is the pattern
+    matrix the reference's driver builds (gap/prmark.py:47): its stored values are 1 byte wide while the semiring computes
+    in FP32 — the case ADVICE.md (round 1) found reading past the value array in kernel X's plan builder."""
+    torch, dev = torch_dev
+    from pygraphblas_amd import rmat, descriptor as D
+    n = 1 << SCALE
+    rowptr, col = rmat.csr_torch(SCALE, dev, seed=42)
+    nnz = int(col.numel())
+    assert nnz >= 1 << 22
+    if mtype == "FP32":
+        vals = torch.ones(nnz, dtype=torch.float32, device=dev)
+    else:
+        vals = torch.ones(nnz, dtype=torch.bool, device=dev)
+    A = gb.Matrix.from_csr(TYPE[mtype], n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+    ws = rmat.values_torch(n, dev, seed=45, dtype=torch.float32)
+    w = gb.Vector.from_dense_array((ws.data_ptr(), n), gb.FP32, device=True)
+    teleport = np.float32(0.15 / n)
+    r = gb.Vector.dense(gb.FP32, n, fill=float(teleport))
+    A.mxv(w, out=r, accum=gb.FP32.PLUS, semiring=gb.FP32.PLUS_SECOND, desc=D.T0)
+    gr, gp = r.to_dense_arrays()
+    assert gp.all()
+    # oracle: y = A' (PLUS_SECOND) w on the CSR of the transpose, then r = teleport + y where y has an entry
+    import scipy.sparse as sp
+    rp = rowptr.cpu().numpy().view(np.uint32).astype(np.int64); ci = col.cpu().numpy().view(np.uint32).astype(np.int64)
+    At = sp.csr_matrix((np.ones(nnz, np.float32), ci, rp), shape=(n, n)).T.tocsr()
+    # (row sums formed in double and rounded once: the reference's own summation order is unspecified, and a sequential
+    #  float sum over a hub's 1.6e5 terms is itself ~1e-5 off — SURVEY.md §8c)
+    y, pres = O.fast_spmv(At.indptr.astype(np.uint32), At.indices.astype(np.uint32), None, ws.cpu().numpy(), semiring="PLUS_SECOND_WIDE")
+    exp = np.where(pres != 0, teleport + y, teleport).astype(np.float32)
+    assert np.allclose(gr, exp, rtol=1e-6, atol=0.0)
+    y64 = At.astype(np.float64) @ ws.cpu().numpy().astype(np.float64)          # second opinion: scipy in FP64
+    assert np.allclose(gr, teleport + y64, rtol=1e-6, atol=0.0)

@@ -183,3 +183,15 @@ def test_readers_on_the_reference_fixture_files():
     assert M.type is gb.INT64 and [list(x) for x in M.to_lists()] == [_DOC_I, _DOC_J, _DOC_V]
     T = gb.Matrix.from_tsv("/root/reference/docs/test_tsvfile.tsv", gb.INT32, 7, 7)
     assert [list(x) for x in T.to_lists()] == [_DOC_I, _DOC_J, _DOC_V]
+
+
+def test_matrix_random_is_the_reference_generator(gb):
+    """Matrix.random draws like the reference's (pygraphblas/matrix.py:499-571): its own test
+    (tests/test_matrix.py:1060-1064) expects these four INT8 values for seed 42; host side only."""
+    v = gb.Matrix.random(gb.INT8, 4, 10, 10, seed=42)
+    assert len(v) == 4
+    I, J, X = v.to_arrays()
+    assert (I.tolist(), J.tolist(), X.tolist()) == ([1, 2, 4, 8], [0, 1, 3, 1], [62, 46, -70, 24])
+    m = gb.Matrix.random(gb.FP64, 10_000, 1000, 1000, seed=42)       # BASELINE.json configs[0]
+    assert m.nvals == 9949                                            # 51 of the 10 000 coordinates repeat
+    assert gb.Matrix.random(gb.UINT8, 20, 5, 5, make_symmetric=True, no_diagonal=True, seed=42).nvals <= 20

@@ -220,3 +220,43 @@ def test_pipeline_results_are_bitwise_reproducible(gpu, method):
         assert ("wavepipe" in gb.last_kernel_plan()) or ("xcd" in gb.last_kernel_plan()), gb.last_kernel_plan()
     finally:
         os.environ.pop("GRB_MI355X_SPMV", None)
+
+
+def test_user_semirings_bitwise_run_and_math_multipliers_are_refused(gpu):
+    """A semiring composed with GrB_Semiring_new from operators beyond FIRST..LXOR: the integer bitwise ones run in the
+    kernels (checked against numpy), the math-library ones (POW, HYPOT, ...) are refused with a message instead of
+    silently computing zeros (grb_opcommon.hpp)."""
+    import ctypes as C
+    lib, h = gb.lib, gb._capi.handle
+    rng = np.random.default_rng(77)
+    n = 60
+    dense = rng.integers(0, 2, (n, n)).astype(bool)
+    I, J = np.nonzero(dense)
+    X = rng.integers(0, 2**32, len(I), dtype=np.uint64).astype(np.uint32)
+    ux = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    A = gb.Matrix.from_arrays(I.astype(np.uint64), J.astype(np.uint64), X, n, n, gb.UINT32)
+    u = gb.Vector.from_arrays(np.arange(n, dtype=np.uint64), ux, n, gb.UINT32)
+    mon, sr = C.c_void_p(), C.c_void_p()
+    assert lib.GrB_Monoid_new_UINT32(C.byref(mon), C.c_void_p(h("GrB_BOR_UINT32")), C.c_uint32(0)) == 0
+    assert lib.GrB_Semiring_new(C.byref(sr), mon, C.c_void_p(h("GrB_BAND_UINT32"))) == 0
+    w = gb.Vector.sparse(gb.UINT32, n)
+    assert lib.GrB_mxv(w._h, None, None, sr, A._h, u._h, None) == 0
+    gi, gx = w.to_arrays()
+    M = np.zeros((n, n), np.uint32); M[I, J] = X
+    exp = np.array([np.bitwise_or.reduce(M[i, dense[i]] & ux[dense[i]]) if dense[i].any() else 0 for i in range(n)], np.uint32)
+    rows = np.flatnonzero(dense.any(axis=1))
+    assert np.array_equal(gi.astype(np.int64), rows) and np.array_equal(gx, exp[rows])
+    lib.GrB_Semiring_free(C.byref(sr)); lib.GrB_Monoid_free(C.byref(mon))
+    # PLUS monoid with the POW multiplier: refused, with a reason
+    Af = gb.Matrix.from_arrays(I.astype(np.uint64), J.astype(np.uint64), X.astype(np.float64), n, n, gb.FP64)
+    uf = gb.Vector.from_arrays(np.arange(n, dtype=np.uint64), ux.astype(np.float64), n, gb.FP64)
+    wf = gb.Vector.sparse(gb.FP64, n)
+    sr2 = C.c_void_p()
+    assert lib.GrB_Semiring_new(C.byref(sr2), C.c_void_p(h("GrB_PLUS_MONOID_FP64")), C.c_void_p(h("GxB_POW_FP64"))) == 0
+    info = lib.GrB_mxv(wf._h, None, None, sr2, Af._h, uf._h, None)
+    assert info == 5                                                # GrB_INVALID_VALUE: "not implemented in the MI355X backend: ..."
+    msg = C.c_char_p()
+    lib.GrB_Vector_error(C.byref(msg), wf._h)
+    assert b"not implemented" in msg.value
+    assert wf.nvals == 0
+    lib.GrB_Semiring_free(C.byref(sr2))

@@ -464,6 +464,8 @@ GrB_Info GrBX_timer_stop(float *milliseconds);     /* hipEventRecord + synchroni
 GrB_Info GrBX_device_info(char *name, int name_len, int *compute_units, size_t *hbm_bytes);
 GrB_Info GrBX_memory_in_use(size_t *bytes);
 GrB_Info GrBX_last_kernel_plan(char *buf, int len); /* which kernels the last hot-path call launched */
+GrB_Info GrBX_last_plan_build_ms(float *milliseconds); /* device time of the most recent SpMV plan build (kernel X), 0 if none */
+GrB_Info GrBX_xcd_mapping(char *buf, int len);      /* how workgroups of a full-chip launch map to XCDs ("roundrobin8", or what was observed) */
 """)
 
 # typed families
