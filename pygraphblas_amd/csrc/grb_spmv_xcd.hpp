@@ -32,7 +32,8 @@
 namespace grb {
 
 constexpr int XP = 8;                 // panels = XCDs
-constexpr uint32_t XP_RB = 2048;      // rows per workgroup of the merge kernel
+constexpr uint32_t XP_RB = 1024;      // rows per workgroup of the merge kernel
+constexpr int XP_CT = 512;            // its threads
 constexpr uint32_t XP_UNIT = 16384;   // entries per unit of the plan-building sweeps
 constexpr int XP_ST = 512;            // threads of a sweep workgroup
 constexpr int XP_SW = XP_ST / 64;     // its waves
@@ -234,7 +235,7 @@ static __global__ __launch_bounds__(256) void k_xp_tile_flags(const uint32_t* __
 }
 // number the sub-rows: sub-row s (panel after panel, in entry order) starts at the s-th flagged entry
 static __global__ __launch_bounds__(256) void k_xp_subrows(const uint32_t* __restrict__ pcol, const uint32_t* __restrict__ rowtmp, const uint32_t* __restrict__ E, uint32_t ntiles,
-                                                           uint32_t* __restrict__ trow, uint32_t* __restrict__ subrow_row, uint16_t* __restrict__ lrow) {
+                                                           uint32_t* __restrict__ trow, uint32_t* __restrict__ subrow_row) {
   const uint32_t lane = threadIdx.x & 63;
   for (uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6); g < ntiles; g += gridDim.x * 4) {
     const size_t q0 = (size_t)g * WP_ENT + lane * 4;
@@ -247,7 +248,7 @@ static __global__ __launch_bounds__(256) void k_xp_subrows(const uint32_t* __res
     uint32_t s = E[g] + incl - mine;            // flagged entries before my first one
     if (lane == 0) trow[g] = E[g] - (f[0] ? 0u : 1u);
 #pragma unroll
-    for (int j = 0; j < 4; j++) if (f[j]) { const uint32_t r = rowtmp[q0 + j]; subrow_row[s] = r; lrow[s] = (uint16_t)(r % XP_RB); s++; }
+    for (int j = 0; j < 4; j++) if (f[j]) { const uint32_t r = rowtmp[q0 + j]; subrow_row[s] = r; s++; }
   }
 }
 static __global__ void k_xp_block_starts(const uint32_t* __restrict__ subrow_row, uint32_t nblocks, const uint32_t* __restrict__ E, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3,
@@ -267,33 +268,98 @@ template <class T> __global__ void k_xp_hot_gather(const T* __restrict__ u, cons
 }
 // y(i) = sum of the partials of row i's sub-rows, in panel order.  A workgroup owns XP_RB consecutive rows: their
 // sub-rows are one contiguous run in each panel (sub-rows are in row order inside a panel), so the eight runs are read
-// with coalesced loads and accumulated panel after panel in LDS — no per-row index chain, fixed order => reproducible.
-// A row that crosses a chunk boundary inside a panel has consecutive sub-rows there: the first of them adds the others.
+// with coalesced loads — all eight issued before the first is used: the kernel is a chain of dependent round trips
+// otherwise — and accumulated panel after panel in LDS: no per-row index chain, fixed order => reproducible.
+// A row that crosses a chunk boundary inside a panel has consecutive sub-rows there.  The plan marks them in the row-id
+// stream (XP_CONT: continues the sub-row before it, XP_HEAD: is followed by continuations), so that the common case
+// costs nothing: the head adds its continuations, the continuations themselves do nothing.
+constexpr uint32_t XP_CONT = 0x8000u, XP_HEAD = 0x4000u, XP_LROW = 0x07FFu;
+static_assert(XP_RB <= XP_LROW + 1, "row id inside a block and the two flags share 16 bits");
+static __global__ void k_xp_cont_flags(const uint32_t* __restrict__ subrow_row, const uint32_t* __restrict__ E, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t t4, uint32_t t5,
+                                       uint32_t t6, uint32_t t7, uint32_t t8, uint16_t* __restrict__ lrow) {
+  const uint32_t tb[XP + 1] = {t0, t1, t2, t3, t4, t5, t6, t7, t8};
+  uint32_t pb[XP + 1];
+#pragma unroll
+  for (int k = 0; k <= XP; k++) pb[k] = E[tb[k]];                 // first sub-row of every panel
+  const uint32_t F = pb[XP];
+  for (uint32_t s = blockIdx.x * 256 + threadIdx.x; s < F; s += gridDim.x * 256) {
+    const uint32_t r = subrow_row[s];
+    bool first = false, last = s + 1 == F;                        // first / last sub-row of its panel
+#pragma unroll
+    for (int k = 0; k <= XP; k++) { first = first || pb[k] == s; last = last || pb[k] == s + 1; }
+    const bool cont = !first && subrow_row[s - 1] == r, more = !last && subrow_row[s + 1] == r;
+    lrow[s] = (uint16_t)((r % XP_RB) | (cont ? XP_CONT : 0u) | (!cont && more ? XP_HEAD : 0u));
+  }
+}
+// What the kernel costs is latency and LDS instruction issue, not bytes (0.115 GB): a row block is a chain of dependent
+// round trips — bounds, data, then per panel an LDS write, a barrier and an LDS read-modify-write — and a CU holds only four
+// of these chains at a time (threads and LDS).  So the chain is kept short: all eight runs are loaded before the first is
+// used, the panels are folded two per barrier (even panels into one accumulator array, odd ones into another; y = even sum
+// + odd sum, a fixed order), and the read-modify-write reads the flag and the sum together instead of one after the other.
+// Measured on R-MAT-22 (40 us before): this version 38 us; without the LDS phases it would be 25 us shorter, without its
+// stores 6 us, without its loads 13 us.  Rejected: accumulators that start at the monoid's identity plus stamped continuation
+// slots (fewer LDS operations per sub-row, but 41 KB of LDS leave three workgroups per CU: 53 us); 320 threads per workgroup
+// (46 us: the blocks of the low row ids of un-permuted R-MAT hold 1000+ sub-rows per panel and need more rounds); a
+// persistent, software-pipelined version (buffer loads issued a block ahead, s_barrier behind lgkmcnt-only waits so that
+// the prefetch survives the barriers: 94-129 us — the same skew, which a static split of the blocks cannot balance).
+constexpr int XP_NA = 2;                      // accumulator arrays = panels folded per barrier
 template <class T, class SR>
-__global__ __launch_bounds__(512) void k_xp_combine(uint32_t nrows, const uint32_t* __restrict__ blockptr, const uint16_t* __restrict__ subrow_lrow, const T* __restrict__ partial,
-                                                    T* __restrict__ y, uint8_t* __restrict__ ypres, const SR sr) {
-  __shared__ T acc[XP_RB];
-  __shared__ uint8_t has[XP_RB];
-  const uint32_t b = blockIdx.x, r0 = b * XP_RB;
-  for (uint32_t i = threadIdx.x; i < XP_RB; i += 512) has[i] = 0;
-  uint32_t lo[XP], hi[XP];
+__global__ __launch_bounds__(XP_CT) void k_xp_combine(uint32_t nrows, const uint32_t* __restrict__ blockptr, const uint16_t* __restrict__ subrow_lrow, const T* __restrict__ partial,
+                                                      T* __restrict__ y, uint8_t* __restrict__ ypres, const SR sr) {
+  __shared__ T acc[XP_NA][XP_RB];
+  __shared__ uint8_t has[XP_NA][XP_RB];
+  __shared__ T cval[2][XP_NA][XP_CT];         // the partials of the continuation sub-rows of the current panels, by thread
+  __shared__ uint8_t ccont[2][XP_NA][XP_CT + 1];   // ... and whether thread t holds one (slot XP_CT: always 0)
+  const uint32_t b = blockIdx.x, r0 = b * XP_RB, tid = threadIdx.x;
+  for (uint32_t i = tid; i < XP_NA * XP_RB; i += XP_CT) (&has[0][0])[i] = 0;
+  if (tid < 2 * XP_NA) ccont[tid / XP_NA][tid % XP_NA][XP_CT] = 0;
+  uint32_t lo[XP], hi[XP], longest = 0;
 #pragma unroll
-  for (int k = 0; k < XP; k++) { lo[k] = blockptr[b * XP + k]; hi[k] = blockptr[(b + 1) * XP + k]; }
-  __syncthreads();
+  for (int k = 0; k < XP; k++) { lo[k] = blockptr[b * XP + k]; hi[k] = blockptr[(b + 1) * XP + k]; longest = hi[k] - lo[k] > longest ? hi[k] - lo[k] : longest; }
+  for (uint32_t base = 0; base < longest; base += XP_CT) {         // (one round unless the block holds more than XP_CT sub-rows of one panel)
+    uint32_t w[XP]; T v[XP];
 #pragma unroll
-  for (int k = 0; k < XP; k++) {
-    for (uint32_t s = lo[k] + threadIdx.x; s < hi[k]; s += 512) {         // one thread per row and panel: no two threads meet on a row
-      const uint32_t r = subrow_lrow[s];
-      if (s > lo[k] && subrow_lrow[s - 1] == r) continue;                 // a continuation: its row's first sub-row of the panel takes it
-      T v = partial[s];
-      for (uint32_t q = s + 1; q < hi[k] && subrow_lrow[q] == r; q++) v = sr.add(v, partial[q]);
-      if (has[r]) acc[r] = sr.add(acc[r], v); else { acc[r] = v; has[r] = 1; }
+    for (int k = 0; k < XP; k++) {
+      const uint32_t s = lo[k] + base + tid; const bool ok = s < hi[k];
+      w[k] = ok ? (uint32_t)subrow_lrow[s] : XP_CONT; v[k] = ok ? partial[s] : T();
+    }
+#pragma unroll
+    for (int k0 = 0; k0 < XP; k0 += XP_NA) {
+      const int buf = (k0 / XP_NA) & 1;
+#pragma unroll
+      for (int j = 0; j < XP_NA; j++) {
+        const int k = k0 + j;
+        const bool cont = (w[k] & XP_CONT) != 0 && lo[k] + base + tid < hi[k];
+        ccont[buf][j][tid] = cont ? 1 : 0;
+        if (cont) cval[buf][j][tid] = v[k];
+      }
+      __syncthreads();                                              // (also orders these panels' updates of acc behind those of the panels before)
+#pragma unroll
+      for (int j = 0; j < XP_NA; j++) {
+        const int k = k0 + j;
+        if (!(w[k] & XP_CONT)) {                                    // one thread per row and panel: no two threads meet on a row of one array
+          const uint32_t r = w[k] & XP_LROW; T x = v[k];
+          const bool h = has[j][r] != 0; const T a = acc[j][r];     // (a is junk while h is false)
+          if (w[k] & XP_HEAD) {                                     // my continuations sit in the threads after me, or (rarely) in the next round
+            uint32_t q = tid + 1;
+            while (ccont[buf][j][q]) { x = sr.add(x, cval[buf][j][q]); q++; }
+            if (q == XP_CT) for (uint32_t g = lo[k] + base + XP_CT; g < hi[k] && (subrow_lrow[g] & XP_CONT); g++) x = sr.add(x, partial[g]);
+          }
+          acc[j][r] = h ? sr.add(a, x) : x; has[j][r] = 1;
+        }
+      }
     }
     __syncthreads();
   }
-  for (uint32_t i = threadIdx.x; i < XP_RB; i += 512) {
+  __syncthreads();
+  for (uint32_t i = tid; i < XP_RB; i += XP_CT) {
     const uint32_t r = r0 + i;
-    if (r < nrows) { if (has[i]) y[r] = acc[i]; ypres[r] = has[i]; }
+    if (r < nrows) {
+      bool h = has[0][i] != 0; T x = acc[0][i];
+#pragma unroll
+      for (int j = 1; j < XP_NA; j++) { const bool hj = has[j][i] != 0; const T xj = acc[j][i]; x = h ? (hj ? sr.add(x, xj) : x) : xj; h = h || hj; }
+      y[r] = h ? x : T(); ypres[r] = h ? 1 : 0;
+    }
   }
 }
 
@@ -391,7 +457,9 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals) {
   P->trow.alloc(((size_t)ntiles + 1) * 4); P->lrow.alloc(P->F * 2 + 4);
   { unsigned nb = (ntiles + 3) / 4; if (nb < 1) nb = 1; if (nb > 16384) nb = 16384;
     hipLaunchKernelGGL(k_xp_subrows, dim3(nb), dim3(256), 0, stream(), P->pcol.as<uint32_t>(), rowtmp.as<uint32_t>(), E.as<uint32_t>(), ntiles, P->trow.as<uint32_t>(),
-                       subrow_row.as<uint32_t>(), P->lrow.as<uint16_t>()); }
+                       subrow_row.as<uint32_t>()); }
+  hipLaunchKernelGGL(k_xp_cont_flags, dim3(grid_n(P->F)), dim3(256), 0, stream(), subrow_row.as<uint32_t>(), E.as<uint32_t>(), P->tbase[0], P->tbase[1], P->tbase[2], P->tbase[3], P->tbase[4],
+                     P->tbase[5], P->tbase[6], P->tbase[7], P->tbase[8], P->lrow.as<uint16_t>());
   // 6. row blocks of the merge kernel: where each block's run of sub-rows starts in every panel
   const uint32_t nblocks = (uint32_t)(((uint64_t)M.nrows + XP_RB - 1) / XP_RB);
   P->blockptr.alloc(((size_t)nblocks + 1) * XP * 4 + 4);
@@ -445,7 +513,7 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
 #endif
     if (!launched) hipLaunchKernelGGL((k_spmv_tiles<T, SR>), dim3(ncu), dim3(XT_WAVES * 64), 0, stream(), call, (const XtPanel<T>*)P->args.p, sr);
     const uint32_t nblocks = (uint32_t)(((uint64_t)M.nrows + XP_RB - 1) / XP_RB);
-    hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3(nblocks), dim3(512), 0, stream(), M.nrows, P->blockptr.as<uint32_t>(), P->lrow.as<uint16_t>(), P->partial.as<T>(),
+    hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3(nblocks), dim3(XP_CT), 0, stream(), M.nrows, P->blockptr.as<uint32_t>(), P->lrow.as<uint16_t>(), P->partial.as<T>(),
                        (T*)c.tval, c.tpres, sr);
     g_last_plan += std::string("k_spmv_xcd<") + (sr.is_static ? "static" : "dynamic") + ",subrows=" + std::to_string(P->F) + "," + xcd_mapping() + "> ";
   });
