@@ -124,18 +124,22 @@ def permutation_torch(scale, device, seed):
     return perm
 
 
-def csr_numpy(scale, seed=42, edgefactor=16, symmetric=False, drop_self_loops=False, lower=False, row_range=None, permute_seed=None):
+def csr_numpy(scale, seed=42, edgefactor=16, symmetric=False, drop_self_loops=False, lower=False, row_range=None, permute_seed=None,
+              transpose=False):
     """Pattern CSR (rowptr u32, col u32) of the de-duplicated R-MAT graph (rows in row_range if given).
-    permute_seed: relabel the vertices pseudo-randomly first (None = keep the generator's labels)."""
+    permute_seed: relabel the vertices pseudo-randomly first (None = keep the generator's labels).
+    transpose: the CSR of A' instead of A (row_range then selects rows of A')."""
     src, dst = edges_numpy(scale, seed, edgefactor)
     if permute_seed is not None:
         perm = permutation_numpy(scale, permute_seed)
         src, dst = perm[src], perm[dst]
+    if transpose:
+        src, dst = dst, src
     return _finish_numpy(src, dst, 1 << scale, symmetric, drop_self_loops, lower, row_range)
 
 
 def csr_torch(scale, device, seed=42, edgefactor=16, symmetric=False, drop_self_loops=False, lower=False, row_range=None,
-              chunk=1 << 26, permute_seed=None):
+              chunk=1 << 26, permute_seed=None, transpose=False):
     """Same CSR as csr_numpy, built in HBM: returns (rowptr int32-as-uint32 tensor, col tensor) on `device`."""
     import torch
     n = 1 << scale
@@ -146,6 +150,8 @@ def csr_torch(scale, device, seed=42, edgefactor=16, symmetric=False, drop_self_
         s, d = edges_torch(scale, device, seed, edgefactor, first, min(chunk, m - first))
         if perm is not None:
             s, d = perm[s], perm[d]
+        if transpose:
+            s, d = d, s
         if symmetric:
             s, d = torch.cat([s, d]), torch.cat([d, s])
         keep = torch.ones_like(s, dtype=torch.bool)

@@ -1,0 +1,162 @@
+"""The row-partitioned workloads (pygraphblas_amd/dist.py) with the HIP kernels running in every rank.
+
+Two ranks share the one GPU of the box: RCCL refuses two ranks on one device, so the slices travel through the "host"
+transport (torch.distributed / gloo) — everything else (partitioning, diagonal / off-diagonal split, the products, the bit
+frontier, the reductions) is the code an 8-GPU run executes.  Each workload is compared with the single-process result:
+bit-exact for the BFS level vector and the INT64 triangle count, 1e-6 relative for the FP32 PageRank vector.
+The library's own RCCL path is exercised with a communicator of one rank (init, all-reduce, allgatherv, bits).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCALE = 14
+
+
+def _single_process_reference(gb):
+    """PageRank vector, BFS levels and the triangle count of R-MAT-14 computed by one process (the loops of the reference)."""
+    from pygraphblas_amd import rmat, dist as gdist, descriptor as D
+    n = 1 << SCALE
+    # PageRank on A' (rows of the transpose), exactly the distributed code with a world of one
+    comm = gdist.Comm(0, 1)
+    rp, col = rmat.csr_numpy(SCALE, transpose=True)
+    At = gb.Matrix.from_csr(gb.FP32, n, n, rp, col, np.ones(len(col), np.float32))
+    empty = gb.Matrix.sparse(gb.FP32, n, n)
+    rpa, _ = rmat.csr_numpy(SCALE)
+    deg = np.diff(rpa.astype(np.int64))
+    d = gb.Vector.from_arrays(np.flatnonzero(deg).astype(np.uint64), deg[deg > 0].astype(np.float32), n, gb.FP32)
+    r, its, rdiff = gdist.pagerank(comm, At, empty, d, n, [0, n])
+    pr = r.to_dense_arrays()[0]
+    # BFS
+    rps, cols = rmat.csr_numpy(SCALE, symmetric=True, drop_self_loops=True)
+    A = gb.Matrix.from_csr(gb.BOOL, n, n, rps, cols, np.ones(len(cols), np.bool_))
+    src = int(np.argmax(np.diff(rps.astype(np.int64))))
+    v = gb.Vector.sparse(gb.UINT8, n); q = gb.Vector.sparse(gb.BOOL, n); q[src] = True
+    level = 1
+    while q.reduce_bool() and level <= n:
+        v.assign_scalar(level, mask=q)
+        v.vxm(A, mask=v, out=q, desc=D.RC)
+        level += 1
+    lev = v.to_dense_arrays()[0]
+    # triangles
+    rpl, coll = rmat.csr_numpy(SCALE, symmetric=True, drop_self_loops=True, lower=True)
+    L = gb.Matrix.from_csr(gb.INT64, n, n, rpl, coll, np.ones(len(coll), np.int64))
+    tri = L.mxm(L, semiring=gb.INT64.PLUS_PAIR, mask=L).reduce_int()
+    return {"pr": pr, "its": its, "lev": lev, "depth": level - 1, "src": src, "tri": tri}
+
+
+def _worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["GRB_MI355X_DEVICE"] = "0"
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        import torch
+        import torch.distributed as tdist
+        tdist.init_process_group("gloo", rank=rank, world_size=world)
+        import pygraphblas_amd as gb
+        from pygraphblas_amd import rmat, dist as gdist
+        assert gb.device_info()["ok"]
+        n = 1 << SCALE
+        comm = gdist.Comm(rank, world, transport="host", tdist=tdist)
+        out = {}
+        # ---- PageRank: rows of A' balanced by entries, split into diagonal / off-diagonal columns
+        rp_all, _ = rmat.csr_numpy(SCALE, transpose=True)
+        bounds = gdist.balanced_row_blocks(rp_all.astype(np.int64), world)
+        r0, r1 = bounds[rank], bounds[rank + 1]
+        rp, col = rmat.csr_numpy(SCALE, transpose=True, row_range=(r0, r1))
+        (rpd, cd, _), (rpo, co, _) = gdist.split_csr_columns(torch.from_numpy(rp.view(np.int32)), torch.from_numpy(col.view(np.int32)), r0, r1)
+        mk = lambda p, c: gb.Matrix.from_csr(gb.FP32, r1 - r0, n, p.numpy().view(np.uint32), c.numpy().view(np.uint32), np.ones(c.numel(), np.float32))
+        Dm, Om = mk(rpd, cd), mk(rpo, co)
+        assert Dm.nvals + Om.nvals == len(col)
+        rpa, _ = rmat.csr_numpy(SCALE, row_range=(r0, r1))
+        deg = np.diff(rpa.astype(np.int64))
+        d = gb.Vector.from_arrays(np.flatnonzero(deg).astype(np.uint64), deg[deg > 0].astype(np.float32), r1 - r0, gb.FP32)
+        r, its, rdiff = gdist.pagerank(comm, Dm, Om, d, n, bounds)
+        out["pr"] = (r0, r1, r.to_dense_arrays()[0], its)
+        # ---- BFS: rows of the symmetric graph, frontier gathered as bits
+        rps_all, _ = rmat.csr_numpy(SCALE, symmetric=True, drop_self_loops=True)
+        b2 = gdist.balanced_row_blocks(rps_all.astype(np.int64), world)
+        s0, s1 = b2[rank], b2[rank + 1]
+        rps, cols = rmat.csr_numpy(SCALE, symmetric=True, drop_self_loops=True, row_range=(s0, s1))
+        Arows = gb.Matrix.from_csr(gb.BOOL, s1 - s0, n, rps, cols, np.ones(len(cols), np.bool_))
+        src = int(np.argmax(np.diff(rps_all.astype(np.int64))))
+        v_loc, depth = gdist.bfs_levels(comm, Arows, n, b2, src)
+        out["bfs"] = (s0, s1, v_loc.to_dense_arrays()[0], depth)
+        # ---- triangles: L replicated, rows balanced by the flop bound
+        rpl, coll = rmat.csr_numpy(SCALE, symmetric=True, drop_self_loops=True, lower=True)
+        b3 = gdist.flop_balanced_row_blocks(torch.from_numpy(rpl.view(np.int32)), torch.from_numpy(coll.view(np.int32)), world)
+        t0, t1 = b3[rank], b3[rank + 1]
+        L = gb.Matrix.from_csr(gb.INT64, n, n, rpl, coll, np.ones(len(coll), np.int64))
+        e0, e1 = int(rpl[t0]), int(rpl[t1])
+        Lrows = gb.Matrix.from_csr(gb.INT64, t1 - t0, n, (rpl[t0:t1 + 1] - rpl[t0]).astype(np.uint32), coll[e0:e1], np.ones(e1 - e0, np.int64))
+        out["tri"] = (gdist.triangle_count(comm, Lrows, L), t0, t1)
+        q.put((rank, out))
+        tdist.destroy_process_group()
+    except Exception as e:          # noqa: BLE001 — surface the failure in the parent
+        import traceback
+        q.put((rank, {"error": traceback.format_exc() + repr(e)}))
+
+
+def test_two_ranks_on_one_gpu_match_the_single_process_results(gb, gpu):
+    import torch.multiprocessing as mp
+    ref = _single_process_reference(gb)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    for r in (0, 1):
+        assert "error" not in res[r], res[r]["error"]
+    n = 1 << SCALE
+    pr = np.zeros(n, np.float32); lev = np.zeros(n, np.uint8)
+    for r in (0, 1):
+        a, b, x, its = res[r]["pr"]; pr[a:b] = x
+        assert its == ref["its"]
+        a, b, x, depth = res[r]["bfs"]; lev[a:b] = x
+        assert depth == ref["depth"]
+    assert res[0]["pr"][1] == res[1]["pr"][0] and 0 < res[0]["pr"][1] < n            # two non-empty blocks
+    assert np.allclose(pr, ref["pr"], rtol=1e-6, atol=0.0)
+    assert np.array_equal(lev, ref["lev"])                                              # bit-exact level vector
+    assert res[0]["tri"][0] == res[1]["tri"][0] == ref["tri"]                           # INT64, exact
+    assert 0 < res[0]["tri"][2] < n
+
+
+def test_library_rccl_path_with_a_communicator_of_one(gb, gpu):
+    """GrBX_dist_init / allreduce / allgatherv / allgatherv_bits through RCCL itself (one rank: what a 1-GPU box allows)."""
+    import ctypes as C
+    lib = gb.lib
+    ident = C.create_string_buffer(128)
+    assert lib.GrBX_dist_unique_id(ident, C.c_int(128)) == 0
+    assert lib.GrBX_dist_init(C.c_int(0), C.c_int(1), ident, C.c_int(128)) == 0
+    try:
+        x = np.array([3.5, -1.25], np.float64)
+        assert lib.GrBX_dist_allreduce(x.ctypes.data_as(C.c_void_p), C.c_uint64(2), C.c_void_p(gb.FP64._h), C.c_void_p(gb.FP64.PLUS.get_op())) == 0
+        assert x.tolist() == [3.5, -1.25]
+        k = np.array([2 ** 40 + 7], np.int64)
+        assert lib.GrBX_dist_allreduce(k.ctypes.data_as(C.c_void_p), C.c_uint64(1), C.c_void_p(gb.INT64._h), C.c_void_p(gb.INT64.PLUS.get_op())) == 0
+        assert int(k[0]) == 2 ** 40 + 7
+        n = 1000
+        rng = np.random.default_rng(5)
+        idx = np.sort(rng.choice(n, 300, replace=False)).astype(np.uint64)
+        loc = gb.Vector.from_arrays(idx, rng.random(300), n, gb.FP64)
+        full = gb.Vector.dense(gb.FP64, n, fill=0.0)
+        b = np.array([0, n], np.uint64)
+        assert lib.GrBX_Vector_allgatherv(full._h, loc._h, b.ctypes.data_as(C.c_void_p), C.c_int(1)) == 0
+        assert lib.GrBX_Vector_device_touch(full._h) == 0
+        fi, fx = full.to_arrays(); li, lx = loc.to_arrays()
+        assert np.array_equal(fi, li) and np.array_equal(fx, lx)
+        ql = gb.Vector.from_arrays(idx, rng.integers(0, 2, 300).astype(np.bool_), n, gb.BOOL)
+        qf = gb.Vector.sparse(gb.BOOL, n)
+        assert lib.GrBX_Vector_allgatherv_bits(qf._h, ql._h, b.ctypes.data_as(C.c_void_p)) == 0
+        qi, qx = qf.to_arrays(); ei, ex = ql.to_arrays()
+        assert np.array_equal(qi, ei[ex]) and qx.all()                                   # only the `true` entries travel
+    finally:
+        assert lib.GrBX_dist_finalize() == 0

@@ -195,3 +195,32 @@ def test_matrix_random_is_the_reference_generator(gb):
     m = gb.Matrix.random(gb.FP64, 10_000, 1000, 1000, seed=42)       # BASELINE.json configs[0]
     assert m.nvals == 9949                                            # 51 of the 10 000 coordinates repeat
     assert gb.Matrix.random(gb.UINT8, 20, 5, 5, make_symmetric=True, no_diagonal=True, seed=42).nvals <= 20
+
+
+def test_dist_partition_helpers_on_cpu():
+    """split_csr_columns / flop_balanced_row_blocks (pygraphblas_amd/dist.py) against plain numpy on a small R-MAT."""
+    import torch
+    from pygraphblas_amd import rmat, dist as gdist
+    scale = 9; n = 1 << scale
+    rp, col = rmat.csr_numpy(scale, symmetric=True, drop_self_loops=True, lower=True)
+    trp, tcol = torch.from_numpy(rp.view(np.int32)), torch.from_numpy(col.view(np.int32))
+    c0, c1 = 100, 300
+    (rpd, cd, vd), (rpo, co, vo) = gdist.split_csr_columns(trp, tcol, c0, c1, torch.arange(len(col)))
+    rows = np.repeat(np.arange(n), np.diff(rp.astype(np.int64)))
+    inside = (col >= c0) & (col < c1)
+    assert np.array_equal(cd.numpy().view(np.uint32), col[inside]) and np.array_equal(co.numpy().view(np.uint32), col[~inside])
+    assert np.array_equal(np.diff(rpd.numpy()), np.bincount(rows[inside], minlength=n))
+    assert np.array_equal(np.diff(rpo.numpy()), np.bincount(rows[~inside], minlength=n))
+    assert np.array_equal(vd.numpy(), np.flatnonzero(inside))                 # values travel with their entries
+    b = gdist.flop_balanced_row_blocks(trp, tcol, 4)
+    deg = np.diff(rp.astype(np.int64))
+    rowflops = np.add.reduceat(np.append(deg[col], 0), rp[:-1].astype(np.int64)) * (deg > 0)
+    parts = [rowflops[b[i]:b[i + 1]].sum() for i in range(4)]
+    assert b[0] == 0 and b[-1] == n and sum(parts) == rowflops.sum()
+    assert max(parts) <= rowflops.sum() / 4 + rowflops.max()                  # balanced up to one row
+    # transpose option of the generator: rows of A' are the columns of A
+    rpa, ca = rmat.csr_numpy(scale); rpt, ct = rmat.csr_numpy(scale, transpose=True)
+    import scipy.sparse as sp
+    M = sp.csr_matrix((np.ones(len(ca)), ca.astype(np.int64), rpa.astype(np.int64)), shape=(n, n))
+    Mt = sp.csr_matrix((np.ones(len(ct)), ct.astype(np.int64), rpt.astype(np.int64)), shape=(n, n))
+    assert (M.T != Mt).nnz == 0

@@ -466,6 +466,17 @@ GrB_Info GrBX_memory_in_use(size_t *bytes);
 GrB_Info GrBX_last_kernel_plan(char *buf, int len); /* which kernels the last hot-path call launched */
 GrB_Info GrBX_last_plan_build_ms(float *milliseconds); /* device time of the most recent SpMV plan build (kernel X), 0 if none */
 GrB_Info GrBX_xcd_mapping(char *buf, int len);      /* how workgroups of a full-chip launch map to XCDs ("roundrobin8", or what was observed) */
+/* The exchange steps of the row-partitioned path (one process per GPU; RCCL over xGMI; grb_dist.cpp).  The reference has no
+ * distributed code: these replace nothing in it, they are what BASELINE.json's north star adds (SURVEY.md section 8e). */
+GrB_Info GrBX_dist_unique_id(void *id, int len);      /* 128 bytes, made on one rank and handed to all (any channel) */
+GrB_Info GrBX_dist_init(int rank, int world, const void *id, int len);   /* ncclCommInitRank on this process's GPU */
+GrB_Info GrBX_dist_finalize(void);
+GrB_Info GrBX_dist_info(int *rank, int *world);
+GrB_Info GrBX_Vector_allgatherv_start(GrB_Vector full, const GrB_Vector local, const GrB_Index *bounds, int presence);
+GrB_Info GrBX_dist_wait(void);                        /* the compute stream waits for the exchange started above */
+GrB_Info GrBX_Vector_allgatherv(GrB_Vector full, const GrB_Vector local, const GrB_Index *bounds, int presence);
+GrB_Info GrBX_Vector_allgatherv_bits(GrB_Vector full, const GrB_Vector local, const GrB_Index *bounds);   /* BOOL frontier, 1 bit per vertex */
+GrB_Info GrBX_dist_allreduce(void *host_buf, GrB_Index count, GrB_Type type, GrB_BinaryOp op);
 """)
 
 # typed families
