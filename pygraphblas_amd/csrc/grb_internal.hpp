@@ -184,6 +184,7 @@ void cast_scalar(int dst_code, void* dst, int src_code, const void* src);
 void csr_transpose(const DevCSR& A, size_t tsize, DevCSR& At);
 // grb_vecops.hip
 void vec_cast_values(int dst_code, void* dst, int src_code, const void* src, uint64_t n);
+void vec_cast_fill_values(int dst_code, void* dst, int src_code, const void* src, const uint8_t* pres, uint64_t n, const void* fill);
 void build_allow(uint64_t n, int mcode, const void* mval, const uint8_t* mpres, bool structural,
                  bool complement, uint8_t* allow);
 uint64_t count_present(const uint8_t* pres, uint64_t n);

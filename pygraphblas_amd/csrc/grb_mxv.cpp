@@ -65,7 +65,25 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
 
   const size_t zs = type_size(sd.zcode);
   DevBuf tval(mr * zs + 1), tpres(mr + 1), ucast, acast;
-  const void* uval = uses_u ? cast_values(sd.zcode, u->type->code, u->dval.p, u->n, ucast) : nullptr;
+  // An operand with holes whose product is accumulated into a full vector with the monoid's own operator, no mask (PageRank:
+  // r<accum PLUS> += A' (+).second w, w = t / d has no entry for dangling vertices — gap/prmark.py:21-23): where T has no
+  // entry the output keeps its value, and where T's entries would come from absent operand entries only, accumulating the
+  // monoid's identity keeps it too.  So the pattern of T does not matter, and the holes can be filled with a value z for
+  // which mult(a, z) is the identity — z = identity for SECOND (any monoid), 0 for integer PLUS_TIMES, false for LOR_LAND —
+  // in the same pass that casts the operand; the product then runs as a full-operand one (kernel X / W instead of the
+  // bitmap variant of the row-block kernel: 0.60 -> 0.17 ms at R-MAT-22).
+  bool fill_holes = false;
+  if (!push && !u_full && !mask && accum && method == SPMV_AUTO && !sd.flip && check_obj(accum) && accum->opcode == sd.addop && accum->xtype->code == sd.zcode &&
+      w->type->code == sd.zcode && w->dev_valid && !w->host_valid && w->dnvals_known && w->dnvals == w->n && w != u) {
+    const bool is_int = sd.zcode != T_FP32 && sd.zcode != T_FP64 && sd.zcode != T_BOOL;
+    fill_holes = sd.mulop == B_SECOND || (sd.mulop == B_TIMES && sd.addop == B_PLUS && is_int) || (sd.mulop == B_LAND && sd.addop == B_LOR && sd.zcode == T_BOOL);
+  }
+  const void* uval = nullptr;
+  if (uses_u && fill_holes) {
+    ucast.alloc(u->n * zs + 1);
+    vec_cast_fill_values(sd.zcode, ucast.p, u->type->code, u->dval.p, u->dpres.as<uint8_t>(), u->n, sd.identity);   // (identity of PLUS / LOR is the 0 / false the two other cases need)
+    uval = ucast.p;
+  } else if (uses_u) uval = cast_values(sd.zcode, u->type->code, u->dval.p, u->n, ucast);
 
   SpmvCall call{};
   call.uval = uval; call.allow = allow; call.tval = tval.p; call.tpres = tpres.as<uint8_t>(); call.method = method;
@@ -77,7 +95,7 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
     spmspv_push(call, sd, u_nvals);
   } else {
     DevCSR& R = useT ? const_cast<DevCSR&>(mat_csc(A)) : A->csr;
-    call.M = &R; call.upres = u_full ? nullptr : u->dpres.as<uint8_t>();
+    call.M = &R; call.upres = (u_full || fill_holes) ? nullptr : u->dpres.as<uint8_t>();
     call.aval = uses_a ? cast_values(sd.zcode, A->type->code, R.val.p, R.nnz, acast) : nullptr;
     spmv_pull(call, sd);
   }

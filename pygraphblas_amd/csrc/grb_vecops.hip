@@ -26,6 +26,21 @@ void vec_cast_values(int dst_code, void* dst, int src_code, const void* src, uin
   });
 }
 
+// values of a bitmap vector cast into another type with the absent positions filled (one pass): what lets a product whose
+// result pattern does not matter treat an operand with holes as a full one (grb_mxv.cpp)
+template <class D, class S> __global__ void k_cast_fill(D* __restrict__ dst, const S* __restrict__ src, const uint8_t* __restrict__ pres, uint64_t n, D fill) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) dst[i] = pres[i] ? cast_to<D, S>(src[i]) : fill;
+}
+void vec_cast_fill_values(int dst_code, void* dst, int src_code, const void* src, const uint8_t* pres, uint64_t n, const void* fill) {
+  if (!n) return;
+  dispatch_type(src_code, [&]<class S>() {
+    dispatch_type(dst_code, [&]<class D>() {
+      D f; memcpy(&f, fill, sizeof(D));
+      hipLaunchKernelGGL((k_cast_fill<D, S>), dim3(grid_for(n)), dim3(256), 0, stream(), (D*)dst, (const S*)src, pres, n, f);
+    });
+  });
+}
+
 // ---- mask -> allow bytes ------------------------------------------------------------------------------
 template <class M> __global__ void k_allow(uint64_t n, const M* __restrict__ mval, const uint8_t* __restrict__ mpres,
                                            bool structural, bool complement, uint8_t* __restrict__ allow) {

@@ -156,3 +156,63 @@ def test_config4_rmat22_pagerank_step_fp32(gb, torch_dev, mtype):
     assert np.allclose(gr, exp, rtol=1e-6, atol=0.0)
     y64 = At.astype(np.float64) @ ws.cpu().numpy().astype(np.float64)          # second opinion: scipy in FP64
     assert np.allclose(gr, teleport + y64, rtol=1e-6, atol=0.0)
+
+
+def test_config4_rmat22_pagerank_loop_with_dangling_vertices(gb, torch_dev):
+    """The whole loop of gap/prmark.py:8-30 (world of one, pygraphblas_amd.dist.pagerank): w = t / d has no entry for the
+    dangling vertices (half of R-MAT-22's), r is full and accumulates with PLUS — the product may then treat the holes of w as
+    the monoid's identity and run the full-operand kernel.  Compared with the same iteration in FP64 (scipy): same number
+    of iterations, every rank value within 1e-6."""
+    torch, dev = torch_dev
+    import scipy.sparse as sp
+    from pygraphblas_amd import rmat, dist as gdist
+    n = 1 << SCALE
+    rowptr, col = rmat.csr_torch(SCALE, dev, seed=42, transpose=True)                    # rows of A'
+    nnz = int(col.numel())
+    ones = torch.ones(nnz, dtype=torch.float32, device=dev)
+    At = gb.Matrix.from_csr(gb.FP32, n, n, rowptr.data_ptr(), col.data_ptr(), (ones.data_ptr(), nnz), device=True)
+    none = gb.Matrix.sparse(gb.FP32, n, n)
+    rp, ci = rowptr.cpu().numpy().view(np.uint32).astype(np.int64), col.cpu().numpy().view(np.uint32).astype(np.int64)
+    deg = np.bincount(ci, minlength=n).astype(np.float64)                                # out-degree of j = entries in column j of A'
+    assert (deg == 0).sum() > n // 4                                                     # plenty of dangling vertices
+    d = gb.Vector.from_arrays(np.flatnonzero(deg).astype(np.uint64), deg[deg > 0].astype(np.float32), n, gb.FP32)
+    r, its, rdiff = gdist.pagerank(gdist.Comm(0, 1), At, none, d, n, [0, n])
+    gr, gp = r.to_dense_arrays()
+    assert gp.all()
+    M = sp.csr_matrix((np.ones(nnz), ci, rp), shape=(n, n))
+    dd = np.where(deg > 0, deg / 0.85, np.nan); rr = np.full(n, 1.0 / n); tt = np.zeros(n); k = 0
+    for i in range(100):
+        tt, rr = rr, tt
+        w = np.where(deg > 0, tt / dd, 0.0)
+        rr = (1 - 0.85) / n + M @ w
+        k = i + 1
+        if np.abs(tt - rr).sum() <= 1e-4:
+            break
+    assert its == k
+    assert np.allclose(gr, rr, rtol=1e-6, atol=0.0)
+
+
+def test_holes_filled_with_the_identity_only_when_the_pattern_cannot_matter(gb, gpu):
+    """Small cases around the fast path above: with a sparse output, a mask, or another accumulator the product must keep
+    the exact pattern semantics (oracle), and with a full output + same-operator accumulator the values must agree."""
+    rng = np.random.default_rng(11)
+    n = 300
+    flat = np.sort(rng.choice(n * n, 4000, replace=False)).astype(np.uint64)
+    I, J = np.divmod(flat, np.uint64(n)); X = rng.integers(1, 5, len(flat)).astype(np.float32)
+    A = gb.Matrix.from_arrays(I, J, X, n, n, gb.FP32)
+    ui = np.sort(rng.choice(n, 120, replace=False)).astype(np.uint64); ux = rng.integers(1, 9, 120).astype(np.float32)
+    u = gb.Vector.from_arrays(ui, ux, n, gb.FP32)
+    At = O.Tuples("FP32", n, n, I, J, X); uo = O.col_vector("FP32", n, ui, ux)
+    for full_out in (True, False):
+        for acc in ("PLUS", "MIN"):
+            wi = np.arange(n, dtype=np.uint64) if full_out else np.sort(rng.choice(n, 50, replace=False)).astype(np.uint64)
+            wx = rng.integers(1, 9, len(wi)).astype(np.float32)
+            if full_out:
+                w = gb.Vector.dense(gb.FP32, n, fill=0.0); w += gb.Vector.from_arrays(wi, wx, n, gb.FP32)      # full, resident in HBM
+            else:
+                w = gb.Vector.from_arrays(wi, wx, n, gb.FP32)
+            A.mxv(u, out=w, accum=getattr(gb.FP32, acc), semiring=gb.FP32.PLUS_SECOND)
+            exp = O.mxv(O.col_vector("FP32", n, wi, wx), At, uo, "PLUS", "SECOND", "FP32", accum=acc)
+            gi, gx = w.to_arrays()
+            assert np.array_equal(gi, exp.I), (full_out, acc)
+            assert np.allclose(gx, exp.X, rtol=1e-6, atol=0.0), (full_out, acc)
