@@ -28,6 +28,16 @@ with open(_HEADER) as _f:
 # cffi knows FILE and the stdint types; the header has no preprocessor logic beyond integer #defines
 ffi.cdef(_src)
 lib = ffi.dlopen(_LIB)
+# Resolve every function of the header now.  In ABI mode cffi binds a name at its first use, under the FFI object's
+# (non-reentrant) lock — the same lock ffi.new() holds while it parses a C type string for the first time.  pygraphblas
+# frees its handles from __del__ (lib.GrB_Matrix_free, pygraphblas/matrix.py:117): a garbage collection that runs inside
+# such a parse and is the first ever to need a *_free would wait for a lock its own thread holds.  (The compiled,
+# API-mode suitesparse_graphblas binds everything at import, as this loop does.)
+for _name in re.findall(r"^GrB_Info\s+(\w+)\s*\(", _src, flags=re.M):
+    try:
+        getattr(lib, _name)
+    except AttributeError:      # declared, not exported: stays an AttributeError at the call site
+        pass
 
 __version__ = "5.1.0+mi355x"
 _initialized = False
