@@ -14,6 +14,11 @@
 
 using namespace grb;
 
+namespace grb {
+bool mxm_few_rows_wanted(const DevCSR& Ad, const DevCSR& Bd);
+void mxm_few_rows(const DevCSR& Ad, GrB_Type atype, GrB_Matrix Mmask, const DescView& dv, GrB_Semiring semiring, GrB_Matrix B, int zcode, DevCSR& T);
+}
+
 namespace {
 
 struct CsrView { const DevCSR* m; DevBuf vals; const void* v; };
@@ -86,7 +91,9 @@ void do_mxm(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, GrB_Semiring semirin
   call.aval = uses_a ? cast_values(sd.zcode, A->type->code, Ad.val.p, Ad.nnz, acast) : nullptr;
   call.bval = uses_b ? cast_values(sd.zcode, B->type->code, Bd.val.p, Bd.nnz, bcast) : nullptr;
   DevCSR T; bool t_masked = false;
-  if (M && !dv.mask_comp) {
+  if (mxm_few_rows_wanted(Ad, Bd)) {            // a handful of output rows (batched BC frontiers): one vxm per row, see grb_mxm_rows.cpp
+    mxm_few_rows(Ad, A->type, M, dv, semiring, B, sd.zcode, T); t_masked = true;
+  } else if (M && !dv.mask_comp) {
     mat_to_device(M);
     call.M = &M->csr; call.mcode = M->type->code; call.mstruct = dv.mask_struct;
     spgemm_masked(call, sd, T); t_masked = true;

@@ -147,3 +147,48 @@ def test_karate_club_has_45_triangles(gpu):
     A = L.eadd(U)
     assert L.mxm(U, mask=A).reduce_int() // 2 == 45           # "cohen"
     assert sum(nx.triangles(G).values()) // 3 == 45
+
+
+@pytest.mark.parametrize("rows_path", [False, True])
+@pytest.mark.parametrize("ns,scale", [(4, 10), (4, 13), (16, 11)])
+def test_bc_batched_frontier_step(gpu, ns, scale, rows_path, monkeypatch):
+    """The inner step of the reference's batched betweenness centrality (gap/bcmark.py:16-44):
+        frontier<!paths, replace> = frontier (+).first A        (FP32.PLUS_FIRST, out aliases the operand)
+    with `paths` a DENSE ns x n FP32 matrix whose zeros mean "not reached yet" (a valued, complemented mask) and the frontier
+    a batch of ns sparse rows; then `paths += frontier`.  Two consecutive levels from ns sources, against the oracle."""
+    # rows_path: the product as one vxm per frontier row (grb_mxm_rows.cpp; chosen by itself for a left operand of <= 64 rows
+    # against a matrix of >= 2^20 entries — forced here on the small graph), else the generic masked / expand-sort-compress path
+    monkeypatch.setenv("GRB_MI355X_MXM_ROWS", "1" if rows_path else "0")
+    n = 1 << scale
+    rp, col = rmat.csr_numpy(scale, symmetric=True, drop_self_loops=True)
+    rows = np.repeat(np.arange(n, dtype=np.uint64), np.diff(rp.astype(np.int64)))
+    A = gb.Matrix.from_csr(gb.FP32, n, n, rp, col, np.ones(len(col), np.float32))
+    At = O.Tuples("FP32", n, n, rows, col.astype(np.uint64), np.ones(len(col), np.float32))
+    deg = np.diff(rp.astype(np.int64))
+    sources = np.argsort(-deg, kind="stable")[:ns].astype(np.uint64)              # high-degree sources: wide frontiers
+    dI = np.repeat(np.arange(ns, dtype=np.uint64), n); dJ = np.tile(np.arange(n, dtype=np.uint64), ns)
+    pv = np.zeros(ns * n, np.float32); pv[np.arange(ns) * n + sources.astype(np.int64)] = 1.0
+    paths = gb.Matrix.from_arrays(dI, dJ, pv, ns, n, gb.FP32)
+    frontier = gb.Matrix.from_arrays(np.arange(ns, dtype=np.uint64), sources, np.ones(ns, np.float32), ns, n, gb.FP32)
+    po = O.Tuples("FP32", ns, n, dI, dJ, pv.copy())
+    fo = O.Tuples("FP32", ns, n, np.arange(ns, dtype=np.uint64), sources, np.ones(ns, np.float32))
+    for level in range(2):
+        frontier.mxm(A, out=frontier, mask=paths, semiring=gb.FP32.PLUS_FIRST, desc=D.RC)
+        fo = O.mxm(fo, fo, At, "PLUS", "FIRST", "FP32", mask=po, mask_comp=True, replace=True)
+        check(frontier, fo, "FP32", what=f"BC frontier level {level} ns={ns}")
+        assert ("mxm_rows" in gb.last_kernel_plan()) == rows_path
+        assert frontier.nvals > ns
+        paths = paths.eadd(frontier, gb.FP32.PLUS)                                # paths.assign_matrix(frontier, accum=PLUS) on a dense matrix
+        acc = po.X.copy(); acc[(fo.I * np.uint64(n) + fo.J).astype(np.int64)] += fo.X
+        po = O.Tuples("FP32", ns, n, dI, dJ, acc)
+        check(paths, po, "FP32", what="BC paths")
+
+
+def test_few_row_products_through_vxm_match_the_oracle(gpu, monkeypatch):
+    """Other shapes of the row-wise path: no mask, structural mask, accumulator, transposed B, integer MIN_PLUS, an empty row."""
+    monkeypatch.setenv("GRB_MI355X_MXM_ROWS", "1")
+    rng = np.random.default_rng(77)
+    for typ, sr, kw in (("INT64", "MIN_PLUS", {}), ("FP64", "PLUS_TIMES", {"mask": {"typ": "BOOL", "struct": True}}), ("INT32", "PLUS_PAIR", {"accum": "PLUS"}),
+                        ("BOOL", "LOR_LAND", {"mask": {"typ": "INT8", "comp": True}, "replace": True}), ("FP32", "PLUS_SECOND", {"tb": True})):
+        run_case(rng, typ, sr, 5, 40, 37, 0.15, 0.2, **kw)
+    assert "mxm_rows" in gb.last_kernel_plan()

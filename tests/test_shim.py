@@ -66,3 +66,20 @@ def test_unmodified_reference_imports_and_runs_its_gpu_free_tests(gb):
     # -k matches substrings, so a few arithmetic tests ride along: without a GPU they must fail loudly (Panic), nothing else
     other = [l for l in r.stdout.splitlines() if l.startswith("FAILED") and "Panic" not in l]
     assert not other, other
+
+
+@needs39
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_unmodified_reference_reads_its_own_grb_fixture_through_the_shim(gb, tmp_path):
+    """`Matrix.from_binfile` of the reference (pygraphblas/matrix.py:489-497 -> suitesparse_graphblas.io.binary.binread, here
+    shim/suitesparse_graphblas/io/binary.py) on docs/test_binfile.grb == docs/test_mm.mm; to_binfile round-trips."""
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "shim") + ":" + REF)
+    code = ("from pygraphblas import *; "
+            f"M = Matrix.from_binfile('{REF}/docs/test_binfile.grb'); "
+            "assert M.type is INT64 and M.shape == (7, 7) and M.nvals == 12; "
+            "mm = [l.split() for l in open('" + REF + "/docs/test_mm.mm') if not l.startswith('%')][1:]; "
+            "want = sorted((int(a) - 1, int(b) - 1, int(c)) for a, b, c in mm); "
+            "I, J, X = M.to_lists(); assert sorted(zip(I, J, X)) == want; "
+            f"M.to_binfile('{tmp_path}/rt.grb'); M2 = Matrix.from_binfile('{tmp_path}/rt.grb'); assert M2.to_lists() == M.to_lists(); print('OK grb')")
+    r = subprocess.run([PY39, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")
+    assert r.returncode == 0 and "OK grb" in r.stdout, r.stdout + r.stderr

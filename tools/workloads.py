@@ -11,7 +11,7 @@ from pygraphblas_amd import rmat, descriptor as D
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--scale", type=int, default=22)
-ap.add_argument("--what", default="bfs,tc,pr")
+ap.add_argument("--what", default="bfs,tc,pr,bc")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--no-check", action="store_true")
 args = ap.parse_args()
@@ -150,3 +150,36 @@ if "pr" in args.what:
         rel = np.abs(rv.astype(np.float64) - rr) / np.abs(rr)
         out["parity"] = {"iterations_equal": bool(k == its), "max_rel_err_vs_fp64": float(rel.max()), "all_present": bool(rp_.all())}
     print(json.dumps(out), flush=True)
+
+
+if "bc" in args.what:
+    # the batched-frontier step of gap/bcmark.py:16-44: frontier<!paths,replace> = frontier (+).first A, ns = 4 sources, FP32
+    ns = 4
+    rowptr, col = rmat.csr_torch(args.scale, dev, seed=42, symmetric=True, drop_self_loops=True)
+    nnz = col.numel()
+    vals = torch.ones(nnz, dtype=torch.float32, device=dev)
+    A = gb.Matrix.from_csr(gb.FP32, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+    deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+    sources = torch.argsort(deg, descending=True, stable=True)[:ns]
+    prp = (torch.arange(ns + 1, device=dev, dtype=torch.int64) * n).to(torch.int32)
+    pcol = torch.arange(n, device=dev, dtype=torch.int32).repeat(ns)
+    def fresh():
+        pv = torch.zeros(ns * n, dtype=torch.float32, device=dev); pv[torch.arange(ns, device=dev) * n + sources] = 1.0
+        paths = gb.Matrix.from_csr(gb.FP32, ns, n, prp.data_ptr(), pcol.data_ptr(), (pv.data_ptr(), ns * n), device=True)
+        frp = torch.arange(ns + 1, device=dev, dtype=torch.int32); fv = torch.ones(ns, dtype=torch.float32, device=dev)
+        frontier = gb.Matrix.from_csr(gb.FP32, ns, n, frp.data_ptr(), sources.to(torch.int32).data_ptr(), (fv.data_ptr(), ns), device=True)
+        return paths, frontier
+    levels = []
+    for rep in range(2):                                        # second pass: warm pool / cached structures
+        paths, frontier = fresh(); levels = []
+        for depth in range(n):
+            torch.cuda.synchronize(); t = time.perf_counter()
+            frontier.mxm(A, out=frontier, mask=paths, semiring=gb.FP32.PLUS_FIRST, desc=D.RC)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t
+            nv = frontier.nvals
+            levels.append({"depth": depth, "seconds": round(dt, 5), "frontier_nvals": nv, "plan": gb.last_kernel_plan()})
+            if nv == 0:
+                break
+            paths = paths.eadd(frontier, gb.FP32.PLUS)
+    print(json.dumps({"workload": f"BC batched-frontier step R-MAT-{args.scale}, ns={ns}: frontier<!paths,replace> = frontier PLUS_FIRST A (gap/bcmark.py:16-44)", "n": n, "nnz": nnz,
+                      "seconds_all_levels": round(sum(l["seconds"] for l in levels), 5), "levels": levels}), flush=True)
