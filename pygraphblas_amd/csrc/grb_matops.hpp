@@ -23,7 +23,9 @@ struct SpgemmCall {
 };
 // T<M> = A (+).(x) B restricted to the entries the mask allows; T's pattern is a subset of M's
 void spgemm_masked(const SpgemmCall& c, const SemiringDesc& d, DevCSR& out);
-// T = A (+).(x) B by expand / sort / compress
+// T = A (+).(x) B by expand / sort / compress (deterministic summation order)
 void spgemm_esc(const SpgemmCall& c, const SemiringDesc& d, DevCSR& out);
+// T = A (+).(x) B by a two-pass (symbolic + numeric) Gustavson with LDS hash accumulators (grb_spgemm_hash.hpp)
+void spgemm_hash(const SpgemmCall& c, const SemiringDesc& d, DevCSR& out);
 
 }  // namespace grb

@@ -98,7 +98,10 @@ void do_mxm(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, GrB_Semiring semirin
     call.M = &M->csr; call.mcode = M->type->code; call.mstruct = dv.mask_struct;
     spgemm_masked(call, sd, T); t_masked = true;
   } else {
-    spgemm_esc(call, sd, T);
+    // no mask, or a complemented one (applied by the write-back): the two-pass LDS-hash Gustavson; expand / sort / compress on
+    // request (it forms floating-point sums in a fixed order): GRB_MI355X_SPGEMM=esc or the descriptor's AxB method GxB_AxB_DOT
+    const char* e = getenv("GRB_MI355X_SPGEMM");
+    if ((e && !strcmp(e, "esc")) || dv.axb == GxB_AxB_DOT) spgemm_esc(call, sd, T); else spgemm_hash(call, sd, T);
   }
   matrix_write_back(C, T, sd.zcode, M, dv, accum, t_masked);
 }

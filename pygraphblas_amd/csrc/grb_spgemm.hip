@@ -7,11 +7,15 @@ namespace grb {
 AuxStreams& aux_streams() { static AuxStreams a; return a; }
 template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDesc& d, DevCSR& out);
 template <class T> void run_spgemm_esc(const SpgemmCall& c, const SemiringDesc& d, DevCSR& out);
+template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc& d, DevCSR& out);
 
 void spgemm_masked(const SpgemmCall& c, const SemiringDesc& d, DevCSR& out) {
   dispatch_type(d.zcode, [&]<class T>() { run_spgemm_masked<T>(c, d, out); });
 }
 void spgemm_esc(const SpgemmCall& c, const SemiringDesc& d, DevCSR& out) {
   dispatch_type(d.zcode, [&]<class T>() { run_spgemm_esc<T>(c, d, out); });
+}
+void spgemm_hash(const SpgemmCall& c, const SemiringDesc& d, DevCSR& out) {
+  dispatch_type(d.zcode, [&]<class T>() { run_spgemm_hash<T>(c, d, out); });
 }
 }  // namespace grb

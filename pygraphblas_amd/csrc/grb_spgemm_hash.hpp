@@ -1,0 +1,244 @@
+// grb_spgemm_hash.hpp — the unmasked (or complement-masked) SpGEMM  T = A (+).(x) B : Gustavson row by row with an
+// LDS hash accumulator, in two passes (the path BASELINE.json's north star names; reference call: lib.GrB_mxm at
+// pygraphblas/matrix.py:2572-2583 without a mask, e.g. `A @ A`).
+//
+//   symbolic  nnz(T(i,:)) for every row: the columns of the products of row i go into a hash set in LDS (keys only:
+//             up to 32768 slots = 128 KB); the set's size is bounded by the row's product count
+//             ub(i) = sum_{k in A(i,:)} nnz(B(k,:)), by which the rows are binned (<= 128 / 1024 / 16384 products: 256 /
+//             2048 / 32768 slots, a wave / 256 / 1024 threads per row).  Rows with more products count into a bitmap of
+//             ncols bits in HBM (one per persistent workgroup; atomicOr returns which bits were new).
+//   scan      row pointers of T (one host round trip: the size of T).
+//   numeric   the rows are binned again, now by their exact entry count (<= 128 / 1024 / 4096 entries: 256 / 2048 / 8192
+//             slots of key + accumulator, load <= 1/2); products combine into the slot of their column with the monoid's
+//             native LDS atomic (CAS loop for monoids that have none), and the live slots are written to T's row.  Rows
+//             with more entries accumulate into a dense array of ncols accumulators in HBM (one per persistent
+//             workgroup, initialised to the identity once and restored after each row), claiming columns in a bitmap.
+//   order     the entries of a row leave the tables in slot order: one segmented radix sort (rocPRIM) over (column, position)
+//             pairs puts every row in column order, and the values follow their positions.
+// Teams walk the entries k of A(i,:) with 16-lane groups, each streaming one row B(k,:) 16 entries at a time.
+// Temporaries: 8 B per row + 8 B per entry of T (sort) — against ~40 B per *product* of the expand/sort/compress path,
+// which stays as the deterministic alternative (floating-point sums here depend on the order the atomics land in; integer
+// and boolean results are exact): GRB_MI355X_SPGEMM=esc, or descriptor AxB method GxB_AxB_DOT.
+#pragma once
+#include "grb_spgemm_kernels.hpp"
+
+namespace grb {
+
+void segmented_sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n, uint32_t nseg, const uint32_t* offsets, int end_bit);
+
+struct HashArgs {
+  const uint32_t* arp; const uint32_t* acol; const uint32_t* brp; const uint32_t* bcol;
+  const uint32_t* rows; uint32_t nrows_bin;            // the rows of this bin
+  uint32_t* rownnz;                                     // symbolic: out
+  const uint32_t* crp; uint32_t* ccol;                  // numeric: T's row pointers, columns (unsorted inside a row)
+};
+
+// rows -> bins by a per-row weight (product count or entry count); bin b holds rows with limit[b-1] < w <= limit[b], the last bin the rest
+static __global__ void k_hash_bin(uint32_t nrows, const unsigned long long* __restrict__ w64, const uint32_t* __restrict__ w32, unsigned long long l0, unsigned long long l1,
+                                  unsigned long long l2, uint32_t* __restrict__ counts, uint32_t* __restrict__ lists /* 4 x nrows */) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t nround = ((uint64_t)nrows + 63) / 64 * 64;
+  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nround; r += (uint64_t)gridDim.x * 256ull) {
+    int b = -1;
+    if (r < nrows) { const unsigned long long w = w64 ? w64[r] : w32[r]; if (w) b = w <= l0 ? 0 : (w <= l1 ? 1 : (w <= l2 ? 2 : 3)); }
+    for (int bb = 0; bb < 4; bb++) {
+      const unsigned long long m = __ballot(b == bb);
+      if (!m) continue;
+      const int leader = __builtin_ctzll(m);
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(&counts[bb], (uint32_t)__popcll(m));
+      base = __shfl(base, leader, 64);
+      if (b == bb) lists[(size_t)bb * nrows + base + __popcll(m & ((1ull << lane) - 1))] = (uint32_t)r;
+    }
+  }
+}
+
+// LDS hash, one team per row.  NUMERIC = false: count the distinct columns; true: accumulate and write the row.
+template <class T, class SR, int SLOTS, int TEAM, int BLOCK, bool NUMERIC>
+__global__ __launch_bounds__(BLOCK) void k_spgemm_hash(const HashArgs a, const T* __restrict__ aval, const T* __restrict__ bval, T* __restrict__ cval, const SR sr) {
+  typedef typename acc_word<T>::type W;
+  constexpr int TEAMS = BLOCK / TEAM, NG = TEAM / 16;
+  __shared__ uint32_t s_key[TEAMS][SLOTS];
+  __shared__ W s_acc[NUMERIC ? TEAMS : 1][NUMERIC ? SLOTS : 1];
+  __shared__ uint32_t s_cnt[TEAMS];
+  const int team = threadIdx.x / TEAM, t = threadIdx.x % TEAM, lane16 = t & 15, grp = t >> 4;
+  uint32_t* key = s_key[team];
+  const bool use_a = sr.uses_a(), use_b = sr.uses_u();
+  const W idw = to_word<T>(sr.identity);
+  auto team_sync = [&]() {
+    if constexpr (TEAM == 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+  };
+  const uint32_t nblk_rows = (a.nrows_bin + TEAMS - 1) / TEAMS * TEAMS;
+  for (uint32_t rbase = blockIdx.x * TEAMS; rbase < nblk_rows; rbase += gridDim.x * TEAMS) {
+    const uint32_t ridx = rbase + team; const bool live = ridx < a.nrows_bin;
+    const uint32_t i = live ? a.rows[ridx] : 0;
+    for (int s = t; s < SLOTS; s += TEAM) { key[s] = HASH_EMPTY; if constexpr (NUMERIC) s_acc[team][s] = idw; }
+    if (t == 0) s_cnt[team] = 0;
+    team_sync();
+    const uint32_t ab = live ? a.arp[i] : 0, ae = live ? a.arp[i + 1] : 0;
+    uint32_t mine = 0;
+    for (uint32_t pa = ab + grp; pa < ae; pa += NG) {
+      const uint32_t k = a.acol[pa]; const T av = (NUMERIC && use_a) ? aval[pa] : T();
+      const uint32_t bb = a.brp[k], be = a.brp[k + 1];
+      for (uint32_t pb = bb + lane16; pb < be; pb += 16) {
+        const uint32_t j = a.bcol[pb];
+        uint32_t h = hash_col(j, SLOTS - 1);
+        for (;;) {
+          const uint32_t old = atomicCAS(&key[h], HASH_EMPTY, j);
+          if (old == HASH_EMPTY) { mine++; break; }
+          if (old == j) break;
+          h = (h + 1) & (SLOTS - 1);
+        }
+        if constexpr (NUMERIC) word_combine<T>(sr.add_op(), &s_acc[team][h], sr.mult(av, use_b ? bval[pb] : T()));
+      }
+    }
+    if constexpr (!NUMERIC) {
+      if (mine) atomicAdd(&s_cnt[team], mine);
+      team_sync();
+      if (live && t == 0) a.rownnz[i] = s_cnt[team];
+    } else {
+      team_sync();
+      const uint32_t base = live ? a.crp[i] : 0;
+      for (int s = t; s < SLOTS; s += TEAM) if (key[s] != HASH_EMPTY) {
+        const uint32_t w = base + atomicAdd(&s_cnt[team], 1u);
+        a.ccol[w] = key[s]; cval[w] = from_word<T>(s_acc[team][s]);
+      }
+    }
+    team_sync();
+  }
+}
+
+// rows beyond the LDS tables.  One persistent workgroup owns a bitmap of ncols bits (symbolic) or a dense accumulator of
+// ncols words + the bitmap (numeric) in HBM and walks its rows one after the other.
+template <class T, class SR, bool NUMERIC>
+__global__ __launch_bounds__(1024) void k_spgemm_dense(const HashArgs a, const T* __restrict__ aval, const T* __restrict__ bval, T* __restrict__ cval, uint32_t ncols,
+                                                       uint32_t* __restrict__ bitmaps, typename acc_word<T>::type* __restrict__ accs, const SR sr) {
+  typedef typename acc_word<T>::type W;
+  const uint32_t words = (ncols + 31) / 32;
+  uint32_t* bits = bitmaps + (size_t)blockIdx.x * words;
+  W* acc = NUMERIC ? accs + (size_t)blockIdx.x * ncols : nullptr;
+  __shared__ uint32_t s_cnt;
+  const int t = threadIdx.x, lane16 = t & 15, grp = t >> 4; constexpr int NG = 1024 / 16;
+  const bool use_a = sr.uses_a(), use_b = sr.uses_u();
+  const W idw = to_word<T>(sr.identity);
+  for (uint32_t ridx = blockIdx.x; ridx < a.nrows_bin; ridx += gridDim.x) {
+    const uint32_t i = a.rows[ridx];
+    if (t == 0) s_cnt = 0;
+    __syncthreads();
+    const uint32_t ab = a.arp[i], ae = a.arp[i + 1], base = NUMERIC ? a.crp[i] : 0;
+    uint32_t mine = 0;
+    for (uint32_t pa = ab + grp; pa < ae; pa += NG) {
+      const uint32_t k = a.acol[pa]; const T av = (NUMERIC && use_a) ? aval[pa] : T();
+      const uint32_t bb = a.brp[k], be = a.brp[k + 1];
+      for (uint32_t pb = bb + lane16; pb < be; pb += 16) {
+        const uint32_t j = a.bcol[pb], bit = 1u << (j & 31);
+        const bool fresh = !(__hip_atomic_load(&bits[j >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) && !(atomicOr(&bits[j >> 5], bit) & bit);
+        if constexpr (NUMERIC) {
+          if (fresh) a.ccol[base + atomicAdd(&s_cnt, 1u)] = j;            // first product of this column: it joins the row
+          word_combine<T>(sr.add_op(), &acc[j], sr.mult(av, use_b ? bval[pb] : T()));
+        } else if (fresh) mine++;
+      }
+    }
+    if constexpr (!NUMERIC) { if (mine) atomicAdd(&s_cnt, mine); }
+    __threadfence(); __syncthreads();
+    if constexpr (!NUMERIC) {
+      if (t == 0) a.rownnz[i] = s_cnt;
+      // clear the bits again: walk the products once more (the row's columns are not stored anywhere yet)
+      for (uint32_t pa = ab + grp; pa < ae; pa += NG) {
+        const uint32_t k = a.acol[pa]; const uint32_t bb = a.brp[k], be = a.brp[k + 1];
+        for (uint32_t pb = bb + lane16; pb < be; pb += 16) { const uint32_t j = a.bcol[pb]; bits[j >> 5] = 0; }
+      }
+    } else {
+      const uint32_t n = s_cnt;
+      for (uint32_t e = t; e < n; e += 1024) {                           // values out, accumulators and bits back to their rest state
+        const uint32_t j = a.ccol[base + e];
+        cval[base + e] = from_word<T>(__hip_atomic_load(&acc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); acc[j] = idw; bits[j >> 5] = 0;
+      }
+    }
+    __threadfence(); __syncthreads();
+  }
+}
+template <class W> __global__ void k_hash_gather(const W* __restrict__ in, const uint32_t* __restrict__ perm, uint64_t n, W* __restrict__ out) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) out[i] = in[perm[i]];
+}
+
+template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc& d, DevCSR& out) {
+  typedef typename acc_word<T>::type W;
+  const DevCSR& A = *c.A; const DevCSR& B = *c.B;
+  const uint32_t nrows = A.nrows, ncols = B.ncols;
+  out.clear(); out.nrows = nrows; out.ncols = ncols;
+  out.rowptr.alloc(((size_t)nrows + 1) * 4);
+  auto grid_n = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 8192) b = 8192; return (unsigned)b; };
+  if (!nrows || !A.nnz || !B.nnz) { GRB_HIP(hipMemsetAsync(out.rowptr.p, 0, ((size_t)nrows + 1) * 4, stream())); out.nnz = 0; out.col.alloc(8); out.val.alloc(8); out.valid = true; return; }
+  const int ncu = device_cus() > 0 ? device_cus() : 256;
+  auto nblocks = [&](uint32_t rows, int teams) { uint64_t b = ((uint64_t)rows + teams - 1) / teams; if (b > (uint64_t)ncu * 32) b = (uint64_t)ncu * 32; if (b < 1) b = 1; return (unsigned)b; };
+  // ---- product counts, symbolic bins -----------------------------------------------------------------------------------------
+  DevBuf ub((size_t)nrows * 8 + 8), rownnz(((size_t)nrows + 1) * 4), counts(64), lists((size_t)4 * nrows * 4 + 4);
+  hipLaunchKernelGGL(k_row_upper_bound, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, A.rowptr.as<uint32_t>(), A.col.as<uint32_t>(), B.rowptr.as<uint32_t>(), ub.as<unsigned long long>());
+  GRB_HIP(hipMemsetAsync(rownnz.p, 0, ((size_t)nrows + 1) * 4, stream()));
+  GRB_HIP(hipMemsetAsync(counts.p, 0, 64, stream()));
+  hipLaunchKernelGGL(k_hash_bin, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, ub.as<unsigned long long>(), (const uint32_t*)nullptr, 128ull, 1024ull, 16384ull, counts.as<uint32_t>(), lists.as<uint32_t>());
+  uint32_t hs[4];
+  GRB_HIP(hipMemcpyAsync(hs, counts.p, 16, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+  const uint32_t words = (ncols + 31) / 32;
+  // persistent workgroups of the dense paths: bounded by memory (bitmaps: ncols/8 bytes each; accumulators: ncols words each, <= 4 GiB in all)
+  auto dense_blocks = [&](uint32_t rows, size_t per_block) { uint64_t fit = (4ull << 30) / (per_block ? per_block : 1); if (fit < 1) fit = 1; return (unsigned)std::min<uint64_t>(std::min<uint64_t>(rows, (uint64_t)ncu * 2), fit); };
+  uint32_t hn[4] = {0, 0, 0, 0};
+  with_semiring<T>(d, [&](auto sr) {
+    typedef decltype(sr) SR;
+    HashArgs a{A.rowptr.as<uint32_t>(), A.col.as<uint32_t>(), B.rowptr.as<uint32_t>(), B.col.as<uint32_t>(), nullptr, 0, rownnz.as<uint32_t>(), nullptr, nullptr};
+    const uint32_t* L = lists.as<uint32_t>();
+    {
+      DevBuf bm;
+      if (hs[3]) { const unsigned nb = dense_blocks(hs[3], (size_t)words * 4); bm.alloc((size_t)nb * words * 4); GRB_HIP(hipMemsetAsync(bm.p, 0, (size_t)nb * words * 4, stream()));
+                   a.rows = L + (size_t)3 * nrows; a.nrows_bin = hs[3];
+                   hipLaunchKernelGGL((k_spgemm_dense<T, SR, false>), dim3(nb), dim3(1024), 0, stream(), a, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, ncols, bm.as<uint32_t>(), (W*)nullptr, sr); }
+      if (hs[2]) { a.rows = L + (size_t)2 * nrows; a.nrows_bin = hs[2]; hipLaunchKernelGGL((k_spgemm_hash<T, SR, 32768, 1024, 1024, false>), dim3(nblocks(hs[2], 1)), dim3(1024), 0, stream(), a, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, sr); }
+      if (hs[1]) { a.rows = L + (size_t)1 * nrows; a.nrows_bin = hs[1]; hipLaunchKernelGGL((k_spgemm_hash<T, SR, 2048, 256, 256, false>), dim3(nblocks(hs[1], 1)), dim3(256), 0, stream(), a, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, sr); }
+      if (hs[0]) { a.rows = L; a.nrows_bin = hs[0]; hipLaunchKernelGGL((k_spgemm_hash<T, SR, 256, 64, 256, false>), dim3(nblocks(hs[0], 4)), dim3(256), 0, stream(), a, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, sr); }
+      GRB_HIP(hipGetLastError());
+      // ---- row pointers, the size of T, numeric bins ---------------------------------------------------------------------------
+      exclusive_scan_u32(rownnz.as<uint32_t>(), out.rowptr.as<uint32_t>(), (uint64_t)nrows + 1);
+      GRB_HIP(hipMemsetAsync(counts.p, 0, 64, stream()));
+      hipLaunchKernelGGL(k_hash_bin, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, (const unsigned long long*)nullptr, rownnz.as<uint32_t>(), 128ull, 1024ull, 4096ull, counts.as<uint32_t>(), lists.as<uint32_t>());
+      uint32_t total = 0;
+      GRB_HIP(hipMemcpyAsync(&total, out.rowptr.as<uint32_t>() + nrows, 4, hipMemcpyDeviceToHost, stream()));
+      GRB_HIP(hipMemcpyAsync(hn, counts.p, 16, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));   // (also: the bitmaps of the symbolic pass are idle now)
+      out.nnz = total;
+    }
+    const uint64_t total = out.nnz;
+    out.col.alloc(total * 4 + 8); out.val.alloc(total * sizeof(T) + 8);
+    if (total) {
+      DevBuf ucol(total * 4 + 8), uval(total * sizeof(T) + 8);
+      a.crp = out.rowptr.as<uint32_t>(); a.ccol = ucol.as<uint32_t>(); a.rownnz = nullptr;
+      const T* av = (const T*)c.aval; const T* bv = (const T*)c.bval;
+      DevBuf bm, accs;
+      if (hn[3]) {
+        const unsigned nb = dense_blocks(hn[3], (size_t)ncols * sizeof(W) + (size_t)words * 4);
+        bm.alloc((size_t)nb * words * 4); accs.alloc((size_t)nb * ncols * sizeof(W));
+        GRB_HIP(hipMemsetAsync(bm.p, 0, (size_t)nb * words * 4, stream()));
+        hipLaunchKernelGGL((k_fill_words<W>), dim3(4096), dim3(256), 0, stream(), accs.as<W>(), (uint64_t)nb * ncols, to_word<T>(sr.identity));
+        a.rows = L + (size_t)3 * nrows; a.nrows_bin = hn[3];
+        hipLaunchKernelGGL((k_spgemm_dense<T, SR, true>), dim3(nb), dim3(1024), 0, stream(), a, av, bv, uval.as<T>(), ncols, bm.as<uint32_t>(), accs.as<W>(), sr);
+      }
+      if (hn[2]) { a.rows = L + (size_t)2 * nrows; a.nrows_bin = hn[2]; hipLaunchKernelGGL((k_spgemm_hash<T, SR, 8192, 1024, 1024, true>), dim3(nblocks(hn[2], 1)), dim3(1024), 0, stream(), a, av, bv, uval.as<T>(), sr); }
+      if (hn[1]) { a.rows = L + (size_t)1 * nrows; a.nrows_bin = hn[1]; hipLaunchKernelGGL((k_spgemm_hash<T, SR, 2048, 256, 256, true>), dim3(nblocks(hn[1], 1)), dim3(256), 0, stream(), a, av, bv, uval.as<T>(), sr); }
+      if (hn[0]) { a.rows = L; a.nrows_bin = hn[0]; hipLaunchKernelGGL((k_spgemm_hash<T, SR, 256, 64, 256, true>), dim3(nblocks(hn[0], 4)), dim3(256), 0, stream(), a, av, bv, uval.as<T>(), sr); }
+      GRB_HIP(hipGetLastError());
+      // ---- column order inside every row ----------------------------------------------------------------------------------------
+      DevBuf perm0(total * 4 + 8), perm(total * 4 + 8);
+      hipLaunchKernelGGL(k_iota32, dim3(grid_n(total)), dim3(256), 0, stream(), perm0.as<uint32_t>(), total);
+      int cbits = 1; while ((1ull << cbits) < (unsigned long long)ncols) cbits++;
+      segmented_sort_pairs_u32(ucol.as<uint32_t>(), out.col.as<uint32_t>(), perm0.as<uint32_t>(), perm.as<uint32_t>(), total, nrows, out.rowptr.as<uint32_t>(), cbits);
+      hipLaunchKernelGGL((k_hash_gather<T>), dim3(grid_n(total)), dim3(256), 0, stream(), uval.as<T>(), perm.as<uint32_t>(), total, out.val.as<T>());
+      GRB_HIP(hipGetLastError());
+      GRB_HIP(hipStreamSynchronize(stream()));                        // the temporaries of this scope go back to the pool
+    }
+    g_last_plan += std::string("spgemm_hash<") + (sr.is_static ? "static" : "dynamic") + "> symbolic bins " + std::to_string(hs[0]) + "/" + std::to_string(hs[1]) + "/" + std::to_string(hs[2]) + "/" +
+                   std::to_string(hs[3]) + " numeric bins " + std::to_string(hn[0]) + "/" + std::to_string(hn[1]) + "/" + std::to_string(hn[2]) + "/" + std::to_string(hn[3]) + " ";
+  });
+  out.valid = true;
+}
+
+}  // namespace grb

@@ -192,3 +192,52 @@ def test_few_row_products_through_vxm_match_the_oracle(gpu, monkeypatch):
                         ("BOOL", "LOR_LAND", {"mask": {"typ": "INT8", "comp": True}, "replace": True}), ("FP32", "PLUS_SECOND", {"tb": True})):
         run_case(rng, typ, sr, 5, 40, 37, 0.15, 0.2, **kw)
     assert "mxm_rows" in gb.last_kernel_plan()
+
+
+def _rmat_matrix(scale, typ, rng, lo=1, hi=4):
+    rp, col = rmat.csr_numpy(scale, symmetric=True, drop_self_loops=True)
+    vals = rand_vals = (rng.integers(lo, hi, len(col))).astype(O.NP[typ]) if typ != "BOOL" else np.ones(len(col), np.bool_)
+    n = 1 << scale
+    return gb.Matrix.from_csr(TYPE[typ], n, n, rp, col, vals), rp, col, vals
+
+
+@pytest.mark.parametrize("typ,sr", [("INT64", "PLUS_TIMES"), ("FP64", "PLUS_TIMES"), ("BOOL", "LOR_LAND"), ("INT32", "MIN_PLUS"), ("INT16", "TIMES_SECOND"), ("FP32", "MAX_PLUS")])
+def test_two_pass_hash_spgemm_every_bin_against_expand_sort_compress(gpu, typ, sr, monkeypatch):
+    """A*A on R-MAT-14 (hub rows: up to millions of products and thousands of distinct columns per row) through the two-pass
+    LDS-hash Gustavson (grb_spgemm_hash.hpp) — every symbolic and numeric bin including the dense HBM paths is populated —
+    against the expand/sort/compress path, which the small-shape tests above pin to the oracle.  Exact for integers / BOOL."""
+    rng = np.random.default_rng(5)
+    A, rp, col, vals = _rmat_matrix(14, typ, rng, 1, 3)
+    monkeypatch.setenv("GRB_MI355X_SPGEMM", "esc")
+    E = A.mxm(A, semiring=getattr(TYPE[typ], sr))
+    assert "spgemm_esc" in gb.last_kernel_plan()
+    monkeypatch.setenv("GRB_MI355X_SPGEMM", "hash")
+    H = A.mxm(A, semiring=getattr(TYPE[typ], sr))
+    plan = gb.last_kernel_plan()
+    assert "spgemm_hash" in plan
+    sym = [int(x) for x in plan.split("symbolic bins ")[1].split()[0].split("/")]
+    num = [int(x) for x in plan.split("numeric bins ")[1].split()[0].split("/")]
+    assert all(x > 0 for x in sym) and all(x > 0 for x in num), plan
+    ei, ej, ex = E.to_arrays(); hi_, hj, hx = H.to_arrays()
+    assert np.array_equal(ei, hi_) and np.array_equal(ej, hj)
+    if typ.startswith("FP"):
+        assert np.allclose(hx, ex, rtol=1e-6, atol=0.0)
+    else:
+        assert np.array_equal(hx, ex)
+
+
+def test_two_pass_hash_spgemm_against_the_oracle(gpu, monkeypatch):
+    monkeypatch.setenv("GRB_MI355X_SPGEMM", "hash")
+    rng = np.random.default_rng(6)
+    scale = 10; n = 1 << scale
+    A, rp, col, vals = _rmat_matrix(scale, "INT64", rng, 1, 5)
+    rows = np.repeat(np.arange(n, dtype=np.uint64), np.diff(rp.astype(np.int64)))
+    At = O.Tuples("INT64", n, n, rows, col.astype(np.uint64), vals)
+    C = A.mxm(A, semiring=gb.INT64.PLUS_TIMES)
+    assert "spgemm_hash" in gb.last_kernel_plan()
+    check(C, O.mxm(O.Tuples("INT64", n, n), At, At, "PLUS", "TIMES", "INT64"), "INT64", what="hash A*A")
+    # complemented mask + accumulate into an existing matrix: the write-back sees the same T
+    Cm = rand_matrix(rng, "INT64", n, n, 0.001); Mm = rand_matrix(rng, "BOOL", n, n, 0.3)
+    gC = to_matrix(Cm)
+    A.mxm(A, semiring=gb.INT64.PLUS_TIMES, out=gC, mask=to_matrix(Mm), accum=gb.INT64.PLUS, desc=D.C)
+    check(gC, O.mxm(Cm, At, At, "PLUS", "TIMES", "INT64", mask=Mm, accum="PLUS", mask_comp=True), "INT64", what="hash A*A <!M> accum")

@@ -12,6 +12,7 @@ from pygraphblas_amd import rmat, descriptor as D
 ap = argparse.ArgumentParser()
 ap.add_argument("--scale", type=int, default=22)
 ap.add_argument("--what", default="bfs,tc,pr,bc")
+ap.add_argument("--aa-scale", type=int, default=18)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--no-check", action="store_true")
 args = ap.parse_args()
@@ -183,3 +184,24 @@ if "bc" in args.what:
             paths = paths.eadd(frontier, gb.FP32.PLUS)
     print(json.dumps({"workload": f"BC batched-frontier step R-MAT-{args.scale}, ns={ns}: frontier<!paths,replace> = frontier PLUS_FIRST A (gap/bcmark.py:16-44)", "n": n, "nnz": nnz,
                       "seconds_all_levels": round(sum(l["seconds"] for l in levels), 5), "levels": levels}), flush=True)
+
+
+if "aa" in args.what:
+    # the unmasked product A @ A (lib.GrB_mxm without a mask, pygraphblas/matrix.py:2572-2583): two-pass LDS-hash Gustavson vs expand/sort/compress
+    S = args.aa_scale; m = 1 << S
+    rowptr, col = rmat.csr_torch(S, dev, seed=42, symmetric=True, drop_self_loops=True)
+    nnz = col.numel(); vals = torch.ones(nnz, dtype=torch.float64, device=dev)
+    A = gb.Matrix.from_csr(gb.FP64, m, m, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+    dA = (rowptr[1:] - rowptr[:-1]).to(torch.int64); products = int(dA[col.to(torch.int64) & 0xFFFFFFFF].sum())
+    res = {}
+    for method in ("hash", "esc"):
+        os.environ["GRB_MI355X_SPGEMM"] = method
+        best = 1e9
+        for _ in range(2):
+            torch.cuda.synchronize(); base = C.c_size_t(0); lib.GrBX_memory_in_use(C.byref(base)); t = time.perf_counter()
+            Cm = A.mxm(A, semiring=gb.FP64.PLUS_TIMES); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t)
+        res[method] = {"seconds": round(best, 4), "GFLOPS": round(2 * products / best / 1e9, 1), "nnz_C": Cm.nvals, "plan": gb.last_kernel_plan()}
+        del Cm
+    os.environ.pop("GRB_MI355X_SPGEMM")
+    res["temporaries"] = {"hash_bytes": 8 * m + 16 * res["hash"]["nnz_C"], "esc_bytes_per_product": 40, "esc_bytes": 40 * min(products, 1 << 27)}
+    print(json.dumps({"workload": f"A @ A (unmasked GrB_mxm) R-MAT-{S} symmetric FP64 PLUS_TIMES", "n": m, "nnz_A": nnz, "products": products, **res}), flush=True)
