@@ -281,7 +281,7 @@ GrB_Info GxB_Matrix_Option_get(GrB_Matrix A, int field, ...) {
     case 1: { int* p = va_arg(ap, int*); if (p) *p = A->format; break; }
     case 0: { double* p = va_arg(ap, double*); if (p) *p = A->hyper_switch; break; }
     case 32: { int* p = va_arg(ap, int*); if (p) *p = A->sparsity_control; break; }
-    case 33: { int* p = va_arg(ap, int*); if (p) *p = (A->nrows > GRB_DIM_DEVICE_MAX) ? 1 : 2; break; }  // hypersparse / sparse
+    case 33: { int* p = va_arg(ap, int*); if (p) *p = (A->nrows > GRB_DIM_DEVICE_MAX || A->hyper_switch >= 1.0 || mat_nvals(A) == 0) ? 1 : 2; break; }  // what SuiteSparse would report: hypersparse for huge or empty matrices and under hyper_switch = GxB_ALWAYS_HYPER (a stored option here), else sparse
     case 34: { double* p = va_arg(ap, double*); if (p) *p = 0.04; break; }
     default: info = GrB_INVALID_VALUE;
   }

@@ -1,0 +1,298 @@
+// grb_host_ops.cpp — index-list extract / assign and kronecker, on the host mirror.
+//
+//   GrB_Vector_extract, GrB_Col_extract, GrB_Matrix_extract     <- Vector / Matrix slicing  (pygraphblas/vector.py:1526-1573, matrix.py:2807-2990)
+//   GrB_Vector_assign, GrB_Row_assign, GrB_Col_assign, GrB_Matrix_assign <- slice assignment (vector.py:1447-1492, matrix.py:2992-3130)
+//   GrB_Matrix_kronecker_BinaryOp                               <- Matrix.kronecker         (matrix.py:2728-2805)
+//   GxB_{Matrix,Vector}_apply_BinaryOp1st/2nd                   <- apply_first / apply_second with a Scalar (matrix.py:1999-2004, 2034-2039)
+//
+// None of these is on the hot path (mxm / mxv / vxm and the O(n) / O(nnz) operations of the BFS, PageRank and
+// triangle-count loops, all HIP): they are the element-wise container surface — notebook slicing `M[2]`, `v[1:3]`,
+// `M[1, :] = v` — beside setElement / extractElement, and like those they edit the host mirror of the container (sorted
+// tuples); the HBM image is rebuilt lazily the next time a kernel needs it.  Semantics: C API 1.3: T is
+// formed, then C<M,replace> = accum(C, T); for assign the mask spans all of C (GrB_assign), for row / column assign only that
+// row / column.
+#include "grb_opcommon.hpp"
+#include <array>
+#include <map>
+
+// the typed apply entry points (grb_matrix_ops.cpp / grb_vector_ops.cpp) that the GxB_Scalar forms forward to
+#define GRB_FOR_TYPES(X) X(BOOL, bool, T_BOOL) X(INT8, int8_t, T_INT8) X(UINT8, uint8_t, T_UINT8) X(INT16, int16_t, T_INT16) X(UINT16, uint16_t, T_UINT16) X(INT32, int32_t, T_INT32) \
+  X(UINT32, uint32_t, T_UINT32) X(INT64, int64_t, T_INT64) X(UINT64, uint64_t, T_UINT64) X(FP32, float, T_FP32) X(FP64, double, T_FP64)
+extern "C" {
+#define GRB_DECL(SUF, CT, CODE) \
+  GrB_Info GxB_Matrix_apply_BinaryOp1st_##SUF(GrB_Matrix, const GrB_Matrix, const GrB_BinaryOp, const GrB_BinaryOp, CT, const GrB_Matrix, const GrB_Descriptor); \
+  GrB_Info GxB_Matrix_apply_BinaryOp2nd_##SUF(GrB_Matrix, const GrB_Matrix, const GrB_BinaryOp, const GrB_BinaryOp, const GrB_Matrix, CT, const GrB_Descriptor); \
+  GrB_Info GxB_Vector_apply_BinaryOp1st_##SUF(GrB_Vector, const GrB_Vector, const GrB_BinaryOp, const GrB_BinaryOp, CT, const GrB_Vector, const GrB_Descriptor); \
+  GrB_Info GxB_Vector_apply_BinaryOp2nd_##SUF(GrB_Vector, const GrB_Vector, const GrB_BinaryOp, const GrB_BinaryOp, const GrB_Vector, CT, const GrB_Descriptor);
+GRB_FOR_TYPES(GRB_DECL)
+#undef GRB_DECL
+}
+
+using namespace grb;
+
+namespace {
+
+typedef std::array<uint8_t, 16> Val;
+typedef std::map<std::pair<uint64_t, uint64_t>, Val> Map;     // (row, column) -> value bytes in some type
+
+Map load(GrB_Matrix A, bool transpose) {
+  mat_to_host(A); Map m; const size_t ts = A->type->size;
+  for (size_t p = 0; p < A->hi.size(); p++) { Val v{}; memcpy(v.data(), &A->hx[p * ts], ts); m[transpose ? std::make_pair(A->hj[p], A->hi[p]) : std::make_pair(A->hi[p], A->hj[p])] = v; }
+  return m;
+}
+Map load(GrB_Vector u) {
+  vec_to_host(u); Map m; const size_t ts = u->type->size;
+  for (size_t p = 0; p < u->hi.size(); p++) { Val v{}; memcpy(v.data(), &u->hx[p * ts], ts); m[{u->hi[p], 0}] = v; }
+  return m;
+}
+void store(GrB_Matrix C, const Map& m) {
+  const size_t ts = C->type->size;
+  C->hi.clear(); C->hj.clear(); C->hx.clear(); C->pending.clear();
+  for (auto& kv : m) { C->hi.push_back(kv.first.first); C->hj.push_back(kv.first.second); C->hx.insert(C->hx.end(), kv.second.data(), kv.second.data() + ts); }
+  C->host_valid = true; mat_invalidate_device(C);
+}
+void store(GrB_Vector w, const Map& m) {
+  const size_t ts = w->type->size;
+  w->hi.clear(); w->hx.clear(); w->pending.clear();
+  for (auto& kv : m) { w->hi.push_back(kv.first.first); w->hx.insert(w->hx.end(), kv.second.data(), kv.second.data() + ts); }
+  w->host_valid = true; vec_invalidate_device(w);
+}
+Val cast(int dst, int src, const Val& v) { Val o{}; cast_scalar(dst, o.data(), src, v.data()); return o; }
+bool truth(int code, const Val& v) { Val b = cast(T_BOOL, code, v); return b[0] != 0; }
+Val combine(GrB_BinaryOp op, int ccode, const Val& c, int tcode, const Val& t) {          // accum(c, t) in the operator's domain, result in C's type
+  const int ac = op->xtype->code; Val a = cast(ac, ccode, c), b = cast(ac, tcode, t), z{};
+  dispatch_type(ac, [&]<class T>() { T x, y; memcpy(&x, a.data(), sizeof(T)); memcpy(&y, b.data(), sizeof(T)); T r = apply_binop<T>(op->opcode, x, y); memcpy(z.data(), &r, sizeof(T)); });
+  return cast(ccode, op->ztype->code, z);
+}
+struct MaskView { const Map* m; int code; bool structural, comp, present;
+  bool allows(const std::pair<uint64_t, uint64_t>& p) const {
+    if (!present) return !comp;
+    auto it = m->find(p); const bool t = it != m->end() && (structural || truth(code, it->second));
+    return t != comp;
+  } };
+
+// C<M,replace> = accum(C, T) on maps.  `in_scope(p)`: positions the mask / replace step may touch (all of C, or one row / column)
+template <class Scope> void write_back(Map& C, int ccode, const Map& T, int tcode, const MaskView& mk, bool replace, GrB_BinaryOp accum, Scope in_scope) {
+  if (accum) check_binop(accum, "accum");
+  Map Z;
+  if (accum) {
+    Z = C;
+    for (auto& kv : T) { auto it = Z.find(kv.first); if (it == Z.end()) Z[kv.first] = cast(ccode, tcode, kv.second); else it->second = combine(accum, ccode, it->second, tcode, kv.second); }
+  } else for (auto& kv : T) Z[kv.first] = cast(ccode, tcode, kv.second);
+  Map out;
+  for (auto& kv : C) { const bool scope = in_scope(kv.first); if (!scope || (!mk.allows(kv.first) && !replace)) out[kv.first] = kv.second; }   // what survives untouched
+  for (auto& kv : Z) if (in_scope(kv.first) && mk.allows(kv.first)) out[kv.first] = kv.second;
+  if (accum) { /* outside the scope Z == C: already kept */ }
+  C.swap(out);
+}
+auto everywhere = [](const std::pair<uint64_t, uint64_t>&) { return true; };
+
+std::vector<uint64_t> indices(const GrB_Index* I, GrB_Index ni, uint64_t dim, const char* what) { return expand_index_list(I, ni, dim, what); }
+void check_m(GrB_Matrix A, const char* w) { if (!check_obj(A)) fail(GrB_UNINITIALIZED_OBJECT, std::string(w) + ": uninitialised matrix"); }
+void check_v(GrB_Vector A, const char* w) { if (!check_obj(A)) fail(GrB_UNINITIALIZED_OBJECT, std::string(w) + ": uninitialised vector"); }
+
+}  // namespace
+
+extern "C" {
+
+GrB_Info GrB_Vector_extract(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Vector u, const GrB_Index* I, GrB_Index ni, const GrB_Descriptor desc) {
+  if (!w || !u) return GrB_NULL_POINTER; if (!check_obj(w)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(w, [&] {
+    check_v(u, "extract"); if (mask) check_v(mask, "extract");
+    const DescView dv(desc);
+    const auto idx = indices(I, ni, u->n, "extract");
+    if (w->n != idx.size() || (mask && mask->n != w->n)) fail(GrB_DIMENSION_MISMATCH, "extract: output size must equal the number of indices");
+    Map U = load(u), T, C = load(w), Mm; if (mask) Mm = load(mask);
+    for (size_t k = 0; k < idx.size(); k++) { auto it = U.find({idx[k], 0}); if (it != U.end()) T[{k, 0}] = it->second; }
+    write_back(C, w->type->code, T, u->type->code, MaskView{&Mm, mask ? mask->type->code : 0, dv.mask_struct, dv.mask_comp, mask != nullptr}, dv.replace, accum, everywhere);
+    store(w, C);
+  });
+}
+
+GrB_Info GrB_Col_extract(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Matrix A, const GrB_Index* I, GrB_Index ni, GrB_Index j, const GrB_Descriptor desc) {
+  if (!w || !A) return GrB_NULL_POINTER; if (!check_obj(w)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(w, [&] {
+    check_m(A, "extract"); if (mask) check_v(mask, "extract");
+    const DescView dv(desc);
+    const uint64_t ar = dv.tran0 ? A->ncols : A->nrows, ac = dv.tran0 ? A->nrows : A->ncols;
+    if (j >= ac) fail(GrB_INVALID_INDEX, "extract: column index out of range");
+    const auto idx = indices(I, ni, ar, "extract");
+    if (w->n != idx.size() || (mask && mask->n != w->n)) fail(GrB_DIMENSION_MISMATCH, "extract: output size must equal the number of indices");
+    Map Am = load(A, dv.tran0), T, C = load(w), Mm; if (mask) Mm = load(mask);
+    for (size_t k = 0; k < idx.size(); k++) { auto it = Am.find({idx[k], j}); if (it != Am.end()) T[{k, 0}] = it->second; }
+    write_back(C, w->type->code, T, A->type->code, MaskView{&Mm, mask ? mask->type->code : 0, dv.mask_struct, dv.mask_comp, mask != nullptr}, dv.replace, accum, everywhere);
+    store(w, C);
+  });
+}
+
+GrB_Info GrB_Matrix_extract(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_Matrix A, const GrB_Index* I, GrB_Index ni, const GrB_Index* J, GrB_Index nj,
+                            const GrB_Descriptor desc) {
+  if (!C || !A) return GrB_NULL_POINTER; if (!check_obj(C)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(C, [&] {
+    check_m(A, "extract"); if (Mask) check_m(Mask, "extract");
+    const DescView dv(desc);
+    const uint64_t ar = dv.tran0 ? A->ncols : A->nrows, ac = dv.tran0 ? A->nrows : A->ncols;
+    const auto ri = indices(I, ni, ar, "extract"), ci = indices(J, nj, ac, "extract");
+    if (C->nrows != ri.size() || C->ncols != ci.size() || (Mask && (Mask->nrows != C->nrows || Mask->ncols != C->ncols))) fail(GrB_DIMENSION_MISMATCH, "extract: output shape must be |I| x |J|");
+    Map Am = load(A, dv.tran0), T, Cm = load(C, false), Mm; if (Mask) Mm = load(Mask, false);
+    std::multimap<uint64_t, uint64_t> rpos, cpos;                       // source index -> output positions (an index may repeat)
+    for (size_t k = 0; k < ri.size(); k++) rpos.insert({ri[k], k});
+    for (size_t k = 0; k < ci.size(); k++) cpos.insert({ci[k], k});
+    for (auto& kv : Am) {
+      auto rr = rpos.equal_range(kv.first.first); auto cc = cpos.equal_range(kv.first.second);
+      for (auto a = rr.first; a != rr.second; ++a) for (auto b = cc.first; b != cc.second; ++b) T[{a->second, b->second}] = kv.second;
+    }
+    write_back(Cm, C->type->code, T, A->type->code, MaskView{&Mm, Mask ? Mask->type->code : 0, dv.mask_struct, dv.mask_comp, Mask != nullptr}, dv.replace, accum, everywhere);
+    store(C, Cm);
+  });
+}
+
+// ---- assign: C(I,J)<M> = accum(C(I,J), A) --------------------------------------------------------------------------------------
+}  // extern "C"
+namespace {
+// the region update: positions of the index grid take A's entry (or lose theirs), combined with accum when given
+void region_update(Map& C, int ccode, const Map& A, int acode, const std::vector<uint64_t>& ri, const std::vector<uint64_t>& ci, GrB_BinaryOp accum, const MaskView& mk, bool replace,
+                   bool whole_mask /* GrB_assign: mask and replace span all of C */, bool row_scope, bool col_scope, uint64_t fixed) {
+  if (accum) check_binop(accum, "accum");
+  Map out;
+  auto in_region = [&](const std::pair<uint64_t, uint64_t>&) { return false; };   (void)in_region;
+  // new values over the region
+  std::map<std::pair<uint64_t, uint64_t>, std::pair<bool, Val>> upd;               // position -> (has value, value in C's type)
+  for (size_t a = 0; a < ri.size(); a++) for (size_t b = 0; b < ci.size(); b++) {
+    const std::pair<uint64_t, uint64_t> p{ri[a], ci[b]};
+    auto ia = A.find({a, b}); auto ic = C.find(p);
+    if (accum) {
+      if (ia != A.end() && ic != C.end()) upd[p] = {true, combine(accum, ccode, ic->second, acode, ia->second)};
+      else if (ia != A.end()) upd[p] = {true, cast(ccode, acode, ia->second)};
+      else if (ic != C.end()) upd[p] = {true, ic->second};
+      else upd[p] = {false, Val{}};
+    } else upd[p] = ia != A.end() ? std::make_pair(true, cast(ccode, acode, ia->second)) : std::make_pair(false, Val{});
+  }
+  auto in_scope = [&](const std::pair<uint64_t, uint64_t>& p) { return whole_mask || (row_scope && p.first == fixed) || (col_scope && p.second == fixed); };
+  auto mkey = [&](const std::pair<uint64_t, uint64_t>& p) { return row_scope ? std::make_pair(p.second, (uint64_t)0) : (col_scope ? std::make_pair(p.first, (uint64_t)0) : p); };
+  for (auto& kv : C) {
+    const bool touched = upd.count(kv.first) != 0;
+    const bool allowed = mk.allows(mkey(kv.first));
+    if (touched && allowed) continue;                                    // replaced below
+    if (!allowed && replace && in_scope(kv.first)) continue;             // deleted by replace
+    out[kv.first] = kv.second;
+  }
+  for (auto& kv : upd) if (kv.second.first && mk.allows(mkey(kv.first))) out[kv.first] = kv.second.second;
+  C.swap(out);
+}
+}  // namespace
+extern "C" {
+
+GrB_Info GrB_Vector_assign(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Vector u, const GrB_Index* I, GrB_Index ni, const GrB_Descriptor desc) {
+  if (!w || !u) return GrB_NULL_POINTER; if (!check_obj(w)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(w, [&] {
+    check_v(u, "assign"); if (mask) check_v(mask, "assign");
+    const DescView dv(desc);
+    const auto idx = indices(I, ni, w->n, "assign");
+    if (u->n != idx.size() || (mask && mask->n != w->n)) fail(GrB_DIMENSION_MISMATCH, "assign: the vector's size must equal the number of indices");
+    Map C = load(w), U = load(u), Mm; if (mask) Mm = load(mask);
+    region_update(C, w->type->code, U, u->type->code, idx, std::vector<uint64_t>{0}, accum, MaskView{&Mm, mask ? mask->type->code : 0, dv.mask_struct, dv.mask_comp, mask != nullptr}, dv.replace,
+                  true, false, false, 0);
+    store(w, C);
+  });
+}
+
+GrB_Info GrB_Matrix_assign(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_Matrix A, const GrB_Index* I, GrB_Index ni, const GrB_Index* J, GrB_Index nj,
+                           const GrB_Descriptor desc) {
+  if (!C || !A) return GrB_NULL_POINTER; if (!check_obj(C)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(C, [&] {
+    check_m(A, "assign"); if (Mask) check_m(Mask, "assign");
+    const DescView dv(desc);
+    const auto ri = indices(I, ni, C->nrows, "assign"), ci = indices(J, nj, C->ncols, "assign");
+    const uint64_t ar = dv.tran0 ? A->ncols : A->nrows, ac = dv.tran0 ? A->nrows : A->ncols;
+    if (ar != ri.size() || ac != ci.size() || (Mask && (Mask->nrows != C->nrows || Mask->ncols != C->ncols))) fail(GrB_DIMENSION_MISMATCH, "assign: the matrix must be |I| x |J|");
+    Map Cm = load(C, false), Am = load(A, dv.tran0), Mm; if (Mask) Mm = load(Mask, false);
+    region_update(Cm, C->type->code, Am, A->type->code, ri, ci, accum, MaskView{&Mm, Mask ? Mask->type->code : 0, dv.mask_struct, dv.mask_comp, Mask != nullptr}, dv.replace, true, false, false, 0);
+    store(C, Cm);
+  });
+}
+
+GrB_Info GrB_Row_assign(GrB_Matrix C, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Vector u, GrB_Index i, const GrB_Index* J, GrB_Index nj, const GrB_Descriptor desc) {
+  if (!C || !u) return GrB_NULL_POINTER; if (!check_obj(C)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(C, [&] {
+    check_v(u, "assign"); if (mask) check_v(mask, "assign");
+    const DescView dv(desc);
+    if (i >= C->nrows) fail(GrB_INVALID_INDEX, "assign: row index out of range");
+    const auto ci = indices(J, nj, C->ncols, "assign");
+    if (u->n != ci.size() || (mask && mask->n != C->ncols)) fail(GrB_DIMENSION_MISMATCH, "assign: the vector's size must equal the number of column indices");
+    Map Cm = load(C, false), U = load(u), Ut, Mm; if (mask) Mm = load(mask);
+    for (auto& kv : U) Ut[{0, kv.first.first}] = kv.second;             // the vector as a 1 x nj row
+    region_update(Cm, C->type->code, Ut, u->type->code, std::vector<uint64_t>{i}, ci, accum, MaskView{&Mm, mask ? mask->type->code : 0, dv.mask_struct, dv.mask_comp, mask != nullptr}, dv.replace,
+                  false, true, false, i);
+    store(C, Cm);
+  });
+}
+
+GrB_Info GrB_Col_assign(GrB_Matrix C, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Vector u, const GrB_Index* I, GrB_Index ni, GrB_Index j, const GrB_Descriptor desc) {
+  if (!C || !u) return GrB_NULL_POINTER; if (!check_obj(C)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(C, [&] {
+    check_v(u, "assign"); if (mask) check_v(mask, "assign");
+    const DescView dv(desc);
+    if (j >= C->ncols) fail(GrB_INVALID_INDEX, "assign: column index out of range");
+    const auto ri = indices(I, ni, C->nrows, "assign");
+    if (u->n != ri.size() || (mask && mask->n != C->nrows)) fail(GrB_DIMENSION_MISMATCH, "assign: the vector's size must equal the number of row indices");
+    Map Cm = load(C, false), U = load(u), Mm; if (mask) Mm = load(mask);
+    region_update(Cm, C->type->code, U, u->type->code, ri, std::vector<uint64_t>{j}, accum, MaskView{&Mm, mask ? mask->type->code : 0, dv.mask_struct, dv.mask_comp, mask != nullptr}, dv.replace,
+                  false, false, true, j);
+    store(C, Cm);
+  });
+}
+
+GrB_Info GrB_Matrix_kronecker_BinaryOp(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Matrix A, const GrB_Matrix B, const GrB_Descriptor desc) {
+  if (!C || !A || !B || !op) return GrB_NULL_POINTER; if (!check_obj(C)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(C, [&] {
+    check_m(A, "kronecker"); check_m(B, "kronecker"); if (Mask) check_m(Mask, "kronecker"); check_binop(op, "kronecker");
+    const DescView dv(desc);
+    const uint64_t ar = dv.tran0 ? A->ncols : A->nrows, ac = dv.tran0 ? A->nrows : A->ncols, br = dv.tran1 ? B->ncols : B->nrows, bc = dv.tran1 ? B->nrows : B->ncols;
+    if (C->nrows != ar * br || C->ncols != ac * bc || (Mask && (Mask->nrows != C->nrows || Mask->ncols != C->ncols))) fail(GrB_DIMENSION_MISMATCH, "kronecker: dimensions do not conform");
+    Map Am = load(A, dv.tran0), Bm = load(B, dv.tran1), T, Cm = load(C, false), Mm; if (Mask) Mm = load(Mask, false);
+    const int oc = op->xtype->code, zc = op->ztype->code;
+    for (auto& a : Am) for (auto& b : Bm) {
+      Val x = cast(oc, A->type->code, a.second), y = cast(oc, B->type->code, b.second), z{};
+      dispatch_type(oc, [&]<class T>() { T p, q; memcpy(&p, x.data(), sizeof(T)); memcpy(&q, y.data(), sizeof(T)); T r = apply_binop<T>(op->opcode, p, q); memcpy(z.data(), &r, sizeof(T)); });
+      T[{a.first.first * br + b.first.first, a.first.second * bc + b.first.second}] = z;
+    }
+    (void)zc;
+    write_back(Cm, C->type->code, T, oc, MaskView{&Mm, Mask ? Mask->type->code : 0, dv.mask_struct, dv.mask_comp, Mask != nullptr}, dv.replace, accum, everywhere);
+    store(C, Cm);
+  });
+}
+
+
+// apply with the bound operand in a GxB_Scalar: forwarded to the typed entry point of the scalar's type
+#define GRB_CASE1(SUF, CT, CODE) case CODE: { CT v; memcpy(&v, x->x, sizeof(CT)); return FN1(SUF)(C, M, accum, op, v, A, desc); }
+#define GRB_CASE2(SUF, CT, CODE) case CODE: { CT v; memcpy(&v, x->x, sizeof(CT)); return FN2(SUF)(C, M, accum, op, A, v, desc); }
+#define GRB_SCALAR_OK(x) if (!x) return GrB_NULL_POINTER; if (!check_obj(x)) return GrB_UNINITIALIZED_OBJECT; if (!x->has) return GrB_INVALID_VALUE;
+GrB_Info GxB_Matrix_apply_BinaryOp1st(GrB_Matrix C, const GrB_Matrix M, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GxB_Scalar x, const GrB_Matrix A, const GrB_Descriptor desc) {
+  GRB_SCALAR_OK(x)
+#define FN1(SUF) GxB_Matrix_apply_BinaryOp1st_##SUF
+  switch (x->type->code) { GRB_FOR_TYPES(GRB_CASE1) default: return GrB_DOMAIN_MISMATCH; }
+#undef FN1
+}
+GrB_Info GxB_Matrix_apply_BinaryOp2nd(GrB_Matrix C, const GrB_Matrix M, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Matrix A, const GxB_Scalar x, const GrB_Descriptor desc) {
+  GRB_SCALAR_OK(x)
+#define FN2(SUF) GxB_Matrix_apply_BinaryOp2nd_##SUF
+  switch (x->type->code) { GRB_FOR_TYPES(GRB_CASE2) default: return GrB_DOMAIN_MISMATCH; }
+#undef FN2
+}
+GrB_Info GxB_Vector_apply_BinaryOp1st(GrB_Vector C, const GrB_Vector M, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GxB_Scalar x, const GrB_Vector A, const GrB_Descriptor desc) {
+  GRB_SCALAR_OK(x)
+#define FN1(SUF) GxB_Vector_apply_BinaryOp1st_##SUF
+  switch (x->type->code) { GRB_FOR_TYPES(GRB_CASE1) default: return GrB_DOMAIN_MISMATCH; }
+#undef FN1
+}
+GrB_Info GxB_Vector_apply_BinaryOp2nd(GrB_Vector C, const GrB_Vector M, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Vector A, const GxB_Scalar x, const GrB_Descriptor desc) {
+  GRB_SCALAR_OK(x)
+#define FN2(SUF) GxB_Vector_apply_BinaryOp2nd_##SUF
+  switch (x->type->code) { GRB_FOR_TYPES(GRB_CASE2) default: return GrB_DOMAIN_MISMATCH; }
+#undef FN2
+}
+
+double GxB_ALWAYS_HYPER = 1.0, GxB_NEVER_HYPER = -1.0, GxB_HYPER_DEFAULT = 0.0625;      // hyper_switch settings (stored options only)
+
+}  // extern "C"

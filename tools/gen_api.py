@@ -278,9 +278,9 @@ typedef struct GrB_Matrix_opaque *GrB_Matrix;
 #define GxB_BITMAP 4
 #define GxB_FULL 8
 #define GxB_AUTO_SPARSITY 15
-#define GxB_RANGE 0
-#define GxB_STRIDE 1
-#define GxB_BACKWARDS 2
+#define GxB_RANGE 9223372036854775807
+#define GxB_STRIDE 9223372036854775806
+#define GxB_BACKWARDS 9223372036854775805
 #define GxB_BEGIN 0
 #define GxB_END 1
 #define GxB_INC 2
@@ -468,6 +468,23 @@ GrB_Info GrBX_last_plan_build_ms(float *milliseconds); /* device time of the mos
 GrB_Info GrBX_xcd_mapping(char *buf, int len);      /* how workgroups of a full-chip launch map to XCDs ("roundrobin8", or what was observed) */
 /* The exchange steps of the row-partitioned path (one process per GPU; RCCL over xGMI; grb_dist.cpp).  The reference has no
  * distributed code: these replace nothing in it, they are what BASELINE.json's north star adds (SURVEY.md section 8e). */
+/* Index-list extract / assign, kronecker and apply with a GxB_Scalar operand: the element-wise container surface, computed on the
+ * host mirror like setElement (grb_host_ops.cpp) — not part of the HIP hot path. */
+GrB_Info GrB_Vector_extract(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Vector u, const GrB_Index *I, GrB_Index ni, const GrB_Descriptor desc);
+GrB_Info GrB_Col_extract(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Matrix A, const GrB_Index *I, GrB_Index ni, GrB_Index j, const GrB_Descriptor desc);
+GrB_Info GrB_Matrix_extract(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_Matrix A, const GrB_Index *I, GrB_Index ni, const GrB_Index *J, GrB_Index nj, const GrB_Descriptor desc);
+GrB_Info GrB_Vector_assign(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Vector u, const GrB_Index *I, GrB_Index ni, const GrB_Descriptor desc);
+GrB_Info GrB_Matrix_assign(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_Matrix A, const GrB_Index *I, GrB_Index ni, const GrB_Index *J, GrB_Index nj, const GrB_Descriptor desc);
+GrB_Info GrB_Row_assign(GrB_Matrix C, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Vector u, GrB_Index i, const GrB_Index *J, GrB_Index nj, const GrB_Descriptor desc);
+GrB_Info GrB_Col_assign(GrB_Matrix C, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Vector u, const GrB_Index *I, GrB_Index ni, GrB_Index j, const GrB_Descriptor desc);
+GrB_Info GrB_Matrix_kronecker_BinaryOp(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Matrix A, const GrB_Matrix B, const GrB_Descriptor desc);
+GrB_Info GxB_Matrix_apply_BinaryOp1st(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GxB_Scalar x, const GrB_Matrix A, const GrB_Descriptor desc);
+GrB_Info GxB_Matrix_apply_BinaryOp2nd(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Matrix A, const GxB_Scalar y, const GrB_Descriptor desc);
+GrB_Info GxB_Vector_apply_BinaryOp1st(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GxB_Scalar x, const GrB_Vector u, const GrB_Descriptor desc);
+GrB_Info GxB_Vector_apply_BinaryOp2nd(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Vector u, const GxB_Scalar y, const GrB_Descriptor desc);
+extern double GxB_ALWAYS_HYPER;
+extern double GxB_NEVER_HYPER;
+extern double GxB_HYPER_DEFAULT;
 GrB_Info GrBX_dist_unique_id(void *id, int len);      /* 128 bytes, made on one rank and handed to all (any channel) */
 GrB_Info GrBX_dist_init(int rank, int world, const void *id, int len);   /* ncclCommInitRank on this process's GPU */
 GrB_Info GrBX_dist_finalize(void);
