@@ -47,6 +47,14 @@ void sort_pairs_u64(const uint64_t* kin, uint64_t* kout, const uint32_t* vin, ui
   GRB_HIP(rocprim::radix_sort_pairs(t.p, tmp, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)end_bit, stream()));
 }
 
+void sort_keys_u32(const uint32_t* kin, uint32_t* kout, uint64_t n, int end_bit) {
+  if (!n) return;
+  size_t tmp = 0;
+  GRB_HIP(rocprim::radix_sort_keys(nullptr, tmp, kin, kout, (size_t)n, 0u, (unsigned)end_bit, stream()));
+  DevBuf t(tmp ? tmp : 16);
+  GRB_HIP(rocprim::radix_sort_keys(t.p, tmp, kin, kout, (size_t)n, 0u, (unsigned)end_bit, stream()));
+}
+
 // every segment [offsets[s], offsets[s+1]) sorted by key on its own (rows of a CSR put in column order)
 void segmented_sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n, uint32_t nseg, const uint32_t* offsets, int end_bit) {
   if (!n || !nseg) return;

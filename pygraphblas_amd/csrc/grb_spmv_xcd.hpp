@@ -52,31 +52,15 @@ struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per 
 extern float g_xcd_plan_build_ms;     // duration of the most recent plan build (grb_spmv.hip; read by GrBX_last_plan_build_ms)
 
 // ---- plan pieces ----------------------------------------------------------------------------------------------------------
-// column counts.  A hub column of R-MAT-22 occurs 1.6e5 times, and atomics on one address complete one per ~80 ns: counting
-// straight into HBM took 13 ms.  Every workgroup aggregates its slice in an LDS table first (the hot columns claim their
-// slots early) and only columns that find no slot go to HBM directly.
-static __global__ __launch_bounds__(1024) void k_xp_col_hist(const uint32_t* __restrict__ col, uint64_t nnz, uint32_t* __restrict__ cnt) {
-  constexpr uint32_t S = 8192;
-  __shared__ uint32_t key[S], val[S];
-  for (uint32_t i = threadIdx.x; i < S; i += 1024) { key[i] = 0xFFFFFFFFu; val[i] = 0; }
-  __syncthreads();
-  const uint64_t per = (nnz + gridDim.x - 1) / gridDim.x, b = blockIdx.x * per, e = b + per < nnz ? b + per : nnz;
-  for (uint64_t p = b + threadIdx.x; p < e; p += 1024) {
-    const uint32_t c = col[p]; uint32_t h = (c * 2654435761u) >> 19;
-    bool done = false;
-#pragma unroll
-    for (int probe = 0; probe < 2; probe++) {
-      if (!done) {
-        uint32_t k = key[h];
-        if (k == 0xFFFFFFFFu) k = atomicCAS(&key[h], 0xFFFFFFFFu, c) == 0xFFFFFFFFu ? c : key[h];
-        if (k == c) { atomicAdd(&val[h], 1u); done = true; }
-        h = (h + 1) & (S - 1);
-      }
-    }
-    if (!done) atomicAdd(&cnt[c], 1u);
-  }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < S; i += 1024) if (val[i]) atomicAdd(&cnt[key[i]], val[i]);
+// column counts = run lengths of the sorted column array.  (Counting with atomics — LDS-aggregated per workgroup, the rest
+// straight into HBM — took 4.5-4.7 ms at R-MAT-22 whatever the grid: ~40 M of the 65 M entries belong to columns too cold
+// for a workgroup's LDS table, and the chip completes ~9 G device-scope atomics per second.  One 22-bit radix sort of the
+// keys and two streaming passes take about a third of that.)
+static __global__ void k_xp_run_starts(const uint32_t* __restrict__ sorted, uint64_t nnz, uint32_t* __restrict__ first) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < nnz; i += gridDim.x * 256ull) if (i == 0 || sorted[i] != sorted[i - 1]) first[sorted[i]] = (uint32_t)i;
+}
+static __global__ void k_xp_run_lengths(const uint32_t* __restrict__ sorted, uint64_t nnz, const uint32_t* __restrict__ first, uint32_t* __restrict__ cnt) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < nnz; i += gridDim.x * 256ull) if (i + 1 == nnz || sorted[i] != sorted[i + 1]) { const uint32_t c = sorted[i]; cnt[c] = (uint32_t)(i + 1) - first[c]; }
 }
 // weight of a line of u = entries in its columns
 static __global__ void k_xp_line_weights(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t line, uint32_t nlines, uint32_t* __restrict__ negw, uint32_t* __restrict__ id) {
@@ -387,8 +371,11 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals) {
   P->hot_cols.alloc((size_t)XP * H * 4 + 4);
   GRB_HIP(hipMemsetAsync(cnt.p, 0, (size_t)n * 4 + 4, stream()));
   GRB_HIP(hipMemsetAsync(P->hot_cols.p, 0, (size_t)XP * H * 4 + 4, stream()));
-  { uint64_t nb = (nnz + 65535) / 65536; if (nb < 1) nb = 1; if (nb > (uint64_t)ncu) nb = (uint64_t)ncu;      // one workgroup per CU: every workgroup ends with up to 8192 atomics on the hottest counters (2048 workgroups: 4.7 ms on un-permuted R-MAT-22)
-    hipLaunchKernelGGL(k_xp_col_hist, dim3((unsigned)nb), dim3(1024), 0, stream(), M.col.as<uint32_t>(), nnz, cnt.as<uint32_t>()); }
+  { DevBuf sorted(nnz * 4 + 4), first((size_t)n * 4 + 4);
+    int cb = 1; while ((1ull << cb) < (unsigned long long)n) cb++;
+    sort_keys_u32(M.col.as<uint32_t>(), sorted.as<uint32_t>(), nnz, cb);
+    hipLaunchKernelGGL(k_xp_run_starts, dim3(grid_n(nnz)), dim3(256), 0, stream(), sorted.as<uint32_t>(), nnz, first.as<uint32_t>());
+    hipLaunchKernelGGL(k_xp_run_lengths, dim3(grid_n(nnz)), dim3(256), 0, stream(), sorted.as<uint32_t>(), nnz, first.as<uint32_t>(), cnt.as<uint32_t>()); }
   {
     DevBuf negw((size_t)nlines * 4 + 4), lid((size_t)nlines * 4 + 4), negw2((size_t)nlines * 4 + 4), lsorted((size_t)nlines * 4 + 4), pol((size_t)nlines + 8);
     hipLaunchKernelGGL(k_xp_line_weights, dim3(grid_n(nlines)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, line, nlines, negw.as<uint32_t>(), lid.as<uint32_t>());
