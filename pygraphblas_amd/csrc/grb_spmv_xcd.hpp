@@ -44,6 +44,12 @@ struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per 
   DevBuf trow;            // u32[tiles]  sub-row (numbered over all panels, panel after panel) of every tile's first entry
   DevBuf lrow;            // u16[F]      row of every sub-row relative to its block of XP_RB rows — what the merge kernel streams
   DevBuf blockptr;        // u32[(nblocks+1)*XP] first sub-row of panel k in row block b
+  // merge in row-major slot order (k_xp_merge): variable row blocks of <= XM_ROWS rows and ~XM_TARGET sub-rows
+  DevBuf m_bstart;        // u32[m_nblocks+1] first row of every block
+  DevBuf m_blockptr;      // u32[(m_nblocks+1)*XP] first sub-row of panel k in block b
+  DevBuf m_slot;          // u16[F]  slot of every sub-row in its block's row-major order (row, then panel, then position in a chain)
+  DevBuf m_rowoff;        // u16[nrows] slot of every row's first sub-row in its block
+  uint32_t m_nblocks = 0; bool m_ok = false;
   DevBuf args;            // XtPanel<T>[XP] in HBM; never changes between calls (u and the partial array arrive as kernel arguments)
   DevBuf xhot, partial;   // per-call work buffers kept with the plan (xhot: T[XP*H], the LDS tables' contents)
   uint64_t ne[XP]; uint32_t tbase[XP + 1]; uint32_t ntiles[XP], nhot[XP];
@@ -347,6 +353,91 @@ __global__ __launch_bounds__(XP_CT) void k_xp_combine(uint32_t nrows, const uint
   }
 }
 
+// ---- the merge in row-major slot order --------------------------------------------------------------------------------------
+// The plan numbers the sub-rows of a block of rows in row-major order (row, then panel, then position in a chain of
+// continuations) and cuts the rows into blocks of <= XM_ROWS rows and about XM_TARGET sub-rows (weight of a row = its
+// sub-rows + XM_TARGET / XM_ROWS, blocks = equal slices of the weight prefix): a workgroup scatters the partials of its
+// block into LDS by slot — one LDS write per sub-row, no read-modify-write, no per-panel phase — and after ONE barrier every
+// row adds its consecutive slots in order (fixed order => reproducible) and writes y.  Against k_xp_combine: 2 LDS operations
+// per sub-row instead of ~7, one barrier instead of four, blocks of equal weight whatever the labels of the graph.
+constexpr uint32_t XM_ROWS = 1024, XM_TARGET = 2048, XM_SLOTS = 2560;   // a block holds < XM_TARGET + (sub-rows of one row) sub-rows; the plan checks that this fits XM_SLOTS
+constexpr int XM_CT = 256;
+static __global__ void k_xm_iota(uint32_t* p, uint64_t n) { for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) p[i] = (uint32_t)i; }
+static __global__ void k_xm_weights(const uint32_t* __restrict__ cnt, uint32_t nrows, uint32_t* __restrict__ w) {
+  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r <= nrows; r += gridDim.x * 256) w[r] = r < nrows ? cnt[r] + XM_TARGET / XM_ROWS : 0u;
+}
+static __global__ void k_xm_newblock(const uint32_t* __restrict__ P, uint32_t nrows, uint32_t* __restrict__ f) {
+  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r <= nrows; r += gridDim.x * 256) f[r] = r < nrows && (r == 0 || P[r] / XM_TARGET != P[r - 1] / XM_TARGET) ? 1u : 0u;
+}
+// bid = exclusive scan of the flags + flag - 1 (the block of row r); first rows of the blocks
+static __global__ void k_xm_bstart(const uint32_t* __restrict__ f, const uint32_t* __restrict__ fscan, uint32_t nrows, uint32_t nblocks, uint32_t* __restrict__ bstart) {
+  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r <= nrows; r += gridDim.x * 256) { if (r == nrows) bstart[nblocks] = nrows; else if (f[r]) bstart[fscan[r]] = r; }
+}
+static __global__ void k_xm_rowoff(const uint32_t* __restrict__ f, const uint32_t* __restrict__ fscan, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ rfirst, uint32_t nrows,
+                                   uint16_t* __restrict__ rowoff) {
+  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < nrows; r += gridDim.x * 256) { const uint32_t b = fscan[r] + f[r] - 1; rowoff[r] = (uint16_t)(rfirst[r] - rfirst[bstart[b]]); }
+}
+// i-th sub-row in row-major order (sidx[i], of row skey[i]) -> its slot inside its block
+static __global__ void k_xm_slots(const uint32_t* __restrict__ skey, const uint32_t* __restrict__ sidx, uint64_t F, const uint32_t* __restrict__ f, const uint32_t* __restrict__ fscan,
+                                  const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ rfirst, uint16_t* __restrict__ slot) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < F; i += gridDim.x * 256ull) { const uint32_t r = skey[i], b = fscan[r] + f[r] - 1; slot[sidx[i]] = (uint16_t)((uint32_t)i - rfirst[bstart[b]]); }
+}
+static __global__ void k_xm_block_starts(const uint32_t* __restrict__ subrow_row, const uint32_t* __restrict__ bstart, uint32_t nblocks, const uint32_t* __restrict__ E, uint32_t t0, uint32_t t1, uint32_t t2,
+                                         uint32_t t3, uint32_t t4, uint32_t t5, uint32_t t6, uint32_t t7, uint32_t t8, uint32_t* __restrict__ blockptr) {
+  const uint32_t tb[XP + 1] = {t0, t1, t2, t3, t4, t5, t6, t7, t8};
+  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < (nblocks + 1) * XP; t += gridDim.x * 256) {
+    const uint32_t b = t / XP, k = t % XP; const uint32_t target = bstart[b];
+    uint32_t lo = E[tb[k]], hi = E[tb[k + 1]];
+    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (subrow_row[mid] < target) lo = mid + 1; else hi = mid; }
+    blockptr[t] = lo;
+  }
+}
+static __global__ void k_xm_max(const uint32_t* __restrict__ cnt, uint32_t nrows, uint32_t* __restrict__ out) {
+  __shared__ uint32_t s_m;
+  if (threadIdx.x == 0) s_m = 0;
+  __syncthreads();
+  uint32_t m = 0;
+  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < nrows; r += gridDim.x * 256) m = cnt[r] > m ? cnt[r] : m;
+  m = __builtin_amdgcn_wave_reduce_max_u32(m, 0);
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(&s_m, m);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_m) atomicMax(out, s_m);                  // one device atomic per workgroup
+}
+template <class T, class SR>
+__global__ __launch_bounds__(XM_CT) void k_xp_merge(uint32_t nrows, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ blockptr, const uint16_t* __restrict__ slot,
+                                                    const uint16_t* __restrict__ rowoff, const T* __restrict__ partial, T* __restrict__ y, uint8_t* __restrict__ ypres, const SR sr) {
+  __shared__ T vals[XM_SLOTS];
+  const uint32_t b = blockIdx.x, tid = threadIdx.x;
+  const uint32_t r0 = bstart[b], r1 = bstart[b + 1];
+  uint32_t lo[XP], pre[XP + 1];
+  pre[0] = 0;
+#pragma unroll
+  for (int k = 0; k < XP; k++) { lo[k] = blockptr[b * XP + k]; pre[k + 1] = pre[k] + (blockptr[(b + 1) * XP + k] - lo[k]); }
+  const uint32_t total = pre[XP];
+  // the block's sub-rows as one index space over the eight runs; four loads in flight per thread before the first LDS write
+  for (uint32_t t0 = tid; t0 < total; t0 += 4 * XM_CT) {
+    T v[4]; uint32_t sl[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t t = t0 + u * XM_CT; const bool ok = t < total;
+      uint32_t s = 0;
+#pragma unroll
+      for (int k = 0; k < XP; k++) if (t >= pre[k] && t < pre[k + 1]) s = lo[k] + (t - pre[k]);
+      v[u] = ok ? partial[s] : T(); sl[u] = ok ? (uint32_t)slot[s] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (sl[u] != 0xFFFFFFFFu) vals[sl[u]] = v[u];
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < r1 - r0; i += XM_CT) {
+    const uint32_t r = r0 + i;
+    const uint32_t o0 = rowoff[r], o1 = i + 1 < r1 - r0 ? (uint32_t)rowoff[r + 1] : total;
+    T acc = T();
+    if (o1 > o0) { acc = vals[o0]; for (uint32_t q = o0 + 1; q < o1; q++) acc = sr.add(acc, vals[q]); }
+    y[r] = acc; ypres[r] = o1 > o0 ? 1 : 0;
+  }
+}
+
 // which instantiation of the tile pipeline runs.  The product uses the defaults; GRB_MI355X_XT=d<depth>w<waves>[e<exp>] picks
 // one of the others in builds with -DXT_VARIANTS (measurement harness, FP64 static semirings only).
 struct XtVariant { int depth, waves, exp; };
@@ -452,6 +543,38 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals) {
   P->blockptr.alloc(((size_t)nblocks + 1) * XP * 4 + 4);
   hipLaunchKernelGGL(k_xp_block_starts, dim3(grid_n(((uint64_t)nblocks + 1) * XP)), dim3(256), 0, stream(), subrow_row.as<uint32_t>(), nblocks, E.as<uint32_t>(), P->tbase[0], P->tbase[1],
                      P->tbase[2], P->tbase[3], P->tbase[4], P->tbase[5], P->tbase[6], P->tbase[7], P->tbase[8], P->blockptr.as<uint32_t>());
+  // 6b. the merge in row-major slot order: sub-rows sorted by row (stable: panel, then chain order inside a row), rows per
+  //     sub-row count, variable row blocks, slots and row offsets inside the blocks (third host round trip: the block count)
+  {
+    const uint32_t nr = M.nrows; const uint64_t F = P->F;
+    int rb = 1; while ((1ull << rb) < (unsigned long long)nr) rb++;
+    DevBuf sidx0(F * 4 + 4), sidx(F * 4 + 4), skey(F * 4 + 4), rcnt(((size_t)nr + 1) * 4 + 4), first(((size_t)nr + 1) * 4 + 4), rfirst(((size_t)nr + 1) * 4 + 4), w(((size_t)nr + 1) * 4 + 4),
+           Pw(((size_t)nr + 1) * 4 + 4), nf(((size_t)nr + 1) * 4 + 4), nfs(((size_t)nr + 1) * 4 + 4), dmax(16);
+    hipLaunchKernelGGL(k_xm_iota, dim3(grid_n(F)), dim3(256), 0, stream(), sidx0.as<uint32_t>(), F);
+    sort_pairs_u32(subrow_row.as<uint32_t>(), skey.as<uint32_t>(), sidx0.as<uint32_t>(), sidx.as<uint32_t>(), F, rb);
+    GRB_HIP(hipMemsetAsync(rcnt.p, 0, ((size_t)nr + 1) * 4, stream())); GRB_HIP(hipMemsetAsync(dmax.p, 0, 16, stream()));
+    hipLaunchKernelGGL(k_xp_run_starts, dim3(grid_n(F)), dim3(256), 0, stream(), skey.as<uint32_t>(), F, first.as<uint32_t>());
+    hipLaunchKernelGGL(k_xp_run_lengths, dim3(grid_n(F)), dim3(256), 0, stream(), skey.as<uint32_t>(), F, first.as<uint32_t>(), rcnt.as<uint32_t>());
+    exclusive_scan_u32(rcnt.as<uint32_t>(), rfirst.as<uint32_t>(), (uint64_t)nr + 1);                 // row-major position of every row's first sub-row
+    hipLaunchKernelGGL(k_xm_weights, dim3(grid_n((uint64_t)nr + 1)), dim3(256), 0, stream(), rcnt.as<uint32_t>(), nr, w.as<uint32_t>());
+    exclusive_scan_u32(w.as<uint32_t>(), Pw.as<uint32_t>(), (uint64_t)nr + 1);
+    hipLaunchKernelGGL(k_xm_newblock, dim3(grid_n((uint64_t)nr + 1)), dim3(256), 0, stream(), Pw.as<uint32_t>(), nr, nf.as<uint32_t>());
+    exclusive_scan_u32(nf.as<uint32_t>(), nfs.as<uint32_t>(), (uint64_t)nr + 1);
+    hipLaunchKernelGGL(k_xm_max, dim3(grid_n(nr) > 1024u ? 1024u : grid_n(nr)), dim3(256), 0, stream(), rcnt.as<uint32_t>(), nr, dmax.as<uint32_t>());
+    uint32_t hnb = 0, hmax = 0;
+    GRB_HIP(hipMemcpyAsync(&hnb, nfs.as<uint32_t>() + nr, 4, hipMemcpyDeviceToHost, stream()));
+    GRB_HIP(hipMemcpyAsync(&hmax, dmax.p, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+    P->m_nblocks = hnb; P->m_ok = hnb > 0 && (uint64_t)XM_TARGET + hmax + XM_TARGET / XM_ROWS <= XM_SLOTS && F < 0xFFFFFFF0ull;
+    if (P->m_ok) {
+      P->m_bstart.alloc(((size_t)hnb + 1) * 4 + 4); P->m_blockptr.alloc(((size_t)hnb + 1) * XP * 4 + 4); P->m_slot.alloc(F * 2 + 4); P->m_rowoff.alloc((size_t)nr * 2 + 4);
+      hipLaunchKernelGGL(k_xm_bstart, dim3(grid_n((uint64_t)nr + 1)), dim3(256), 0, stream(), nf.as<uint32_t>(), nfs.as<uint32_t>(), nr, hnb, P->m_bstart.as<uint32_t>());
+      hipLaunchKernelGGL(k_xm_rowoff, dim3(grid_n(nr)), dim3(256), 0, stream(), nf.as<uint32_t>(), nfs.as<uint32_t>(), P->m_bstart.as<uint32_t>(), rfirst.as<uint32_t>(), nr, P->m_rowoff.as<uint16_t>());
+      hipLaunchKernelGGL(k_xm_slots, dim3(grid_n(F)), dim3(256), 0, stream(), skey.as<uint32_t>(), sidx.as<uint32_t>(), F, nf.as<uint32_t>(), nfs.as<uint32_t>(), P->m_bstart.as<uint32_t>(),
+                         rfirst.as<uint32_t>(), P->m_slot.as<uint16_t>());
+      hipLaunchKernelGGL(k_xm_block_starts, dim3(grid_n(((uint64_t)hnb + 1) * XP)), dim3(256), 0, stream(), subrow_row.as<uint32_t>(), P->m_bstart.as<uint32_t>(), hnb, E.as<uint32_t>(), P->tbase[0], P->tbase[1],
+                         P->tbase[2], P->tbase[3], P->tbase[4], P->tbase[5], P->tbase[6], P->tbase[7], P->tbase[8], P->m_blockptr.as<uint32_t>());
+    }
+  }
   // 7. the panels' argument block and the per-call buffers
   P->args.alloc(XP * sizeof(XtPanel<T>));
   P->xhot.alloc((size_t)XP * H * sizeof(T) + 8); P->partial.alloc(P->F * sizeof(T) + 8);
@@ -500,8 +623,13 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
 #endif
     if (!launched) hipLaunchKernelGGL((k_spmv_tiles<T, SR>), dim3(ncu), dim3(XT_WAVES * 64), 0, stream(), call, (const XtPanel<T>*)P->args.p, sr);
     const uint32_t nblocks = (uint32_t)(((uint64_t)M.nrows + XP_RB - 1) / XP_RB);
-    hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3(nblocks), dim3(XP_CT), 0, stream(), M.nrows, P->blockptr.as<uint32_t>(), P->lrow.as<uint16_t>(), P->partial.as<T>(),
-                       (T*)c.tval, c.tpres, sr);
+    static const bool old_merge = wp_env("GRB_MI355X_XP_OLD_MERGE", 0) != 0;       // measurement hook: the per-panel merge kernel
+    if (P->m_ok && !old_merge)
+      hipLaunchKernelGGL((k_xp_merge<T, SR>), dim3(P->m_nblocks), dim3(XM_CT), 0, stream(), M.nrows, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), P->m_slot.as<uint16_t>(),
+                         P->m_rowoff.as<uint16_t>(), P->partial.as<T>(), (T*)c.tval, c.tpres, sr);
+    else
+      hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3(nblocks), dim3(XP_CT), 0, stream(), M.nrows, P->blockptr.as<uint32_t>(), P->lrow.as<uint16_t>(), P->partial.as<T>(),
+                         (T*)c.tval, c.tpres, sr);
     g_last_plan += std::string("k_spmv_xcd<") + (sr.is_static ? "static" : "dynamic") + ",subrows=" + std::to_string(P->F) + "," + xcd_mapping() + "> ";
   });
   return true;
