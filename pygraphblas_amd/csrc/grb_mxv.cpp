@@ -76,7 +76,9 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   if (!push && !u_full && !mask && accum && method == SPMV_AUTO && !sd.flip && check_obj(accum) && accum->opcode == sd.addop && accum->xtype->code == sd.zcode &&
       w->type->code == sd.zcode && w->dev_valid && !w->host_valid && w->dnvals_known && w->dnvals == w->n && w != u) {
     const bool is_int = sd.zcode != T_FP32 && sd.zcode != T_FP64 && sd.zcode != T_BOOL;
-    fill_holes = sd.mulop == B_SECOND || (sd.mulop == B_TIMES && sd.addop == B_PLUS && is_int) || (sd.mulop == B_LAND && sd.addop == B_LOR && sd.zcode == T_BOOL);
+    // (the accumulator must leave w alone when it meets the identity: true for these monoid operators, not for ANY)
+    const bool neutral = sd.addop == B_PLUS || sd.addop == B_TIMES || sd.addop == B_MIN || sd.addop == B_MAX || sd.addop == B_LOR || sd.addop == B_LAND || sd.addop == B_LXOR;
+    fill_holes = neutral && (sd.mulop == B_SECOND || (sd.mulop == B_TIMES && sd.addop == B_PLUS && is_int) || (sd.mulop == B_LAND && sd.addop == B_LOR && sd.zcode == T_BOOL));
   }
   const void* uval = nullptr;
   if (uses_u && fill_holes) {

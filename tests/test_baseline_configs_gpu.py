@@ -216,3 +216,30 @@ def test_holes_filled_with_the_identity_only_when_the_pattern_cannot_matter(gb, 
             gi, gx = w.to_arrays()
             assert np.array_equal(gi, exp.I), (full_out, acc)
             assert np.allclose(gx, exp.X, rtol=1e-6, atol=0.0), (full_out, acc)
+
+
+def test_config1_per_panel_merge_fallback_in_a_fresh_process(gpu):
+    """Kernel X keeps its per-panel merge kernel (k_xp_combine) for matrices whose rows have more sub-rows than a block of the
+    row-major merge holds; GRB_MI355X_XP_OLD_MERGE=1 selects it (read once per process, hence the subprocess).  Same check as
+    configs[1]: R-MAT-22 FP64 PLUS_TIMES against the oracle's loop, and bit-identical results call after call."""
+    import os, subprocess, sys
+    code = r"""
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+import pygraphblas_amd as gb
+from pygraphblas_amd import rmat
+from oracle import oracle as O
+S = 22; n = 1 << S; dev = torch.device("cuda", 0)
+rowptr, col = rmat.csr_torch(S, dev, seed=42); nnz = int(col.numel())
+vals = rmat.values_torch(nnz, dev, seed=43); xs = rmat.values_torch(n, dev, seed=44)
+A = gb.Matrix.from_csr(gb.FP64, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+x = gb.Vector.from_dense_array((xs.data_ptr(), n), gb.FP64, device=True)
+w = A.mxv(x, semiring=gb.FP64.PLUS_TIMES); assert "k_spmv_xcd" in gb.last_kernel_plan()
+gy, gp = w.to_dense_arrays()
+y, pres = O.fast_spmv(rowptr.cpu().numpy().view(np.uint32), col.cpu().numpy().view(np.uint32), vals.cpu().numpy(), xs.cpu().numpy())
+assert np.array_equal(gp != 0, pres != 0) and np.allclose(gy[pres != 0], y[pres != 0], rtol=1e-6, atol=0.0)
+g2, _ = A.mxv(x, semiring=gb.FP64.PLUS_TIMES).to_dense_arrays(); assert np.array_equal(g2[pres != 0], gy[pres != 0])
+print("OK old merge")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, GRB_MI355X_XP_OLD_MERGE="1"))
+    assert r.returncode == 0 and "OK old merge" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
