@@ -26,6 +26,8 @@ extern "C" {
   GrB_Info GxB_Vector_apply_BinaryOp2nd_##SUF(GrB_Vector, const GrB_Vector, const GrB_BinaryOp, const GrB_BinaryOp, const GrB_Vector, CT, const GrB_Descriptor);
 GRB_FOR_TYPES(GRB_DECL)
 #undef GRB_DECL
+GrB_Info GrB_Matrix_eWiseAdd_BinaryOp(GrB_Matrix, const GrB_Matrix, const GrB_BinaryOp, const GrB_BinaryOp, const GrB_Matrix, const GrB_Matrix, const GrB_Descriptor);
+GrB_Info GrB_Vector_eWiseAdd_BinaryOp(GrB_Vector, const GrB_Vector, const GrB_BinaryOp, const GrB_BinaryOp, const GrB_Vector, const GrB_Vector, const GrB_Descriptor);
 }
 
 using namespace grb;
@@ -185,6 +187,7 @@ extern "C" {
 
 GrB_Info GrB_Vector_assign(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Vector u, const GrB_Index* I, GrB_Index ni, const GrB_Descriptor desc) {
   if (!w || !u) return GrB_NULL_POINTER; if (!check_obj(w)) return GrB_UNINITIALIZED_OBJECT;
+  if (I == GrB_ALL && !mask && accum && check_obj(u) && device_ok() && u->n == w->n) return GrB_Vector_eWiseAdd_BinaryOp(w, nullptr, nullptr, accum, w, u, nullptr);   // w = accum(w, u), in HBM
   return guarded(w, [&] {
     check_v(u, "assign"); if (mask) check_v(mask, "assign");
     const DescView dv(desc);
@@ -200,6 +203,12 @@ GrB_Info GrB_Vector_assign(GrB_Vector w, const GrB_Vector mask, const GrB_Binary
 GrB_Info GrB_Matrix_assign(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_Matrix A, const GrB_Index* I, GrB_Index ni, const GrB_Index* J, GrB_Index nj,
                            const GrB_Descriptor desc) {
   if (!C || !A) return GrB_NULL_POINTER; if (!check_obj(C)) return GrB_UNINITIALIZED_OBJECT;
+  // the whole container, no mask, with an accumulator (`paths.assign_matrix(frontier, accum=PLUS)`, gap/bcmark.py:41): that is
+  // C = accum(C, A) on the union of the patterns — the eWiseAdd kernel, in HBM (a dense ns x n `paths` must not visit the host)
+  if (I == GrB_ALL && J == GrB_ALL && !Mask && accum && check_obj(A) && device_ok()) {
+    const DescView dv0(desc);
+    if (!dv0.tran0 && A->nrows == C->nrows && A->ncols == C->ncols) return GrB_Matrix_eWiseAdd_BinaryOp(C, nullptr, nullptr, accum, C, A, nullptr);
+  }
   return guarded(C, [&] {
     check_m(A, "assign"); if (Mask) check_m(Mask, "assign");
     const DescView dv(desc);

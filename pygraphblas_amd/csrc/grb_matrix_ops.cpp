@@ -17,6 +17,8 @@ using namespace grb;
 namespace grb {
 bool mxm_few_rows_wanted(const DevCSR& Ad, const DevCSR& Bd);
 void mxm_few_rows(const DevCSR& Ad, GrB_Type atype, GrB_Matrix Mmask, const DescView& dv, GrB_Semiring semiring, GrB_Matrix B, int zcode, DevCSR& T);
+bool few_long_rows(uint64_t nrows, uint64_t ncols, uint64_t nnz);
+void ewise_few_rows(GrB_Matrix C, GrB_Matrix Mmask, const DescView& dv, GrB_BinaryOp accum, GrB_BinaryOp op, const DevCSR& Ad, GrB_Type atype, const DevCSR& Bd, GrB_Type btype, bool is_union, DevCSR& T);
 }
 
 namespace {
@@ -132,6 +134,11 @@ void do_ewise(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, GrB_BinaryOp op, G
   const uint64_t br = dv.tran1 ? B->ncols : B->nrows, bc = dv.tran1 ? B->nrows : B->ncols;
   if (ar != br || ac != bc || C->nrows != ar || C->ncols != ac || (M && (M->nrows != ar || M->ncols != ac))) fail(GrB_DIMENSION_MISMATCH, "eWise: dimensions do not conform");
   const DevCSR& Ad = operand(A, dv.tran0); const DevCSR& Bd = operand(B, dv.tran1);
+  if (!M && dv.mask_comp) { if (dv.replace) GrB_Matrix_clear(C); return; }
+  if (few_long_rows(C->nrows, C->ncols, Ad.nnz + Bd.nnz)) {          // a batch of a few very long rows (BC sweeps): row by row through the vector kernels
+    DevCSR T; ewise_few_rows(C, M, dv, accum, op, Ad, A->type, Bd, B->type, is_union, T);
+    adopt(C, T, C->type->code); return;
+  }
   const int xc = op->xtype->code;
   DevBuf acast, bcast;
   const void* av = cast_values(xc, A->type->code, Ad.val.p, Ad.nnz, acast);

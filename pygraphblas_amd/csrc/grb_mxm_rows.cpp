@@ -14,6 +14,8 @@
 
 extern "C" GrB_Info GrB_vxm(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Semiring semiring, const GrB_Vector u, const GrB_Matrix A,
                             const GrB_Descriptor desc);
+extern "C" GrB_Info GrB_Vector_eWiseAdd_BinaryOp(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Vector u, const GrB_Vector v, const GrB_Descriptor desc);
+extern "C" GrB_Info GrB_Vector_eWiseMult_BinaryOp(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Vector u, const GrB_Vector v, const GrB_Descriptor desc);
 
 namespace grb {
 
@@ -114,6 +116,61 @@ void mxm_few_rows(const DevCSR& Ad, GrB_Type atype, GrB_Matrix Mmask, const Desc
   GRB_HIP(hipStreamSynchronize(stream()));                            // (trp lives on the host stack of this call)
   T.valid = true;
   g_last_plan = "mxm_rows<" + std::to_string(nr) + " x vxm> first row: " + plans;
+}
+
+
+// ---- element-wise operations on matrices of a few very long rows ---------------------------------------------------------------
+// The matrix eWise / write-back kernels merge one row per wave: right for graphs, hopeless for the ns x n batches of the BC
+// sweeps (`bc.emult(paths, DIV, out=W, mask=S[i], desc=R)`, `paths.assign(frontier, accum=PLUS)`, gap/bcmark.py:41-58: 4 rows
+// of 4 M entries took 1-4 s each).  Such a matrix is ns bitmap vectors: every row goes through the vector kernel of the same
+// operation — mask, accumulator and replace included, so the result row is final — and the rows are compacted back into a CSR.
+bool few_long_rows(uint64_t nrows, uint64_t ncols, uint64_t nnz) {
+  if (getenv("GRB_MI355X_EWISE_ROWS")) return atoi(getenv("GRB_MI355X_EWISE_ROWS")) != 0;
+  return nrows <= 64 && ncols >= 65536u && nnz >= (1u << 18);
+}
+
+void ewise_few_rows(GrB_Matrix C, GrB_Matrix Mmask, const DescView& dv, GrB_BinaryOp accum, GrB_BinaryOp op, const DevCSR& Ad, GrB_Type atype, const DevCSR& Bd, GrB_Type btype, bool is_union,
+                    DevCSR& T) {
+  const uint32_t nr = (uint32_t)C->nrows; const uint64_t n = C->ncols;
+  const size_t cs = C->type->size;
+  mat_to_device(C); if (Mmask) mat_to_device(Mmask);
+  auto fetch = [&](const DevCSR& S) { std::vector<uint32_t> rp((size_t)nr + 1); GRB_HIP(hipMemcpyAsync(rp.data(), S.rowptr.p, rp.size() * 4, hipMemcpyDeviceToHost, stream())); return rp; };
+  std::vector<uint32_t> arp = fetch(Ad), brp = fetch(Bd), crp = fetch(C->csr), mrp; if (Mmask) mrp = fetch(Mmask->csr);
+  GRB_HIP(hipStreamSynchronize(stream()));
+  GrB_Descriptor_opaque d{GRB_MAGIC, dv.replace ? GrB_REPLACE : 0, (dv.mask_comp ? GrB_COMP : 0) | (dv.mask_struct ? GrB_STRUCTURE : 0), 0, 0, 0, 0, 0, 0.0, false, "ewise_rows"};
+  VecGuard outs; outs.v.resize(nr, nullptr);
+  std::vector<uint32_t> cnt(nr, 0); std::vector<DevBuf> pos(nr);
+  for (uint32_t s = 0; s < nr; s++) {
+    VecGuard tmp;
+    GrB_Vector va = row_vector(Ad, atype, s, arp, n), vb = row_vector(Bd, btype, s, brp, n); tmp.v.push_back(va); tmp.v.push_back(vb);
+    GrB_Vector vm = nullptr; if (Mmask) { vm = row_vector(Mmask->csr, Mmask->type, s, mrp, n); tmp.v.push_back(vm); }
+    GrB_Vector vc = row_vector(C->csr, C->type, s, crp, n); outs.v[s] = vc;
+    const GrB_Info info = is_union ? GrB_Vector_eWiseAdd_BinaryOp(vc, vm, accum, op, va, vb, &d) : GrB_Vector_eWiseMult_BinaryOp(vc, vm, accum, op, va, vb, &d);
+    if (info != GrB_SUCCESS) fail(info, "eWise (row-wise): " + vc->err);
+    vec_to_device(vc);
+    pos[s].alloc((n + 1) * 4 + 4);
+    DevBuf flags((n + 1) * 4 + 4);
+    hipLaunchKernelGGL(k_pres_to_u32, dim3(grid_of(n + 1)), dim3(256), 0, stream(), vc->dpres.as<uint8_t>(), n, flags.as<uint32_t>());
+    exclusive_scan_u32(flags.as<uint32_t>(), pos[s].as<uint32_t>(), n + 1);
+    GRB_HIP(hipMemcpyAsync(&cnt[s], pos[s].as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, stream()));
+  }
+  GRB_HIP(hipStreamSynchronize(stream()));
+  std::vector<uint32_t> trp((size_t)nr + 1, 0);
+  uint64_t total = 0; for (uint32_t s = 0; s < nr; s++) { trp[s] = (uint32_t)total; total += cnt[s]; }
+  if (total > 0xFFFFFFF0ull) fail(GrB_INSUFFICIENT_SPACE, "eWise: result has more than 2^32 entries");
+  trp[nr] = (uint32_t)total;
+  T.clear(); T.nrows = nr; T.ncols = (uint32_t)n; T.nnz = total;
+  T.rowptr.alloc(((size_t)nr + 1) * 4); T.col.alloc(total * 4 + 8); T.val.alloc(total * cs + 8);
+  GRB_HIP(hipMemcpyAsync(T.rowptr.p, trp.data(), trp.size() * 4, hipMemcpyHostToDevice, stream()));
+  for (uint32_t s = 0; s < nr; s++) if (cnt[s]) by_size(cs, [&](auto TS) {
+    GrB_Vector w = outs.v[s];
+    hipLaunchKernelGGL((k_bitmap_to_row<decltype(TS)::value>), dim3(grid_of(n)), dim3(256), 0, stream(), w->dpres.as<uint8_t>(), (const uint8_t*)w->dval.p, pos[s].as<uint32_t>(), n, trp[s],
+                       T.col.as<uint32_t>(), (uint8_t*)T.val.p);
+  });
+  GRB_HIP(hipGetLastError());
+  GRB_HIP(hipStreamSynchronize(stream()));
+  T.valid = true;
+  g_last_plan = "ewise_rows<" + std::to_string(nr) + " x vector eWise> ";
 }
 
 }  // namespace grb

@@ -68,6 +68,9 @@ class Matrix:
     def dense(cls, typ, nrows, ncols, fill=None):
         if fill is None:
             fill = typ.default_zero
+        if nrows * ncols < (1 << 32) - 16 and _capi.device_info()["ok"]:      # straight to a CSR in HBM (the ns x n batches of the BC sweeps)
+            return cls.from_csr(typ, nrows, ncols, np.arange(nrows + 1, dtype=np.uint64) * np.uint64(ncols), np.tile(np.arange(ncols, dtype=np.uint32), nrows),
+                                np.full(nrows * ncols, fill, dtype=typ._np))
         I, J = np.divmod(np.arange(nrows * ncols, dtype=np.uint64), np.uint64(ncols))
         return cls.from_arrays(I, J, np.full(nrows * ncols, fill, dtype=typ._np), nrows, ncols, typ)
 
@@ -523,6 +526,20 @@ class Matrix:
         mh, ah, dh = get_args(mask, accum, desc)
         check(lib.GrB_Matrix_apply(out._h, mh, ah, C.c_void_p(op.get_op()), self._h, dh), out)
         return out
+
+    def assign_matrix(self, value, rindex=None, cindex=None, mask=None, accum=None, desc=None):
+        """`C(I,J)<mask> = accum(C(I,J), value)` (reference: pygraphblas/matrix.py:3057-3130); index lists or None for all."""
+        mh, ah, dh = get_args(mask, accum, desc)
+
+        def idx(ix):
+            if ix is None:
+                return C.cast(_capi.handle("GrB_ALL"), C.c_void_p), 0, None
+            keep = np.ascontiguousarray(list(ix), np.uint64)
+            return _p(keep), len(keep), keep
+        I, ni, k1 = idx(rindex); J, nj, k2 = idx(cindex)
+        check(lib.GrB_Matrix_assign(self._h, mh, ah, value._h, I, u64(ni), J, u64(nj), dh), self)
+
+    assign = assign_matrix
 
     def select(self, op, thunk=None, out=None, mask=None, accum=None, desc=None):
         """`GxB_Matrix_select` with a built-in select operator name ("TRIL", ">0", ...) (reference: matrix.py:2042-2140)."""

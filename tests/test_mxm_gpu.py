@@ -241,3 +241,60 @@ def test_two_pass_hash_spgemm_against_the_oracle(gpu, monkeypatch):
     gC = to_matrix(Cm)
     A.mxm(A, semiring=gb.INT64.PLUS_TIMES, out=gC, mask=to_matrix(Mm), accum=gb.INT64.PLUS, desc=D.C)
     check(gC, O.mxm(Cm, At, At, "PLUS", "TIMES", "INT64", mask=Mm, accum="PLUS", mask_comp=True), "INT64", what="hash A*A <!M> accum")
+
+
+@pytest.mark.parametrize("scale,ns", [(8, 4), (10, 4)])
+def test_whole_batched_betweenness_centrality_of_the_gap_driver(gpu, scale, ns, monkeypatch):
+    """gap/bcmark.py:16-67 end to end over the mirror (forward sweep of masked frontier products, backward sweep of masked
+    mxm / emult, reduce over the batch), against networkx's Brandes on the same directed graph: for every vertex that is not
+    one of the sources the value is the sum over the sources of the dependency delta_s(v)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import networkx as nx
+    from bc_algorithm import bc
+    monkeypatch.setenv("GRB_MI355X_MXM_ROWS", "1")                    # the row-wise mxm the product picks by itself at scale
+    n = 1 << scale
+    rp, col = rmat.csr_numpy(scale, drop_self_loops=True)             # directed
+    rows = np.repeat(np.arange(n), np.diff(rp.astype(np.int64)))
+    A = gb.Matrix.from_csr(gb.FP32, n, n, rp, col, np.ones(len(col), np.float32))
+    AT = A.transpose()
+    deg = np.diff(rp.astype(np.int64))
+    sources = [int(x) for x in np.argsort(-deg, kind="stable")[:ns]]
+    cent, depth = bc(gb, sources, AT, A)
+    got = cent.to_dense_arrays()[0].astype(np.float64)
+    G = nx.DiGraph(); G.add_nodes_from(range(n)); G.add_edges_from(zip(rows.tolist(), col.astype(np.int64).tolist()))
+    want = nx.betweenness_centrality_subset(G, sources=sources, targets=list(range(n)), normalized=False)
+    others = np.array([v for v in range(n) if v not in sources])
+    w = np.array([want[v] for v in others])
+    assert depth >= 3 and w.max() > 1.0
+    assert np.allclose(got[others], w, rtol=1e-4, atol=1e-4), (np.abs(got[others] - w).max())
+
+
+def test_ewise_on_few_long_rows_matches_the_row_merge_kernels(gpu, monkeypatch):
+    """Matrix eWiseAdd / eWiseMult through the vector kernels, one row at a time (the ns x n batches of the BC sweeps,
+    grb_mxm_rows.cpp), against the generic row-merge kernels on the same operands: masks (valued / complemented), accumulator,
+    replace, output aliasing an input, mixed types."""
+    rng = np.random.default_rng(21)
+    nr, nc = 5, 3000
+    def mk(typ, dens):
+        return rand_matrix(rng, typ, nr, nc, dens)
+    cases = [("FP32", "DIV", False, dict(mask="BOOL", replace=True)), ("FP32", "TIMES", False, dict(accum="PLUS")), ("FP32", "PLUS", True, dict()),
+             ("INT64", "MIN", True, dict(mask="INT8", comp=True)), ("FP64", "PLUS", True, dict(accum="PLUS", alias=True)), ("INT32", "TIMES", False, dict(mask="BOOL", comp=True, replace=True, accum="MAX"))]
+    for typ, opn, union, kw in cases:
+        At, Bt, Ct = mk(typ, 0.4), mk(typ, 0.5), mk(typ, 0.3)
+        Mt = mk(kw["mask"], 0.5) if "mask" in kw else None
+        flags = ("R" if kw.get("replace") else "") + ("C" if kw.get("comp") else "")
+        res = []
+        for forced in ("0", "1"):
+            monkeypatch.setenv("GRB_MI355X_EWISE_ROWS", forced)
+            A, B, Cm = to_matrix(At), to_matrix(Bt), to_matrix(Ct)
+            out = A if kw.get("alias") else Cm
+            fn = A.eadd if union else A.emult
+            fn(B, getattr(TYPE[typ], opn), out=out, mask=to_matrix(Mt) if Mt is not None else None, accum=getattr(TYPE[typ], kw["accum"]) if "accum" in kw else None,
+               desc=getattr(D, flags) if flags else None)
+            if forced == "1":
+                assert "ewise_rows" in gb.last_kernel_plan()
+            res.append(matrix_tuples(out))
+        a, b = res
+        assert np.array_equal(a.I, b.I) and np.array_equal(a.J, b.J), (typ, opn, kw)
+        assert np.allclose(a.X.astype(np.float64), b.X.astype(np.float64), rtol=1e-6, atol=0.0, equal_nan=True), (typ, opn, kw)

@@ -205,3 +205,21 @@ if "aa" in args.what:
     os.environ.pop("GRB_MI355X_SPGEMM")
     res["temporaries"] = {"hash_bytes": 8 * m + 16 * res["hash"]["nnz_C"], "esc_bytes_per_product": 40, "esc_bytes": 40 * min(products, 1 << 27)}
     print(json.dumps({"workload": f"A @ A (unmasked GrB_mxm) R-MAT-{S} symmetric FP64 PLUS_TIMES", "n": m, "nnz_A": nnz, "products": products, **res}), flush=True)
+
+
+if "bcfull" in args.what:
+    # the whole batched BC of gap/bcmark.py:16-67 (tools/bc_algorithm.py), ns = 4 sources of maximum degree, directed R-MAT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bc_algorithm import bc as bc_full
+    rowptr, col = rmat.csr_torch(args.scale, dev, seed=42, drop_self_loops=True)
+    nnz = col.numel(); vals = torch.ones(nnz, dtype=torch.float32, device=dev)
+    A = gb.Matrix.from_csr(gb.FP32, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+    AT = A.transpose()
+    deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+    sources = [int(x) for x in torch.argsort(deg, descending=True, stable=True)[:4].cpu()]
+    best = 1e9
+    for rep in range(2):
+        torch.cuda.synchronize(); t = time.perf_counter(); cent, depth = bc_full(gb, sources, AT, A); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t)
+    cv = cent.to_dense_arrays()[0]
+    print(json.dumps({"workload": f"batched betweenness centrality, gap/bcmark.py:16-67, R-MAT-{args.scale} directed, ns=4", "n": n, "nnz": nnz, "depth": depth, "seconds": round(best, 4),
+                      "max_centrality": float(cv.max()), "plan": gb.last_kernel_plan()}), flush=True)
