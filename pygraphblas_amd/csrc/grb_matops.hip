@@ -3,9 +3,9 @@
 //   * row-wise union / intersection (eWiseAdd / eWiseMult)
 //   * entry filters (select: tril/triu/diag/offdiag/value tests) and flag compaction
 //   * value maps (apply, apply with a bound scalar), row reductions (reduce to vector)
-// Two-pass pattern everywhere: count per row -> exclusive scan (rocPRIM) -> fill.  Rows are merged by
-// one thread each (sorted column lists), which is simple, exact and order-preserving; the heavy
-// lifting of the hot path is in grb_spgemm.hip / grb_spmv_kernels.hpp, not here.
+// Entry-parallel throughout since round 2 (flags -> exclusive scan (rocPRIM) -> scatter; union / intersection by one stable
+// merge of (row, column) keys): a power-law graph has rows of 10^5 entries, and kernels that give a row to one thread ran at
+// 1-2 G entries/s on R-MAT-22.  The heavy lifting of the hot path is in grb_spgemm.hip / grb_spmv_kernels.hpp, not here.
 #include "grb_api.hpp"
 #include "grb_device.hpp"
 #include "grb_matops.hpp"
@@ -27,180 +27,179 @@ __device__ __forceinline__ bool mask_truth(const void* mval, int mcode, uint32_t
   }
 }
 
-// ---- write-back merge:  out(i,:) from C(i,:), T(i,:), M(i,:) -------------------------------------------------------
-// FILL = false: count entries of each output row.  FILL = true: write them at orow[i].
-template <class T, bool FILL, bool MATH = false>
-__global__ void k_writeback(uint32_t nrows, const uint32_t* __restrict__ crp, const uint32_t* __restrict__ ccol, const T* __restrict__ cval,
-                            const uint32_t* __restrict__ trp, const uint32_t* __restrict__ tcol, const T* __restrict__ tval,
-                            const uint32_t* __restrict__ mrp, const uint32_t* __restrict__ mcol, const void* __restrict__ mval, int mcode,
-                            bool has_mask, bool mstruct, bool mcomp, bool replace, int accum,
-                            uint32_t* __restrict__ ocount, const uint32_t* __restrict__ orp, uint32_t* __restrict__ ocol, T* __restrict__ oval) {
-  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < nrows; i += (uint64_t)gridDim.x * 256ull) {
-    uint32_t pc = crp[i], ec = crp[i + 1], pt = trp[i], et = trp[i + 1];
-    uint32_t pm = has_mask ? mrp[i] : 0, em = has_mask ? mrp[i + 1] : 0;
-    uint32_t w = FILL ? orp[i] : 0, cnt = 0;
-    while (pc < ec || pt < et) {
-      const uint32_t jc = pc < ec ? ccol[pc] : 0xFFFFFFFFu, jt = pt < et ? tcol[pt] : 0xFFFFFFFFu;
-      const uint32_t j = jc < jt ? jc : jt;
-      const bool inc = jc == j, intt = jt == j;
-      bool m = true;
-      if (has_mask) {
-        while (pm < em && mcol[pm] < j) pm++;
-        m = pm < em && mcol[pm] == j && mask_truth(mval, mcode, pm, mstruct);
-      }
-      if (mcomp) m = !m;
-      bool outp; T outv = T();
-      if (m) {
-        if (accum >= 0) {
-          if (inc && intt) { outp = true; if (FILL) outv = apply_binop<T, true, MATH>(accum, cval[pc], tval[pt]); }
-          else if (intt) { outp = true; if (FILL) outv = tval[pt]; }
-          else { outp = true; if (FILL) outv = cval[pc]; }
-        } else { outp = intt; if (FILL && intt) outv = tval[pt]; }
-      } else if (replace) outp = false;
-      else { outp = inc; if (FILL && inc) outv = cval[pc]; }
-      if (outp) { if (FILL) { ocol[w] = j; oval[w] = outv; w++; } cnt++; }
-      if (inc) pc++;
-      if (intt) pt++;
-    }
-    if (!FILL) ocount[i] = cnt;
-  }
+// ---- entry-parallel building blocks -------------------------------------------------------------------------------------------
+// Round 1 merged, filtered and compacted ONE ROW PER THREAD: simple and order-preserving, but a power-law graph has rows of
+// 10^5 entries, and a single thread walking one of them is the whole kernel — tril / select 68-100 ms, eWiseAdd 137 ms, a masked
+// write-back 179 ms on the 1.3e8 entries of symmetric R-MAT-22 (1-2 G entries/s).  Everything below works per ENTRY:
+//   row of an entry     the non-empty rows mark their first entry, an inclusive max-scan fills the rest;
+//   compaction          exclusive scan of the keep flags = new position of every kept entry; new rowptr[r] = scan[rowptr[r]];
+//   mask membership     every entry binary-searches its row of the mask;
+//   union/intersection  (row, column) keys of the two operands — each already sorted — go through ONE merge (rocPRIM, stable:
+//                       A before B on equal keys), equal neighbours are the intersection, run heads the union; the number of
+//                       merged entries before row r is arp[r] + brp[r], so the new row pointers are a gather from the scan;
+//   write-back          Z = accum(C, T) as a union, Z restricted to the mask by compaction, C's entries outside the mask kept
+//                       (unless replace) by a second compaction, the two disjoint parts merged.
+static __global__ void k_mark_row_starts(const uint32_t* __restrict__ rowptr, uint32_t nrows, uint32_t* __restrict__ rowidx) {
+  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nrows; r += (uint64_t)gridDim.x * 256ull) { const uint32_t s = rowptr[r]; if (rowptr[r + 1] > s) rowidx[s] = (uint32_t)r; }
+}
+void csr_row_indices(const DevCSR& A, uint32_t* rowidx) {
+  if (!A.nnz) return;
+  GRB_HIP(hipMemsetAsync(rowidx, 0, A.nnz * 4, stream()));
+  hipLaunchKernelGGL(k_mark_row_starts, dim3(grid_n(A.nrows)), dim3(256), 0, stream(), A.rowptr.as<uint32_t>(), A.nrows, rowidx);
+  inclusive_scan_max_u32(rowidx, rowidx, A.nnz);
 }
 
-void csr_writeback(int code, uint32_t nrows, const DevCSR& C, const DevCSR& Tm, const DevCSR* M, int mcode, bool mstruct, bool mcomp,
-                   bool replace, int accum, DevCSR& out) {
-  out.clear(); out.nrows = nrows; out.ncols = C.ncols;
-  DevBuf cnt(((size_t)nrows + 1) * 4);
-  out.rowptr.alloc(((size_t)nrows + 1) * 4);
-  GRB_HIP(hipMemsetAsync(cnt.p, 0, ((size_t)nrows + 1) * 4, stream()));
-  dispatch_type(code, [&]<class T>() {
-    hipLaunchKernelGGL((k_writeback<T, false>), dim3(grid_rows(nrows)), dim3(256), 0, stream(), nrows, C.rowptr.as<uint32_t>(), C.col.as<uint32_t>(), C.val.as<T>(),
-                       Tm.rowptr.as<uint32_t>(), Tm.col.as<uint32_t>(), Tm.val.as<T>(), M ? M->rowptr.as<uint32_t>() : nullptr, M ? M->col.as<uint32_t>() : nullptr,
-                       M ? M->val.p : nullptr, mcode, M != nullptr, mstruct, mcomp, replace, accum, cnt.as<uint32_t>(), nullptr, nullptr, (T*)nullptr);
-    exclusive_scan_u32(cnt.as<uint32_t>(), out.rowptr.as<uint32_t>(), (uint64_t)nrows + 1);
-    uint32_t total = 0;
-    GRB_HIP(hipMemcpyAsync(&total, out.rowptr.as<uint32_t>() + nrows, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
-    out.nnz = total; out.col.alloc((size_t)total * 4); out.val.alloc((size_t)total * sizeof(T));
-#define GRB_WB_FILL(MATH) hipLaunchKernelGGL((k_writeback<T, true, MATH>), dim3(grid_rows(nrows)), dim3(256), 0, stream(), nrows, C.rowptr.as<uint32_t>(), C.col.as<uint32_t>(), C.val.as<T>(), \
-                       Tm.rowptr.as<uint32_t>(), Tm.col.as<uint32_t>(), Tm.val.as<T>(), M ? M->rowptr.as<uint32_t>() : nullptr, M ? M->col.as<uint32_t>() : nullptr, \
-                       M ? M->val.p : nullptr, mcode, M != nullptr, mstruct, mcomp, replace, accum, (uint32_t*)nullptr, out.rowptr.as<uint32_t>(), out.col.as<uint32_t>(), out.val.as<T>())
-    if (accum >= 0 && binop_needs_math(accum)) GRB_WB_FILL(true); else GRB_WB_FILL(false);
-#undef GRB_WB_FILL
-  });
-  GRB_HIP(hipGetLastError());
-  out.valid = true;
+static __global__ void k_keep_to_u32(const uint8_t* __restrict__ keep, uint64_t n, uint32_t* __restrict__ out) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i <= n; i += gridDim.x * 256ull) out[i] = (i < n && keep[i]) ? 1u : 0u;
 }
-
-// ---- element-wise union / intersection -----------------------------------------------------------------------------
-template <class T, bool FILL, bool MATH = false>      // MATH: the operator may call into the math library (see grb_ops.hpp)
-__global__ void k_ewise(uint32_t nrows, const uint32_t* __restrict__ arp, const uint32_t* __restrict__ acol, const T* __restrict__ aval,
-                        const uint32_t* __restrict__ brp, const uint32_t* __restrict__ bcol, const T* __restrict__ bval, int op, bool is_union,
-                        uint32_t* __restrict__ ocount, const uint32_t* __restrict__ orp, uint32_t* __restrict__ ocol, T* __restrict__ oval) {
-  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < nrows; i += (uint64_t)gridDim.x * 256ull) {
-    uint32_t pa = arp[i], ea = arp[i + 1], pb = brp[i], eb = brp[i + 1];
-    uint32_t w = FILL ? orp[i] : 0, cnt = 0;
-    while (pa < ea || pb < eb) {
-      const uint32_t ja = pa < ea ? acol[pa] : 0xFFFFFFFFu, jb = pb < eb ? bcol[pb] : 0xFFFFFFFFu;
-      if (ja == jb) { if (FILL) { ocol[w] = ja; oval[w] = apply_binop<T, true, MATH>(op, aval[pa], bval[pb]); w++; } cnt++; pa++; pb++; }
-      else if (ja < jb) { if (is_union) { if (FILL) { ocol[w] = ja; oval[w] = aval[pa]; w++; } cnt++; } pa++; }
-      else { if (is_union) { if (FILL) { ocol[w] = jb; oval[w] = bval[pb]; w++; } cnt++; } pb++; }
-    }
-    if (!FILL) ocount[i] = cnt;
-  }
+static __global__ void k_gather_rowptr(const uint32_t* __restrict__ rowptr, uint32_t nrows, const uint32_t* __restrict__ pos, uint32_t* __restrict__ orp) {
+  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r <= nrows; r += (uint64_t)gridDim.x * 256ull) orp[r] = pos[rowptr[r]];
 }
-
-void csr_ewise(int code, const DevCSR& A, const void* aval, const DevCSR& B, const void* bval, int op, bool is_union, DevCSR& out) {
-  const uint32_t nrows = A.nrows;
-  out.clear(); out.nrows = nrows; out.ncols = A.ncols;
-  DevBuf cnt(((size_t)nrows + 1) * 4);
-  out.rowptr.alloc(((size_t)nrows + 1) * 4);
-  GRB_HIP(hipMemsetAsync(cnt.p, 0, ((size_t)nrows + 1) * 4, stream()));
-  dispatch_type(code, [&]<class T>() {
-    hipLaunchKernelGGL((k_ewise<T, false>), dim3(grid_rows(nrows)), dim3(256), 0, stream(), nrows, A.rowptr.as<uint32_t>(), A.col.as<uint32_t>(), (const T*)aval,
-                       B.rowptr.as<uint32_t>(), B.col.as<uint32_t>(), (const T*)bval, op, is_union, cnt.as<uint32_t>(), nullptr, nullptr, (T*)nullptr);
-    exclusive_scan_u32(cnt.as<uint32_t>(), out.rowptr.as<uint32_t>(), (uint64_t)nrows + 1);
-    uint32_t total = 0;
-    GRB_HIP(hipMemcpyAsync(&total, out.rowptr.as<uint32_t>() + nrows, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
-    out.nnz = total; out.col.alloc((size_t)total * 4); out.val.alloc((size_t)total * sizeof(T));
-#define GRB_EW_FILL(MATH) hipLaunchKernelGGL((k_ewise<T, true, MATH>), dim3(grid_rows(nrows)), dim3(256), 0, stream(), nrows, A.rowptr.as<uint32_t>(), A.col.as<uint32_t>(), (const T*)aval, \
-                       B.rowptr.as<uint32_t>(), B.col.as<uint32_t>(), (const T*)bval, op, is_union, (uint32_t*)nullptr, out.rowptr.as<uint32_t>(), out.col.as<uint32_t>(), out.val.as<T>())
-    if (binop_needs_math(op)) GRB_EW_FILL(true); else GRB_EW_FILL(false);
-#undef GRB_EW_FILL
-  });
-  GRB_HIP(hipGetLastError());
-  out.valid = true;
-}
-
-// ---- keep-flag compaction of a CSR (select, masked-SpGEMM output, mask application) -------------------------------------
-__global__ void k_row_of_entry(const uint32_t* __restrict__ rowptr, uint32_t nrows, uint32_t* __restrict__ rowidx) {
-  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nrows; r += (uint64_t)gridDim.x * 256ull)
-    for (uint32_t p = rowptr[r]; p < rowptr[r + 1]; p++) rowidx[p] = (uint32_t)r;
-}
-__global__ void k_count_kept(const uint32_t* __restrict__ rowptr, uint32_t nrows, const uint8_t* __restrict__ keep, uint32_t* __restrict__ cnt) {
-  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nrows; r += (uint64_t)gridDim.x * 256ull) {
-    uint32_t c = 0; for (uint32_t p = rowptr[r]; p < rowptr[r + 1]; p++) c += keep[p] != 0; cnt[r] = c;
-  }
-}
-template <int TS> __global__ void k_compact_rows(const uint32_t* __restrict__ rowptr, uint32_t nrows, const uint8_t* __restrict__ keep,
-                                                 const uint32_t* __restrict__ col, const uint8_t* __restrict__ val, const uint32_t* __restrict__ orp,
-                                                 uint32_t* __restrict__ ocol, uint8_t* __restrict__ oval) {
-  typedef typename std::conditional<TS == 8, uint64_t, typename std::conditional<TS == 4, uint32_t,
-          typename std::conditional<TS == 2, uint16_t, uint8_t>::type>::type>::type W;
-  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nrows; r += (uint64_t)gridDim.x * 256ull) {
-    uint32_t w = orp[r];
-    for (uint32_t p = rowptr[r]; p < rowptr[r + 1]; p++) if (keep[p]) { ocol[w] = col[p]; ((W*)oval)[w] = ((const W*)val)[p]; w++; }
-  }
+template <int TS> __global__ void k_compact_entries(uint64_t n, const uint8_t* __restrict__ keep, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ col, const uint8_t* __restrict__ val,
+                                                    uint32_t* __restrict__ ocol, uint8_t* __restrict__ oval) {
+  typedef typename std::conditional<TS == 8, uint64_t, typename std::conditional<TS == 4, uint32_t, typename std::conditional<TS == 2, uint16_t, uint8_t>::type>::type>::type W;
+  for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < n; p += gridDim.x * 256ull) if (keep[p]) { const uint32_t w = pos[p]; ocol[w] = col[p]; ((W*)oval)[w] = ((const W*)val)[p]; }
 }
 void csr_compact(const DevCSR& A, const void* aval, size_t ts, const uint8_t* keep, DevCSR& out) {
-  const uint32_t nrows = A.nrows;
+  const uint32_t nrows = A.nrows; const uint64_t n = A.nnz;
   out.clear(); out.nrows = nrows; out.ncols = A.ncols;
-  DevBuf cnt(((size_t)nrows + 1) * 4);
   out.rowptr.alloc(((size_t)nrows + 1) * 4);
-  GRB_HIP(hipMemsetAsync(cnt.p, 0, ((size_t)nrows + 1) * 4, stream()));
-  hipLaunchKernelGGL(k_count_kept, dim3(grid_rows(nrows)), dim3(256), 0, stream(), A.rowptr.as<uint32_t>(), nrows, keep, cnt.as<uint32_t>());
-  exclusive_scan_u32(cnt.as<uint32_t>(), out.rowptr.as<uint32_t>(), (uint64_t)nrows + 1);
+  DevBuf flags((n + 1) * 4 + 4), pos((n + 1) * 4 + 4);
+  hipLaunchKernelGGL(k_keep_to_u32, dim3(grid_n(n + 1)), dim3(256), 0, stream(), keep, n, flags.as<uint32_t>());
+  exclusive_scan_u32(flags.as<uint32_t>(), pos.as<uint32_t>(), n + 1);
+  hipLaunchKernelGGL(k_gather_rowptr, dim3(grid_n((uint64_t)nrows + 1)), dim3(256), 0, stream(), A.rowptr.as<uint32_t>(), nrows, pos.as<uint32_t>(), out.rowptr.as<uint32_t>());
   uint32_t total = 0;
-  GRB_HIP(hipMemcpyAsync(&total, out.rowptr.as<uint32_t>() + nrows, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
-  out.nnz = total; out.col.alloc((size_t)total * 4); out.val.alloc((size_t)total * ts);
-  const unsigned g = grid_rows(nrows);
-#define GRB_COMPACT(TS) hipLaunchKernelGGL((k_compact_rows<TS>), dim3(g), dim3(256), 0, stream(), A.rowptr.as<uint32_t>(), nrows, keep, A.col.as<uint32_t>(), \
-                                           (const uint8_t*)aval, out.rowptr.as<uint32_t>(), out.col.as<uint32_t>(), out.val.as<uint8_t>())
-  switch (ts) { case 1: GRB_COMPACT(1); break; case 2: GRB_COMPACT(2); break; case 4: GRB_COMPACT(4); break; default: GRB_COMPACT(8); break; }
+  GRB_HIP(hipMemcpyAsync(&total, pos.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+  out.nnz = total; out.col.alloc((size_t)total * 4 + 4); out.val.alloc((size_t)total * ts + 8);
+  if (n) {
+#define GRB_COMPACT(TS) hipLaunchKernelGGL((k_compact_entries<TS>), dim3(grid_n(n)), dim3(256), 0, stream(), n, keep, pos.as<uint32_t>(), A.col.as<uint32_t>(), (const uint8_t*)aval, \
+                                           out.col.as<uint32_t>(), out.val.as<uint8_t>())
+    switch (ts) { case 1: GRB_COMPACT(1); break; case 2: GRB_COMPACT(2); break; case 4: GRB_COMPACT(4); break; default: GRB_COMPACT(8); break; }
 #undef GRB_COMPACT
+  }
   GRB_HIP(hipGetLastError());
+  GRB_HIP(hipStreamSynchronize(stream()));       // flags / pos return to the pool
   out.valid = true;
 }
 
 // positional select flags: keep entry (i,j) by its diagonal index j - i against k
-__global__ void k_select_positional(const uint32_t* __restrict__ rowptr, uint32_t nrows, const uint32_t* __restrict__ col, int sel, int64_t k, uint8_t* __restrict__ keep) {
-  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nrows; r += (uint64_t)gridDim.x * 256ull)
-    for (uint32_t p = rowptr[r]; p < rowptr[r + 1]; p++) {
-      const int64_t d = (int64_t)col[p] - (int64_t)r; bool kp;
-      switch (sel) { case SEL_TRIL: kp = d <= k; break; case SEL_TRIU: kp = d >= k; break; case SEL_DIAG: kp = d == k; break; default: kp = d != k; }
-      keep[p] = kp ? 1 : 0;
-    }
+static __global__ void k_select_positional(uint64_t n, const uint32_t* __restrict__ rowidx, const uint32_t* __restrict__ col, int sel, int64_t k, uint8_t* __restrict__ keep) {
+  for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < n; p += gridDim.x * 256ull) {
+    const int64_t d = (int64_t)col[p] - (int64_t)rowidx[p]; bool kp;
+    switch (sel) { case SEL_TRIL: kp = d <= k; break; case SEL_TRIU: kp = d >= k; break; case SEL_DIAG: kp = d == k; break; default: kp = d != k; }
+    keep[p] = kp ? 1 : 0;
+  }
 }
 void select_positional_flags(const DevCSR& A, int sel, int64_t k, uint8_t* keep) {
   if (!A.nnz) return;
-  hipLaunchKernelGGL(k_select_positional, dim3(grid_rows(A.nrows)), dim3(256), 0, stream(), A.rowptr.as<uint32_t>(), A.nrows, A.col.as<uint32_t>(), sel, k, keep);
+  DevBuf rowidx(A.nnz * 4 + 4);
+  csr_row_indices(A, rowidx.as<uint32_t>());
+  hipLaunchKernelGGL(k_select_positional, dim3(grid_n(A.nnz)), dim3(256), 0, stream(), A.nnz, rowidx.as<uint32_t>(), A.col.as<uint32_t>(), sel, k, keep);
+  GRB_HIP(hipStreamSynchronize(stream()));
 }
 
-// mask flags for entries of T: keep[p] = mask allows (i, col[p])
-__global__ void k_mask_flags(uint32_t nrows, const uint32_t* __restrict__ trp, const uint32_t* __restrict__ tcol, const uint32_t* __restrict__ mrp,
-                             const uint32_t* __restrict__ mcol, const void* __restrict__ mval, int mcode, bool mstruct, bool mcomp, uint8_t* __restrict__ keep) {
-  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < nrows; i += (uint64_t)gridDim.x * 256ull) {
-    uint32_t pm = mrp[i]; const uint32_t em = mrp[i + 1];
-    for (uint32_t p = trp[i]; p < trp[i + 1]; p++) {
-      const uint32_t j = tcol[p];
-      while (pm < em && mcol[pm] < j) pm++;
-      bool m = pm < em && mcol[pm] == j && mask_truth(mval, mcode, pm, mstruct);
-      keep[p] = (m != mcomp) ? 1 : 0;
-    }
+// mask flags for entries of T: keep[p] = mask allows (i, col[p])  (INVERT: the entries the mask does NOT allow)
+static __global__ void k_mask_flags(uint64_t n, const uint32_t* __restrict__ rowidx, const uint32_t* __restrict__ tcol, const uint32_t* __restrict__ mrp, const uint32_t* __restrict__ mcol,
+                                    const void* __restrict__ mval, int mcode, bool mstruct, bool mcomp, bool invert, uint8_t* __restrict__ keep) {
+  for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < n; p += gridDim.x * 256ull) {
+    const uint32_t i = rowidx[p], j = tcol[p];
+    uint32_t lo = mrp[i], hi = mrp[i + 1];
+    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (mcol[mid] < j) lo = mid + 1; else hi = mid; }
+    const bool m = lo < mrp[i + 1] && mcol[lo] == j && mask_truth(mval, mcode, lo, mstruct);
+    keep[p] = ((m != mcomp) != invert) ? 1 : 0;
   }
 }
-void mask_flags(const DevCSR& Tm, const DevCSR& M, int mcode, bool mstruct, bool mcomp, uint8_t* keep) {
+static void mask_flags_ex(const DevCSR& Tm, const DevCSR& M, int mcode, bool mstruct, bool mcomp, bool invert, uint8_t* keep) {
   if (!Tm.nnz) return;
-  hipLaunchKernelGGL(k_mask_flags, dim3(grid_rows(Tm.nrows)), dim3(256), 0, stream(), Tm.nrows, Tm.rowptr.as<uint32_t>(), Tm.col.as<uint32_t>(),
-                     M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(), M.val.p, mcode, mstruct, mcomp, keep);
+  DevBuf rowidx(Tm.nnz * 4 + 4);
+  csr_row_indices(Tm, rowidx.as<uint32_t>());
+  hipLaunchKernelGGL(k_mask_flags, dim3(grid_n(Tm.nnz)), dim3(256), 0, stream(), Tm.nnz, rowidx.as<uint32_t>(), Tm.col.as<uint32_t>(), M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(), M.val.p, mcode,
+                     mstruct, mcomp, invert, keep);
+  GRB_HIP(hipStreamSynchronize(stream()));
+}
+void mask_flags(const DevCSR& Tm, const DevCSR& M, int mcode, bool mstruct, bool mcomp, uint8_t* keep) { mask_flags_ex(Tm, M, mcode, mstruct, mcomp, false, keep); }
+
+// ---- element-wise union / intersection -----------------------------------------------------------------------------------------
+void merge_pairs_u64(const uint64_t* k1, const uint64_t* k2, uint64_t* kout, const uint32_t* v1, const uint32_t* v2, uint32_t* vout, uint64_t n1, uint64_t n2);   // grb_prims.hip
+static __global__ void k_entry_keys(uint64_t n, const uint32_t* __restrict__ rowidx, const uint32_t* __restrict__ col, uint32_t tag, unsigned long long* __restrict__ key, uint32_t* __restrict__ idx) {
+  for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < n; p += gridDim.x * 256ull) { key[p] = ((unsigned long long)rowidx[p] << 32) | col[p]; idx[p] = (uint32_t)p | tag; }
+}
+static __global__ void k_merge_emit(uint64_t n, const unsigned long long* __restrict__ key, bool is_union, uint32_t* __restrict__ e) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i <= n; i += gridDim.x * 256ull) {
+    bool out = false;
+    if (i < n) { const bool head = i == 0 || key[i] != key[i - 1], both = i + 1 < n && key[i + 1] == key[i]; out = head && (is_union || both); }
+    e[i] = out ? 1u : 0u;
+  }
+}
+static __global__ void k_merge_rowptr(const uint32_t* __restrict__ arp, const uint32_t* __restrict__ brp, uint32_t nrows, const uint32_t* __restrict__ pos, uint32_t* __restrict__ orp) {
+  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r <= nrows; r += (uint64_t)gridDim.x * 256ull) orp[r] = pos[(uint64_t)arp[r] + brp[r]];
+}
+template <class T, bool MATH> __global__ void k_merge_fill(uint64_t n, const unsigned long long* __restrict__ key, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ e,
+                                                           const uint32_t* __restrict__ pos, const T* __restrict__ aval, const T* __restrict__ bval, int op, uint32_t* __restrict__ ocol, T* __restrict__ oval) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) if (e[i]) {
+    const uint32_t w = pos[i]; const unsigned long long k = key[i]; const uint32_t x = idx[i];
+    const bool both = i + 1 < n && key[i + 1] == k;
+    T v;
+    if (both) { const uint32_t x2 = idx[i + 1]; const uint32_t xa = (x & 0x80000000u) ? x2 : x, xb = (x & 0x80000000u) ? x : x2;     // (whichever of the two came first)
+                v = apply_binop<T, true, MATH>(op, aval[xa & 0x7FFFFFFFu], bval[xb & 0x7FFFFFFFu]); }
+    else v = (x & 0x80000000u) ? bval[x & 0x7FFFFFFFu] : aval[x];
+    ocol[w] = (uint32_t)k; oval[w] = v;
+  }
+}
+void csr_ewise(int code, const DevCSR& A, const void* aval, const DevCSR& B, const void* bval, int op, bool is_union, DevCSR& out) {
+  const uint32_t nrows = A.nrows; const uint64_t na = A.nnz, nb = B.nnz, n = na + nb;
+  if (na >= 0x7FFFFFF0ull || nb >= 0x7FFFFFF0ull) fail(GrB_INSUFFICIENT_SPACE, "eWise: more than 2^31 entries in one operand");
+  out.clear(); out.nrows = nrows; out.ncols = A.ncols;
+  out.rowptr.alloc(((size_t)nrows + 1) * 4);
+  if (!n) { GRB_HIP(hipMemsetAsync(out.rowptr.p, 0, ((size_t)nrows + 1) * 4, stream())); out.nnz = 0; out.col.alloc(8); out.val.alloc(8); out.valid = true; return; }
+  DevBuf ka(na * 8 + 8), kb(nb * 8 + 8), ia(na * 4 + 4), ib(nb * 4 + 4), km(n * 8 + 8), im(n * 4 + 4), e((n + 1) * 4 + 4), pos((n + 1) * 4 + 4);
+  { DevBuf rowidx((na > nb ? na : nb) * 4 + 4);
+    if (na) { csr_row_indices(A, rowidx.as<uint32_t>()); hipLaunchKernelGGL(k_entry_keys, dim3(grid_n(na)), dim3(256), 0, stream(), na, rowidx.as<uint32_t>(), A.col.as<uint32_t>(), 0u, (unsigned long long*)ka.p, ia.as<uint32_t>()); }
+    if (nb) { csr_row_indices(B, rowidx.as<uint32_t>()); hipLaunchKernelGGL(k_entry_keys, dim3(grid_n(nb)), dim3(256), 0, stream(), nb, rowidx.as<uint32_t>(), B.col.as<uint32_t>(), 0x80000000u, (unsigned long long*)kb.p, ib.as<uint32_t>()); }
+    GRB_HIP(hipStreamSynchronize(stream())); }
+  merge_pairs_u64((const uint64_t*)ka.p, (const uint64_t*)kb.p, (uint64_t*)km.p, ia.as<uint32_t>(), ib.as<uint32_t>(), im.as<uint32_t>(), na, nb);
+  hipLaunchKernelGGL(k_merge_emit, dim3(grid_n(n + 1)), dim3(256), 0, stream(), n, (const unsigned long long*)km.p, is_union, e.as<uint32_t>());
+  exclusive_scan_u32(e.as<uint32_t>(), pos.as<uint32_t>(), n + 1);
+  hipLaunchKernelGGL(k_merge_rowptr, dim3(grid_n((uint64_t)nrows + 1)), dim3(256), 0, stream(), A.rowptr.as<uint32_t>(), B.rowptr.as<uint32_t>(), nrows, pos.as<uint32_t>(), out.rowptr.as<uint32_t>());
+  uint32_t total = 0;
+  GRB_HIP(hipMemcpyAsync(&total, pos.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+  out.nnz = total;
+  dispatch_type(code, [&]<class T>() {
+    out.col.alloc((size_t)total * 4 + 4); out.val.alloc((size_t)total * sizeof(T) + 8);
+#define GRB_EW_FILL(MATH) hipLaunchKernelGGL((k_merge_fill<T, MATH>), dim3(grid_n(n)), dim3(256), 0, stream(), n, (const unsigned long long*)km.p, im.as<uint32_t>(), e.as<uint32_t>(), pos.as<uint32_t>(), \
+                                             (const T*)aval, (const T*)bval, op, out.col.as<uint32_t>(), out.val.as<T>())
+    if (binop_needs_math(op)) GRB_EW_FILL(true); else GRB_EW_FILL(false);
+#undef GRB_EW_FILL
+  });
+  GRB_HIP(hipGetLastError());
+  GRB_HIP(hipStreamSynchronize(stream()));       // the temporaries return to the pool
+  out.valid = true;
+}
+
+// ---- write-back  out = C<M,replace> (+accum) T ------------------------------------------------------------------------------------
+static void csr_copy(const DevCSR& S, size_t ts, DevCSR& out) {
+  out.clear(); out.nrows = S.nrows; out.ncols = S.ncols; out.nnz = S.nnz;
+  out.rowptr.alloc(((size_t)S.nrows + 1) * 4); out.col.alloc(S.nnz * 4 + 4); out.val.alloc(S.nnz * ts + 8);
+  GRB_HIP(hipMemcpyAsync(out.rowptr.p, S.rowptr.p, ((size_t)S.nrows + 1) * 4, hipMemcpyDeviceToDevice, stream()));
+  if (S.nnz) { GRB_HIP(hipMemcpyAsync(out.col.p, S.col.p, S.nnz * 4, hipMemcpyDeviceToDevice, stream())); GRB_HIP(hipMemcpyAsync(out.val.p, S.val.p, S.nnz * ts, hipMemcpyDeviceToDevice, stream())); }
+  out.valid = true;
+}
+void csr_writeback(int code, uint32_t nrows, const DevCSR& C, const DevCSR& Tm, const DevCSR* M, int mcode, bool mstruct, bool mcomp,
+                   bool replace, int accum, DevCSR& out) {
+  (void)nrows;
+  const size_t ts = (size_t)type_size(code);
+  DevCSR Zacc; const DevCSR* Z = &Tm;
+  if (accum >= 0) { csr_ewise(code, C, C.val.p, Tm, Tm.val.p, accum, true, Zacc); Z = &Zacc; }       // Z = accum(C, T) on the union of the patterns
+  if (!M) {                                         // no mask: everything is allowed (the complemented no-mask case never gets here)
+    if (Z == &Zacc) out = std::move(Zacc); else csr_copy(Tm, ts, out);
+    return;
+  }
+  DevCSR Zk;
+  { DevBuf keep(Z->nnz + 8); mask_flags_ex(*Z, *M, mcode, mstruct, mcomp, false, keep.as<uint8_t>()); csr_compact(*Z, Z->val.p, ts, keep.as<uint8_t>(), Zk); }
+  if (replace || !C.nnz) { out = std::move(Zk); return; }
+  DevCSR Ck;
+  { DevBuf keep(C.nnz + 8); mask_flags_ex(C, *M, mcode, mstruct, mcomp, true, keep.as<uint8_t>()); csr_compact(C, C.val.p, ts, keep.as<uint8_t>(), Ck); }
+  csr_ewise(code, Zk, Zk.val.p, Ck, Ck.val.p, B_FIRST, true, out);              // disjoint patterns: a plain merge
 }
 
 // ---- reduce each row with a monoid -> bitmap vector ------------------------------------------------------------------------
@@ -228,9 +227,5 @@ void csr_reduce_rows(int code, const DevCSR& A, const void* aval, int op, void* 
   GRB_HIP(hipGetLastError());
 }
 
-void csr_row_indices(const DevCSR& A, uint32_t* rowidx) {
-  if (!A.nnz) return;
-  hipLaunchKernelGGL(k_row_of_entry, dim3(grid_rows(A.nrows)), dim3(256), 0, stream(), A.rowptr.as<uint32_t>(), A.nrows, rowidx);
-}
 
 }  // namespace grb

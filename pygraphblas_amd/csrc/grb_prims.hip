@@ -55,6 +55,15 @@ void sort_keys_u32(const uint32_t* kin, uint32_t* kout, uint64_t n, int end_bit)
   GRB_HIP(rocprim::radix_sort_keys(t.p, tmp, kin, kout, (size_t)n, 0u, (unsigned)end_bit, stream()));
 }
 
+// stable merge of two sorted key sequences with their values (equal keys: the first input's entries first)
+void merge_pairs_u64(const uint64_t* k1, const uint64_t* k2, uint64_t* kout, const uint32_t* v1, const uint32_t* v2, uint32_t* vout, uint64_t n1, uint64_t n2) {
+  if (!(n1 + n2)) return;
+  size_t tmp = 0;
+  GRB_HIP(rocprim::merge(nullptr, tmp, k1, k2, kout, v1, v2, vout, (size_t)n1, (size_t)n2, rocprim::less<uint64_t>(), stream()));
+  DevBuf t(tmp ? tmp : 16);
+  GRB_HIP(rocprim::merge(t.p, tmp, k1, k2, kout, v1, v2, vout, (size_t)n1, (size_t)n2, rocprim::less<uint64_t>(), stream()));
+}
+
 // every segment [offsets[s], offsets[s+1]) sorted by key on its own (rows of a CSR put in column order)
 void segmented_sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n, uint32_t nseg, const uint32_t* offsets, int end_bit) {
   if (!n || !nseg) return;
