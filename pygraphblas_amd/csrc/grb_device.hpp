@@ -165,6 +165,7 @@ struct ScalarSlot {
 // ---- library-backed primitives (grb_prims.hip: rocPRIM scan / radix sort) ------------------------------------
 void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n);            // out[i] = sum in[0..i)
 void inclusive_scan_max_u32(const uint32_t* in, uint32_t* out, uint64_t n);        // out[i] = max in[0..i]   (in == out allowed)
+void exclusive_scan_u64(const uint64_t* in, uint64_t* out, uint64_t n);                // out[i] = sum in[0..i)
 void exclusive_scan_max_u64(const uint64_t* in, uint64_t* out, uint64_t n);        // out[i] = max(0, in[0..i))
 void sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n, int end_bit);
 void sort_keys_u32(const uint32_t* kin, uint32_t* kout, uint64_t n, int end_bit);

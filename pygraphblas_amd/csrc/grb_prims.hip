@@ -23,6 +23,14 @@ void inclusive_scan_max_u32(const uint32_t* in, uint32_t* out, uint64_t n) {
   GRB_HIP(rocprim::inclusive_scan(t.p, tmp, in, out, (size_t)n, rocprim::maximum<uint32_t>(), stream()));
 }
 
+void exclusive_scan_u64(const uint64_t* in, uint64_t* out, uint64_t n) {
+  if (!n) return;
+  size_t tmp = 0;
+  GRB_HIP(rocprim::exclusive_scan(nullptr, tmp, in, out, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), stream()));
+  DevBuf t(tmp ? tmp : 16);
+  GRB_HIP(rocprim::exclusive_scan(t.p, tmp, in, out, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), stream()));
+}
+
 void exclusive_scan_max_u64(const uint64_t* in, uint64_t* out, uint64_t n) {
   if (!n) return;
   size_t tmp = 0;

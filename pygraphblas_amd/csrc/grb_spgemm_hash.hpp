@@ -175,7 +175,7 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
   auto nblocks = [&](uint32_t rows, int teams) { uint64_t b = ((uint64_t)rows + teams - 1) / teams; if (b > (uint64_t)ncu * 32) b = (uint64_t)ncu * 32; if (b < 1) b = 1; return (unsigned)b; };
   // ---- product counts, symbolic bins -----------------------------------------------------------------------------------------
   DevBuf ub((size_t)nrows * 8 + 8), rownnz(((size_t)nrows + 1) * 4), counts(64), lists((size_t)4 * nrows * 4 + 4);
-  hipLaunchKernelGGL(k_row_upper_bound, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, A.rowptr.as<uint32_t>(), A.col.as<uint32_t>(), B.rowptr.as<uint32_t>(), ub.as<unsigned long long>());
+  row_upper_bound(A, B, ub.as<unsigned long long>());
   GRB_HIP(hipMemsetAsync(rownnz.p, 0, ((size_t)nrows + 1) * 4, stream()));
   GRB_HIP(hipMemsetAsync(counts.p, 0, 64, stream()));
   hipLaunchKernelGGL(k_hash_bin, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, ub.as<unsigned long long>(), (const uint32_t*)nullptr, 128ull, 1024ull, 16384ull, counts.as<uint32_t>(), lists.as<uint32_t>());

@@ -398,13 +398,21 @@ template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDes
 }
 
 // ---- (2) expand / sort / compress ------------------------------------------------------------------------------------------
-static __global__ void k_row_upper_bound(uint32_t nrows, const uint32_t* __restrict__ arp, const uint32_t* __restrict__ acol, const uint32_t* __restrict__ brp,
-                                  unsigned long long* __restrict__ ub) {
-  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nrows; r += (uint64_t)gridDim.x * 256ull) {
-    unsigned long long s = 0;
-    for (uint32_t p = arp[r]; p < arp[r + 1]; p++) { const uint32_t k = acol[p]; s += brp[k + 1] - brp[k]; }
-    ub[r] = s;
-  }
+// products of every row, ub[r] = sum_{k in A(r,:)} nnz(B(k,:)), per ENTRY: the B-row lengths of the entries, an exclusive scan over
+// them, and the difference at the row boundaries (a thread walking a 1e5-entry hub row alone was the whole kernel)
+static __global__ void k_entry_products(uint64_t nnz, const uint32_t* __restrict__ acol, const uint32_t* __restrict__ brp, unsigned long long* __restrict__ c) {
+  for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p <= nnz; p += gridDim.x * 256ull) { if (p < nnz) { const uint32_t k = acol[p]; c[p] = brp[k + 1] - brp[k]; } else c[p] = 0; }
+}
+static __global__ void k_row_products(uint32_t nrows, const uint32_t* __restrict__ arp, const unsigned long long* __restrict__ P, unsigned long long* __restrict__ ub) {
+  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nrows; r += (uint64_t)gridDim.x * 256ull) ub[r] = P[arp[r + 1]] - P[arp[r]];
+}
+static inline void row_upper_bound(const DevCSR& A, const DevCSR& B, unsigned long long* ub) {
+  auto grid_n = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 8192) b = 8192; return (unsigned)b; };
+  DevBuf c((A.nnz + 1) * 8 + 8), P((A.nnz + 1) * 8 + 8);
+  hipLaunchKernelGGL(k_entry_products, dim3(grid_n(A.nnz + 1)), dim3(256), 0, stream(), A.nnz, A.col.as<uint32_t>(), B.rowptr.as<uint32_t>(), c.as<unsigned long long>());
+  exclusive_scan_u64((const uint64_t*)c.p, (uint64_t*)P.p, A.nnz + 1);
+  hipLaunchKernelGGL(k_row_products, dim3(grid_n(A.nrows)), dim3(256), 0, stream(), A.nrows, A.rowptr.as<uint32_t>(), P.as<unsigned long long>(), ub);
+  GRB_HIP(hipStreamSynchronize(stream()));
 }
 
 // one wave per row of the chunk: products of row i are written at off[i - r0] in (k, then B-row) order
@@ -458,7 +466,7 @@ template <class T> void run_spgemm_esc(const SpgemmCall& c, const SemiringDesc& 
   auto grid_n = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 8192) b = 8192; return (unsigned)b; };
   // per-row product counts on the host decide the chunking (bounded temporary memory)
   DevBuf ub((size_t)nrows * 8 + 8);
-  hipLaunchKernelGGL(k_row_upper_bound, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, A.rowptr.as<uint32_t>(), A.col.as<uint32_t>(), B.rowptr.as<uint32_t>(), ub.as<unsigned long long>());
+  row_upper_bound(A, B, ub.as<unsigned long long>());
   std::vector<unsigned long long> hub(nrows);
   if (nrows) GRB_HIP(hipMemcpyAsync(hub.data(), ub.p, (size_t)nrows * 8, hipMemcpyDeviceToHost, stream()));
   GRB_HIP(hipStreamSynchronize(stream()));
