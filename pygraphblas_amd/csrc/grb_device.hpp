@@ -143,6 +143,12 @@ template <class T> __device__ __forceinline__ bool val_eq(T a, T b) {
 #define memcmp_eq(a, b) ::grb::val_eq(a, b)
 
 // ---- a device word the host can read back (count results, flags) ------------------------------------------
+// 256 bytes of page-locked host memory per thread: the landing place of the small device-to-host readbacks (counts, reduced scalars)
+inline void* pinned_scratch() {
+  static thread_local void* p = nullptr;
+  if (!p) GRB_HIP(hipHostMalloc(&p, 256, hipHostMallocDefault));
+  return p;
+}
 struct ScalarSlot {
   // two 64-bit counters that are zero between uses: the reader re-zeroes them right behind its copy, so the memset is
   // dispatched while the host waits for the result instead of in front of the next counting kernel
@@ -154,10 +160,11 @@ struct ScalarSlot {
   void* dev() { return buf().p; }
   void zero() {}
   void read(uint64_t out[2]) {
-    out[0] = out[1] = 0;
-    GRB_HIP(hipMemcpyAsync(out, buf().p, 16, hipMemcpyDeviceToHost, stream()));
+    uint64_t* pin = (uint64_t*)pinned_scratch();      // a copy into pageable memory goes through a staging kernel (18 us per readback on this box)
+    GRB_HIP(hipMemcpyAsync(pin, buf().p, 16, hipMemcpyDeviceToHost, stream()));
     GRB_HIP(hipMemsetAsync(buf().p, 0, 16, stream()));
     GRB_HIP(hipStreamSynchronize(stream()));
+    out[0] = pin[0]; out[1] = pin[1];
   }
   uint64_t read_u64() { uint64_t v[2]; read(v); return v[0]; }
 };

@@ -216,9 +216,10 @@ void reduce_values(int code, uint64_t n, const void* val, const uint8_t* pres, i
     DevBuf part((size_t)g * sizeof(T)), fin(sizeof(T) * 1);
     hipLaunchKernelGGL((k_reduce<T>), dim3(g), dim3(256), 0, stream(), n, (const T*)val, pres, op, id, part.as<T>());
     hipLaunchKernelGGL((k_reduce<T>), dim3(1), dim3(256), 0, stream(), (uint64_t)g, (const T*)part.as<T>(), (const uint8_t*)nullptr, op, id, fin.as<T>());
-    T r; GRB_HIP(hipMemcpyAsync(&r, fin.p, sizeof(T), hipMemcpyDeviceToHost, stream()));
+    void* pin = pinned_scratch();
+    GRB_HIP(hipMemcpyAsync(pin, fin.p, sizeof(T), hipMemcpyDeviceToHost, stream()));
     GRB_HIP(hipStreamSynchronize(stream()));
-    memcpy(result_host, &r, sizeof(T));
+    memcpy(result_host, pin, sizeof(T));
   });
 }
 
@@ -229,9 +230,10 @@ void reduce_values_f32_f64(uint64_t n, const void* val_f32, const uint8_t* pres,
   DevBuf part((size_t)g * 8), fin(8);
   hipLaunchKernelGGL(k_reduce_f32_f64, dim3(g), dim3(256), 0, stream(), n, (const float*)val_f32, pres, op, id, part.as<double>());
   hipLaunchKernelGGL((k_reduce<double>), dim3(1), dim3(256), 0, stream(), (uint64_t)g, (const double*)part.as<double>(), (const uint8_t*)nullptr, op, id, fin.as<double>());
-  double r; GRB_HIP(hipMemcpyAsync(&r, fin.p, 8, hipMemcpyDeviceToHost, stream()));
+  void* pin = pinned_scratch();
+  GRB_HIP(hipMemcpyAsync(pin, fin.p, 8, hipMemcpyDeviceToHost, stream()));
   GRB_HIP(hipStreamSynchronize(stream()));
-  memcpy(result_host, &r, 8);
+  memcpy(result_host, pin, 8);
 }
 
 // ---- element-wise union / intersection of two bitmap vectors ----------------------------------------------------
