@@ -319,12 +319,6 @@ template <class T> __global__ void k_scatter_acc(uint64_t mnz, const uint32_t* _
   for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < mnz; p += gridDim.x * 256ull)
     if (cflag[p]) { const uint32_t w = pos[p]; ocol[w] = mcol[p]; oval[w] = from_word<T>(cacc[p]); }
 }
-static __global__ void k_count_flags_rows(uint32_t nrows, const uint32_t* __restrict__ rp, const uint8_t* __restrict__ flag, uint32_t* __restrict__ cnt) {
-  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nrows; r += (uint64_t)gridDim.x * 256ull) {
-    uint32_t c = 0; for (uint32_t p = rp[r]; p < rp[r + 1]; p++) c += flag[p] != 0; cnt[r] = c;
-  }
-}
-
 template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDesc& d, DevCSR& out) {
   typedef typename acc_word<T>::type W;
   const DevCSR& A = *c.A; const DevCSR& B = *c.B; const DevCSR& M = *c.M;

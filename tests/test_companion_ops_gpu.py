@@ -203,3 +203,39 @@ def test_bulk_csr_roundtrip_and_scipy(gpu):
     perm = rng.permutation(S.nnz); coo = S.tocoo()
     m2 = gb.Matrix.from_arrays(coo.row[perm].astype(np.uint64), coo.col[perm].astype(np.uint64), coo.data[perm], 300, 200, gb.FP64)
     assert m2.iseq(m)
+
+
+def test_entry_parallel_companions_on_a_power_law_graph(gpu):
+    """select / eWise / masked write-back on R-MAT-15 (hub rows of thousands of entries, long runs of empty rows) against scipy:
+    the entry-parallel kernels (scan, binary search, one stable merge) must not depend on how the entries split into rows."""
+    from pygraphblas_amd import rmat
+    scale = 15; n = 1 << scale
+    rp, col = rmat.csr_numpy(scale, symmetric=True, drop_self_loops=True)
+    rng = np.random.default_rng(3)
+    av = rng.integers(1, 9, len(col)).astype(np.int64)
+    A = gb.Matrix.from_csr(gb.INT64, n, n, rp, col, av)
+    SA = sp.csr_matrix((av, col.astype(np.int64), rp.astype(np.int64)), shape=(n, n))
+    rp2, col2 = rmat.csr_numpy(scale, seed=7)                                 # another graph, not symmetric
+    bv = rng.integers(1, 9, len(col2)).astype(np.int64)
+    B = gb.Matrix.from_csr(gb.INT64, n, n, rp2, col2, bv)
+    SB = sp.csr_matrix((bv, col2.astype(np.int64), rp2.astype(np.int64)), shape=(n, n))
+
+    def same(M, S):
+        S = S.tocsr(); S.sort_indices()
+        grp, gci, gx = M.to_csr()
+        assert np.array_equal(grp.astype(np.int64), S.indptr) and np.array_equal(gci.astype(np.int64), S.indices) and np.array_equal(gx, S.data)
+    same(A.tril(), sp.tril(SA)); same(A.triu(1), sp.triu(SA, 1)); same(A.offdiag(), SA - sp.diags(SA.diagonal()))
+    same(A.select(">", 4), SA.multiply(SA > 4))
+    same(A.eadd(B, gb.INT64.PLUS), SA + SB)
+    PA = (SA != 0).astype(np.int64); PB = (SB != 0).astype(np.int64)
+    same(A.emult(B, gb.INT64.TIMES), SA.multiply(SB))
+    # C<L> = accum(C, B): entries of C outside the mask stay, inside they take C + B (or B where C has none)
+    Lm = A.tril(); SL = (sp.tril(SA) != 0).astype(np.int64)
+    C = A.dup()
+    B.apply(gb.INT64.IDENTITY, out=C, mask=Lm, accum=gb.INT64.PLUS)
+    want = SA + SB.multiply(SL)
+    same(C, want)
+    # ... and with replace: everything outside the mask goes
+    C = A.dup()
+    B.apply(gb.INT64.IDENTITY, out=C, mask=Lm, accum=gb.INT64.PLUS, desc=D.R)
+    same(C, (SA + SB).multiply(SL))
