@@ -227,6 +227,64 @@ __global__ __launch_bounds__(256) void k_spmv_rowgroup(const SpmvKArgs<T> a, con
   }
 }
 
+// ---- kernel B': one LANE per row for the first entries, the wave for what is left ----------------------------------------------
+// The masked pull of a BFS level asks, for every unvisited vertex, whether ONE of its neighbours is visited: most rows are
+// empty, masked out, or decided by their first few entries.  With 8 lanes per row a wave has 8 rows in flight and every row is
+// a chain of four dependent loads (mask byte, row pointers, column, operand byte): 132 us for the 4 M rows of R-MAT-22, 2 TB/s
+// on paper and latency in fact.  Here a lane owns a row — 64 chains in flight per wave — and walks its first SPMV_LANE_E
+// entries; the rows that are neither finished nor at their monoid's terminal value by then (hub rows) are completed by the
+// whole wave, 64 entries per step, starting from the lane's partial result.
+constexpr uint32_t SPMV_LANE_E = 8;
+template <class T, class SR, bool U_FULL>
+__global__ __launch_bounds__(256) void k_spmv_rowlane(const SpmvKArgs<T> a, const SR sr) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = (uint64_t)gridDim.x * 4;
+  const bool use_a = sr.uses_a(), use_u = sr.uses_u();
+  const uint64_t nround = ((uint64_t)a.nrows + 63) / 64 * 64;
+  for (uint64_t base = wave * 64; base < nround; base += nwaves * 64) {
+    const uint64_t r = base + lane;
+    const bool valid = r < a.nrows, allowed = valid && (!a.allow || a.allow[r]);
+    uint32_t pb = 0, pe = 0;
+    if (allowed) { pb = a.rowptr[r]; pe = a.rowptr[r + 1]; }
+    T acc = sr.identity; bool has = false, done = !allowed;
+    if (allowed) {
+      const uint32_t e = pe - pb > SPMV_LANE_E ? pb + SPMV_LANE_E : pe;
+      for (uint32_t p = pb; p < e; p++) {
+        const uint32_t c = a.col[p];
+        bool pr = true;
+        if constexpr (!U_FULL) pr = a.upres[c] != 0;
+        if (pr) {
+          const T m = sr.mult(use_a ? a.aval[p] : T(), use_u ? a.uval[c] : T());
+          acc = has ? sr.add(acc, m) : m; has = true;
+          if (sr.has_terminal && memcmp_eq(acc, sr.terminal)) { done = true; break; }
+        }
+      }
+      if (pe - pb <= SPMV_LANE_E) done = true;
+    }
+    // the unfinished rows, one after the other, by the whole wave
+    unsigned long long todo = __ballot(allowed && !done);
+    while (todo) {
+      const int L = __builtin_ctzll(todo); todo &= todo - 1;
+      const uint32_t qb = (uint32_t)__shfl((int)pb, L, 64) + SPMV_LANE_E, qe = (uint32_t)__shfl((int)pe, L, 64);
+      T part = sr.identity; bool phas = false;
+      for (uint32_t p0 = qb; p0 < qe; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        if (p < qe) {
+          const uint32_t c = a.col[p];
+          bool pr = true;
+          if constexpr (!U_FULL) pr = a.upres[c] != 0;
+          if (pr) { const T m = sr.mult(use_a ? a.aval[p] : T(), use_u ? a.uval[c] : T()); part = phas ? sr.add(part, m) : m; phas = true; }
+        }
+        if (sr.has_terminal && __ballot(phas && memcmp_eq(part, sr.terminal))) break;      // some lane is at the terminal value: so is the row
+      }
+      const unsigned long long hb = __ballot(phas);
+      const T red = wave_reduce_op<T, false>(sr.add_op(), phas ? part : sr.identity);
+      if (lane == L && hb) { acc = has ? sr.add(acc, red) : red; has = true; }
+    }
+    if (valid) { if (allowed && has) a.tval[r] = acc; a.tpres[r] = (allowed && has) ? 1 : 0; }
+  }
+}
+
 // ---- kernel C: push.  t is pre-initialised (tpres = 0); entries are claimed with tpres CAS-free flags ---------------
 // Scatter with one atomic combine per product.  Used only for semirings whose monoid has a
 // native atomic (PLUS on 32/64-bit ints and floats, MIN/MAX on ints, LOR/ANY): chosen by the driver.
@@ -351,6 +409,14 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
 #define GRB_LAUNCH_B(GG) \
       if (full) hipLaunchKernelGGL((k_spmv_rowgroup<T, SR, GG, true>), dim3((unsigned)nb), dim3(256), 0, stream(), a, sr); \
       else hipLaunchKernelGGL((k_spmv_rowgroup<T, SR, GG, false>), dim3((unsigned)nb), dim3(256), 0, stream(), a, sr);
+      static const bool no_lane = wp_env("GRB_MI355X_NO_ROWLANE", 0) != 0;      // measurement hook
+      if (G == 8 && !no_lane && c.method == SPMV_AUTO) {                          // short rows on average: a lane per row (kernel B')
+        uint64_t nbl = ((uint64_t)M.nrows + 255) / 256; if (nbl < 1) nbl = 1; if (nbl > 65536) nbl = 65536;
+        if (full) hipLaunchKernelGGL((k_spmv_rowlane<T, SR, true>), dim3((unsigned)nbl), dim3(256), 0, stream(), a, sr);
+        else hipLaunchKernelGGL((k_spmv_rowlane<T, SR, false>), dim3((unsigned)nbl), dim3(256), 0, stream(), a, sr);
+        g_last_plan += std::string("k_spmv_rowlane<") + (sr.is_static ? "static>" : "dynamic>") + " ";
+        return;
+      }
       if (G == 64) { GRB_LAUNCH_B(64) } else { GRB_LAUNCH_B(8) }
 #undef GRB_LAUNCH_B
       g_last_plan += std::string("k_spmv_rowgroup<G=") + std::to_string(G) + (sr.is_static ? ",static>" : ",dynamic>") + " ";
