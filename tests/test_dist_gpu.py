@@ -160,3 +160,20 @@ def test_library_rccl_path_with_a_communicator_of_one(gb, gpu):
         assert np.array_equal(qi, ei[ex]) and qx.all()                                   # only the `true` entries travel
     finally:
         assert lib.GrBX_dist_finalize() == 0
+
+
+def test_bench_py_runs_its_two_rank_path_on_one_gpu(gpu):
+    """`bench.py --gpus 2` — what the driver launches for the scaling curve — end to end on this box: two ranks on GPU 0
+    (BENCH_DEVICE_OVERRIDE), the exchange through the host transport (RCCL cannot put two ranks on one device), at R-MAT-17
+    per rank.  The JSON line must parse, carry the N = 2 fields and a PageRank sub-object whose iteration count matches the
+    single-process loop."""
+    import json, subprocess
+    env = dict(os.environ, BENCH_DEVICE_OVERRIDE="0", BENCH_TRANSPORT="host", MASTER_ADDR="127.0.0.1")
+    port = 29800 + (os.getpid() % 1000)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--scale", "17"], capture_output=True, text=True, timeout=500, env=env, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["n"] == 1 << 18
+    assert d["roofline"]["bound"] == "hbm" and d["pagerank"]["iterations_to_converge"] > 5 and d["pagerank"]["dtype"] == "f32"
