@@ -154,6 +154,10 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
   XtStage<T> S[NS];
   auto load_cols = [&](XtStage<T>& s) {
     const bool ok = s.tile != WP_NONE;
+    if constexpr (EXP == 3) {        // timing experiment (wrong results): half the bytes of the column stream — what a 16-bit column plane could save at most
+      uint32_t h[2]; xt_stream_load<uint32_t, 2>(c_rsrc, ok ? (s.tile * (uint32_t)WP_ENT / 2 + lane * 2) * 4u : 0xFFFFFFFFu, h);
+      s.c[0] = h[0]; s.c[1] = h[1]; s.c[2] = h[0] ^ 0x11u; s.c[3] = h[1] ^ 0x7u;
+    } else
     xt_stream_load<uint32_t, WP_PER>(c_rsrc, ok ? (s.tile * (uint32_t)WP_ENT + lane * WP_PER) * 4u : 0xFFFFFFFFu, s.c);
     s.rf = wp_ld(a.trow + (ok ? s.tile : 0u));
   };

@@ -617,7 +617,7 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
       const XtVariant v = xt_variant();
 #define XT_TRY(D_, W_, E_) if (!launched && v.depth == D_ && v.waves == W_ && v.exp == E_) { \
         hipLaunchKernelGGL((k_spmv_tiles<T, SR, D_, W_, E_>), dim3(ncu), dim3(W_ * 64), 0, stream(), call, (const XtPanel<T>*)P->args.p, sr); launched = true; }
-      XT_TRY(1, 16, 1) XT_TRY(1, 16, 2) XT_TRY(2, 16, 0) XT_TRY(1, 8, 0) XT_TRY(2, 8, 0) XT_TRY(3, 8, 0) XT_TRY(2, 8, 2) XT_TRY(3, 8, 2) XT_TRY(4, 8, 0)
+      XT_TRY(1, 16, 1) XT_TRY(1, 16, 2) XT_TRY(1, 16, 3) XT_TRY(2, 16, 0) XT_TRY(1, 8, 0) XT_TRY(2, 8, 0) XT_TRY(3, 8, 0) XT_TRY(2, 8, 2) XT_TRY(3, 8, 2) XT_TRY(4, 8, 0)
 #undef XT_TRY
     }
 #endif
