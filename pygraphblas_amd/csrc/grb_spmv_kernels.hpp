@@ -221,8 +221,11 @@ __global__ __launch_bounds__(256) void k_spmv_rowgroup(const SpmvKArgs<T> a, con
     // reduce the G lanes (identity where a lane saw nothing)
     T v = has ? acc : sr.identity;
     unsigned long long hb = __ballot(has);
-    if constexpr (G == 64) { v = wave_reduce_op<T, false>(sr.add_op(), v); }
-    else { v = group_reduce_op<T, G, false>(sr.add_op(), v); hb = (hb >> ((threadIdx.x & 63) & ~(G - 1))) & ((G == 64) ? ~0ull : ((1ull << G) - 1)); }
+    const int gbase = (threadIdx.x & 63) & ~(G - 1);
+    const unsigned long long gb = G == 64 ? hb : ((hb >> gbase) & ((1ull << (G & 63)) - 1));
+    if (sr.add_op() == B_ANY) { v = shfl_t<T>(v, gbase + (gb ? __builtin_ctzll(gb) : 0)); hb = gb; }        // ANY: the value of a lane that has one, not the identity of one that has none
+    else if constexpr (G == 64) { v = wave_reduce_op<T, false>(sr.add_op(), v); }
+    else { v = group_reduce_op<T, G, false>(sr.add_op(), v); hb = gb; }
     if (lane == 0) { const bool h = hb != 0; if (h) a.tval[r] = v; a.tpres[r] = h ? 1 : 0; }
   }
 }
@@ -278,7 +281,8 @@ __global__ __launch_bounds__(256) void k_spmv_rowlane(const SpmvKArgs<T> a, cons
         if (sr.has_terminal && __ballot(phas && memcmp_eq(part, sr.terminal))) break;      // some lane is at the terminal value: so is the row
       }
       const unsigned long long hb = __ballot(phas);
-      const T red = wave_reduce_op<T, false>(sr.add_op(), phas ? part : sr.identity);
+      // (ANY keeps "a" value: the tree below would also consider the identity of the lanes that saw nothing — take a real one)
+      const T red = sr.add_op() == B_ANY ? shfl_t<T>(part, hb ? __builtin_ctzll(hb) : 0) : wave_reduce_op<T, false>(sr.add_op(), phas ? part : sr.identity);
       if (lane == L && hb) { acc = has ? sr.add(acc, red) : red; has = true; }
     }
     if (valid) { if (allowed && has) a.tval[r] = acc; a.tpres[r] = (allowed && has) ? 1 : 0; }

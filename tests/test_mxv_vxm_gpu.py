@@ -260,3 +260,23 @@ def test_user_semirings_bitwise_run_and_math_multipliers_are_refused(gpu):
     assert b"not implemented" in msg.value
     assert wf.nvals == 0
     lib.GrB_Semiring_free(C.byref(sr2))
+
+
+def test_any_monoid_under_a_mask_takes_a_real_value(gpu):
+    """Found by tools/fuzz_parity.py: the masked pull kernels reduce the lanes of a row with a tree that also saw the identity
+    of the lanes without an entry — harmless for every monoid but ANY, which may keep either argument.  Rows longer than the
+    lane-per-row prefix (8 entries) and than a row group, automatic kernel choice and the forced row-group kernel."""
+    rng = np.random.default_rng(2)
+    for typ in ("INT64", "FP32", "UINT8"):
+        for method in (None, "rowgroup"):
+            for vxm in (False, True):
+                run_case(rng, typ, "ANY_PAIR", 120, 90, 0.5, 0.7, vxm=vxm, mask={"typ": "UINT8", "dens": 0.0, "comp": True}, method=method)
+                run_case(rng, typ, "ANY_PAIR", 120, 90, 0.5, 0.7, vxm=vxm, mask={"typ": "BOOL", "dens": 0.6}, method=method)
+
+
+def test_short_differential_fuzz_against_the_oracle(gpu):
+    """Ten seconds of tools/fuzz_parity.py (random types / semirings / masks / accumulators / descriptors for mxv, vxm, mxm)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--seconds", "10", "--seed", "11"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
