@@ -49,7 +49,7 @@ struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per 
   DevBuf m_blockptr;      // u32[(m_nblocks+1)*XP] first sub-row of panel k in block b
   DevBuf m_slot;          // u16[F]  slot of every sub-row in its block's row-major order (row, then panel, then position in a chain)
   DevBuf m_rowoff;        // u16[nrows] slot of every row's first sub-row in its block
-  uint32_t m_nblocks = 0; bool m_ok = false;
+  uint32_t m_nblocks = 0, m_slots = 0; bool m_ok = false;      // m_slots: LDS slots a block may need (XM_TARGET + the longest row's sub-rows)
   DevBuf args;            // XtPanel<T>[XP] in HBM; never changes between calls (u and the partial array arrive as kernel arguments)
   DevBuf xhot, partial;   // per-call work buffers kept with the plan (xhot: T[XP*H], the LDS tables' contents)
   uint64_t ne[XP]; uint32_t tbase[XP + 1]; uint32_t ntiles[XP], nhot[XP];
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(XP_CT) void k_xp_combine(uint32_t nrows, const uint
 // block into LDS by slot — one LDS write per sub-row, no read-modify-write, no per-panel phase — and after ONE barrier every
 // row adds its consecutive slots in order (fixed order => reproducible) and writes y.  Against k_xp_combine: 2 LDS operations
 // per sub-row instead of ~7, one barrier instead of four, blocks of equal weight whatever the labels of the graph.
-constexpr uint32_t XM_ROWS = 1024, XM_TARGET = 2048, XM_SLOTS = 2560;   // a block holds < XM_TARGET + (sub-rows of one row) sub-rows; the plan checks that this fits XM_SLOTS
+constexpr uint32_t XM_ROWS = 1024, XM_TARGET = 2048, XM_SLOTS = 2560;   // a block holds < XM_TARGET + (sub-rows of one row) sub-rows: XM_SLOTS of LDS, more (up to 64 KB) when a row has very many
 constexpr int XM_CT = 256;
 static __global__ void k_xm_iota(uint32_t* p, uint64_t n) { for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) p[i] = (uint32_t)i; }
 static __global__ void k_xm_weights(const uint32_t* __restrict__ cnt, uint32_t nrows, uint32_t* __restrict__ w) {
@@ -406,7 +406,8 @@ static __global__ void k_xm_max(const uint32_t* __restrict__ cnt, uint32_t nrows
 template <class T, class SR>
 __global__ __launch_bounds__(XM_CT) void k_xp_merge(uint32_t nrows, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ blockptr, const uint16_t* __restrict__ slot,
                                                     const uint16_t* __restrict__ rowoff, const T* __restrict__ partial, T* __restrict__ y, uint8_t* __restrict__ ypres, const SR sr) {
-  __shared__ T vals[XM_SLOTS];
+  extern __shared__ __attribute__((aligned(16))) unsigned char xm_lds[];      // m_slots values: XM_SLOTS unless some row has very many sub-rows
+  T* const vals = (T*)xm_lds;
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
   const uint32_t r0 = bstart[b], r1 = bstart[b + 1];
   uint32_t lo[XP], pre[XP + 1];
@@ -429,12 +430,25 @@ __global__ __launch_bounds__(XM_CT) void k_xp_merge(uint32_t nrows, const uint32
     for (int u = 0; u < 4; u++) if (sl[u] != 0xFFFFFFFFu) vals[sl[u]] = v[u];
   }
   __syncthreads();
-  for (uint32_t i = tid; i < r1 - r0; i += XM_CT) {
+  const int lane = tid & 63;
+  const uint32_t nr = r1 - r0, nround = (nr + XM_CT - 1) / XM_CT * XM_CT;
+  for (uint32_t i = tid; i < nround; i += XM_CT) {
+    const bool live = i < nr;
     const uint32_t r = r0 + i;
-    const uint32_t o0 = rowoff[r], o1 = i + 1 < r1 - r0 ? (uint32_t)rowoff[r + 1] : total;
+    const uint32_t o0 = live ? (uint32_t)rowoff[r] : 0u, o1 = live ? (i + 1 < nr ? (uint32_t)rowoff[r + 1] : total) : 0u;
+    const bool wide = o1 - o0 > 64u;                                  // a row cut into many sub-rows (a dense row: 8 panels x its chunks): the whole wave adds it
     T acc = T();
-    if (o1 > o0) { acc = vals[o0]; for (uint32_t q = o0 + 1; q < o1; q++) acc = sr.add(acc, vals[q]); }
-    y[r] = acc; ypres[r] = o1 > o0 ? 1 : 0;
+    if (o1 > o0 && !wide) { acc = vals[o0]; for (uint32_t q = o0 + 1; q < o1; q++) acc = sr.add(acc, vals[q]); }
+    unsigned long long todo = __ballot(wide);
+    while (todo) {
+      const int L = __builtin_ctzll(todo); todo &= todo - 1;
+      const uint32_t q0 = (uint32_t)__shfl((int)o0, L, 64), q1 = (uint32_t)__shfl((int)o1, L, 64);
+      T part = sr.identity; bool has = false;
+      for (uint32_t q = q0 + lane; q < q1; q += 64) { part = has ? sr.add(part, vals[q]) : vals[q]; has = true; }      // lane-strided, then a fixed tree: reproducible
+      const T red = wave_reduce_op<T, false>(sr.add_op(), has ? part : sr.identity);
+      if (lane == L) acc = red;
+    }
+    if (live) { y[r] = acc; ypres[r] = o1 > o0 ? 1 : 0; }
   }
 }
 
@@ -564,7 +578,9 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals) {
     uint32_t hnb = 0, hmax = 0;
     GRB_HIP(hipMemcpyAsync(&hnb, nfs.as<uint32_t>() + nr, 4, hipMemcpyDeviceToHost, stream()));
     GRB_HIP(hipMemcpyAsync(&hmax, dmax.p, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
-    P->m_nblocks = hnb; P->m_ok = hnb > 0 && (uint64_t)XM_TARGET + hmax + XM_TARGET / XM_ROWS <= XM_SLOTS && F < 0xFFFFFFF0ull;
+    const uint64_t need = (uint64_t)XM_TARGET + hmax + XM_TARGET / XM_ROWS;
+    P->m_slots = need <= XM_SLOTS ? XM_SLOTS : (uint32_t)((need + 255) / 256 * 256);
+    P->m_nblocks = hnb; P->m_ok = hnb > 0 && (uint64_t)P->m_slots * sizeof(T) <= 64u * 1024u && P->m_slots < 65536u && F < 0xFFFFFFF0ull;      // (16-bit slots; 64 KB of LDS at most)
     if (P->m_ok) {
       P->m_bstart.alloc(((size_t)hnb + 1) * 4 + 4); P->m_blockptr.alloc(((size_t)hnb + 1) * XP * 4 + 4); P->m_slot.alloc(F * 2 + 4); P->m_rowoff.alloc((size_t)nr * 2 + 4);
       hipLaunchKernelGGL(k_xm_bstart, dim3(grid_n((uint64_t)nr + 1)), dim3(256), 0, stream(), nf.as<uint32_t>(), nfs.as<uint32_t>(), nr, hnb, P->m_bstart.as<uint32_t>());
@@ -625,7 +641,7 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
     const uint32_t nblocks = (uint32_t)(((uint64_t)M.nrows + XP_RB - 1) / XP_RB);
     static const bool old_merge = wp_env("GRB_MI355X_XP_OLD_MERGE", 0) != 0;       // measurement hook: the per-panel merge kernel
     if (P->m_ok && !old_merge)
-      hipLaunchKernelGGL((k_xp_merge<T, SR>), dim3(P->m_nblocks), dim3(XM_CT), 0, stream(), M.nrows, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), P->m_slot.as<uint16_t>(),
+      hipLaunchKernelGGL((k_xp_merge<T, SR>), dim3(P->m_nblocks), dim3(XM_CT), (size_t)P->m_slots * sizeof(T), stream(), M.nrows, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), P->m_slot.as<uint16_t>(),
                          P->m_rowoff.as<uint16_t>(), P->partial.as<T>(), (T*)c.tval, c.tpres, sr);
     else
       hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3(nblocks), dim3(XP_CT), 0, stream(), M.nrows, P->blockptr.as<uint32_t>(), P->lrow.as<uint16_t>(), P->partial.as<T>(),
