@@ -280,3 +280,37 @@ def test_short_differential_fuzz_against_the_oracle(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--seconds", "10", "--seed", "11"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_kernel_x_extreme_shapes_at_scale(gpu):
+    """Kernel X (panel pipeline + merge) on large matrices far from a graph: one dense row of 8 M entries (more sub-rows than a
+    block of the row-major merge can hold: the per-panel merge takes over), a few dozen dense rows (wide rows added by a whole
+    wave), millions of two-entry rows confined to one line of u (seven empty panels).  INT64 PLUS_TIMES, exact."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    for nrows, ncols, kind in ((1, 1 << 23, "dense"), (48, 1 << 18, "dense"), (1 << 22, 8, "two")):
+        if kind == "dense":
+            rowptr = (torch.arange(nrows + 1, device=dev, dtype=torch.int64) * ncols).to(torch.int32)
+            col = torch.arange(ncols, device=dev, dtype=torch.int32).repeat(nrows)
+        else:
+            rowptr = (torch.arange(nrows + 1, device=dev, dtype=torch.int64) * 2).to(torch.int32)
+            c0 = torch.randint(0, 4, (nrows,), device=dev, generator=g, dtype=torch.int32)
+            col = torch.stack([c0, c0 + 1 + torch.randint(0, 3, (nrows,), device=dev, generator=g, dtype=torch.int32)], 1).reshape(-1).contiguous()
+        nnz = int(col.numel())
+        vals = torch.randint(-3, 4, (nnz,), device=dev, generator=g, dtype=torch.int64)
+        xs = torch.randint(-5, 6, (ncols,), device=dev, generator=g, dtype=torch.int64)
+        A = gb.Matrix.from_csr(gb.INT64, nrows, ncols, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+        x = gb.Vector.from_dense_array((xs.data_ptr(), ncols), gb.INT64, device=True)
+        os.environ["GRB_MI355X_SPMV"] = "xcd"
+        try:
+            w = A.mxv(x, semiring=gb.INT64.PLUS_TIMES)
+            assert "k_spmv_xcd" in gb.last_kernel_plan(), gb.last_kernel_plan()
+            w2 = A.mxv(x, semiring=gb.INT64.PLUS_TIMES)
+        finally:
+            os.environ.pop("GRB_MI355X_SPMV", None)
+        gy, gp = w.to_dense_arrays()
+        prod = vals * xs[col.to(torch.int64)]
+        want = torch.zeros(nrows, dtype=torch.int64, device=dev).index_add_(0, torch.repeat_interleave(torch.arange(nrows, device=dev), (rowptr[1:] - rowptr[:-1]).to(torch.int64)), prod)
+        assert gp.all() and np.array_equal(gy, want.cpu().numpy()), (nrows, ncols, kind)
+        assert np.array_equal(w2.to_dense_arrays()[0], gy)
