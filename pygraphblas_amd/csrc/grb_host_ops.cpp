@@ -62,7 +62,8 @@ void store(GrB_Vector w, const Map& m) {
 Val cast(int dst, int src, const Val& v) { Val o{}; cast_scalar(dst, o.data(), src, v.data()); return o; }
 bool truth(int code, const Val& v) { Val b = cast(T_BOOL, code, v); return b[0] != 0; }
 Val combine(GrB_BinaryOp op, int ccode, const Val& c, int tcode, const Val& t) {          // accum(c, t) in the operator's domain, result in C's type
-  const int ac = op->xtype->code; Val a = cast(ac, ccode, c), b = cast(ac, tcode, t), z{};
+  const int ac = op->xtype->code; if (ac >= T_FC32) fail(GrB_DOMAIN_MISMATCH, "operators on complex values are out of scope");
+  Val a = cast(ac, ccode, c), b = cast(ac, tcode, t), z{};
   dispatch_type(ac, [&]<class T>() { T x, y; memcpy(&x, a.data(), sizeof(T)); memcpy(&y, b.data(), sizeof(T)); T r = apply_binop<T>(op->opcode, x, y); memcpy(z.data(), &r, sizeof(T)); });
   return cast(ccode, op->ztype->code, z);
 }
@@ -304,4 +305,45 @@ GrB_Info GxB_Vector_apply_BinaryOp2nd(GrB_Vector C, const GrB_Vector M, const Gr
 
 double GxB_ALWAYS_HYPER = 1.0, GxB_NEVER_HYPER = -1.0, GxB_HYPER_DEFAULT = 0.0625;      // hyper_switch settings (stored options only)
 
+
+// ---- a complex scalar into a region: host-side container work, like the index assigns above ---------------------
+// (`Matrix.dense(FC64, 10, 10)` is `M[:, :] = 0j`, pygraphblas/matrix.py:225-230; tests/test_matrix.py:853)
+typedef struct { float re, im; } GxB_FC32_t;
+typedef struct { double re, im; } GxB_FC64_t;
+static GrB_Info mat_assign_complex(GrB_Matrix C, GrB_Matrix Mask, GrB_BinaryOp accum, const void* x, int xcode, const GrB_Index* I, GrB_Index ni, const GrB_Index* J, GrB_Index nj, GrB_Descriptor desc) {
+  if (!C) return GrB_NULL_POINTER; if (!check_obj(C)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(C, [&] {
+    if (Mask) check_m(Mask, "assign");
+    const DescView dv(desc);
+    if (Mask && (Mask->nrows != C->nrows || Mask->ncols != C->ncols)) fail(GrB_DIMENSION_MISMATCH, "assign: mask dimensions");
+    if ((I == GrB_ALL ? (double)C->nrows : (double)ni) * (J == GrB_ALL ? (double)C->ncols : (double)nj) > 16777216.0)
+      fail(GrB_INSUFFICIENT_SPACE, "assign: a complex scalar over more than 2^24 positions (complex containers are kept on the host)");
+    const auto ri = indices(I, ni, C->nrows, "assign"), ci = indices(J, nj, C->ncols, "assign");
+    Map Cm = load(C, false), Am, Mm; if (Mask) Mm = load(Mask, false);
+    Val v{}; memcpy(v.data(), x, (size_t)type_size(xcode));
+    for (size_t a = 0; a < ri.size(); a++) for (size_t b = 0; b < ci.size(); b++) Am[{a, b}] = v;
+    region_update(Cm, C->type->code, Am, xcode, ri, ci, accum, MaskView{&Mm, Mask ? Mask->type->code : 0, dv.mask_struct, dv.mask_comp, Mask != nullptr}, dv.replace, true, false, false, 0);
+    store(C, Cm);
+  });
+}
+static GrB_Info vec_assign_complex(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const void* x, int xcode, const GrB_Index* I, GrB_Index ni, GrB_Descriptor desc) {
+  if (!w) return GrB_NULL_POINTER; if (!check_obj(w)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(w, [&] {
+    if (mask) check_v(mask, "assign");
+    const DescView dv(desc);
+    if (mask && mask->n != w->n) fail(GrB_DIMENSION_MISMATCH, "assign: mask size");
+    if ((I == GrB_ALL ? (double)w->n : (double)ni) > 16777216.0)
+      fail(GrB_INSUFFICIENT_SPACE, "assign: a complex scalar over more than 2^24 positions (complex containers are kept on the host)");
+    const auto idx = indices(I, ni, w->n, "assign");
+    Map C = load(w), U, Mm; if (mask) Mm = load(mask);
+    Val v{}; memcpy(v.data(), x, (size_t)type_size(xcode));
+    for (size_t a = 0; a < idx.size(); a++) U[{a, 0}] = v;
+    region_update(C, w->type->code, U, xcode, idx, std::vector<uint64_t>{0}, accum, MaskView{&Mm, mask ? mask->type->code : 0, dv.mask_struct, dv.mask_comp, mask != nullptr}, dv.replace, true, false, false, 0);
+    store(w, C);
+  });
+}
+GrB_Info GxB_Matrix_assign_FC32(GrB_Matrix C, const GrB_Matrix M, const GrB_BinaryOp accum, GxB_FC32_t x, const GrB_Index* I, GrB_Index ni, const GrB_Index* J, GrB_Index nj, const GrB_Descriptor desc) { return mat_assign_complex(C, M, accum, &x, T_FC32, I, ni, J, nj, desc); }
+GrB_Info GxB_Matrix_assign_FC64(GrB_Matrix C, const GrB_Matrix M, const GrB_BinaryOp accum, GxB_FC64_t x, const GrB_Index* I, GrB_Index ni, const GrB_Index* J, GrB_Index nj, const GrB_Descriptor desc) { return mat_assign_complex(C, M, accum, &x, T_FC64, I, ni, J, nj, desc); }
+GrB_Info GxB_Vector_assign_FC32(GrB_Vector w, const GrB_Vector m, const GrB_BinaryOp accum, GxB_FC32_t x, const GrB_Index* I, GrB_Index ni, const GrB_Descriptor desc) { return vec_assign_complex(w, m, accum, &x, T_FC32, I, ni, desc); }
+GrB_Info GxB_Vector_assign_FC64(GrB_Vector w, const GrB_Vector m, const GrB_BinaryOp accum, GxB_FC64_t x, const GrB_Index* I, GrB_Index ni, const GrB_Descriptor desc) { return vec_assign_complex(w, m, accum, &x, T_FC64, I, ni, desc); }
 }  // extern "C"

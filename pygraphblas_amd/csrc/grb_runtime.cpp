@@ -94,7 +94,23 @@ GrB_Type type_by_code(int code) {
   return nullptr;
 }
 
+// complex values exist as stored container entries only: real <-> complex casts follow the C rules
+// SuiteSparse applies (real part kept, zero imaginary part added)
+static void cast_complex(int dst_code, void* dst, int src_code, const void* src) {
+  double re = 0, im = 0;
+  if (src_code == T_FC32) { float f[2]; memcpy(f, src, 8); re = f[0]; im = f[1]; }
+  else if (src_code == T_FC64) { double d[2]; memcpy(d, src, 16); re = d[0]; im = d[1]; }
+  else if (src_code < T_FC32) cast_scalar(T_FP64, &re, src_code, src);
+  else fail(GrB_DOMAIN_MISMATCH, "user-defined types are out of scope");
+  if (dst_code == T_FC32) { float f[2] = {(float)re, (float)im}; memcpy(dst, f, 8); }
+  else if (dst_code == T_FC64) { double d[2] = {re, im}; memcpy(dst, d, 16); }
+  else if (dst_code == T_BOOL) { const uint8_t b = (re != 0 || im != 0); memcpy(dst, &b, 1); }
+  else if (dst_code < T_FC32) cast_scalar(dst_code, dst, T_FP64, &re);
+  else fail(GrB_DOMAIN_MISMATCH, "user-defined types are out of scope");
+}
+
 void cast_scalar(int dst_code, void* dst, int src_code, const void* src) {
+  if (dst_code >= T_FC32 || src_code >= T_FC32) { cast_complex(dst_code, dst, src_code, src); return; }
   dispatch_type(src_code, [&]<class S>() {
     S s; memcpy(&s, src, sizeof(S));
     dispatch_type(dst_code, [&]<class D>() { D d = cast_to<D, S>(s); memcpy(dst, &d, sizeof(D)); });

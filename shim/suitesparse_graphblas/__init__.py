@@ -39,6 +39,58 @@ for _name in re.findall(r"^GrB_Info\s+(\w+)\s*\(", _src, flags=re.M):
     except AttributeError:      # declared, not exported: stays an AttributeError at the call site
         pass
 
+
+
+class _Lib:
+    """`lib` as pygraphblas sees it: the dlopen()ed library, with the complex-typed entry points made callable.
+
+    The compiled (API-mode) suitesparse_graphblas passes `double _Complex` by value; cffi's ABI mode cannot (libffi
+    call descriptions for complex arguments are refused), so the header declares GxB_FC32_t / GxB_FC64_t as
+    {re, im} structs — the same register classes in the x86-64 SysV ABI — and the few *_FC32 / *_FC64 functions get a
+    wrapper that turns a Python complex into that struct and a `double _Complex *` buffer (what pygraphblas/types.py:332,343
+    allocates) into the struct pointer.  Every other name resolves straight to the library object."""
+
+    def __init__(self, real, names):
+        object.__setattr__(self, "_real", real)
+        for name in names:
+            try:
+                fn = getattr(real, name)
+            except AttributeError:
+                continue
+            m = re.search(r"_(FC32|FC64)$", name)
+            self.__dict__[name] = self._complex_call(fn, "GxB_%s_t" % m.group(1)) if m else fn
+
+    @staticmethod
+    def _complex_call(fn, cname):
+        kinds = [a.cname for a in ffi.typeof(fn).args]
+        ptr = cname + " *"
+
+        def call(*args):
+            conv = []
+            for a, k in zip(args, kinds):
+                if k == cname:
+                    a = complex(a)
+                    a = (a.real, a.imag)
+                elif k == ptr and isinstance(a, ffi.CData):
+                    a = ffi.cast(ptr, a)
+                conv.append(a)
+            return fn(*conv)
+
+        call.__name__ = getattr(fn, "__name__", "complex_call")
+        return call
+
+    def __getattr__(self, name):          # constants and handles: read through, at the time of the access
+        return getattr(self._real, name)
+
+    def __setattr__(self, name, value):
+        setattr(self._real, name, value)
+
+    def __dir__(self):
+        return dir(self._real)
+
+
+lib = _Lib(lib, re.findall(r"^GrB_Info\s+(\w+)\s*\(", _src, flags=re.M))
+
 __version__ = "5.1.0+mi355x"
 _initialized = False
 
@@ -59,4 +111,5 @@ def initialize(*, blocking=False, memory_manager="numpy"):
 
 
 def supports_complex():
-    return False
+    """Complex containers can be built, set, read and listed (host side); arithmetic on them reports DomainMismatch."""
+    return True

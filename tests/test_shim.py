@@ -83,3 +83,23 @@ def test_unmodified_reference_reads_its_own_grb_fixture_through_the_shim(gb, tmp
             f"M.to_binfile('{tmp_path}/rt.grb'); M2 = Matrix.from_binfile('{tmp_path}/rt.grb'); assert M2.to_lists() == M.to_lists(); print('OK grb')")
     r = subprocess.run([PY39, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")
     assert r.returncode == 0 and "OK grb" in r.stdout, r.stdout + r.stderr
+
+
+@needs39
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_unmodified_reference_stores_complex_entries_through_the_shim(gb):
+    """Complex containers (FC32 / FC64) are host-side storage here: what the reference's tests ask of them
+    (tests/test_matrix.py:56-60, 853-855; tests/test_vector.py:385-387) works without arithmetic."""
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "shim") + ":" + REF)
+    code = ("from pygraphblas import *\n"
+            "m = Matrix.from_lists([0], [0], [0j]); assert m.type is FC64 and m.shape == (1, 1) and m.nvals == 1 and m[0, 0] == 0j\n"
+            "m[0, 0] = 3 + 4j; assert m[0, 0] == 3 + 4j and m.to_lists() == [[0], [0], [3 + 4j]]\n"
+            "v = Vector.sparse(FC32, 10); v[3] = 1.5 - 2j; assert v[3] == 1.5 - 2j and v.nvals == 1 and v.to_lists() == [[3], [1.5 - 2j]]\n"
+            "d = Matrix.dense(FC64, 10, 10); assert d.nvals == 100 and d[9, 9] == 0j\n"
+            "w = Vector.dense(FC64, 5, fill=2j); assert w.nvals == 5 and w[4] == 2j\n"
+            "import pytest\n"
+            "with pytest.raises(TypeError): d.to_arrays()\n"
+            "r = Matrix.sparse(FP64, 2, 2); r[0, 1] = 2.5; c = Matrix.sparse(FC64, 2, 2); c[0, 1] = r[0, 1]; assert c[0, 1] == 2.5 + 0j\n"
+            "print('OK complex')\n")
+    r = subprocess.run([PY39, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")
+    assert r.returncode == 0 and "OK complex" in r.stdout, r.stdout + r.stderr

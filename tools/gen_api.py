@@ -521,14 +521,18 @@ GrB_Info GxB_Scalar_extractElement_{t}({c} *x, const GxB_Scalar s);
 GrB_Info GrB_Monoid_new_{t}(GrB_Monoid *monoid, GrB_BinaryOp op, {c} identity);
 """)
 # complex types: the handles and the 17 typed entry points exist so that the reference's type registry imports
-# (pygraphblas/types.py:87-110 resolves them for all 13 types); every one returns GrB_DOMAIN_MISMATCH (DESIGN.md §8)
+# (pygraphblas/types.py:87-110 resolves them for all 13 types).  Complex containers are kept on the host: entries can be
+# built, set, read, listed and assigned; everything that would compute on them returns GrB_DOMAIN_MISMATCH (DESIGN.md §8)
 H.append("""
-/* ---- complex types are declared for registry compatibility only; all return GrB_DOMAIN_MISMATCH ---- */
+/* ---- complex types: host-side containers (build / set / extract / assign a scalar); arithmetic on them
+ *      (reduce, apply, monoids, every device operation) returns GrB_DOMAIN_MISMATCH ---- */
 typedef struct { float re; float im; } GxB_FC32_t;
 typedef struct { double re; double im; } GxB_FC64_t;
 """)
 for t, c in (("FC32", "GxB_FC32_t"), ("FC64", "GxB_FC64_t")):
     H.append(f"""
+GrB_Info GxB_Matrix_build_{t}(GrB_Matrix C, const GrB_Index *I, const GrB_Index *J, const {c} *X, GrB_Index nvals, const GrB_BinaryOp dup);
+GrB_Info GxB_Vector_build_{t}(GrB_Vector w, const GrB_Index *I, const {c} *X, GrB_Index nvals, const GrB_BinaryOp dup);
 GrB_Info GxB_Matrix_setElement_{t}(GrB_Matrix C, {c} x, GrB_Index i, GrB_Index j);
 GrB_Info GxB_Matrix_extractElement_{t}({c} *x, const GrB_Matrix A, GrB_Index i, GrB_Index j);
 GrB_Info GxB_Matrix_extractTuples_{t}(GrB_Index *I, GrB_Index *J, {c} *X, GrB_Index *nvals, const GrB_Matrix A);
