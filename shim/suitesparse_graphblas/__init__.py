@@ -7,7 +7,7 @@ pygraphblas/base.py:7).  It binds the MI355X backend instead of SuiteSparse:Grap
 
 so the *unmodified* reference package runs on the HIP kernels:
 
-    PYTHONPATH=<repo>/shim:/root/reference  /opt/conda/bin/python3.9 -c "import pygraphblas"
+    PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=<repo>/shim:/root/reference  /opt/conda/bin/python3.9 -c "import pygraphblas"
 
 Needs a Python with cffi (the image's /opt/conda/bin/python3.9); the default python3.10 has no cffi and uses
 the ctypes mirror `pygraphblas_amd` instead.  See INTEGRATION.md.

@@ -41,7 +41,7 @@ def test_cffi_boundary_on_gpu(gpu):
 @needs39
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
 def test_unmodified_reference_imports_and_runs_its_gpu_free_tests(gb):
-    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "shim") + ":" + REF)
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "shim") + ":" + REF, PYTHONDONTWRITEBYTECODE="1")   # the reference tree is read-only to us: no __pycache__ there
     code = ("import pygraphblas as p; from pygraphblas import *; "
             "assert INT64.PLUS_TIMES.ztype is INT64 and BOOL.LOR_LAND.ztype is BOOL and FP32.PLUS_SECOND is not None; "
             "m = Matrix.from_lists([0,1,2],[1,2,0],[1,2,3]); assert m.nvals == 3 and m[0,1] == 1 and m.type is INT64; "
@@ -73,7 +73,7 @@ def test_unmodified_reference_imports_and_runs_its_gpu_free_tests(gb):
 def test_unmodified_reference_reads_its_own_grb_fixture_through_the_shim(gb, tmp_path):
     """`Matrix.from_binfile` of the reference (pygraphblas/matrix.py:489-497 -> suitesparse_graphblas.io.binary.binread, here
     shim/suitesparse_graphblas/io/binary.py) on docs/test_binfile.grb == docs/test_mm.mm; to_binfile round-trips."""
-    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "shim") + ":" + REF)
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "shim") + ":" + REF, PYTHONDONTWRITEBYTECODE="1")   # the reference tree is read-only to us: no __pycache__ there
     code = ("from pygraphblas import *; "
             f"M = Matrix.from_binfile('{REF}/docs/test_binfile.grb'); "
             "assert M.type is INT64 and M.shape == (7, 7) and M.nvals == 12; "
@@ -90,7 +90,7 @@ def test_unmodified_reference_reads_its_own_grb_fixture_through_the_shim(gb, tmp
 def test_unmodified_reference_stores_complex_entries_through_the_shim(gb):
     """Complex containers (FC32 / FC64) are host-side storage here: what the reference's tests ask of them
     (tests/test_matrix.py:56-60, 853-855; tests/test_vector.py:385-387) works without arithmetic."""
-    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "shim") + ":" + REF)
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "shim") + ":" + REF, PYTHONDONTWRITEBYTECODE="1")   # the reference tree is read-only to us: no __pycache__ there
     code = ("from pygraphblas import *\n"
             "m = Matrix.from_lists([0], [0], [0j]); assert m.type is FC64 and m.shape == (1, 1) and m.nvals == 1 and m[0, 0] == 0j\n"
             "m[0, 0] = 3 + 4j; assert m[0, 0] == 3 + 4j and m.to_lists() == [[0], [0], [3 + 4j]]\n"
