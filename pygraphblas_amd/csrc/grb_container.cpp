@@ -18,7 +18,9 @@
 namespace grb {
 
 // ---- host assemble: apply pending setElement/removeElement in program order ---------------------
+static const char* const ISO_MSG = "a full one-valued container of this dimension can be read element-wise only";
 void mat_host_assemble(GrB_Matrix A) {
+  if (A->iso_full) fail(GrB_INSUFFICIENT_SPACE, ISO_MSG);
   if (A->pending.empty()) return;
   const size_t ts = A->type->size;
   auto& P = A->pending;
@@ -52,6 +54,7 @@ void mat_invalidate_host(GrB_Matrix A) {
 }
 
 void mat_to_host(GrB_Matrix A) {
+  if (A->iso_full) fail(GrB_INSUFFICIENT_SPACE, ISO_MSG);
   if (A->host_valid) { mat_host_assemble(A); return; }
   // download the device CSR and expand to sorted tuples
   const DevCSR& c = A->csr; const size_t ts = A->type->size;
@@ -94,6 +97,7 @@ void mat_to_device(GrB_Matrix A) {
 }
 
 uint64_t mat_nvals(GrB_Matrix A) {
+  if (A->iso_full) { const unsigned __int128 t = (unsigned __int128)A->nrows * A->ncols; return t > UINT64_MAX ? UINT64_MAX : (uint64_t)t; }
   if (A->host_valid) { mat_host_assemble(A); return A->hi.size(); }
   return A->csr.nnz;
 }
@@ -106,6 +110,7 @@ const DevCSR& mat_csc(GrB_Matrix A) {
 
 // ---- vectors ---------------------------------------------------------------------------------------
 void vec_host_assemble(GrB_Vector v) {
+  if (v->iso_full) fail(GrB_INSUFFICIENT_SPACE, ISO_MSG);
   if (v->pending.empty()) return;
   const size_t ts = v->type->size; auto& P = v->pending;
   std::vector<uint32_t> ord(P.size()); std::iota(ord.begin(), ord.end(), 0u);
@@ -129,6 +134,7 @@ void vec_invalidate_host(GrB_Vector v) {
   v->host_valid = false; v->hi.clear(); v->hx.clear(); v->pending.clear(); v->hi.shrink_to_fit(); v->hx.shrink_to_fit();
 }
 void vec_to_host(GrB_Vector v) {
+  if (v->iso_full) fail(GrB_INSUFFICIENT_SPACE, ISO_MSG);
   if (v->host_valid) { vec_host_assemble(v); return; }
   const size_t ts = v->type->size; const uint64_t n = v->n;
   std::vector<uint8_t> val(n * ts), pres(n);
@@ -163,6 +169,7 @@ uint64_t vec_dev_nvals(GrB_Vector v) {
   return v->dnvals;
 }
 uint64_t vec_nvals(GrB_Vector v) {
+  if (v->iso_full) return v->n;
   if (v->host_valid) { vec_host_assemble(v); return v->hi.size(); }
   return vec_dev_nvals(v);
 }
@@ -225,7 +232,8 @@ GrB_Info GrB_Matrix_dup(GrB_Matrix* C, const GrB_Matrix A) {
   GrB_Matrix m = nullptr; GrB_Info info = GrB_Matrix_new(&m, A->type, A->nrows, A->ncols); if (info) return info;
   info = guarded(A, [&] {
     m->format = A->format; m->sparsity_control = A->sparsity_control; m->hyper_switch = A->hyper_switch;
-    if (A->host_valid) { mat_host_assemble(A); m->hi = A->hi; m->hj = A->hj; m->hx = A->hx; m->host_valid = true; }
+    if (A->iso_full) { m->iso_full = true; memcpy(m->iso_val, A->iso_val, 16); }
+    else if (A->host_valid) { mat_host_assemble(A); m->hi = A->hi; m->hj = A->hj; m->hx = A->hx; m->host_valid = true; }
     else {
       const DevCSR& s = A->csr; DevCSR& d = m->csr; const size_t ts = A->type->size;
       d.nrows = s.nrows; d.ncols = s.ncols; d.nnz = s.nnz;
@@ -240,7 +248,7 @@ GrB_Info GrB_Matrix_dup(GrB_Matrix* C, const GrB_Matrix A) {
   *C = m; return GrB_SUCCESS;
 }
 GrB_Info GrB_Matrix_clear(GrB_Matrix A) {
-  CHECK_MAT(A); A->hi.clear(); A->hj.clear(); A->hx.clear(); A->pending.clear(); A->host_valid = true; mat_invalidate_device(A); return GrB_SUCCESS;
+  CHECK_MAT(A); A->hi.clear(); A->hj.clear(); A->hx.clear(); A->pending.clear(); A->host_valid = true; A->iso_full = false; mat_invalidate_device(A); return GrB_SUCCESS;
 }
 GrB_Info GrB_Matrix_nrows(GrB_Index* n, const GrB_Matrix A) { if (!n) return GrB_NULL_POINTER; CHECK_MAT(A); *n = A->nrows; return GrB_SUCCESS; }
 GrB_Info GrB_Matrix_ncols(GrB_Index* n, const GrB_Matrix A) { if (!n) return GrB_NULL_POINTER; CHECK_MAT(A); *n = A->ncols; return GrB_SUCCESS; }
@@ -249,7 +257,7 @@ GrB_Info GrB_Matrix_nvals(GrB_Index* n, const GrB_Matrix A) {
 }
 GrB_Info GrB_Matrix_wait(GrB_Matrix* A) {
   if (!A) return GrB_NULL_POINTER; CHECK_MAT(*A);
-  return guarded(*A, [&] { if ((*A)->host_valid) mat_host_assemble(*A); if (device_ok()) GRB_HIP(hipStreamSynchronize(stream())); });
+  return guarded(*A, [&] { if ((*A)->host_valid && !(*A)->iso_full) mat_host_assemble(*A); if (device_ok()) GRB_HIP(hipStreamSynchronize(stream())); });
 }
 // the reference asks `self` for the message even when the failing object was the output (pygraphblas/matrix.py:43-51)
 GrB_Info GrB_Matrix_error(const char** s, const GrB_Matrix A) { if (!s) return GrB_NULL_POINTER; CHECK_MAT(A); *s = A->err.empty() ? g_last_error.c_str() : A->err.c_str(); return GrB_SUCCESS; }
@@ -284,7 +292,7 @@ GrB_Info GxB_Matrix_Option_get(GrB_Matrix A, int field, ...) {
     case 1: { int* p = va_arg(ap, int*); if (p) *p = A->format; break; }
     case 0: { double* p = va_arg(ap, double*); if (p) *p = A->hyper_switch; break; }
     case 32: { int* p = va_arg(ap, int*); if (p) *p = A->sparsity_control; break; }
-    case 33: { int* p = va_arg(ap, int*); if (p) *p = (A->nrows > GRB_DIM_DEVICE_MAX || A->hyper_switch >= 1.0 || mat_nvals(A) == 0) ? 1 : 2; break; }  // what SuiteSparse would report: hypersparse for huge or empty matrices and under hyper_switch = GxB_ALWAYS_HYPER (a stored option here), else sparse
+    case 33: { int* p = va_arg(ap, int*); if (p) *p = A->iso_full ? 8 : (A->nrows > GRB_DIM_DEVICE_MAX || A->hyper_switch >= 1.0 || mat_nvals(A) == 0) ? 1 : 2; break; }  // what SuiteSparse would report: hypersparse for huge or empty matrices and under hyper_switch = GxB_ALWAYS_HYPER (a stored option here), else sparse
     case 34: { double* p = va_arg(ap, double*); if (p) *p = 0.04; break; }
     default: info = GrB_INVALID_VALUE;
   }
@@ -308,6 +316,7 @@ static GrB_Info mat_build(GrB_Matrix C, const GrB_Index* I, const GrB_Index* J, 
 static GrB_Info mat_set(GrB_Matrix C, const void* x, int xcode, GrB_Index i, GrB_Index j) {
   CHECK_MAT(C); if (i >= C->nrows || j >= C->ncols) return GrB_INVALID_INDEX;
   return guarded(C, [&] {
+    if (C->iso_full) fail(GrB_INSUFFICIENT_SPACE, ISO_MSG);
     if (!C->host_valid) mat_to_host(C);
     GrB_Matrix_opaque::Pending p{i, j, false, {0}}; cast_scalar(C->type->code, p.x, xcode, x);
     C->pending.push_back(p); mat_invalidate_device(C);
@@ -321,7 +330,9 @@ static size_t mat_find(GrB_Matrix A, GrB_Index i, GrB_Index j) {   // index into
 static GrB_Info mat_get(void* x, int xcode, GrB_Matrix A, GrB_Index i, GrB_Index j) {
   if (!x) return GrB_NULL_POINTER; CHECK_MAT(A); if (i >= A->nrows || j >= A->ncols) return GrB_INVALID_INDEX;
   GrB_Info r = GrB_SUCCESS;
-  GrB_Info info = guarded(A, [&] { mat_to_host(A); size_t k = mat_find(A, i, j);
+  GrB_Info info = guarded(A, [&] {
+    if (A->iso_full) { cast_scalar(xcode, x, A->type->code, A->iso_val); return; }
+    mat_to_host(A); size_t k = mat_find(A, i, j);
     if (k == SIZE_MAX) r = GrB_NO_VALUE; else cast_scalar(xcode, x, A->type->code, &A->hx[k * A->type->size]); });
   return info ? info : r;
 }
@@ -357,7 +368,8 @@ GrB_Info GrB_Vector_dup(GrB_Vector* w, const GrB_Vector u) {
   if (!w) return GrB_NULL_POINTER; CHECK_VEC(u);
   GrB_Vector r = nullptr; GrB_Info info = GrB_Vector_new(&r, u->type, u->n); if (info) return info;
   info = guarded(u, [&] {
-    if (u->host_valid) { vec_host_assemble(u); r->hi = u->hi; r->hx = u->hx; }
+    if (u->iso_full) { r->iso_full = true; memcpy(r->iso_val, u->iso_val, 16); }
+    else if (u->host_valid) { vec_host_assemble(u); r->hi = u->hi; r->hx = u->hx; }
     else {
       const size_t ts = u->type->size;
       r->dval.alloc(u->n * ts ? u->n * ts : 1); r->dpres.alloc(u->n ? u->n : 1);
@@ -369,7 +381,7 @@ GrB_Info GrB_Vector_dup(GrB_Vector* w, const GrB_Vector u) {
   if (info) { GrB_Vector_free(&r); return info; }
   *w = r; return GrB_SUCCESS;
 }
-GrB_Info GrB_Vector_clear(GrB_Vector v) { CHECK_VEC(v); v->hi.clear(); v->hx.clear(); v->pending.clear(); v->host_valid = true; vec_invalidate_device(v); return GrB_SUCCESS; }
+GrB_Info GrB_Vector_clear(GrB_Vector v) { CHECK_VEC(v); v->hi.clear(); v->hx.clear(); v->pending.clear(); v->host_valid = true; v->iso_full = false; vec_invalidate_device(v); return GrB_SUCCESS; }
 GrB_Info GrB_Vector_size(GrB_Index* n, const GrB_Vector v) { if (!n) return GrB_NULL_POINTER; CHECK_VEC(v); *n = v->n; return GrB_SUCCESS; }
 GrB_Info GrB_Vector_nvals(GrB_Index* n, const GrB_Vector v) { if (!n) return GrB_NULL_POINTER; CHECK_VEC(v); return guarded(v, [&] { *n = vec_nvals(v); }); }
 GrB_Info GrB_Vector_wait(GrB_Vector* v) {
@@ -418,13 +430,15 @@ static GrB_Info vec_build(GrB_Vector w, const GrB_Index* I, const void* X, int x
 }
 static GrB_Info vec_set(GrB_Vector w, const void* x, int xcode, GrB_Index i) {
   CHECK_VEC(w); if (i >= w->n) return GrB_INVALID_INDEX;
-  return guarded(w, [&] { if (!w->host_valid) vec_to_host(w);
+  return guarded(w, [&] { if (w->iso_full) fail(GrB_INSUFFICIENT_SPACE, ISO_MSG); if (!w->host_valid) vec_to_host(w);
     GrB_Vector_opaque::Pending p{i, false, {0}}; cast_scalar(w->type->code, p.x, xcode, x); w->pending.push_back(p); vec_invalidate_device(w); });
 }
 static GrB_Info vec_get(void* x, int xcode, GrB_Vector v, GrB_Index i) {
   if (!x) return GrB_NULL_POINTER; CHECK_VEC(v); if (i >= v->n) return GrB_INVALID_INDEX;
   GrB_Info r = GrB_SUCCESS;
-  GrB_Info info = guarded(v, [&] { vec_to_host(v);
+  GrB_Info info = guarded(v, [&] {
+    if (v->iso_full) { cast_scalar(xcode, x, v->type->code, v->iso_val); return; }
+    vec_to_host(v);
     auto it = std::lower_bound(v->hi.begin(), v->hi.end(), i);
     if (it == v->hi.end() || *it != i) r = GrB_NO_VALUE;
     else cast_scalar(xcode, x, v->type->code, &v->hx[(it - v->hi.begin()) * v->type->size]); });

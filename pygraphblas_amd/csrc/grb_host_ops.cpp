@@ -306,44 +306,108 @@ GrB_Info GxB_Vector_apply_BinaryOp2nd(GrB_Vector C, const GrB_Vector M, const Gr
 double GxB_ALWAYS_HYPER = 1.0, GxB_NEVER_HYPER = -1.0, GxB_HYPER_DEFAULT = 0.0625;      // hyper_switch settings (stored options only)
 
 
-// ---- a complex scalar into a region: host-side container work, like the index assigns above ---------------------
-// (`Matrix.dense(FC64, 10, 10)` is `M[:, :] = 0j`, pygraphblas/matrix.py:225-230; tests/test_matrix.py:853)
+// ---- a scalar into a region, on the host mirror ------------------------------------------------------------------
+// Used for containers that have no HBM layout: complex ones (`Matrix.dense(FC64, 10, 10)` is `M[:, :] = 0j`,
+// pygraphblas/matrix.py:225-230; tests/test_matrix.py:853) and those whose dimensions exceed the 32-bit device layout
+// (the hypersparse default, GxB_INDEX_MAX: `Matrix.sparse(float, fill=3.14, mask=mask)`, pygraphblas/matrix.py:154-162,
+// `Matrix.iso(3)`, :234-266).  Container bookkeeping, like setElement — never on the mxm / mxv / vxm path.
 typedef struct { float re, im; } GxB_FC32_t;
 typedef struct { double re, im; } GxB_FC64_t;
+}  // extern "C"
+namespace grb {
+void host_assign_scalar(GrB_Matrix C, GrB_Matrix Mask, GrB_BinaryOp accum, const void* x, int xcode, const GrB_Index* I, GrB_Index ni, const GrB_Index* J, GrB_Index nj, GrB_Descriptor desc) {
+  if (Mask) check_m(Mask, "assign");
+  const DescView dv(desc);
+  if (Mask && (Mask->nrows != C->nrows || Mask->ncols != C->ncols)) fail(GrB_DIMENSION_MISMATCH, "assign: mask dimensions");
+  const bool all = (I == GrB_ALL && J == GrB_ALL);
+  const int ccode = C->type->code;
+  Val v{}; memcpy(v.data(), x, (size_t)type_size(xcode));
+  const double positions = (I == GrB_ALL ? (double)C->nrows : (double)ni) * (J == GrB_ALL ? (double)C->ncols : (double)nj);
+  if (all && Mask && !dv.mask_comp) {                    // the result's pattern is bounded by the mask's
+    Map Cm = load(C, false), Mm = load(Mask, false), T;
+    const MaskView mk{&Mm, Mask->type->code, dv.mask_struct, false, true};
+    for (auto& kv : Mm) if (mk.allows(kv.first)) T[kv.first] = v;
+    write_back(Cm, ccode, T, xcode, mk, dv.replace, accum, everywhere);
+    store(C, Cm); return;
+  }
+  if (all && !Mask && positions > 16777216.0) {          // every position of a container too large to enumerate: one stored value
+    if (accum && mat_nvals(C) != 0) fail(GrB_INSUFFICIENT_SPACE, "assign: accumulating a scalar into every position of a container of this dimension");
+    GrB_Matrix_clear(C); C->iso_full = true; memset(C->iso_val, 0, 16); cast_scalar(ccode, C->iso_val, xcode, x); return;
+  }
+  if (positions > 16777216.0) fail(GrB_INSUFFICIENT_SPACE, "assign: a scalar over more than 2^24 positions of a host-side container");
+  const auto ri = indices(I, ni, C->nrows, "assign"), ci = indices(J, nj, C->ncols, "assign");
+  Map Cm = load(C, false), Am, Mm; if (Mask) Mm = load(Mask, false);
+  for (size_t a = 0; a < ri.size(); a++) for (size_t b = 0; b < ci.size(); b++) Am[{a, b}] = v;
+  region_update(Cm, ccode, Am, xcode, ri, ci, accum, MaskView{&Mm, Mask ? Mask->type->code : 0, dv.mask_struct, dv.mask_comp, Mask != nullptr}, dv.replace, true, false, false, 0);
+  store(C, Cm);
+}
+void host_assign_scalar(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const void* x, int xcode, const GrB_Index* I, GrB_Index ni, GrB_Descriptor desc) {
+  if (mask) check_v(mask, "assign");
+  const DescView dv(desc);
+  if (mask && mask->n != w->n) fail(GrB_DIMENSION_MISMATCH, "assign: mask size");
+  const bool all = (I == GrB_ALL);
+  const int wcode = w->type->code;
+  Val v{}; memcpy(v.data(), x, (size_t)type_size(xcode));
+  const double positions = all ? (double)w->n : (double)ni;
+  if (all && mask && !dv.mask_comp) {
+    Map C = load(w), Mm = load(mask), T;
+    const MaskView mk{&Mm, mask->type->code, dv.mask_struct, false, true};
+    for (auto& kv : Mm) if (mk.allows(kv.first)) T[kv.first] = v;
+    write_back(C, wcode, T, xcode, mk, dv.replace, accum, everywhere);
+    store(w, C); return;
+  }
+  if (all && !mask && positions > 16777216.0) {
+    if (accum && vec_nvals(w) != 0) fail(GrB_INSUFFICIENT_SPACE, "assign: accumulating a scalar into every position of a container of this dimension");
+    GrB_Vector_clear(w); w->iso_full = true; memset(w->iso_val, 0, 16); cast_scalar(wcode, w->iso_val, xcode, x); return;
+  }
+  if (positions > 16777216.0) fail(GrB_INSUFFICIENT_SPACE, "assign: a scalar over more than 2^24 positions of a host-side container");
+  const auto idx = indices(I, ni, w->n, "assign");
+  Map C = load(w), U, Mm; if (mask) Mm = load(mask);
+  for (size_t a = 0; a < idx.size(); a++) U[{a, 0}] = v;
+  region_update(C, wcode, U, xcode, idx, std::vector<uint64_t>{0}, accum, MaskView{&Mm, mask ? mask->type->code : 0, dv.mask_struct, dv.mask_comp, mask != nullptr}, dv.replace, true, false, false, 0);
+  store(w, C);
+}
+}  // namespace grb
+extern "C" {
 static GrB_Info mat_assign_complex(GrB_Matrix C, GrB_Matrix Mask, GrB_BinaryOp accum, const void* x, int xcode, const GrB_Index* I, GrB_Index ni, const GrB_Index* J, GrB_Index nj, GrB_Descriptor desc) {
   if (!C) return GrB_NULL_POINTER; if (!check_obj(C)) return GrB_UNINITIALIZED_OBJECT;
-  return guarded(C, [&] {
-    if (Mask) check_m(Mask, "assign");
-    const DescView dv(desc);
-    if (Mask && (Mask->nrows != C->nrows || Mask->ncols != C->ncols)) fail(GrB_DIMENSION_MISMATCH, "assign: mask dimensions");
-    if ((I == GrB_ALL ? (double)C->nrows : (double)ni) * (J == GrB_ALL ? (double)C->ncols : (double)nj) > 16777216.0)
-      fail(GrB_INSUFFICIENT_SPACE, "assign: a complex scalar over more than 2^24 positions (complex containers are kept on the host)");
-    const auto ri = indices(I, ni, C->nrows, "assign"), ci = indices(J, nj, C->ncols, "assign");
-    Map Cm = load(C, false), Am, Mm; if (Mask) Mm = load(Mask, false);
-    Val v{}; memcpy(v.data(), x, (size_t)type_size(xcode));
-    for (size_t a = 0; a < ri.size(); a++) for (size_t b = 0; b < ci.size(); b++) Am[{a, b}] = v;
-    region_update(Cm, C->type->code, Am, xcode, ri, ci, accum, MaskView{&Mm, Mask ? Mask->type->code : 0, dv.mask_struct, dv.mask_comp, Mask != nullptr}, dv.replace, true, false, false, 0);
-    store(C, Cm);
-  });
+  return guarded(C, [&] { host_assign_scalar(C, Mask, accum, x, xcode, I, ni, J, nj, desc); });
 }
 static GrB_Info vec_assign_complex(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const void* x, int xcode, const GrB_Index* I, GrB_Index ni, GrB_Descriptor desc) {
   if (!w) return GrB_NULL_POINTER; if (!check_obj(w)) return GrB_UNINITIALIZED_OBJECT;
-  return guarded(w, [&] {
-    if (mask) check_v(mask, "assign");
-    const DescView dv(desc);
-    if (mask && mask->n != w->n) fail(GrB_DIMENSION_MISMATCH, "assign: mask size");
-    if ((I == GrB_ALL ? (double)w->n : (double)ni) > 16777216.0)
-      fail(GrB_INSUFFICIENT_SPACE, "assign: a complex scalar over more than 2^24 positions (complex containers are kept on the host)");
-    const auto idx = indices(I, ni, w->n, "assign");
-    Map C = load(w), U, Mm; if (mask) Mm = load(mask);
-    Val v{}; memcpy(v.data(), x, (size_t)type_size(xcode));
-    for (size_t a = 0; a < idx.size(); a++) U[{a, 0}] = v;
-    region_update(C, w->type->code, U, xcode, idx, std::vector<uint64_t>{0}, accum, MaskView{&Mm, mask ? mask->type->code : 0, dv.mask_struct, dv.mask_comp, mask != nullptr}, dv.replace, true, false, false, 0);
-    store(w, C);
-  });
+  return guarded(w, [&] { host_assign_scalar(w, mask, accum, x, xcode, I, ni, desc); });
 }
 GrB_Info GxB_Matrix_assign_FC32(GrB_Matrix C, const GrB_Matrix M, const GrB_BinaryOp accum, GxB_FC32_t x, const GrB_Index* I, GrB_Index ni, const GrB_Index* J, GrB_Index nj, const GrB_Descriptor desc) { return mat_assign_complex(C, M, accum, &x, T_FC32, I, ni, J, nj, desc); }
 GrB_Info GxB_Matrix_assign_FC64(GrB_Matrix C, const GrB_Matrix M, const GrB_BinaryOp accum, GxB_FC64_t x, const GrB_Index* I, GrB_Index ni, const GrB_Index* J, GrB_Index nj, const GrB_Descriptor desc) { return mat_assign_complex(C, M, accum, &x, T_FC64, I, ni, J, nj, desc); }
 GrB_Info GxB_Vector_assign_FC32(GrB_Vector w, const GrB_Vector m, const GrB_BinaryOp accum, GxB_FC32_t x, const GrB_Index* I, GrB_Index ni, const GrB_Descriptor desc) { return vec_assign_complex(w, m, accum, &x, T_FC32, I, ni, desc); }
 GrB_Info GxB_Vector_assign_FC64(GrB_Vector w, const GrB_Vector m, const GrB_BinaryOp accum, GxB_FC64_t x, const GrB_Index* I, GrB_Index ni, const GrB_Descriptor desc) { return vec_assign_complex(w, m, accum, &x, T_FC64, I, ni, desc); }
+
+// ---- GxB_Matrix_diag / GxB_Vector_diag (Matrix.from_diag, Matrix.vector_diag: pygraphblas/matrix.py:333-375, 2225-2277) ----
+GrB_Info GxB_Matrix_diag(GrB_Matrix C, const GrB_Vector v, int64_t k, const GrB_Descriptor desc) {
+  (void)desc; if (!C || !v) return GrB_NULL_POINTER; if (!check_obj(C)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(C, [&] {
+    check_v(v, "diag");
+    const uint64_t ak = (uint64_t)(k < 0 ? -k : k), n = v->n + ak;
+    if (C->nrows != n || C->ncols != n) fail(GrB_DIMENSION_MISMATCH, "diag: C must be square of dimension size(v) + |k|");
+    Map V = load(v), out;
+    for (auto& kv : V) { const uint64_t i = kv.first.first; out[k >= 0 ? std::make_pair(i, i + ak) : std::make_pair(i + ak, i)] = cast(C->type->code, v->type->code, kv.second); }
+    store(C, out);
+  });
+}
+GrB_Info GxB_Vector_diag(GrB_Vector v, const GrB_Matrix A, int64_t k, const GrB_Descriptor desc) {
+  (void)desc; if (!v || !A) return GrB_NULL_POINTER; if (!check_obj(v)) return GrB_UNINITIALIZED_OBJECT;
+  return guarded(v, [&] {
+    check_m(A, "diag");
+    const uint64_t m = A->nrows, n = A->ncols; uint64_t len = 0;
+    if (k >= 0 && (uint64_t)k < n) len = std::min(m, n - (uint64_t)k);
+    else if (k < 0 && (uint64_t)(-k) < m) len = std::min(m - (uint64_t)(-k), n);
+    if (v->n != len) fail(GrB_DIMENSION_MISMATCH, "diag: the vector must have the length of the k-th diagonal");
+    Map Am = load(A, false), out;
+    for (auto& kv : Am) {
+      const uint64_t i = kv.first.first, j = kv.first.second;
+      if (k >= 0 ? (j >= i && j - i == (uint64_t)k) : (i > j && i - j == (uint64_t)(-k))) out[{k >= 0 ? i : j, 0}] = cast(v->type->code, A->type->code, kv.second);
+    }
+    store(v, out);
+  });
+}
 }  // extern "C"

@@ -120,6 +120,9 @@ struct GrB_Matrix_opaque {
   // pending host edits (setElement / removeElement), applied in order at assemble time
   struct Pending { GrB_Index i, j; bool del; uint8_t x[16]; };
   std::vector<Pending> pending;
+  // a full, one-valued ("iso") container of a dimension beyond both layouts — what `Matrix.dense(T)` / `Matrix.iso(x)` make with
+  // the default GxB_INDEX_MAX dimensions (pygraphblas/matrix.py:220-230, 234-266): it can be read element-wise, nothing more
+  bool iso_full = false; uint8_t iso_val[16] = {0};
   // device
   bool dev_valid = false;
   grb::DevCSR csr;          // by-row
@@ -138,6 +141,7 @@ struct GrB_Vector_opaque {
   std::vector<GrB_Index> hi; std::vector<uint8_t> hx;
   struct Pending { GrB_Index i; bool del; uint8_t x[16]; };
   std::vector<Pending> pending;
+  bool iso_full = false; uint8_t iso_val[16] = {0};   // as for matrices: `Vector.iso(x)` of the default size
   bool dev_valid = false;
   grb::DevBuf dval, dpres;   // T[n], u8[n]
   uint64_t dnvals = 0; bool dnvals_known = true;   // entry count of the device bitmap, recounted lazily
@@ -164,6 +168,9 @@ void mat_to_device(GrB_Matrix A);         // ensure device CSR valid (assembles 
 void mat_invalidate_host(GrB_Matrix A);   // device was written
 void mat_invalidate_device(GrB_Matrix A); // host was written
 uint64_t mat_nvals(GrB_Matrix A);
+// scalar into a region on the host mirror (grb_host_ops.cpp): for complex containers and for dimensions beyond the device layout
+void host_assign_scalar(GrB_Matrix C, GrB_Matrix Mask, GrB_BinaryOp accum, const void* x, int xcode, const GrB_Index* I, GrB_Index ni, const GrB_Index* J, GrB_Index nj, GrB_Descriptor desc);
+void host_assign_scalar(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const void* x, int xcode, const GrB_Index* I, GrB_Index ni, GrB_Descriptor desc);
 void vec_host_assemble(GrB_Vector v);
 void vec_to_host(GrB_Vector v);
 void vec_to_device(GrB_Vector v);

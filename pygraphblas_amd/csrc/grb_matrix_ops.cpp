@@ -204,10 +204,11 @@ void do_reduce_vector(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Mon
 
 // C<M>(I,J) = accum(C(I,J), x): built as a T with the scalar at every (i,j) of I x J, then assign semantics
 void do_assign_scalar(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, const void* x, int xcode, const GrB_Index* I, GrB_Index ni, const GrB_Index* J, GrB_Index nj, GrB_Descriptor desc) {
+  // no HBM layout for this container (hypersparse dimensions, or complex entries): bookkeeping on the host mirror
+  if (C->nrows > GRB_DIM_DEVICE_MAX || C->ncols > GRB_DIM_DEVICE_MAX || C->type->code >= T_FC32) { host_assign_scalar(C, M, accum, x, xcode, I, ni, J, nj, desc); return; }
   need_device(); if (M) check_mat(M, "assign");
   const DescView dv(desc);
   if (M && (M->nrows != C->nrows || M->ncols != C->ncols)) fail(GrB_DIMENSION_MISMATCH, "assign: mask dimensions");
-  if (C->nrows > GRB_DIM_DEVICE_MAX || C->ncols > GRB_DIM_DEVICE_MAX) fail(GrB_INSUFFICIENT_SPACE, "assign: matrix too large for the device layout");
   // (indices are validated as 64-bit values before they are narrowed to the device layout's 32 bits)
   const std::vector<uint64_t> rows64 = expand_index_list(I, ni, C->nrows, "assign (rows)"), cols64 = expand_index_list(J, nj, C->ncols, "assign (columns)");
   std::vector<uint32_t> rows(rows64.begin(), rows64.end()), cols(cols64.begin(), cols64.end());

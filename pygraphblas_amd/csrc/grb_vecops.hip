@@ -200,6 +200,15 @@ __global__ void k_any_byte(uint64_t n, const uint8_t* __restrict__ val, const ui
   block_add_u64(c, out);
 }
 // fixed-shape two-level tree: results are run-to-run deterministic for floating point as well
+// up to 64 positions: one lane folds them in index order — one launch instead of two, and for floating point the
+// same association as a sequential loop (what the reference's library does with an input this small; its docstring values
+// such as Vector.reduce's 0.9517456293106079, pygraphblas/vector.py:1107-1109, come out bit-for-bit)
+template <class T> __global__ void k_reduce_seq(uint32_t n, const T* __restrict__ val, const uint8_t* __restrict__ pres, int op, T id, T* __restrict__ out) {
+  T acc = id; bool have = false;
+  for (uint32_t i = 0; i < n; i++) if (!pres || pres[i]) { const T v = val[i]; acc = have ? apply_binop<T>(op, acc, v) : v; have = true; }
+  *out = acc;
+}
+
 void reduce_values(int code, uint64_t n, const void* val, const uint8_t* pres, int op, const void* identity, void* result_host) {
   if (code == T_BOOL && n && (op == B_LOR || op == B_LAND) && ((uintptr_t)val % 16 == 0) && (!pres || (uintptr_t)pres % 16 == 0)) {
     ScalarSlot slot; slot.zero();
@@ -214,8 +223,11 @@ void reduce_values(int code, uint64_t n, const void* val, const uint8_t* pres, i
     if (!n) { memcpy(result_host, &id, sizeof(T)); return; }
     const int g = grid_for(n, 4);
     DevBuf part((size_t)g * sizeof(T)), fin(sizeof(T) * 1);
-    hipLaunchKernelGGL((k_reduce<T>), dim3(g), dim3(256), 0, stream(), n, (const T*)val, pres, op, id, part.as<T>());
-    hipLaunchKernelGGL((k_reduce<T>), dim3(1), dim3(256), 0, stream(), (uint64_t)g, (const T*)part.as<T>(), (const uint8_t*)nullptr, op, id, fin.as<T>());
+    if (n <= 64) hipLaunchKernelGGL((k_reduce_seq<T>), dim3(1), dim3(1), 0, stream(), (uint32_t)n, (const T*)val, pres, op, id, fin.as<T>());
+    else {
+      hipLaunchKernelGGL((k_reduce<T>), dim3(g), dim3(256), 0, stream(), n, (const T*)val, pres, op, id, part.as<T>());
+      hipLaunchKernelGGL((k_reduce<T>), dim3(1), dim3(256), 0, stream(), (uint64_t)g, (const T*)part.as<T>(), (const uint8_t*)nullptr, op, id, fin.as<T>());
+    }
     void* pin = pinned_scratch();
     GRB_HIP(hipMemcpyAsync(pin, fin.p, sizeof(T), hipMemcpyDeviceToHost, stream()));
     GRB_HIP(hipStreamSynchronize(stream()));

@@ -35,16 +35,31 @@ static void reduce_common(void* c, int ccode, GrB_BinaryOp accum, GrB_Monoid mon
   scalar_accum(c, ccode, r, mc, accum);
 }
 
+// a container whose dimensions exceed the device layout (hypersparse, GxB_INDEX_MAX by default: `Matrix.sparse(INT8)`,
+// pygraphblas/matrix.py:1785-1793) still reduces in HBM: a reduction needs the stored values only, not their coordinates
+static void reduce_host_values(void* c, int ccode, GrB_BinaryOp accum, GrB_Monoid monoid, GrB_Type type, const std::vector<uint8_t>& hx) {
+  if (type->code >= T_FC32) fail(GrB_DOMAIN_MISMATCH, "reduce: complex values are out of scope");
+  need_device();
+  const uint64_t n = hx.size() / type->size; DevBuf d; d.alloc(hx.empty() ? 8 : hx.size());
+  if (n) { GRB_HIP(hipMemcpyAsync(d.p, hx.data(), hx.size(), hipMemcpyHostToDevice, stream())); GRB_HIP(hipStreamSynchronize(stream())); }
+  reduce_common(c, ccode, accum, monoid, type->code, d.p, nullptr, n);
+}
+
 static GrB_Info vec_reduce(void* c, int ccode, GrB_BinaryOp accum, GrB_Monoid monoid, GrB_Vector u) {
   if (!c || !u || !monoid) return GrB_NULL_POINTER; if (!check_obj(u)) return GrB_UNINITIALIZED_OBJECT;
-  return guarded(u, [&] { vec_to_device(u); reduce_common(c, ccode, accum, monoid, u->type->code, u->dval.p, u->dpres.as<uint8_t>(), u->n); });
+  return guarded(u, [&] {
+    if (u->n > GRB_DIM_DEVICE_MAX) { vec_to_host(u); reduce_host_values(c, ccode, accum, monoid, u->type, u->hx); return; }
+    vec_to_device(u); reduce_common(c, ccode, accum, monoid, u->type->code, u->dval.p, u->dpres.as<uint8_t>(), u->n); });
 }
 static GrB_Info mat_reduce(void* c, int ccode, GrB_BinaryOp accum, GrB_Monoid monoid, GrB_Matrix A) {
   if (!c || !A || !monoid) return GrB_NULL_POINTER; if (!check_obj(A)) return GrB_UNINITIALIZED_OBJECT;
-  return guarded(A, [&] { mat_to_device(A); reduce_common(c, ccode, accum, monoid, A->type->code, A->csr.val.p, nullptr, A->csr.nnz); });
+  return guarded(A, [&] {
+    if (A->nrows > GRB_DIM_DEVICE_MAX || A->ncols > GRB_DIM_DEVICE_MAX) { mat_to_host(A); reduce_host_values(c, ccode, accum, monoid, A->type, A->hx); return; }
+    mat_to_device(A); reduce_common(c, ccode, accum, monoid, A->type->code, A->csr.val.p, nullptr, A->csr.nnz); });
 }
 
 static void vec_assign(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const void* x, int xcode, const GrB_Index* I, GrB_Index ni, GrB_Descriptor desc) {
+  if (w->n > GRB_DIM_DEVICE_MAX || w->type->code >= T_FC32) { host_assign_scalar(w, mask, accum, x, xcode, I, ni, desc); return; }   // no HBM layout: host mirror
   need_device();
   if (mask && !check_obj(mask)) fail(GrB_UNINITIALIZED_OBJECT, "assign: mask is not initialised");
   const DescView dv(desc);

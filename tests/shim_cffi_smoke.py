@@ -123,5 +123,42 @@ else:
     err = ffi.new("char**"); check(lib.GrB_Vector_error(err, w[0]))
     assert b"no device" in ffi.string(err[0])
     print("OK cpu (compute refused without a device)")
+# ---- container features outside the device layouts (host mirror; same answers with or without a GPU) ------------------
+IMAX = lib.GxB_INDEX_MAX
+H = ffi.new("GrB_Matrix*"); check(lib.GrB_Matrix_new(H, lib.GrB_INT8, IMAX, IMAX))           # hypersparse default dims (matrix.py:167-170)
+check(lib.GrB_Matrix_setElement_INT8(H[0], 42, 0, 1)); check(lib.GrB_Matrix_setElement_INT8(H[0], 42, 0, 2))
+Mk = ffi.new("GrB_Matrix*"); check(lib.GrB_Matrix_new(Mk, lib.GrB_BOOL, IMAX, IMAX)); check(lib.GrB_Matrix_setElement_BOOL(Mk[0], True, 1, 1))
+F = ffi.new("GrB_Matrix*"); check(lib.GrB_Matrix_new(F, lib.GrB_FP64, IMAX, IMAX))
+check(lib.GrB_Matrix_assign_FP64(F[0], Mk[0], ffi.NULL, 3.14, lib.GrB_ALL, 0, lib.GrB_ALL, 0, ffi.NULL))          # Matrix.sparse(float, fill=3.14, mask=mask)
+x = ffi.new("double*"); check(lib.GrB_Matrix_extractElement_FP64(x, F[0], 1, 1)); check(lib.GrB_Matrix_nvals(n, F[0])); assert x[0] == 3.14 and n[0] == 1
+iso = ffi.new("GrB_Matrix*"); check(lib.GrB_Matrix_new(iso, lib.GrB_INT64, IMAX, IMAX))
+check(lib.GrB_Matrix_assign_INT64(iso[0], ffi.NULL, ffi.NULL, 3, lib.GrB_ALL, 0, lib.GrB_ALL, 0, ffi.NULL))       # Matrix.iso(3): readable element-wise
+y = ffi.new("int64_t*"); check(lib.GrB_Matrix_extractElement_INT64(y, iso[0], 42, 42)); assert y[0] == 3
+assert lib.GrB_Matrix_setElement_INT64(iso[0], 1, 0, 0) == lib.GrB_INSUFFICIENT_SPACE
+dg = ffi.new("GrB_Matrix*"); check(lib.GrB_Matrix_new(dg, lib.GrB_INT64, 4, 4))
+check(lib.GxB_Matrix_diag(dg[0], v[0], -1, ffi.NULL))                                                                # Matrix.from_diag(v, -1), matrix.py:360-366
+I3 = ffi.new("GrB_Index[3]"); J3 = ffi.new("GrB_Index[3]"); X3 = ffi.new("int64_t[3]"); n[0] = 3
+check(lib.GrB_Matrix_extractTuples_INT64(I3, J3, X3, n, dg[0])); assert (list(I3), list(J3), list(X3)) == ([1, 2, 3], [0, 1, 2], [2, 3, 4])
+dv = ffi.new("GrB_Vector*"); check(lib.GrB_Vector_new(dv, lib.GrB_INT64, 3)); check(lib.GxB_Vector_diag(dv[0], dg[0], -1, ffi.NULL))
+check(lib.GrB_Vector_extractTuples_INT64(I3, X3, n, dv[0])); assert (list(I3), list(X3)) == ([0, 1, 2], [2, 3, 4])
+assert lib.GxB_Vector_diag(dv[0], dg[0], 2, ffi.NULL) == lib.GrB_DIMENSION_MISMATCH                                  # that diagonal has 2 positions
+Z = ffi.new("GrB_Matrix*"); check(lib.GrB_Matrix_new(Z, lib.GxB_FC64, 2, 2)); check(lib.GxB_Matrix_setElement_FC64(Z[0], 3 + 4j, 0, 1))
+z = ffi.new("double _Complex*"); check(lib.GxB_Matrix_extractElement_FC64(z, Z[0], 0, 1)); assert z[0] == 3 + 4j
+Z2 = ffi.new("GrB_Matrix*"); check(lib.GrB_Matrix_new(Z2, lib.GxB_FC64, 2, 2))
+assert lib.GrB_transpose(Z2[0], ffi.NULL, ffi.NULL, Z[0], ffi.NULL) in (lib.GrB_DOMAIN_MISMATCH, lib.GrB_PANIC)    # no arithmetic on complex containers
+if "--gpu" in sys.argv:
+    r8 = ffi.new("int64_t*"); check(lib.GrB_Matrix_reduce_INT64(r8, ffi.NULL, lib.GrB_PLUS_MONOID_INT64, H[0], ffi.NULL)); assert r8[0] == 84   # matrix.py:1785-1791
+    check(lib.GrB_Matrix_reduce_INT64(r8, ffi.NULL, lib.GrB_MIN_MONOID_INT8, H[0], ffi.NULL)); assert r8[0] == 42
+    assert lib.GrB_transpose(Z2[0], ffi.NULL, ffi.NULL, Z[0], ffi.NULL) == lib.GrB_DOMAIN_MISMATCH
+    fv = ffi.new("GrB_Vector*"); check(lib.GrB_Vector_new(fv, lib.GrB_FP32, 10))
+    vals = (0.6394267678260803, 0.025010755658149719, 0.27502930164337158)
+    for i, xv in zip((1, 4, 8), vals):
+        check(lib.GrB_Vector_setElement_FP32(fv[0], xv, i))
+    d = ffi.new("double*"); check(lib.GrB_Vector_reduce_FP64(d, ffi.NULL, lib.GrB_PLUS_MONOID_FP32, fv[0], ffi.NULL))
+    import struct
+    f32 = lambda q: struct.unpack("f", struct.pack("f", q))[0]
+    assert d[0] == f32(f32(f32(vals[0]) + f32(vals[1])) + f32(vals[2])), d[0]     # a few values fold in index order (the sequential association)
+    print("OK gpu containers: hypersparse reduce, complex refusal, sequential small reduce")
+print("OK containers: hypersparse masked assign, iso, diag, complex entries")
 for h, fn in ((A, lib.GrB_Matrix_free), (v, lib.GrB_Vector_free), (w, lib.GrB_Vector_free)):
     check(fn(h)); check(fn(h))                                                        # double free is a no-op
