@@ -1,7 +1,8 @@
 #!/bin/bash
 # The UNMODIFIED reference package and its own tests, run on top of shim/ (CFFI -> libgrb_mi355x.so) on the GPU box.
 # The reference tree is not part of this repository: the caller places an untracked scratch copy of
-# /root/reference/{pygraphblas,tests} under .refscratch/ (git-ignored) before `gpurun`.
+# /root/reference/{pygraphblas,tests} under .refscratch/ (git-ignored) before `gpurun` — tools/make_refscratch.sh — and
+# deletes it after the call.
 # usage: tools/ref_tests_gpu.sh <outdir> [pytest args...]
 set -u
 out=${1:-gpurun_out/reftests}; shift || true
