@@ -31,7 +31,17 @@ namespace grb {
 #ifndef XT_WAVES
 #define XT_WAVES WP_WAVES              // waves per workgroup of the panel pipeline (one workgroup per CU)
 #endif
-template <class T> struct xt_hot { static constexpr int H = (WP_LDS_BYTES - 16 - WP_WAVES * 64 * (int)sizeof(T)) / (int)sizeof(T); };   // all of the LDS but the staging slots is the table: 19454 (8 B) / 39932 (4 B)
+#ifndef XT_C16
+#define XT_C16 1                       // 1: 16-bit column plane + 16-bit extras for the cold columns; 0: one 32-bit column word per entry
+#endif
+// all of the LDS but the staging slots is the table: 19454 slots of 8 bytes.  With the 16-bit column plane a word holds a
+// 15-bit code — a slot, or XT escape + the high bits of a cold column — so the table is capped at 24576 slots (4-byte and
+// smaller types; 8192 escape codes x 65536 = 2^29 columns) and kernel X takes matrices of up to xt_hot<T>::MAXCOLS columns.
+template <class T> struct xt_hot {
+  static constexpr int HLDS = (WP_LDS_BYTES - 16 - WP_WAVES * 64 * (int)sizeof(T)) / (int)sizeof(T);
+  static constexpr int H = XT_C16 ? (HLDS < 24576 ? HLDS : 24576) : HLDS;
+  static constexpr uint64_t MAXCOLS = XT_C16 ? ((uint64_t)(32768 - H) << 16) : 0x7FFFFFFFull - (uint64_t)H;
+};
 
 // the segmented scan of the sums and the prefix count of the row starts in one pass: x = flag << 31 | count
 template <class T, class SR> __device__ __forceinline__ void xt_seg_scan_count(T& v, uint32_t& x, int lane, const SR& sr) {
@@ -96,21 +106,29 @@ template <class E, int N> __device__ __forceinline__ void xt_stream_load(__amdgp
 
 // one panel's share of the plan; the block of XP of these lives in HBM and never changes between calls
 template <class T> struct XtPanel {
-  const uint32_t* pcol;      // column words of the panel's entries (tile t = entries [256 t, 256 t + 256))
+  const uint32_t* pcol;      // 32-bit format: column words of the panel's entries (tile t = entries [256 t, 256 t + 256)); nullptr once packed
   const T* aval;             // their values (nullptr when the plan was built for multipliers that ignore them)
-  const uint32_t* trow;      // [ntiles] sub-row (numbered over all panels) of every tile's first entry
+  const uint32_t* trow;      // 32-bit format: [ntiles] sub-row (numbered over all panels) of every tile's first entry
   const T* xhot;             // the LDS table's contents for this call, T[nhot] (k_xp_hot_gather)
   uint32_t nnz, ntiles, tiles_per_chunk, nhot, static_pct, pad;
+  // 16-bit format: bit 15 of a word = first entry of a sub-row; the low 15 bits are the slot in the LDS table, or H + (column >> 16)
+  // for a column the table does not hold — whose low 16 bits are the next halfword of `extras`, the cold entries of all tiles in
+  // entry order.  tinfo[2t] = sub-row of tile t's first entry, tinfo[2t + 1] = index in `extras` of its first cold entry.
+  const uint16_t* col16; const uint32_t* tinfo; const uint16_t* extras; uint64_t nextras;
 };
 template <class T> struct XtCall { const T* u; uint32_t ulen; uint32_t pad; T* partial; };     // what changes from call to call
 
-template <class T> struct XtStage { uint32_t c[WP_PER]; T v[WP_PER], g[WP_PER]; uint32_t rf; uint32_t tile; };   // what one tile has in flight (rf: sub-row of its first entry)
+template <class T> struct XtStage {       // what one tile has in flight
+  uint32_t c[WP_PER]; T v[WP_PER], g[WP_PER]; uint32_t rf; uint32_t tile;   // column words (32-bit form), values, gathered operands; rf: sub-row of its first entry
+  uint32_t h[2], xq[3], cb, xr;             // 16-bit format: the four raw words, three dwords of extras, the tile's base in `extras`, index of the lane's first extra
+};
+typedef uint32_t xt_v3u __attribute__((ext_vector_type(3)));
 
 template <class F, int... I> __device__ __forceinline__ bool xt_unroll_steps(F&& f, std::integer_sequence<int, I...>) { return (f.template operator()<I>() && ...); }
 
 // D = prefetch depth, W = waves per workgroup; EXP selects a timing experiment (wrong results!): 1 = no gathers of u (streams
 // only), 2 = loads only (no scan, no stores: what the load side of the pipeline can deliver)
-template <class T, class SR, int D = XT_DEPTH, int W = XT_WAVES, int EXP = 0>
+template <class T, class SR, int D = XT_DEPTH, int W = XT_WAVES, int EXP = 0, bool C16 = (XT_C16 != 0)>
 __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, const XtPanel<T>* __restrict__ panels, const SR sr) {
   const XtPanel<T> a = panels[blockIdx.x & 7];          // workgroup b works on column panel b % 8 — the XCD it is observed to run on
   constexpr int H = xt_hot<T>::H;
@@ -125,7 +143,11 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
   const bool use_a = sr.uses_a() && a.aval != nullptr, use_u = sr.uses_u();
   const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)call.u, (short)0, (int)(call.ulen * (uint32_t)sizeof(T)), 0x00020000);
   if (use_u) for (uint32_t h = threadIdx.x; h < a.nhot; h += XT_WAVES_ * 64) s_hot[h] = wp_ld(a.xhot + h);      // the table's contents, gathered from u once per call
-  const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.pcol, (short)0, (int)(a.nnz * 4u), 0x00020000);
+  // (16-bit words: the range covers whole tiles — the plan pads them with zeros — because the range check works on dwords and an
+  //  odd entry count would otherwise cut the panel's last word off)
+  const __amdgpu_buffer_rsrc_t c_rsrc = C16 ? __builtin_amdgcn_make_buffer_rsrc((void*)a.col16, (short)0, (int)(a.ntiles * (uint32_t)WP_ENT * 2u), 0x00020000)
+                                            : __builtin_amdgcn_make_buffer_rsrc((void*)a.pcol, (short)0, (int)(a.nnz * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.extras, (short)0, (int)(C16 ? (a.nextras * 2u + 15u) & ~15ull : 0ull), 0x00020000);
   const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.aval, (short)0, (int)(a.aval ? a.nnz * (uint32_t)sizeof(T) : 0u), 0x00020000);
   __syncthreads();
   // Work split (see k_spmv_wavepipe): chunk ids [0, dyn0) are static ranges of s0 chunks dealt to (workgroup, wave), ids >= dyn0
@@ -135,14 +157,14 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
   uint32_t s0 = (uint32_t)((uint64_t)nchunks * a.static_pct / 100 / (nwg * XT_WAVES_)); if (s0 > WP_MAX_STATIC) s0 = WP_MAX_STATIC;
   const uint32_t dyn0 = s0 * nwg * XT_WAVES_;
   uint32_t st_next = ((uint32_t)__builtin_amdgcn_readfirstlane(wv) * nwg + jwg) * s0; const uint32_t st_end = st_next + s0;
-  auto next_chunk = [&]() -> uint32_t {
+  auto next_chunk = [&]() __attribute__((always_inline)) -> uint32_t {
     if (st_next < st_end) return st_next++;
     uint32_t v = 0; if (lane == 0) v = atomicAdd(&s_next, 1u);
     return dyn0 + (uint32_t)__builtin_amdgcn_readfirstlane(v) * nwg + jwg;
   };
   // the wave's tiles, in the order of its chunks; WP_NONE once the work is exhausted
   uint32_t ic = next_chunk(), ij = 0;
-  auto next_tile = [&]() -> uint32_t {
+  auto next_tile = [&]() __attribute__((always_inline)) -> uint32_t {
     for (;;) {
       if (ic >= nchunks) return WP_NONE;
       const uint32_t t = ic * K + ij;
@@ -152,16 +174,36 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
   };
 
   XtStage<T> S[NS];
-  auto load_cols = [&](XtStage<T>& s) {
+  static_assert(!C16 || WP_PER == 4, "the 16-bit column plane packs a lane's four words in two dwords");
+  auto load_cols = [&](XtStage<T>& s) __attribute__((always_inline)) {
     const bool ok = s.tile != WP_NONE;
-    if constexpr (EXP == 3) {        // timing experiment (wrong results): half the bytes of the column stream — what a 16-bit column plane could save at most
-      uint32_t h[2]; xt_stream_load<uint32_t, 2>(c_rsrc, ok ? (s.tile * (uint32_t)WP_ENT / 2 + lane * 2) * 4u : 0xFFFFFFFFu, h);
-      s.c[0] = h[0]; s.c[1] = h[1]; s.c[2] = h[0] ^ 0x11u; s.c[3] = h[1] ^ 0x7u;
-    } else
-    xt_stream_load<uint32_t, WP_PER>(c_rsrc, ok ? (s.tile * (uint32_t)WP_ENT + lane * WP_PER) * 4u : 0xFFFFFFFFu, s.c);
-    s.rf = wp_ld(a.trow + (ok ? s.tile : 0u));
+    if constexpr (C16) {
+      xt_stream_load<uint32_t, 2>(c_rsrc, ok ? (s.tile * (uint32_t)WP_ENT + lane * WP_PER) * 2u : 0xFFFFFFFFu, s.h);
+      const uint2 ti = *(const uint2*)(a.tinfo + 2u * (ok ? s.tile : 0u));
+      s.rf = ti.x; s.cb = ti.y;
+    } else {
+      xt_stream_load<uint32_t, WP_PER>(c_rsrc, ok ? (s.tile * (uint32_t)WP_ENT + lane * WP_PER) * 4u : 0xFFFFFFFFu, s.c);
+      s.rf = wp_ld(a.trow + (ok ? s.tile : 0u));
+    }
   };
-  auto issue_gather = [&](XtStage<T>& s) {
+  // 16-bit format, one tile behind load_cols: the lane's cold entries are consecutive halfwords of `extras` (entry order =
+  // lane-major), starting at the tile's base + the number of cold entries in the lanes before it: three aligned dwords cover
+  // any four consecutive halfwords.  Lanes without a cold entry make no request.
+  auto load_extras = [&](XtStage<T>& s) __attribute__((always_inline)) {
+    if constexpr (C16) {
+      const bool ok = s.tile != WP_NONE;
+      const uint32_t h0 = s.h[0], h1 = s.h[1];
+      uint32_t before = 0; bool any = false;
+#define XT_COLD(W) { const bool cold = ok && ((W) & 0x7FFFu) >= (uint32_t)H; const unsigned long long m = __ballot(cold); any = any || cold; \
+                     before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, before)); }
+      XT_COLD(h0) XT_COLD(h0 >> 16) XT_COLD(h1) XT_COLD(h1 >> 16)
+#undef XT_COLD
+      s.xr = (uint32_t)__builtin_amdgcn_readfirstlane(s.cb) + before;
+      const xt_v3u q = __builtin_amdgcn_raw_buffer_load_b96(x_rsrc, (int)(any ? (s.xr >> 1) * 4u : 0xFFFFFFFFu), 0, XT_STREAM_AUX);
+      s.xq[0] = q.x; s.xq[1] = q.y; s.xq[2] = q.z;
+    }
+  };
+  auto issue_gather = [&](XtStage<T>& s) __attribute__((always_inline)) {
     const bool ok = s.tile != WP_NONE;
     const uint32_t e0 = ok ? s.tile * (uint32_t)WP_ENT : 0u, left = a.nnz - e0, cnt = !ok ? 0u : (left < (uint32_t)WP_ENT ? left : (uint32_t)WP_ENT);
     if (use_a) xt_stream_load<T, WP_PER>(v_rsrc, ok ? (e0 + lane * WP_PER) * (uint32_t)sizeof(T) : 0xFFFFFFFFu, s.v);
@@ -169,10 +211,27 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
 #pragma unroll
       for (int u = 0; u < WP_PER; u++) s.v[u] = T();
     }
+    if constexpr (C16) {
+      // the lane's extras as a window of four halfwords (two overlapping 64-bit views of the three dwords, shifted by the
+      // parity of its first one); every cold entry takes the lowest and shifts the window on.  Entries behind the end of the
+      // panel are zero words — slot 0 of the table — and fetch nothing.
+      const uint32_t sh = (s.xr & 1u) << 4;
+      uint32_t wl = __builtin_amdgcn_alignbit(s.xq[1], s.xq[0], sh), wh = __builtin_amdgcn_alignbit(s.xq[2], s.xq[1], sh);
 #pragma unroll
-    for (int u = 0; u < WP_PER; u++) {
-      const uint32_t cc = (uint32_t)(lane * WP_PER + u) < cnt ? (s.c[u] & WP_COLMASK) : 0u;   // slot in the LDS table, or H + column
-      s.g[u] = (use_u && EXP != 1) ? xt_buf_load<T>(u_rsrc, cc >= (uint32_t)H ? (cc - (uint32_t)H) * (uint32_t)sizeof(T) : 0xFFFFFFFFu) : T();   // only the columns the table does not hold are fetched
+      for (int u = 0; u < WP_PER; u++) {
+        const uint32_t code = (s.h[u >> 1] >> (16 * (u & 1))) & 0x7FFFu;
+        const bool cold = code >= (uint32_t)H;
+        const uint32_t col = ((code - (uint32_t)H) << 16) | (wl & 0xFFFFu);
+        s.g[u] = (use_u && EXP != 1) ? xt_buf_load<T>(u_rsrc, cold ? col * (uint32_t)sizeof(T) : 0xFFFFFFFFu) : T();
+        const uint32_t adv = cold ? 16u : 0u;
+        wl = __builtin_amdgcn_alignbit(wh, wl, adv); wh >>= adv;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < WP_PER; u++) {
+        const uint32_t cc = (uint32_t)(lane * WP_PER + u) < cnt ? (s.c[u] & WP_COLMASK) : 0u;   // slot in the LDS table, or H + column
+        s.g[u] = (use_u && EXP != 1) ? xt_buf_load<T>(u_rsrc, cc >= (uint32_t)H ? (cc - (uint32_t)H) * (uint32_t)sizeof(T) : 0xFFFFFFFFu) : T();   // only the columns the table does not hold are fetched
+      }
     }
   };
 
@@ -180,12 +239,14 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
 #pragma unroll
   for (int d = 0; d < D + 2; d++) { S[d].tile = next_tile(); load_cols(S[d]); }
 #pragma unroll
+  for (int d = 0; d < D + 1; d++) load_extras(S[d]);
+#pragma unroll
   for (int d = 0; d < D; d++) issue_gather(S[d]);
 
   // one tile: slot I is reduced while the values and gathers of the tile D ahead and the column words of the tile D + 2
   // ahead are issued; the loop is unrolled over the ring so that the register sets swap roles without being copied
   auto step = [&]<int I>() __attribute__((always_inline)) -> bool {
-    XtStage<T>& A = S[I % NS]; XtStage<T>& N1 = S[(I + 1) % NS]; XtStage<T>& G = S[(I + D) % NS]; XtStage<T>& C = S[(I + D + 2) % NS];
+    XtStage<T>& A = S[I % NS]; XtStage<T>& N1 = S[(I + 1) % NS]; XtStage<T>& G = S[(I + D) % NS]; XtStage<T>& M = S[(I + D + 1) % NS]; XtStage<T>& C = S[(I + D + 2) % NS];
     if (A.tile == WP_NONE) return false;
     const uint32_t t = A.tile;
     const uint32_t e0 = t * (uint32_t)WP_ENT, cnt = a.nnz - e0 < (uint32_t)WP_ENT ? a.nnz - e0 : (uint32_t)WP_ENT;
@@ -194,23 +255,24 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
     T p[WP_PER];
 #pragma unroll
     for (int u = 0; u < WP_PER; u++) {
-      const uint32_t cc = A.c[u] & WP_COLMASK;
+      const uint32_t cc = C16 ? (A.h[u >> 1] >> (16 * (u & 1))) & 0x7FFFu : A.c[u] & WP_COLMASK;
       const T uvv = use_u ? (cc < (uint32_t)H ? s_hot[cc < (uint32_t)H ? cc : 0] : A.g[u]) : T();
       p[u] = sr.mult(A.v[u], uvv);                             // entries past cnt hold junk: a forward scan never lets it reach a live position
     }
     if constexpr (D > 0) issue_gather(G);
+    load_extras(M);
     C.tile = next_tile(); load_cols(C);
     const uint32_t rf = (uint32_t)__builtin_amdgcn_readfirstlane(A.rf);
     if constexpr (EXP == 2) {                                  // timing experiment: consume the loads, nothing else
       T q = sr.add(sr.add(p[0], p[1]), sr.add(p[2], p[3]));
-      if (A.c[0] == 0x12345678u && rf == 0x7FFFFFFFu) wp_st(call.partial + lane, q);
+      if ((C16 ? A.h[0] : A.c[0]) == 0x12345678u && rf == 0x7FFFFFFFu) wp_st(call.partial + lane, q);
       return true;
     }
     bool rs[WP_PER];                                           // my entry u is the first of its sub-row
 #pragma unroll
-    for (int u = 0; u < WP_PER; u++) rs[u] = (int32_t)A.c[u] < 0;
+    for (int u = 0; u < WP_PER; u++) rs[u] = C16 ? ((A.h[u >> 1] >> (16 * (u & 1) + 15)) & 1u) != 0u : (int32_t)A.c[u] < 0;
     // what follows the tile's last entry: a row start (always, at the end of a chunk), or the end of the work?
-    const bool last_end = N1.tile == WP_NONE || (int32_t)__builtin_amdgcn_readfirstlane(N1.c[0]) < 0;
+    const bool last_end = N1.tile == WP_NONE || (C16 ? (__builtin_amdgcn_readfirstlane(N1.h[0]) & 0x8000u) != 0u : (int32_t)__builtin_amdgcn_readfirstlane(N1.c[0]) < 0);
     // ---- segmented inclusive scan of the products in entry order, and in the same wave scan the number of row starts
     // behind the tile's first entry (sub-row of an entry = rf + that count, up to and including the entry)
     uint32_t mine = 0;

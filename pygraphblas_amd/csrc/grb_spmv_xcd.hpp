@@ -40,8 +40,10 @@ constexpr int XP_SW = XP_ST / 64;     // its waves
 
 struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per matrix and value type
   DevBuf hot_cols;        // u32[XP*H]   column held by slot h of panel k's LDS table
-  DevBuf pcol, pval;      // u32[.], T[.] panel-major entries (column word, value); panel k starts at tile tbase[k]
+  DevBuf pcol, pval;      // u32[.], T[.] panel-major entries (column word, value); panel k starts at tile tbase[k].  pcol is dropped once packed
   DevBuf trow;            // u32[tiles]  sub-row (numbered over all panels, panel after panel) of every tile's first entry
+  DevBuf col16, extras, tinfo;   // the 16-bit column plane the kernel streams (grb_spmv_tiles.hpp): u16[.] words, u16[ncold] low halves of the cold columns, u32[2*tiles] {sub-row, first extra}
+  uint64_t ncold = 0;
   DevBuf lrow;            // u16[F]      row of every sub-row relative to its block of XP_RB rows — what the merge kernel streams
   DevBuf blockptr;        // u32[(nblocks+1)*XP] first sub-row of panel k in row block b
   // merge in row-major slot order (k_xp_merge): variable row blocks of <= XM_ROWS rows and ~XM_TARGET sub-rows
@@ -249,6 +251,71 @@ static __global__ void k_xp_block_starts(const uint32_t* __restrict__ subrow_row
     uint32_t lo = E[tb[k]], hi = E[tb[k + 1]];                 // panel k's sub-rows; first one whose row is >= target
     while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (subrow_row[mid] < target) lo = mid + 1; else hi = mid; }
     blockptr[t] = lo;
+  }
+}
+// ---- the 16-bit column plane: per tile the number of cold entries, after a scan the packed words and the extras ----
+static __global__ __launch_bounds__(256) void k_xc_count(const uint32_t* __restrict__ pcol, uint32_t ntiles, uint32_t H, uint32_t* __restrict__ tcnt) {
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6); g < ntiles; g += gridDim.x * 4) {
+    const uint4 wd = *(const uint4*)(pcol + (size_t)g * WP_ENT + lane * 4);
+    const uint32_t c = ((wd.x & WP_COLMASK) >= H) + ((wd.y & WP_COLMASK) >= H) + ((wd.z & WP_COLMASK) >= H) + ((wd.w & WP_COLMASK) >= H);
+    const uint32_t tot = __builtin_amdgcn_wave_reduce_add_u32(c, 0);
+    if (lane == 0) tcnt[g] = tot;
+  }
+}
+static __global__ __launch_bounds__(256) void k_xc_pack(const uint32_t* __restrict__ pcol, const uint32_t* __restrict__ trow, const uint32_t* __restrict__ tcold, uint32_t ntiles, uint32_t H,
+                                                        uint16_t* __restrict__ col16, uint16_t* __restrict__ extras, uint32_t* __restrict__ tinfo) {
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6); g < ntiles; g += gridDim.x * 4) {
+    const size_t q0 = (size_t)g * WP_ENT + lane * 4;
+    const uint4 wd = *(const uint4*)(pcol + q0);
+    const uint32_t w[4] = {wd.x, wd.y, wd.z, wd.w};
+    uint32_t mine = 0; bool cold[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { cold[j] = (w[j] & WP_COLMASK) >= H; mine += cold[j] ? 1u : 0u; }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += o; }
+    uint32_t x = tcold[g] + incl - mine;
+    uint32_t o16[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t v = w[j] & WP_COLMASK, flag = (w[j] >> 31) << 15;
+      if (cold[j]) { const uint32_t c = v - H; o16[j] = flag | (H + (c >> 16)); extras[x++] = (uint16_t)(c & 0xFFFFu); }
+      else o16[j] = flag | v;
+    }
+    *(uint2*)(col16 + q0) = make_uint2(o16[0] | (o16[1] << 16), o16[2] | (o16[3] << 16));
+    if (lane == 0) { tinfo[2 * (size_t)g] = trow[g]; tinfo[2 * (size_t)g + 1] = tcold[g]; }
+  }
+}
+// debugging aid (GRB_MI355X_XC_VERIFY=1 at plan build): decode every tile the way the tile pipeline does and compare with the 32-bit words
+static __global__ __launch_bounds__(256) void k_xc_verify(const uint32_t* __restrict__ pcol, const uint16_t* __restrict__ col16, const uint16_t* __restrict__ extras, const uint32_t* __restrict__ tinfo,
+                                                          const uint32_t* __restrict__ trow, uint32_t ntiles, uint32_t H, unsigned long long* __restrict__ bad) {
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6); g < ntiles; g += gridDim.x * 4) {
+    const size_t q0 = (size_t)g * WP_ENT + lane * 4;
+    const uint2 hh = *(const uint2*)(col16 + q0);
+    const uint32_t h[2] = {hh.x, hh.y};
+    uint32_t before = 0, nc = 0;
+    for (int u = 0; u < 4; u++) {
+      const uint32_t w = (h[u >> 1] >> (16 * (u & 1))) & 0x7FFFu; const bool cold = w >= H;
+      const unsigned long long m = __ballot(cold);
+      before += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); nc += cold ? 1u : 0u;
+    }
+    const uint32_t xr = tinfo[2 * (size_t)g + 1] + before;
+    uint32_t x0 = 0, x1 = 0, x2 = 0;
+    if (nc) { const uint32_t* xp = (const uint32_t*)extras + (xr >> 1); x0 = xp[0]; x1 = xp[1]; x2 = xp[2]; }
+    const uint64_t wa = ((uint64_t)x1 << 32) | x0, wb = ((uint64_t)x2 << 32) | x1;
+    uint32_t q = xr & 1u;
+    for (int u = 0; u < 4; u++) {
+      const uint32_t w16 = (h[u >> 1] >> (16 * (u & 1))) & 0xFFFFu, code = w16 & 0x7FFFu, flag = (w16 & 0x8000u) << 16;
+      const bool cold = code >= H;
+      const uint32_t lo = (uint32_t)((q < 2u ? wa >> (16u * q) : wb >> (16u * (q - 2u)))) & 0xFFFFu;
+      const uint32_t c = flag | (cold ? H + (((code - H) << 16) | lo) : code);
+      q += cold ? 1u : 0u;
+      if (c != pcol[q0 + u]) { const unsigned long long n = atomicAdd(bad, 1ull); if (n == 0) { bad[1] = q0 + u; bad[2] = ((unsigned long long)c << 32) | pcol[q0 + u]; } }
+    }
+    if (lane == 0 && tinfo[2 * (size_t)g] != trow[g]) atomicAdd(bad + 3, 1ull);
   }
 }
 // xhot[k*H + h] = u[hot column h of panel k]: the eight LDS tables' contents, gathered once per call (every workgroup of a
@@ -591,14 +658,40 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals) {
                          P->tbase[2], P->tbase[3], P->tbase[4], P->tbase[5], P->tbase[6], P->tbase[7], P->tbase[8], P->m_blockptr.as<uint32_t>());
     }
   }
+  // 6c. the 16-bit column plane (fourth host round trip: the number of cold entries); the 32-bit words are dropped
+  const bool keep32 = !XT_C16 || wp_env("GRB_MI355X_XT_KEEP32", 0) != 0;
+  if (XT_C16) {
+    DevBuf tcnt(((size_t)ntiles + 1) * 4), tcold(((size_t)ntiles + 1) * 4);
+    GRB_HIP(hipMemsetAsync(tcnt.as<uint32_t>() + ntiles, 0, 4, stream()));
+    unsigned nb = (ntiles + 3) / 4; if (nb < 1) nb = 1; if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(k_xc_count, dim3(nb), dim3(256), 0, stream(), P->pcol.as<uint32_t>(), ntiles, H, tcnt.as<uint32_t>());
+    exclusive_scan_u32(tcnt.as<uint32_t>(), tcold.as<uint32_t>(), (uint64_t)ntiles + 1);
+    uint32_t nc32 = 0;
+    GRB_HIP(hipMemcpyAsync(&nc32, tcold.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+    P->ncold = nc32;
+    P->col16.alloc(nstore * 2); P->extras.alloc(P->ncold * 2 + 32); P->tinfo.alloc(((size_t)ntiles + 1) * 8);
+    hipLaunchKernelGGL(k_xc_pack, dim3(nb), dim3(256), 0, stream(), P->pcol.as<uint32_t>(), P->trow.as<uint32_t>(), tcold.as<uint32_t>(), ntiles, H, P->col16.as<uint16_t>(), P->extras.as<uint16_t>(),
+                       P->tinfo.as<uint32_t>());
+    if (wp_env("GRB_MI355X_XC_VERIFY", 0)) {
+      DevBuf bad(64); GRB_HIP(hipMemsetAsync(bad.p, 0, 64, stream()));
+      hipLaunchKernelGGL(k_xc_verify, dim3(nb), dim3(256), 0, stream(), P->pcol.as<uint32_t>(), P->col16.as<uint16_t>(), P->extras.as<uint16_t>(), P->tinfo.as<uint32_t>(), P->trow.as<uint32_t>(), ntiles, H,
+                         (unsigned long long*)bad.p);
+      unsigned long long hb[4]; GRB_HIP(hipMemcpyAsync(hb, bad.p, 32, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+      fprintf(stderr, "[grb] 16-bit column plane check: %llu words differ (first at entry %llu: decoded %08llx, stored %08llx), %llu tile infos differ; cold entries %llu of %llu\n", hb[0], hb[1], hb[2] >> 32,
+              hb[2] & 0xFFFFFFFFull, hb[3], (unsigned long long)P->ncold, (unsigned long long)nstore);
+    }
+    if (!keep32) { P->pcol.reset(); P->trow.reset(); }
+  }
   // 7. the panels' argument block and the per-call buffers
   P->args.alloc(XP * sizeof(XtPanel<T>));
   P->xhot.alloc((size_t)XP * H * sizeof(T) + 8); P->partial.alloc(P->F * sizeof(T) + 8);
   XtPanel<T> ha[XP];
   for (int k = 0; k < XP; k++) {
     XtPanel<T>& a = ha[k];
-    a.pcol = P->pcol.as<uint32_t>() + (size_t)P->tbase[k] * WP_ENT; a.aval = with_vals ? P->pval.as<T>() + (size_t)P->tbase[k] * WP_ENT : nullptr;
-    a.trow = P->trow.as<uint32_t>() + P->tbase[k]; a.xhot = P->xhot.as<T>() + (size_t)k * H;
+    a.pcol = keep32 ? P->pcol.as<uint32_t>() + (size_t)P->tbase[k] * WP_ENT : nullptr; a.aval = with_vals ? P->pval.as<T>() + (size_t)P->tbase[k] * WP_ENT : nullptr;
+    a.trow = keep32 ? P->trow.as<uint32_t>() + P->tbase[k] : nullptr; a.xhot = P->xhot.as<T>() + (size_t)k * H;
+    a.col16 = XT_C16 ? P->col16.as<uint16_t>() + (size_t)P->tbase[k] * WP_ENT : nullptr; a.tinfo = XT_C16 ? P->tinfo.as<uint32_t>() + 2 * (size_t)P->tbase[k] : nullptr;
+    a.extras = XT_C16 ? P->extras.as<uint16_t>() : nullptr; a.nextras = P->ncold;
     a.nnz = (uint32_t)P->ne[k]; a.ntiles = P->ntiles[k]; a.tiles_per_chunk = kt[k]; a.nhot = P->nhot[k];
     a.static_pct = wp_env("GRB_MI355X_WP_STATIC", WP_STATIC_PCT); a.pad = 0;
   }
@@ -617,6 +710,7 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals) {
 template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int ncu) {
   DevCSR& M = *c.M;
   if (ncu < XP || ncu % XP) return false;
+  if ((uint64_t)M.ncols > xt_hot<T>::MAXCOLS) return false;        // a column must fit a code word (16-bit plane: 2^29 columns and more go to kernel W)
   const bool need_vals = c.aval != nullptr;
   if (need_vals && c.aval != M.val.p) return false;   // the plan's panel-major values are a copy of the stored ones (no typecast)
   auto* P = static_cast<XcdPlan*>(M.xcd.get());
@@ -633,7 +727,9 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
       const XtVariant v = xt_variant();
 #define XT_TRY(D_, W_, E_) if (!launched && v.depth == D_ && v.waves == W_ && v.exp == E_) { \
         hipLaunchKernelGGL((k_spmv_tiles<T, SR, D_, W_, E_>), dim3(ncu), dim3(W_ * 64), 0, stream(), call, (const XtPanel<T>*)P->args.p, sr); launched = true; }
-      XT_TRY(1, 16, 1) XT_TRY(1, 16, 2) XT_TRY(1, 16, 3) XT_TRY(2, 16, 0) XT_TRY(1, 8, 0) XT_TRY(2, 8, 0) XT_TRY(3, 8, 0) XT_TRY(2, 8, 2) XT_TRY(3, 8, 2) XT_TRY(4, 8, 0)
+      XT_TRY(1, 16, 1) XT_TRY(1, 16, 2) XT_TRY(2, 16, 0)
+      if (!launched && v.exp == 4 && ((const XcdPlan*)P)->pcol.p) {      // e4: the 32-bit column words (plans built under GRB_MI355X_XT_KEEP32=1)
+        hipLaunchKernelGGL((k_spmv_tiles<T, SR, XT_DEPTH, XT_WAVES, 0, false>), dim3(ncu), dim3(XT_WAVES * 64), 0, stream(), call, (const XtPanel<T>*)P->args.p, sr); launched = true; } XT_TRY(1, 8, 0) XT_TRY(2, 8, 0) XT_TRY(3, 8, 0) XT_TRY(2, 8, 2) XT_TRY(3, 8, 2) XT_TRY(4, 8, 0)
 #undef XT_TRY
     }
 #endif
