@@ -199,7 +199,9 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
       XT_COLD(h0) XT_COLD(h0 >> 16) XT_COLD(h1) XT_COLD(h1 >> 16)
 #undef XT_COLD
       s.xr = (uint32_t)__builtin_amdgcn_readfirstlane(s.cb) + before;
-      const xt_v3u q = __builtin_amdgcn_raw_buffer_load_b96(x_rsrc, (int)(any ? (s.xr >> 1) * 4u : 0xFFFFFFFFu), 0, XT_STREAM_AUX);
+      // (default cache policy, not the streams' nt: a tile's extras end inside a 128-byte line that the next tile's begin in;
+      //  with nt that line was fetched from HBM twice — 65 MB of extras traffic per product instead of 30)
+      const xt_v3u q = __builtin_amdgcn_raw_buffer_load_b96(x_rsrc, (int)(any ? (s.xr >> 1) * 4u : 0xFFFFFFFFu), 0, 0);
       s.xq[0] = q.x; s.xq[1] = q.y; s.xq[2] = q.z;
     }
   };

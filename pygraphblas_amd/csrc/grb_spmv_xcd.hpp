@@ -471,11 +471,16 @@ static __global__ void k_xm_max(const uint32_t* __restrict__ cnt, uint32_t nrows
   if (threadIdx.x == 0 && s_m) atomicMax(out, s_m);                  // one device atomic per workgroup
 }
 template <class T, class SR>
-__global__ __launch_bounds__(XM_CT) void k_xp_merge(uint32_t nrows, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ blockptr, const uint16_t* __restrict__ slot,
+__global__ __launch_bounds__(XM_CT) void k_xp_merge(uint32_t nrows, uint32_t nblocks, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ blockptr, const uint16_t* __restrict__ slot,
                                                     const uint16_t* __restrict__ rowoff, const T* __restrict__ partial, T* __restrict__ y, uint8_t* __restrict__ ypres, const SR sr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char xm_lds[];      // m_slots values: XM_SLOTS unless some row has very many sub-rows
   T* const vals = (T*)xm_lds;
-  const uint32_t b = blockIdx.x, tid = threadIdx.x;
+  // workgroup w runs on XCD w % 8 (observed, grb_spmv.hip): give every XCD a contiguous eighth of the row blocks, so that the 128-byte
+  // lines two neighbouring blocks share (the ends of their runs of partials, slots, row offsets and y) meet in one L2
+  // (the grid is the block count rounded up to a multiple of 8)
+  const uint32_t per = gridDim.x / XP, b = (blockIdx.x & (XP - 1)) * per + (blockIdx.x >> 3);
+  const uint32_t tid = threadIdx.x;
+  if (b >= nblocks) return;
   const uint32_t r0 = bstart[b], r1 = bstart[b + 1];
   uint32_t lo[XP], pre[XP + 1];
   pre[0] = 0;
@@ -737,7 +742,7 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
     const uint32_t nblocks = (uint32_t)(((uint64_t)M.nrows + XP_RB - 1) / XP_RB);
     static const bool old_merge = wp_env("GRB_MI355X_XP_OLD_MERGE", 0) != 0;       // measurement hook: the per-panel merge kernel
     if (P->m_ok && !old_merge)
-      hipLaunchKernelGGL((k_xp_merge<T, SR>), dim3(P->m_nblocks), dim3(XM_CT), (size_t)P->m_slots * sizeof(T), stream(), M.nrows, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), P->m_slot.as<uint16_t>(),
+      hipLaunchKernelGGL((k_xp_merge<T, SR>), dim3((P->m_nblocks + XP - 1) / XP * XP), dim3(XM_CT), (size_t)P->m_slots * sizeof(T), stream(), M.nrows, P->m_nblocks, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), P->m_slot.as<uint16_t>(),
                          P->m_rowoff.as<uint16_t>(), P->partial.as<T>(), (T*)c.tval, c.tpres, sr);
     else
       hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3(nblocks), dim3(XP_CT), 0, stream(), M.nrows, P->blockptr.as<uint32_t>(), P->lrow.as<uint16_t>(), P->partial.as<T>(),

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes for the SpMV kernel (run on the GPU box).  Counters are collected in separate runs
 # without any tracing flags, as the MI355X guide prescribes (TCC has 4 slots; FETCH_SIZE needs 3).
-# usage: tools/pmc_spmv.sh <outdir> [probe args...]
+# usage: tools/pmc_spmv.sh <outdir> [probe args...]      (the numbers in profiles/: --variants FP64.PLUS_TIMES --methods auto; PMC_PASSES=2 = traffic only)
 set -u
 out=${1:-gpurun_out/pmc}; shift || true
 mkdir -p "$out"
@@ -17,6 +17,7 @@ passes=(
 i=0
 for p in "${passes[@]}"; do
   i=$((i+1))
+  if [ -n "${PMC_PASSES:-}" ] && [ "$i" -gt "$PMC_PASSES" ]; then break; fi       # PMC_PASSES=2: the two traffic passes only
   timeout 150 rocprofv3 --pmc $p --output-format csv -d "$out/p$i" -o pmc -- python tools/spmv_probe.py --reps 3 "$@" < /dev/null > "$out/p$i.log" 2>&1
 done
 python - "$out" <<'PY'
