@@ -37,10 +37,13 @@ namespace grb {
 // all of the LDS but the staging slots is the table: 19454 slots of 8 bytes.  With the 16-bit column plane a word holds a
 // 15-bit code — a slot, or XT escape + the high bits of a cold column — so the table is capped at 24576 slots (4-byte and
 // smaller types; 8192 escape codes x 65536 = 2^29 columns) and kernel X takes matrices of up to xt_hot<T>::MAXCOLS columns.
+// The 16-bit plane is used for 8-byte types only: with 4-byte values the table would shrink from 39932 to 24576 slots, and the
+// pattern-only FP32 product (PageRank's PLUS_SECOND) measured 130 us with it against 105 us with 32-bit words.
+template <class T> struct xt_fmt { static constexpr bool C16 = XT_C16 != 0 && sizeof(T) >= 8; };
 template <class T> struct xt_hot {
   static constexpr int HLDS = (WP_LDS_BYTES - 16 - WP_WAVES * 64 * (int)sizeof(T)) / (int)sizeof(T);
-  static constexpr int H = XT_C16 ? (HLDS < 24576 ? HLDS : 24576) : HLDS;
-  static constexpr uint64_t MAXCOLS = XT_C16 ? ((uint64_t)(32768 - H) << 16) : 0x7FFFFFFFull - (uint64_t)H;
+  static constexpr int H = xt_fmt<T>::C16 ? (HLDS < 24576 ? HLDS : 24576) : HLDS;
+  static constexpr uint64_t MAXCOLS = xt_fmt<T>::C16 ? ((uint64_t)(32768 - H) << 16) : 0x7FFFFFFFull - (uint64_t)H;
 };
 
 // the segmented scan of the sums and the prefix count of the row starts in one pass: x = flag << 31 | count
@@ -128,7 +131,7 @@ template <class F, int... I> __device__ __forceinline__ bool xt_unroll_steps(F&&
 
 // D = prefetch depth, W = waves per workgroup; EXP selects a timing experiment (wrong results!): 1 = no gathers of u (streams
 // only), 2 = loads only (no scan, no stores: what the load side of the pipeline can deliver)
-template <class T, class SR, int D = XT_DEPTH, int W = XT_WAVES, int EXP = 0, bool C16 = (XT_C16 != 0)>
+template <class T, class SR, int D = XT_DEPTH, int W = XT_WAVES, int EXP = 0, bool C16 = xt_fmt<T>::C16>
 __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, const XtPanel<T>* __restrict__ panels, const SR sr) {
   const XtPanel<T> a = panels[blockIdx.x & 7];          // workgroup b works on column panel b % 8 — the XCD it is observed to run on
   constexpr int H = xt_hot<T>::H;

@@ -664,8 +664,9 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals) {
     }
   }
   // 6c. the 16-bit column plane (fourth host round trip: the number of cold entries); the 32-bit words are dropped
-  const bool keep32 = !XT_C16 || wp_env("GRB_MI355X_XT_KEEP32", 0) != 0;
-  if (XT_C16) {
+  constexpr bool c16 = xt_fmt<T>::C16;
+  const bool keep32 = !c16 || wp_env("GRB_MI355X_XT_KEEP32", 0) != 0;
+  if (c16) {
     DevBuf tcnt(((size_t)ntiles + 1) * 4), tcold(((size_t)ntiles + 1) * 4);
     GRB_HIP(hipMemsetAsync(tcnt.as<uint32_t>() + ntiles, 0, 4, stream()));
     unsigned nb = (ntiles + 3) / 4; if (nb < 1) nb = 1; if (nb > 16384) nb = 16384;
@@ -695,8 +696,8 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals) {
     XtPanel<T>& a = ha[k];
     a.pcol = keep32 ? P->pcol.as<uint32_t>() + (size_t)P->tbase[k] * WP_ENT : nullptr; a.aval = with_vals ? P->pval.as<T>() + (size_t)P->tbase[k] * WP_ENT : nullptr;
     a.trow = keep32 ? P->trow.as<uint32_t>() + P->tbase[k] : nullptr; a.xhot = P->xhot.as<T>() + (size_t)k * H;
-    a.col16 = XT_C16 ? P->col16.as<uint16_t>() + (size_t)P->tbase[k] * WP_ENT : nullptr; a.tinfo = XT_C16 ? P->tinfo.as<uint32_t>() + 2 * (size_t)P->tbase[k] : nullptr;
-    a.extras = XT_C16 ? P->extras.as<uint16_t>() : nullptr; a.nextras = P->ncold;
+    a.col16 = c16 ? P->col16.as<uint16_t>() + (size_t)P->tbase[k] * WP_ENT : nullptr; a.tinfo = c16 ? P->tinfo.as<uint32_t>() + 2 * (size_t)P->tbase[k] : nullptr;
+    a.extras = c16 ? P->extras.as<uint16_t>() : nullptr; a.nextras = P->ncold;
     a.nnz = (uint32_t)P->ne[k]; a.ntiles = P->ntiles[k]; a.tiles_per_chunk = kt[k]; a.nhot = P->nhot[k];
     a.static_pct = wp_env("GRB_MI355X_WP_STATIC", WP_STATIC_PCT); a.pad = 0;
   }
