@@ -429,6 +429,9 @@ __global__ __launch_bounds__(XP_CT) void k_xp_combine(uint32_t nrows, const uint
 // per sub-row instead of ~7, one barrier instead of four, blocks of equal weight whatever the labels of the graph.
 constexpr uint32_t XM_ROWS = 1024, XM_TARGET = 2048, XM_SLOTS = 2560;   // a block holds < XM_TARGET + (sub-rows of one row) sub-rows: XM_SLOTS of LDS, more (up to 64 KB) when a row has very many
 constexpr int XM_CT = 256;
+#ifndef XM_INFL
+#define XM_INFL 4                     // pairs of loads in flight per thread of the merge kernel (8: no faster)
+#endif
 static __global__ void k_xm_iota(uint32_t* p, uint64_t n) { for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) p[i] = (uint32_t)i; }
 static __global__ void k_xm_weights(const uint32_t* __restrict__ cnt, uint32_t nrows, uint32_t* __restrict__ w) {
   for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r <= nrows; r += gridDim.x * 256) w[r] = r < nrows ? cnt[r] + XM_TARGET / XM_ROWS : 0u;
@@ -487,11 +490,11 @@ __global__ __launch_bounds__(XM_CT) void k_xp_merge(uint32_t nrows, uint32_t nbl
 #pragma unroll
   for (int k = 0; k < XP; k++) { lo[k] = blockptr[b * XP + k]; pre[k + 1] = pre[k] + (blockptr[(b + 1) * XP + k] - lo[k]); }
   const uint32_t total = pre[XP];
-  // the block's sub-rows as one index space over the eight runs; four loads in flight per thread before the first LDS write
-  for (uint32_t t0 = tid; t0 < total; t0 += 4 * XM_CT) {
-    T v[4]; uint32_t sl[4];
+  // the block's sub-rows as one index space over the eight runs; XM_INFL pairs of loads in flight per thread before the first LDS write
+  for (uint32_t t0 = tid; t0 < total; t0 += XM_INFL * XM_CT) {
+    T v[XM_INFL]; uint32_t sl[XM_INFL];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < XM_INFL; u++) {
       const uint32_t t = t0 + u * XM_CT; const bool ok = t < total;
       uint32_t s = 0;
 #pragma unroll
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(XM_CT) void k_xp_merge(uint32_t nrows, uint32_t nbl
       v[u] = ok ? partial[s] : T(); sl[u] = ok ? (uint32_t)slot[s] : 0xFFFFFFFFu;
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) if (sl[u] != 0xFFFFFFFFu) vals[sl[u]] = v[u];
+    for (int u = 0; u < XM_INFL; u++) if (sl[u] != 0xFFFFFFFFu) vals[sl[u]] = v[u];
   }
   __syncthreads();
   const int lane = tid & 63;
