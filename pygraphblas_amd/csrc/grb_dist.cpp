@@ -1,4 +1,4 @@
-// grb_dist.cpp — the exchange steps of the row-partitioned hot path, inside the library (RCCL linked directly).
+// grb_dist.cpp — the exchange steps of the row-partitioned hot path, inside the library (RCCL, bound at first use: see below).
 //
 // The reference has no distributed code; BASELINE.json's north star partitions the matrix by row
 // blocks across the GPUs of one node — one process per GPU — and names the exchange: an allgatherv of the operand /
