@@ -168,6 +168,12 @@ void mat_to_device(GrB_Matrix A);         // ensure device CSR valid (assembles 
 void mat_invalidate_host(GrB_Matrix A);   // device was written
 void mat_invalidate_device(GrB_Matrix A); // host was written
 uint64_t mat_nvals(GrB_Matrix A);
+// hypersparse containers (a dimension beyond the device layouts): the products and eWise operations on the index sets that occur (grb_hyper.cpp)
+bool is_hyper(const GrB_Matrix_opaque* A); bool is_hyper(const GrB_Vector_opaque* v);
+void hyper_mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semiring semiring, GrB_Matrix A, GrB_Vector u, GrB_Descriptor desc, bool is_vxm);
+void hyper_mxm(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, GrB_Semiring semiring, GrB_Matrix A, GrB_Matrix B, GrB_Descriptor desc);
+void hyper_vec_ewise(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_BinaryOp op, GrB_Vector u, GrB_Vector v, GrB_Descriptor desc, bool is_union);
+void hyper_mat_ewise(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, GrB_BinaryOp op, GrB_Matrix A, GrB_Matrix B, GrB_Descriptor desc, bool is_union);
 // scalar into a region on the host mirror (grb_host_ops.cpp): for complex containers and for dimensions beyond the device layout
 void host_assign_scalar(GrB_Matrix C, GrB_Matrix Mask, GrB_BinaryOp accum, const void* x, int xcode, const GrB_Index* I, GrB_Index ni, const GrB_Index* J, GrB_Index nj, GrB_Descriptor desc);
 void host_assign_scalar(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const void* x, int xcode, const GrB_Index* I, GrB_Index ni, GrB_Descriptor desc);

@@ -77,6 +77,7 @@ void check_mat(GrB_Matrix A, const char* what) { if (!check_obj(A)) fail(GrB_UNI
 // ---------------------------------------------------------------------------------------------------------------------
 void do_mxm(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, GrB_Semiring semiring, GrB_Matrix A, GrB_Matrix B, GrB_Descriptor desc) {
   need_device();
+  if (is_hyper(C) || is_hyper(M) || is_hyper(A) || is_hyper(B)) { hyper_mxm(C, M, accum, semiring, A, B, desc); return; }   // dimensions beyond the device layouts
   check_mat(A, "mxm"); check_mat(B, "mxm"); if (M) check_mat(M, "mxm");
   const DescView dv(desc);
   const uint64_t ar = dv.tran0 ? A->ncols : A->nrows, ac = dv.tran0 ? A->nrows : A->ncols;
@@ -129,6 +130,7 @@ void do_transpose(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, GrB_Matrix A, 
 void do_ewise(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, GrB_BinaryOp op, GrB_Matrix A, GrB_Matrix B, GrB_Descriptor desc, bool is_union) {
   need_device(); check_mat(A, "eWise"); check_mat(B, "eWise"); if (M) check_mat(M, "eWise");
   check_binop(op, "eWise");
+  if (is_hyper(C) || is_hyper(M) || is_hyper(A) || is_hyper(B)) { hyper_mat_ewise(C, M, accum, op, A, B, desc, is_union); return; }
   const DescView dv(desc);
   const uint64_t ar = dv.tran0 ? A->ncols : A->nrows, ac = dv.tran0 ? A->nrows : A->ncols;
   const uint64_t br = dv.tran1 ? B->ncols : B->nrows, bc = dv.tran1 ? B->nrows : B->ncols;

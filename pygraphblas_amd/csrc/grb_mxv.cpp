@@ -19,6 +19,7 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   need_device();
   if (!check_obj(w) || !check_obj(A) || !check_obj(u) || (mask && !check_obj(mask)))
     fail(GrB_UNINITIALIZED_OBJECT, "mxv/vxm: uninitialised operand");
+  if (is_hyper(A) || is_hyper(w) || is_hyper(u) || is_hyper(mask)) { hyper_mxv_like(w, mask, accum, semiring, A, u, desc, is_vxm); return; }   // dimensions beyond the device layouts
   const DescView dv(desc);
   const bool useT = is_vxm ? !dv.tran1 : dv.tran0;           // M = useT ? A^T : A
   const uint64_t mr = useT ? A->ncols : A->nrows, mc = useT ? A->nrows : A->ncols;

@@ -98,6 +98,7 @@ static void vec_ewise_op(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_
   need_device();
   if (!check_obj(u) || !check_obj(v) || (mask && !check_obj(mask))) fail(GrB_UNINITIALIZED_OBJECT, "eWise: uninitialised operand");
   check_binop(op, "eWise");
+  if (is_hyper(w)) { hyper_vec_ewise(w, mask, accum, op, u, v, desc, is_union); return; }      // a size beyond the device layout
   const DescView dv(desc); const uint64_t n = w->n;
   if (u->n != n || v->n != n || (mask && mask->n != n)) fail(GrB_DIMENSION_MISMATCH, "eWise: vector sizes differ");
   DevBuf allow_buf; bool nothing = false;

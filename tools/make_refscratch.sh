@@ -7,5 +7,6 @@ cd "$(dirname "$0")/.."
 rm -rf .refscratch && mkdir -p .refscratch/docs
 cp -r /root/reference/pygraphblas /root/reference/tests .refscratch/
 cp /root/reference/docs/test_mm.mm /root/reference/docs/test_tsvfile.tsv /root/reference/docs/test_binfile.grb .refscratch/docs/
+cp -r /root/reference/demo .refscratch/demo        # the notebooks (tools/ref_notebooks_run.py), their font and data files
 find .refscratch -name __pycache__ -prune -exec rm -rf {} +
 echo "scratch copy in .refscratch/ (git-ignored); delete it after the gpurun call"

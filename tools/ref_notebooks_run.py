@@ -1,0 +1,57 @@
+"""Harness (not part of the product): execute the code cells of the reference's demo notebooks, unmodified, on top of shim/.
+
+usage (python3.9 with cffi; PYTHONPATH=<repo>/shim:<scratch copy of the reference>:<repo>/tools/ref_harness_stubs):
+    python3.9 tools/ref_notebooks_run.py <dir with *.ipynb> [name ...]
+Every notebook runs in its own namespace, cell after cell; IPython magics are dropped; a cell that raises is recorded and the
+notebook goes on (later cells may then fail for want of its names — they are counted as 'follow-on').  One line per notebook and
+a total at the end; the first line of every exception is listed."""
+import glob, json, os, signal, sys, traceback, io, contextlib
+
+nbdir = sys.argv[1]
+only = set(sys.argv[2:])
+os.chdir(nbdir)
+
+
+class CellTimeout(Exception):
+    pass
+
+
+def on_alarm(sig, frm):
+    raise CellTimeout("cell ran longer than 120 s")
+
+
+signal.signal(signal.SIGALRM, on_alarm)
+tot_ok = tot_cells = 0
+for f in sorted(glob.glob("*.ipynb")):
+    name = f[:-6]
+    if only and name not in only:
+        continue
+    nb = json.load(open(f))
+    cells = ["".join(c["source"]) for c in nb["cells"] if c["cell_type"] == "code"]
+    ns = {"__name__": "__main__"}
+    ok = 0
+    errs = []
+    for i, src in enumerate(cells):
+        src = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith(("%", "!")))
+        if not src.strip():
+            ok += 1
+            continue
+        try:
+            code = compile(src, f"{name}[{i}]", "exec")
+            signal.alarm(120)
+            with contextlib.redirect_stdout(io.StringIO()):
+                exec(code, ns)
+            signal.alarm(0)
+            ok += 1
+        except BaseException as e:  # noqa: BLE001 - a harness: every failure is data
+            signal.alarm(0)
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            errs.append((i, type(e).__name__, str(e).splitlines()[0][:160] if str(e) else ""))
+    tot_ok += ok
+    tot_cells += len(cells)
+    print(f"== {name}: {ok} of {len(cells)} code cells run")
+    for i, t, m in errs:
+        print(f"     cell {i}: {t}: {m}")
+    sys.stdout.flush()
+print(f"TOTAL: {tot_ok} of {tot_cells} code cells run")
