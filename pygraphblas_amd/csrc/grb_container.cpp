@@ -24,6 +24,17 @@ void mat_host_assemble(GrB_Matrix A) {
   if (A->pending.empty()) return;
   const size_t ts = A->type->size;
   auto& P = A->pending;
+  if (P.size() <= 8) {            // a few edits (`M[i, j] = x` then a read): in place, one memmove each, instead of rebuilding the tuple arrays
+    for (const auto& e : P) {
+      size_t lo = 0, hi = A->hi.size();
+      while (lo < hi) { const size_t m = (lo + hi) / 2; if (A->hi[m] < e.i || (A->hi[m] == e.i && A->hj[m] < e.j)) lo = m + 1; else hi = m; }
+      const bool found = lo < A->hi.size() && A->hi[lo] == e.i && A->hj[lo] == e.j;
+      if (e.del) { if (found) { A->hi.erase(A->hi.begin() + lo); A->hj.erase(A->hj.begin() + lo); A->hx.erase(A->hx.begin() + lo * ts, A->hx.begin() + (lo + 1) * ts); } }
+      else if (found) memcpy(&A->hx[lo * ts], e.x, ts);
+      else { A->hi.insert(A->hi.begin() + lo, e.i); A->hj.insert(A->hj.begin() + lo, e.j); A->hx.insert(A->hx.begin() + lo * ts, e.x, e.x + ts); }
+    }
+    P.clear(); return;
+  }
   std::vector<uint32_t> ord(P.size());
   std::iota(ord.begin(), ord.end(), 0u);
   std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {

@@ -94,6 +94,61 @@ std::vector<uint64_t> indices(const GrB_Index* I, GrB_Index ni, uint64_t dim, co
 void check_m(GrB_Matrix A, const char* w) { if (!check_obj(A)) fail(GrB_UNINITIALIZED_OBJECT, std::string(w) + ": uninitialised matrix"); }
 void check_v(GrB_Vector A, const char* w) { if (!check_obj(A)) fail(GrB_UNINITIALIZED_OBJECT, std::string(w) + ": uninitialised vector"); }
 
+// ---- the common slices on the sorted tuples themselves (no map of the whole matrix): `M[i]`, `M[:, j]`, `M[i] = v`, `M[a:b, c:d]` ----
+typedef std::vector<std::pair<uint64_t, Val>> Line;                     // (index, value bytes), sorted by index
+Val val_at(const GrB_Matrix A, size_t p) { Val v{}; memcpy(v.data(), &A->hx[p * A->type->size], A->type->size); return v; }
+std::pair<size_t, size_t> row_range(const GrB_Matrix A, uint64_t i) {
+  const auto lo = std::lower_bound(A->hi.begin(), A->hi.end(), i), hi = std::upper_bound(lo, A->hi.end(), i);
+  return {(size_t)(lo - A->hi.begin()), (size_t)(hi - A->hi.begin())};
+}
+// column j of op(A): a row of A is a contiguous run of its tuples, a column is picked out in one pass
+Line line_of(GrB_Matrix A, bool transposed, uint64_t j) {
+  mat_to_host(A); Line out;
+  if (transposed) { const auto r = row_range(A, j); out.reserve(r.second - r.first); for (size_t p = r.first; p < r.second; p++) out.push_back({A->hj[p], val_at(A, p)}); }
+  else for (size_t p = 0; p < A->hj.size(); p++) if (A->hj[p] == j) out.push_back({A->hi[p], val_at(A, p)});
+  return out;
+}
+// row i (or column i) of C := `line` (values already in C's type)
+void replace_line(GrB_Matrix C, bool is_row, uint64_t i, const Line& line) {
+  const size_t ts = C->type->size;
+  if (is_row) {
+    const auto r = row_range(C, i);
+    std::vector<GrB_Index> nj; std::vector<uint8_t> nx; nj.reserve(line.size()); nx.reserve(line.size() * ts);
+    for (auto& e : line) { nj.push_back(e.first); nx.insert(nx.end(), e.second.data(), e.second.data() + ts); }
+    C->hi.erase(C->hi.begin() + r.first, C->hi.begin() + r.second); C->hi.insert(C->hi.begin() + r.first, line.size(), i);
+    C->hj.erase(C->hj.begin() + r.first, C->hj.begin() + r.second); C->hj.insert(C->hj.begin() + r.first, nj.begin(), nj.end());
+    C->hx.erase(C->hx.begin() + r.first * ts, C->hx.begin() + r.second * ts); C->hx.insert(C->hx.begin() + r.first * ts, nx.begin(), nx.end());
+  } else {
+    const size_t n = C->hi.size();
+    std::vector<GrB_Index> ni, nj; std::vector<uint8_t> nx; ni.reserve(n + line.size()); nj.reserve(n + line.size()); nx.reserve((n + line.size()) * ts);
+    size_t q = 0;
+    auto emit = [&](const std::pair<uint64_t, Val>& e) { ni.push_back(e.first); nj.push_back(i); nx.insert(nx.end(), e.second.data(), e.second.data() + ts); };
+    for (size_t p = 0; p < n; p++) {
+      while (q < line.size() && (line[q].first < C->hi[p] || (line[q].first == C->hi[p] && i < C->hj[p]))) emit(line[q++]);
+      if (C->hj[p] == i) continue;                                      // the column's old entry
+      ni.push_back(C->hi[p]); nj.push_back(C->hj[p]); nx.insert(nx.end(), &C->hx[p * ts], &C->hx[p * ts] + ts);
+    }
+    while (q < line.size()) emit(line[q++]);
+    C->hi.swap(ni); C->hj.swap(nj); C->hx.swap(nx);
+  }
+  C->host_valid = true; mat_invalidate_device(C);
+}
+// the line C gets from `C(line) = accum(C(line), u)` over ALL positions, no mask: u's entries (cast), united with C's under accum
+Line assigned_line(const Line& cur, int ccode, GrB_Vector u, GrB_BinaryOp accum) {
+  if (accum) check_binop(accum, "accum");
+  vec_to_host(u); const size_t us = u->type->size; const int ucode = u->type->code;
+  Line out; out.reserve(cur.size() + u->hi.size());
+  size_t a = 0, b = 0;
+  auto uval = [&](size_t k) { Val v{}; memcpy(v.data(), &u->hx[k * us], us); return v; };
+  while (a < cur.size() || b < u->hi.size()) {
+    if (b >= u->hi.size() || (a < cur.size() && cur[a].first < u->hi[b])) { if (accum) out.push_back(cur[a]); a++; }          // C only: kept under accum, deleted without
+    else if (a >= cur.size() || u->hi[b] < cur[a].first) { out.push_back({u->hi[b], cast(ccode, ucode, uval(b))}); b++; }
+    else { out.push_back({u->hi[b], accum ? combine(accum, ccode, cur[a].second, ucode, uval(b)) : cast(ccode, ucode, uval(b))}); a++; b++; }
+  }
+  return out;
+}
+bool strictly_increasing(const std::vector<uint64_t>& v) { for (size_t k = 1; k < v.size(); k++) if (v[k] <= v[k - 1]) return false; return true; }
+
 }  // namespace
 
 extern "C" {
@@ -121,8 +176,13 @@ GrB_Info GrB_Col_extract(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp
     if (j >= ac) fail(GrB_INVALID_INDEX, "extract: column index out of range");
     const auto idx = indices(I, ni, ar, "extract");
     if (w->n != idx.size() || (mask && mask->n != w->n)) fail(GrB_DIMENSION_MISMATCH, "extract: output size must equal the number of indices");
-    Map Am = load(A, dv.tran0), T, C = load(w), Mm; if (mask) Mm = load(mask);
-    for (size_t k = 0; k < idx.size(); k++) { auto it = Am.find({idx[k], j}); if (it != Am.end()) T[{k, 0}] = it->second; }
+    const Line col = line_of(A, dv.tran0, j);                             // (index in op(A)'s column j, value), sorted
+    Map T, C = load(w), Mm; if (mask) Mm = load(mask);
+    if (I == GrB_ALL) for (auto& e : col) T[{e.first, 0}] = e.second;
+    else for (size_t k = 0; k < idx.size(); k++) {
+      auto it = std::lower_bound(col.begin(), col.end(), idx[k], [](const std::pair<uint64_t, Val>& e, uint64_t x) { return e.first < x; });
+      if (it != col.end() && it->first == idx[k]) T[{k, 0}] = it->second;
+    }
     write_back(C, w->type->code, T, A->type->code, MaskView{&Mm, mask ? mask->type->code : 0, dv.mask_struct, dv.mask_comp, mask != nullptr}, dv.replace, accum, everywhere);
     store(w, C);
   });
@@ -137,6 +197,24 @@ GrB_Info GrB_Matrix_extract(GrB_Matrix C, const GrB_Matrix Mask, const GrB_Binar
     const uint64_t ar = dv.tran0 ? A->ncols : A->nrows, ac = dv.tran0 ? A->nrows : A->ncols;
     const auto ri = indices(I, ni, ar, "extract"), ci = indices(J, nj, ac, "extract");
     if (C->nrows != ri.size() || C->ncols != ci.size() || (Mask && (Mask->nrows != C->nrows || Mask->ncols != C->ncols))) fail(GrB_DIMENSION_MISMATCH, "extract: output shape must be |I| x |J|");
+    if (!Mask && !accum && strictly_increasing(ri) && strictly_increasing(ci)) {       // a slice `A[a:b, c:d]` into a fresh output: one pass over A's tuples
+      mat_to_host(A); const size_t ts = A->type->size; const int acode = A->type->code, ccode = C->type->code;
+      struct E { uint64_t i, j; Val v; }; std::vector<E> out;
+      for (size_t p = 0; p < A->hi.size(); p++) {
+        const uint64_t si = dv.tran0 ? A->hj[p] : A->hi[p], sj = dv.tran0 ? A->hi[p] : A->hj[p];
+        const auto a = std::lower_bound(ri.begin(), ri.end(), si); if (a == ri.end() || *a != si) continue;
+        const auto b = std::lower_bound(ci.begin(), ci.end(), sj); if (b == ci.end() || *b != sj) continue;
+        Val v{}; memcpy(v.data(), &A->hx[p * ts], ts);
+        out.push_back({(uint64_t)(a - ri.begin()), (uint64_t)(b - ci.begin()), cast(ccode, acode, v)});
+      }
+      if (dv.tran0) std::sort(out.begin(), out.end(), [](const E& x, const E& y) { return x.i != y.i ? x.i < y.i : x.j < y.j; });
+      const size_t cs = C->type->size;
+      C->hi.clear(); C->hj.clear(); C->hx.clear(); C->pending.clear(); C->iso_full = false;
+      C->hi.reserve(out.size()); C->hj.reserve(out.size()); C->hx.reserve(out.size() * cs);
+      for (auto& e : out) { C->hi.push_back(e.i); C->hj.push_back(e.j); C->hx.insert(C->hx.end(), e.v.data(), e.v.data() + cs); }
+      C->host_valid = true; mat_invalidate_device(C);
+      return;
+    }
     Map Am = load(A, dv.tran0), T, Cm = load(C, false), Mm; if (Mask) Mm = load(Mask, false);
     std::multimap<uint64_t, uint64_t> rpos, cpos;                       // source index -> output positions (an index may repeat)
     for (size_t k = 0; k < ri.size(); k++) rpos.insert({ri[k], k});
@@ -230,6 +308,13 @@ GrB_Info GrB_Row_assign(GrB_Matrix C, const GrB_Vector mask, const GrB_BinaryOp 
     if (i >= C->nrows) fail(GrB_INVALID_INDEX, "assign: row index out of range");
     const auto ci = indices(J, nj, C->ncols, "assign");
     if (u->n != ci.size() || (mask && mask->n != C->ncols)) fail(GrB_DIMENSION_MISMATCH, "assign: the vector's size must equal the number of column indices");
+    if (!mask && J == GrB_ALL && C->type->code < T_FC32 && u->type->code < T_FC32) {   // `M[i] = v`: the row's run of tuples is replaced in place
+      mat_to_host(C);
+      const auto r = row_range(C, i); Line cur; cur.reserve(r.second - r.first);
+      for (size_t p = r.first; p < r.second; p++) cur.push_back({C->hj[p], val_at(C, p)});
+      replace_line(C, true, i, assigned_line(cur, C->type->code, u, accum));
+      return;
+    }
     Map Cm = load(C, false), U = load(u), Ut, Mm; if (mask) Mm = load(mask);
     for (auto& kv : U) Ut[{0, kv.first.first}] = kv.second;             // the vector as a 1 x nj row
     region_update(Cm, C->type->code, Ut, u->type->code, std::vector<uint64_t>{i}, ci, accum, MaskView{&Mm, mask ? mask->type->code : 0, dv.mask_struct, dv.mask_comp, mask != nullptr}, dv.replace,
@@ -246,6 +331,10 @@ GrB_Info GrB_Col_assign(GrB_Matrix C, const GrB_Vector mask, const GrB_BinaryOp 
     if (j >= C->ncols) fail(GrB_INVALID_INDEX, "assign: column index out of range");
     const auto ri = indices(I, ni, C->nrows, "assign");
     if (u->n != ri.size() || (mask && mask->n != C->nrows)) fail(GrB_DIMENSION_MISMATCH, "assign: the vector's size must equal the number of row indices");
+    if (!mask && I == GrB_ALL && C->type->code < T_FC32 && u->type->code < T_FC32) {   // `M[:, j] = v`: one merge pass over the tuples
+      replace_line(C, false, j, assigned_line(line_of(C, false, j), C->type->code, u, accum));
+      return;
+    }
     Map Cm = load(C, false), U = load(u), Mm; if (mask) Mm = load(mask);
     region_update(Cm, C->type->code, U, u->type->code, ri, std::vector<uint64_t>{j}, accum, MaskView{&Mm, mask ? mask->type->code : 0, dv.mask_struct, dv.mask_comp, mask != nullptr}, dv.replace,
                   false, false, true, j);
