@@ -103,3 +103,13 @@ def test_unmodified_reference_stores_complex_entries_through_the_shim(gb):
             "print('OK complex')\n")
     r = subprocess.run([PY39, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")
     assert r.returncode == 0 and "OK complex" in r.stdout, r.stdout + r.stderr
+
+
+@needs39
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_host_mirror_slices_against_a_model_through_the_unmodified_reference(gb):
+    """`M[i]`, `M[:, j]`, `M[i] = v`, `M[a:b, c:d]`, `M[i, j] = x` / `del M[i, j]` work on the sorted tuples of the host mirror
+    (grb_host_ops.cpp); 300 random cases against a dict model (tests/shim_host_slices_check.py)."""
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "shim") + ":" + REF, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([PY39, os.path.join(ROOT, "tests", "shim_host_slices_check.py")], capture_output=True, text=True, timeout=600, env=env, cwd="/tmp")
+    assert r.returncode == 0 and "OK host slices" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
