@@ -80,7 +80,30 @@ def main():
         box = [ident]
         tdist.broadcast_object_list(box, src=0)
         return box[0]
-    comm = gdist.Comm(rank, world, transport=os.environ.get("BENCH_TRANSPORT", "rccl"), share=share, tdist=tdist if world > 1 else None)
+    transport = os.environ.get("BENCH_TRANSPORT", "rccl")
+    transport_note = transport
+    if world > 1 and transport == "rccl":
+        # the data path is the library's RCCL communicator.  It is set up and self-tested (an all-reduce of rank + 1) on every
+        # rank; if any rank fails, ALL ranks fall back to host copies over gloo (slower, and labelled so in the line) instead
+        # of leaving the driver without a number.
+        ok, why = 1, ""
+        try:
+            comm = gdist.Comm(rank, world, transport="rccl", share=share, tdist=tdist)
+            ok = int(comm.allreduce(rank + 1, gb.INT64, "PLUS") == world * (world + 1) // 2)
+            why = "" if ok else "all-reduce self-test returned a wrong sum"
+        except Exception as e:          # noqa: BLE001 - any failure of the communicator selects the fallback
+            ok, why = 0, f"{type(e).__name__}: {e}"
+        flag = torch.tensor([ok], dtype=torch.int64); tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            try:
+                comm.close()
+            except Exception:           # noqa: BLE001
+                pass
+            print(f"bench.py[{rank}]: RCCL data path unavailable ({why or 'another rank failed'}); falling back to host transport", file=sys.stderr)
+            comm = gdist.Comm(rank, world, transport="host", share=share, tdist=tdist)
+            transport_note = "host copies over gloo (RCCL set-up failed on some rank; NOT the designed data path)"
+    else:
+        comm = gdist.Comm(rank, world, transport=transport, share=share, tdist=tdist if world > 1 else None)
 
     def barrier():
         if world > 1:
@@ -186,7 +209,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"R-MAT scale-{scale} FP64 PLUS_TIMES SpMV (GrB_mxv), edgefactor 16, "
                                f"{'row-partitioned into %d entry-balanced blocks + allgatherv of x (RCCL, overlapped with the diagonal block)' % world if world > 1 else 'BASELINE.json configs[1]'}",
-                   "n": n, "nnz": nnz_total, "semiring": "PLUS_TIMES_FP64", "parallelism": f"rowblock{world}",
+                   "n": n, "nnz": nnz_total, "semiring": "PLUS_TIMES_FP64", "parallelism": f"rowblock{world}", "transport": transport_note if world > 1 else "none (one GPU)",
                    "graph_build_s": round(t_gen, 2), "device": info["name"]},
         "gbps_algorithmic": round(alg_bytes * args.steps / (elapsed if world == 1 else kernel_ms * 1e-3 * args.steps) / 1e9, 1),
         "roofline": roofline,

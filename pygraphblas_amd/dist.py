@@ -103,9 +103,16 @@ class Comm:
         self._pending = None
         if world > 1 and transport == "rccl":
             buf = C.create_string_buffer(128)
+            ident, err = b"", None
             if rank == 0:
-                _check(lib.GrBX_dist_unique_id(buf, C.c_int(128)))
-            ident = share(bytes(buf.raw))
+                try:
+                    _check(lib.GrBX_dist_unique_id(buf, C.c_int(128)))
+                    ident = bytes(buf.raw)
+                except Exception as e:          # noqa: BLE001 - the other ranks wait in share(): tell them instead of leaving them there
+                    err = e
+            ident = share(ident)
+            if not ident:
+                raise err or RuntimeError("rank 0 could not create the RCCL communicator id")
             _check(lib.GrBX_dist_init(C.c_int(rank), C.c_int(world), C.c_char_p(ident), C.c_int(128)))
         elif world > 1 and transport != "host":
             raise ValueError("transport must be 'rccl' or 'host'")
