@@ -140,7 +140,7 @@ void vec_host_assemble(GrB_Vector v) {
   while (b < nb) push_base(b++);
   v->hi.swap(ni); v->hx.swap(nx); P.clear(); P.shrink_to_fit();
 }
-void vec_invalidate_device(GrB_Vector v) { v->dev_valid = false; v->dval.reset(); v->dpres.reset(); v->dnvals = 0; v->dnvals_known = true; }
+void vec_invalidate_device(GrB_Vector v) { v->dev_valid = false; v->dval.reset(); v->dpres.reset(); v->dnvals = 0; v->dnvals_known = true; v->fe_lb = 0; v->fe_lb_key = nullptr; }
 void vec_invalidate_host(GrB_Vector v) {
   v->host_valid = false; v->hi.clear(); v->hx.clear(); v->pending.clear(); v->hi.shrink_to_fit(); v->hx.shrink_to_fit();
 }

@@ -145,6 +145,10 @@ struct GrB_Vector_opaque {
   bool dev_valid = false;
   grb::DevBuf dval, dpres;   // T[n], u8[n]
   uint64_t dnvals = 0; bool dnvals_known = true;   // entry count of the device bitmap, recounted lazily
+  // a lower bound of the edges that leave the vector's entries in one matrix (keyed by its row-pointer buffer), valid while entries are
+  // only added (scalar assign under a mask without replace — the `v[q] = level` of a BFS loop): a masked product whose operand was
+  // already too heavy for a push step needs no recount to stay a pull step.  A stale value can only cost speed, never correctness.
+  uint64_t fe_lb = 0; const void* fe_lb_key = nullptr;
   int sparsity_control = 15;
   std::string err;
 };

@@ -40,13 +40,17 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   // the entry count of u and (for the direction choice below) the edges leaving it come from one kernel and one round
   // trip when the count is not known yet — the usual state inside a BFS loop, where u was just updated under a mask
   uint64_t fe_cached = ~0ull;
+  bool stays_pull = false;            // the operand was too heavy for a push step when it was last counted and has only grown since
   if (!u->dnvals_known && mask && method == SPMV_AUTO && spmspv_push_supported(sd) && u->n && (useT || A->csc.valid)) {      // (a masked product: frontier-like operand; never build a transpose just for this)
     const DevCSR& P0 = useT ? A->csr : mat_csc(A);
-    uint64_t cnt = 0;
-    fe_cached = frontier_edges_and_count(u->dpres.as<uint8_t>(), P0.rowptr.as<uint32_t>(), u->n, &cnt);
-    u->dnvals = cnt; u->dnvals_known = true;
+    if (u->fe_lb_key == P0.rowptr.p && u->fe_lb * 16 >= P0.nnz + 16) stays_pull = true;      // no kernel, no host round trip
+    else {
+      uint64_t cnt = 0;
+      fe_cached = frontier_edges_and_count(u->dpres.as<uint8_t>(), P0.rowptr.as<uint32_t>(), u->n, &cnt);
+      u->dnvals = cnt; u->dnvals_known = true; u->fe_lb = fe_cached; u->fe_lb_key = P0.rowptr.p;
+    }
   }
-  const uint64_t u_nvals = vec_dev_nvals(u);
+  const uint64_t u_nvals = stays_pull ? (u->n ? u->n - 1 : 0) : vec_dev_nvals(u);             // (not counted: treated as "has holes")
   const bool u_full = u_nvals == u->n;
 
   // does the multiply read the matrix / vector values at all?
@@ -58,7 +62,7 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   // frontier (an exact count on the device) are < 1/16 of all entries.
   bool push = false;
   if (method == SPMV_PUSH) push = spmspv_push_supported(sd);
-  else if (method == SPMV_AUTO && spmspv_push_supported(sd) && !u_full && u_nvals * 16 < (uint64_t)A->csr.nnz + 16) {
+  else if (method == SPMV_AUTO && !stays_pull && spmspv_push_supported(sd) && !u_full && u_nvals * 16 < (uint64_t)A->csr.nnz + 16) {
     const DevCSR& P = useT ? A->csr : mat_csc(A);
     const uint64_t fe = fe_cached != ~0ull ? fe_cached : frontier_edges(u->dpres.as<uint8_t>(), P.rowptr.as<uint32_t>(), u->n);
     push = fe * 16 < P.nnz + 16;

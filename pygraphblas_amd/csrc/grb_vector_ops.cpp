@@ -90,6 +90,7 @@ static void vec_assign(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const 
     vec_cast_values(wcode, w->dval.p, ecode, wc.p, n);
   }
   vec_invalidate_host(w);
+  if (dv.replace) { w->fe_lb = 0; w->fe_lb_key = nullptr; }                      // (without replace a scalar assign only adds entries: the bound stays)
   w->dnvals_known = !allow && !reg; w->dnvals = w->dnvals_known ? n : 0;       // every index, no mask: the vector is full now
 }
 
