@@ -113,3 +113,14 @@ def test_host_mirror_slices_against_a_model_through_the_unmodified_reference(gb)
     env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "shim") + ":" + REF, PYTHONDONTWRITEBYTECODE="1")
     r = subprocess.run([PY39, os.path.join(ROOT, "tests", "shim_host_slices_check.py")], capture_output=True, text=True, timeout=600, env=env, cwd="/tmp")
     assert r.returncode == 0 and "OK host slices" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@needs39
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_host_mirror_index_operations_fuzzed_against_a_model(gb):
+    """extract / assign (matrix, row, column, vector) with index lists, ranges, masks (valued, structural, complemented),
+    accumulators and replace, through the unmodified reference, against a Python model of the GraphBLAS rules
+    (tools/fuzz_host_ops.py; 12 000 cases were run while it was written)."""
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "shim") + ":" + REF, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([PY39, os.path.join(ROOT, "tools", "fuzz_host_ops.py"), "--cases", "600", "--seed", "11"], capture_output=True, text=True, timeout=600, env=env, cwd="/tmp")
+    assert r.returncode == 0 and "fuzz host ops ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
