@@ -239,3 +239,15 @@ def test_entry_parallel_companions_on_a_power_law_graph(gpu):
     C = A.dup()
     B.apply(gb.INT64.IDENTITY, out=C, mask=Lm, accum=gb.INT64.PLUS, desc=D.R)
     same(C, (SA + SB).multiply(SL))
+
+
+def test_companions_fuzzed_against_a_model(gpu):
+    """Six seconds of tools/fuzz_companions.py: eWise, apply, bound apply, select, transpose, reduce to a vector and scalar assign
+    with random masks (valued / structural / complemented), accumulators, replace and transposed inputs against a Python model
+    of the GraphBLAS rules (1.6e5 cases were clean when it was written)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_companions.py"), "--seconds", "6", "--seed", "5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fuzz companions ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
