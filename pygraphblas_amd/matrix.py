@@ -39,6 +39,27 @@ def get_args(mask, accum, desc):
     return mh, ah, dh
 
 
+def build_range(rslice, stop_val):
+    """An index argument of the slicing operations -> (I pointer, ni, size or None, keep-alive array): a list, `None` / `:` for
+    all, or a slice — whose `stop` is INCLUSIVE, as in the reference (`_build_range`, pygraphblas/base.py:216-250: GxB_RANGE /
+    GxB_STRIDE / GxB_BACKWARDS index triples)."""
+    if isinstance(rslice, (list, tuple, np.ndarray)):
+        keep = np.ascontiguousarray(rslice, np.uint64)
+        return _p(keep), len(keep), len(keep), keep
+    if rslice is None or rslice == slice(None):
+        return C.cast(_capi.handle("GrB_ALL"), C.c_void_p), 0, None, None
+    start = 0 if rslice.start is None else rslice.start
+    stop = stop_val if rslice.stop is None else rslice.stop
+    step = rslice.step
+    if step is None:
+        keep, ni, size = np.array([start, stop], np.uint64), _capi.constants["GxB_RANGE"], stop - start + 1
+    elif step < 0:
+        keep, ni, size = np.array([start, stop, -step], np.uint64), _capi.constants["GxB_BACKWARDS"], (0 if start < stop else (start - stop) // -step + 1)
+    else:
+        keep, ni, size = np.array([start, stop, step], np.uint64), _capi.constants["GxB_STRIDE"], (0 if start > stop or step == 0 else (stop - start) // step + 1)
+    return _p(keep), ni, size, keep
+
+
 class Matrix:
     _kind = "matrix"
 
@@ -366,16 +387,110 @@ class Matrix:
         return iter(zip(I.tolist(), J.tolist(), X.tolist()))
 
     def __setitem__(self, index, value):
+        """`M[i, j] = x`, `M[i] = v` / `M[i, :] = v` (row), `M[:, j] = v` (column), `M[I, J] = A` (sub-matrix) — reference: matrix.py:3236-3330."""
+        from .vector import Vector
+        if isinstance(index, int):
+            return self.assign_row(index, value)
+        if isinstance(index, slice):
+            return self.assign_matrix(value, index, None)
         i, j = index
-        fn = getattr(lib, "GrB_Matrix_setElement_" + self.type.__name__)
-        check(fn(self._h, self.type._c(value), u64(i), u64(j)), self)
+        if isinstance(i, int) and isinstance(j, int):
+            fn = getattr(lib, "GrB_Matrix_setElement_" + self.type.__name__)
+            check(fn(self._h, self.type._c(value), u64(i), u64(j)), self)
+        elif isinstance(i, int) and isinstance(value, Vector):
+            self.assign_row(i, value, j)
+        elif isinstance(j, int) and isinstance(value, Vector):
+            self.assign_col(j, value, i)
+        elif isinstance(value, Matrix):
+            self.assign_matrix(value, i, j)
+        else:
+            raise TypeError("unsupported index / value combination")
 
     def __getitem__(self, index):
+        """`M[i, j]` (element), `M[i]` / `M[i, :]` (row vector), `M[:, j]` (column vector), `M[a:b, c:d]` / `M[[..], [..]]` (sub-matrix;
+        slices include their stop, as in the reference: matrix.py:2967-3003)."""
+        if isinstance(index, int):
+            return self.extract_row(index)
+        if isinstance(index, slice):
+            return self.extract_matrix(index, None)
         i, j = index
-        out = self.type._c()
-        fn = getattr(lib, "GrB_Matrix_extractElement_" + self.type.__name__)
-        check(fn(C.byref(out), self._h, u64(i), u64(j)), self)
-        return out.value
+        if isinstance(i, int) and isinstance(j, int):
+            out = self.type._c()
+            fn = getattr(lib, "GrB_Matrix_extractElement_" + self.type.__name__)
+            check(fn(C.byref(out), self._h, u64(i), u64(j)), self)
+            return out.value
+        if isinstance(i, int):
+            return self.extract_row(i, j)
+        if isinstance(j, int):
+            return self.extract_col(j, i)
+        return self.extract_matrix(i, j)
+
+    # ---- slices (host-mirror operations of the library: grb_host_ops.cpp) -----------------------------------------------
+    def extract_matrix(self, row_index=None, col_index=None, out=None, mask=None, accum=None, desc=None):
+        """`out<mask> = accum(out, op(self)(I, J))` (reference: matrix.py:2807-2900)."""
+        t0 = desc is not None and _d.T0 in desc
+        nr, nc = (self.ncols, self.nrows) if t0 else (self.nrows, self.ncols)
+        I, ni, isz, k1 = build_range(row_index, nr - 1); J, nj, jsz, k2 = build_range(col_index, nc - 1)
+        if out is None:
+            out = Matrix.sparse(self.type, nr if isz is None else isz, nc if jsz is None else jsz)
+        mh, ah, dh = get_args(mask, accum, desc)
+        check(lib.GrB_Matrix_extract(out._h, mh, ah, self._h, I, u64(ni), J, u64(nj), dh), out)
+        return out
+
+    def extract_col(self, col_index, row_slice=None, out=None, mask=None, accum=None, desc=None):
+        """Column `col_index` of op(self) as a vector (reference: matrix.py:2902-2941)."""
+        from .vector import Vector
+        t0 = desc is not None and _d.T0 in desc
+        length = self.ncols if t0 else self.nrows
+        I, ni, size, keep = build_range(row_slice, length - 1)
+        if out is None:
+            out = Vector.sparse(self.type, length if size is None else size)
+        mh, ah, dh = get_args(mask, accum, desc)
+        check(lib.GrB_Col_extract(out._h, mh, ah, self._h, I, u64(ni), u64(col_index), dh), out)
+        return out
+
+    def extract_row(self, row_index, col_slice=None, out=None, mask=None, accum=None, desc=None):
+        """Row `row_index` as a vector: the column of the transpose (reference: matrix.py:2943-2965)."""
+        return self.extract_col(row_index, col_slice, out, mask, accum, (desc & _d.T0) if desc is not None else _d.T0)
+
+    def assign_col(self, col_index, value, row_slice=None, mask=None, accum=None, desc=None):
+        """`self(I, j)<mask> = accum(self(I, j), value)` (reference: matrix.py:3005-3029)."""
+        I, ni, size, keep = build_range(row_slice, self.nrows - 1)
+        mh, ah, dh = get_args(mask, accum, desc)
+        check(lib.GrB_Col_assign(self._h, mh, ah, value._h, I, u64(ni), u64(col_index), dh), self)
+
+    def assign_row(self, row_index, value, col_slice=None, mask=None, accum=None, desc=None):
+        """`self(i, J)<mask> = accum(self(i, J), value)` (reference: matrix.py:3031-3055)."""
+        J, nj, size, keep = build_range(col_slice, self.ncols - 1)
+        mh, ah, dh = get_args(mask, accum, desc)
+        check(lib.GrB_Row_assign(self._h, mh, ah, value._h, u64(row_index), J, u64(nj), dh), self)
+
+    @classmethod
+    def from_diag(cls, v, k=0):
+        """The matrix with `v` on its k-th diagonal (reference: matrix.py:333-375)."""
+        n = v.size + abs(k)
+        out = cls.sparse(v.type, n, n)
+        check(lib.GxB_Matrix_diag(out._h, v._h, C.c_int64(k), None), out)
+        return out
+
+    def vector_diag(self, k=0):
+        """The k-th diagonal as a vector (reference: matrix.py:2225-2277)."""
+        from .vector import Vector
+        m, n = self.nrows, self.ncols
+        length = min(m, n - k) if 0 <= k < n else (min(m + k, n) if -m < k < 0 else 0)
+        out = Vector.sparse(self.type, length)
+        check(lib.GxB_Vector_diag(out._h, self._h, C.c_int64(k), None), out)
+        return out
+
+    def kronecker(self, other, op=None, cast=None, out=None, mask=None, accum=None, desc=None):
+        """Kronecker product (reference: matrix.py:2728-2805)."""
+        if op is None:
+            op = current_binop.get(None) or types.promote(self.type, other.type)._default_multop()
+        if out is None:
+            out = Matrix.sparse(cast or types.promote(self.type, other.type), self.nrows * other.nrows, self.ncols * other.ncols)
+        mh, ah, dh = get_args(mask, accum, desc)
+        check(lib.GrB_Matrix_kronecker_BinaryOp(out._h, mh, ah, C.c_void_p(op.get_op()), self._h, other._h, dh), out)
+        return out
 
     def get(self, i, j, default=None):
         try:
@@ -530,13 +645,7 @@ class Matrix:
     def assign_matrix(self, value, rindex=None, cindex=None, mask=None, accum=None, desc=None):
         """`C(I,J)<mask> = accum(C(I,J), value)` (reference: pygraphblas/matrix.py:3057-3130); index lists or None for all."""
         mh, ah, dh = get_args(mask, accum, desc)
-
-        def idx(ix):
-            if ix is None:
-                return C.cast(_capi.handle("GrB_ALL"), C.c_void_p), 0, None
-            keep = np.ascontiguousarray(list(ix), np.uint64)
-            return _p(keep), len(keep), keep
-        I, ni, k1 = idx(rindex); J, nj, k2 = idx(cindex)
+        I, ni, _s1, k1 = build_range(rindex, self.nrows - 1); J, nj, _s2, k2 = build_range(cindex, self.ncols - 1)
         check(lib.GrB_Matrix_assign(self._h, mh, ah, value._h, I, u64(ni), J, u64(nj), dh), self)
 
     assign = assign_matrix

@@ -142,9 +142,29 @@ class Vector:
         return iter(zip(I.tolist(), X.tolist()))
 
     def __getitem__(self, i):
+        """`v[i]` (element) or `v[a:b]` / `v[[..]]` (sub-vector; a slice includes its stop, as in the reference: vector.py:1526-1547)."""
+        if isinstance(i, (slice, list, tuple, np.ndarray)):
+            return self.extract(i)
         out = self.type._c()
         check(getattr(lib, "GrB_Vector_extractElement_" + self.type.__name__)(C.byref(out), self._h, u64(i)), self)
         return out.value
+
+    def extract(self, index, out=None, mask=None, accum=None, desc=None):
+        """`out<mask> = accum(out, self(I))` (reference: vector.py:1549-1575); host-mirror operation of the library."""
+        from .matrix import build_range
+        I, ni, size, keep = build_range(index, self.size - 1)
+        if out is None:
+            out = Vector.sparse(self.type, self.size if size is None else size)
+        mh, ah, dh = get_args(mask, accum, desc)
+        check(lib.GrB_Vector_extract(out._h, mh, ah, self._h, I, u64(ni), dh), out)
+        return out
+
+    def assign(self, value, index=None, mask=None, accum=None, desc=None):
+        """`self(I)<mask> = accum(self(I), value)` (reference: vector.py:1454-1492)."""
+        from .matrix import build_range
+        I, ni, size, keep = build_range(index, self.size - 1)
+        mh, ah, dh = get_args(mask, accum, desc)
+        check(lib.GrB_Vector_assign(self._h, mh, ah, value._h, I, u64(ni), dh), self)
 
     def get(self, i, default=None):
         try:
@@ -153,9 +173,13 @@ class Vector:
             return default
 
     def __setitem__(self, index, value):
+        if isinstance(value, Vector):
+            return self.assign(value, index if not isinstance(index, Vector) else None, mask=index if isinstance(index, Vector) else None)
+        if isinstance(index, Vector):                       # `v[q] = level`: scalar assign under the mask q (reference: vector.py:1428-1441)
+            return self.assign_scalar(value, mask=index)
         if isinstance(index, slice):
             if index != slice(None):
-                raise NotImplementedError("only v[:] = scalar is supported")
+                raise NotImplementedError("only v[:] = scalar is supported for slices")
             self.assign_scalar(value)
             return
         check(getattr(lib, "GrB_Vector_setElement_" + self.type.__name__)(self._h, self.type._c(value), u64(index)), self)

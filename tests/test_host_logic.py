@@ -245,3 +245,60 @@ def test_grb_binary_reader_against_the_references_fixture(tmp_path):
     assert F2.type is gb.FP32 and F2.shape == (3, 4) and F2.to_lists() == F.to_lists()
     with pytest.raises(ValueError):
         (tmp_path / "bad.grb").write_bytes(b"not a matrix"); gb.Matrix.binread(str(tmp_path / "bad.grb"))
+
+
+def test_mirror_slicing_surface_runs_on_the_host_mirror(gb):
+    """`M[i]`, `M[:, j]`, `M[a:b, c:d]` (stop inclusive, as in the reference), `M[i] = v`, `M[:, j] = v`, `M[I, J] = A`, `v[a:b]`,
+    `v[I] = u`, from_diag / vector_diag, kronecker — the index operations of the C ABI edit the host mirror, so they work (and are
+    checked here) without a device.  Reference: pygraphblas/matrix.py:2807-3130, vector.py:1454-1575."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    n = 12
+    dense = rng.integers(-9, 10, (n, n)); keep = rng.random((n, n)) < 0.4
+    I, J = np.nonzero(keep)
+    A = gb.Matrix.from_lists(I.tolist(), J.tolist(), dense[keep].tolist(), n, n, gb.INT64)
+
+    def mat(M):
+        out = np.zeros((M.nrows, M.ncols), np.int64); pres = np.zeros((M.nrows, M.ncols), bool)
+        for i, j, x in M:
+            out[i, j] = x; pres[i, j] = True
+        return out, pres
+
+    def vec(v):
+        out = np.zeros(v.size, np.int64); pres = np.zeros(v.size, bool)
+        for i, x in zip(*v.to_lists()):
+            out[i] = x; pres[i] = True
+        return out, pres
+    D = np.where(keep, dense, 0)
+    r, rp = vec(A[3]); assert (r == D[3]).all() and (rp == keep[3]).all()
+    c, cp = vec(A[:, 5]); assert (c == D[:, 5]).all() and (cp == keep[:, 5]).all()
+    s, sp = mat(A[2:6, 1:4]); assert s.shape == (5, 4) and (s == D[2:7, 1:5]).all() and (sp == keep[2:7, 1:5]).all()      # stop inclusive
+    s, sp = mat(A[[7, 1, 1], [0, 11]]); assert (s == D[[7, 1, 1]][:, [0, 11]]).all() and (sp == keep[[7, 1, 1]][:, [0, 11]]).all()
+    s, sp = mat(A.extract_matrix(slice(0, 3), None, desc=gb.descriptor.T0)); assert (s == D.T[0:4]).all() and (sp == keep.T[0:4]).all()
+    seg, segp = vec(A[3, 2:8]); assert (seg == D[3, 2:9]).all() and (segp == keep[3, 2:9]).all()
+    # assignments
+    v = gb.Vector.from_lists([0, 4, 9], [5, 6, 7], n, gb.INT64)
+    B = A.dup(); B[3] = v
+    want, wp = D.copy(), keep.copy(); want[3] = 0; wp[3] = False; want[3, [0, 4, 9]] = [5, 6, 7]; wp[3, [0, 4, 9]] = True
+    got, gp = mat(B); assert (got == want).all() and (gp == wp).all()
+    B = A.dup(); B[:, 5] = v
+    want, wp = D.copy(), keep.copy(); want[:, 5] = 0; wp[:, 5] = False; want[[0, 4, 9], 5] = [5, 6, 7]; wp[[0, 4, 9], 5] = True
+    got, gp = mat(B); assert (got == want).all() and (gp == wp).all()
+    B = A.dup(); B.assign_row(3, v, accum=gb.INT64.PLUS)
+    want, wp = D.copy(), keep.copy(); want[3, [0, 4, 9]] += [5, 6, 7]; wp[3, [0, 4, 9]] = True
+    got, gp = mat(B); assert (got == want).all() and (gp == wp).all()
+    S = gb.Matrix.from_lists([0, 1], [1, 0], [100, 200], 2, 2, gb.INT64)
+    B = A.dup(); B[[2, 8], [3, 4]] = S
+    want, wp = D.copy(), keep.copy(); want[np.ix_([2, 8], [3, 4])] = [[0, 100], [200, 0]]; wp[np.ix_([2, 8], [3, 4])] = [[False, True], [True, False]]
+    got, gp = mat(B); assert (got == want).all() and (gp == wp).all()
+    # vectors
+    u = gb.Vector.from_lists([1, 2, 5, 8], [10, 20, 50, 80], 10, gb.INT64)
+    assert u[2:5].to_lists() == [[0, 3], [20, 50]] and u[[8, 8, 0]].to_lists() == [[0, 1], [80, 80]]
+    w = gb.Vector.sparse(gb.INT64, 10); w[[9, 3, 4, 7]] = gb.Vector.from_lists([0, 2], [1, 2], 4, gb.INT64)
+    assert w.to_lists() == [[4, 9], [2, 1]]
+    # diagonals and kronecker
+    d = gb.Vector.from_lists([0, 2], [3, 4], 3, gb.INT64)
+    Dm = gb.Matrix.from_diag(d, -1); assert Dm.shape == (4, 4) and sorted(Dm) == [(1, 0, 3), (3, 2, 4)]
+    assert Dm.vector_diag(-1).to_lists() == [[0, 2], [3, 4]] and Dm.vector_diag(2).size == 2 and Dm.vector_diag(9).size == 0
+    K = gb.Matrix.from_lists([0, 1], [1, 0], [2, 3], 2, 2, gb.INT64).kronecker(gb.Matrix.from_lists([0], [1], [5], 1, 2, gb.INT64), gb.INT64.TIMES)
+    assert K.shape == (2, 4) and sorted(K) == [(0, 3, 10), (1, 1, 15)]
