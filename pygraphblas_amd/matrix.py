@@ -43,7 +43,7 @@ def build_range(rslice, stop_val):
     """An index argument of the slicing operations -> (I pointer, ni, size or None, keep-alive array): a list, `None` / `:` for
     all, or a slice — whose `stop` is INCLUSIVE, as in the reference (`_build_range`, pygraphblas/base.py:216-250: GxB_RANGE /
     GxB_STRIDE / GxB_BACKWARDS index triples)."""
-    if isinstance(rslice, (list, tuple, np.ndarray)):
+    if isinstance(rslice, (list, tuple, np.ndarray, range)):
         keep = np.ascontiguousarray(rslice, np.uint64)
         return _p(keep), len(keep), len(keep), keep
     if rslice is None or rslice == slice(None):

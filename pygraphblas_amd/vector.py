@@ -143,7 +143,7 @@ class Vector:
 
     def __getitem__(self, i):
         """`v[i]` (element) or `v[a:b]` / `v[[..]]` (sub-vector; a slice includes its stop, as in the reference: vector.py:1526-1547)."""
-        if isinstance(i, (slice, list, tuple, np.ndarray)):
+        if isinstance(i, (slice, list, tuple, np.ndarray, range)):
             return self.extract(i)
         out = self.type._c()
         check(getattr(lib, "GrB_Vector_extractElement_" + self.type.__name__)(C.byref(out), self._h, u64(i)), self)
