@@ -100,7 +100,7 @@ for case in range(args.cases):
     nr, nc = rnd.randint(1, 7), rnd.randint(1, 7)
     acc = rnd.choice(list(ACC)); accop = getattr(INT64, acc) if acc else None
     replace = rnd.random() < 0.3
-    kind = rnd.choice(["mextract", "cextract", "vextract", "massign", "rassign", "cassign", "vassign"])
+    kind = rnd.choice(["mextract", "cextract", "vextract", "massign", "rassign", "cassign", "vassign", "hvscalar", "hmscalar"])
     bvals = lambda: rnd.random() < 0.7
     if kind == "mextract":
         t0 = rnd.random() < 0.3
@@ -182,6 +182,42 @@ for case in range(args.cases):
         scope = (lambda p: p[0] == f) if row else (lambda p: p[1] == f)
         exp = finish(c, Z, space, mm, struct, comp, replace, scope)
         assert mdict(C) == exp, (case, kind, f, Jarg, acc, replace, struct, comp, mdict(C), exp)
+    elif kind in ("hvscalar", "hmscalar"):
+        # a scalar assigned into a hypersparse container (2^60 dimensions: host-side bookkeeping, grb_host_ops.cpp host_assign_scalar):
+        # either everywhere under a non-complemented mask (the pattern is bounded by the mask's), or over a short index list
+        IMAX = 1 << 60
+        pool = sorted({rnd.randrange(IMAX) for _ in range(6)} | {0, IMAX - 1})
+        s_val = rnd.randint(-5, 5)
+        if kind == "hvscalar":
+            w = Vector.sparse(INT64, IMAX); wd = {}
+            for p in pool:
+                if rnd.random() < 0.5: x = rnd.randint(-9, 9); w[p] = x; wd[p] = x
+            use_list = rnd.random() < 0.5
+            M = Vector.sparse(BOOL, IMAX); m = {}
+            for p in pool:
+                if rnd.random() < 0.6: x = rnd.random() < 0.7; M[p] = x; m[p] = x
+            struct = rnd.random() < 0.4; comp = use_list and rnd.random() < 0.4
+            idx = rnd.sample(pool, rnd.randint(1, len(pool))) if use_list else None
+            w.assign_scalar(s_val, idx, mask=M, accum=accop, desc=desc_of(replace, struct, comp))
+            region = idx if use_list else [p for p in pool]              # (ALL: only positions the mask allows can change, all of them in the pool)
+            Z = dict(wd)
+            for p in region:
+                Z[p] = ACC[acc](Z[p], s_val) if (acc and p in Z) else s_val
+            exp = finish(wd, Z, pool, m, struct, comp, replace)
+            assert vdict(w) == exp, (case, kind, idx, acc, replace, struct, comp, wd, m, vdict(w), exp)
+        else:
+            C = Matrix.sparse(INT64, IMAX, IMAX); c = {}; M = Matrix.sparse(BOOL, IMAX, IMAX); m = {}
+            cells = [(a, b) for a in pool[:4] for b in pool[-4:]]
+            for p in cells:
+                if rnd.random() < 0.4: x = rnd.randint(-9, 9); C[p] = x; c[p] = x
+                if rnd.random() < 0.5: x = rnd.random() < 0.7; M[p] = x; m[p] = x
+            struct = rnd.random() < 0.4
+            C.assign_scalar(s_val, mask=M, accum=accop, desc=desc_of(replace, struct, False))
+            Z = dict(c)
+            for p in cells:
+                Z[p] = ACC[acc](Z[p], s_val) if (acc and p in Z) else s_val
+            exp = finish(c, Z, cells, m, struct, False, replace)
+            assert mdict(C) == exp, (case, kind, acc, replace, struct, c, m, mdict(C), exp)
     else:   # vassign
         w, wd = rand_vec(nr, 0.5)
         Iarg, I = rand_index(nr, False)
