@@ -294,6 +294,35 @@ GrB_Info GrB_Matrix_assign(GrB_Matrix C, const GrB_Matrix Mask, const GrB_Binary
     const auto ri = indices(I, ni, C->nrows, "assign"), ci = indices(J, nj, C->ncols, "assign");
     const uint64_t ar = dv.tran0 ? A->ncols : A->nrows, ac = dv.tran0 ? A->nrows : A->ncols;
     if (ar != ri.size() || ac != ci.size() || (Mask && (Mask->nrows != C->nrows || Mask->ncols != C->ncols))) fail(GrB_DIMENSION_MISMATCH, "assign: the matrix must be |I| x |J|");
+    if (!Mask && !dv.tran0 && C != A && strictly_increasing(ri) && strictly_increasing(ci) && C->type->code < T_FC32 && A->type->code < T_FC32) {
+      // `M[a:b, c:d] = A` with increasing index lists: A's tuples stay sorted when they move to (I[i], J[j]) — one merge of C's tuples
+      // (without those of the region, unless an accumulator keeps them) with A's
+      if (accum) check_binop(accum, "accum");
+      mat_to_host(C); mat_to_host(A);
+      const size_t cs = C->type->size, as = A->type->size; const int ccode = C->type->code, acode = A->type->code;
+      auto in_region = [&](uint64_t i, uint64_t j) { return std::binary_search(ri.begin(), ri.end(), i) && std::binary_search(ci.begin(), ci.end(), j); };
+      std::vector<GrB_Index> ni2, nj2; std::vector<uint8_t> nx;
+      const size_t nc = C->hi.size(), na = A->hi.size();
+      ni2.reserve(nc + na); nj2.reserve(nc + na); nx.reserve((nc + na) * cs);
+      auto put = [&](uint64_t i, uint64_t j, const Val& v) { ni2.push_back(i); nj2.push_back(j); nx.insert(nx.end(), v.data(), v.data() + cs); };
+      size_t p = 0, q = 0;
+      while (p < nc || q < na) {
+        const uint64_t ai = q < na ? ri[A->hi[q]] : 0, aj = q < na ? ci[A->hj[q]] : 0;
+        const bool take_c = q >= na || (p < nc && (C->hi[p] < ai || (C->hi[p] == ai && C->hj[p] < aj)));
+        if (take_c) {                                                   // an entry of C with no counterpart in A: kept outside the region, and inside it under an accumulator
+          if (accum || !in_region(C->hi[p], C->hj[p])) put(C->hi[p], C->hj[p], val_at(C, p));
+          p++;
+        } else {
+          Val av{}; memcpy(av.data(), &A->hx[q * as], as);
+          const bool both = p < nc && C->hi[p] == ai && C->hj[p] == aj;
+          put(ai, aj, both && accum ? combine(accum, ccode, val_at(C, p), acode, av) : cast(ccode, acode, av));
+          if (both) p++;
+          q++;
+        }
+      }
+      C->hi.swap(ni2); C->hj.swap(nj2); C->hx.swap(nx); C->host_valid = true; mat_invalidate_device(C);
+      return;
+    }
     Map Cm = load(C, false), Am = load(A, dv.tran0), Mm; if (Mask) Mm = load(Mask, false);
     region_update(Cm, C->type->code, Am, A->type->code, ri, ci, accum, MaskView{&Mm, Mask ? Mask->type->code : 0, dv.mask_struct, dv.mask_comp, Mask != nullptr}, dv.replace, true, false, false, 0);
     store(C, Cm);
