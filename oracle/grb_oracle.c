@@ -351,6 +351,20 @@ void fast_spmv_plus_second_fp32_wide(uint32_t nrows, const uint32_t* rp, const u
     }
   }
 }
+/* the same pattern product in FP64 throughout: the reference iteration of the PageRank parity tests (every rank value of the
+ * FP32 loop must lie within 1e-6 of this one, and stop after the same number of iterations) */
+void fast_spmv_plus_second_fp64(uint32_t nrows, const uint32_t* rp, const uint32_t* col, const double* x, double* y, uint8_t* ypres) {
+  const int P = omp_get_max_threads() * 8;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int q = 0; q < P; q++) {
+    uint32_t r0, r1; spmv_piece(rp, nrows, q, P, &r0, &r1);
+    for (uint32_t i = r0; i < r1; i++) {
+      double s = 0.0; const uint32_t b = rp[i], e = rp[i + 1];
+      for (uint32_t p = b; p < e; p++) s += x[col[p]];
+      y[i] = s; ypres[i] = e > b;
+    }
+  }
+}
 /* sum over (i,k) in L, of |L(k,:) ∩ L(i,:)|  ==  reduce(L.mxm(L, PLUS_PAIR, mask=L))  (demo/TriangleCentrality.ipynb cell 17) */
 int64_t fast_tricount_LL_maskL(uint32_t n, const uint32_t* rp, const uint32_t* col) {
   int64_t total = 0;
@@ -385,6 +399,43 @@ int fast_bfs_levels(uint32_t n, const uint32_t* rp, const uint32_t* col, uint32_
   }
   free(q); free(nq); return lev - 1;
 }
+/* single-source shortest paths written exactly as the reference's loop does it (demo/Intro-Prez.ipynb:1034-1045, the doctest
+ * pygraphblas/vector.py:883-885 `with Accum(INT64.min): o @= M`):
+ *     v = sparse; v[src] = 0;  repeat { w = dup(v);  v<accum MIN> = v MIN_PLUS A;  } until w.iseq(v)
+ * one Jacobi sweep per iteration (every product of a sweep reads the distances of the previous one), so the number of
+ * sweeps is the reference's too.  A is CSR u32; the sweep pulls along the transpose (built here by a counting sort), which
+ * needs no atomics: t(j) = min_i v(i) + A(i,j), v(j) = min(v(j), t(j)) on the union of the patterns.
+ * INT64 sums wrap modulo 2^64 like the C operator; FP64 MIN is fmin (omits NaN).  Returns the number of sweeps done
+ * (the last one changed nothing). */
+#define FAST_SSSP(NAME, T, ADD, LESS)                                                                                      \
+int NAME(uint32_t n, const uint32_t* rp, const uint32_t* col, const T* val, uint32_t src, int max_sweeps, T* dist, uint8_t* pres) { \
+  const uint64_t nnz = rp[n];                                                                                              \
+  uint32_t* tp = (uint32_t*)calloc((size_t)n + 2, 4); uint32_t* ti = (uint32_t*)malloc((nnz + 1) * 4); T* tv = (T*)malloc((nnz + 1) * sizeof(T)); \
+  for (uint64_t p = 0; p < nnz; p++) tp[col[p] + 2]++;                                                                     \
+  for (uint32_t j = 0; j < n; j++) tp[j + 2] += tp[j + 1];                                                                 \
+  for (uint32_t i = 0; i < n; i++) for (uint32_t p = rp[i]; p < rp[i + 1]; p++) { const uint32_t q = tp[col[p] + 1]++; ti[q] = i; tv[q] = val[p]; } \
+  T* nd = (T*)malloc((size_t)n * sizeof(T)); uint8_t* np_ = (uint8_t*)malloc(n);                                           \
+  memset(pres, 0, n); memset(dist, 0, (size_t)n * sizeof(T)); pres[src] = 1; dist[src] = 0;                                \
+  int sweeps = 0, changed = 1;                                                                                             \
+  while (changed && sweeps < max_sweeps) {                                                                                 \
+    changed = 0;                                                                                                           \
+    _Pragma("omp parallel for schedule(dynamic, 4096) reduction(| : changed)")                                             \
+    for (int64_t j = 0; j < (int64_t)n; j++) {                                                                             \
+      T best = dist[j]; uint8_t has = pres[j];                                                                             \
+      for (uint32_t q = tp[j]; q < tp[j + 1]; q++) { const uint32_t i = ti[q]; if (!pres[i]) continue;                     \
+        const T c = ADD(dist[i], tv[q]); if (!has) { best = c; has = 1; } else if (LESS(c, best)) best = c; }              \
+      nd[j] = best; np_[j] = has;                                                                                          \
+      if (has != pres[j] || (has && memcmp(&best, &dist[j], sizeof(T)) != 0)) changed = 1;                                 \
+    }                                                                                                                      \
+    memcpy(dist, nd, (size_t)n * sizeof(T)); memcpy(pres, np_, n); sweeps++;                                               \
+  }                                                                                                                        \
+  free(tp); free(ti); free(tv); free(nd); free(np_); return sweeps;                                                        \
+}
+#define SSSP_ADD_I64(a, b) ((int64_t)((uint64_t)(a) + (uint64_t)(b)))
+#define SSSP_ADD_F64(a, b) ((a) + (b))
+#define SSSP_LESS(a, b) ((a) < (b))
+FAST_SSSP(fast_sssp_min_plus_int64, int64_t, SSSP_ADD_I64, SSSP_LESS)
+FAST_SSSP(fast_sssp_min_plus_fp64, double, SSSP_ADD_F64, SSSP_LESS)
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

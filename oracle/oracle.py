@@ -165,6 +165,9 @@ def fast_spmv(rowptr, col, val, x, semiring="PLUS_TIMES"):
     elif semiring == "PLUS_TIMES":
         val, x = _arr(val, np.float32), _arr(x, np.float32); y = np.zeros(n, np.float32)
         L.fast_spmv_plus_times_fp32(C.c_uint32(n), _p(rowptr), _p(col), _p(val), _p(x), _p(y), _p(pres))
+    elif semiring == "PLUS_SECOND" and np.asarray(x).dtype == np.float64:
+        x = _arr(x, np.float64); y = np.zeros(n, np.float64)
+        L.fast_spmv_plus_second_fp64(C.c_uint32(n), _p(rowptr), _p(col), _p(x), _p(y), _p(pres))
     elif semiring == "PLUS_SECOND":
         x = _arr(x, np.float32); y = np.zeros(n, np.float32)
         L.fast_spmv_plus_second_fp32(C.c_uint32(n), _p(rowptr), _p(col), _p(x), _p(y), _p(pres))
@@ -187,6 +190,23 @@ def fast_bfs(rowptr, col, src):
     lev = np.zeros(n, np.uint8)
     depth = lib().fast_bfs_levels(C.c_uint32(n), _p(rowptr), _p(col), C.c_uint32(src), _p(lev))
     return lev, depth
+
+
+def fast_sssp(rowptr, col, val, src, max_sweeps=1 << 30):
+    """The reference's MIN_PLUS shortest-path loop (v.vxm(A, MIN_PLUS, accum=MIN, out=v) until nothing changes) on a CSR with
+    INT64 or FP64 weights: returns (dist, present, sweeps) — `sweeps` counts the products, the last of which changed nothing."""
+    rowptr, col = _arr(rowptr, np.uint32), _arr(col, np.uint32)
+    n = len(rowptr) - 1
+    val = np.ascontiguousarray(val)
+    pres = np.zeros(n, np.uint8)
+    if val.dtype == np.int64:
+        dist = np.zeros(n, np.int64); fn = lib().fast_sssp_min_plus_int64
+    elif val.dtype == np.float64:
+        dist = np.zeros(n, np.float64); fn = lib().fast_sssp_min_plus_fp64
+    else:
+        raise ValueError(val.dtype)
+    sweeps = fn(C.c_uint32(n), _p(rowptr), _p(col), _p(val), C.c_uint32(src), C.c_int(min(max_sweeps, 1 << 30)), _p(dist), _p(pres))
+    return dist, pres, int(sweeps)
 
 
 def num_threads():

@@ -91,6 +91,16 @@ template <class Scope> void write_back(Map& C, int ccode, const Map& T, int tcod
 auto everywhere = [](const std::pair<uint64_t, uint64_t>&) { return true; };
 
 std::vector<uint64_t> indices(const GrB_Index* I, GrB_Index ni, uint64_t dim, const char* what) { return expand_index_list(I, ni, dim, what); }
+// an index list that is never materialised when it is GrB_ALL (the identity map): the default-dimension (2^60) hypersparse
+// containers are sliced with it (`H[1]`, `H[:, 2]`), and a vector of `dim` indices cannot exist there
+struct Sel {
+  bool all = false; uint64_t dim = 0; std::vector<uint64_t> v;
+  Sel(const GrB_Index* I, GrB_Index ni, uint64_t d, const char* what) : all(I == GrB_ALL), dim(d) { if (!all) v = expand_index_list(I, ni, d, what); }
+  uint64_t size() const { return all ? dim : v.size(); }
+  bool increasing() const { if (all) return true; for (size_t k = 1; k < v.size(); k++) if (v[k] <= v[k - 1]) return false; return true; }
+  // position of source index x in an increasing list, or ~0
+  uint64_t find_sorted(uint64_t x) const { if (all) return x < dim ? x : ~0ull; const auto a = std::lower_bound(v.begin(), v.end(), x); return (a == v.end() || *a != x) ? ~0ull : (uint64_t)(a - v.begin()); }
+};
 void check_m(GrB_Matrix A, const char* w) { if (!check_obj(A)) fail(GrB_UNINITIALIZED_OBJECT, std::string(w) + ": uninitialised matrix"); }
 void check_v(GrB_Vector A, const char* w) { if (!check_obj(A)) fail(GrB_UNINITIALIZED_OBJECT, std::string(w) + ": uninitialised vector"); }
 
@@ -158,10 +168,11 @@ GrB_Info GrB_Vector_extract(GrB_Vector w, const GrB_Vector mask, const GrB_Binar
   return guarded(w, [&] {
     check_v(u, "extract"); if (mask) check_v(mask, "extract");
     const DescView dv(desc);
-    const auto idx = indices(I, ni, u->n, "extract");
+    const Sel idx(I, ni, u->n, "extract");
     if (w->n != idx.size() || (mask && mask->n != w->n)) fail(GrB_DIMENSION_MISMATCH, "extract: output size must equal the number of indices");
     Map U = load(u), T, C = load(w), Mm; if (mask) Mm = load(mask);
-    for (size_t k = 0; k < idx.size(); k++) { auto it = U.find({idx[k], 0}); if (it != U.end()) T[{k, 0}] = it->second; }
+    if (idx.all) T = U;
+    else for (size_t k = 0; k < idx.v.size(); k++) { auto it = U.find({idx.v[k], 0}); if (it != U.end()) T[{k, 0}] = it->second; }
     write_back(C, w->type->code, T, u->type->code, MaskView{&Mm, mask ? mask->type->code : 0, dv.mask_struct, dv.mask_comp, mask != nullptr}, dv.replace, accum, everywhere);
     store(w, C);
   });
@@ -174,14 +185,14 @@ GrB_Info GrB_Col_extract(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp
     const DescView dv(desc);
     const uint64_t ar = dv.tran0 ? A->ncols : A->nrows, ac = dv.tran0 ? A->nrows : A->ncols;
     if (j >= ac) fail(GrB_INVALID_INDEX, "extract: column index out of range");
-    const auto idx = indices(I, ni, ar, "extract");
+    const Sel idx(I, ni, ar, "extract");
     if (w->n != idx.size() || (mask && mask->n != w->n)) fail(GrB_DIMENSION_MISMATCH, "extract: output size must equal the number of indices");
     const Line col = line_of(A, dv.tran0, j);                             // (index in op(A)'s column j, value), sorted
     Map T, C = load(w), Mm; if (mask) Mm = load(mask);
-    if (I == GrB_ALL) for (auto& e : col) T[{e.first, 0}] = e.second;
-    else for (size_t k = 0; k < idx.size(); k++) {
-      auto it = std::lower_bound(col.begin(), col.end(), idx[k], [](const std::pair<uint64_t, Val>& e, uint64_t x) { return e.first < x; });
-      if (it != col.end() && it->first == idx[k]) T[{k, 0}] = it->second;
+    if (idx.all) for (auto& e : col) T[{e.first, 0}] = e.second;
+    else for (size_t k = 0; k < idx.v.size(); k++) {
+      auto it = std::lower_bound(col.begin(), col.end(), idx.v[k], [](const std::pair<uint64_t, Val>& e, uint64_t x) { return e.first < x; });
+      if (it != col.end() && it->first == idx.v[k]) T[{k, 0}] = it->second;
     }
     write_back(C, w->type->code, T, A->type->code, MaskView{&Mm, mask ? mask->type->code : 0, dv.mask_struct, dv.mask_comp, mask != nullptr}, dv.replace, accum, everywhere);
     store(w, C);
@@ -195,17 +206,17 @@ GrB_Info GrB_Matrix_extract(GrB_Matrix C, const GrB_Matrix Mask, const GrB_Binar
     check_m(A, "extract"); if (Mask) check_m(Mask, "extract");
     const DescView dv(desc);
     const uint64_t ar = dv.tran0 ? A->ncols : A->nrows, ac = dv.tran0 ? A->nrows : A->ncols;
-    const auto ri = indices(I, ni, ar, "extract"), ci = indices(J, nj, ac, "extract");
+    const Sel ri(I, ni, ar, "extract"), ci(J, nj, ac, "extract");
     if (C->nrows != ri.size() || C->ncols != ci.size() || (Mask && (Mask->nrows != C->nrows || Mask->ncols != C->ncols))) fail(GrB_DIMENSION_MISMATCH, "extract: output shape must be |I| x |J|");
-    if (!Mask && !accum && strictly_increasing(ri) && strictly_increasing(ci)) {       // a slice `A[a:b, c:d]` into a fresh output: one pass over A's tuples
+    if (!Mask && !accum && ri.increasing() && ci.increasing()) {       // a slice `A[a:b, c:d]` into a fresh output: one pass over A's tuples
       mat_to_host(A); const size_t ts = A->type->size; const int acode = A->type->code, ccode = C->type->code;
       struct E { uint64_t i, j; Val v; }; std::vector<E> out;
       for (size_t p = 0; p < A->hi.size(); p++) {
         const uint64_t si = dv.tran0 ? A->hj[p] : A->hi[p], sj = dv.tran0 ? A->hi[p] : A->hj[p];
-        const auto a = std::lower_bound(ri.begin(), ri.end(), si); if (a == ri.end() || *a != si) continue;
-        const auto b = std::lower_bound(ci.begin(), ci.end(), sj); if (b == ci.end() || *b != sj) continue;
+        const uint64_t a = ri.find_sorted(si); if (a == ~0ull) continue;
+        const uint64_t b = ci.find_sorted(sj); if (b == ~0ull) continue;
         Val v{}; memcpy(v.data(), &A->hx[p * ts], ts);
-        out.push_back({(uint64_t)(a - ri.begin()), (uint64_t)(b - ci.begin()), cast(ccode, acode, v)});
+        out.push_back({a, b, cast(ccode, acode, v)});
       }
       if (dv.tran0) std::sort(out.begin(), out.end(), [](const E& x, const E& y) { return x.i != y.i ? x.i < y.i : x.j < y.j; });
       const size_t cs = C->type->size;
@@ -216,12 +227,14 @@ GrB_Info GrB_Matrix_extract(GrB_Matrix C, const GrB_Matrix Mask, const GrB_Binar
       return;
     }
     Map Am = load(A, dv.tran0), T, Cm = load(C, false), Mm; if (Mask) Mm = load(Mask, false);
-    std::multimap<uint64_t, uint64_t> rpos, cpos;                       // source index -> output positions (an index may repeat)
-    for (size_t k = 0; k < ri.size(); k++) rpos.insert({ri[k], k});
-    for (size_t k = 0; k < ci.size(); k++) cpos.insert({ci[k], k});
+    std::multimap<uint64_t, uint64_t> rpos, cpos;                       // source index -> output positions (an index may repeat; GrB_ALL is the identity and is not listed)
+    if (!ri.all) for (size_t k = 0; k < ri.v.size(); k++) rpos.insert({ri.v[k], k});
+    if (!ci.all) for (size_t k = 0; k < ci.v.size(); k++) cpos.insert({ci.v[k], k});
     for (auto& kv : Am) {
-      auto rr = rpos.equal_range(kv.first.first); auto cc = cpos.equal_range(kv.first.second);
-      for (auto a = rr.first; a != rr.second; ++a) for (auto b = cc.first; b != cc.second; ++b) T[{a->second, b->second}] = kv.second;
+      std::vector<uint64_t> ra, ca;
+      if (ri.all) ra.push_back(kv.first.first); else { auto rr = rpos.equal_range(kv.first.first); for (auto a = rr.first; a != rr.second; ++a) ra.push_back(a->second); }
+      if (ci.all) ca.push_back(kv.first.second); else { auto cc = cpos.equal_range(kv.first.second); for (auto b = cc.first; b != cc.second; ++b) ca.push_back(b->second); }
+      for (uint64_t a : ra) for (uint64_t b : ca) T[{a, b}] = kv.second;
     }
     write_back(Cm, C->type->code, T, A->type->code, MaskView{&Mm, Mask ? Mask->type->code : 0, dv.mask_struct, dv.mask_comp, Mask != nullptr}, dv.replace, accum, everywhere);
     store(C, Cm);
@@ -335,15 +348,15 @@ GrB_Info GrB_Row_assign(GrB_Matrix C, const GrB_Vector mask, const GrB_BinaryOp 
     check_v(u, "assign"); if (mask) check_v(mask, "assign");
     const DescView dv(desc);
     if (i >= C->nrows) fail(GrB_INVALID_INDEX, "assign: row index out of range");
-    const auto ci = indices(J, nj, C->ncols, "assign");
-    if (u->n != ci.size() || (mask && mask->n != C->ncols)) fail(GrB_DIMENSION_MISMATCH, "assign: the vector's size must equal the number of column indices");
-    if (!mask && J == GrB_ALL && C->type->code < T_FC32 && u->type->code < T_FC32) {   // `M[i] = v`: the row's run of tuples is replaced in place
+    if (!mask && J == GrB_ALL && u->n == C->ncols && C->type->code < T_FC32 && u->type->code < T_FC32) {   // `M[i] = v`: the row's run of tuples is replaced in place (GrB_ALL is never listed: C may be 2^60 wide)
       mat_to_host(C);
       const auto r = row_range(C, i); Line cur; cur.reserve(r.second - r.first);
       for (size_t p = r.first; p < r.second; p++) cur.push_back({C->hj[p], val_at(C, p)});
       replace_line(C, true, i, assigned_line(cur, C->type->code, u, accum));
       return;
     }
+    const auto ci = indices(J, nj, C->ncols, "assign");
+    if (u->n != ci.size() || (mask && mask->n != C->ncols)) fail(GrB_DIMENSION_MISMATCH, "assign: the vector's size must equal the number of column indices");
     Map Cm = load(C, false), U = load(u), Ut, Mm; if (mask) Mm = load(mask);
     for (auto& kv : U) Ut[{0, kv.first.first}] = kv.second;             // the vector as a 1 x nj row
     region_update(Cm, C->type->code, Ut, u->type->code, std::vector<uint64_t>{i}, ci, accum, MaskView{&Mm, mask ? mask->type->code : 0, dv.mask_struct, dv.mask_comp, mask != nullptr}, dv.replace,
@@ -358,12 +371,12 @@ GrB_Info GrB_Col_assign(GrB_Matrix C, const GrB_Vector mask, const GrB_BinaryOp 
     check_v(u, "assign"); if (mask) check_v(mask, "assign");
     const DescView dv(desc);
     if (j >= C->ncols) fail(GrB_INVALID_INDEX, "assign: column index out of range");
-    const auto ri = indices(I, ni, C->nrows, "assign");
-    if (u->n != ri.size() || (mask && mask->n != C->nrows)) fail(GrB_DIMENSION_MISMATCH, "assign: the vector's size must equal the number of row indices");
-    if (!mask && I == GrB_ALL && C->type->code < T_FC32 && u->type->code < T_FC32) {   // `M[:, j] = v`: one merge pass over the tuples
+    if (!mask && I == GrB_ALL && u->n == C->nrows && C->type->code < T_FC32 && u->type->code < T_FC32) {   // `M[:, j] = v`: one merge pass over the tuples (GrB_ALL is never listed)
       replace_line(C, false, j, assigned_line(line_of(C, false, j), C->type->code, u, accum));
       return;
     }
+    const auto ri = indices(I, ni, C->nrows, "assign");
+    if (u->n != ri.size() || (mask && mask->n != C->nrows)) fail(GrB_DIMENSION_MISMATCH, "assign: the vector's size must equal the number of row indices");
     Map Cm = load(C, false), U = load(u), Mm; if (mask) Mm = load(mask);
     region_update(Cm, C->type->code, U, u->type->code, ri, std::vector<uint64_t>{j}, accum, MaskView{&Mm, mask ? mask->type->code : 0, dv.mask_struct, dv.mask_comp, mask != nullptr}, dv.replace,
                   false, false, true, j);

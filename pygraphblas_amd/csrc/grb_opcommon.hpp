@@ -37,12 +37,17 @@ inline SemiringDesc make_semiring_desc(GrB_Semiring s, bool swap_mult_args) {
 constexpr uint64_t GXB_RANGE = 0x7FFFFFFFFFFFFFFFull, GXB_STRIDE = GXB_RANGE - 1, GXB_BACKWARDS = GXB_RANGE - 2;
 inline std::vector<uint64_t> expand_index_list(const GrB_Index* I, GrB_Index ni, uint64_t dim, const char* what) {
   std::vector<uint64_t> out;
-  if (I == GrB_ALL) { out.resize(dim); for (uint64_t i = 0; i < dim; i++) out[i] = i; return out; }
+  // an explicit list of positions is only ever built for lists that fit in memory: GrB_ALL or an open-ended range over a
+  // hypersparse dimension (2^60) is refused with an error instead of an allocation failure
+  constexpr uint64_t LIST_MAX = 1ull << 28;
+  auto too_many = [&](uint64_t k) { fail(GrB_INSUFFICIENT_SPACE, std::string(what) + ": an index list of " + std::to_string(k) + " positions (more than 2^28) is not materialised; slice hypersparse containers with explicit indices"); };
+  if (I == GrB_ALL) { if (dim > LIST_MAX) too_many(dim); out.resize(dim); for (uint64_t i = 0; i < dim; i++) out[i] = i; return out; }
   if (!I) fail(GrB_NULL_POINTER, std::string(what) + ": index list is NULL");
   auto oob = [&]() { fail(GrB_INDEX_OUT_OF_BOUNDS, std::string(what) + ": index out of bounds"); };
   if (ni == GXB_RANGE || ni == GXB_STRIDE || ni == GXB_BACKWARDS) {
     const uint64_t b = I[0], e = I[1], st = ni == GXB_RANGE ? 1 : I[2];
     if (st == 0) return out;
+    { const uint64_t lo = ni == GXB_BACKWARDS ? e : b, hi = ni == GXB_BACKWARDS ? b : e; if (hi >= lo && (hi - lo) / st >= LIST_MAX) too_many((hi - lo) / st + 1); }
     if (ni == GXB_BACKWARDS) { if (b >= dim && b >= e) oob(); for (uint64_t i = b; i + 1 > e; i -= st) { if (i >= dim) oob(); out.push_back(i); if (i < st) break; } }
     else for (uint64_t i = b; i <= e; i += st) { if (i >= dim) oob(); out.push_back(i); }
     return out;

@@ -163,6 +163,14 @@ template <class W> __global__ void k_hash_gather(const W* __restrict__ in, const
   for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) out[i] = in[perm[i]];
 }
 
+// 64-bit sum of the rows' entry counts: the 32-bit row pointers of the result must not wrap (A@A on a power-law graph can exceed 2^32 entries)
+static __global__ void k_hash_total(const uint32_t* __restrict__ rownnz, uint32_t nrows, unsigned long long* __restrict__ total) {
+  unsigned long long s = 0;
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < nrows; i += gridDim.x * 256ull) s += rownnz[i];
+  for (int o = 32; o; o >>= 1) s += __shfl_down(s, o);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(total, s);
+}
+
 template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc& d, DevCSR& out) {
   typedef typename acc_word<T>::type W;
   const DevCSR& A = *c.A; const DevCSR& B = *c.B;
@@ -202,10 +210,12 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
       exclusive_scan_u32(rownnz.as<uint32_t>(), out.rowptr.as<uint32_t>(), (uint64_t)nrows + 1);
       GRB_HIP(hipMemsetAsync(counts.p, 0, 64, stream()));
       hipLaunchKernelGGL(k_hash_bin, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, (const unsigned long long*)nullptr, rownnz.as<uint32_t>(), 128ull, 1024ull, 4096ull, counts.as<uint32_t>(), lists.as<uint32_t>());
-      uint32_t total = 0;
-      GRB_HIP(hipMemcpyAsync(&total, out.rowptr.as<uint32_t>() + nrows, 4, hipMemcpyDeviceToHost, stream()));
-      GRB_HIP(hipMemcpyAsync(hn, counts.p, 16, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));   // (also: the bitmaps of the symbolic pass are idle now)
-      out.nnz = total;
+      hipLaunchKernelGGL(k_hash_total, dim3(grid_n(nrows)), dim3(256), 0, stream(), rownnz.as<uint32_t>(), nrows, (unsigned long long*)(counts.as<uint8_t>() + 32));
+      uint64_t hc[5] = {0, 0, 0, 0, 0};                                // four bin counts (u32 x 4) | - | the 64-bit total at byte 32
+      GRB_HIP(hipMemcpyAsync(hc, counts.p, 40, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));   // (also: the bitmaps of the symbolic pass are idle now)
+      memcpy(hn, hc, 16);
+      if (hc[4] > 0xFFFFFFF0ull) fail(GrB_INSUFFICIENT_SPACE, "mxm: the result holds " + std::to_string(hc[4]) + " entries; the device layout's 32-bit offsets hold < 2^32");
+      out.nnz = hc[4];
     }
     const uint64_t total = out.nnz;
     out.col.alloc(total * 4 + 8); out.val.alloc(total * sizeof(T) + 8);

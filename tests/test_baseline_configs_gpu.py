@@ -6,7 +6,9 @@ against the oracle (oracle/grb_oracle.c) — and scipy as a second opinion where
   configs[2]  R-MAT scale-22 BOOL LOR_LAND BFS, the reference's loop                  (demo/Introduction-to-GraphBLAS-with-Python.ipynb:4301-4313)
   configs[3]  triangle count L.mxm(L, PLUS_PAIR, mask=L).reduce_int() on R-MAT-22     (demo/TriangleCentrality.ipynb:1446-1449)
   configs[4]  one FP32 PageRank step (PLUS_SECOND, T0, accum PLUS) on R-MAT-22        (gap/prmark.py:17-29); the BOOL-pattern
-              matrix of the reference's driver (gap/prmark.py:47 `.pattern()`) with an FP32 semiring at nnz >= 2^22
+              matrix of the reference's driver (gap/prmark.py:47 `.pattern()`) with an FP32 semiring at nnz >= 2^22;
+              and the step + the whole loop at the STATED scale-25 on one GPU
+  MIN_PLUS    the reference's shortest-path loop (repeated vxm, accum MIN) on R-MAT-22, INT64 and FP64 weights
 Tolerances: bit-exact for BOOL / integer results, 1e-6 relative for FP64 / FP32 (BASELINE.json north_star).
 The scale-22 graphs are generated in HBM by pygraphblas_amd.rmat (counter-based R-MAT) and the oracle's typed
 OpenMP loops run on the same CSR arrays; every case finishes in seconds.
@@ -190,6 +192,107 @@ def test_config4_rmat22_pagerank_loop_with_dangling_vertices(gb, torch_dev):
             break
     assert its == k
     assert np.allclose(gr, rr, rtol=1e-6, atol=0.0)
+
+
+# ---- configs[4] at its STATED size: R-MAT scale-25 on one MI355X ------------------------------------------------------------
+def test_config4_rmat25_pagerank_single_gpu(gb, torch_dev):
+    """FP32 PageRank of gap/prmark.py:8-30 on R-MAT scale-25 (n = 33 554 432, 16·2^25 sampled edges) held by ONE MI355X — the
+    single-GPU anchor of configs[4]'s 1→8 curve.  (a) one product r<accum PLUS> += A' (PLUS_SECOND) w with desc T0 against the
+    oracle's loop with double row sums (1e-6); (b) the whole loop against the same iteration carried in FP64 on the host
+    (oracle fast_spmv PLUS_SECOND on doubles): same number of iterations, every rank value within 1e-6."""
+    torch, dev = torch_dev
+    from pygraphblas_amd import rmat, loops, descriptor as D
+    S = 25
+    n = 1 << S
+    rowptr, col = rmat.csr_torch(S, dev, seed=42)                                        # A
+    nnz = int(col.numel())
+    assert nnz > 5 * 10**8
+    ones = torch.ones(nnz, dtype=torch.float32, device=dev)
+    A = gb.Matrix.from_csr(gb.FP32, n, n, rowptr.data_ptr(), col.data_ptr(), (ones.data_ptr(), nnz), device=True)
+    deg_t = (rowptr[1:] - rowptr[:-1])
+    deg = deg_t.cpu().numpy().astype(np.float64)                                         # out-degrees = row lengths of A
+    del rowptr, col, ones, deg_t
+    torch.cuda.empty_cache()
+    trp, tcol = rmat.csr_torch(S, dev, seed=42, transpose=True)                          # rows of A' for the host-side oracle
+    assert int(tcol.numel()) == nnz
+    rp = trp.cpu().numpy().view(np.uint32); ci = tcol.cpu().numpy().view(np.uint32)
+    del trp, tcol
+    torch.cuda.empty_cache()
+    # (a) one step
+    ws = rmat.values_torch(n, dev, seed=45, dtype=torch.float32)
+    w = gb.Vector.from_dense_array((ws.data_ptr(), n), gb.FP32, device=True)
+    teleport = np.float32(0.15 / n)
+    r = gb.Vector.dense(gb.FP32, n, fill=float(teleport))
+    A.mxv(w, out=r, accum=gb.FP32.PLUS, semiring=gb.FP32.PLUS_SECOND, desc=D.T0)
+    plan = gb.last_kernel_plan()
+    assert "k_spmv_xcd" in plan or "k_spmv_wavepipe" in plan, plan                      # a full-operand pipeline kernel, not the row-block fallback
+    gr, gp = r.to_dense_arrays()
+    assert gp.all()
+    y, pres = O.fast_spmv(rp, ci, None, ws.cpu().numpy(), semiring="PLUS_SECOND_WIDE")
+    exp = np.where(pres != 0, teleport + y, teleport).astype(np.float32)
+    assert np.allclose(gr, exp, rtol=1e-6, atol=0.0)
+    del w, r, ws, gr, gp, y, exp
+    # (b) the loop
+    assert (deg == 0).sum() > n // 4
+    d = gb.Vector.from_dense_array(deg.astype(np.float32), gb.FP32, present=(deg > 0).astype(np.uint8))
+    r, its, rdiff = loops.pagerank(A, d)
+    gr, gp = r.to_dense_arrays()
+    assert gp.all()
+    dd = np.where(deg > 0, deg / 0.85, 1.0); rr = np.full(n, 1.0 / n); tt = np.zeros(n); k = 0
+    for i in range(100):
+        tt, rr = rr, tt
+        wv = np.where(deg > 0, tt / dd, 0.0)
+        yy, _ = O.fast_spmv(rp, ci, None, wv, semiring="PLUS_SECOND")
+        rr = (1 - 0.85) / n + yy
+        k = i + 1
+        if np.abs(tt - rr).sum() <= 1e-4:
+            break
+    assert its == k
+    assert np.allclose(gr, rr, rtol=1e-6, atol=0.0)
+
+
+# ---- MIN_PLUS at scale: the reference's shortest-path loop on R-MAT-22 ------------------------------------------------------
+@pytest.mark.parametrize("wtype", ["INT64", "FP64"])
+def test_min_plus_sssp_rmat22(gb, torch_dev, wtype):
+    """`v<accum MIN> = v MIN_PLUS A` repeated until nothing changes (demo/Intro-Prez.ipynb:1034-1045, pygraphblas/vector.py:883-885)
+    on the directed R-MAT-22 with INT64 weights in [1, 255] / FP64 weights in (0, 1]: distances bit-exact (INT64) / 1e-6 (FP64)
+    against the oracle's loop — sweep count included — and against scipy.sparse.csgraph.dijkstra; the first sweeps must run the
+    push kernel (a one-entry operand), the late ones a pull kernel (the operand holds a third of the vertices)."""
+    torch, dev = torch_dev
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import dijkstra
+    from pygraphblas_amd import rmat, loops
+    n = 1 << SCALE
+    rowptr, col = rmat.csr_torch(SCALE, dev, seed=42, drop_self_loops=True)
+    nnz = int(col.numel())
+    u = rmat.values_torch(nnz, dev, seed=47)
+    if wtype == "INT64":
+        vals = (u * 255.0).to(torch.int64) + 1
+    else:
+        vals = 1.0 - u                                                                   # (0, 1]
+    A = gb.Matrix.from_csr(TYPE[wtype], n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+    src = int(torch.argmax(rowptr[1:] - rowptr[:-1]))
+    plans = []
+    v, sweeps = loops.sssp(A, src, plans=plans)
+    gd, gp = v.to_dense_arrays()
+    rp = rowptr.cpu().numpy().view(np.uint32); ci = col.cpu().numpy().view(np.uint32); hv = vals.cpu().numpy()
+    dist, pres, osweeps = O.fast_sssp(rp, ci, hv, src)
+    assert sweeps == osweeps
+    assert np.array_equal(gp != 0, pres != 0)
+    assert int(pres.sum()) > n // 4
+    if wtype == "INT64":
+        assert np.array_equal(gd[pres != 0], dist[pres != 0])                            # bit-exact
+    else:
+        assert np.allclose(gd[pres != 0], dist[pres != 0], rtol=1e-6, atol=0.0)
+    assert plans[0] == "k_spmspv_push", plans
+    assert plans[-1].startswith("k_spmv_"), plans
+    G = sp.csr_matrix((hv.astype(np.float64), ci.astype(np.int32), rp.astype(np.int64)), shape=(n, n))
+    dj = dijkstra(G, directed=True, indices=src)
+    assert np.array_equal(np.isfinite(dj), pres != 0)
+    if wtype == "INT64":
+        assert np.array_equal(dj[pres != 0].astype(np.int64), gd[pres != 0])
+    else:
+        assert np.allclose(gd[pres != 0], dj[pres != 0], rtol=1e-6, atol=0.0)
 
 
 def test_holes_filled_with_the_identity_only_when_the_pattern_cannot_matter(gb, gpu):

@@ -302,3 +302,21 @@ def test_mirror_slicing_surface_runs_on_the_host_mirror(gb):
     assert Dm.vector_diag(-1).to_lists() == [[0, 2], [3, 4]] and Dm.vector_diag(2).size == 2 and Dm.vector_diag(9).size == 0
     K = gb.Matrix.from_lists([0, 1], [1, 0], [2, 3], 2, 2, gb.INT64).kronecker(gb.Matrix.from_lists([0], [1], [5], 1, 2, gb.INT64), gb.INT64.TIMES)
     assert K.shape == (2, 4) and sorted(K) == [(0, 3, 10), (1, 1, 15)]
+
+
+def test_grb_all_is_never_materialised_on_hypersparse_containers(gb):
+    """`H[1]` / `H[:, 2]` on a default-dimension (2^60) matrix expanded GrB_ALL into a vector of 2^60 indices
+    (Panic from the allocator).  GrB_ALL is the identity map now, and a list that cannot exist is refused with an error."""
+    H = gb.Matrix.sparse(gb.INT64)
+    H[1, 2] = 3
+    H[5, 2] = 7
+    assert H[1].to_lists() == [[2], [3]]
+    assert H[:, 2].to_lists() == [[1, 5], [3, 7]]
+    v = gb.Vector.sparse(gb.INT64)
+    v[4] = 9
+    H[7] = v                                  # GrB_Row_assign over GrB_ALL
+    assert H[7].to_lists() == [[4], [9]]
+    H[:, 11] = v                              # GrB_Col_assign over GrB_ALL
+    assert H[:, 11].to_lists() == [[4], [9]]
+    w = v.extract(slice(None))                # GrB_Vector_extract over GrB_ALL
+    assert w.to_lists() == [[4], [9]]

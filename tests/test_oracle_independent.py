@@ -157,3 +157,36 @@ def test_fast_spmv_matches_generic():
     assert np.allclose(y, A @ x)
     y32, _ = O.fast_spmv(rp, col, None, x.astype(np.float32), "PLUS_SECOND")
     assert np.allclose(y32, sp.csr_matrix((np.ones(len(col), np.float32), col.astype(np.int64), rp.astype(np.int64)), shape=(n, n)) @ x.astype(np.float32), rtol=1e-5)
+
+
+@pytest.mark.parametrize("wtype", ["INT64", "FP64"])
+def test_sssp_fast_path_matches_generic_and_scipy(wtype):
+    """`fast_sssp` = the reference's MIN_PLUS loop (demo/Intro-Prez.ipynb:1034-1045; vector.py:883-885): against the same loop
+    through the generic restatement (sweep count included) and against scipy.sparse.csgraph's Bellman-Ford / Dijkstra."""
+    from scipy.sparse.csgraph import bellman_ford, dijkstra
+    rng = np.random.default_rng(9)
+    rp, col = rmat.csr_numpy(9, drop_self_loops=True)
+    n = 1 << 9
+    nnz = len(col)
+    val = rng.integers(1, 256, nnz).astype(np.int64) if wtype == "INT64" else (rng.random(nnz) + 1e-3)
+    src = int(np.argmax(np.diff(rp.astype(np.int64))))
+    dist, pres, sweeps = O.fast_sssp(rp, col, val, src)
+    G = sp.csr_matrix((val.astype(np.float64), col.astype(np.int64), rp.astype(np.int64)), shape=(n, n))
+    for algo in (bellman_ford, dijkstra):
+        d = algo(G, directed=True, indices=src)
+        assert np.array_equal(np.isfinite(d), pres != 0)
+        if wtype == "INT64":
+            assert np.array_equal(d[pres != 0].astype(np.int64), dist[pres != 0])
+        else:
+            assert np.allclose(d[pres != 0], dist[pres != 0], rtol=1e-12, atol=0.0)
+    rows = np.repeat(np.arange(n, dtype=np.uint64), np.diff(rp.astype(np.int64)))
+    At = O.Tuples(wtype, n, n, rows, col, val)
+    v = O.row_vector(wtype, n, [src], [0]); k = 0
+    while True:
+        w = v
+        v = O.vxm(v, v, At, "MIN", "PLUS", wtype, accum="MIN")
+        k += 1
+        if np.array_equal(w.J, v.J) and np.array_equal(w.X, v.X):
+            break
+    assert k == sweeps
+    assert np.array_equal(np.flatnonzero(pres), v.J.astype(int)) and np.array_equal(dist[pres != 0], v.X)
