@@ -8,19 +8,23 @@ GrB_mxv / GrB_mxm hot path on synthetic R-MAT.
 A "step" is one pass of the hot path over one batch of synthetic input: one FP64 PLUS_TIMES `A.mxv(x)` (GrB_mxv through
 the C ABI) with every operand already resident in HBM — `value`, `ms_per_step` and `roofline` are about that step.
   N = 1 : BASELINE.json configs[1] — R-MAT scale-22 (n = 4 194 304, 16·2^22 sampled edges).
-  N > 1 : weak scaling — R-MAT scale 22+log2(N) row-partitioned into N entry-balanced blocks (N = 8 is the scale-25
-          partition of configs[4]); each step the ranks' slices of x are exchanged by the library's allgatherv (RCCL
-          send/recv over xGMI on its own stream, pygraphblas_amd/csrc/grb_dist.cpp) while the diagonal block of the row
-          block is multiplied, then the off-diagonal block.  value = 2·(entries of all ranks)·K / max-over-ranks time.
-Beside the step the JSON line carries:
-  spmv_extra   what the plan of the SpMV kernel costs (plan_build_ms: a matrix of the same size built second in the process;
-               ..._first_in_process also pays the one-time code-object loads), the rate without a plan (row-block
-               kernel A) and the rate on a label-permuted R-MAT-22 (Graph500 permutes; BASELINE's recipe does not) [N = 1]
-  mxm          configs[3]: triangle count L.mxm(L, PLUS_PAIR, mask=L).reduce_int() on R-MAT-22, GFLOP/s, algorithmic
-               GB/s and fraction of the roofline, bit-exact parity with the oracle                           [N = 1]
-  bfs          configs[2]: the reference's BOOL LOR_LAND BFS loop on R-MAT-22, GTEPS, bit-exact level vector [N = 1]
-  pagerank     configs[4]: the FP32 PageRank loop of gap/prmark.py (PLUS_SECOND, accum, 5 vector ops, 1 all-reduce per
-               iteration) on the same partition — ms per iteration and aggregate GFLOP/s                     [every N]
+  N > 1 : `--scaling weak` (default): R-MAT scale 22+log2(N) row-partitioned into N entry-balanced blocks (N = 8 is the
+          scale-25 partition of configs[4]); `--scaling strong`: the fixed R-MAT-`--scale` graph over N ranks.  Each step the
+          ranks' slices of x are exchanged by the library's allgatherv (RCCL send/recv over xGMI on its own stream,
+          pygraphblas_amd/csrc/grb_dist.cpp) while the diagonal block of the row block is multiplied, then the off-diagonal
+          block.  value = 2·(entries of all ranks)·K / max-over-ranks time.  The other mode's SpMV is reported beside it
+          (`spmv_strong` / `spmv_weak`) with per-phase times (exchange, diagonal block, off-diagonal block).
+The timed region is run `--blocks` times (default 5), each block EXACTLY K steps between barrier + synchronize; the line
+reports the median block (`ms_per_step_blocks` lists all of them).
+Beside the step the JSON line carries, every one with its own `roofline`:
+  spmv_extra        what the plan of the SpMV kernel costs, the rate without a plan, the rate on permuted labels   [N = 1]
+  mxm               configs[3]: triangle count L.mxm(L, PLUS_PAIR, mask=L).reduce_int() on R-MAT-22, bit-exact; for N > 1
+                    the rows of L and of the mask in flop-balanced blocks, L replicated, INT64 all-reduce          [every N]
+  bfs               configs[2]: the reference's BOOL LOR_LAND BFS loop on R-MAT-22, bit-exact level vector; for N > 1 the
+                    frontier is gathered as bits                                                                   [every N]
+  pagerank          configs[4]'s loop (gap/prmark.py, FP32 PLUS_SECOND) on the step's partition                    [every N]
+  pagerank_scale25  configs[4] at its stated size: R-MAT scale-25 on one GPU / over the N ranks                    [every N]
+  sssp              the reference's MIN_PLUS shortest-path loop on R-MAT-22, INT64 weights, bit-exact              [N = 1]
 Rank 0 prints ONE JSON line; see DESIGN.md §6 for how `roofline` and `cpu_baseline` are measured.
 """
 import argparse
@@ -33,15 +37,42 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK = 8000.0          # GB/s, MI355X HBM3E (spec); 6290 GB/s is the measured copy rate of /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def roof(alg_bytes, seconds, **extra):
+    a = alg_bytes / seconds / 1e9
+    r = {"bound": "hbm", "achieved": round(a, 1), "peak": PEAK, "unit": "GB/s", "frac": round(a / PEAK, 4), "algorithmic_bytes": int(alg_bytes),
+         "frac_of_measured_copy_peak_6290": round(a / 6290.0, 4)}
+    r.update(extra)
+    return r
+
+
+def static_traffic(name):
+    """HBM-side bytes per launch from the PMC passes of an earlier, separate run of the same workload (profiles/*.json)."""
+    f = os.path.join(ROOT, "profiles", name)
+    try:
+        d = json.load(open(f))
+        return d.get("hbm_bytes_per_launch"), f"profiles/{name} (static: rocprofv3 --pmc passes of this workload in their own runs, {d.get('collected_with', 'tools/pmc_*.sh')}; not measured in this run)"
+    except Exception:       # noqa: BLE001
+        return None, None
+
+
+class Ctx:
+    pass
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--scale", type=int, default=22, help="R-MAT scale per GPU (22 = the BASELINE config)")
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of exactly --steps steps; the median block is reported")
+    ap.add_argument("--scale", type=int, default=22, help="R-MAT scale (22 = the BASELINE config): per GPU for weak scaling, of the whole graph for strong")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="what the headline step does for N > 1")
+    ap.add_argument("--pr-scale", type=int, default=25, help="scale of the pagerank_scale25 sub-object (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="only the timed step (no mxm / bfs / pagerank / plan-cost sub-objects)")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed step (no sub-objects)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -68,7 +99,7 @@ def main():
         tdist.init_process_group("gloo", rank=rank, world_size=world)
 
     import pygraphblas_amd as gb
-    from pygraphblas_amd import rmat
+    from pygraphblas_amd import rmat, loops
     from pygraphblas_amd import dist as gdist
     lib = gb.lib
     info = gb.device_info()
@@ -101,9 +132,15 @@ def main():
                 pass
             print(f"bench.py[{rank}]: RCCL data path unavailable ({why or 'another rank failed'}); falling back to host transport", file=sys.stderr)
             comm = gdist.Comm(rank, world, transport="host", share=share, tdist=tdist)
-            transport_note = "host copies over gloo (RCCL set-up failed on some rank; NOT the designed data path)"
+            transport_note = "host copies over gloo (RCCL set-up failed on some rank; NOT the designed data path: read this line as UNMEASURED)"
     else:
         comm = gdist.Comm(rank, world, transport=transport, share=share, tdist=tdist if world > 1 else None)
+        if world > 1 and transport == "host":
+            transport_note = "host copies over gloo (test transport: NOT the designed data path)"
+
+    cx = Ctx()
+    cx.gb, cx.rmat, cx.loops, cx.gdist, cx.torch, cx.np, cx.lib, cx.dev, cx.comm = gb, rmat, loops, gdist, torch, np, lib, dev, comm
+    cx.rank, cx.world, cx.tdist, cx.args = rank, world, tdist, args
 
     def barrier():
         if world > 1:
@@ -119,105 +156,40 @@ def main():
         if world == 1:
             return x
         t = torch.tensor([x], dtype=torch.float64); tdist.all_reduce(t, op=tdist.ReduceOp.SUM); return float(t[0])
+    cx.barrier, cx.max_over_ranks, cx.sum_over_ranks = barrier, max_over_ranks, sum_over_ranks
 
-    def plan_ms():
-        ms = C.c_float(0); lib.GrBX_last_plan_build_ms(C.byref(ms)); return round(ms.value, 2)
-
-    # ---- synthetic workload, generated in HBM -----------------------------------------------------
     log2w = world.bit_length() - 1
     assert 1 << log2w == world, "--gpus must be a power of two"
-    scale = args.scale + log2w
-    n = 1 << scale
-    if world > 1:
-        bounds = gdist.balanced_row_blocks(gdist.rmat_expected_row_prefix(scale), world)
-    else:
-        bounds = [0, n]
-    r0, r1 = bounds[rank], bounds[rank + 1]
-    t_gen = time.time()
-    rowptr, col = rmat.csr_torch(scale, dev, seed=42, row_range=(r0, r1) if world > 1 else None)
-    nnz = int(col.numel())
-    vals = rmat.values_torch(nnz, dev, seed=43 + rank)
-    x_all = rmat.values_torch(n, dev, seed=44)
-    torch.cuda.synchronize()
-    t_gen = time.time() - t_gen
-    mats = []
-    if world > 1:       # diagonal block (the columns this rank owns) and the rest: the first needs no remote data
-        for rp_, c_, v_ in gdist.split_csr_columns(rowptr, col, r0, r1, vals):
-            mats.append(gb.Matrix.from_csr(gb.FP64, r1 - r0, n, rp_.data_ptr(), c_.data_ptr(), (v_.data_ptr(), int(c_.numel())), device=True))
-        del rp_, c_, v_
-    else:
-        mats.append(gb.Matrix.from_csr(gb.FP64, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True))
-    A = mats[0]
-    x = gb.Vector.from_dense_array((x_all.data_ptr(), n), gb.FP64, device=True)           # the full operand (every slice valid at the start)
-    x_mine = gb.Vector.from_dense_array((x_all[r0:r1].contiguous().data_ptr(), r1 - r0), gb.FP64, device=True)
-    w = gb.Vector.sparse(gb.FP64, r1 - r0)
-    del rowptr, col, vals, x_all
-    torch.cuda.empty_cache()
-    sr = gb.FP64.PLUS_TIMES
-
-    def step():
-        if world > 1:
-            comm.allgatherv_start(x, x_mine, bounds)              # remote slices of x -> the HBM buffer the kernel gathers from
-            mats[0].mxv(x, semiring=sr, out=w)                    # diagonal block: local columns only
-            comm.wait()
-            mats[1].mxv(x, semiring=sr, out=w, accum=gb.FP64.PLUS)
-        else:
-            A.mxv(x, semiring=sr, out=w)
-
-    step()
-    plan_build_ms = plan_ms()                                     # the first product built the plan of kernel X (of the last matrix multiplied)
-    for _ in range(max(0, args.warmup - 1)):
-        step()
-    plan = gb.last_kernel_plan()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
-    nnz_total = int(sum_over_ranks(float(nnz)))
-    ms_per_step = elapsed / args.steps * 1e3
-    gflops = 2.0 * nnz_total * args.steps / elapsed / 1e9
-
-    # ---- roofline of the dominant kernel: HIP events on the library's stream around K launches -------
-    # algorithmic bytes per launch: nnz*(8+4) + (nrows+1)*4 + ncols*8 + nrows*8
-    alg_bytes = nnz * 12 + (r1 - r0 + 1) * 4 + n * 8 + (r1 - r0) * 8
-    torch.cuda.synchronize()
-    lib.GrBX_timer_start()
-    for _ in range(args.steps):
-        step()
-    ms = C.c_float(0)
-    lib.GrBX_timer_stop(C.byref(ms))
-    kernel_ms = ms.value / args.steps
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    traffic, traffic_source = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "spmv_pmc_traffic.json")
-    if os.path.exists(pmc_file) and world == 1 and args.scale == 22:     # the PMC passes were collected on this exact workload, in their own runs
-        try:
-            traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
-            traffic_source = "profiles/spmv_pmc_traffic.json (static: rocprofv3 --pmc passes of this workload, tools/pmc_spmv.sh; not measured in this run)"
-        except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
-                "traffic": traffic, "traffic_source": traffic_source, "kernel": plan, "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": alg_bytes,
-                "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4)}
-
+    weak_scale, strong_scale = args.scale + log2w, args.scale
+    head_scale = weak_scale if (args.scaling == "weak" or world == 1) else strong_scale
+    head = SpmvJob(cx, head_scale)
+    res = head.run(args.steps, args.warmup, args.blocks)
+    n, nnz_total = head.n, res["nnz_total"]
+    traffic, traffic_source = (None, None)
+    if world == 1 and head_scale == 22:       # the PMC passes were collected on this exact workload, in their own runs
+        traffic, traffic_source = static_traffic("spmv_pmc_traffic.json")
+    roofline = roof(res["alg_bytes"], res["kernel_ms"] * 1e-3, traffic=traffic, traffic_source=traffic_source, kernel=res["plan"], kernel_ms=round(res["kernel_ms"], 4))
     out = {
         "metric": "GFLOPS + GB/s (vs roofline) for mxv/mxm on R-MAT-22, 1/2/4/8 GPU",
-        "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": round(res["gflops"], 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(res["ms_per_step"], 4), "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"R-MAT scale-{scale} FP64 PLUS_TIMES SpMV (GrB_mxv), edgefactor 16, "
+        "config": {"workload": f"R-MAT scale-{head_scale} FP64 PLUS_TIMES SpMV (GrB_mxv), edgefactor 16, "
                                f"{'row-partitioned into %d entry-balanced blocks + allgatherv of x (RCCL, overlapped with the diagonal block)' % world if world > 1 else 'BASELINE.json configs[1]'}",
                    "n": n, "nnz": nnz_total, "semiring": "PLUS_TIMES_FP64", "parallelism": f"rowblock{world}", "transport": transport_note if world > 1 else "none (one GPU)",
-                   "graph_build_s": round(t_gen, 2), "device": info["name"]},
-        "gbps_algorithmic": round(alg_bytes * args.steps / (elapsed if world == 1 else kernel_ms * 1e-3 * args.steps) / 1e9, 1),
+                   "graph_build_s": round(head.t_gen, 2), "device": info["name"]},
+        "ms_per_step_blocks": [round(b, 4) for b in res["blocks_ms"]],
+        "timing": f"median of {len(res['blocks_ms'])} blocks of exactly {args.steps} steps, each between barrier + synchronize (max over ranks)",
+        "gbps_algorithmic": round(res["alg_bytes_total"] / (res["ms_per_step"] * 1e-3) / 1e9, 1),
         "roofline": roofline,
     }
+    if world > 1:
+        out["phases"] = head.phases(min(args.steps, 20))
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle's typed OpenMP loop on a bounded sample ------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
+        A, x, w = head.mats[0], head.x, head.w
         rp, ci, av = A.to_csr()
         xh, _ = x.to_dense_arrays()
         y, pres = O.fast_spmv(rp, ci, av, xh)               # first call: page-in + parity check
@@ -229,55 +201,38 @@ def main():
         for _ in range(reps):
             O.fast_spmv(rp, ci, av, xh)
         cpu_t = (time.perf_counter() - t1) / reps
-        out["cpu_baseline"] = {"value": round(2.0 * nnz / cpu_t / 1e9, 3), "unit": "GFLOP/s", "cores": O.num_threads(), "kind": "port",
-                               "sample": f"{reps} passes of the same scale-{scale} FP64 SpMV with oracle/grb_oracle.c fast_spmv_plus_times_fp64 "
+        out["cpu_baseline"] = {"value": round(2.0 * head.nnz / cpu_t / 1e9, 3), "unit": "GFLOP/s", "cores": O.num_threads(), "kind": "port",
+                               "sample": f"{reps} passes of the same scale-{head_scale} FP64 SpMV with oracle/grb_oracle.c fast_spmv_plus_times_fp64 "
                                          f"(OpenMP, {O.num_threads()} threads); SuiteSparse:GraphBLAS itself is not installed on this machine",
-                               "ms_per_pass": round(cpu_t * 1e3, 2), "gbps_algorithmic": round(alg_bytes / cpu_t / 1e9, 2)}
+                               "ms_per_pass": round(cpu_t * 1e3, 2), "gbps_algorithmic": round(res["alg_bytes"] / cpu_t / 1e9, 2)}
         out["parity_vs_oracle"] = "ok (pattern exact, values rtol 1e-6)" if ok else "MISMATCH"
         del rp, ci, av, xh, y, pres
 
-    def timed_mxv(Amat, xv, wv, reps):
-        for _ in range(3):
-            Amat.mxv(xv, semiring=sr, out=wv)
-        torch.cuda.synchronize(); lib.GrBX_timer_start()
-        for _ in range(reps):
-            Amat.mxv(xv, semiring=sr, out=wv)
-        m = C.c_float(0); lib.GrBX_timer_stop(C.byref(m)); return m.value / reps
-
     if not args.no_extras:
-        # ---- what the plan costs, and the rates without it / on permuted labels (N = 1) ------------------
         if world == 1:
-            os.environ["GRB_MI355X_SPMV"] = "adaptive"
-            t_a = timed_mxv(A, x, w, 10)
-            os.environ.pop("GRB_MI355X_SPMV")
-            extra = {"plan_build_ms_first_in_process": plan_build_ms,      # includes the one-time loading of the ~40 plan-building kernels' code objects
-                     "ms_per_step_without_plan": round(t_a, 4),
-                     "frac_without_plan": round(alg_bytes / (t_a * 1e-3) / 1e9 / 8000.0, 4),
-                     "without_plan_kernel": "k_spmv_adaptive (row-block kernel A: what a masked or one-off product runs; its row-block list is built in one host pass)"}
-            del A, mats, x, x_mine
+            out["spmv_extra"] = spmv_extra(cx, head, res)
+        bounds_head = head.bounds
+        head.release(); del head
+        torch.cuda.empty_cache()
+        if world > 1:
+            other_scale = strong_scale if args.scaling == "weak" else weak_scale
+            other = SpmvJob(cx, other_scale)
+            r2 = other.run(min(args.steps, 20), min(args.warmup, 3), 3)
+            key = "spmv_strong" if args.scaling == "weak" else "spmv_weak"
+            out[key] = {"workload": f"R-MAT scale-{other_scale} FP64 PLUS_TIMES SpMV over {world} ranks ({'fixed graph: strong scaling' if key == 'spmv_strong' else 'scale grows with N: weak scaling'})",
+                        "n": other.n, "nnz": r2["nnz_total"], "ms_per_step": round(r2["ms_per_step"], 4), "GFLOPS": round(r2["gflops"], 1),
+                        "roofline": roof(r2["alg_bytes"], r2["kernel_ms"] * 1e-3, kernel=r2["plan"], kernel_ms=round(r2["kernel_ms"], 4), note="this rank's row block"),
+                        "phases": other.phases(min(args.steps, 20))}
+            other.release(); del other
             torch.cuda.empty_cache()
-            rp2, c2 = rmat.csr_torch(scale, dev, seed=42, permute_seed=7)
-            v2 = rmat.values_torch(int(c2.numel()), dev, seed=43)
-            x2t = rmat.values_torch(n, dev, seed=44)
-            A2 = gb.Matrix.from_csr(gb.FP64, n, n, rp2.data_ptr(), c2.data_ptr(), (v2.data_ptr(), int(c2.numel())), device=True)
-            x2 = gb.Vector.from_dense_array((x2t.data_ptr(), n), gb.FP64, device=True)
-            t_p = timed_mxv(A2, x2, w, 20)
-            alg2 = int(c2.numel()) * 12 + (n + 1) * 4 + 2 * n * 8
-            warm = plan_ms()                                                # a second matrix of the same size in the same process: what a plan costs
-            extra["plan_build_ms"] = warm
-            extra["plan_build_in_steps"] = round(warm / ms_per_step, 1)
-            extra["permuted_labels"] = {"ms_per_step": round(t_p, 4), "GFLOPS": round(2.0 * int(c2.numel()) / t_p / 1e6, 1),
-                                        "frac": round(alg2 / (t_p * 1e-3) / 1e9 / 8000.0, 4), "plan_build_ms": warm, "kernel": gb.last_kernel_plan(),
-                                        "note": "same R-MAT-22 with vertex labels permuted pseudo-randomly (rmat.py permute_seed=7)"}
-            out["spmv_extra"] = extra
-            del A2, x2, rp2, c2, v2, x2t
-            torch.cuda.empty_cache()
-            out["mxm"] = bench_triangles(gb, rmat, torch, dev, args.scale, lib, rank)
-            out["bfs"] = bench_bfs(gb, rmat, torch, dev, args.scale, lib)
-        else:
-            del mats, x, x_mine
-            torch.cuda.empty_cache()
-        out["pagerank"] = bench_pagerank(gb, rmat, gdist, torch, dev, scale, bounds, comm, barrier, max_over_ranks, sum_over_ranks, min(args.steps, 20))
+        out["mxm"] = bench_triangles(cx, args.scale)
+        out["bfs"] = bench_bfs(cx, args.scale)
+        out["pagerank"] = bench_pagerank(cx, head_scale, bounds_head, min(args.steps, 20), "pagerank")
+        if args.pr_scale > 0:
+            pr_bounds = gdist.balanced_row_blocks(gdist.rmat_expected_row_prefix(args.pr_scale), world) if world > 1 else [0, 1 << args.pr_scale]
+            out["pagerank_scale25"] = bench_pagerank(cx, args.pr_scale, pr_bounds, min(args.steps, 10), "pagerank_scale25")
+        if world == 1:
+            out["sssp"] = bench_sssp(cx, args.scale)
 
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -286,9 +241,162 @@ def main():
         tdist.destroy_process_group()
 
 
-def bench_triangles(gb, rmat, torch, dev, scale, lib, rank):
-    """configs[3]: L.mxm(L, PLUS_PAIR, mask=L).reduce_int() on R-MAT-`scale`, checked against the oracle's count."""
-    import numpy as np
+class SpmvJob:
+    """The timed step: FP64 PLUS_TIMES GrB_mxv on this rank's row block of R-MAT-`scale` (the whole graph for one rank)."""
+
+    def __init__(self, cx, scale):
+        gb, rmat, gdist, torch, dev = cx.gb, cx.rmat, cx.gdist, cx.torch, cx.dev
+        self.cx, self.scale = cx, scale
+        world, rank = cx.world, cx.rank
+        n = self.n = 1 << scale
+        self.bounds = gdist.balanced_row_blocks(gdist.rmat_expected_row_prefix(scale), world) if world > 1 else [0, n]
+        r0, r1 = self.r0, self.r1 = self.bounds[rank], self.bounds[rank + 1]
+        t_gen = time.time()
+        rowptr, col = rmat.csr_torch(scale, dev, seed=42, row_range=(r0, r1) if world > 1 else None)
+        nnz = self.nnz = int(col.numel())
+        vals = rmat.values_torch(nnz, dev, seed=43 + rank)
+        x_all = rmat.values_torch(n, dev, seed=44)
+        torch.cuda.synchronize()
+        self.t_gen = time.time() - t_gen
+        self.mats = []
+        if world > 1:       # diagonal block (the columns this rank owns) and the rest: the first needs no remote data
+            for rp_, c_, v_ in gdist.split_csr_columns(rowptr, col, r0, r1, vals):
+                self.mats.append(gb.Matrix.from_csr(gb.FP64, r1 - r0, n, rp_.data_ptr(), c_.data_ptr(), (v_.data_ptr(), int(c_.numel())), device=True))
+            del rp_, c_, v_
+        else:
+            self.mats.append(gb.Matrix.from_csr(gb.FP64, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True))
+        self.x = gb.Vector.from_dense_array((x_all.data_ptr(), n), gb.FP64, device=True)           # the full operand (every slice valid at the start)
+        self.x_mine = gb.Vector.from_dense_array((x_all[r0:r1].contiguous().data_ptr(), r1 - r0), gb.FP64, device=True)
+        self.w = gb.Vector.sparse(gb.FP64, r1 - r0)
+        del rowptr, col, vals, x_all
+        torch.cuda.empty_cache()
+        self.sr = gb.FP64.PLUS_TIMES
+        # algorithmic bytes per launch (SURVEY.md §8d): nnz*(8+4) + (nrows+1)*4 + ncols*8 + nrows*8
+        self.alg_bytes = nnz * 12 + (r1 - r0 + 1) * 4 + n * 8 + (r1 - r0) * 8
+
+    def step(self):
+        cx = self.cx
+        if cx.world > 1:
+            cx.comm.allgatherv_start(self.x, self.x_mine, self.bounds)    # remote slices of x -> the HBM buffer the kernel gathers from
+            self.mats[0].mxv(self.x, semiring=self.sr, out=self.w)        # diagonal block: local columns only
+            cx.comm.wait()
+            self.mats[1].mxv(self.x, semiring=self.sr, out=self.w, accum=cx.gb.FP64.PLUS)
+        else:
+            self.mats[0].mxv(self.x, semiring=self.sr, out=self.w)
+
+    def run(self, steps, warmup, blocks):
+        cx = self.cx
+        lib, torch = cx.lib, cx.torch
+        self.step()
+        ms = C.c_float(0); lib.GrBX_last_plan_build_ms(C.byref(ms)); self.plan_build_ms = round(ms.value, 2)    # the first product built the plan of kernel X
+        for _ in range(max(0, warmup - 1)):
+            self.step()
+        plan = cx.gb.last_kernel_plan()
+        blocks_ms = []
+        for _ in range(max(1, blocks)):
+            cx.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            cx.barrier()
+            blocks_ms.append(cx.max_over_ranks(time.perf_counter() - t0) / steps * 1e3)
+        ms_per_step = sorted(blocks_ms)[len(blocks_ms) // 2]
+        nnz_total = int(cx.sum_over_ranks(float(self.nnz)))
+        # roofline of the dominant kernel(s): HIP events on the library's stream around K launches
+        kms = []
+        for _ in range(max(1, min(blocks, 3))):
+            torch.cuda.synchronize()
+            lib.GrBX_timer_start()
+            for _ in range(steps):
+                self.step()
+            m = C.c_float(0); lib.GrBX_timer_stop(C.byref(m)); kms.append(m.value / steps)
+        kernel_ms = sorted(kms)[len(kms) // 2]
+        return {"ms_per_step": ms_per_step, "blocks_ms": blocks_ms, "gflops": 2.0 * nnz_total / (ms_per_step * 1e-3) / 1e9, "nnz_total": nnz_total, "kernel_ms": kernel_ms,
+                "alg_bytes": self.alg_bytes, "alg_bytes_total": int(cx.sum_over_ranks(float(self.alg_bytes))), "plan": plan}
+
+    def phases(self, reps):
+        """Per-phase times of the N > 1 step on this rank, each measured alone (HIP events on the library's stream; the exchange
+        by the host clock around start + wait + synchronize): what overlaps in the step is the exchange and the diagonal block."""
+        cx = self.cx
+        lib, torch = cx.lib, cx.torch
+
+        def ev(fn):
+            fn(); torch.cuda.synchronize(); lib.GrBX_timer_start()
+            for _ in range(reps):
+                fn()
+            m = C.c_float(0); lib.GrBX_timer_stop(C.byref(m)); return m.value / reps
+        diag = ev(lambda: self.mats[0].mxv(self.x, semiring=self.sr, out=self.w))
+        off = ev(lambda: self.mats[1].mxv(self.x, semiring=self.sr, out=self.w, accum=cx.gb.FP64.PLUS))
+        cx.barrier(); t = time.perf_counter()
+        for _ in range(reps):
+            cx.comm.allgatherv_start(self.x, self.x_mine, self.bounds); cx.comm.wait(); torch.cuda.synchronize()
+        cx.barrier(); ex = (time.perf_counter() - t) / reps * 1e3
+        return {"exchange_ms": round(cx.max_over_ranks(ex), 4), "diag_ms": round(cx.max_over_ranks(diag), 4), "offdiag_ms": round(cx.max_over_ranks(off), 4),
+                "exchange_bytes_received_per_rank": int((self.n - (self.r1 - self.r0)) * 8), "note": "max over ranks; each phase timed alone"}
+
+    def release(self):
+        self.mats = []; self.x = self.x_mine = self.w = None
+
+
+def spmv_extra(cx, head, res):
+    """What the plan costs, and the rates without it / on permuted labels (N = 1)."""
+    gb, rmat, torch, dev, lib = cx.gb, cx.rmat, cx.torch, cx.dev, cx.lib
+    n, scale = head.n, head.scale
+
+    def timed_mxv(Amat, xv, wv, reps):
+        for _ in range(3):
+            Amat.mxv(xv, semiring=head.sr, out=wv)
+        torch.cuda.synchronize(); lib.GrBX_timer_start()
+        for _ in range(reps):
+            Amat.mxv(xv, semiring=head.sr, out=wv)
+        m = C.c_float(0); lib.GrBX_timer_stop(C.byref(m)); return m.value / reps
+
+    def plan_ms():
+        ms = C.c_float(0); lib.GrBX_last_plan_build_ms(C.byref(ms)); return round(ms.value, 2)
+    extra = {"plan_build_ms_first_in_process": head.plan_build_ms}      # includes the one-time loading of the ~40 plan-building kernels' code objects
+    for key, env, what in (("without_plan", "adaptive", "k_spmv_adaptive (row-block kernel A: its row-block list is built in one host pass)"),
+                           ("wavepipe", "wavepipe", "k_spmv_wavepipe (kernel W: the pipeline on the matrix as stored; its plan is a re-labelled column array, no panel copy)")):
+        os.environ["GRB_MI355X_SPMV"] = env
+        try:
+            t_a = timed_mxv(head.mats[0], head.x, head.w, 10)
+            extra[f"ms_per_step_{key}"] = round(t_a, 4)
+            extra[f"frac_{key}"] = round(res["alg_bytes"] / (t_a * 1e-3) / 1e9 / PEAK, 4)
+            extra[f"{key}_kernel"] = what
+        finally:
+            os.environ.pop("GRB_MI355X_SPMV")
+    head.release()
+    torch.cuda.empty_cache()
+    rp2, c2 = rmat.csr_torch(scale, dev, seed=42, permute_seed=7)
+    v2 = rmat.values_torch(int(c2.numel()), dev, seed=43)
+    x2t = rmat.values_torch(n, dev, seed=44)
+    A2 = gb.Matrix.from_csr(gb.FP64, n, n, rp2.data_ptr(), c2.data_ptr(), (v2.data_ptr(), int(c2.numel())), device=True)
+    x2 = gb.Vector.from_dense_array((x2t.data_ptr(), n), gb.FP64, device=True)
+    w2 = gb.Vector.sparse(gb.FP64, n)
+    t_p = timed_mxv(A2, x2, w2, 20)
+    alg2 = int(c2.numel()) * 12 + (n + 1) * 4 + 2 * n * 8
+    warm = plan_ms()                                                # a second matrix of the same size in the same process: what a plan costs
+    extra["plan_build_ms"] = warm
+    extra["plan_build_in_steps"] = round(warm / res["ms_per_step"], 1)
+    extra["permuted_labels"] = {"ms_per_step": round(t_p, 4), "GFLOPS": round(2.0 * int(c2.numel()) / t_p / 1e6, 1),
+                                "frac": round(alg2 / (t_p * 1e-3) / 1e9 / PEAK, 4), "plan_build_ms": warm, "kernel": gb.last_kernel_plan(),
+                                "note": "same R-MAT-22 with vertex labels permuted pseudo-randomly (rmat.py permute_seed=7)"}
+    return extra
+
+
+def _rows_slice(cx, typ, rowptr, col, vals, r0, r1, ncols):
+    """Rows [r0, r1) of a CSR held as torch tensors, as a library matrix."""
+    torch = cx.torch
+    rp = (rowptr[r0:r1 + 1].to(torch.int64) & 0xFFFFFFFF)
+    b, e = int(rp[0]), int(rp[-1])
+    rp32 = (rp - b).to(torch.int32).contiguous()
+    c = col[b:e].contiguous(); v = vals[b:e].contiguous()
+    return cx.gb.Matrix.from_csr(typ, r1 - r0, ncols, rp32.data_ptr(), c.data_ptr(), (v.data_ptr(), e - b), device=True), e - b
+
+
+def bench_triangles(cx, scale):
+    """configs[3]: L.mxm(L, PLUS_PAIR, mask=L).reduce_int() on R-MAT-`scale`, checked against the oracle's count.  N > 1: the rows
+    of A and of the mask in flop-balanced blocks, L replicated, the INT64 counts all-reduced (pygraphblas_amd.dist.triangle_count)."""
+    gb, rmat, torch, dev, np, world, rank = cx.gb, cx.rmat, cx.torch, cx.dev, cx.np, cx.world, cx.rank
     n = 1 << scale
     rowptr, col = rmat.csr_torch(scale, dev, seed=42, symmetric=True, drop_self_loops=True, lower=True)
     nnz = int(col.numel())
@@ -296,27 +404,53 @@ def bench_triangles(gb, rmat, torch, dev, scale, lib, rank):
     L = gb.Matrix.from_csr(gb.INT64, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
     dL = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
     flops = 2 * int(dL[col.to(torch.int64) & 0xFFFFFFFF].sum())
-    tri = L.mxm(L, semiring=gb.INT64.PLUS_PAIR, mask=L).reduce_int()           # first run: row binning buffers, pool warm-up
-    best = 1e9
+    nnz_c = None
+
+    def single():
+        return L.mxm(L, semiring=gb.INT64.PLUS_PAIR, mask=L).reduce_int()
+    if world == 1:
+        run = single
+        my_nnz = nnz
+    else:
+        tb = cx.gdist.flop_balanced_row_blocks(rowptr, col, world)
+        Lrows, my_nnz = _rows_slice(cx, gb.INT64, rowptr, col, vals, tb[rank], tb[rank + 1], n)
+
+        def run():
+            return cx.gdist.triangle_count(cx.comm, Lrows, L)
+    tri = run()                                                                  # first run: row binning buffers, pool warm-up
+    times = []
     for _ in range(3):
-        torch.cuda.synchronize(); t = time.perf_counter()
-        tri = L.mxm(L, semiring=gb.INT64.PLUS_PAIR, mask=L).reduce_int()
-        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t)
-    alg_bytes = 2 * (nnz * 4 + (n + 1) * 4) + (flops // 2) * 4 + nnz * 12      # A and M streams, the B-row entries of every product, C written
-    from oracle import oracle as O
-    t = time.perf_counter(); otri = O.fast_tricount(rowptr.cpu().numpy().view(np.uint32), col.cpu().numpy().view(np.uint32)); cpu_s = time.perf_counter() - t
-    return {"workload": f"triangle count R-MAT-{scale}: L.mxm(L, PLUS_PAIR, mask=L).reduce_int() (BASELINE.json configs[3])", "nnz_L": nnz, "triangles": int(tri),
-            "flops": flops, "seconds": round(best, 5), "GFLOPS": round(flops / best / 1e9, 1), "dtype": "int64",
-            "roofline": {"bound": "hbm", "achieved": round(alg_bytes / best / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg_bytes / best / 1e9 / 8000.0, 4),
-                         "algorithmic_bytes": alg_bytes, "note": "B-row entries are counted once per product although most are served by L2 / Infinity Cache"},
-            "kernel": gb.last_kernel_plan(), "parity_vs_oracle": "bit-exact" if int(tri) == int(otri) else f"MISMATCH (oracle {otri})",
-            "cpu_baseline": {"seconds": round(cpu_s, 3), "GFLOPS": round(flops / cpu_s / 1e9, 2), "cores": O.num_threads(), "kind": "port", "sample": "one pass of oracle fast_tricount on the same L"}}
+        cx.barrier(); t = time.perf_counter()
+        tri = run()
+        cx.barrier(); times.append(cx.max_over_ranks(time.perf_counter() - t))
+    best = min(times)
+    plan = gb.last_kernel_plan()
+    # A and M streams (this graph's, once), the B-row entries of every product, C written (nnz(C) <= nnz(M))
+    alg_bytes = 2 * (nnz * 4 + (n + 1) * 4) + (flops // 2) * 4 + nnz * 12
+    traffic, traffic_source = static_traffic("spgemm_pmc_traffic.json") if (world == 1 and scale == 22) else (None, None)
+    out = {"workload": f"triangle count R-MAT-{scale}: L.mxm(L, PLUS_PAIR, mask=L).reduce_int() (BASELINE.json configs[3])" + (f", rows of L and of the mask in {world} flop-balanced blocks, L replicated" if world > 1 else ""),
+           "nnz_L": nnz, "triangles": int(tri), "flops": flops, "seconds": round(best, 5), "GFLOPS": round(flops / best / 1e9, 1), "dtype": "int64",
+           "roofline": roof(alg_bytes, best, traffic=traffic, traffic_source=traffic_source,
+                            note="B-row entries are counted once per product although part of them is served by L2 / Infinity Cache; whole job (all ranks)"),
+           "kernel": plan}
+    if rank == 0:
+        if world > 1:
+            single(); torch.cuda.synchronize(); t = time.perf_counter(); one = single(); torch.cuda.synchronize()
+            out["single_gpu_seconds_on_rank0"] = round(time.perf_counter() - t, 5)
+            out["parity_vs_single_gpu"] = "bit-exact" if int(one) == int(tri) else f"MISMATCH (single {one})"
+        if not cx.args.no_cpu_baseline:
+            from oracle import oracle as O
+            t = time.perf_counter(); otri = O.fast_tricount(rowptr.cpu().numpy().view(np.uint32), col.cpu().numpy().view(np.uint32)); cpu_s = time.perf_counter() - t
+            out["parity_vs_oracle"] = "bit-exact" if int(tri) == int(otri) else f"MISMATCH (oracle {otri})"
+            out["cpu_baseline"] = {"seconds": round(cpu_s, 3), "GFLOPS": round(flops / cpu_s / 1e9, 2), "cores": O.num_threads(), "kind": "port", "sample": "one pass of oracle fast_tricount on the same L"}
+    cx.barrier()
+    return out
 
 
-def bench_bfs(gb, rmat, torch, dev, scale, lib):
-    """configs[2]: the reference's loop (demo/Introduction-to-GraphBLAS-with-Python.ipynb:4301-4313), level vector checked bit for bit."""
-    import numpy as np
-    from pygraphblas_amd import descriptor as D
+def bench_bfs(cx, scale):
+    """configs[2]: the reference's loop (demo/Introduction-to-GraphBLAS-with-Python.ipynb:4301-4313), level vector checked bit for
+    bit.  N > 1: entry-balanced row blocks, the frontier gathered as one bit per vertex (pygraphblas_amd.dist.bfs_levels)."""
+    gb, rmat, torch, dev, np, world, rank = cx.gb, cx.rmat, cx.torch, cx.dev, cx.np, cx.world, cx.rank
     n = 1 << scale
     rowptr, col = rmat.csr_torch(scale, dev, seed=42, symmetric=True, drop_self_loops=True)
     nnz = int(col.numel())
@@ -324,58 +458,155 @@ def bench_bfs(gb, rmat, torch, dev, scale, lib):
     A = gb.Matrix.from_csr(gb.BOOL, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
     deg = rowptr[1:] - rowptr[:-1]
     src = int(torch.argmax(deg))
+    plans = []
 
-    def bfs():
-        v = gb.Vector.sparse(gb.UINT8, n); q = gb.Vector.sparse(gb.BOOL, n); q[src] = True
-        level, plans = 1, []
-        while q.reduce_bool() and level <= n:
-            v.assign_scalar(level, mask=q)
-            v.vxm(A, mask=v, out=q, desc=D.RC)
-            plans.append(gb.last_kernel_plan().split("<")[0]); level += 1
-        return v, level - 1, plans
-    bfs()                                                                        # first run builds the cached transpose / plans
+    loops = cx.loops
+
+    def single():
+        del plans[:]
+        return loops.bfs(A, src, plans=plans)
+    if world == 1:
+        run = single
+    else:
+        bounds = cx.gdist.balanced_row_blocks((rowptr.to(torch.int64) & 0xFFFFFFFF).cpu().numpy(), world)
+        Arows, _ = _rows_slice(cx, gb.BOOL, rowptr, col, vals, bounds[rank], bounds[rank + 1], n)
+
+        def run():
+            return cx.gdist.bfs_levels(cx.comm, Arows, n, bounds, src)
+    run()                                                                        # first run builds the cached transpose / plans
+    times = []
+    for _ in range(3):
+        cx.barrier(); t = time.perf_counter(); v, depth = run(); cx.barrier(); times.append(cx.max_over_ranks(time.perf_counter() - t))
+    best = min(times)
+    lev_mine, _ = v.to_dense_arrays()
+    out = {"workload": f"BFS R-MAT-{scale} BOOL LOR_LAND, the reference's vxm loop (BASELINE.json configs[2])" + (f", {world} entry-balanced row blocks, bit frontier" if world > 1 else ""),
+           "nnz": nnz, "source": src, "depth": depth, "seconds": round(best, 5), "dtype": "bool"}
+    # parity and the rate need the whole level vector: every rank holds the graph, so the single-GPU loop gives it
+    v1, d1 = single(); lev, _ = v1.to_dense_arrays()
+    if world > 1:
+        ok = bool(d1 == depth and np.array_equal(lev[bounds[rank]:bounds[rank + 1]], lev_mine))
+        flag = torch.tensor([int(ok)], dtype=torch.int64); cx.tdist.all_reduce(flag, op=cx.tdist.ReduceOp.MIN)
+        out["parity_vs_single_gpu"] = "bit-exact level vector (every rank's slice)" if int(flag[0]) else "MISMATCH"
+    else:
+        out["kernels_per_level"] = list(plans)
+    reached = lev > 0
+    degh = deg.cpu().numpy().astype(np.int64)
+    edges = int(degh[reached].sum()); vr = int(reached.sum())
+    # E_r·4 + V_r·8 + n·1 (level write) + n/8·2·D (bitmap read + write per level)
+    alg_bytes = edges * 4 + vr * 8 + n + (n // 8) * 2 * depth
+    out.update({"reached": vr, "edges_reachable": edges, "GTEPS": round(edges / best / 1e9, 2),
+                "roofline": roof(alg_bytes, best, note="E_r*4 + V_r*8 + n + n/8*2*D (SURVEY.md 8d): the whole loop, host round trips of the loop condition included")})
+    if rank == 0 and not cx.args.no_cpu_baseline:
+        from oracle import oracle as O
+        t = time.perf_counter(); olev, odepth = O.fast_bfs(rowptr.cpu().numpy().view(np.uint32), col.cpu().numpy().view(np.uint32), src); cpu_s = time.perf_counter() - t
+        out["parity_vs_oracle"] = "bit-exact level vector" if bool(np.array_equal(olev, lev) and odepth == d1) else "MISMATCH"
+        out["cpu_baseline"] = {"seconds": round(cpu_s, 4), "GTEPS": round(edges / cpu_s / 1e9, 3), "cores": O.num_threads(), "kind": "port", "sample": "one pass of oracle fast_bfs"}
+    cx.barrier()
+    return out
+
+
+def bench_pagerank(cx, scale, bounds, iters, name):
+    """configs[4]: gap/prmark.py's loop in FP32.  One rank: the reference's loop as written (pygraphblas_amd.loops.pagerank: the
+    adjacency matrix, desc T0).  N > 1: the row-partitioned form (pygraphblas_amd.dist.pagerank).  A fixed number of iterations is
+    timed, then the loop runs to convergence as the reference does."""
+    gb, rmat, gdist, torch, dev, world, rank = cx.gb, cx.rmat, cx.gdist, cx.torch, cx.dev, cx.world, cx.rank
+    n = 1 << scale
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    if world == 1:
+        rowptr, col = rmat.csr_torch(scale, dev, seed=42)
+        nnz = int(col.numel())
+        ones = torch.ones(nnz, dtype=torch.float32, device=dev)
+        A = gb.Matrix.from_csr(gb.FP32, n, n, rowptr.data_ptr(), col.data_ptr(), (ones.data_ptr(), nnz), device=True)
+        deg = (rowptr[1:] - rowptr[:-1]).to(torch.float32)
+        pres = (deg > 0).to(torch.uint8)
+        del rowptr, col, ones
+        torch.cuda.empty_cache()
+
+        def degrees():
+            return gb.Vector.from_dense_array((deg.data_ptr(), n), gb.FP32, present=pres.data_ptr(), device=True)
+
+        def run(fixed):
+            return cx.loops.pagerank(A, degrees(), fixed_iterations=fixed)
+    else:
+        rowptr, col = rmat.csr_torch(scale, dev, seed=42, transpose=True, row_range=(r0, r1))        # rows of A'
+        nnz = int(col.numel())
+        ones = torch.ones(nnz, dtype=torch.float32, device=dev)
+        (rpd, cd, vd), (rpo, co, vo) = gdist.split_csr_columns(rowptr, col, r0, r1, ones)
+        Dm = gb.Matrix.from_csr(gb.FP32, r1 - r0, n, rpd.data_ptr(), cd.data_ptr(), (vd.data_ptr(), int(cd.numel())), device=True)
+        Om = gb.Matrix.from_csr(gb.FP32, r1 - r0, n, rpo.data_ptr(), co.data_ptr(), (vo.data_ptr(), int(co.numel())), device=True)
+        del rowptr, col, ones, rpd, cd, vd, rpo, co, vo
+        rpa, ca = rmat.csr_torch(scale, dev, seed=42, row_range=(r0, r1))                             # out-degrees of the owned vertices
+        deg = (rpa[1:] - rpa[:-1]).to(torch.float32)
+        pres = (deg > 0).to(torch.uint8)
+        del rpa, ca
+        torch.cuda.empty_cache()
+
+        def degrees():
+            return gb.Vector.from_dense_array((deg.data_ptr(), r1 - r0), gb.FP32, present=pres.data_ptr(), device=True)
+
+        def run(fixed):
+            return gdist.pagerank(cx.comm, Dm, Om, degrees(), n, bounds, fixed_iterations=fixed)
+    run(3)                                                                                            # plans, pool warm-up
+    times = []
+    for _ in range(3):
+        cx.barrier(); t = time.perf_counter()
+        r, its, rdiff = run(iters)
+        cx.barrier(); times.append(cx.max_over_ranks(time.perf_counter() - t))
+    sec = sorted(times)[1]
+    plan = gb.last_kernel_plan()
+    nnz_total = int(cx.sum_over_ranks(float(nnz)))
+    conv = run(None)                                                                                  # to convergence, as the reference runs it
+    # algorithmic bytes of one iteration on this rank, fully fused: the pattern product nnz·4 + (nrows+1)·4 + ncols·4 (w) + nrows·4 (r written;
+    # `r[:] = teleport` and the accumulate fold into that store) ; w = t / d reads t, d and writes w (3 × 4 B per owned vertex);
+    # t = |t − r| reads t, r and writes t (3 × 4 B), its sum costs no traffic
+    nb = r1 - r0
+    alg = nnz * 4 + (nb + 1) * 4 + n * 4 + nb * 4 + 6 * nb * 4
+    return {"workload": f"PageRank R-MAT-{scale} FP32, gap/prmark.py loop (PLUS_SECOND, accum PLUS, w = t/d, |t-r| reduced) on {world} row block(s) (BASELINE.json configs[4])",
+            "dtype": "f32", "iterations_timed": its, "ms_per_iteration": round(sec / its * 1e3, 4), "GFLOPS": round(2.0 * nnz_total * its / sec / 1e9, 1), "nnz": nnz_total,
+            "iterations_to_converge": conv[1], "rdiff": float(conv[2]), "kernel": plan,
+            "roofline": roof(alg, sec / its, note="per iteration on this rank: product nnz*4+(nrows+1)*4+ncols*4+nrows*4, plus 6 vector streams of 4 B per owned vertex (w = t/d; t = |t-r|) — what a fully fused iteration must move")}
+
+
+def bench_sssp(cx, scale):
+    """MIN_PLUS at scale: the reference's shortest-path loop (demo/Intro-Prez.ipynb:1034-1045) on the directed R-MAT-`scale`
+    with INT64 weights in [1, 255], distances checked bit for bit against the oracle's loop (sweep count included)."""
+    gb, rmat, torch, dev, np = cx.gb, cx.rmat, cx.torch, cx.dev, cx.np
+    n = 1 << scale
+    rowptr, col = rmat.csr_torch(scale, dev, seed=42, drop_self_loops=True)
+    nnz = int(col.numel())
+    vals = (rmat.values_torch(nnz, dev, seed=47) * 255.0).to(torch.int64) + 1
+    A = gb.Matrix.from_csr(gb.INT64, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+    deg = (rowptr[1:] - rowptr[:-1])
+    src = int(torch.argmax(deg))
+    plans = []
+    cx.loops.sssp(A, src)                                                         # cached transpose, plans
     best = 1e9
     for _ in range(3):
-        torch.cuda.synchronize(); t = time.perf_counter(); v, depth, plans = bfs(); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t)
-    lev, _ = v.to_dense_arrays()
-    edges = int(deg.cpu().numpy().astype(np.int64)[lev > 0].sum())
-    from oracle import oracle as O
-    t = time.perf_counter(); olev, odepth = O.fast_bfs(rowptr.cpu().numpy().view(np.uint32), col.cpu().numpy().view(np.uint32), src); cpu_s = time.perf_counter() - t
-    ok = bool(np.array_equal(olev, lev) and odepth == depth)
-    return {"workload": f"BFS R-MAT-{scale} BOOL LOR_LAND, the reference's vxm loop (BASELINE.json configs[2])", "nnz": nnz, "source": src, "depth": depth,
-            "reached": int((lev > 0).sum()), "seconds": round(best, 5), "GTEPS": round(edges / best / 1e9, 2), "dtype": "bool", "kernels_per_level": plans,
-            "parity_vs_oracle": "bit-exact level vector" if ok else "MISMATCH",
-            "cpu_baseline": {"seconds": round(cpu_s, 4), "GTEPS": round(edges / cpu_s / 1e9, 3), "cores": O.num_threads(), "kind": "port", "sample": "one pass of oracle fast_bfs"}}
+        del plans[:]
+        torch.cuda.synchronize(); t = time.perf_counter(); v, sweeps = cx.loops.sssp(A, src, plans=plans); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t)
+    gd, gp = v.to_dense_arrays()
+    # algorithmic bytes: per sweep the edges leaving the operand's entries (weight + column: 12 B) + the operand's entries (8 B) +
+    # the output read and written with its presence bytes (2·9 B per vertex) + the loop's dup and iseq (4 streams of 9 B)
+    degh = deg.cpu().numpy().astype(np.int64)
+    acc = [0]
 
-
-def bench_pagerank(gb, rmat, gdist, torch, dev, scale, bounds, comm, barrier, max_over_ranks, sum_over_ranks, iters):
-    """configs[4]: gap/prmark.py's loop in FP32 on the row partition (pygraphblas_amd.dist.pagerank), a fixed number of iterations timed."""
-    n = 1 << scale
-    rank, world = comm.rank, comm.world
-    r0, r1 = bounds[rank], bounds[rank + 1]
-    rowptr, col = rmat.csr_torch(scale, dev, seed=42, transpose=True, row_range=(r0, r1) if world > 1 else None)    # rows of A'
-    nnz = int(col.numel())
-    ones = torch.ones(nnz, dtype=torch.float32, device=dev)
-    (rpd, cd, vd), (rpo, co, vo) = gdist.split_csr_columns(rowptr, col, r0, r1, ones)
-    Dm = gb.Matrix.from_csr(gb.FP32, r1 - r0, n, rpd.data_ptr(), cd.data_ptr(), (vd.data_ptr(), int(cd.numel())), device=True)
-    Om = gb.Matrix.from_csr(gb.FP32, r1 - r0, n, rpo.data_ptr(), co.data_ptr(), (vo.data_ptr(), int(co.numel())), device=True)
-    del rowptr, col, ones, rpd, cd, vd, rpo, co, vo
-    rpa, ca = rmat.csr_torch(scale, dev, seed=42, row_range=(r0, r1) if world > 1 else None)                           # out-degrees of the owned vertices
-    deg = (rpa[1:] - rpa[:-1]).to(torch.float32)
-    pres = (deg > 0).to(torch.uint8)
-    del rpa, ca
-
-    def degrees():
-        return gb.Vector.from_dense_array((deg.data_ptr(), r1 - r0), gb.FP32, present=pres.data_ptr(), device=True)
-    gdist.pagerank(comm, Dm, Om, degrees(), n, bounds, fixed_iterations=3)                                              # plans, pool warm-up
-    barrier(); t = time.perf_counter()
-    r, its, rdiff = gdist.pagerank(comm, Dm, Om, degrees(), n, bounds, fixed_iterations=iters)
-    barrier(); sec = max_over_ranks(time.perf_counter() - t)
-    nnz_total = int(sum_over_ranks(float(nnz)))
-    conv = gdist.pagerank(comm, Dm, Om, degrees(), n, bounds)                                                            # to convergence, as the reference runs it
-    return {"workload": f"PageRank R-MAT-{scale} FP32, gap/prmark.py loop (PLUS_SECOND, accum PLUS, w = t/d, |t-r| all-reduced) on {world} row block(s) (BASELINE.json configs[4])",
-            "dtype": "f32", "iterations_timed": its, "ms_per_iteration": round(sec / its * 1e3, 4), "GFLOPS": round(2.0 * nnz_total * its / sec / 1e9, 1), "nnz": nnz_total,
-            "iterations_to_converge": conv[1], "rdiff": float(conv[2]), "kernel": gb.last_kernel_plan()}
+    def account(vs):
+        _, ps = vs.to_dense_arrays()
+        acc[0] += int(degh[ps != 0].sum()) * 12 + int((ps != 0).sum()) * 8 + n * 9 * 6
+    cx.loops.sssp(A, src, before_sweep=account)                                   # (untimed pass)
+    alg = acc[0]
+    out = {"workload": f"SSSP R-MAT-{scale} INT64 MIN_PLUS: v<accum MIN> = v MIN_PLUS A until nothing changes (demo/Intro-Prez.ipynb:1034-1045)", "nnz": nnz, "source": src,
+           "sweeps": sweeps, "reached": int((gp != 0).sum()), "seconds": round(best, 5), "ms_per_sweep": round(best / sweeps * 1e3, 3), "dtype": "int64", "kernels_per_sweep": list(plans),
+           "roofline": roof(alg, best, note="sum over sweeps of E_s*12 + V_s*8 (edges leaving / entries of the operand) + 6 vector streams of 9 B per vertex (output read + write, dup, iseq)")}
+    if not cx.args.no_cpu_baseline:
+        from oracle import oracle as O
+        t = time.perf_counter()
+        dist, pres, osweeps = O.fast_sssp(rowptr.cpu().numpy().view(np.uint32), col.cpu().numpy().view(np.uint32), vals.cpu().numpy(), src)
+        cpu_s = time.perf_counter() - t
+        ok = bool(osweeps == sweeps and np.array_equal(gp != 0, pres != 0) and np.array_equal(gd[pres != 0], dist[pres != 0]))
+        out["parity_vs_oracle"] = "bit-exact distances, same sweep count" if ok else f"MISMATCH (oracle sweeps {osweeps})"
+        out["cpu_baseline"] = {"seconds": round(cpu_s, 3), "cores": O.num_threads(), "kind": "port", "sample": "one pass of oracle fast_sssp (includes its transpose)"}
+    return out
 
 
 if __name__ == "__main__":

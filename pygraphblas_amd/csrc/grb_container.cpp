@@ -140,11 +140,13 @@ void vec_host_assemble(GrB_Vector v) {
   while (b < nb) push_base(b++);
   v->hi.swap(ni); v->hx.swap(nx); P.clear(); P.shrink_to_fit();
 }
-void vec_invalidate_device(GrB_Vector v) { v->dev_valid = false; v->dval.reset(); v->dpres.reset(); v->dnvals = 0; v->dnvals_known = true; v->fe_lb = 0; v->fe_lb_key = nullptr; }
+void vec_invalidate_device(GrB_Vector v) { vec_overwritten(v); v->holes_zero = false; v->dev_valid = false; v->dval.reset(); v->dpres.reset(); v->dnvals = 0; v->dnvals_known = true; v->fe_lb = 0; v->fe_lb_key = nullptr; }
 void vec_invalidate_host(GrB_Vector v) {
+  vec_overwritten(v); v->holes_zero = false;
   v->host_valid = false; v->hi.clear(); v->hx.clear(); v->pending.clear(); v->hi.shrink_to_fit(); v->hx.shrink_to_fit();
 }
 void vec_to_host(GrB_Vector v) {
+  vec_gate(v);
   if (v->iso_full) fail(GrB_INSUFFICIENT_SPACE, ISO_MSG);
   if (v->host_valid) { vec_host_assemble(v); return; }
   const size_t ts = v->type->size; const uint64_t n = v->n;
@@ -159,15 +161,32 @@ void vec_to_host(GrB_Vector v) {
   v->host_valid = true;
 }
 void vec_to_device(GrB_Vector v) {
+  vec_gate(v);
   if (v->dev_valid) return;
   if (v->type->code >= T_FC32) fail(GrB_DOMAIN_MISMATCH, "complex vectors are host-side containers here: no device arithmetic on them");
   need_device();
   vec_host_assemble(v);
   if (v->n > GRB_DIM_DEVICE_MAX) fail(GrB_INSUFFICIENT_SPACE, "vector length exceeds the 32-bit index range of the HBM bitmap layout");
   const size_t ts = v->type->size; const uint64_t n = v->n;
+  v->dval.alloc(n * ts ? n * ts : 1); v->dpres.alloc(n ? n : 1);
+  if (n && v->hi.size() * 16 <= n) {
+    // few entries (an empty output vector, the one-entry frontier of a BFS): zero the bitmap in HBM and scatter the entries —
+    // staging n zero bytes on the host and copying them cost 2 x 15 ms per PageRank run at R-MAT-25 and half of a BFS at R-MAT-22
+    const uint32_t k = (uint32_t)v->hi.size();
+    GRB_HIP(hipMemsetAsync(v->dval.p, 0, n * ts, stream())); GRB_HIP(hipMemsetAsync(v->dpres.p, 0, n, stream()));
+    if (k) {
+      std::vector<uint32_t> i32(k); for (uint32_t e = 0; e < k; e++) i32[e] = (uint32_t)v->hi[e];
+      DevBuf di((size_t)k * 4), dx((size_t)k * ts);
+      GRB_HIP(hipMemcpyAsync(di.p, i32.data(), (size_t)k * 4, hipMemcpyHostToDevice, stream()));
+      GRB_HIP(hipMemcpyAsync(dx.p, v->hx.data(), (size_t)k * ts, hipMemcpyHostToDevice, stream()));
+      scatter_entries(k, di.as<uint32_t>(), dx.p, ts, v->dval.p, v->dpres.as<uint8_t>());
+      GRB_HIP(hipStreamSynchronize(stream()));                          // the host staging vectors go out of scope
+    }
+    v->dnvals = k; v->dnvals_known = true; v->dev_valid = true;
+    return;
+  }
   std::vector<uint8_t> val(n * ts, 0), pres(n, 0);
   for (size_t k = 0; k < v->hi.size(); k++) { pres[v->hi[k]] = 1; memcpy(&val[v->hi[k] * ts], &v->hx[k * ts], ts); }
-  v->dval.alloc(n * ts ? n * ts : 1); v->dpres.alloc(n ? n : 1);
   if (n) {
     GRB_HIP(hipMemcpyAsync(v->dval.p, val.data(), n * ts, hipMemcpyHostToDevice, stream()));
     GRB_HIP(hipMemcpyAsync(v->dpres.p, pres.data(), n, hipMemcpyHostToDevice, stream()));
@@ -176,10 +195,12 @@ void vec_to_device(GrB_Vector v) {
   v->dnvals = v->hi.size(); v->dnvals_known = true; v->dev_valid = true;
 }
 uint64_t vec_dev_nvals(GrB_Vector v) {
+  vec_gate(v);
   if (!v->dnvals_known) { v->dnvals = count_present(v->dpres.as<uint8_t>(), v->n); v->dnvals_known = true; }
   return v->dnvals;
 }
 uint64_t vec_nvals(GrB_Vector v) {
+  vec_gate(v);
   if (v->iso_full) return v->n;
   if (v->host_valid) { vec_host_assemble(v); return v->hi.size(); }
   return vec_dev_nvals(v);
@@ -372,13 +393,16 @@ GrB_Info GrB_Vector_new(GrB_Vector* v, GrB_Type type, GrB_Index n) {
 }
 GrB_Info GrB_Vector_free(GrB_Vector* v) {
   if (!v || !*v) return GrB_SUCCESS;
-  if (check_obj(*v)) { (*v)->magic = GRB_FREED; delete *v; }
+  if (check_obj(*v)) {
+    if ((*v)->lazy | (*v)->q_reads) { GrB_Vector x = *v; (void)guarded(x, [&] { vec_overwritten(x); }); }   // deferred work that reads it runs first; work that only wrote it is dropped
+    (*v)->magic = GRB_FREED; delete *v; }
   *v = nullptr; return GrB_SUCCESS;
 }
 GrB_Info GrB_Vector_dup(GrB_Vector* w, const GrB_Vector u) {
   if (!w) return GrB_NULL_POINTER; CHECK_VEC(u);
   GrB_Vector r = nullptr; GrB_Info info = GrB_Vector_new(&r, u->type, u->n); if (info) return info;
   info = guarded(u, [&] {
+    vec_gate(u);
     if (u->iso_full) { r->iso_full = true; memcpy(r->iso_val, u->iso_val, 16); }
     else if (u->host_valid) { vec_host_assemble(u); r->hi = u->hi; r->hx = u->hx; }
     else {
@@ -392,12 +416,12 @@ GrB_Info GrB_Vector_dup(GrB_Vector* w, const GrB_Vector u) {
   if (info) { GrB_Vector_free(&r); return info; }
   *w = r; return GrB_SUCCESS;
 }
-GrB_Info GrB_Vector_clear(GrB_Vector v) { CHECK_VEC(v); v->hi.clear(); v->hx.clear(); v->pending.clear(); v->host_valid = true; v->iso_full = false; vec_invalidate_device(v); return GrB_SUCCESS; }
+GrB_Info GrB_Vector_clear(GrB_Vector v) { CHECK_VEC(v); if (v->lazy | v->q_reads) { GrB_Info e = guarded(v, [&] { vec_overwritten(v); }); if (e) return e; } v->hi.clear(); v->hx.clear(); v->pending.clear(); v->host_valid = true; v->iso_full = false; vec_invalidate_device(v); return GrB_SUCCESS; }
 GrB_Info GrB_Vector_size(GrB_Index* n, const GrB_Vector v) { if (!n) return GrB_NULL_POINTER; CHECK_VEC(v); *n = v->n; return GrB_SUCCESS; }
 GrB_Info GrB_Vector_nvals(GrB_Index* n, const GrB_Vector v) { if (!n) return GrB_NULL_POINTER; CHECK_VEC(v); return guarded(v, [&] { *n = vec_nvals(v); }); }
 GrB_Info GrB_Vector_wait(GrB_Vector* v) {
   if (!v) return GrB_NULL_POINTER; CHECK_VEC(*v);
-  return guarded(*v, [&] { if ((*v)->host_valid) vec_host_assemble(*v); if (device_ok()) GRB_HIP(hipStreamSynchronize(stream())); });
+  return guarded(*v, [&] { vec_gate(*v); if ((*v)->host_valid) vec_host_assemble(*v); if (device_ok()) GRB_HIP(hipStreamSynchronize(stream())); });
 }
 GrB_Info GrB_Vector_error(const char** s, const GrB_Vector v) { if (!s) return GrB_NULL_POINTER; CHECK_VEC(v); *s = v->err.empty() ? g_last_error.c_str() : v->err.c_str(); return GrB_SUCCESS; }
 GrB_Info GxB_Vector_type(GrB_Type* t, const GrB_Vector v) { if (!t) return GrB_NULL_POINTER; CHECK_VEC(v); *t = v->type; return GrB_SUCCESS; }
@@ -421,7 +445,7 @@ GrB_Info GxB_Vector_Option_get(GrB_Vector v, int field, ...) {
   CHECK_VEC(v); va_list ap; va_start(ap, field); GrB_Info info = GrB_SUCCESS;
   switch (field) {
     case 32: { int* p = va_arg(ap, int*); if (p) *p = v->sparsity_control; break; }
-    case 33: { int* p = va_arg(ap, int*); if (p) *p = v->dev_valid && !v->host_valid ? (vec_dev_nvals(v) == v->n ? 8 : 4) : 2; break; }
+    case 33: { int* p = va_arg(ap, int*); (void)guarded(v, [&] { vec_gate(v); }); if (p) *p = v->dev_valid && !v->host_valid ? (vec_dev_nvals(v) == v->n ? 8 : 4) : 2; break; }
     case 1: { int* p = va_arg(ap, int*); if (p) *p = 1; break; }
     case 34: { double* p = va_arg(ap, double*); if (p) *p = 0.04; break; }
     default: info = GrB_INVALID_VALUE;

@@ -149,6 +149,14 @@ struct GrB_Vector_opaque {
   // only added (scalar assign under a mask without replace — the `v[q] = level` of a BFS loop): a masked product whose operand was
   // already too heavy for a push step needs no recount to stay a pull step.  A stale value can only cost speed, never correctness.
   uint64_t fe_lb = 0; const void* fe_lb_key = nullptr;
+  // ---- non-blocking state (grb_lazy.cpp; the library is initialised GrB_NONBLOCKING by the reference, pygraphblas/__init__.py:251-256) ----
+  // lazy == 1: `w(:) = lazy_fill` over every index was requested and nothing has been written yet (no buffers): a product that
+  //            accumulates into w with its monoid's operator folds the fill into its own store; anything else materialises it.
+  // lazy == 2: w is the output of queued element-wise operations (its stored value, if any, is the old one).
+  // q_reads:   queued operations that read this vector's stored value — it must not change before they ran.
+  // Every access goes through vec_gate() (vec_to_device / vec_to_host / vec_nvals / the entry points of grb_container.cpp).
+  int lazy = 0; uint8_t lazy_fill[16] = {0}; int q_reads = 0;
+  bool holes_zero = false;     // the device values of absent positions are all-zero bits (written so by the element-wise chain kernel)
   int sparsity_control = 15;
   std::string err;
 };
@@ -181,6 +189,10 @@ void hyper_mat_ewise(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, GrB_BinaryO
 // scalar into a region on the host mirror (grb_host_ops.cpp): for complex containers and for dimensions beyond the device layout
 void host_assign_scalar(GrB_Matrix C, GrB_Matrix Mask, GrB_BinaryOp accum, const void* x, int xcode, const GrB_Index* I, GrB_Index ni, const GrB_Index* J, GrB_Index nj, GrB_Descriptor desc);
 void host_assign_scalar(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const void* x, int xcode, const GrB_Index* I, GrB_Index ni, GrB_Descriptor desc);
+void vec_resolve(GrB_Vector v);           // complete deferred work that involves v (grb_lazy.cpp)
+inline void vec_gate(GrB_Vector v) { if (v->lazy | v->q_reads) vec_resolve(v); }
+void vec_overwritten(GrB_Vector v);       // v's value is about to be replaced as a whole: deferred work that only produced it is dropped
+bool nonblocking();                       // GrB_init(GrB_NONBLOCKING) and not GRB_MI355X_BLOCKING=1
 void vec_host_assemble(GrB_Vector v);
 void vec_to_host(GrB_Vector v);
 void vec_to_device(GrB_Vector v);
@@ -205,6 +217,7 @@ void vec_cast_fill_values(int dst_code, void* dst, int src_code, const void* src
 void build_allow(uint64_t n, int mcode, const void* mval, const uint8_t* mpres, bool structural,
                  bool complement, uint8_t* allow);
 uint64_t count_present(const uint8_t* pres, uint64_t n);
+void scatter_entries(uint32_t k, const uint32_t* idx_dev, const void* vals_dev, size_t ts, void* val, uint8_t* pres);   // val[idx[e]] = vals[e], pres[idx[e]] = 1
 uint64_t frontier_edges(const uint8_t* pres, const uint32_t* rowptr, uint64_t n);
 uint64_t frontier_edges_and_count(const uint8_t* pres, const uint32_t* rowptr, uint64_t n, uint64_t* count);
 

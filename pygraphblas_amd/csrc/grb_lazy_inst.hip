@@ -1,0 +1,209 @@
+// grb_lazy_inst.hip — k_vec_chain (compiled once per value type, -DGRB_INST_TYPE=..., like the SpMV kernels): a short queue of element-wise vector operations (grb_lazy.cpp) as ONE streaming pass over
+// the bitmap layout (val T[n] | present u8[n]), optionally with the monoid reduction of the last result on the way.
+//
+// HBM-bound like every O(n) companion: per position the stored operands are read once (the presence bytes of a
+// full operand are not read at all), every step combines registers, the results that some vector must hold afterwards are
+// written once — zeros where a result has no entry, so that a later product may gather from the values without a fill pass.
+// `t -= r; t = abs(t); t.reduce_float()` (gap/prmark.py:24-26) moves 3 x 4 B per vertex instead of 8 x 4 + 6 x 1 in four kernels.
+// The operator codes are wave-uniform kernel arguments: one scalar branch per step, as in the runtime-opcode semirings.
+#include "grb_api.hpp"
+#include "grb_device.hpp"
+#include "grb_lazy.hpp"
+
+namespace grb {
+
+template <class T> struct ChainK {
+  uint64_t n; int nsteps, next;
+  const T* ev[CHAIN_MAX_IN]; const uint8_t* ep[CHAIN_MAX_IN];      // always valid addresses (unused slots repeat slot 0): the loads are unconditional
+  uint32_t full_mask, used_mask;                                    // bit k: operand k has every position present / slot k is in use
+  T* ov[CHAIN_MAX_OUT]; uint8_t* op[CHAIN_MAX_OUT];
+  int kind[CHAIN_MAX_STEPS], opc[CHAIN_MAX_STEPS], mode[CHAIN_MAX_STEPS], uni[CHAIN_MAX_STEPS], sa[CHAIN_MAX_STEPS], sb[CHAIN_MAX_STEPS], out[CHAIN_MAX_STEPS];
+  T scalar[CHAIN_MAX_STEPS];
+  int red_op;
+};
+
+template <class T, int NIN> __device__ __forceinline__ T pickn(const T (&e)[NIN], int k) {
+  T r = e[0];
+#pragma unroll
+  for (int j = 1; j < NIN; j++) r = (k == j) ? e[j] : r;
+  return r;
+}
+
+// RED: 0 no reduction, 1 reduce the last result in T, 2 reduce FP32 values in FP64.  R = the reduction type.  NIN: stored operands read.
+// VEC consecutive positions per lane and step of the grid-stride loop (4: one 16-byte load per operand and lane — two for 8-byte
+// types — and one 4-byte load of presence bytes; 1: the fallback for buffers that are not 16-byte aligned).  All loads of a step are
+// issued before anything is computed and every load is unconditional (a branch around a load makes the compiler wait for it on the
+// spot: the first version of this kernel had ONE load in flight per lane and ran 48 us where the 13 us k_vec_ewise does the same work);
+// results leave as vector stores.
+template <class T, int VEC> struct alignas(sizeof(T) * VEC >= 16 ? 16 : sizeof(T) * VEC) ChainPack { T v[VEC]; };
+template <int VEC> struct alignas(VEC) ChainBytes { uint8_t v[VEC]; };
+
+template <class T, int RED, class R, int NIN, int VEC>
+__global__ __launch_bounds__(256) void k_vec_chain(const ChainK<T> a, const R rid, R* __restrict__ partial) {
+  R racc = rid;
+  const uint64_t stride = gridDim.x * 256ull * VEC;
+  for (uint64_t base = (blockIdx.x * 256ull + threadIdx.x) * VEC; base < a.n; base += stride) {
+    const int nv = a.n - base >= (uint64_t)VEC ? VEC : (int)(a.n - base);       // < VEC only for the lane that holds the vector's tail
+    T e[VEC][NIN]; bool p[VEC][NIN];
+    if (nv == VEC) {
+      ChainPack<T, VEC> ve[NIN]; ChainBytes<VEC> vp[NIN];
+#pragma unroll
+      for (int k = 0; k < NIN; k++) ve[k] = *(const ChainPack<T, VEC>*)(a.ev[k] + base);
+#pragma unroll
+      for (int k = 0; k < NIN; k++) vp[k] = *(const ChainBytes<VEC>*)(a.ep[k] + base);
+#pragma unroll
+      for (int k = 0; k < NIN; k++) {
+        const bool used = (a.used_mask >> k) & 1u, full = (a.full_mask >> k) & 1u;
+#pragma unroll
+        for (int h = 0; h < VEC; h++) { e[h][k] = ve[k].v[h]; p[h][k] = used && (full || vp[k].v[h] != 0); }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NIN; k++) {
+        const bool used = (a.used_mask >> k) & 1u, full = (a.full_mask >> k) & 1u;
+#pragma unroll
+        for (int h = 0; h < VEC; h++) { const uint64_t i = h < nv ? base + h : base; e[h][k] = a.ev[k][i]; p[h][k] = used && (full || a.ep[k][i] != 0); }
+      }
+    }
+    T ov[CHAIN_MAX_OUT][VEC]; bool opv[CHAIN_MAX_OUT][VEC];
+#pragma unroll
+    for (int oo = 0; oo < CHAIN_MAX_OUT; oo++)
+#pragma unroll
+      for (int h = 0; h < VEC; h++) { ov[oo][h] = T(); opv[oo][h] = false; }
+    T acc[VEC]; bool ap[VEC];
+#pragma unroll
+    for (int h = 0; h < VEC; h++) { acc[h] = T(); ap[h] = false; }
+#pragma unroll 1
+    for (int s = 0; s < a.nsteps; s++) {                                 // (not unrolled: the step descriptors are scalar loads, the operator switches exist VEC times)
+      // one operator evaluation per step: eWise f(x, y) on stored operands / the previous result; apply with a bound scalar is the
+      // same call with the scalar in one seat; only a unary operator takes the other switch.  (FULL = false: the compact switches —
+      // FIRST .. LXOR and IDENTITY .. BNOT; grb_lazy.cpp queues nothing else.)
+      const int ia = a.sa[s], ib = a.sb[s], kd = a.kind[s], m = a.mode[s], opc = a.opc[s], o = a.out[s];
+      const bool uni = a.uni[s] != 0; const T sc = a.scalar[s];
+#pragma unroll
+      for (int h = 0; h < VEC; h++) {
+        const T x = ia == CHAIN_PREV ? acc[h] : pickn<T, NIN>(e[h], ia); const bool xp = ia == CHAIN_PREV ? ap[h] : pickn<bool, NIN>(p[h], ia);
+        T y = sc; bool yp = true;
+        if (kd == 0) { y = ib == CHAIN_PREV ? acc[h] : pickn<T, NIN>(e[h], ib); yp = ib == CHAIN_PREV ? ap[h] : pickn<bool, NIN>(p[h], ib); }
+        T z; bool zp;
+        if (kd == 1 && m == 0) { z = apply_unop<T, false>(opc, x); zp = xp; }
+        else {
+          const bool swap = kd == 1 && m == 1;                            // z = f(s, x)
+          const T fz = apply_binop<T, false, false>(opc, swap ? y : x, swap ? x : y);
+          const bool both = xp && yp;
+          z = both ? fz : (xp ? x : y);
+          zp = (kd == 0 && uni) ? (xp || yp) : both;
+        }
+        acc[h] = zp ? z : T(); ap[h] = zp;
+#pragma unroll
+        for (int oo = 0; oo < CHAIN_MAX_OUT; oo++) if (o == oo) { ov[oo][h] = acc[h]; opv[oo][h] = ap[h]; }
+      }
+    }
+#pragma unroll
+    for (int oo = 0; oo < CHAIN_MAX_OUT; oo++) {
+      if (a.ov[oo]) {
+        if (nv == VEC) {
+          ChainPack<T, VEC> w; ChainBytes<VEC> wp;
+#pragma unroll
+          for (int h = 0; h < VEC; h++) { w.v[h] = ov[oo][h]; wp.v[h] = opv[oo][h] ? 1 : 0; }
+          *(ChainPack<T, VEC>*)(a.ov[oo] + base) = w;
+          if (a.op[oo]) *(ChainBytes<VEC>*)(a.op[oo] + base) = wp;
+        } else {
+#pragma unroll
+          for (int h = 0; h < VEC; h++) if (h < nv) { a.ov[oo][base + h] = ov[oo][h]; if (a.op[oo]) a.op[oo][base + h] = opv[oo][h] ? 1 : 0; }
+        }
+      }
+    }
+    if constexpr (RED != 0) {
+#pragma unroll
+      for (int h = 0; h < VEC; h++) if (h < nv && ap[h]) racc = apply_binop<R, false, false>(a.red_op, racc, (R)acc[h]);
+    }
+  }
+  if constexpr (RED != 0) {
+    // lanes -> wave -> workgroup -> one partial per workgroup; a one-workgroup k_chain_final folds the partials in index order (a fixed
+    // tree: the result does not depend on the order the workgroups ran in).  (Folding them in the last workgroup to finish, behind
+    // an agent-scope fence and a ticket, made every workgroup write back its XCD's L2 in the middle of the stores: 102 us.)
+    __shared__ R sh[4];
+    racc = wave_reduce_op<R, false>(a.red_op, racc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = racc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      R r = sh[0];
+      for (int w = 1; w < 4; w++) r = apply_binop<R, false, false>(a.red_op, r, sh[w]);
+      partial[blockIdx.x] = r;
+    }
+  }
+}
+template <class R> __global__ __launch_bounds__(256) void k_chain_final(const R* __restrict__ partial, uint32_t g, int op, R rid, R* __restrict__ result) {
+  __shared__ R sh[4];
+  R r = rid;
+  for (uint32_t b = threadIdx.x; b < g; b += 256) r = apply_binop<R, false, false>(op, r, partial[b]);
+  r = wave_reduce_op<R, false>(op, r);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = r;
+  __syncthreads();
+  if (threadIdx.x == 0) { R t = sh[0]; for (int w = 1; w < 4; w++) t = apply_binop<R, false, false>(op, t, sh[w]); *result = t; }
+}
+
+template <class T, int RED, class R, int NIN> static void launch_chain(const ChainLaunch& L, void* red_result) {
+  ChainK<T> a{};
+  a.n = L.n; a.nsteps = L.nsteps; a.next = L.next;
+  bool aligned = true;
+  for (int k = 0; k < CHAIN_MAX_IN; k++) {
+    const bool used = k < L.next;
+    a.ev[k] = (const T*)(used ? L.ev[k] : L.ev[0]);
+    a.ep[k] = (used && L.ep[k]) ? L.ep[k] : (const uint8_t*)L.ev[0];        // not looked at for a full or unused operand: any readable n bytes
+    if (used) a.used_mask |= 1u << k;
+    if (used && !L.ep[k]) a.full_mask |= 1u << k;
+    if (((uintptr_t)a.ev[k] & 15) || ((uintptr_t)a.ep[k] & 3)) aligned = false;
+  }
+  for (int k = 0; k < CHAIN_MAX_OUT; k++) {
+    a.ov[k] = k < L.nout ? (T*)L.ov[k] : nullptr; a.op[k] = k < L.nout ? L.op[k] : nullptr;
+    if (((uintptr_t)a.ov[k] & 15) || ((uintptr_t)a.op[k] & 3)) aligned = false;
+  }
+  for (int s = 0; s < CHAIN_MAX_STEPS; s++) {
+    const ChainStepDesc& st = L.st[s];
+    a.kind[s] = st.kind; a.opc[s] = st.op; a.mode[s] = st.mode; a.uni[s] = st.is_union; a.sa[s] = st.src[0]; a.sb[s] = st.src[1]; a.out[s] = s < L.nsteps ? st.out : -1;
+    memcpy(&a.scalar[s], st.scalar, sizeof(T));
+  }
+  a.red_op = L.red.op;
+  // one round of workgroups: 4 per CU are resident whatever the variant's register count (with 2048 workgroups of a 69-register
+  // variant — 7 per CU — the eighth waited for a slot and the kernel ran a second, nearly empty round: 27 us for 50 MB)
+  const uint64_t gmax = (uint64_t)(device_cus() > 0 ? device_cus() : 256) * 4;
+  uint64_t g = (L.n + 256ull * 4 - 1) / (256ull * 4); if (g < 1) g = 1; if (g > gmax) g = gmax; if (g > 2048) g = 2048;
+  R rid{}; R* result = nullptr; R* partial = nullptr;
+  if constexpr (RED != 0) {
+    static thread_local DevBuf work;                                    // [result 16 B | partials]
+    if (!work.p) work.alloc(16 + 2048 * sizeof(double));
+    memcpy(&rid, L.red.identity, sizeof(R));
+    result = (R*)work.p; partial = (R*)((char*)work.p + 16);
+  }
+  if (aligned) hipLaunchKernelGGL((k_vec_chain<T, RED, R, NIN, 4>), dim3((unsigned)g), dim3(256), 0, stream(), a, rid, partial);
+  else hipLaunchKernelGGL((k_vec_chain<T, RED, R, NIN, 1>), dim3((unsigned)g), dim3(256), 0, stream(), a, rid, partial);
+  if constexpr (RED != 0) {
+    hipLaunchKernelGGL((k_chain_final<R>), dim3(1), dim3(256), 0, stream(), (const R*)partial, (uint32_t)g, L.red.op, rid, result);
+    void* pin = pinned_scratch();
+    GRB_HIP(hipMemcpyAsync(pin, result, sizeof(R), hipMemcpyDeviceToHost, stream()));
+    GRB_HIP(hipStreamSynchronize(stream()));
+    memcpy(red_result, pin, sizeof(R));
+  }
+  GRB_HIP(hipGetLastError());
+}
+
+// one translation unit per value type (Makefile: *_inst.hip); the 1- and 2-byte types have no chain kernel (their vectors — BFS levels,
+// frontiers — are not what the deferred element-wise queue is for) and run every operation the blocking way
+template <class T> void vec_chain_launch_t(const ChainLaunch& L, void* red_result) {
+  if constexpr (sizeof(T) >= 4) {
+    auto go = [&](auto nin) {
+      constexpr int NIN = decltype(nin)::value;
+      // (operators that need the math library — pow, trigonometry, ... — are never queued: grb_lazy.cpp runs them the blocking way)
+      if (!L.red.on) launch_chain<T, 0, T, NIN>(L, nullptr);
+      else if (L.red.widen) { if constexpr (std::is_same<T, float>::value) launch_chain<T, 2, double, NIN>(L, red_result); }
+      else launch_chain<T, 1, T, NIN>(L, red_result);
+    };
+    if (L.next <= 2) go(std::integral_constant<int, 2>()); else go(std::integral_constant<int, 4>());
+  }
+}
+using std::int8_t; using std::uint8_t; using std::int16_t; using std::uint16_t; using std::int32_t; using std::uint32_t; using std::int64_t; using std::uint64_t;
+template void vec_chain_launch_t<GRB_INST_TYPE>(const ChainLaunch&, void*);
+
+}  // namespace grb

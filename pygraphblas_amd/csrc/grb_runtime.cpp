@@ -3,6 +3,7 @@
 // one process per GPU, see pygraphblas_amd/dist.py.)
 #include "grb_internal.hpp"
 #include "grb_api.hpp"
+#include "grb_lazy.hpp"
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -160,9 +161,9 @@ using namespace grb;
 
 extern "C" {
 
-GrB_Info GrB_init(int mode) { (void)mode; return do_init(); }
+GrB_Info GrB_init(int mode) { set_nonblocking(mode == 0 /* GrB_NONBLOCKING */); return do_init(); }
 GrB_Info GxB_init(int mode, void* (*m)(size_t), void* (*c)(size_t, size_t), void* (*r)(void*, size_t),
-                  void (*f)(void*), bool ts) { (void)mode; (void)m; (void)c; (void)r; (void)f; (void)ts; return do_init(); }
+                  void (*f)(void*), bool ts) { set_nonblocking(mode == 0); (void)m; (void)c; (void)r; (void)f; (void)ts; return do_init(); }
 GrB_Info GrB_finalize(void) { dev_pool_release(); return GrB_SUCCESS; }
 GrB_Info GrB_getVersion(unsigned int* v, unsigned int* s) { if (v) *v = 1; if (s) *s = 3; return GrB_SUCCESS; }
 

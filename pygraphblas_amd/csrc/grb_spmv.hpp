@@ -25,6 +25,11 @@ struct SpmvCall {
   const uint8_t* allow;     // per-output "mask allows writing" bytes, nullptr = all allowed
   void* tval; uint8_t* tpres;   // output bitmap vector (semiring type)
   int method = SPMV_AUTO;
+  // optional fused epilogue `w = accum(w, t)` with accum = the monoid's own operator, no mask, w full (grb_mxv.cpp):
+  //   epi == 1: w's values are `epi_w` (in place: rows with products become w (+) sum, the others stay), presence bytes untouched
+  //   epi == 2: w is the pending fill `epi_fill` everywhere (`w(:) = s` not yet written): tval = s (+) sum / s, tpres = 1
+  // A kernel that honours it sets *epi_done; otherwise the product lands in tval/tpres as usual and the caller runs the epilogue.
+  int epi = 0; void* epi_w = nullptr; uint8_t epi_fill[16] = {0}; bool* epi_done = nullptr;
 };
 
 const std::string& xcd_mapping();   // "roundrobin8" when workgroup b of a full-chip launch runs on XCD b % 8 (probed once)

@@ -473,9 +473,12 @@ static __global__ void k_xm_max(const uint32_t* __restrict__ cnt, uint32_t nrows
   __syncthreads();
   if (threadIdx.x == 0 && s_m) atomicMax(out, s_m);                  // one device atomic per workgroup
 }
-template <class T, class SR>
+// EPI: 0 y = the row sums, ypres = "the row has entries";  1 y(r) = y(r) (+) sum where the row has entries (in place, ypres untouched: the
+// accumulate of a product into a full vector with the monoid's operator);  2 y(r) = fill (+) sum / fill, ypres = 1 (the same into a vector
+// whose pending `w(:) = fill` was never written: gap/prmark.py:21-23 `r[:] = teleport; r += A' (+).second w` is this one store)
+template <class T, class SR, int EPI = 0>
 __global__ __launch_bounds__(XM_CT) void k_xp_merge(uint32_t nrows, uint32_t nblocks, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ blockptr, const uint16_t* __restrict__ slot,
-                                                    const uint16_t* __restrict__ rowoff, const T* __restrict__ partial, T* __restrict__ y, uint8_t* __restrict__ ypres, const SR sr) {
+                                                    const uint16_t* __restrict__ rowoff, const T* __restrict__ partial, T* __restrict__ y, uint8_t* __restrict__ ypres, const SR sr, const T fill = T()) {
   extern __shared__ __attribute__((aligned(16))) unsigned char xm_lds[];      // m_slots values: XM_SLOTS unless some row has very many sub-rows
   T* const vals = (T*)xm_lds;
   // workgroup w runs on XCD w % 8 (observed, grb_spmv.hip): give every XCD a contiguous eighth of the row blocks, so that the 128-byte
@@ -523,7 +526,9 @@ __global__ __launch_bounds__(XM_CT) void k_xp_merge(uint32_t nrows, uint32_t nbl
       const T red = wave_reduce_op<T, false>(sr.add_op(), has ? part : sr.identity);
       if (lane == L) acc = red;
     }
-    if (live) { y[r] = acc; ypres[r] = o1 > o0 ? 1 : 0; }
+    if constexpr (EPI == 0) { if (live) { y[r] = acc; ypres[r] = o1 > o0 ? 1 : 0; } }
+    else if constexpr (EPI == 1) { if (live && o1 > o0) y[r] = sr.add(y[r], acc); }
+    else { if (live) { y[r] = o1 > o0 ? sr.add(fill, acc) : fill; ypres[r] = 1; } }
   }
 }
 
@@ -745,10 +750,21 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
     if (!launched) hipLaunchKernelGGL((k_spmv_tiles<T, SR>), dim3(ncu), dim3(XT_WAVES * 64), 0, stream(), call, (const XtPanel<T>*)P->args.p, sr);
     const uint32_t nblocks = (uint32_t)(((uint64_t)M.nrows + XP_RB - 1) / XP_RB);
     static const bool old_merge = wp_env("GRB_MI355X_XP_OLD_MERGE", 0) != 0;       // measurement hook: the per-panel merge kernel
-    if (P->m_ok && !old_merge)
-      hipLaunchKernelGGL((k_xp_merge<T, SR>), dim3((P->m_nblocks + XP - 1) / XP * XP), dim3(XM_CT), (size_t)P->m_slots * sizeof(T), stream(), M.nrows, P->m_nblocks, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), P->m_slot.as<uint16_t>(),
-                         P->m_rowoff.as<uint16_t>(), P->partial.as<T>(), (T*)c.tval, c.tpres, sr);
-    else
+    if (P->m_ok && !old_merge) {
+      const dim3 mg((P->m_nblocks + XP - 1) / XP * XP), mb(XM_CT); const size_t ml = (size_t)P->m_slots * sizeof(T);
+      if (c.epi == 1 && c.epi_done) {
+        hipLaunchKernelGGL((k_xp_merge<T, SR, 1>), mg, mb, ml, stream(), M.nrows, P->m_nblocks, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), P->m_slot.as<uint16_t>(),
+                           P->m_rowoff.as<uint16_t>(), P->partial.as<T>(), (T*)c.epi_w, (uint8_t*)nullptr, sr, T());
+        *c.epi_done = true;
+      } else if (c.epi == 2 && c.epi_done) {
+        T fill; memcpy(&fill, c.epi_fill, sizeof(T));
+        hipLaunchKernelGGL((k_xp_merge<T, SR, 2>), mg, mb, ml, stream(), M.nrows, P->m_nblocks, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), P->m_slot.as<uint16_t>(),
+                           P->m_rowoff.as<uint16_t>(), P->partial.as<T>(), (T*)c.tval, c.tpres, sr, fill);
+        *c.epi_done = true;
+      } else
+      hipLaunchKernelGGL((k_xp_merge<T, SR, 0>), mg, mb, ml, stream(), M.nrows, P->m_nblocks, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), P->m_slot.as<uint16_t>(),
+                         P->m_rowoff.as<uint16_t>(), P->partial.as<T>(), (T*)c.tval, c.tpres, sr, T());
+    } else
       hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3(nblocks), dim3(XP_CT), 0, stream(), M.nrows, P->blockptr.as<uint32_t>(), P->lrow.as<uint16_t>(), P->partial.as<T>(),
                          (T*)c.tval, c.tpres, sr);
     g_last_plan += std::string("k_spmv_xcd<") + (sr.is_static ? "static" : "dynamic") + ",subrows=" + std::to_string(P->F) + "," + xcd_mapping() + "> ";

@@ -90,6 +90,19 @@ uint64_t count_present(const uint8_t* pres, uint64_t n) {
   return slot.read_u64();
 }
 
+// ---- a few entries into a zeroed bitmap (upload of a sparse host vector: the `q[start] = True` of a BFS, an empty output) ----------
+__global__ void k_scatter_entries(uint32_t k, const uint32_t* __restrict__ idx, const uint8_t* __restrict__ vals, uint32_t ts, uint8_t* __restrict__ val, uint8_t* __restrict__ pres) {
+  for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < k; e += gridDim.x * 256u) {
+    const uint64_t i = idx[e];
+    for (uint32_t b = 0; b < ts; b++) val[i * ts + b] = vals[(uint64_t)e * ts + b];
+    pres[i] = 1;
+  }
+}
+void scatter_entries(uint32_t k, const uint32_t* idx_dev, const void* vals_dev, size_t ts, void* val, uint8_t* pres) {
+  if (!k) return;
+  hipLaunchKernelGGL(k_scatter_entries, dim3(grid_for(k)), dim3(256), 0, stream(), k, idx_dev, (const uint8_t*)vals_dev, (uint32_t)ts, (uint8_t*)val, pres);
+}
+
 // ---- sum of the row lengths of the present entries (how many edges a push from this frontier would walk) ----------------
 __global__ void k_frontier_edges(const uint8_t* __restrict__ pres, const uint32_t* __restrict__ rowptr, uint64_t n, unsigned long long* out, unsigned long long* out_count) {
   unsigned long long c = 0, np = 0;

@@ -6,6 +6,7 @@
 //   GrB_Vector_eWiseAdd/eWiseMult_*  <- Vector.eadd / emult            (pygraphblas/vector.py:604-833)
 //   GrB_Vector_apply, GxB_Vector_apply_BinaryOp1st/2nd, GxB_Vector_select  (pygraphblas/vector.py:1204-1340)
 #include "grb_opcommon.hpp"
+#include "grb_lazy.hpp"
 
 using namespace grb;
 
@@ -49,6 +50,11 @@ static GrB_Info vec_reduce(void* c, int ccode, GrB_BinaryOp accum, GrB_Monoid mo
   if (!c || !u || !monoid) return GrB_NULL_POINTER; if (!check_obj(u)) return GrB_UNINITIALIZED_OBJECT;
   return guarded(u, [&] {
     if (u->n > GRB_DIM_DEVICE_MAX) { vec_to_host(u); reduce_host_values(c, ccode, accum, monoid, u->type, u->hx); return; }
+    if (u->lazy == 2 && check_obj(monoid) && check_obj(monoid->op) && monoid->op->opcode < B_FIRSTI && monoid->op->xtype == monoid->op->ytype) {
+      // u is the result of queued element-wise operations: their one kernel reduces it on the way (`t -= r; abs(t); reduce_float()`)
+      const int mc = monoid->op->ztype->code; uint8_t r[16] = {0};
+      if (lazy_reduce(u, monoid->op->opcode, mc, monoid->identity, r)) { scalar_accum(c, ccode, r, mc, accum); return; }
+    }
     vec_to_device(u); reduce_common(c, ccode, accum, monoid, u->type->code, u->dval.p, u->dpres.as<uint8_t>(), u->n); });
 }
 static GrB_Info mat_reduce(void* c, int ccode, GrB_BinaryOp accum, GrB_Monoid monoid, GrB_Matrix A) {
@@ -69,6 +75,10 @@ static void vec_assign(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const 
   DevBuf allow_buf, region; bool nothing = false;
   const uint8_t* allow = vector_allow(mask, dv, n, allow_buf, &nothing);
   if (nothing) { if (dv.replace) { GrB_Vector_clear(w); } return; }
+  if (I == GrB_ALL && !mask && !accum) {                     // `w(:) = s`: a note on the vector in non-blocking mode (grb_lazy.cpp)
+    uint8_t sw[16] = {0}; cast_scalar(w->type->code, sw, xcode, x);
+    if (lazy_fill(w, sw)) return;
+  }
   vec_to_device(w);
   const uint8_t* reg = nullptr;
   if (I != GrB_ALL) {
@@ -105,6 +115,7 @@ static void vec_ewise_op(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_
   DevBuf allow_buf; bool nothing = false;
   const uint8_t* allow = vector_allow(mask, dv, n, allow_buf, &nothing);
   if (nothing) { if (dv.replace) GrB_Vector_clear(w); return; }
+  if (!mask && !accum && lazy_ewise(w, op, u, v, is_union)) return;      // queued: runs fused with its neighbours when a result is looked at
   vec_to_device(u); vec_to_device(v);
   const int xc = op->xtype->code;
   DevBuf uc, vc, tval(n * type_size(xc) + 1), tpres(n + 1);
@@ -118,7 +129,7 @@ static void vec_ewise_op(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_
 }
 
 // mode 0: unary op; 1: z = f(s, x); 2: z = f(x, s)
-static void vec_apply_op(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, int mode, int opcode, int opxcode, const void* scalar, int scode,
+static void vec_apply_op(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, int mode, int opcode, int opxcode, int opzcode, const void* scalar, int scode,
                          GrB_Vector u, GrB_Descriptor desc) {
   need_device();
   if (!check_obj(u) || (mask && !check_obj(mask))) fail(GrB_UNINITIALIZED_OBJECT, "apply: uninitialised operand");
@@ -127,10 +138,11 @@ static void vec_apply_op(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, int 
   DevBuf allow_buf; bool nothing = false;
   const uint8_t* allow = vector_allow(mask, dv, n, allow_buf, &nothing);
   if (nothing) { if (dv.replace) GrB_Vector_clear(w); return; }
+  uint8_t s[16] = {0}; if (scalar) cast_scalar(opxcode, s, scode, scalar);
+  if (!mask && !accum && lazy_apply(w, mode, opcode, opxcode, opzcode, s, u)) return;
   vec_to_device(u);
   DevBuf uc, tval(n * type_size(opxcode) + 1), tpres(n + 1);
   const void* uv = cast_values(opxcode, u->type->code, u->dval.p, n, uc);
-  uint8_t s[16] = {0}; if (scalar) cast_scalar(opxcode, s, scode, scalar);
   vec_apply(opxcode, n, uv, u->dpres.as<uint8_t>(), mode, opcode, s, tval.p, tpres.as<uint8_t>());
   vector_write_back(w, opxcode, tval, tpres, allow, accum, dv.replace, false, u->dnvals_known ? u->dnvals : ~0ull);     // apply keeps the pattern
 }
@@ -155,7 +167,7 @@ GrB_Info GrB_Vector_eWiseMult_Semiring(GrB_Vector w, const GrB_Vector mask, cons
 GrB_Info GrB_Vector_apply(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_UnaryOp op, const GrB_Vector u, const GrB_Descriptor desc) {
   VEC_GUARD(w); if (!op || !u) return GrB_NULL_POINTER; if (!check_obj(op)) return GrB_UNINITIALIZED_OBJECT;
   return guarded(w, [&] { if (op->opcode >= U_POSITIONI) not_implemented("positional / user-defined unary operator");
-    vec_apply_op(w, mask, accum, 0, op->opcode, op->xtype->code, nullptr, 0, u, desc); });
+    vec_apply_op(w, mask, accum, 0, op->opcode, op->xtype->code, op->ztype->code, nullptr, 0, u, desc); });
 }
 
 GrB_Info GxB_Vector_select(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GxB_SelectOp op, const GrB_Vector u, const GxB_Scalar thunk, const GrB_Descriptor desc) {
@@ -195,9 +207,9 @@ GrB_Info GxB_Vector_select(GrB_Vector w, const GrB_Vector mask, const GrB_Binary
   GrB_Info GrB_Vector_assign_##SUF(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, CT x, const GrB_Index* I, GrB_Index ni, const GrB_Descriptor desc) { \
     VEC_GUARD(w); return guarded(w, [&] { vec_assign(w, mask, accum, &x, CODE, I, ni, desc); }); } \
   GrB_Info GxB_Vector_apply_BinaryOp1st_##SUF(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, CT x, const GrB_Vector u, const GrB_Descriptor desc) { \
-    VEC_GUARD(w); if (!op || !u) return GrB_NULL_POINTER; return guarded(w, [&] { check_binop(op, "apply"); vec_apply_op(w, mask, accum, 1, op->opcode, op->xtype->code, &x, CODE, u, desc); }); } \
+    VEC_GUARD(w); if (!op || !u) return GrB_NULL_POINTER; return guarded(w, [&] { check_binop(op, "apply"); vec_apply_op(w, mask, accum, 1, op->opcode, op->xtype->code, op->ztype->code, &x, CODE, u, desc); }); } \
   GrB_Info GxB_Vector_apply_BinaryOp2nd_##SUF(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Vector u, CT y, const GrB_Descriptor desc) { \
-    VEC_GUARD(w); if (!op || !u) return GrB_NULL_POINTER; return guarded(w, [&] { check_binop(op, "apply"); vec_apply_op(w, mask, accum, 2, op->opcode, op->xtype->code, &y, CODE, u, desc); }); }
+    VEC_GUARD(w); if (!op || !u) return GrB_NULL_POINTER; return guarded(w, [&] { check_binop(op, "apply"); vec_apply_op(w, mask, accum, 2, op->opcode, op->xtype->code, op->ztype->code, &y, CODE, u, desc); }); }
 GRB_TYPED_VECOPS(BOOL, bool, T_BOOL) GRB_TYPED_VECOPS(INT8, int8_t, T_INT8) GRB_TYPED_VECOPS(UINT8, uint8_t, T_UINT8)
 GRB_TYPED_VECOPS(INT16, int16_t, T_INT16) GRB_TYPED_VECOPS(UINT16, uint16_t, T_UINT16) GRB_TYPED_VECOPS(INT32, int32_t, T_INT32)
 GRB_TYPED_VECOPS(UINT32, uint32_t, T_UINT32) GRB_TYPED_VECOPS(INT64, int64_t, T_INT64) GRB_TYPED_VECOPS(UINT64, uint64_t, T_UINT64)

@@ -53,15 +53,17 @@ def bfs(A, start, plans=None):
     return v, level - 1
 
 
-def sssp(A, start, plans=None, max_sweeps=None):
+def sssp(A, start, plans=None, max_sweeps=None, before_sweep=None):
     """Shortest path lengths from `start` by repeated `v<accum MIN> = v MIN_PLUS A` until a sweep changes nothing.
-    Returns (v, sweeps)."""
+    `before_sweep(v)` (bench.py's byte accounting) sees the operand of every product.  Returns (v, sweeps)."""
     from . import Vector, last_kernel_plan
     typ = A.type
     v = Vector.sparse(typ, A.nrows)
     v[start] = 0
     sweeps = 0
     while max_sweeps is None or sweeps < max_sweeps:
+        if before_sweep is not None:
+            before_sweep(v)
         w = v.dup()
         v.vxm(A, semiring=typ.MIN_PLUS, accum=typ.MIN, out=v)
         if plans is not None:

@@ -162,18 +162,31 @@ def test_library_rccl_path_with_a_communicator_of_one(gb, gpu):
         assert lib.GrBX_dist_finalize() == 0
 
 
-def test_bench_py_runs_its_two_rank_path_on_one_gpu(gpu):
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_py_runs_its_two_rank_path_on_one_gpu(gpu, scaling):
     """`bench.py --gpus 2` — what the driver launches for the scaling curve — end to end on this box: two ranks on GPU 0
-    (BENCH_DEVICE_OVERRIDE), the exchange through the host transport (RCCL cannot put two ranks on one device), at R-MAT-17
-    per rank.  The JSON line must parse, carry the N = 2 fields and a PageRank sub-object whose iteration count matches the
-    single-process loop."""
+    (BENCH_DEVICE_OVERRIDE), the exchange through the host transport (RCCL cannot put two ranks on one device), at R-MAT-17.
+    The JSON line must parse, carry the N = 2 fields in both scaling modes, the other mode's SpMV with per-phase times, and the
+    distributed mxm / bfs / pagerank sub-objects with their parity fields (triangle count bit-exact against the single-GPU
+    count and the oracle, level vector bit-exact on every rank's slice, PageRank converging in the single-process count)."""
     import json, subprocess
     env = dict(os.environ, BENCH_DEVICE_OVERRIDE="0", BENCH_TRANSPORT="host", MASTER_ADDR="127.0.0.1")
-    port = 29800 + (os.getpid() % 1000)
+    port = 29800 + (os.getpid() % 1000) + (7 if scaling == "strong" else 0)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--scale", "17"], capture_output=True, text=True, timeout=500, env=env, cwd=ROOT)
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--blocks", "2", "--scale", "17", "--pr-scale", "16", "--scaling", scaling],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-3000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["n"] == 1 << 18
-    assert d["roofline"]["bound"] == "hbm" and d["pagerank"]["iterations_to_converge"] > 5 and d["pagerank"]["dtype"] == "f32"
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == scaling and d["value"] > 0
+    assert d["config"]["n"] == (1 << 18 if scaling == "weak" else 1 << 17)
+    assert len(d["ms_per_step_blocks"]) == 2 and "host copies" in d["config"]["transport"]
+    other = d["spmv_strong" if scaling == "weak" else "spmv_weak"]
+    assert other["n"] == (1 << 17 if scaling == "weak" else 1 << 18) and other["GFLOPS"] > 0
+    for ph in (d["phases"], other["phases"]):
+        assert ph["exchange_ms"] > 0 and ph["diag_ms"] > 0 and ph["offdiag_ms"] > 0
+    assert d["roofline"]["bound"] == "hbm"
+    assert d["mxm"]["parity_vs_single_gpu"] == "bit-exact" and d["mxm"]["parity_vs_oracle"] == "bit-exact" and d["mxm"]["roofline"]["frac"] > 0
+    assert d["bfs"]["parity_vs_single_gpu"].startswith("bit-exact") and d["bfs"]["parity_vs_oracle"].startswith("bit-exact") and d["bfs"]["roofline"]["frac"] > 0
+    assert d["pagerank"]["iterations_to_converge"] > 5 and d["pagerank"]["dtype"] == "f32" and d["pagerank"]["roofline"]["frac"] > 0
+    assert d["pagerank_scale25"]["iterations_to_converge"] > 5 and "R-MAT-16" in d["pagerank_scale25"]["workload"]
