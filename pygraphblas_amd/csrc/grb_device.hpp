@@ -142,6 +142,18 @@ template <class T> __device__ __forceinline__ bool val_eq(T a, T b) {
 }
 #define memcmp_eq(a, b) ::grb::val_eq(a, b)
 
+// ---- a mask entry's truth from the mask vector itself (value cast to BOOL: x != 0; -0.0 is false, NaN true) -------------------------
+// `mcode` is wave-uniform: one scalar branch.  Lets a kernel read the mask directly instead of "allow" bytes a k_allow pass prepared.
+__device__ __forceinline__ bool mask_truth_at(const void* mval, int mcode, uint64_t p, bool structural) {
+  if (structural) return true;
+  switch (type_size(mcode)) {
+    case 1: return ((const uint8_t*)mval)[p] != 0;
+    case 2: return ((const uint16_t*)mval)[p] != 0;
+    case 4: return mcode == T_FP32 ? ((const float*)mval)[p] != 0.0f : ((const uint32_t*)mval)[p] != 0;
+    default: return mcode == T_FP64 ? ((const double*)mval)[p] != 0.0 : ((const uint64_t*)mval)[p] != 0;
+  }
+}
+
 // ---- a device word the host can read back (count results, flags) ------------------------------------------
 // 256 bytes of page-locked host memory per thread: the landing place of the small device-to-host readbacks (counts, reduced scalars)
 inline void* pinned_scratch() {
@@ -187,6 +199,10 @@ void vec_ewise(int code, uint64_t n, const void* uval, const uint8_t* upres, con
                bool is_union, void* tval, uint8_t* tpres);
 void vec_apply(int code, uint64_t n, const void* uval, const uint8_t* upres, int mode, int op, const void* scalar, void* tval, uint8_t* tpres);
 void vec_assign_scalar(int code, uint64_t n, void* wval, uint8_t* wpres, const uint8_t* allow, const uint8_t* region, const void* scalar, int accum, bool replace);
+// the same over every index with the mask vector read in place (no "allow" pass): `v.assign_scalar(level, mask=q)` of a BFS level is one kernel
+void vec_assign_scalar_masked(int code, uint64_t n, void* wval, uint8_t* wpres, int mcode, const void* mval, const uint8_t* mpres, bool mstruct, bool mcomp, const void* scalar, int accum, bool replace);
+// allow bytes of a mask AND its values cast to BOOL in one pass (the mask is also the operand: `v.vxm(A, mask=v, desc=RC)` with a BOOL semiring)
+void build_allow_and_bool(uint64_t n, int mcode, const void* mval, const uint8_t* mpres, bool structural, bool complement, uint8_t* allow, uint8_t* as_bool);
 void select_value_flags(int code, uint64_t n, const void* val, const uint8_t* pres, int sel, const void* thunk, uint8_t* keep);
 
 }  // namespace grb

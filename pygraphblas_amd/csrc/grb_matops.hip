@@ -228,4 +228,31 @@ void csr_reduce_rows(int code, const DevCSR& A, const void* aval, int op, void* 
 }
 
 
+// ---- a full one-valued matrix: `Matrix.dense(T, ns, n)` / `M[:, :] = x` (the ns x n batches of the BC sweeps, gap/bcmark.py:19-20, 48) ----
+// Built in HBM by one kernel (round 2 built the three arrays with numpy and uploaded 134 MB per batch: half of the algorithm's time).
+template <int TS> __global__ void k_dense_fill(uint32_t nrows, uint32_t ncols, uint64_t total, uint64_t lo, uint64_t hi, uint32_t* __restrict__ rowptr, uint32_t* __restrict__ col, uint8_t* __restrict__ val) {
+  for (uint64_t e = blockIdx.x * 256ull + threadIdx.x; e < total; e += gridDim.x * 256ull) {
+    col[e] = (uint32_t)(e % ncols);
+    if constexpr (TS == 8) ((uint64_t*)val)[e] = lo;
+    else if constexpr (TS == 4) ((uint32_t*)val)[e] = (uint32_t)lo;
+    else if constexpr (TS == 2) ((uint16_t*)val)[e] = (uint16_t)lo;
+    else val[e] = (uint8_t)lo;
+    if (e <= nrows) rowptr[e] = (uint32_t)(e * ncols);
+  }
+  if (total <= nrows) for (uint64_t e = total + blockIdx.x * 256ull + threadIdx.x; e <= nrows; e += gridDim.x * 256ull) rowptr[e] = (uint32_t)(e * ncols);
+  (void)hi;
+}
+void csr_dense_fill(uint32_t nrows, uint32_t ncols, const void* scalar, size_t ts, DevCSR& out) {
+  const uint64_t total = (uint64_t)nrows * ncols;
+  out.clear(); out.nrows = nrows; out.ncols = ncols; out.nnz = total;
+  out.rowptr.alloc(((size_t)nrows + 1) * 4); out.col.alloc(total * 4 + 8); out.val.alloc(total * ts + 8);
+  uint64_t lo = 0; memcpy(&lo, scalar, ts < 8 ? ts : 8);
+  uint64_t g = ((total > nrows ? total : (uint64_t)nrows + 1) + 255) / 256; if (g < 1) g = 1; if (g > 8192) g = 8192;
+#define GRB_DF(TS_) hipLaunchKernelGGL((k_dense_fill<TS_>), dim3((unsigned)g), dim3(256), 0, stream(), nrows, ncols, total, lo, 0ull, out.rowptr.as<uint32_t>(), out.col.as<uint32_t>(), out.val.as<uint8_t>())
+  if (ts == 8) GRB_DF(8); else if (ts == 4) GRB_DF(4); else if (ts == 2) GRB_DF(2); else GRB_DF(1);
+#undef GRB_DF
+  GRB_HIP(hipGetLastError());
+  out.valid = true;
+}
+
 }  // namespace grb

@@ -14,6 +14,7 @@ void select_positional_flags(const DevCSR& A, int sel, int64_t k, uint8_t* keep)
 void mask_flags(const DevCSR& Tm, const DevCSR& M, int mcode, bool mstruct, bool mcomp, uint8_t* keep);
 void csr_reduce_rows(int code, const DevCSR& A, const void* aval, int op, void* tval, uint8_t* tpres);
 void csr_row_indices(const DevCSR& A, uint32_t* rowidx);
+void csr_dense_fill(uint32_t nrows, uint32_t ncols, const void* scalar, size_t ts, DevCSR& out);     // every position holds `scalar`: rowptr[i] = i ncols, col[e] = e mod ncols
 
 // ---- SpGEMM ----------------------------------------------------------------------------------------------
 struct SpgemmCall {

@@ -211,6 +211,13 @@ void do_assign_scalar(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, const void
   need_device(); if (M) check_mat(M, "assign");
   const DescView dv(desc);
   if (M && (M->nrows != C->nrows || M->ncols != C->ncols)) fail(GrB_DIMENSION_MISMATCH, "assign: mask dimensions");
+  if (I == GrB_ALL && J == GrB_ALL && !M && !accum && !dv.mask_comp && C->nrows * C->ncols <= 0xFFFFFFF0ull && C->nrows * C->ncols > 0) {
+    // every position of C: the full one-valued matrix, written by one kernel (`Matrix.dense`, `M[:, :] = x`)
+    uint8_t s0[16]; cast_scalar(C->type->code, s0, xcode, x);
+    DevCSR T; csr_dense_fill((uint32_t)C->nrows, (uint32_t)C->ncols, s0, C->type->size, T);
+    adopt(C, T, C->type->code);
+    return;
+  }
   // (indices are validated as 64-bit values before they are narrowed to the device layout's 32 bits)
   const std::vector<uint64_t> rows64 = expand_index_list(I, ni, C->nrows, "assign (rows)"), cols64 = expand_index_list(J, nj, C->ncols, "assign (columns)");
   std::vector<uint32_t> rows(rows64.begin(), rows64.end()), cols(cols64.begin(), cols64.end());

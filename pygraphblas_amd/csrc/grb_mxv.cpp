@@ -32,8 +32,16 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   if (env) method = !strcmp(env, "adaptive") ? SPMV_ADAPTIVE : !strcmp(env, "rowgroup") ? SPMV_ROWGROUP : !strcmp(env, "push") ? SPMV_PUSH : !strcmp(env, "wavepipe") ? SPMV_WAVEPIPE : !strcmp(env, "xcd") ? SPMV_XCD : SPMV_AUTO;
   g_last_plan.clear();
 
-  DevBuf allow_buf; bool nothing = false;
-  const uint8_t* allow = vector_allow(mask, dv, mr, allow_buf, &nothing);
+  DevBuf allow_buf, ubool; bool nothing = false;
+  const uint8_t* allow = nullptr;
+  if (mask && mask == u && sd.zcode == T_BOOL && u->type->code != T_BOOL && mr) {
+    // the mask is also the operand and the semiring is Boolean (`v.vxm(A, mask=v, desc=RC)` on the UINT8 level vector of a BFS): its
+    // allow bytes and its values as BOOL come out of ONE pass instead of a k_allow and a k_cast
+    vec_to_device(u);
+    allow_buf.alloc(mr); ubool.alloc(mr + 1);
+    build_allow_and_bool(mr, u->type->code, u->dval.p, u->dpres.as<uint8_t>(), dv.mask_struct, dv.mask_comp, allow_buf.as<uint8_t>(), ubool.as<uint8_t>());
+    allow = allow_buf.as<uint8_t>();
+  } else allow = vector_allow(mask, dv, mr, allow_buf, &nothing);
   if (nothing) {   // no mask + complement: nothing may be written; replace clears w
     if (dv.replace) { w->hi.clear(); w->hx.clear(); w->pending.clear(); w->host_valid = true; vec_invalidate_device(w); }
     return;
@@ -99,7 +107,7 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
     ucast.alloc(u->n * zs + 1);
     vec_cast_fill_values(sd.zcode, ucast.p, u->type->code, u->dval.p, u->dpres.as<uint8_t>(), u->n, sd.identity);   // (identity of PLUS / LOR is the 0 / false the two other cases need)
     uval = ucast.p;
-  } else if (uses_u) uval = cast_values(sd.zcode, u->type->code, u->dval.p, u->n, ucast);
+  } else if (uses_u) uval = ubool.p ? ubool.p : cast_values(sd.zcode, u->type->code, u->dval.p, u->n, ucast);
 
   SpmvCall call{};
   call.uval = uval; call.allow = allow; call.tval = tval.p; call.tpres = tpres.as<uint8_t>(); call.method = method;

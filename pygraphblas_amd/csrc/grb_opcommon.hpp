@@ -18,6 +18,18 @@ inline void check_binop(GrB_BinaryOp op, const char* what) {
   if (op->xtype != op->ytype) not_implemented(std::string("mixed-type operator ") + op->name);
 }
 
+// ONE rule for NaN under a floating-point MIN / MAX monoid, on every path: the operator is fmin / fmax (a NaN operand is omitted, as in
+// SuiteSparse), and an entry all of whose products are NaN is NaN — what a reduction that starts from its first product gives
+// (the oracle's rule).  Kernels that start their accumulators from the monoid's identity (push SpMSpV, hash tables, padding lanes
+// of wave reductions) get the same answer when that identity is NaN instead of +-inf: fmin(NaN, x) = x, fmin(NaN, NaN) = NaN — NaN
+// IS the identity of fmin / fmax.  (Round 2: +-inf there dropped such an entry's NaN on some paths and kept it on others.)
+inline bool fp_minmax_identity(int zcode, int addop, uint8_t* identity) {
+  if (!(addop == B_MIN || addop == B_MAX)) return false;
+  if (zcode == T_FP32) { const float q = std::numeric_limits<float>::quiet_NaN(); memcpy(identity, &q, 4); return true; }
+  if (zcode == T_FP64) { const double q = std::numeric_limits<double>::quiet_NaN(); memcpy(identity, &q, 8); return true; }
+  return false;
+}
+
 inline SemiringDesc make_semiring_desc(GrB_Semiring s, bool swap_mult_args) {
   if (!check_obj(s)) fail(GrB_UNINITIALIZED_OBJECT, "semiring is not initialised");
   check_binop(s->mul, "multiply"); check_binop(s->add->op, "monoid");
@@ -28,6 +40,7 @@ inline SemiringDesc make_semiring_desc(GrB_Semiring s, bool swap_mult_args) {
   d.zcode = s->add->op->ztype->code; d.addop = s->add->op->opcode; d.mulop = s->mul->opcode; d.flip = false;
   if (swap_mult_args) { int m; if (mirror_binop(d.mulop, &m)) d.mulop = m; else d.flip = true; }
   memcpy(d.identity, s->add->identity, 16); memcpy(d.terminal, s->add->terminal, 16); d.has_terminal = s->add->has_terminal;
+  fp_minmax_identity(d.zcode, d.addop, d.identity);
   return d;
 }
 

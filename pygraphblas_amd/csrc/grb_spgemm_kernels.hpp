@@ -197,17 +197,32 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
 // Nearly every product misses the mask, and a lookup in the 4-bytes-per-column map is a random HBM access.  A bit filter
 // in LDS (1 Mbit, column mod 2^20: a mask row of 30 000 entries lets ~2 % of the misses through) answers most products
 // without leaving the CU; only the survivors read the map for their exact position.
-constexpr uint32_t SPG_FILTER_WORDS = 32768;        // 2^20 bits = 128 KiB of LDS
-template <class T, class SR>
-__global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T> a, const uint32_t* __restrict__ rows, uint32_t nrows_bin,
+// Round 3: the hits no longer go to HBM one 8-byte atomic at a time (2e9 of them on R-MAT-22's 567 hub rows: 16 GB written for a
+// 0.77 GB result).  The mask row's first LC positions — its lowest columns, the hubs every neighbourhood shares, where nearly all
+// hits land — have their accumulators in LDS (native ds atomics; 32-bit counters when the product only counts, as PLUS_PAIR does)
+// and reach cacc as ONE plain store each at the end of the row; positions behind LC keep the global atomic.  The LDS they take
+// comes out of the filter: 2^18 bits instead of 2^20 (a 30 000-entry mask row lets ~11 % of the misses through to the map).
+constexpr uint32_t SPG_FILTER_WORDS = 8192;         // 2^18 bits = 32 KiB of LDS
+constexpr uint32_t SPG_MAP_LDS_BYTES = 96 * 1024;   // accumulators of the first positions of the mask row
+constexpr uint32_t SPG_MAP_SLICE = 1024;            // entries of A(i,:) per task
+template <class T, class SR, bool CNT32>
+__global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T> a, const uint32_t* __restrict__ rows, uint32_t nrows_bin, uint32_t nslices,
                                                             uint32_t* __restrict__ maps, uint32_t ncols, const SR sr) {
+  typedef typename acc_word<T>::type W;
+  typedef typename std::conditional<CNT32, uint32_t, W>::type LW;        // what an LDS accumulator holds
+  constexpr uint32_t LC = SPG_MAP_LDS_BYTES / sizeof(LW);
+  // counters: 0 = no hit yet.  Generic accumulators start at the identity and carry a flag byte each (LCF words + LCF bytes in the same budget)
+  constexpr uint32_t LCF = CNT32 ? LC : (uint32_t)(SPG_MAP_LDS_BYTES / (sizeof(LW) + 1));
   __shared__ uint32_t s_filter[SPG_FILTER_WORDS];
+  __shared__ LW s_acc[LC];
+  uint8_t* const s_flag = (uint8_t*)(s_acc + LCF);
   constexpr uint32_t HL = 4096;                            // A-entries whose B row is huge: set aside by the waves, then walked by the whole block
   __shared__ uint32_t s_hl[HL];
   __shared__ uint32_t s_nh;
   uint32_t* map = maps + (size_t)blockIdx.x * ncols;       // zero-initialised; entry = mask position + 1
   const int t = threadIdx.x;
   const bool use_a = sr.uses_a(), use_b = sr.uses_u();
+  const W idw = to_word<T>(sr.identity);
   // one B row against the filter and the map: `step` lanes apart, 4 loads in flight per lane
   auto walk = [&](uint32_t pa, uint32_t first, uint32_t be, uint32_t step, uint32_t mb) {
     const T av = use_a ? a.aval[pa] : T();
@@ -219,23 +234,38 @@ __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T>
       for (int u = 0; u < 4; u++) {
         const uint32_t pb = pb0 + step * u; const uint32_t j = ss[u];
         const bool maybe = pb < be && ((s_filter[(j >> 5) & (SPG_FILTER_WORDS - 1)] >> (j & 31)) & 1u);
-        ss[u] = maybe ? map[j] : 0u;                                     // the rare survivors: exact position from the map
+        ss[u] = maybe ? map[j] : 0u;                                     // the survivors: exact position from the map
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const uint32_t pb = pb0 + step * u;
         if (ss[u]) {
-          const T m = sr.mult(av, use_b ? a.bval[pb] : T());
-          word_combine<T>(sr.add_op(), &a.cacc[mb + ss[u] - 1], m);
-          a.cflag[mb + ss[u] - 1] = 1;
+          const uint32_t mp = ss[u] - 1;
+          if (mp < LCF) {
+            if constexpr (CNT32) atomicAdd(&s_acc[mp], 1u);             // PLUS_PAIR: the product is 1
+            else { word_combine<T>(sr.add_op(), (W*)&s_acc[mp], sr.mult(av, use_b ? a.bval[pb] : T())); s_flag[mp] = 1; }
+          } else {
+            word_combine<T>(sr.add_op(), &a.cacc[mb + mp], sr.mult(av, use_b ? a.bval[pb] : T()));
+            a.cflag[mb + mp] = 1;
+          }
         }
       }
     }
   };
-  for (uint32_t ridx = blockIdx.x; ridx < nrows_bin; ridx += gridDim.x) {
+  // a task = SPG_MAP_SLICE consecutive entries of one row's A(i,:): a hub row of 50 000 entries against B rows of thousands is 2e8
+  // products — one workgroup alone on it was the tail of the whole product (33 ms for 4 % of the products).  Tasks are numbered
+  // slice-major, so the slices of the heaviest rows spread over all workgroups; every task builds the row's map for itself.
+  for (uint64_t q = blockIdx.x; q < (uint64_t)nrows_bin * nslices; q += gridDim.x) {
+    const uint32_t ridx = (uint32_t)(q % nrows_bin), sl = (uint32_t)(q / nrows_bin);
     const uint32_t i = rows[ridx];
+    const uint32_t ab0 = a.arp[i], ae0 = a.arp[i + 1];
+    if ((uint64_t)ab0 + (uint64_t)sl * SPG_MAP_SLICE >= ae0) continue;                      // (the whole workgroup takes the same branch)
+    const uint32_t ab = ab0 + sl * SPG_MAP_SLICE, ae = ae0 - ab < SPG_MAP_SLICE ? ae0 : ab + SPG_MAP_SLICE;
+    const bool shared_row = ae0 - ab0 > SPG_MAP_SLICE;                                      // other workgroups accumulate into the same slots
     const uint32_t mb = a.mrp[i], me = a.mrp[i + 1];
     for (uint32_t w = t; w < SPG_FILTER_WORDS; w += 1024) s_filter[w] = 0;
+    const uint32_t nl = (me - mb) < LCF ? (me - mb) : LCF;
+    for (uint32_t w = t; w < nl; w += 1024) { if constexpr (CNT32) s_acc[w] = 0; else { s_acc[w] = (LW)idw; s_flag[w] = 0; } }
     if (t == 0) s_nh = 0;
     __syncthreads();
     for (uint32_t p = mb + t; p < me; p += 1024) if (spgemm_mask_truth(a.mval, a.mcode, p, a.mstruct)) {
@@ -243,7 +273,6 @@ __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T>
       map[j] = p - mb + 1; atomicOr(&s_filter[(j >> 5) & (SPG_FILTER_WORDS - 1)], 1u << (j & 31));
     }
     __threadfence_block(); __syncthreads();
-    const uint32_t ab = a.arp[i], ae = a.arp[i + 1];
     // one wave per entry k of A(i,:): these rows have thousands of k's, most with long B rows; the longest ones are kept
     // for the whole block (a wave alone on a 30 000-entry row leaves the other fifteen waiting at the end of the row)
     for (uint32_t pa = ab + (t >> 6); pa < ae; pa += 16) {
@@ -264,6 +293,16 @@ __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T>
       walk(pa, a.brp[k] + t, a.brp[k + 1], 1024, mb);
     }
     __syncthreads();
+    // the LDS accumulators leave coalesced: plain stores when this task is the row's only one, else one atomic per touched position
+    for (uint32_t w = t; w < nl; w += 1024) {
+      if constexpr (CNT32) {
+        const uint32_t c = s_acc[w];
+        if (c) { if (shared_row) word_combine<T>(B_PLUS, &a.cacc[mb + w], (T)c); else a.cacc[mb + w] = to_word<T>((T)c); a.cflag[mb + w] = 1; }
+      } else if (s_flag[w]) {
+        if (shared_row) word_combine<T>(sr.add_op(), &a.cacc[mb + w], from_word<T>((W)s_acc[w])); else a.cacc[mb + w] = (W)s_acc[w];
+        a.cflag[mb + w] = 1;
+      }
+    }
     for (uint32_t p = mb + t; p < me; p += 1024) map[a.mcol[p]] = 0;
     __threadfence_block(); __syncthreads();
   }
@@ -303,6 +342,8 @@ static __global__ void k_bin_rows(uint32_t nrows, const uint32_t* __restrict__ m
       base = __shfl(base, leader, 64);
       if (b == bb) lists[(size_t)bb * nrows + base + __popcll(m & ((1ull << lane) - 1))] = (uint32_t)r;
     }
+    // counts[5]: the longest A row among the hub-bin rows (their A rows are cut into slices shared by all workgroups)
+    if (__ballot(b == 4)) { uint32_t al4 = (b == 4) ? arp[r + 1] - arp[r] : 0u; al4 = __builtin_amdgcn_wave_reduce_max_u32(al4, 0); if (lane == 0) atomicMax(&counts[5], al4); }
   }
 }
 // entry-parallel compaction of the per-mask-entry accumulators: pos = exclusive scan of the flags
@@ -346,11 +387,12 @@ template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDes
     // everything that can throw (allocation of the position maps of the HBM-map bin) happens before the fork; between fork and
     // join only kernel launches are issued, and the guard joins the side streams again if anything unwinds past it — the
     // accumulators return to the pool only after every bin kernel has been ordered before the library stream
-    DevBuf maps; unsigned nb_map = 0;
+    DevBuf maps; unsigned nb_map = 0; uint32_t nslices = 1;
     if (hc[4]) {
       const uint64_t per_map = (uint64_t)B.ncols * 4, budget = 4ull << 30;          // position maps: at most 4 GiB in all
       uint64_t fit = per_map ? budget / per_map : 256; if (fit < 1) fit = 1;
-      nb_map = (unsigned)std::min<uint64_t>(std::min<uint64_t>(hc[4], 256), fit);
+      nslices = (hc[5] + SPG_MAP_SLICE - 1) / SPG_MAP_SLICE; if (nslices < 1) nslices = 1;
+      nb_map = (unsigned)std::min<uint64_t>(std::min<uint64_t>((uint64_t)hc[4] * nslices, 256), fit);
       maps.alloc((size_t)nb_map * per_map);
       GRB_HIP(hipMemsetAsync(maps.p, 0, (size_t)nb_map * per_map, stream()));
     }
@@ -363,7 +405,14 @@ template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDes
     if (hc[1]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 512, 256, 256>), dim3(nblocks(hc[1], 1)), dim3(256), 0, bs[1], a, L + (size_t)nrows, hc[1], sr);
     if (hc[2]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 2048, 512, 512>), dim3(nblocks(hc[2], 1)), dim3(512), 0, bs[2], a, L + (size_t)2 * nrows, hc[2], sr);
     if (hc[3]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 8192, 1024, 1024>), dim3(nblocks(hc[3], 1)), dim3(1024), 0, bs[3], a, L + (size_t)3 * nrows, hc[3], sr);
-    if (hc[4]) hipLaunchKernelGGL((k_spgemm_masked_map<T, SR>), dim3(nb_map), dim3(1024), 0, stream(), a, L + (size_t)4 * nrows, hc[4], maps.as<uint32_t>(), B.ncols, sr);
+    if (hc[4]) {
+      // a product that only counts (PLUS over PAIR on an integer type): 32-bit LDS counters, 24 576 positions per mask row
+      constexpr bool can_count = SR::is_static && std::is_integral<T>::value && sizeof(T) >= 4;
+      bool counted = false;
+      if constexpr (can_count) if (sr.add_op() == B_PLUS && sr.mul_op() == B_PAIR) {
+        hipLaunchKernelGGL((k_spgemm_masked_map<T, SR, true>), dim3(nb_map), dim3(1024), 0, stream(), a, L + (size_t)4 * nrows, hc[4], nslices, maps.as<uint32_t>(), B.ncols, sr); counted = true; }
+      if (!counted) hipLaunchKernelGGL((k_spgemm_masked_map<T, SR, false>), dim3(nb_map), dim3(1024), 0, stream(), a, L + (size_t)4 * nrows, hc[4], nslices, maps.as<uint32_t>(), B.ncols, sr);
+    }
     ax.join(stream()); guard.joined = true;
     if (hc[4]) GRB_HIP(hipStreamSynchronize(stream()));       // the maps go back to the pool when this scope ends
     g_last_plan += std::string("k_spgemm_masked<") + (sr.is_static ? "static" : "dynamic") + "> bins " + std::to_string(hc[0]) + "/" + std::to_string(hc[1]) + "/" +

@@ -324,6 +324,39 @@ void vec_assign_scalar(int code, uint64_t n, void* wval, uint8_t* wpres, const u
   });
 }
 
+template <class T, bool MATH> __global__ void k_vec_assign_scalar_masked(uint64_t n, T* __restrict__ wval, uint8_t* __restrict__ wpres, int mcode, const void* __restrict__ mval,
+                                                                         const uint8_t* __restrict__ mpres, bool mstruct, bool mcomp, T s, int accum, bool replace) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {
+    const bool ok = (mpres[i] != 0 && mask_truth_at(mval, mcode, i, mstruct)) != mcomp;
+    if (ok) {
+      if (accum >= 0 && wpres[i]) wval[i] = apply_binop<T, true, MATH>(accum, wval[i], s); else wval[i] = s;
+      wpres[i] = 1;
+    } else if (replace) wpres[i] = 0;
+  }
+}
+void vec_assign_scalar_masked(int code, uint64_t n, void* wval, uint8_t* wpres, int mcode, const void* mval, const uint8_t* mpres, bool mstruct, bool mcomp, const void* scalar, int accum, bool replace) {
+  if (!n) return;
+  dispatch_type(code, [&]<class T>() {
+    T s; memcpy(&s, scalar, sizeof(T));
+    if (accum >= 0 && binop_needs_math(accum)) hipLaunchKernelGGL((k_vec_assign_scalar_masked<T, true>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (T*)wval, wpres, mcode, mval, mpres, mstruct, mcomp, s, accum, replace);
+    else hipLaunchKernelGGL((k_vec_assign_scalar_masked<T, false>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (T*)wval, wpres, mcode, mval, mpres, mstruct, mcomp, s, accum, replace);
+  });
+}
+
+__global__ void k_allow_and_bool(uint64_t n, int mcode, const void* __restrict__ mval, const uint8_t* __restrict__ mpres, bool structural, bool complement,
+                                 uint8_t* __restrict__ allow, uint8_t* __restrict__ as_bool) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {
+    const bool truth = mask_truth_at(mval, mcode, i, false);
+    const bool m = mpres[i] != 0 && (structural || truth);
+    allow[i] = (uint8_t)(m != complement);
+    as_bool[i] = truth ? 1 : 0;
+  }
+}
+void build_allow_and_bool(uint64_t n, int mcode, const void* mval, const uint8_t* mpres, bool structural, bool complement, uint8_t* allow, uint8_t* as_bool) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_allow_and_bool, dim3(grid_for(n)), dim3(256), 0, stream(), n, mcode, mval, mpres, structural, complement, allow, as_bool);
+}
+
 // ---- value-based select on a bitmap vector / value array: keep[i] = pred(val[i]) --------------------------------------------
 template <class T> __global__ void k_select_value(uint64_t n, const T* __restrict__ val, const uint8_t* __restrict__ pres, int sel, T thunk,
                                                   uint8_t* __restrict__ keep) {

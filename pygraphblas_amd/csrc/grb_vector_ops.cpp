@@ -20,6 +20,13 @@ static void scalar_accum(void* c, int ccode, const void* s, int scode, GrB_Binar
   cast_scalar(ccode, c, ac, z);
 }
 
+// a NaN result of an FP MIN / MAX reduction that started from NaN: every value was NaN — or there was none, and the answer is the monoid's identity
+static void nan_or_empty(uint8_t* r, int mc, GrB_Monoid monoid, const uint8_t* pres, uint64_t n) {
+  bool is_nan = false;
+  if (mc == T_FP32) { float f; memcpy(&f, r, 4); is_nan = f != f; } else { double f; memcpy(&f, r, 8); is_nan = f != f; }
+  if (is_nan && (n == 0 || (pres && count_present(pres, n) == 0))) memcpy(r, monoid->identity, 16);
+}
+
 static void reduce_common(void* c, int ccode, GrB_BinaryOp accum, GrB_Monoid monoid, int vcode, const void* val, const uint8_t* pres, uint64_t n) {
   need_device();
   if (!check_obj(monoid)) fail(GrB_UNINITIALIZED_OBJECT, "monoid is not initialised");
@@ -27,12 +34,15 @@ static void reduce_common(void* c, int ccode, GrB_BinaryOp accum, GrB_Monoid mon
   const int mc = monoid->op->ztype->code;
   uint8_t r[16];
   const int mop = monoid->op->opcode;
+  uint8_t id[16]; memcpy(id, monoid->identity, 16);
+  const bool nan_id = fp_minmax_identity(mc, mop, id);                        // FP MIN / MAX: start from NaN = from the first value (grb_opcommon.hpp)
   if (mc == T_FP64 && vcode == T_FP32 && (mop == B_PLUS || mop == B_MIN || mop == B_MAX || mop == B_TIMES)) {
-    reduce_values_f32_f64(n, val, pres, mop, monoid->identity, r);          // no cast pass: the first reduction level widens on the fly
+    reduce_values_f32_f64(n, val, pres, mop, id, r);                        // no cast pass: the first reduction level widens on the fly
   } else {
     DevBuf tmp; const void* v = cast_values(mc, vcode, val, n, tmp);
-    reduce_values(mc, n, v, pres, mop, monoid->identity, r);
+    reduce_values(mc, n, v, pres, mop, id, r);
   }
+  if (nan_id) nan_or_empty(r, mc, monoid, pres, n);
   scalar_accum(c, ccode, r, mc, accum);
 }
 
@@ -52,8 +62,12 @@ static GrB_Info vec_reduce(void* c, int ccode, GrB_BinaryOp accum, GrB_Monoid mo
     if (u->n > GRB_DIM_DEVICE_MAX) { vec_to_host(u); reduce_host_values(c, ccode, accum, monoid, u->type, u->hx); return; }
     if (u->lazy == 2 && check_obj(monoid) && check_obj(monoid->op) && monoid->op->opcode < B_FIRSTI && monoid->op->xtype == monoid->op->ytype) {
       // u is the result of queued element-wise operations: their one kernel reduces it on the way (`t -= r; abs(t); reduce_float()`)
-      const int mc = monoid->op->ztype->code; uint8_t r[16] = {0};
-      if (lazy_reduce(u, monoid->op->opcode, mc, monoid->identity, r)) { scalar_accum(c, ccode, r, mc, accum); return; }
+      const int mc = monoid->op->ztype->code; uint8_t r[16] = {0}, id[16]; memcpy(id, monoid->identity, 16);
+      const bool nan_id = fp_minmax_identity(mc, monoid->op->opcode, id);
+      if (lazy_reduce(u, monoid->op->opcode, mc, id, r)) {
+        if (nan_id) nan_or_empty(r, mc, monoid, u->dpres.as<uint8_t>(), u->n);      // (u is materialised now)
+        scalar_accum(c, ccode, r, mc, accum); return;
+      }
     }
     vec_to_device(u); reduce_common(c, ccode, accum, monoid, u->type->code, u->dval.p, u->dpres.as<uint8_t>(), u->n); });
 }
@@ -72,6 +86,20 @@ static void vec_assign(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const 
   if (mask && mask->n != w->n) fail(GrB_DIMENSION_MISMATCH, "assign: mask size");
   if (accum) check_binop(accum, "accum");
   const uint64_t n = w->n;
+  if (I == GrB_ALL && mask && mask != w && n) {
+    // every index under a mask (`v.assign_scalar(level, mask=q)`, the BFS loop): the kernel reads the mask vector itself
+    const int wcode0 = w->type->code; const int ecode0 = accum ? accum->xtype->code : wcode0;
+    if (ecode0 == wcode0) {
+      vec_to_device(mask); vec_to_device(w);
+      uint8_t s0[16]; cast_scalar(wcode0, s0, xcode, x);
+      vec_assign_scalar_masked(wcode0, n, w->dval.p, w->dpres.as<uint8_t>(), mask->type->code, mask->dval.p, mask->dpres.as<uint8_t>(), dv.mask_struct, dv.mask_comp, s0,
+                               accum ? accum->opcode : -1, dv.replace);
+      vec_invalidate_host(w);
+      if (dv.replace) { w->fe_lb = 0; w->fe_lb_key = nullptr; }
+      w->dnvals_known = false; w->dnvals = 0;
+      return;
+    }
+  }
   DevBuf allow_buf, region; bool nothing = false;
   const uint8_t* allow = vector_allow(mask, dv, n, allow_buf, &nothing);
   if (nothing) { if (dv.replace) { GrB_Vector_clear(w); } return; }

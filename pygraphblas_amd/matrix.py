@@ -89,9 +89,11 @@ class Matrix:
     def dense(cls, typ, nrows, ncols, fill=None):
         if fill is None:
             fill = typ.default_zero
-        if nrows * ncols < (1 << 32) - 16 and _capi.device_info()["ok"]:      # straight to a CSR in HBM (the ns x n batches of the BC sweeps)
-            return cls.from_csr(typ, nrows, ncols, np.arange(nrows + 1, dtype=np.uint64) * np.uint64(ncols), np.tile(np.arange(ncols, dtype=np.uint32), nrows),
-                                np.full(nrows * ncols, fill, dtype=typ._np))
+        if 0 < nrows * ncols < (1 << 32) - 16 and _capi.device_info()["ok"]:  # one fill kernel in HBM (the ns x n batches of the BC sweeps): the
+            m = cls.sparse(typ, nrows, ncols)                                  # reference's own `m[:, :] = fill` (pygraphblas/matrix.py:220-230)
+            ALL = C.cast(_capi.handle("GrB_ALL"), C.c_void_p)
+            check(getattr(lib, "GrB_Matrix_assign_" + typ.__name__)(m._h, None, None, typ._c(fill), ALL, u64(nrows), ALL, u64(ncols), None), m)
+            return m
         I, J = np.divmod(np.arange(nrows * ncols, dtype=np.uint64), np.uint64(ncols))
         return cls.from_arrays(I, J, np.full(nrows * ncols, fill, dtype=typ._np), nrows, ncols, typ)
 

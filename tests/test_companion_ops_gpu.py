@@ -251,3 +251,19 @@ def test_companions_fuzzed_against_a_model(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_companions.py"), "--seconds", "6", "--seed", "5"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fuzz companions ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("tname,fill", [("FP32", 2.5), ("INT64", -7), ("BOOL", True), ("UINT8", 200)])
+def test_dense_matrix_is_filled_on_the_device(gb, gpu, tname, fill):
+    """`Matrix.dense(T, ns, n, fill)` / `M[:, :] = x` over every position (the ns x n batches of gap/bcmark.py:19-20, 48): one fill
+    kernel in HBM; rows, columns and values of the resulting CSR, and the degenerate one-column / one-row shapes."""
+    typ = getattr(gb, tname)
+    for nr, nc in ((4, 100_003), (1, 70_000), (3000, 1), (37, 41)):
+        m = gb.Matrix.dense(typ, nr, nc, fill=fill)
+        assert m.nvals == nr * nc
+        I, J, X = m.to_arrays()
+        assert np.array_equal(I, np.repeat(np.arange(nr, dtype=np.uint64), nc))
+        assert np.array_equal(J, np.tile(np.arange(nc, dtype=np.uint64), nr))
+        assert np.all(X == typ._np(fill))
+        rp, ci, vals = m.to_csr()
+        assert np.array_equal(rp, np.arange(nr + 1, dtype=np.uint32) * np.uint32(nc))

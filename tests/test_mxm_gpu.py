@@ -76,21 +76,29 @@ def test_typecasts_and_min_accum(gpu):
 
 
 def test_every_mask_bin_and_heavy_rows(gpu):
-    # mask rows of 1..9000 entries exercise all LDS table sizes (64/512/2048/8192 slots) and the HBM position map
+    # mask rows of 1..30000 entries exercise all LDS table sizes (64/512/2048/8192 slots) and the HBM position map — whose first
+    # 24 576 (counting products) / 10 922 (8-byte accumulators) positions accumulate in LDS and the rest with global atomics
     rng = np.random.default_rng(13)
-    n = 9500
-    rows = np.concatenate([np.full(c, r) for r, c in enumerate([1, 20, 40, 200, 300, 900, 1500, 3000, 5000, 9000])]).astype(np.uint64)
-    cols = np.concatenate([np.sort(rng.choice(n, size=c, replace=False)) for c in [1, 20, 40, 200, 300, 900, 1500, 3000, 5000, 9000]]).astype(np.uint64)
-    M = O.Tuples("BOOL", 10, n, rows, cols, np.ones(len(rows), bool))
-    A = rand_matrix(rng, "INT64", 10, 300, 0.5)
+    n = 31000
+    lens = [1, 20, 40, 200, 300, 900, 1500, 3000, 5000, 9000, 12000, 30000]
+    rows = np.concatenate([np.full(c, r) for r, c in enumerate(lens)]).astype(np.uint64)
+    cols = np.concatenate([np.sort(rng.choice(n, size=c, replace=False)) for c in lens]).astype(np.uint64)
+    M = O.Tuples("BOOL", len(lens), n, rows, cols, np.ones(len(rows), bool))
+    A = rand_matrix(rng, "INT64", len(lens), 300, 0.5)
     B = rand_matrix(rng, "INT64", 300, n, 0.05)
     for sr, typ in (("PLUS_PAIR", "INT64"), ("PLUS_TIMES", "INT64"), ("MIN_PLUS", "INT64")):
         got = to_matrix(A).mxm(to_matrix(B), semiring=getattr(gb.INT64, sr), mask=to_matrix(M))
         add, mul = sr.split("_")
-        check(got, O.mxm(O.Tuples("INT64", 10, n), A, B, add, mul, "INT64", mask=M), "INT64", what=sr)
-    Af, Bf = rand_matrix(rng, "FP64", 10, 300, 0.5, small=False), rand_matrix(rng, "FP64", 300, n, 0.05, small=False)
+        check(got, O.mxm(O.Tuples("INT64", len(lens), n), A, B, add, mul, "INT64", mask=M), "INT64", what=sr)
+    # A rows of ~2250 entries: the hub rows' A(i,:) is cut into slices of 1024 entries that several workgroups accumulate into the same slots
+    A2, B2 = rand_matrix(rng, "INT64", len(lens), 2500, 0.9), rand_matrix(rng, "INT64", 2500, n, 0.01)
+    for sr in ("PLUS_PAIR", "MIN_PLUS", "PLUS_TIMES"):
+        got = to_matrix(A2).mxm(to_matrix(B2), semiring=getattr(gb.INT64, sr), mask=to_matrix(M))
+        add, mul = sr.split("_")
+        check(got, O.mxm(O.Tuples("INT64", len(lens), n), A2, B2, add, mul, "INT64", mask=M), "INT64", what=sr + " sliced")
+    Af, Bf = rand_matrix(rng, "FP64", len(lens), 300, 0.5, small=False), rand_matrix(rng, "FP64", 300, n, 0.05, small=False)
     got = to_matrix(Af).mxm(to_matrix(Bf), semiring=gb.FP64.PLUS_TIMES, mask=to_matrix(M))
-    check(got, O.mxm(O.Tuples("FP64", 10, n), Af, Bf, "PLUS", "TIMES", "FP64", mask=M), "FP64", rtol=1e-6)
+    check(got, O.mxm(O.Tuples("FP64", len(lens), n), Af, Bf, "PLUS", "TIMES", "FP64", mask=M), "FP64", rtol=1e-6)
 
 
 def test_empty_operands_and_aliasing(gpu):

@@ -314,3 +314,42 @@ def test_kernel_x_extreme_shapes_at_scale(gpu):
         want = torch.zeros(nrows, dtype=torch.int64, device=dev).index_add_(0, torch.repeat_interleave(torch.arange(nrows, device=dev), (rowptr[1:] - rowptr[:-1]).to(torch.int64)), prod)
         assert gp.all() and np.array_equal(gy, want.cpu().numpy()), (nrows, ncols, kind)
         assert np.array_equal(w2.to_dense_arrays()[0], gy)
+
+
+@pytest.mark.parametrize("typ", ["FP64", "FP32"])
+@pytest.mark.parametrize("sr", ["MIN_DIV", "MAX_DIV", "MIN_RDIV"])
+def test_nan_products_under_fp_min_max_agree_on_every_path(gpu, typ, sr, monkeypatch):
+    """ONE NaN rule for a floating-point MIN / MAX monoid on every path (DESIGN.md §8, round-2 verdict): a NaN product (0/0 under DIV)
+    is omitted by fmin / fmax, and an entry ALL of whose products are NaN is NaN — the oracle's first-product rule.  The same
+    operands through every forced kernel (push SpMSpV and its atomics, row-block, row-group, the wave pipeline, the panel pipeline),
+    with and without an accumulator and a mask, and as GrB_mxm through the masked LDS kernel, the two-pass hash and expand/sort/compress."""
+    import helpers
+    import test_mxm_gpu as TM
+    # operands over {0, 1, 2}: one product in nine is 0/0, so entries whose products are ALL NaN are common
+    monkeypatch.setattr(helpers, "rand_values", lambda r, t, n, small=True: r.integers(0, 3, n).astype(O.NP[t]))
+    rng = np.random.default_rng(99)
+    saw_nan = 0
+    for method in (None, "adaptive", "rowgroup", "push", "wavepipe", "xcd"):
+        for (nr, nc, dens, udens) in ((300, 280, 0.01, 0.5), (300, 280, 0.15, 0.5), (60, 9000, 0.6, 1.0), (4000, 30, 0.06, 1.0), (3000, 900, 0.002, 1.0)):
+            for vxm in (False, True):
+                for accum in (None, "MIN"):
+                    if method in ("wavepipe", "xcd") and udens < 1.0:
+                        continue
+                    r = np.random.default_rng(int(rng.integers(1 << 30)))
+                    run_case(r, typ, sr, nr, nc, dens, udens, vxm=vxm, accum=accum, method=method,
+                             mask={"typ": "BOOL", "comp": True} if (method in (None, "rowgroup") and accum is None) else None)
+    # at least one of the cases above must have produced an all-NaN entry, or the test shows nothing: count them through the oracle
+    A = rand_matrix(rng, typ, 300, 280, 0.01); ui, ux = rand_vector(rng, typ, 280, 0.5)
+    add, mul = sr.split("_")
+    exp = O.mxv(O.col_vector(typ, 300), A, O.col_vector(typ, 280, ui, ux), add, mul, typ)
+    saw_nan += int(np.isnan(exp.X).sum())
+    assert saw_nan > 0
+    for env in ({}, {"GRB_MI355X_SPGEMM": "esc"}, {"GRB_MI355X_MXM_ROWS": "1"}):
+        for k in ("GRB_MI355X_SPGEMM", "GRB_MI355X_MXM_ROWS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for mask in (None, {"typ": "BOOL"}, {"typ": "BOOL", "comp": True}):
+            TM.run_case(np.random.default_rng(5), typ, sr, 60, 50, 40, 0.05, 0.05, mask=mask, accum=None)
+            TM.run_case(np.random.default_rng(7), typ, sr, 60, 50, 40, 0.3, 0.3, mask=mask, accum=None)
+            TM.run_case(np.random.default_rng(6), typ, sr, 300, 20, 300, 0.5, 0.5, mask=mask, accum="MAX")
