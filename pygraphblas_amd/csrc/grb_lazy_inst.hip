@@ -29,6 +29,38 @@ template <class T, int NIN> __device__ __forceinline__ T pickn(const T (&e)[NIN]
   return r;
 }
 
+// The operator of a step is wave-uniform, but a switch per POSITION costs a chain of scalar compares and branches each time (measured:
+// 20 us for a 2-step chain over 2^22 positions whatever the grid — 16 wave-iterations per SIMD x 16 switches x ~100 cycles).  So the
+// switch is taken once per step and the case applies its operator — a compile-time constant there — to all VEC positions.
+#define GRB_CHAIN_BINOPS(X) X(B_FIRST) X(B_SECOND) X(B_PAIR) X(B_ANY) X(B_MIN) X(B_MAX) X(B_PLUS) X(B_MINUS) X(B_RMINUS) X(B_TIMES) X(B_DIV) X(B_RDIV) \
+                            X(B_ISEQ) X(B_ISNE) X(B_ISGT) X(B_ISLT) X(B_ISGE) X(B_ISLE) X(B_LOR) X(B_LAND) X(B_LXOR)
+#define GRB_CHAIN_UNOPS(X) X(U_IDENTITY) X(U_AINV) X(U_MINV) X(U_LNOT) X(U_ONE) X(U_ABS) X(U_BNOT)
+template <class T, int N> __device__ __forceinline__ void chain_binop_vec(int op, const T (&x)[N], const T (&y)[N], T (&z)[N]) {
+  switch (op) {
+#define GRB_X(K) case K: { _Pragma("unroll") for (int h = 0; h < N; h++) z[h] = apply_binop<T, false, false>(K, x[h], y[h]); } break;
+    GRB_CHAIN_BINOPS(GRB_X)
+#undef GRB_X
+    default: { _Pragma("unroll") for (int h = 0; h < N; h++) z[h] = x[h]; } break;
+  }
+}
+template <class T, int N> __device__ __forceinline__ void chain_unop_vec(int op, const T (&x)[N], T (&z)[N]) {
+  switch (op) {
+#define GRB_X(K) case K: { _Pragma("unroll") for (int h = 0; h < N; h++) z[h] = apply_unop<T, false>(K, x[h]); } break;
+    GRB_CHAIN_UNOPS(GRB_X)
+#undef GRB_X
+    default: { _Pragma("unroll") for (int h = 0; h < N; h++) z[h] = x[h]; } break;
+  }
+}
+template <class R, int N> __device__ __forceinline__ R chain_reduce_vec(int op, R acc, const R (&v)[N], const bool (&ok)[N]) {
+  switch (op) {
+#define GRB_X(K) case K: { _Pragma("unroll") for (int h = 0; h < N; h++) if (ok[h]) acc = apply_binop<R, false, false>(K, acc, v[h]); } break;
+    GRB_CHAIN_BINOPS(GRB_X)
+#undef GRB_X
+    default: break;
+  }
+  return acc;
+}
+
 // RED: 0 no reduction, 1 reduce the last result in T, 2 reduce FP32 values in FP64.  R = the reduction type.  NIN: stored operands read.
 // VEC consecutive positions per lane and step of the grid-stride loop (4: one 16-byte load per operand and lane — two for 8-byte
 // types — and one 4-byte load of presence bytes; 1: the fallback for buffers that are not 16-byte aligned).  All loads of a step are
@@ -80,23 +112,35 @@ __global__ __launch_bounds__(256) void k_vec_chain(const ChainK<T> a, const R ri
       // FIRST .. LXOR and IDENTITY .. BNOT; grb_lazy.cpp queues nothing else.)
       const int ia = a.sa[s], ib = a.sb[s], kd = a.kind[s], m = a.mode[s], opc = a.opc[s], o = a.out[s];
       const bool uni = a.uni[s] != 0; const T sc = a.scalar[s];
+      T x[VEC], y[VEC], z[VEC]; bool xp[VEC], yp[VEC];
 #pragma unroll
       for (int h = 0; h < VEC; h++) {
-        const T x = ia == CHAIN_PREV ? acc[h] : pickn<T, NIN>(e[h], ia); const bool xp = ia == CHAIN_PREV ? ap[h] : pickn<bool, NIN>(p[h], ia);
-        T y = sc; bool yp = true;
-        if (kd == 0) { y = ib == CHAIN_PREV ? acc[h] : pickn<T, NIN>(e[h], ib); yp = ib == CHAIN_PREV ? ap[h] : pickn<bool, NIN>(p[h], ib); }
-        T z; bool zp;
-        if (kd == 1 && m == 0) { z = apply_unop<T, false>(opc, x); zp = xp; }
-        else {
-          const bool swap = kd == 1 && m == 1;                            // z = f(s, x)
-          const T fz = apply_binop<T, false, false>(opc, swap ? y : x, swap ? x : y);
-          const bool both = xp && yp;
-          z = both ? fz : (xp ? x : y);
-          zp = (kd == 0 && uni) ? (xp || yp) : both;
-        }
-        acc[h] = zp ? z : T(); ap[h] = zp;
+        x[h] = ia == CHAIN_PREV ? acc[h] : pickn<T, NIN>(e[h], ia); xp[h] = ia == CHAIN_PREV ? ap[h] : pickn<bool, NIN>(p[h], ia);
+        y[h] = sc; yp[h] = true;
+        if (kd == 0) { y[h] = ib == CHAIN_PREV ? acc[h] : pickn<T, NIN>(e[h], ib); yp[h] = ib == CHAIN_PREV ? ap[h] : pickn<bool, NIN>(p[h], ib); }
+      }
+      if (kd == 1 && m == 0) {
+        chain_unop_vec<T, VEC>(opc, x, z);
 #pragma unroll
-        for (int oo = 0; oo < CHAIN_MAX_OUT; oo++) if (o == oo) { ov[oo][h] = acc[h]; opv[oo][h] = ap[h]; }
+        for (int h = 0; h < VEC; h++) { ap[h] = xp[h]; acc[h] = xp[h] ? z[h] : T(); }
+      } else {
+        if (kd == 1 && m == 1) {                                            // z = f(s, x): the scalar takes the first seat
+#pragma unroll
+          for (int h = 0; h < VEC; h++) { const T tmp = x[h]; x[h] = y[h]; y[h] = tmp; const bool tp = xp[h]; xp[h] = yp[h]; yp[h] = tp; }
+        }
+        chain_binop_vec<T, VEC>(opc, x, y, z);
+#pragma unroll
+        for (int h = 0; h < VEC; h++) {
+          const bool both = xp[h] && yp[h];
+          const bool zp = (kd == 0 && uni) ? (xp[h] || yp[h]) : both;
+          const T v = both ? z[h] : (xp[h] ? x[h] : y[h]);
+          ap[h] = zp; acc[h] = zp ? v : T();
+        }
+      }
+#pragma unroll
+      for (int oo = 0; oo < CHAIN_MAX_OUT; oo++) if (o == oo) {
+#pragma unroll
+        for (int h = 0; h < VEC; h++) { ov[oo][h] = acc[h]; opv[oo][h] = ap[h]; }
       }
     }
 #pragma unroll
@@ -115,8 +159,10 @@ __global__ __launch_bounds__(256) void k_vec_chain(const ChainK<T> a, const R ri
       }
     }
     if constexpr (RED != 0) {
+      R rv[VEC]; bool rok[VEC];
 #pragma unroll
-      for (int h = 0; h < VEC; h++) if (h < nv && ap[h]) racc = apply_binop<R, false, false>(a.red_op, racc, (R)acc[h]);
+      for (int h = 0; h < VEC; h++) { rv[h] = (R)acc[h]; rok[h] = h < nv && ap[h]; }
+      racc = chain_reduce_vec<R, VEC>(a.red_op, racc, rv, rok);
     }
   }
   if constexpr (RED != 0) {
@@ -168,12 +214,20 @@ template <class T, int RED, class R, int NIN> static void launch_chain(const Cha
   a.red_op = L.red.op;
   // one round of workgroups: 4 per CU are resident whatever the variant's register count (with 2048 workgroups of a 69-register
   // variant — 7 per CU — the eighth waited for a slot and the kernel ran a second, nearly empty round: 27 us for 50 MB)
-  const uint64_t gmax = (uint64_t)(device_cus() > 0 ? device_cus() : 256) * 4;
-  uint64_t g = (L.n + 256ull * 4 - 1) / (256ull * 4); if (g < 1) g = 1; if (g > gmax) g = gmax; if (g > 2048) g = 2048;
+  // (as many workgroups as are resident at once for THIS variant: the occupancy API, asked once per instantiation)
+  static int occ4 = 0, occ1 = 0;
+  if (!occ4) { int b = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_vec_chain<T, RED, R, NIN, 4>, 256, 0) != hipSuccess || b < 1) { (void)hipGetLastError(); b = 4; } occ4 = b > 64 ? 64 : b; }
+  if (!occ1) { int b = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_vec_chain<T, RED, R, NIN, 1>, 256, 0) != hipSuccess || b < 1) { (void)hipGetLastError(); b = 4; } occ1 = b > 64 ? 64 : b; }
+  static const int env_vec = getenv("GRB_MI355X_CHAIN_VEC") ? atoi(getenv("GRB_MI355X_CHAIN_VEC")) : 4;            // measurement hooks
+  static const int env_bpc = getenv("GRB_MI355X_CHAIN_BPC") ? atoi(getenv("GRB_MI355X_CHAIN_BPC")) : 0;
+  if (env_vec == 1) aligned = false;
+  if (env_bpc > 0) { occ4 = env_bpc; occ1 = env_bpc; }
+  const uint64_t gmax = (uint64_t)(device_cus() > 0 ? device_cus() : 256) * (uint64_t)(aligned ? occ4 : occ1);
+  uint64_t g = (L.n + 256ull * 4 - 1) / (256ull * 4); if (g < 1) g = 1; if (g > gmax) g = gmax; if (g > 16384) g = 16384;
   R rid{}; R* result = nullptr; R* partial = nullptr;
   if constexpr (RED != 0) {
     static thread_local DevBuf work;                                    // [result 16 B | partials]
-    if (!work.p) work.alloc(16 + 2048 * sizeof(double));
+    if (!work.p) work.alloc(16 + 16384 * sizeof(double));
     memcpy(&rid, L.red.identity, sizeof(R));
     result = (R*)work.p; partial = (R*)((char*)work.p + 16);
   }

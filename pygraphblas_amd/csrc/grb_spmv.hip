@@ -117,6 +117,8 @@ static __global__ __launch_bounds__(1024) void k_xcc_probe(uint32_t* __restrict_
 }
 const std::string& xcd_mapping() {
   static std::string res;
+  static const bool reprobe = getenv("GRB_MI355X_XCD_REPROBE") != nullptr;      // measurement hook: probe at every call (tools/xcd_probe.py)
+  if (reprobe) res.clear();
   if (!res.empty() || !device_ok()) return res;
   const int ncu = device_cus();
   if (ncu <= 0) { res = "unknown"; return res; }
@@ -127,8 +129,14 @@ const std::string& xcd_mapping() {
   int match = 0; uint32_t seen = 0;
   for (int b = 0; b < ncu; b++) { match += (h[b] == (uint32_t)(b & 7)); seen |= 1u << h[b]; }
   const int nx = __builtin_popcount(seen);
-  if (match == ncu) res = "roundrobin8";
-  else res = "xcds=" + std::to_string(nx) + ",workgroups_on_xcd_b%8=" + std::to_string(match) + "/" + std::to_string(ncu);
+  if (match == ncu) { res = "roundrobin8"; return res; }
+  // a rotated deal (workgroup b on XCD (b + r) % 8: the dispatcher started at another XCD) serves kernel X as well: every panel still
+  // has one XCD to itself for the launch
+  for (int r = 1; r < 8; r++) {
+    int m = 0; for (int b = 0; b < ncu; b++) m += (h[b] == (uint32_t)((b + r) & 7));
+    if (m == ncu) { res = "roundrobin8+" + std::to_string(r); return res; }
+  }
+  res = "xcds=" + std::to_string(nx) + ",workgroups_on_xcd_b%8=" + std::to_string(match) + "/" + std::to_string(ncu);
   return res;
 }
 }  // namespace grb

@@ -204,6 +204,13 @@ if "aa" in args.what:
         del Cm
     os.environ.pop("GRB_MI355X_SPGEMM")
     res["temporaries"] = {"hash_bytes": 8 * m + 16 * res["hash"]["nnz_C"], "esc_bytes_per_product": 40, "esc_bytes": 40 * min(products, 1 << 27)}
+    # algorithmic bytes (unmasked form): A once, one B-row entry (column + FP64 value) per product, C written
+    nc = res["hash"]["nnz_C"]
+    alg = nnz * 12 + (m + 1) * 4 + products * 12 + nc * 12 + (m + 1) * 4
+    for method in ("hash", "esc"):
+        a = alg / res[method]["seconds"] / 1e9
+        res[method]["roofline"] = {"bound": "hbm", "achieved": round(a, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(a / 8000.0, 4), "algorithmic_bytes": alg,
+                                   "note": "nnz(A)*12 + products*12 (B-row entries, column + value) + nnz(C)*12 + 2*(n+1)*4; the hash path also writes and sorts 16 B per entry of C"}
     print(json.dumps({"workload": f"A @ A (unmasked GrB_mxm) R-MAT-{S} symmetric FP64 PLUS_TIMES", "n": m, "nnz_A": nnz, "products": products, **res}), flush=True)
 
 
