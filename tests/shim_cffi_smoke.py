@@ -117,7 +117,96 @@ if "--gpu" in sys.argv:
         wb = vec([0], [True], "BOOL", 3); vb = ffi.new("GrB_Vector*"); check(lib.GrB_Vector_new(vb, lib.GrB_BOOL, 3))
         check(lib.GrB_mxv(wb[0], vb[0], ffi.NULL, lib.GrB_LOR_LAND_SEMIRING_BOOL, Mb[0], wb[0], desc))
         assert vtuples(wb, "BOOL") == (want, [1]), vtuples(wb, "BOOL")
-    print("OK gpu", list(X), r[0], "+ reference test_mxm/test_mxm_context/test_mxv/test_vxm/test_RCT0/test_RC sequences")
+    # tests/test_matrix.py:858-864 test_pow: (m @ m) on a dense UINT8 matrix wraps modulo 256
+    import random
+    rnd = random.Random(4); D8 = [[rnd.randrange(256) for _ in range(6)] for _ in range(6)]
+    m8 = ffi.new("GrB_Matrix*"); check(lib.GrB_Matrix_new(m8, lib.GrB_UINT8, 6, 6))
+    for i in range(6):
+        for jj in range(6):
+            check(lib.GrB_Matrix_setElement_UINT8(m8[0], D8[i][jj], i, jj))
+    p8 = ffi.new("GrB_Matrix*"); check(lib.GrB_Matrix_new(p8, lib.GrB_UINT8, 6, 6))
+    check(lib.GrB_mxm(p8[0], ffi.NULL, ffi.NULL, lib.GrB_PLUS_TIMES_SEMIRING_UINT8, m8[0], m8[0], ffi.NULL))
+    nv8 = ffi.new("GrB_Index*"); check(lib.GrB_Matrix_nvals(nv8, p8[0])); assert nv8[0] == 36
+    I8 = ffi.new("GrB_Index[36]"); J8 = ffi.new("GrB_Index[36]"); X8 = ffi.new("uint8_t[36]")
+    check(lib.GrB_Matrix_extractTuples_UINT8(I8, J8, X8, nv8, p8[0]))
+    for q in range(36):
+        assert X8[q] == sum(D8[I8[q]][k] * D8[k][J8[q]] for k in range(6)) % 256
+    # ---- the reference's LOOPS as the raw call sequences its methods make, in the non-blocking mode the reference initialises ----
+    # (the library defers and fuses the vector operations between the observations: results must be as-if sequential)
+    rnd = random.Random(11); NV = 60
+    edges = sorted({(rnd.randrange(NV), rnd.randrange(NV)) for _ in range(400)})
+    Ag = ffi.new("GrB_Matrix*"); check(lib.GrB_Matrix_new(Ag, lib.GrB_FP32, NV, NV))
+    for (i, jj) in edges:
+        check(lib.GrB_Matrix_setElement_FP32(Ag[0], 1.0, i, jj))
+    outdeg = [0] * NV
+    for (i, jj) in edges:
+        outdeg[i] += 1
+
+    def fvec(n):
+        h = ffi.new("GrB_Vector*"); check(lib.GrB_Vector_new(h, lib.GrB_FP32, n)); return h
+
+    # gap/prmark.py:8-30
+    dv = fvec(NV)
+    for i in range(NV):
+        if outdeg[i]:
+            check(lib.GrB_Vector_setElement_FP32(dv[0], float(outdeg[i]), i))
+    damping = 0.85
+    r_ = fvec(NV); t_ = fvec(NV)
+    check(lib.GrB_Vector_assign_FP32(dv[0], ffi.NULL, lib.GrB_DIV_FP32, damping, lib.GrB_ALL, NV, ffi.NULL))
+    check(lib.GrB_Vector_assign_FP32(r_[0], ffi.NULL, ffi.NULL, 1.0 / NV, lib.GrB_ALL, NV, ffi.NULL))
+    teleport = (1 - damping) / NV
+    rr = [1.0 / NV] * NV; tt = [0.0] * NV; its = 0; rdiff = ffi.new("float*")
+    for it in range(100):
+        t_, r_ = r_, t_
+        wv = fvec(NV)
+        check(lib.GrB_Vector_eWiseMult_BinaryOp(wv[0], ffi.NULL, ffi.NULL, lib.GrB_DIV_FP32, t_[0], dv[0], ffi.NULL))                  # w = t / d
+        check(lib.GrB_Vector_assign_FP32(r_[0], ffi.NULL, ffi.NULL, teleport, lib.GrB_ALL, NV, ffi.NULL))                             # r[:] = teleport
+        check(lib.GrB_mxv(r_[0], ffi.NULL, lib.GrB_PLUS_FP32, lib.GxB_PLUS_SECOND_FP32, Ag[0], wv[0], lib.GrB_DESC_T0))              # r += A' (+).second w
+        check(lib.GrB_Vector_eWiseAdd_BinaryOp(t_[0], ffi.NULL, ffi.NULL, lib.GrB_MINUS_FP32, r_[0], t_[0], ffi.NULL))                # t -= r  (the reference's operand order)
+        check(lib.GrB_Vector_apply(t_[0], ffi.NULL, ffi.NULL, lib.GrB_ABS_FP32, t_[0], ffi.NULL))                                    # t = abs(t)
+        check(lib.GrB_Vector_reduce_FP32(rdiff, ffi.NULL, lib.GrB_PLUS_MONOID_FP32, t_[0], ffi.NULL))                                # rdiff = t.reduce_float()
+        check(lib.GrB_Vector_free(wv))
+        # the same iteration in Python floats
+        tt, rr = rr, tt
+        w_ = [tt[i] / (outdeg[i] / damping) if outdeg[i] else None for i in range(NV)]
+        rr = [teleport] * NV
+        for (i, jj) in edges:
+            if w_[i] is not None:
+                rr[jj] += w_[i]
+        ref_rdiff = sum(abs(a - b) for a, b in zip(tt, rr))
+        its += 1
+        assert abs(rdiff[0] - ref_rdiff) <= 1e-5 * max(ref_rdiff, 1e-6) + 1e-7, (it, rdiff[0], ref_rdiff)
+        if rdiff[0] <= 1e-4:
+            break
+    nvr = ffi.new("GrB_Index*"); check(lib.GrB_Vector_nvals(nvr, r_[0])); assert nvr[0] == NV
+    xr = ffi.new("float*")
+    for i in range(NV):
+        check(lib.GrB_Vector_extractElement_FP32(xr, r_[0], i)); assert abs(xr[0] - rr[i]) <= 1e-5 * abs(rr[i]) + 1e-9, (i, xr[0], rr[i])
+    # demo/Introduction-to-GraphBLAS-with-Python.ipynb:4301-4313 (BFS) on the same graph as BOOL
+    Ab = ffi.new("GrB_Matrix*"); check(lib.GrB_Matrix_new(Ab, lib.GrB_BOOL, NV, NV))
+    for (i, jj) in edges:
+        check(lib.GrB_Matrix_setElement_BOOL(Ab[0], True, i, jj))
+    lv = ffi.new("GrB_Vector*"); check(lib.GrB_Vector_new(lv, lib.GrB_UINT8, NV))
+    qv = ffi.new("GrB_Vector*"); check(lib.GrB_Vector_new(qv, lib.GrB_BOOL, NV)); check(lib.GrB_Vector_setElement_BOOL(qv[0], True, edges[0][0]))
+    go = ffi.new("_Bool*"); level = 1
+    while True:
+        check(lib.GrB_Vector_reduce_BOOL(go, ffi.NULL, lib.GrB_LOR_MONOID_BOOL, qv[0], ffi.NULL))
+        if not go[0] or level > NV:
+            break
+        check(lib.GrB_Vector_assign_UINT8(lv[0], qv[0], ffi.NULL, level, lib.GrB_ALL, NV, ffi.NULL))
+        check(lib.GrB_vxm(qv[0], lv[0], ffi.NULL, lib.GrB_LOR_LAND_SEMIRING_BOOL, lv[0], Ab[0], lib.GrB_DESC_RC))
+        level += 1
+    lev = [0] * NV; lev[edges[0][0]] = 1; frontier = [edges[0][0]]; d_ = 1
+    while frontier:
+        nxt = sorted({jj for (i, jj) in edges if i in frontier and not lev[jj]}); d_ += 1
+        for jj in nxt:
+            lev[jj] = d_
+        frontier = nxt
+    u8 = ffi.new("uint8_t*")
+    for i in range(NV):
+        info = lib.GrB_Vector_extractElement_UINT8(u8, lv[0], i)
+        assert (info == lib.GrB_NO_VALUE and lev[i] == 0) or (info == lib.GrB_SUCCESS and u8[0] == lev[i]), (i, info, u8[0], lev[i])
+    print("OK gpu", list(X), r[0], "+ reference test_mxm/test_mxm_context/test_mxv/test_vxm/test_RCT0/test_RC/test_pow sequences + the PageRank (%d iterations) and BFS (%d levels) loops in non-blocking mode" % (its, level - 1))
 else:
     assert info == lib.GrB_PANIC, info                                                # no device: fail loudly
     err = ffi.new("char**"); check(lib.GrB_Vector_error(err, w[0]))
