@@ -164,7 +164,7 @@ extern "C" {
 GrB_Info GrB_init(int mode) { set_nonblocking(mode == 0 /* GrB_NONBLOCKING */); return do_init(); }
 GrB_Info GxB_init(int mode, void* (*m)(size_t), void* (*c)(size_t, size_t), void* (*r)(void*, size_t),
                   void (*f)(void*), bool ts) { set_nonblocking(mode == 0); (void)m; (void)c; (void)r; (void)f; (void)ts; return do_init(); }
-GrB_Info GrB_finalize(void) { dev_pool_release(); return GrB_SUCCESS; }
+GrB_Info GrB_finalize(void) { if (g_device_ok) { try { lazy_flush(); } catch (...) {} } dev_pool_release(); return GrB_SUCCESS; }
 GrB_Info GrB_getVersion(unsigned int* v, unsigned int* s) { if (v) *v = 1; if (s) *s = 3; return GrB_SUCCESS; }
 
 GrB_Info GxB_Global_Option_set(int field, ...) {
@@ -322,14 +322,18 @@ GRB_MONOID_NEW(UINT32, uint32_t, T_UINT32) GRB_MONOID_NEW(INT64, int64_t, T_INT6
 GRB_MONOID_NEW(FP32, float, T_FP32) GRB_MONOID_NEW(FP64, double, T_FP64)
 
 // ---- backend extensions -----------------------------------------------------------------------------
-GrB_Info GrBX_set_stream(void* s) { g_stream = (hipStream_t)s; return GrB_SUCCESS; }
+// (deferred vector operations — grb_lazy.cpp — are completed first: they belong to the work these calls order or measure)
+static GrB_Info flush_deferred() { try { lazy_flush(); return GrB_SUCCESS; } catch (const GrbError& e) { g_last_error = e.msg; return e.info; } catch (...) { return GrB_PANIC; } }
+GrB_Info GrBX_set_stream(void* s) { if (g_device_ok) { const GrB_Info i = flush_deferred(); if (i) return i; } g_stream = (hipStream_t)s; return GrB_SUCCESS; }
 GrB_Info GrBX_device_synchronize(void) {
   if (!g_device_ok) return GrB_PANIC;
+  const GrB_Info i = flush_deferred(); if (i) return i;
   return hipStreamSynchronize(g_stream) == hipSuccess ? GrB_SUCCESS : GrB_PANIC;
 }
 GrB_Info GrBX_timer_start(void) { if (!g_device_ok) return GrB_PANIC; return hipEventRecord(g_ev0, g_stream) == hipSuccess ? GrB_SUCCESS : GrB_PANIC; }
 GrB_Info GrBX_timer_stop(float* ms) {
   if (!g_device_ok) return GrB_PANIC;
+  { const GrB_Info i = flush_deferred(); if (i) return i; }
   if (hipEventRecord(g_ev1, g_stream) != hipSuccess) return GrB_PANIC;
   if (hipEventSynchronize(g_ev1) != hipSuccess) return GrB_PANIC;
   float t = 0; if (hipEventElapsedTime(&t, g_ev0, g_ev1) != hipSuccess) return GrB_PANIC;

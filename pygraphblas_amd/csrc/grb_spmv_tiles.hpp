@@ -63,6 +63,43 @@ template <class T, class SR> __device__ __forceinline__ void xt_seg_scan_count(T
     }
   }
 }
+// Round 3: the same scan with the segment flags kept OUT of the vector registers.  Which lanes may take the value `d` lanes below them at
+// a step depends only on the flag mask F (one bit per lane: "a sub-row starts in this lane's entries"): lane i accepts iff no flag in
+// the d lanes ending at i — the OR of F over that window, which the scalar unit computes for all 64 lanes at once (G2 = G1 | G1 << 1, ...,
+// masked at the 16-lane row boundaries DPP shifts respect).  The vector side of a step is then: DPP move, add, one v_cndmask on the
+// accept mask — 3 instructions for 4-byte values where the flag-carrying form took ~10 (DPP move of value and flag word, lane-range
+// compare, flag test, add, select, four operations on the flag / count word).  The count of row starts that rode in the flag word is
+// taken from ballots instead (v_mbcnt).  Same steps, same association: the sums come out bit for bit as before.
+template <class E> __device__ __forceinline__ E xt_select_mask(E if_clear, E if_set, unsigned long long mask) {     // per lane: bit(lane) of mask ? if_set : if_clear
+  if constexpr (sizeof(E) == 8) {
+    union { E e; uint32_t u[2]; } a, b, r; a.e = if_clear; b.e = if_set;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r.u[0]) : "v"(a.u[0]), "v"(b.u[0]), "s"(mask));
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r.u[1]) : "v"(a.u[1]), "v"(b.u[1]), "s"(mask));
+    return r.e;
+  } else {
+    union { E e; uint32_t u; } a, b, r; a.u = 0; b.u = 0; a.e = if_clear; b.e = if_set;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r.u) : "v"(a.u), "v"(b.u), "s"(mask));
+    return r.e;
+  }
+}
+template <class T, class SR> __device__ __forceinline__ void xt_seg_scan_masked(T& v, unsigned long long F, const SR& sr) {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "DPP scan handles 4- and 8-byte types");
+  constexpr unsigned long long LT1 = 0x0001000100010001ull, LT2 = 0x0003000300030003ull, LT4 = 0x000F000F000F000Full, LT8 = 0x00FF00FF00FF00FFull;
+  constexpr unsigned long long ROWS13 = 0xFFFF0000FFFF0000ull, ROWS23 = 0xFFFFFFFF00000000ull, ROW3 = 0xFFFF000000000000ull;
+  // G_d(i) = some flag among the d lanes ending at lane i, inside i's row of 16
+  const unsigned long long G1 = F;
+  const unsigned long long G2 = G1 | ((G1 << 1) & ~LT1);
+  const unsigned long long G4 = G2 | ((G2 << 2) & ~LT2);
+  const unsigned long long G8 = G4 | ((G4 << 4) & ~LT4);
+  const unsigned long long G16 = G8 | ((G8 << 8) & ~LT8);                 // a flag between the start of the row and lane i
+#define XT_MS_STEP(CTRL, MASK, ACCEPT) { const T vu = dpp_move_t<T, CTRL, MASK>(v); const T sum = sr.add(vu, v); v = xt_select_mask<T>(v, sum, (ACCEPT)); }
+  XT_MS_STEP(0x111, 0xf, ~G1 & ~LT1) XT_MS_STEP(0x112, 0xf, ~G2 & ~LT2) XT_MS_STEP(0x114, 0xf, ~G4 & ~LT4) XT_MS_STEP(0x118, 0xf, ~G8 & ~LT8)
+  XT_MS_STEP(0x142, 0xa, ~G16 & ROWS13)                                   // lane 15 / 47 into the next row
+  // rows 2 and 3 take lane 31: nothing may start between lane 32 and lane i — for row 3 that includes all of row 2 (its lane 47 in G16)
+  const unsigned long long H = G16 | (((G16 >> 47) & 1ull) ? ROW3 : 0ull);
+  XT_MS_STEP(0x143, 0xc, ~H & ROWS23)
+#undef XT_MS_STEP
+}
 template <class E> __device__ __forceinline__ E xt_readlane(E v, int src) {          // src wave-uniform
   if constexpr (sizeof(E) == 8) { union { E e; int i[2]; } u; u.e = v; u.i[0] = __builtin_amdgcn_readlane(u.i[0], src); u.i[1] = __builtin_amdgcn_readlane(u.i[1], src); return u.e; }
   else if constexpr (sizeof(E) == 4) { union { E e; int i; } u; u.e = v; u.i = __builtin_amdgcn_readlane(u.i, src); return u.e; }
@@ -280,6 +317,16 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
     const bool last_end = N1.tile == WP_NONE || (C16 ? (__builtin_amdgcn_readfirstlane(N1.h[0]) & 0x8000u) != 0u : (int32_t)__builtin_amdgcn_readfirstlane(N1.c[0]) < 0);
     // ---- segmented inclusive scan of the products in entry order, and in the same wave scan the number of row starts
     // behind the tile's first entry (sub-row of an entry = rf + that count, up to and including the entry)
+    // row starts behind the tile's first entry, in the lanes below mine (entry order = lane-major): ballots + v_mbcnt; the total is scalar
+    uint32_t excl = 0, starts = 0;
+    if constexpr (sizeof(T) == 4 || sizeof(T) == 8) {
+#pragma unroll
+      for (int u = 0; u < WP_PER; u++) {
+        unsigned long long mk = __ballot(rs[u]); if (u == 0) mk &= ~1ull;
+        excl = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, excl));
+        starts += (uint32_t)__popcll(mk);
+      }
+    }
     uint32_t mine = 0;
 #pragma unroll
     for (int u = 0; u < WP_PER; u++) mine += (rs[u] && (u > 0 || lane > 0)) ? 1u : 0u;
@@ -290,9 +337,16 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
 #pragma unroll
       for (int u = 1; u < WP_PER; u++) { agg = rs[u] ? p[u] : sr.add(agg, p[u]); anyf = anyf || rs[u]; }
       if (lane == 0 && !anyf) agg = sr.add(carry, agg);        // the carried partial flows through lane 0
-      T v = agg; uint32_t x = (anyf ? 0x80000000u : 0u) | mine;
-      xt_seg_scan_count<T, SR>(v, x, lane, sr);
-      incl = x & 0x7FFFFFFFu;
+      T v = agg;
+      if constexpr (sizeof(T) == 4 || sizeof(T) == 8) {
+        xt_seg_scan_masked<T, SR>(v, __ballot(anyf), sr);
+        incl = excl + mine;
+      } else {
+        uint32_t x = (anyf ? 0x80000000u : 0u) | mine;
+        xt_seg_scan_count<T, SR>(v, x, lane, sr);
+        incl = x & 0x7FFFFFFFu;
+        starts = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      }
       T run = shfl_up_t<T>(v, 1); if (lane == 0) run = carry;  // what flows into my first entry (unused when it starts a row)
       run = st0 ? p[0] : sr.add(run, p[0]); p[0] = run;
 #pragma unroll
@@ -310,8 +364,7 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
     // ---- the sums of the sub-rows that end in this tile leave through the wave's staging slots: the ends are ranked by
     // sub-row (rf, rf+1, ... — consecutive), so 64 of them at a time become one coalesced store.  (Storing from the
     // owning lanes, 8 scattered bytes per sub-row in four sparse store instructions, cost 25-30 us per product.)
-    const uint32_t starts = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);      // row starts behind the tile's first entry
-    const uint32_t nends = starts + (last_end ? 1u : 0u);
+    const uint32_t nends = starts + (last_end ? 1u : 0u);             // starts: row starts behind the tile's first entry
     for (uint32_t base = 0; base < nends; base += 64) {
       uint32_t row = incl - mine;
 #pragma unroll

@@ -194,6 +194,46 @@ def test_config4_rmat22_pagerank_loop_with_dangling_vertices(gb, torch_dev):
     assert np.allclose(gr, rr, rtol=1e-6, atol=0.0)
 
 
+def test_accumulate_into_a_full_vector_in_the_merge_kernel(gb, torch_dev):
+    """`w += A (+).(x) u` with the monoid's own operator into a resident full w, no mask: kernel X's merge applies the accumulator in
+    its store (k_xp_merge<T, SR, 1>: rows with entries become w (+) sum in place, the others stay, no tval, no epilogue kernel) — and
+    when w is a fill that was never written (`w[:] = s`, non-blocking mode) the fill folds into that store too (k_xp_merge<T, SR, 2>).
+    R-MAT-22 FP64 PLUS_TIMES against the oracle's loop; both forms twice (the second call accumulates onto the first's result)."""
+    torch, dev = torch_dev
+    from pygraphblas_amd import rmat
+    n = 1 << SCALE
+    rowptr, col = rmat.csr_torch(SCALE, dev, seed=42)
+    nnz = int(col.numel())
+    vals = rmat.values_torch(nnz, dev, seed=43)
+    xs = rmat.values_torch(n, dev, seed=44)
+    w0 = rmat.values_torch(n, dev, seed=48)
+    A = gb.Matrix.from_csr(gb.FP64, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+    x = gb.Vector.from_dense_array((xs.data_ptr(), n), gb.FP64, device=True)
+    y, pres = O.fast_spmv(rowptr.cpu().numpy().view(np.uint32), col.cpu().numpy().view(np.uint32), vals.cpu().numpy(), xs.cpu().numpy())
+    y = np.where(pres != 0, y, 0.0)
+    # (1) a resident full vector
+    w = gb.Vector.from_dense_array((w0.data_ptr(), n), gb.FP64, device=True)
+    A.mxv(x, out=w, accum=gb.FP64.PLUS, semiring=gb.FP64.PLUS_TIMES)
+    assert "k_spmv_xcd" in gb.last_kernel_plan()
+    g1, p1 = w.to_dense_arrays()
+    assert p1.all() and np.allclose(g1, w0.cpu().numpy() + y, rtol=1e-6, atol=0.0)
+    A.mxv(x, out=w, accum=gb.FP64.PLUS, semiring=gb.FP64.PLUS_TIMES)
+    g2, p2 = w.to_dense_arrays()
+    assert p2.all() and np.allclose(g2, w0.cpu().numpy() + 2 * y, rtol=1e-6, atol=0.0)
+    # (2) a pending fill
+    w = gb.Vector.sparse(gb.FP64, n)
+    w[:] = 0.25
+    A.mxv(x, out=w, accum=gb.FP64.PLUS, semiring=gb.FP64.PLUS_TIMES)
+    g3, p3 = w.to_dense_arrays()
+    assert p3.all() and np.allclose(g3, 0.25 + y, rtol=1e-6, atol=0.0)
+    assert w.nvals == n
+    # (3) another accumulator than the monoid's: the general epilogue
+    w = gb.Vector.from_dense_array((w0.data_ptr(), n), gb.FP64, device=True)
+    A.mxv(x, out=w, accum=gb.FP64.MAX, semiring=gb.FP64.PLUS_TIMES)
+    g4, _ = w.to_dense_arrays()
+    assert np.allclose(g4, np.where(pres != 0, np.maximum(w0.cpu().numpy(), y), w0.cpu().numpy()), rtol=1e-6, atol=0.0)
+
+
 # ---- configs[4] at its STATED size: R-MAT scale-25 on one MI355X ------------------------------------------------------------
 def test_config4_rmat25_pagerank_single_gpu(gb, torch_dev):
     """FP32 PageRank of gap/prmark.py:8-30 on R-MAT scale-25 (n = 33 554 432, 16·2^25 sampled edges) held by ONE MI355X — the
