@@ -234,11 +234,22 @@ template <class T, int RED, class R, int NIN> static void launch_chain(const Cha
   if (aligned) hipLaunchKernelGGL((k_vec_chain<T, RED, R, NIN, 4>), dim3((unsigned)g), dim3(256), 0, stream(), a, rid, partial);
   else hipLaunchKernelGGL((k_vec_chain<T, RED, R, NIN, 1>), dim3((unsigned)g), dim3(256), 0, stream(), a, rid, partial);
   if constexpr (RED != 0) {
-    hipLaunchKernelGGL((k_chain_final<R>), dim3(1), dim3(256), 0, stream(), (const R*)partial, (uint32_t)g, L.red.op, rid, result);
-    void* pin = pinned_scratch();
-    GRB_HIP(hipMemcpyAsync(pin, result, sizeof(R), hipMemcpyDeviceToHost, stream()));
-    GRB_HIP(hipStreamSynchronize(stream()));
-    memcpy(red_result, pin, sizeof(R));
+    // the per-workgroup partials (<= 16 384 x 8 B) travel to page-locked memory and the host folds them in index order — a fixed
+    // tree like the one-workgroup k_chain_final it replaces in the common case (one kernel and one launch gap less per PageRank iteration)
+    static thread_local R* pin = nullptr;
+    if (!pin) GRB_HIP(hipHostMalloc((void**)&pin, 16384 * sizeof(double), hipHostMallocDefault));
+    if (g <= 4096) {
+      GRB_HIP(hipMemcpyAsync(pin, partial, (size_t)g * sizeof(R), hipMemcpyDeviceToHost, stream()));
+      GRB_HIP(hipStreamSynchronize(stream()));
+      R r = rid;
+      for (uint64_t b = 0; b < g; b++) r = apply_binop<R, false, false>(L.red.op, r, pin[b]);
+      memcpy(red_result, &r, sizeof(R));
+    } else {
+      hipLaunchKernelGGL((k_chain_final<R>), dim3(1), dim3(256), 0, stream(), (const R*)partial, (uint32_t)g, L.red.op, rid, result);
+      GRB_HIP(hipMemcpyAsync(pin, result, sizeof(R), hipMemcpyDeviceToHost, stream()));
+      GRB_HIP(hipStreamSynchronize(stream()));
+      memcpy(red_result, pin, sizeof(R));
+    }
   }
   GRB_HIP(hipGetLastError());
 }
