@@ -15,3 +15,13 @@ extern "C" int GrBX_wp_prof_read(unsigned long long* out8) {
   return 0;
 }
 #endif
+
+#ifdef XT_PROFILE
+// measurement build only: read the per-wave phase counters of the tile pipeline (this translation unit's copy: one per value type)
+#define XT_CAT2(a, b) a##b
+#define XT_CAT(a, b) XT_CAT2(a, b)
+extern "C" int XT_CAT(GrBX_xt_prof_read_, GRB_INST_TYPE)(unsigned long long* out) {
+  hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(grb::g_xt_prof), 4096 * 8 * 8);
+}
+#endif

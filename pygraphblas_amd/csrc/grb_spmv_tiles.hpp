@@ -100,6 +100,16 @@ template <class T, class SR> __device__ __forceinline__ void xt_seg_scan_masked(
   XT_MS_STEP(0x143, 0xc, ~H & ROWS23)
 #undef XT_MS_STEP
 }
+template <class E> __device__ __forceinline__ E xt_wave_shr1(E v, E into_lane0) {     // lane i takes lane i - 1's value, lane 0 `into_lane0`
+  if constexpr (sizeof(E) == 8) {
+    union { E e; int i[2]; } a, o, r; a.e = v; o.e = into_lane0;
+    r.i[0] = __builtin_amdgcn_update_dpp(o.i[0], a.i[0], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(o.i[1], a.i[1], 0x138, 0xf, 0xf, false); return r.e;
+  } else {
+    union { E e; int i; } a, o, r; a.i = 0; o.i = 0; a.e = v; o.e = into_lane0;
+    r.i = __builtin_amdgcn_update_dpp(o.i, a.i, 0x138, 0xf, 0xf, false); return r.e;
+  }
+}
 template <class E> __device__ __forceinline__ E xt_readlane(E v, int src) {          // src wave-uniform
   if constexpr (sizeof(E) == 8) { union { E e; int i[2]; } u; u.e = v; u.i[0] = __builtin_amdgcn_readlane(u.i[0], src); u.i[1] = __builtin_amdgcn_readlane(u.i[1], src); return u.e; }
   else if constexpr (sizeof(E) == 4) { union { E e; int i; } u; u.e = v; u.i = __builtin_amdgcn_readlane(u.i, src); return u.e; }
@@ -164,6 +174,15 @@ template <class T> struct XtStage {       // what one tile has in flight
 };
 typedef uint32_t xt_v3u __attribute__((ext_vector_type(3)));
 
+#ifdef XT_PROFILE
+// measurement build (make BUILD=build_prof LIB=../libgrb_prof.so XTFLAGS=-DXT_PROFILE): cycles of every wave of the last launch by phase —
+// [0] until the tile's products exist (waits for column words, values, gathers, LDS table), [1] issuing the next tiles' loads,
+// [2] scan and end flags, [3] staging and stores, [4] tiles, [5] whole kernel.  tools/xt_phase_probe.py reads them.
+static __device__ unsigned long long g_xt_prof[4096 * 8];
+#define XT_PF(K) { const unsigned long long pf_t = __builtin_amdgcn_s_memtime(); pf[K] += pf_t - pf_prev; pf_prev = pf_t; }
+#else
+#define XT_PF(K)
+#endif
 template <class F, int... I> __device__ __forceinline__ bool xt_unroll_steps(F&& f, std::integer_sequence<int, I...>) { return (f.template operator()<I>() && ...); }
 
 // D = prefetch depth, W = waves per workgroup; EXP selects a timing experiment (wrong results!): 1 = no gathers of u (streams
@@ -277,6 +296,9 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
     }
   };
 
+#ifdef XT_PROFILE
+  unsigned long long pf[6] = {0, 0, 0, 0, 0, 0}; const unsigned long long pf_start = __builtin_amdgcn_s_memtime(); unsigned long long pf_prev = pf_start;
+#endif
   T carry = sr.identity; bool carry_has = false;        // partial of the sub-row the current tile starts in (wave-uniform)
 #pragma unroll
   for (int d = 0; d < D + 2; d++) { S[d].tile = next_tile(); load_cols(S[d]); }
@@ -290,6 +312,9 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
   auto step = [&]<int I>() __attribute__((always_inline)) -> bool {
     XtStage<T>& A = S[I % NS]; XtStage<T>& N1 = S[(I + 1) % NS]; XtStage<T>& G = S[(I + D) % NS]; XtStage<T>& M = S[(I + D + 1) % NS]; XtStage<T>& C = S[(I + D + 2) % NS];
     if (A.tile == WP_NONE) return false;
+#ifdef XT_PROFILE
+    pf_prev = __builtin_amdgcn_s_memtime(); pf[4]++;
+#endif
     const uint32_t t = A.tile;
     const uint32_t e0 = t * (uint32_t)WP_ENT, cnt = a.nnz - e0 < (uint32_t)WP_ENT ? a.nnz - e0 : (uint32_t)WP_ENT;
     if constexpr (D == 0) issue_gather(A);
@@ -301,9 +326,14 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
       const T uvv = use_u ? (cc < (uint32_t)H ? s_hot[cc < (uint32_t)H ? cc : 0] : A.g[u]) : T();
       p[u] = sr.mult(A.v[u], uvv);                             // entries past cnt hold junk: a forward scan never lets it reach a live position
     }
+#ifdef XT_PROFILE
+    { T sink = p[0]; for (int u = 1; u < WP_PER; u++) sink = sr.add(sink, p[u]); asm volatile("" :: "v"(sink)); }     // the products must exist here
+    XT_PF(0)
+#endif
     if constexpr (D > 0) issue_gather(G);
     load_extras(M);
     C.tile = next_tile(); load_cols(C);
+    XT_PF(1)
     const uint32_t rf = (uint32_t)__builtin_amdgcn_readfirstlane(A.rf);
     if constexpr (EXP == 2) {                                  // timing experiment: consume the loads, nothing else
       T q = sr.add(sr.add(p[0], p[1]), sr.add(p[2], p[3]));
@@ -347,13 +377,16 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
         incl = x & 0x7FFFFFFFu;
         starts = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
       }
-      T run = shfl_up_t<T>(v, 1); if (lane == 0) run = carry;  // what flows into my first entry (unused when it starts a row)
+      // what flows into my first entry (unused when it starts a row): the scanned value of the lane below — one DPP wave shift
+      // (wave_shr:1; gfx9 has it) instead of a ds_bpermute through the LDS crossbar and the wait for it; lane 0 takes the carry
+      T run;
+      if constexpr (sizeof(T) == 4 || sizeof(T) == 8) run = xt_wave_shr1<T>(v, carry); else { run = shfl_up_t<T>(v, 1); if (lane == 0) run = carry; }
       run = st0 ? p[0] : sr.add(run, p[0]); p[0] = run;
 #pragma unroll
       for (int u = 1; u < WP_PER; u++) { run = rs[u] ? p[u] : sr.add(run, p[u]); p[u] = run; }
     }
     // ---- an entry ends its sub-row when the next entry starts one
-    const int nxt0 = __shfl_down((int)rs[0], 1, 64);           // first flag of the next lane
+    const int nxt0 = (int)__builtin_amdgcn_update_dpp(0, (int)rs[0], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);   // first flag of the next lane (lane 63: 0, never used — pos + 1 == cnt there)
     bool end[WP_PER];
 #pragma unroll
     for (int u = 0; u < WP_PER; u++) {
@@ -365,6 +398,10 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
     // sub-row (rf, rf+1, ... — consecutive), so 64 of them at a time become one coalesced store.  (Storing from the
     // owning lanes, 8 scattered bytes per sub-row in four sparse store instructions, cost 25-30 us per product.)
     const uint32_t nends = starts + (last_end ? 1u : 0u);             // starts: row starts behind the tile's first entry
+#ifdef XT_PROFILE
+    { asm volatile("" :: "v"(p[WP_PER - 1])); }
+    XT_PF(2)
+#endif
     for (uint32_t base = 0; base < nends; base += 64) {
       uint32_t row = incl - mine;
 #pragma unroll
@@ -380,9 +417,13 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
     }
     if (cnt == (uint32_t)WP_ENT && !last_end) { carry = xt_readlane<T>(p[WP_PER - 1], 63); carry_has = true; }
     else { carry = sr.identity; carry_has = false; }
+    XT_PF(3)
     return true;
   };
   while (xt_unroll_steps(step, std::make_integer_sequence<int, NS>{})) {}
+#ifdef XT_PROFILE
+  if (lane == 0) { pf[5] = __builtin_amdgcn_s_memtime() - pf_start; for (int k = 0; k < 6; k++) g_xt_prof[((size_t)blockIdx.x * W + wv) * 8 + k] = pf[k]; }
+#endif
 }
 
 }  // namespace grb
