@@ -146,7 +146,23 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
         const uint32_t sl = LCAP - 1 - q;
         const T av = use_a ? a.aval[lpa[sl]] : T();
         const uint32_t be = lbe[sl];
-        for (uint32_t pb0 = lbb[sl] + lane64; pb0 < be; pb0 += 256) {
+        uint32_t pb0 = lbb[sl] + lane64;
+        // whole blocks of 512 entries first: EIGHT loads in flight per lane (the kernel is parked on its B-row loads 65 % of its
+        // cycles — profiles/r03_spgemm_sq_wave_cycles.txt — and a wave with four 256-byte loads in flight cannot cover the latency)
+        for (; pb0 + 448 < be; pb0 += 512) {
+          uint32_t j8[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) j8[u] = a.bcol[pb0 + 64 * u];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const uint32_t j = j8[u];
+            uint32_t h = hash_col(j, KS - 1);
+            uint32_t kk = key[h];
+            while (kk != j && kk != HASH_EMPTY) { h = (h + 1) & (KS - 1); kk = key[h]; }
+            if (kk == j) { const uint32_t mp = pos[h]; word_combine<T>(sr.add_op(), &acc[mp], sr.mult(av, use_b ? a.bval[pb0 + 64 * u] : T())); flag[mp] = 1; }
+          }
+        }
+        for (; pb0 < be; pb0 += 256) {
           uint32_t jj[4];
 #pragma unroll
           for (int u = 0; u < 4; u++) { const uint32_t pb = pb0 + 64 * u; jj[u] = a.bcol[pb < be ? pb : be - 1]; }   // 4 loads in flight
@@ -168,7 +184,21 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
         for (uint32_t q = 0; q < nhuge; q++) {
           const T av = use_a ? a.aval[s_hpa[team][q]] : T();
           const uint32_t be = s_hbe[team][q];
-          for (uint32_t pb0 = s_hbb[team][q] + t; pb0 < be; pb0 += 4 * TEAM) {
+          uint32_t pb0 = s_hbb[team][q] + t;
+          for (; pb0 + 7 * TEAM < be; pb0 += 8 * TEAM) {                    // eight loads in flight per lane while whole blocks remain
+            uint32_t j8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) j8[u] = a.bcol[pb0 + TEAM * u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const uint32_t j = j8[u];
+              uint32_t h = hash_col(j, KS - 1);
+              uint32_t kk = key[h];
+              while (kk != j && kk != HASH_EMPTY) { h = (h + 1) & (KS - 1); kk = key[h]; }
+              if (kk == j) { const uint32_t mp = pos[h]; word_combine<T>(sr.add_op(), &acc[mp], sr.mult(av, use_b ? a.bval[pb0 + TEAM * u] : T())); flag[mp] = 1; }
+            }
+          }
+          for (; pb0 < be; pb0 += 4 * TEAM) {
             uint32_t jj[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) { const uint32_t pb = pb0 + TEAM * u; jj[u] = a.bcol[pb < be ? pb : be - 1]; }

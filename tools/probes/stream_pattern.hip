@@ -48,6 +48,57 @@ __global__ __launch_bounds__(1024, 1) void k_stream(const uint8_t* __restrict__ 
   if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) sink[0] = acc.z + acc.w;
 }
 
+// the masked SpGEMM's pattern: a wave walks a "row" of `row_entries` 4-byte entries, 64 entries (256 B) per load instruction, INFL loads in
+// flight per lane (plain global loads) — or 4 entries (16 B) per lane per instruction when VEC
+template <int INFL, bool VEC>
+__global__ __launch_bounds__(512, 2) void k_rows(const uint32_t* __restrict__ base, uint64_t entries, uint32_t row_entries, unsigned long long* sink) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t nrowsT = entries / row_entries, nwaves = (uint64_t)gridDim.x * 8, wid = (uint64_t)blockIdx.x * 8 + (threadIdx.x >> 6);
+  uint32_t acc = 0;
+  for (uint64_t r = wid; r < nrowsT; r += nwaves) {
+    const uint32_t* row = base + r * row_entries;
+    if (VEC) {
+      for (uint32_t p = lane * 4; p < row_entries; p += 256 * INFL) {
+        uint4 v[INFL];
+#pragma unroll
+        for (int u = 0; u < INFL; u++) { const uint32_t q = p + 256 * u; v[u] = q < row_entries ? *(const uint4*)(row + q) : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+        for (int u = 0; u < INFL; u++) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+      }
+    } else {
+      for (uint32_t p = lane; p < row_entries; p += 64 * INFL) {
+        uint32_t v[INFL];
+#pragma unroll
+        for (int u = 0; u < INFL; u++) { const uint32_t q = p + 64 * u; v[u] = row[q < row_entries ? q : row_entries - 1]; }
+#pragma unroll
+        for (int u = 0; u < INFL; u++) acc += v[u];
+      }
+    }
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+template <int INFL, bool VEC> static float run_rows(const uint8_t* buf, uint64_t bytes, uint32_t row_entries, int reps, unsigned long long* sink) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < 2; i++) hipLaunchKernelGGL((k_rows<INFL, VEC>), dim3(1024), dim3(512), 0, 0, (const uint32_t*)buf, bytes / 4, row_entries, sink);
+  hipEventRecord(a, 0);
+  for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k_rows<INFL, VEC>), dim3(1024), dim3(512), 0, 0, (const uint32_t*)buf, bytes / 4, row_entries, sink);
+  hipEventRecord(b, 0); hipEventSynchronize(b);
+  float ms = 0; hipEventElapsedTime(&ms, a, b); hipEventDestroy(a); hipEventDestroy(b);
+  return ms / reps;
+}
+extern "C" int row_pattern_probe(uint64_t bytes) {
+  uint8_t* buf; unsigned long long* sink;
+  if (hipMalloc(&buf, bytes) != hipSuccess || hipMalloc(&sink, 64) != hipSuccess) return 1;
+  hipMemset(buf, 1, bytes); hipDeviceSynchronize();
+  printf("%-12s %-6s %-5s %10s\n", "row entries", "infl", "vec", "GB/s");
+  for (uint32_t re : {512u, 2048u, 8192u, 32768u}) {
+#define RR(I, V) { const float ms = run_rows<I, V>(buf, bytes, re, 10, sink); printf("%-12u %-6d %-5d %10.0f\n", re, I, (int)V, bytes / (ms * 1e-3) / 1e9); }
+    RR(4, false) RR(8, false) RR(16, false) RR(1, true) RR(2, true) RR(4, true)
+#undef RR
+  }
+  fflush(stdout); hipFree(buf); hipFree(sink); return 0;
+}
+
 template <int BURST, int DEPTH, bool NT> static float run(const uint8_t* buf, uint64_t bytes, uint32_t chunk_bytes, int contiguous, int reps, unsigned long long* sink) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int i = 0; i < 2; i++) hipLaunchKernelGGL((k_stream<BURST, DEPTH, NT>), dim3(256), dim3(1024), 0, 0, buf, bytes, chunk_bytes, contiguous, sink);
