@@ -9,6 +9,7 @@
 // Ownership: the library allocates in *_new and frees in *_free(&h); free of NULL / already freed
 // handles is a successful no-op (reference __del__ checks the return code).
 #include "grb_api.hpp"
+#include "grb_device.hpp"
 #include <algorithm>
 #include <numeric>
 #include <string.h>
@@ -140,9 +141,38 @@ void vec_host_assemble(GrB_Vector v) {
   while (b < nb) push_base(b++);
   v->hi.swap(ni); v->hx.swap(nx); P.clear(); P.shrink_to_fit();
 }
-void vec_invalidate_device(GrB_Vector v) { vec_overwritten(v); v->holes_zero = false; v->dev_valid = false; v->dval.reset(); v->dpres.reset(); v->dnvals = 0; v->dnvals_known = true; v->fe_lb = 0; v->fe_lb_key = nullptr; }
+// ---- "any stored value true" of a BOOL product result (grb_spmv.hpp: SpmvCall::any_true) -----------------------------------
+// One device word per thread.  Every product brings a fresh non-zero tag and its kernels store that tag, so the word never has
+// to be cleared: it answers "true" for the vector that holds the tag it currently shows, and only the latest product's vector
+// may ask (GrB_Vector_reduce_BOOL with LOR then reads four bytes instead of launching a kernel over the vector).
+namespace { struct AnyTrue { DevBuf word; GrB_Vector owner = nullptr; uint32_t tag = 0; }; thread_local AnyTrue t_any; }
+uint32_t* any_true_acquire(uint32_t* tag) {
+  AnyTrue& s = t_any;
+  if (!s.word.p) { s.word.alloc(64); GRB_HIP(hipMemsetAsync(s.word.p, 0, 64, stream())); }
+  if (++s.tag == 0) s.tag = 1;            // (a wrap after 2^32 products could meet a stale equal tag only if the word was last written 2^32 products ago)
+  s.owner = nullptr; *tag = s.tag;
+  return s.word.as<uint32_t>();
+}
+void any_true_written(GrB_Vector w, const void* key, uint32_t tag) {
+  t_any.owner = w;
+  if (w) { w->lor_state = 1; w->lor_key = key; w->lor_tag = tag; }
+}
+bool any_true_lookup(GrB_Vector u, bool* value) {
+  if (!u->lor_state || u->lazy || u->q_reads || !u->dev_valid || u->dval.p != u->lor_key) return false;
+  if (u->lor_state == 1) {
+    AnyTrue& s = t_any;
+    if (s.owner != u || s.tag != u->lor_tag) { u->lor_state = 0; return false; }
+    uint32_t* pin = (uint32_t*)pinned_scratch();
+    GRB_HIP(hipMemcpyAsync(pin, s.word.p, 4, hipMemcpyDeviceToHost, stream()));
+    GRB_HIP(hipStreamSynchronize(stream()));
+    u->lor_state = pin[0] == u->lor_tag ? 3 : 2; s.owner = nullptr;
+  }
+  *value = u->lor_state == 3; return true;
+}
+
+void vec_invalidate_device(GrB_Vector v) { vec_overwritten(v); v->holes_zero = false; v->lor_state = 0; v->dev_valid = false; v->dval.reset(); v->dpres.reset(); v->dnvals = 0; v->dnvals_known = true; v->fe_lb = 0; v->fe_lb_key = nullptr; }
 void vec_invalidate_host(GrB_Vector v) {
-  vec_overwritten(v); v->holes_zero = false;
+  vec_overwritten(v); v->holes_zero = false; v->lor_state = 0;
   v->host_valid = false; v->hi.clear(); v->hx.clear(); v->pending.clear(); v->hi.shrink_to_fit(); v->hx.shrink_to_fit();
 }
 void vec_to_host(GrB_Vector v) {

@@ -157,6 +157,9 @@ struct GrB_Vector_opaque {
   // Every access goes through vec_gate() (vec_to_device / vec_to_host / vec_nvals / the entry points of grb_container.cpp).
   int lazy = 0; uint8_t lazy_fill[16] = {0}; int q_reads = 0;
   bool holes_zero = false;     // the device values of absent positions are all-zero bits (written so by the element-wise chain kernel)
+  // BOOL vectors: "is any stored value true", recorded by the product kernel that wrote the device buffers `lor_key`
+  // (0 unknown, 1 in the device word of grb_container.cpp's any_true_*, 2 false, 3 true) — `while q.reduce_bool()` of a BFS loop
+  uint8_t lor_state = 0; uint32_t lor_tag = 0; const void* lor_key = nullptr;
   int sparsity_control = 15;
   std::string err;
 };
@@ -192,6 +195,9 @@ void host_assign_scalar(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const
 void vec_resolve(GrB_Vector v);           // complete deferred work that involves v (grb_lazy.cpp)
 inline void vec_gate(GrB_Vector v) { if (v->lazy | v->q_reads) vec_resolve(v); }
 void vec_overwritten(GrB_Vector v);       // v's value is about to be replaced as a whole: deferred work that only produced it is dropped
+uint32_t* any_true_acquire(uint32_t* tag);        // a device word a BOOL product kernel sets to the (fresh, non-zero) tag when it writes a true value (see lor_state)
+void any_true_written(GrB_Vector w_or_null, const void* key, uint32_t tag);    // a kernel honoured it; w's device buffers `key` are the result it describes (nullptr: nobody's)
+bool any_true_lookup(GrB_Vector u, bool* value);
 bool nonblocking();                       // GrB_init(GrB_NONBLOCKING) and not GRB_MI355X_BLOCKING=1
 void vec_host_assemble(GrB_Vector v);
 void vec_to_host(GrB_Vector v);

@@ -111,6 +111,11 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
 
   SpmvCall call{};
   call.uval = uval; call.allow = allow; call.tval = tval.p; call.tpres = tpres.as<uint8_t>(); call.method = method;
+  // a BOOL result that replaces w: the kernel notes whether it wrote a true value, and the `q.reduce_bool()` that follows a BFS
+  // level (tests/test_bfs.py loop: `while q.reduce_bool() and level <= n`) reads that word instead of scanning q
+  bool any_done = false;
+  if (sd.zcode == T_BOOL && w->type->code == T_BOOL && !accum && method == SPMV_AUTO) { call.any_true = any_true_acquire(&call.any_true_tag); call.any_true_done = &any_done; }
+  const void* const tkey = tval.p;
   if (push) {
     // push walks rows of M^T:  M^T = useT ? A : A^T
     DevCSR& P = useT ? A->csr : const_cast<DevCSR&>(mat_csc(A));
@@ -141,6 +146,7 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
     }
   }
   vector_write_back(w, sd.zcode, tval, tpres, allow, accum, dv.replace, /*t_only_allowed=*/true);
+  if (any_done) any_true_written(w->lazy == 0 && w->dev_valid && w->dval.p == tkey ? w : nullptr, tkey, call.any_true_tag);       // (adopted as they are: w is exactly T)
 }
 
 extern "C" {

@@ -30,6 +30,10 @@ struct SpmvCall {
   //   epi == 2: w is the pending fill `epi_fill` everywhere (`w(:) = s` not yet written): tval = s (+) sum / s, tpres = 1
   // A kernel that honours it sets *epi_done; otherwise the product lands in tval/tpres as usual and the caller runs the epilogue.
   int epi = 0; void* epi_w = nullptr; uint8_t epi_fill[16] = {0}; bool* epi_done = nullptr;
+  // optional summary of a BOOL result: a device word the kernel sets to `any_true_tag` when it writes an entry whose value is true
+  // (`while q.reduce_bool()` of a BFS loop then needs no kernel of its own; a fresh tag per product, so the word is never
+  // cleared).  A kernel that honours it sets *any_true_done.
+  uint32_t* any_true = nullptr; uint32_t any_true_tag = 0; bool* any_true_done = nullptr;
 };
 
 const std::string& xcd_mapping();   // "roundrobin8" when workgroup b of a full-chip launch runs on XCD b % 8 (probed once)

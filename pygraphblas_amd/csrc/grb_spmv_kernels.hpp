@@ -48,7 +48,9 @@ template <class T> struct SpmvKArgs {
   T* tval; uint8_t* tpres;
   const SpmvBlock* blocks; uint32_t* tickets; T* partial; uint8_t* pflag;
   uint32_t nrows;
+  uint32_t* any_true; uint32_t any_true_tag;      // BOOL results only (nullptr otherwise): set to the tag when an entry with value true is written
 };
+template <class T> __device__ __forceinline__ bool spmv_truthy(T v) { if constexpr (is_bool<T>::value) return v.v != 0; else return v != T(); }
 
 // ---- kernel A ---------------------------------------------------------------------------------------------------
 template <class T, class SR, bool U_FULL, bool HAS_ALLOW, int GM = 0, int SM = 0>
@@ -286,6 +288,7 @@ __global__ __launch_bounds__(256) void k_spmv_rowlane(const SpmvKArgs<T> a, cons
       if (lane == L && hb) { acc = has ? sr.add(acc, red) : red; has = true; }
     }
     if (valid) { if (allowed && has) a.tval[r] = acc; a.tpres[r] = (allowed && has) ? 1 : 0; }
+    if (a.any_true) { if (__ballot(valid && allowed && has && spmv_truthy<T>(acc)) && lane == 0) *a.any_true = a.any_true_tag; }      // (same value from every wave: a benign race)
   }
 }
 
@@ -325,7 +328,7 @@ template <class T, class SR>
 __global__ __launch_bounds__(256) void k_spmspv_push(const uint32_t* __restrict__ fidx, uint32_t nf, const uint32_t* __restrict__ rowptr,
                                                      const uint32_t* __restrict__ col, const T* __restrict__ aval, const T* __restrict__ uval,
                                                      const uint8_t* __restrict__ allow, T* __restrict__ tval, uint8_t* __restrict__ tpres,
-                                                     uint32_t* __restrict__ longlist, const SR sr) {
+                                                     uint32_t* __restrict__ longlist, const SR sr, uint32_t* __restrict__ any_true = nullptr, const uint32_t any_tag = 0) {
   // one wave per frontier entry: its row of M^T (= CSR row of the stored matrix) is streamed coalesced
   const int lane = threadIdx.x & 63;
   const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6;
@@ -345,6 +348,7 @@ __global__ __launch_bounds__(256) void k_spmspv_push(const uint32_t* __restrict_
       const T m = sr.mult(use_a ? aval[p] : T(), ui);
       atomic_combine<T>(sr.add_op(), &tval[j], m);
       tpres[j] = 1;
+      if (any_true && spmv_truthy<T>(m)) *any_true = any_tag;             // BOOL monoids of the push path only OR values in: a true product is a true entry
     }
   }
 }
@@ -353,7 +357,8 @@ __global__ __launch_bounds__(256) void k_spmspv_push(const uint32_t* __restrict_
 template <class T, class SR>
 __global__ __launch_bounds__(256) void k_spmspv_push_long(const uint32_t* __restrict__ longlist, const uint32_t* __restrict__ rowptr,
                                                           const uint32_t* __restrict__ col, const T* __restrict__ aval, const T* __restrict__ uval,
-                                                          const uint8_t* __restrict__ allow, T* __restrict__ tval, uint8_t* __restrict__ tpres, const SR sr) {
+                                                          const uint8_t* __restrict__ allow, T* __restrict__ tval, uint8_t* __restrict__ tpres, const SR sr,
+                                                          uint32_t* __restrict__ any_true = nullptr, const uint32_t any_tag = 0) {
   const uint32_t nl = longlist[0];
   const bool use_a = sr.uses_a(), use_u = sr.uses_u();
   // few long rows: every block takes a slice of each; many: one block per row
@@ -368,6 +373,7 @@ __global__ __launch_bounds__(256) void k_spmspv_push_long(const uint32_t* __rest
       const T m = sr.mult(use_a ? aval[p] : T(), ui);
       atomic_combine<T>(sr.add_op(), &tval[j], m);
       tpres[j] = 1;
+      if (any_true && spmv_truthy<T>(m)) *any_true = any_tag;
     }
   }
 }
@@ -400,7 +406,7 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
     typedef decltype(sr) SR;
     SpmvKArgs<T> a{};
     a.rowptr = M.rowptr.as<uint32_t>(); a.col = M.col.as<uint32_t>(); a.aval = (const T*)c.aval;
-    a.uval = (const T*)c.uval; a.upres = c.upres; a.allow = c.allow; a.tval = (T*)c.tval; a.tpres = c.tpres; a.nrows = M.nrows;
+    a.uval = (const T*)c.uval; a.upres = c.upres; a.allow = c.allow; a.tval = (T*)c.tval; a.tpres = c.tpres; a.nrows = M.nrows; a.any_true = nullptr;
     const bool full = c.upres == nullptr;
     // masked pull with a terminal monoid (BFS) -> row-group kernel with early exit; otherwise the row-block kernel
     const bool prefer_rowgroup = c.method == SPMV_ROWGROUP || (c.method == SPMV_AUTO && c.allow && d.has_terminal);
@@ -416,6 +422,7 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
       static const bool no_lane = wp_env("GRB_MI355X_NO_ROWLANE", 0) != 0;      // measurement hook
       if (G == 8 && !no_lane && c.method == SPMV_AUTO) {                          // short rows on average: a lane per row (kernel B')
         uint64_t nbl = ((uint64_t)M.nrows + 255) / 256; if (nbl < 1) nbl = 1; if (nbl > 65536) nbl = 65536;
+        if (c.any_true && c.any_true_done && is_bool<T>::value) { a.any_true = c.any_true; a.any_true_tag = c.any_true_tag; *c.any_true_done = true; }
         if (full) hipLaunchKernelGGL((k_spmv_rowlane<T, SR, true>), dim3((unsigned)nbl), dim3(256), 0, stream(), a, sr);
         else hipLaunchKernelGGL((k_spmv_rowlane<T, SR, false>), dim3((unsigned)nbl), dim3(256), 0, stream(), a, sr);
         g_last_plan += std::string("k_spmv_rowlane<") + (sr.is_static ? "static>" : "dynamic>") + " ";
@@ -483,10 +490,12 @@ template <class T> void run_push(const SpmvCall& c, const SemiringDesc& d, const
     typedef decltype(sr) SR;
     if (nout) hipLaunchKernelGGL((k_fill<T>), dim3(grid_of(nout)), dim3(256), 0, stream(), (T*)c.tval, nout, sr.identity);
     uint64_t nb = (u_nvals + 3) / 4; if (nb < 1) nb = 1; if (nb > 16384) nb = 16384;
+    uint32_t* any_true = nullptr;
+    if (c.any_true && c.any_true_done && is_bool<T>::value && (sr.add_op() == B_LOR || sr.add_op() == B_PLUS || sr.add_op() == B_MAX)) { any_true = c.any_true; *c.any_true_done = true; }
     hipLaunchKernelGGL((k_spmspv_push<T, SR>), dim3((unsigned)nb), dim3(256), 0, stream(), fidx, (uint32_t)u_nvals,
-                       M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(), (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, longlist, sr);
+                       M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(), (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, longlist, sr, any_true, c.any_true_tag);
     hipLaunchKernelGGL((k_spmspv_push_long<T, SR>), dim3(1024), dim3(256), 0, stream(), longlist, M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(),
-                       (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, sr);
+                       (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, sr, any_true, c.any_true_tag);
     g_last_plan += std::string("k_spmspv_push<") + (sr.is_static ? "static> " : "dynamic> ");
   });
 }

@@ -69,6 +69,18 @@ static GrB_Info vec_reduce(void* c, int ccode, GrB_BinaryOp accum, GrB_Monoid mo
         scalar_accum(c, ccode, r, mc, accum); return;
       }
     }
+    if (u->lor_state && u->type->code == T_BOOL && check_obj(monoid) && check_obj(monoid->op) && monoid->op->opcode == B_LOR && monoid->op->ztype->code == T_BOOL) {
+      bool any = false;                                  // the kernel that produced u already noted it (grb_mxv.cpp)
+      if (any_true_lookup(u, &any)) { const uint8_t r = any ? 1 : 0; scalar_accum(c, ccode, &r, T_BOOL, accum); return; }
+    }
+    if (u->host_valid && !u->lazy && !u->q_reads && !u->iso_full && u->type->code == T_BOOL && check_obj(monoid) && check_obj(monoid->op) &&
+        (monoid->op->opcode == B_LOR || monoid->op->opcode == B_LAND) && monoid->op->ztype->code == T_BOOL) {
+      // the entries are on the host (`q[start] = True` in front of the loop): LOR / LAND over them needs no device at all
+      vec_host_assemble(u);
+      const bool want = monoid->op->opcode == B_LOR; bool hit = false;
+      for (uint8_t x : u->hx) if ((x != 0) == want) { hit = true; break; }
+      const uint8_t r = want ? hit : !hit; scalar_accum(c, ccode, &r, T_BOOL, accum); return;
+    }
     vec_to_device(u); reduce_common(c, ccode, accum, monoid, u->type->code, u->dval.p, u->dpres.as<uint8_t>(), u->n); });
 }
 static GrB_Info mat_reduce(void* c, int ccode, GrB_BinaryOp accum, GrB_Monoid monoid, GrB_Matrix A) {

@@ -353,3 +353,47 @@ def test_nan_products_under_fp_min_max_agree_on_every_path(gpu, typ, sr, monkeyp
             TM.run_case(np.random.default_rng(5), typ, sr, 60, 50, 40, 0.05, 0.05, mask=mask, accum=None)
             TM.run_case(np.random.default_rng(7), typ, sr, 60, 50, 40, 0.3, 0.3, mask=mask, accum=None)
             TM.run_case(np.random.default_rng(6), typ, sr, 300, 20, 300, 0.5, 0.5, mask=mask, accum="MAX")
+
+
+def test_reduce_bool_after_a_bool_product_reads_the_kernels_summary(gpu):
+    """`while q.reduce_bool()` of the BFS loop (reference tests/test_bfs.py): the masked pull and the push kernels note whether
+    they wrote a true value, and GrB_Vector_reduce_BOOL(LOR) reads that word instead of scanning q.  The answer must be the one a
+    scan gives — with false-valued entries in the result (stored false values in A), an empty result, pull and push directions,
+    after the vector changes (setElement, masked assign, clear), after a second product claimed the word, and for a dup."""
+    rng = np.random.default_rng(77)
+    n = 3000
+    for dens_a, dens_u, a_true in ((0.004, 0.5, 0.5), (0.004, 0.001, 1.0), (0.004, 0.001, 0.0), (0.004, 0.3, 0.0), (0.02, 0.0005, 0.3)):
+        nnz = int(n * n * dens_a); flat = np.sort(rng.choice(n * n, nnz, replace=False)); I, J = np.divmod(flat, n)
+        X = rng.random(nnz) < a_true
+        A = gb.Matrix.from_arrays(I.astype(np.uint64), J.astype(np.uint64), X, n, n, gb.BOOL)
+        ui = np.sort(rng.choice(n, max(1, int(n * dens_u)), replace=False)).astype(np.uint64)
+        u = gb.Vector.from_arrays(ui, np.ones(len(ui), np.bool_), n, gb.BOOL)
+        mi = np.sort(rng.choice(n, n // 3, replace=False)).astype(np.uint64)
+        seen = gb.Vector.from_arrays(mi, np.ones(len(mi), np.uint8), n, gb.UINT8)
+        for mask, desc in ((seen, D.RC), (None, None), (seen, D.R)):
+            q = gb.Vector.sparse(gb.BOOL, n)
+            u.vxm(A, out=q, mask=mask, desc=desc)
+            plan = gb.last_kernel_plan()
+            got = q.reduce_bool()
+            idx, val = vector_pairs(q)
+            assert got == bool(np.any(val)), (plan, dens_a, dens_u, a_true)
+            assert q.reduce_bool() == got                         # the cached answer
+            d = q.dup(); assert d.reduce_bool() == got
+            # a second product takes the word over: the first vector falls back to the scan
+            q2 = gb.Vector.sparse(gb.BOOL, n); u.vxm(A, out=q2, mask=mask, desc=desc)
+            q3 = gb.Vector.sparse(gb.BOOL, n); u.vxm(A, out=q3, mask=mask, desc=desc)
+            assert q2.reduce_bool() == got and q3.reduce_bool() == got
+            # changes after the product
+            q2[5] = True; assert q2.reduce_bool() is True
+            q3.assign_scalar(False, mask=seen); i3, v3 = vector_pairs(q3); assert q3.reduce_bool() == bool(np.any(v3))
+            q.clear(); assert q.reduce_bool() is False
+    # the loop itself, both directions taken along the way
+    A = gb.Matrix.from_arrays(I.astype(np.uint64), J.astype(np.uint64), np.ones(nnz, np.bool_), n, n, gb.BOOL)
+    v = gb.Vector.sparse(gb.UINT8, n); q = gb.Vector.sparse(gb.BOOL, n); q[0] = True
+    level = 1; sizes = []
+    while q.reduce_bool() and level <= n:
+        sizes.append(q.nvals)
+        v.assign_scalar(level, mask=q)
+        v.vxm(A, mask=v, out=q, desc=D.RC)
+        level += 1
+    assert sum(sizes) == v.nvals and level > 2
