@@ -49,24 +49,53 @@ __device__ __forceinline__ bool spgemm_mask_truth(const void* mval, int mcode, u
 // Work inside a row is wildly uneven (R-MAT: B rows of 1 ... 40 000 entries), so the entries k of A(i,:) are first
 // sorted into two LDS work lists by the length of B(k,:): short rows (< 64 entries) are walked by 16-lane groups,
 // four at a time per wave; long rows by a whole wave each, 64 coalesced entries per step.
+struct __attribute__((packed, aligned(4))) spg_u4 { uint32_t x, y, z, w; };     // four consecutive column indices of a row, one 16-byte load at 4-byte alignment
+// measurement builds (make XTFLAGS=-DSPG_EXP=n): 1 = no B-row loads (synthetic columns: what the probes and barriers cost alone),
+// 2 = B-row loads without the probes (what the streams cost under this kernel's work split), 3 = every B row read from one 2 MiB window
+#ifndef SPG_EXP
+#define SPG_EXP 0
+#endif
+__device__ __forceinline__ uint32_t spg_ld(const uint32_t* __restrict__ p, uint32_t i) {
+  if constexpr (SPG_EXP == 1) return (i * 2654435761u) >> 10; else return p[i];
+}
+__device__ __forceinline__ spg_u4 spg_ld4(const uint32_t* __restrict__ p, uint32_t i) {
+  if constexpr (SPG_EXP == 1) { spg_u4 r; r.x = (i * 2654435761u) >> 10; r.y = ((i + 1) * 2654435761u) >> 10; r.z = ((i + 2) * 2654435761u) >> 10; r.w = ((i + 3) * 2654435761u) >> 10; return r; }
+  else return *(const spg_u4*)(p + i);
+}
 constexpr int SPG_LIST = 512;       // k's staged per round (per team)
 constexpr uint32_t SPG_HUGE = 2048; // B rows at least this long are shared by the whole team
+constexpr int SPG_QCAP = 128;       // survivor queue of a wave (flushed 64 at a time)
+constexpr uint32_t SPG_FILTER_MUL = 0x9E3779u;   // 24-bit multiplier: v_mul_u32_u24 runs at full rate, v_mul_lo_u32 at a quarter
+// Round 3, second half.  The measurement builds (SPG_EXP) showed what the kernel's time is: without any B-row load it still took
+// 53 of 67 ms, with the loads and without the probes 38 ms, with every B row read out of one L2-resident window 63 ms.  It is the
+// VALU: eight waves per SIMD keep it 80 % busy (SQ_ACTIVE_INST_VALU = 10 % of wave cycles x 8), because a probe is a
+// quarter-rate integer multiply plus a linear-probing loop that the whole wave repeats until its unluckiest lane is done
+// (~2.75 rounds of 5 VALU + 5 SALU instructions at load 1/4), and 96 % of the products are misses that only had to learn "no".
+// Now a product first asks a BIT FILTER of the mask row (16 bits per table slot, one 24-bit multiply, one LDS read, no loop);
+// the few lanes that pass (the 3.7 % hits + ~1-3 % false positives) append their column to the wave's queue in LDS (ballot +
+// mbcnt), and whenever the queue holds 64 columns the wave looks all of them up in the exact table with every lane busy.
+// When the multiply reads no value (PLUS_PAIR: the triangle count) the queue is carried from B row to B row; otherwise it is
+// flushed at the end of every B row (the A value changes), and B rows shorter than 256 entries keep the direct lookup.
 template <class T, class SR, int SLOTS, int TEAM, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T> a, const uint32_t* __restrict__ rows, uint32_t nrows_bin, const SR sr) {
   typedef typename acc_word<T>::type W;
   constexpr int TEAMS = BLOCK / TEAM;
   constexpr int LCAP = TEAM >= 256 ? SPG_LIST : 64;
-  // Nearly every product of a masked product misses the mask (triangle counting: most wedges are open), and the kernel is
-  // bound by its random LDS reads — so the key table is kept sparse: KS = 2 * SLOTS keys for at most SLOTS / 2 mask entries
-  // (load <= 1/4: 1.4 reads per miss instead of 2.5 at load 1/2), while the accumulators are indexed by the mask position the
-  // slot carries and take only SLOTS / 2 words.  (A bucketised table — four keys per 16-byte read, ~1.1 reads per product —
-  // was slower, 0.130 s against 0.099 s for the R-MAT-22 triangle count: the limit is LDS bytes and bank conflicts, not the
-  // length of the dependent chain.)
-  constexpr int KS = 2 * SLOTS, ML = SLOTS / 2;
+  constexpr bool NOVAL = SR::pair_only;                 // the product is a constant: a queued survivor is its column alone
+  // the exact table: open addressing, at most SLOTS / 2 mask entries in KS keys (load <= 1/4 in the two small bins, <= 1/2 in the
+  // large ones, where the LDS goes to the filter and the queues instead — only survivors of the filter walk its chains now);
+  // the accumulators are indexed by the mask position the slot carries and take only SLOTS / 2 words
+  constexpr int KS = SLOTS <= 512 ? 2 * SLOTS : SLOTS, ML = SLOTS / 2;
+  constexpr int FBITS = 16 * SLOTS, FW = FBITS / 32;    // the filter: >= 32 bits per mask entry
+  constexpr int FSH = 32 - __builtin_ctz(FBITS);
+  constexpr int WAVES = BLOCK / 64;
   __shared__ uint32_t s_key[TEAMS][KS];
   __shared__ uint16_t s_pos[TEAMS][KS];
   __shared__ W s_acc[TEAMS][ML];
   __shared__ uint8_t s_flag[TEAMS][ML];
+  __shared__ uint32_t s_filt[TEAMS][FW];
+  __shared__ uint32_t s_qj[WAVES][SPG_QCAP];
+  __shared__ uint32_t s_qp[NOVAL ? 1 : WAVES][NOVAL ? 1 : SPG_QCAP];
   __shared__ uint32_t s_lpa[TEAMS][LCAP], s_lbb[TEAMS][LCAP], s_lbe[TEAMS][LCAP];     // work list: A-entry position, B row begin / end
   __shared__ uint32_t s_cnt[TEAMS][3];                                                  // [0] short rows fill from the front, [1] long rows from the back, [2] huge rows
   constexpr int HCAP = TEAM > 64 ? 64 : 1;                                              // B rows of >= SPG_HUGE entries are walked by the whole team (one wave would hold the others at the barrier)
@@ -76,13 +105,58 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
   constexpr int NG = TEAM / 16, NW = TEAM / 64;
   const bool use_a = sr.uses_a(), use_b = sr.uses_u();
   const W idw = to_word<T>(sr.identity);
-  uint32_t* key = s_key[team]; W* acc = s_acc[team]; uint16_t* pos = s_pos[team]; uint8_t* flag = s_flag[team];
+  uint32_t* key = s_key[team]; W* acc = s_acc[team]; uint16_t* pos = s_pos[team]; uint8_t* flag = s_flag[team]; uint32_t* filt = s_filt[team];
   uint32_t* lpa = s_lpa[team]; uint32_t* lbb = s_lbb[team]; uint32_t* lbe = s_lbe[team]; uint32_t* cnt = s_cnt[team];
+  uint32_t* qj = s_qj[threadIdx.x >> 6]; uint32_t* qp = s_qp[NOVAL ? 0 : (threadIdx.x >> 6)];
   // a team of one wave (the bin of the shortest mask rows: four rows per block) needs no block barrier: its LDS slices are
   // private and LDS operations of a wave execute in order, so every row runs exactly its own number of rounds
+  auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
   auto team_sync = [&]() {
-    if constexpr (TEAM == 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+    if constexpr (TEAM == 64) wave_sync();
     else __syncthreads();
+  };
+  // one product against the table: column j of B(k,:) at position pb
+  auto probe = [&](const uint32_t j, const uint32_t pb, const T av) {
+    if constexpr (SPG_EXP == 2) { if (j == 0xFFFFFFF1u) flag[0] = 1; return; }
+    uint32_t h = hash_col(j, KS - 1);
+    uint32_t kk = key[h];
+    while (kk != j && kk != HASH_EMPTY) { h = (h + 1) & (KS - 1); kk = key[h]; }
+    if (kk == j) { const uint32_t mp = pos[h]; word_combine<T>(sr.add_op(), &acc[mp], sr.mult(av, use_b ? a.bval[pb] : T())); flag[mp] = 1; }
+  };
+  // bit FSH.. of the 24-bit product picks the filter bit: the top LW bits the word, the five below them the bit in the word
+  constexpr int LW = __builtin_ctz(FW);
+  auto filter_hash = [&](const uint32_t j) -> uint32_t { return (uint32_t)__umul24(j, SPG_FILTER_MUL); };      // (the intrinsic returns a signed int: shift the unsigned value)
+  auto filter_bit = [&](const uint32_t j) -> uint32_t { return filter_hash(j) >> FSH; };
+  auto filter_word = [&](const uint32_t j) -> uint32_t { return filt[filter_hash(j) >> (32 - LW)]; };
+  auto filter_pass = [&](const uint32_t j, const uint32_t word) -> bool { return __builtin_amdgcn_ubfe(word, filter_hash(j) >> FSH, 1u) != 0u; };
+  // ---- the filtered path (whole waves only: every lane of the wave calls these together) ----
+  uint32_t qn = 0;                                         // entries in this wave's queue (wave-uniform)
+  auto flush = [&](const uint32_t n, const T av) {         // look the first n (<= 64) queued columns up in the table
+    wave_sync();
+    if ((uint32_t)lane64 < n) probe(qj[lane64], NOVAL ? 0u : qp[lane64], av);
+  };
+  auto push = [&](const bool pass, const uint32_t j, const uint32_t pb, const T av) {
+    const unsigned long long m = __ballot(pass);
+    if (m) {
+      const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      if (pass) { qj[qn + r] = j; if constexpr (!NOVAL) qp[qn + r] = pb; }
+      qn = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qn + (uint32_t)__popcll(m)));     // (kept in a scalar register)
+      if (qn >= 64) {
+        flush(64, av);
+        const uint32_t rest = qn - 64;                     // < 64: the tail moves to the front
+        uint32_t xj = 0, xp = 0;
+        if ((uint32_t)lane64 < rest) { xj = qj[64 + lane64]; if constexpr (!NOVAL) xp = qp[64 + lane64]; }
+        wave_sync();
+        if ((uint32_t)lane64 < rest) { qj[lane64] = xj; if constexpr (!NOVAL) qp[lane64] = xp; }
+        qn = rest;
+      }
+    }
+  };
+  // four consecutive entries per lane / one entry per lane, `ok` = the entry exists
+  auto sift4 = [&](const spg_u4 j4, const uint32_t pb, const T av) {
+    const uint32_t w0 = filter_word(j4.x), w1 = filter_word(j4.y), w2 = filter_word(j4.z), w3 = filter_word(j4.w);
+    push(filter_pass(j4.x, w0), j4.x, pb, av); push(filter_pass(j4.y, w1), j4.y, pb + 1, av);
+    push(filter_pass(j4.z, w2), j4.z, pb + 2, av); push(filter_pass(j4.w, w3), j4.w, pb + 3, av);
   };
   const uint32_t nblk_rows = (nrows_bin + TEAMS - 1) / TEAMS * TEAMS;     // every team runs the same trip count
   for (uint32_t rbase = blockIdx.x * TEAMS; rbase < nblk_rows; rbase += gridDim.x * TEAMS) {
@@ -91,6 +165,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
     const uint32_t i = live ? rows[ridx] : 0;
     for (int s2 = t; s2 < KS; s2 += TEAM) key[s2] = HASH_EMPTY;
     for (int s2 = t; s2 < ML; s2 += TEAM) { acc[s2] = idw; flag[s2] = 0; }
+    for (int s2 = t; s2 < FW; s2 += TEAM) filt[s2] = 0;
     team_sync();
     const uint32_t mb = live ? a.mrp[i] : 0, me = live ? a.mrp[i + 1] : 0;
     for (uint32_t p = mb + t; p < me; p += TEAM) {
@@ -99,6 +174,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
       uint32_t h = hash_col(j, KS - 1);
       while (atomicCAS(&key[h], HASH_EMPTY, j) != HASH_EMPTY) h = (h + 1) & (KS - 1);
       pos[h] = (uint16_t)(p - mb);
+      const uint32_t fb = filter_bit(j);
+      atomicOr(&filt[fb >> 5], 1u << (fb & 31));
     }
     const uint32_t ab = live ? a.arp[i] : 0, ae = live ? a.arp[i + 1] : 0;
     // the longest A row of the block decides the number of rounds, so every team reaches every barrier
@@ -117,8 +194,9 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
       // stage the next LCAP entries of A(i,:) into the short / long lists
       for (uint32_t q = r0 + t; q < r0 + LCAP && ab + q < ae; q += TEAM) {
         const uint32_t pa = ab + q, k = a.acol[pa];
-        const uint32_t bb = a.brp[k], be = a.brp[k + 1];
+        uint32_t bb = a.brp[k], be = a.brp[k + 1];
         if (be == bb) continue;
+        if constexpr (SPG_EXP == 3) { const uint32_t len = be - bb; bb &= 0x7FFFFu; be = bb + len; }      // every B row out of one 2 MiB window: what L2-resident streams would give
         if (TEAM > 64 && be - bb >= SPG_HUGE) {
           const uint32_t hs = atomicAdd(&cnt[2], 1u);
           if (hs < (uint32_t)HCAP) { s_hpa[team][hs] = pa; s_hbb[team][hs] = bb; s_hbe[team][hs] = be; continue; }
@@ -129,16 +207,13 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
       }
       team_sync();
       const uint32_t nshort = cnt[0], nlong = cnt[1], nhuge = cnt[2] < (uint32_t)HCAP ? cnt[2] : (uint32_t)HCAP;
-      // short rows: one 16-lane group each
+      // short rows: one 16-lane group each, straight to the table
       for (uint32_t q = grp; q < nshort; q += NG) {
         const T av = use_a ? a.aval[lpa[q]] : T();
         const uint32_t be = lbe[q];
         for (uint32_t pb = lbb[q] + lane16; pb < be; pb += 16) {
-          const uint32_t j = a.bcol[pb];
-          uint32_t h = hash_col(j, KS - 1);
-          uint32_t kk = key[h];
-          while (kk != j && kk != HASH_EMPTY) { h = (h + 1) & (KS - 1); kk = key[h]; }
-          if (kk == j) { const uint32_t mp = pos[h]; word_combine<T>(sr.add_op(), &acc[mp], sr.mult(av, use_b ? a.bval[pb] : T())); flag[mp] = 1; }
+          const uint32_t j = spg_ld(a.bcol, pb);
+          probe(j, pb, av);
         }
       }
       // long rows: one wave each
@@ -146,76 +221,66 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
         const uint32_t sl = LCAP - 1 - q;
         const T av = use_a ? a.aval[lpa[sl]] : T();
         const uint32_t be = lbe[sl];
-        uint32_t pb0 = lbb[sl] + lane64;
-        // whole blocks of 512 entries first: EIGHT loads in flight per lane (the kernel is parked on its B-row loads 65 % of its
-        // cycles — profiles/r03_spgemm_sq_wave_cycles.txt — and a wave with four 256-byte loads in flight cannot cover the latency)
-        for (; pb0 + 448 < be; pb0 += 512) {
-          uint32_t j8[8];
+        uint32_t base = lbb[sl];
+        if (NOVAL || be - base >= 256) {
+          // blocks of 1024 entries as FOUR 16-byte loads per lane (1 KiB per wave instruction, at the row's own 4-byte alignment)
+          for (; base + 1024 <= be; base += 1024) {
+            spg_u4 j4[4];
 #pragma unroll
-          for (int u = 0; u < 8; u++) j8[u] = a.bcol[pb0 + 64 * u];
+            for (int u = 0; u < 4; u++) j4[u] = spg_ld4(a.bcol, base + 256 * u + 4 * lane64);
 #pragma unroll
-          for (int u = 0; u < 8; u++) {
-            const uint32_t j = j8[u];
-            uint32_t h = hash_col(j, KS - 1);
-            uint32_t kk = key[h];
-            while (kk != j && kk != HASH_EMPTY) { h = (h + 1) & (KS - 1); kk = key[h]; }
-            if (kk == j) { const uint32_t mp = pos[h]; word_combine<T>(sr.add_op(), &acc[mp], sr.mult(av, use_b ? a.bval[pb0 + 64 * u] : T())); flag[mp] = 1; }
+            for (int u = 0; u < 4; u++) sift4(j4[u], base + 256 * u + 4 * lane64, av);
           }
-        }
-        for (; pb0 < be; pb0 += 256) {
-          uint32_t jj[4];
+          for (; base < be; base += 256) {                 // the rest, 64 entries per load, four loads in flight
+            uint32_t jj[4], bt[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) { const uint32_t pb = pb0 + 64 * u; jj[u] = a.bcol[pb < be ? pb : be - 1]; }   // 4 loads in flight
+            for (int u = 0; u < 4; u++) { const uint32_t pb = base + 64 * u + lane64; jj[u] = spg_ld(a.bcol, pb < be ? pb : be - 1); }
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const uint32_t pb = pb0 + 64 * u;
-            if (pb < be) {
-              const uint32_t j = jj[u];
-              uint32_t h = hash_col(j, KS - 1);
-              uint32_t kk = key[h];
-              while (kk != j && kk != HASH_EMPTY) { h = (h + 1) & (KS - 1); kk = key[h]; }
-              if (kk == j) { const uint32_t mp = pos[h]; word_combine<T>(sr.add_op(), &acc[mp], sr.mult(av, use_b ? a.bval[pb] : T())); flag[mp] = 1; }
-            }
+            for (int u = 0; u < 4; u++) bt[u] = filter_word(jj[u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t pb = base + 64 * u + lane64; if (base + 64 * u < be) push(filter_pass(jj[u], bt[u]) && pb < be, jj[u], pb, av); }
+          }
+          if constexpr (!NOVAL) { if (qn) { flush(qn, av); qn = 0; wave_sync(); } }
+        } else {
+          for (uint32_t pb0 = base + lane64; pb0 < be; pb0 += 256) {
+            uint32_t jj[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t pb = pb0 + 64 * u; jj[u] = spg_ld(a.bcol, pb < be ? pb : be - 1); }   // 4 loads in flight
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t pb = pb0 + 64 * u; if (pb < be) probe(jj[u], pb, av); }
           }
         }
       }
-      // huge rows: the whole team, TEAM coalesced entries per step, 4 loads in flight per lane
+      // huge rows: the whole team, 4 * TEAM coalesced entries per step (16 bytes per lane)
       if constexpr (TEAM > 64) {
         for (uint32_t q = 0; q < nhuge; q++) {
           const T av = use_a ? a.aval[s_hpa[team][q]] : T();
           const uint32_t be = s_hbe[team][q];
-          uint32_t pb0 = s_hbb[team][q] + t;
-          for (; pb0 + 7 * TEAM < be; pb0 += 8 * TEAM) {                    // eight loads in flight per lane while whole blocks remain
-            uint32_t j8[8];
+          uint32_t base = s_hbb[team][q];
+          constexpr int HD = TEAM >= 512 ? 1 : 2;                        // 16-byte loads per lane and step: 4 * TEAM * HD <= SPG_HUGE entries, so every huge row takes this path
+          for (; base + 4 * TEAM * HD <= be; base += 4 * TEAM * HD) {
+            spg_u4 j4[HD];
 #pragma unroll
-            for (int u = 0; u < 8; u++) j8[u] = a.bcol[pb0 + TEAM * u];
+            for (int u = 0; u < HD; u++) j4[u] = spg_ld4(a.bcol, base + 4 * TEAM * u + 4 * t);
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-              const uint32_t j = j8[u];
-              uint32_t h = hash_col(j, KS - 1);
-              uint32_t kk = key[h];
-              while (kk != j && kk != HASH_EMPTY) { h = (h + 1) & (KS - 1); kk = key[h]; }
-              if (kk == j) { const uint32_t mp = pos[h]; word_combine<T>(sr.add_op(), &acc[mp], sr.mult(av, use_b ? a.bval[pb0 + TEAM * u] : T())); flag[mp] = 1; }
-            }
+            for (int u = 0; u < HD; u++) sift4(j4[u], base + 4 * TEAM * u + 4 * t, av);
           }
-          for (; pb0 < be; pb0 += 4 * TEAM) {
-            uint32_t jj[4];
+          for (; base < be; base += 4 * TEAM) {
+            uint32_t jj[4], bt[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t pb = pb0 + TEAM * u; jj[u] = a.bcol[pb < be ? pb : be - 1]; }
+            for (int u = 0; u < 4; u++) { const uint32_t pb = base + TEAM * u + t; jj[u] = spg_ld(a.bcol, pb < be ? pb : be - 1); }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const uint32_t pb = pb0 + TEAM * u;
-              if (pb < be) {
-                const uint32_t j = jj[u];
-                uint32_t h = hash_col(j, KS - 1);
-                uint32_t kk = key[h];
-                while (kk != j && kk != HASH_EMPTY) { h = (h + 1) & (KS - 1); kk = key[h]; }
-                if (kk == j) { const uint32_t mp = pos[h]; word_combine<T>(sr.add_op(), &acc[mp], sr.mult(av, use_b ? a.bval[pb] : T())); flag[mp] = 1; }
-              }
-            }
+            for (int u = 0; u < 4; u++) bt[u] = filter_word(jj[u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t pb = base + TEAM * u + t; if (base + TEAM * u + (t & ~63) < be) push(filter_pass(jj[u], bt[u]) && pb < be, jj[u], pb, av); }
           }
+          if constexpr (!NOVAL) { if (qn) { flush(qn, av); qn = 0; wave_sync(); } }
         }
       }
+      team_sync();
+    }
+    if constexpr (NOVAL) {                               // what is still queued belongs to this mask row
+      if (qn) { flush(qn, T()); qn = 0; }
       team_sync();
     }
     for (uint32_t mp = t; mp < me - mb; mp += TEAM) if (flag[mp]) { a.cacc[mb + mp] = acc[mp]; a.cflag[mb + mp] = 1; }     // by mask position: coalesced
