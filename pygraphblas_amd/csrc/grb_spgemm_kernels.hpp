@@ -100,14 +100,15 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
   __shared__ uint32_t s_cnt[TEAMS][3];                                                  // [0] short rows fill from the front, [1] long rows from the back, [2] huge rows
   constexpr int HCAP = TEAM > 64 ? 64 : 1;                                              // B rows of >= SPG_HUGE entries are walked by the whole team (one wave would hold the others at the barrier)
   __shared__ uint32_t s_hpa[TEAMS][HCAP], s_hbb[TEAMS][HCAP], s_hbe[TEAMS][HCAP];
-  const int team = threadIdx.x / TEAM, t = threadIdx.x % TEAM;
+  const int team = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TEAM)), t = threadIdx.x % TEAM;      // (TEAM >= 64: the same for every lane of a wave — kept in a scalar register, and with it every LDS base below)
   const int lane16 = t & 15, grp = t >> 4, lane64 = t & 63, wv = t >> 6;
   constexpr int NG = TEAM / 16, NW = TEAM / 64;
   const bool use_a = sr.uses_a(), use_b = sr.uses_u();
   const W idw = to_word<T>(sr.identity);
   uint32_t* key = s_key[team]; W* acc = s_acc[team]; uint16_t* pos = s_pos[team]; uint8_t* flag = s_flag[team]; uint32_t* filt = s_filt[team];
   uint32_t* lpa = s_lpa[team]; uint32_t* lbb = s_lbb[team]; uint32_t* lbe = s_lbe[team]; uint32_t* cnt = s_cnt[team];
-  uint32_t* qj = s_qj[threadIdx.x >> 6]; uint32_t* qp = s_qp[NOVAL ? 0 : (threadIdx.x >> 6)];
+  const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint32_t* qj = s_qj[wave_in_block]; uint32_t* qp = s_qp[NOVAL ? 0 : wave_in_block];
   // a team of one wave (the bin of the shortest mask rows: four rows per block) needs no block barrier: its LDS slices are
   // private and LDS operations of a wave execute in order, so every row runs exactly its own number of rounds
   auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
@@ -127,7 +128,10 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
   constexpr int LW = __builtin_ctz(FW);
   auto filter_hash = [&](const uint32_t j) -> uint32_t { return (uint32_t)__umul24(j, SPG_FILTER_MUL); };      // (the intrinsic returns a signed int: shift the unsigned value)
   auto filter_bit = [&](const uint32_t j) -> uint32_t { return filter_hash(j) >> FSH; };
-  auto filter_word = [&](const uint32_t j) -> uint32_t { return filt[filter_hash(j) >> (32 - LW)]; };
+  auto filter_word = [&](const uint32_t j) -> uint32_t {      // (the index through an opaque bfe, so the address is bfe + lshl_add: the plain shift is rewritten into shift + and + add)
+    uint32_t idx; asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(idx) : "v"(filter_hash(j)), "n"(32 - LW), "n"(LW));
+    return filt[idx];
+  };
   auto filter_pass = [&](const uint32_t j, const uint32_t word) -> bool { return __builtin_amdgcn_ubfe(word, filter_hash(j) >> FSH, 1u) != 0u; };
   // ---- the filtered path (whole waves only: every lane of the wave calls these together) ----
   uint32_t qn = 0;                                         // entries in this wave's queue (wave-uniform)
@@ -138,9 +142,11 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
   auto push = [&](const bool pass, const uint32_t j, const uint32_t pb, const T av) {
     const unsigned long long m = __ballot(pass);
     if (m) {
+      const uint32_t q0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)qn);                  // (the count lives in a scalar register: the slot address is one VALU operation)
       const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      if (pass) { qj[qn + r] = j; if constexpr (!NOVAL) qp[qn + r] = pb; }
-      qn = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qn + (uint32_t)__popcll(m)));     // (kept in a scalar register)
+      uint32_t* const qslot = qj + q0;
+      if (pass) { qslot[r] = j; if constexpr (!NOVAL) (qp + q0)[r] = pb; }
+      qn = q0 + (uint32_t)__popcll(m);
       if (qn >= 64) {
         flush(64, av);
         const uint32_t rest = qn - 64;                     // < 64: the tail moves to the front

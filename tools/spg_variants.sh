@@ -13,6 +13,12 @@ for lib in "$@"; do
   timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/$tag" -o tc -- python tools/tc_probe.py --scale 22 --reps 2 --serial > "$out/$tag.serial.json" 2>/dev/null
   cat "$out/$tag.serial.json" | tee -a "$out/summary.txt"
   f=$(find "$out/$tag" -name '*kernel_stats.csv' | head -1)
-  [ -n "$f" ] && grep "spgemm" "$f" | awk -F'","' '{n=$1; sub(/^"void grb::/,"",n); printf "   %-90s calls %s avg %.3f ms\n", substr(n,1,90), $2, $4/1e6}' | tee -a "$out/summary.txt"
+  [ -n "$f" ] && python - "$f" <<'PY' | tee -a "$out/summary.txt"
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r["Name"]
+    if "spgemm" in n or "k_bin_rows" in n or "k_scatter_acc" in n or "k_reduce" in n or "k_flags" in n:
+        print("   %-100s calls %3s avg %8.3f ms" % (n.replace("void grb::", "")[:100], r["Calls"], float(r["AverageNs"]) / 1e6))
+PY
   find "$out/$tag" -name '*kernel_trace.csv' -delete
 done
