@@ -230,6 +230,33 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
         uint32_t base = lbb[sl];
         if (NOVAL || be - base >= 256) {
           // blocks of 1024 entries as FOUR 16-byte loads per lane (1 KiB per wave instruction, at the row's own 4-byte alignment)
+          // (one-wave teams: two register sets, the next block's loads are in flight while this block is sifted — 7.3 -> 6.7 ms for
+          // the shortest mask rows of the R-MAT-22 triangle count; in the larger teams the 16 extra registers cost a wave per SIMD
+          // and the same change made their kernels 25-55 % slower)
+          if constexpr (TEAM == 64) if (base + 1024 <= be) {
+            spg_u4 ja[4], jb[4];
+            auto ld = [&](spg_u4 (&d)[4], const uint32_t at) {
+#pragma unroll
+              for (int u = 0; u < 4; u++) d[u] = spg_ld4(a.bcol, at + 256 * u + 4 * lane64);
+            };
+            auto sift = [&](const spg_u4 (&d)[4], const uint32_t at) {
+#pragma unroll
+              for (int u = 0; u < 4; u++) sift4(d[u], at + 256 * u + 4 * lane64, av);
+            };
+            {
+              ld(ja, base);
+              for (;;) {
+                const bool nb = base + 2048 <= be;
+                if (nb) ld(jb, base + 1024);
+                sift(ja, base); base += 1024;
+                if (!nb) break;
+                const bool na = base + 2048 <= be;
+                if (na) ld(ja, base + 1024);
+                sift(jb, base); base += 1024;
+                if (!na) break;
+              }
+            }
+          }
           for (; base + 1024 <= be; base += 1024) {
             spg_u4 j4[4];
 #pragma unroll
@@ -264,7 +291,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
           const uint32_t be = s_hbe[team][q];
           uint32_t base = s_hbb[team][q];
           constexpr int HD = TEAM >= 512 ? 1 : 2;                        // 16-byte loads per lane and step: 4 * TEAM * HD <= SPG_HUGE entries, so every huge row takes this path
-          for (; base + 4 * TEAM * HD <= be; base += 4 * TEAM * HD) {
+          constexpr uint32_t HS = 4 * TEAM * HD;
+          for (; base + HS <= be; base += HS) {
             spg_u4 j4[HD];
 #pragma unroll
             for (int u = 0; u < HD; u++) j4[u] = spg_ld4(a.bcol, base + 4 * TEAM * u + 4 * t);
@@ -325,9 +353,44 @@ __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T>
   const bool use_a = sr.uses_a(), use_b = sr.uses_u();
   const W idw = to_word<T>(sr.identity);
   // one B row against the filter and the map: `step` lanes apart, 4 loads in flight per lane
+  auto hit = [&](const uint32_t slot1, const uint32_t pb, const T av, const uint32_t mb) {
+    const uint32_t mp = slot1 - 1;
+    if (mp < LCF) {
+      if constexpr (CNT32) atomicAdd(&s_acc[mp], 1u);             // PLUS_PAIR: the product is 1
+      else { word_combine<T>(sr.add_op(), (W*)&s_acc[mp], sr.mult(av, use_b ? a.bval[pb] : T())); s_flag[mp] = 1; }
+    } else {
+      word_combine<T>(sr.add_op(), &a.cacc[mb + mp], sr.mult(av, use_b ? a.bval[pb] : T()));
+      a.cflag[mb + mp] = 1;
+    }
+  };
   auto walk = [&](uint32_t pa, uint32_t first, uint32_t be, uint32_t step, uint32_t mb) {
     const T av = use_a ? a.aval[pa] : T();
-    for (uint32_t pb0 = first; pb0 < be; pb0 += 4 * step) {
+    // whole blocks first: 16 bytes per lane and load, two loads = 8 entries per lane in flight, then up to eight map reads in flight
+    uint32_t base = first - (step == 64 ? (uint32_t)(threadIdx.x & 63) : (uint32_t)threadIdx.x);
+    const uint32_t ln = step == 64 ? (uint32_t)(threadIdx.x & 63) : (uint32_t)threadIdx.x;
+    // (software-pipelined: the next block's B-row loads are issued before this block's map reads are consumed — the kernel runs
+    // four waves per SIMD and was parked on two dependent memory round trips per block)
+    if (base + 8 * step <= be) {
+      spg_u4 j4[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) j4[u] = spg_ld4(a.bcol, base + 4 * step * u + 4 * ln);
+      for (; base + 8 * step <= be; base += 8 * step) {
+        uint32_t ss[8];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const uint32_t jv[4] = {j4[u].x, j4[u].y, j4[u].z, j4[u].w};
+#pragma unroll
+          for (int c = 0; c < 4; c++) { const uint32_t j = jv[c]; ss[4 * u + c] = ((s_filter[(j >> 5) & (SPG_FILTER_WORDS - 1)] >> (j & 31)) & 1u) ? map[j] : 0u; }
+        }
+        if (base + 16 * step <= be) {
+#pragma unroll
+          for (int u = 0; u < 2; u++) j4[u] = spg_ld4(a.bcol, base + 8 * step + 4 * step * u + 4 * ln);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (ss[u]) hit(ss[u], base + 4 * step * (u >> 2) + 4 * ln + (u & 3), av, mb);
+      }
+    }
+    for (uint32_t pb0 = base + ln; pb0 < be; pb0 += 4 * step) {
       uint32_t ss[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) { const uint32_t pb = pb0 + step * u; ss[u] = a.bcol[pb < be ? pb : be - 1]; }
