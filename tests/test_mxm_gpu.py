@@ -96,6 +96,14 @@ def test_every_mask_bin_and_heavy_rows(gpu):
         got = to_matrix(A2).mxm(to_matrix(B2), semiring=getattr(gb.INT64, sr), mask=to_matrix(M))
         add, mul = sr.split("_")
         check(got, O.mxm(O.Tuples("INT64", len(lens), n), A2, B2, add, mul, "INT64", mask=M), "INT64", what=sr + " sliced")
+    # B rows of ~6200 entries (walked by a whole team, 16-byte loads) and of ~150 (counting products are sifted through the mask
+    # row's bit filter at every length; products that read a value go straight to the table below 256 entries)
+    for dens_b, ka in ((0.2, 120), (0.005, 400)):
+        A3, B3 = rand_matrix(rng, "INT64", len(lens), ka, 0.6), rand_matrix(rng, "INT64", ka, n, dens_b)
+        for sr in ("PLUS_PAIR", "PLUS_TIMES", "MAX_FIRST"):
+            got = to_matrix(A3).mxm(to_matrix(B3), semiring=getattr(gb.INT64, sr), mask=to_matrix(M))
+            add, mul = sr.split("_")
+            check(got, O.mxm(O.Tuples("INT64", len(lens), n), A3, B3, add, mul, "INT64", mask=M), "INT64", what=f"{sr} B density {dens_b}")
     Af, Bf = rand_matrix(rng, "FP64", len(lens), 300, 0.5, small=False), rand_matrix(rng, "FP64", 300, n, 0.05, small=False)
     got = to_matrix(Af).mxm(to_matrix(Bf), semiring=gb.FP64.PLUS_TIMES, mask=to_matrix(M))
     check(got, O.mxm(O.Tuples("FP64", len(lens), n), Af, Bf, "PLUS", "TIMES", "FP64", mask=M), "FP64", rtol=1e-6)
