@@ -208,7 +208,7 @@ GrB_Info GrB_Matrix_extract(GrB_Matrix C, const GrB_Matrix Mask, const GrB_Binar
     const uint64_t ar = dv.tran0 ? A->ncols : A->nrows, ac = dv.tran0 ? A->nrows : A->ncols;
     const Sel ri(I, ni, ar, "extract"), ci(J, nj, ac, "extract");
     if (C->nrows != ri.size() || C->ncols != ci.size() || (Mask && (Mask->nrows != C->nrows || Mask->ncols != C->ncols))) fail(GrB_DIMENSION_MISMATCH, "extract: output shape must be |I| x |J|");
-    if (!Mask && !accum && ri.increasing() && ci.increasing()) {       // a slice `A[a:b, c:d]` into a fresh output: one pass over A's tuples
+    if (!Mask && !dv.mask_comp && !accum && ri.increasing() && ci.increasing()) {       // a slice `A[a:b, c:d]` into a fresh output: one pass over A's tuples
       mat_to_host(A); const size_t ts = A->type->size; const int acode = A->type->code, ccode = C->type->code;
       struct E { uint64_t i, j; Val v; }; std::vector<E> out;
       for (size_t p = 0; p < A->hi.size(); p++) {
@@ -275,11 +275,14 @@ void region_update(Map& C, int ccode, const Map& A, int acode, const std::vector
   C.swap(out);
 }
 }  // namespace
+// the whole-container fast paths forward to eWiseAdd without the caller's descriptor: only when it asks for nothing they would
+// drop (a complemented mask without a mask object allows no writes at all; an invalid descriptor is the general path's error)
+static inline bool plain_desc(GrB_Descriptor d) { return !d || (check_obj(d) && (d->mask & GrB_COMP) == 0); }
 extern "C" {
 
 GrB_Info GrB_Vector_assign(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Vector u, const GrB_Index* I, GrB_Index ni, const GrB_Descriptor desc) {
   if (!w || !u) return GrB_NULL_POINTER; if (!check_obj(w)) return GrB_UNINITIALIZED_OBJECT;
-  if (I == GrB_ALL && !mask && accum && check_obj(u) && device_ok() && u->n == w->n) return GrB_Vector_eWiseAdd_BinaryOp(w, nullptr, nullptr, accum, w, u, nullptr);   // w = accum(w, u), in HBM
+  if (I == GrB_ALL && !mask && plain_desc(desc) && accum && check_obj(u) && device_ok() && u->n == w->n) return GrB_Vector_eWiseAdd_BinaryOp(w, nullptr, nullptr, accum, w, u, nullptr);   // w = accum(w, u), in HBM
   return guarded(w, [&] {
     check_v(u, "assign"); if (mask) check_v(mask, "assign");
     const DescView dv(desc);
@@ -297,7 +300,7 @@ GrB_Info GrB_Matrix_assign(GrB_Matrix C, const GrB_Matrix Mask, const GrB_Binary
   if (!C || !A) return GrB_NULL_POINTER; if (!check_obj(C)) return GrB_UNINITIALIZED_OBJECT;
   // the whole container, no mask, with an accumulator (`paths.assign_matrix(frontier, accum=PLUS)`, gap/bcmark.py:41): that is
   // C = accum(C, A) on the union of the patterns — the eWiseAdd kernel, in HBM (a dense ns x n `paths` must not visit the host)
-  if (I == GrB_ALL && J == GrB_ALL && !Mask && accum && check_obj(A) && device_ok()) {
+  if (I == GrB_ALL && J == GrB_ALL && !Mask && plain_desc(desc) && accum && check_obj(A) && device_ok()) {      // (a complemented mask without a mask object allows nothing: not this path)
     const DescView dv0(desc);
     if (!dv0.tran0 && A->nrows == C->nrows && A->ncols == C->ncols) return GrB_Matrix_eWiseAdd_BinaryOp(C, nullptr, nullptr, accum, C, A, nullptr);
   }
@@ -307,7 +310,7 @@ GrB_Info GrB_Matrix_assign(GrB_Matrix C, const GrB_Matrix Mask, const GrB_Binary
     const auto ri = indices(I, ni, C->nrows, "assign"), ci = indices(J, nj, C->ncols, "assign");
     const uint64_t ar = dv.tran0 ? A->ncols : A->nrows, ac = dv.tran0 ? A->nrows : A->ncols;
     if (ar != ri.size() || ac != ci.size() || (Mask && (Mask->nrows != C->nrows || Mask->ncols != C->ncols))) fail(GrB_DIMENSION_MISMATCH, "assign: the matrix must be |I| x |J|");
-    if (!Mask && !dv.tran0 && C != A && strictly_increasing(ri) && strictly_increasing(ci) && C->type->code < T_FC32 && A->type->code < T_FC32) {
+    if (!Mask && !dv.mask_comp && !dv.tran0 && C != A && strictly_increasing(ri) && strictly_increasing(ci) && C->type->code < T_FC32 && A->type->code < T_FC32) {
       // `M[a:b, c:d] = A` with increasing index lists: A's tuples stay sorted when they move to (I[i], J[j]) — one merge of C's tuples
       // (without those of the region, unless an accumulator keeps them) with A's
       if (accum) check_binop(accum, "accum");
@@ -348,7 +351,7 @@ GrB_Info GrB_Row_assign(GrB_Matrix C, const GrB_Vector mask, const GrB_BinaryOp 
     check_v(u, "assign"); if (mask) check_v(mask, "assign");
     const DescView dv(desc);
     if (i >= C->nrows) fail(GrB_INVALID_INDEX, "assign: row index out of range");
-    if (!mask && J == GrB_ALL && u->n == C->ncols && C->type->code < T_FC32 && u->type->code < T_FC32) {   // `M[i] = v`: the row's run of tuples is replaced in place (GrB_ALL is never listed: C may be 2^60 wide)
+    if (!mask && !dv.mask_comp && J == GrB_ALL && u->n == C->ncols && C->type->code < T_FC32 && u->type->code < T_FC32) {   // `M[i] = v`: the row's run of tuples is replaced in place (GrB_ALL is never listed: C may be 2^60 wide)
       mat_to_host(C);
       const auto r = row_range(C, i); Line cur; cur.reserve(r.second - r.first);
       for (size_t p = r.first; p < r.second; p++) cur.push_back({C->hj[p], val_at(C, p)});
@@ -371,7 +374,7 @@ GrB_Info GrB_Col_assign(GrB_Matrix C, const GrB_Vector mask, const GrB_BinaryOp 
     check_v(u, "assign"); if (mask) check_v(mask, "assign");
     const DescView dv(desc);
     if (j >= C->ncols) fail(GrB_INVALID_INDEX, "assign: column index out of range");
-    if (!mask && I == GrB_ALL && u->n == C->nrows && C->type->code < T_FC32 && u->type->code < T_FC32) {   // `M[:, j] = v`: one merge pass over the tuples (GrB_ALL is never listed)
+    if (!mask && !dv.mask_comp && I == GrB_ALL && u->n == C->nrows && C->type->code < T_FC32 && u->type->code < T_FC32) {   // `M[:, j] = v`: one merge pass over the tuples (GrB_ALL is never listed)
       replace_line(C, false, j, assigned_line(line_of(C, false, j), C->type->code, u, accum));
       return;
     }
@@ -453,7 +456,7 @@ void host_assign_scalar(GrB_Matrix C, GrB_Matrix Mask, GrB_BinaryOp accum, const
   const bool all = (I == GrB_ALL && J == GrB_ALL);
   const int ccode = C->type->code;
   Val v{}; memcpy(v.data(), x, (size_t)type_size(xcode));
-  const double positions = (I == GrB_ALL ? (double)C->nrows : (double)ni) * (J == GrB_ALL ? (double)C->ncols : (double)nj);
+  const double positions = index_count(I, ni, C->nrows) * index_count(J, nj, C->ncols);      // (ni / nj may be a range sentinel, not a count)
   if (all && Mask && !dv.mask_comp) {                    // the result's pattern is bounded by the mask's
     Map Cm = load(C, false), Mm = load(Mask, false), T;
     const MaskView mk{&Mm, Mask->type->code, dv.mask_struct, false, true};
@@ -479,7 +482,7 @@ void host_assign_scalar(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const
   const bool all = (I == GrB_ALL);
   const int wcode = w->type->code;
   Val v{}; memcpy(v.data(), x, (size_t)type_size(xcode));
-  const double positions = all ? (double)w->n : (double)ni;
+  const double positions = index_count(I, ni, w->n);
   if (all && mask && !dv.mask_comp) {
     Map C = load(w), Mm = load(mask), T;
     const MaskView mk{&Mm, mask->type->code, dv.mask_struct, false, true};

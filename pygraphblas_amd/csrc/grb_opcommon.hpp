@@ -71,6 +71,22 @@ inline std::vector<uint64_t> expand_index_list(const GrB_Index* I, GrB_Index ni,
   return out;
 }
 
+// how many positions an index argument names (GrB_ALL, an explicit list, or a GxB_RANGE / GxB_STRIDE / GxB_BACKWARDS triple whose
+// `ni` is a sentinel, not a count), without building the list
+inline double index_count(const GrB_Index* I, GrB_Index ni, uint64_t dim) {
+  if (I == GrB_ALL) return (double)dim;
+  if (!I) return 0.0;
+  if (ni == GXB_RANGE || ni == GXB_STRIDE || ni == GXB_BACKWARDS) {
+    const uint64_t b = I[0], e = I[1], st = ni == GXB_RANGE ? 1 : I[2];
+    if (st == 0) return 0.0;
+    const uint64_t lo = ni == GXB_BACKWARDS ? e : b, hi0 = ni == GXB_BACKWARDS ? b : e;
+    if (hi0 < lo) return 0.0;
+    const uint64_t hi = hi0 >= dim && dim ? dim - 1 : hi0;          // (an end beyond the dimension is an error raised later; count what could exist)
+    return hi < lo ? 0.0 : (double)((hi - lo) / st + 1);
+  }
+  return (double)ni;
+}
+
 // values of a device array in another type: returns `src` itself when no cast is needed, else fills `tmp`
 inline const void* cast_values(int dst_code, int src_code, const void* src, uint64_t n, DevBuf& tmp) {
   if (dst_code == src_code || n == 0) return src;

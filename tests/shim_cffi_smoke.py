@@ -206,6 +206,18 @@ if "--gpu" in sys.argv:
     for i in range(NV):
         info = lib.GrB_Vector_extractElement_UINT8(u8, lv[0], i)
         assert (info == lib.GrB_NO_VALUE and lev[i] == 0) or (info == lib.GrB_SUCCESS and u8[0] == lev[i]), (i, info, u8[0], lev[i])
+    # a complemented mask without a mask object allows no writes: `w(:) += u` under GrB_DESC_C leaves w as it is (the whole-vector
+    # and whole-matrix accumulate fast paths used to forward to eWiseAdd without the descriptor)
+    wa, ua = vec([0, 2], [10, 20], size=4), vec([0, 1], [1, 2], size=4)
+    check(lib.GrB_Vector_assign(wa[0], ffi.NULL, lib.GrB_PLUS_INT64, ua[0], lib.GrB_ALL, 4, lib.GrB_DESC_C))
+    assert vtuples(wa) == ([0, 2], [10, 20]), vtuples(wa)
+    check(lib.GrB_Vector_assign(wa[0], ffi.NULL, lib.GrB_PLUS_INT64, ua[0], lib.GrB_ALL, 4, ffi.NULL))
+    assert vtuples(wa) == ([0, 1, 2], [11, 2, 20]), vtuples(wa)
+    Ca, Aa = mat([0, 1], [0, 1], [10, 20], nr=2, nc=2), mat([0, 0], [0, 1], [1, 2], nr=2, nc=2)
+    check(lib.GrB_Matrix_assign(Ca[0], ffi.NULL, lib.GrB_PLUS_INT64, Aa[0], lib.GrB_ALL, 2, lib.GrB_ALL, 2, lib.GrB_DESC_C))
+    assert mtuples(Ca) == [(0, 0, 10), (1, 1, 20)], mtuples(Ca)
+    check(lib.GrB_Matrix_assign(Ca[0], ffi.NULL, lib.GrB_PLUS_INT64, Aa[0], lib.GrB_ALL, 2, lib.GrB_ALL, 2, ffi.NULL))
+    assert mtuples(Ca) == [(0, 0, 11), (0, 1, 2), (1, 1, 20)], mtuples(Ca)
     print("OK gpu", list(X), r[0], "+ reference test_mxm/test_mxm_context/test_mxv/test_vxm/test_RCT0/test_RC/test_pow sequences + the PageRank (%d iterations) and BFS (%d levels) loops in non-blocking mode" % (its, level - 1))
 else:
     assert info == lib.GrB_PANIC, info                                                # no device: fail loudly

@@ -320,3 +320,4 @@ def test_grb_all_is_never_materialised_on_hypersparse_containers(gb):
     assert H[:, 11].to_lists() == [[4], [9]]
     w = v.extract(slice(None))                # GrB_Vector_extract over GrB_ALL
     assert w.to_lists() == [[4], [9]]
+

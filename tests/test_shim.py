@@ -107,6 +107,23 @@ def test_unmodified_reference_stores_complex_entries_through_the_shim(gb):
 
 @needs39
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_scalar_assign_over_a_slice_of_a_hypersparse_or_complex_container(gb):
+    """the position count of a scalar assign was taken from the raw `ni`, which for a slice is the
+    GxB_RANGE / GxB_STRIDE sentinel (~2^63) — `H[0:3, 0:3] = 5` on a default-dimension matrix was refused as "more than 2^24
+    positions".  (The reference's slices are inclusive: 0:2 names three positions.)"""
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "shim") + ":" + REF, PYTHONDONTWRITEBYTECODE="1")
+    code = ("from pygraphblas import *\n"
+            "H = Matrix.sparse(INT64); H[0:2, 0:2] = 5; assert H.nvals == 9 and H[2, 2] == 5\n"
+            "H[0:4:2, 1] = 7; assert H[0, 1] == 7 and H[2, 1] == 7 and H[4, 1] == 7 and H[1, 1] == 5\n"
+            "v = Vector.sparse(INT64); v[3:5] = 1; assert v.to_lists() == [[3, 4, 5], [1, 1, 1]]\n"
+            "Z = Matrix.sparse(FC64, 10, 10); Z[1:3, 1:3] = 1j; assert Z.nvals == 9 and Z[2, 2] == 1j\n"
+            "print('OK slices')\n")
+    r = subprocess.run([PY39, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")
+    assert r.returncode == 0 and "OK slices" in r.stdout, r.stdout + r.stderr
+
+
+@needs39
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
 def test_host_mirror_slices_against_a_model_through_the_unmodified_reference(gb):
     """`M[i]`, `M[:, j]`, `M[i] = v`, `M[a:b, c:d]`, `M[i, j] = x` / `del M[i, j]` work on the sorted tuples of the host mirror
     (grb_host_ops.cpp); 300 random cases against a dict model (tests/shim_host_slices_check.py)."""
