@@ -191,6 +191,10 @@ void sort_keys_u32(const uint32_t* kin, uint32_t* kout, uint64_t n, int end_bit)
 void sort_pairs_u64(const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n, int end_bit);
 
 // ---- kernels in grb_vecops.hip ---------------------------------------------------------------------------------
+// min / max of the present finite values (in the type itself), how many present values are NaN or infinite, how many are present;
+// false for types other than INT32 / INT64 / FP32 / FP64
+bool value_range(int code, uint64_t n, const void* val, const uint8_t* pres, void* vmin, void* vmax, uint64_t* nonfinite, uint64_t* count);
+void big_to_absent(int code, uint64_t n, const void* val, uint8_t* pres, const void* thresh, bool keep_below);   // pres[i] = 0 where val[i] is not strictly below / above thresh
 void vec_epilogue(int code, uint64_t n, void* wval, uint8_t* wpres, const void* tval, const uint8_t* tpres,
                   const uint8_t* allow, int accum, bool replace);
 void reduce_values(int code, uint64_t n, const void* val, const uint8_t* pres, int op, const void* identity, void* result_host);

@@ -98,6 +98,8 @@ struct DevCSR {
   // entries, long rows split into parts.  Built on first mxv, cached with the matrix.
   DevBuf plan_blocks; uint32_t plan_nblocks = 0; DevBuf plan_aux; uint32_t plan_nlong = 0;
   bool has_plan = false;
+  int range_state = 0;          // largest |value| of the stored values: 0 not measured, 1 = range_abs holds it, 2 = not usable (NaN / infinity / a type without a range)
+  double range_abs = 0;         // (as a double: an upper bound is all the caller needs — grb_mxv.cpp "big holes")
   int locality_pct = -1;        // share of entries whose column is < 16 behind its predecessor in the row (measured once, -1 = not yet): gathers with locality need no panels
   // kernel-W plan (grb_spmv_wavepipe.hpp): per-task first row, hot-column list, remapped column array, per-wave carries
   DevBuf wp_rs, wp_hot, wp_pcol, wp_carry; uint32_t wp_nhot = 0, wp_ntasks = 0, wp_nwarm = 0; int wp_tsize = 0;
@@ -105,7 +107,7 @@ struct DevCSR {
   bool valid = false;
   void clear() { rowptr.reset(); col.reset(); val.reset(); plan_blocks.reset(); plan_aux.reset();
                  wp_rs.reset(); wp_hot.reset(); wp_pcol.reset(); wp_carry.reset(); wp_nhot = wp_ntasks = 0; wp_tsize = 0; xcd.reset();
-                 nnz = 0; has_plan = false; locality_pct = -1; valid = false; plan_nblocks = plan_nlong = 0; }
+                 nnz = 0; has_plan = false; locality_pct = -1; range_state = 0; valid = false; plan_nblocks = plan_nlong = 0; }
 };
 
 }  // namespace grb

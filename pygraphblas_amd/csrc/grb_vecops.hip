@@ -41,6 +41,78 @@ void vec_cast_fill_values(int dst_code, void* dst, int src_code, const void* src
   });
 }
 
+// ---- range of the stored values (MIN_PLUS / MAX_PLUS products over an operand with holes: grb_mxv.cpp "big holes") ---------------
+// min, max and the number of non-finite values of the present entries, in the type itself; one kernel, per-workgroup results
+// combined with ordered-integer atomics (floats: the usual sign-flip encoding), one read-back.
+template <class T> struct RangeEnc;
+template <> struct RangeEnc<int32_t> { typedef int32_t E; static __host__ __device__ E enc(int32_t v) { return v; } static __host__ __device__ int32_t dec(E e) { return e; } };
+template <> struct RangeEnc<int64_t> { typedef long long E; static __host__ __device__ E enc(int64_t v) { return (long long)v; } static __host__ __device__ int64_t dec(E e) { return (int64_t)e; } };
+template <> struct RangeEnc<float> { typedef int32_t E;
+  static __host__ __device__ E enc(float v) { int32_t b; memcpy(&b, &v, 4); return b >= 0 ? b : (int32_t)(b ^ 0x7FFFFFFF); }
+  static __host__ __device__ float dec(E e) { int32_t b = e >= 0 ? e : (int32_t)(e ^ 0x7FFFFFFF); float v; memcpy(&v, &b, 4); return v; } };
+template <> struct RangeEnc<double> { typedef long long E;
+  static __host__ __device__ E enc(double v) { long long b; memcpy(&b, &v, 8); return b >= 0 ? b : (long long)(b ^ 0x7FFFFFFFFFFFFFFFll); }
+  static __host__ __device__ double dec(E e) { long long b = e >= 0 ? e : (long long)(e ^ 0x7FFFFFFFFFFFFFFFll); double v; memcpy(&v, &b, 8); return v; } };
+template <class T> __global__ void k_value_range(uint64_t n, const T* __restrict__ val, const uint8_t* __restrict__ pres, long long* __restrict__ out /* [min, max, nonfinite, count] */) {
+  typedef typename RangeEnc<T>::E E;
+  E mn = std::numeric_limits<E>::max(), mx = std::numeric_limits<E>::min(); unsigned long long bad = 0, cnt = 0;
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) if (!pres || pres[i]) {
+    const T v = val[i]; cnt++;
+    if constexpr (std::is_floating_point<T>::value) { if (!(v - v == T(0))) { bad++; continue; } }      // NaN or infinity
+    const E e = RangeEnc<T>::enc(v); mn = e < mn ? e : mn; mx = e > mx ? e : mx;
+  }
+  __shared__ long long smn[4], smx[4]; __shared__ unsigned long long sbad[4], scnt[4];
+  long long lmn = (long long)mn, lmx = (long long)mx;
+  for (int o = 32; o; o >>= 1) { const long long a = __shfl_xor(lmn, o, 64), b = __shfl_xor(lmx, o, 64); lmn = a < lmn ? a : lmn; lmx = b > lmx ? b : lmx; }
+  bad = wave_reduce_add_u64(bad); cnt = wave_reduce_add_u64(cnt);
+  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = lmn; smx[threadIdx.x >> 6] = lmx; sbad[threadIdx.x >> 6] = bad; scnt[threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) { lmn = smn[w] < lmn ? smn[w] : lmn; lmx = smx[w] > lmx ? smx[w] : lmx; bad += sbad[w]; cnt += scnt[w]; }
+    if (cnt) { atomicMin(&out[0], lmn); atomicMax(&out[1], lmx); atomicAdd((unsigned long long*)&out[2], bad); atomicAdd((unsigned long long*)&out[3], cnt); }
+  }
+}
+bool value_range(int code, uint64_t n, const void* val, const uint8_t* pres, void* vmin, void* vmax, uint64_t* nonfinite, uint64_t* count) {
+  if (code != T_INT32 && code != T_INT64 && code != T_FP32 && code != T_FP64) return false;
+  *nonfinite = 0; *count = 0;
+  if (!n) return true;
+  DevBuf acc(32);
+  const long long init[4] = {std::numeric_limits<long long>::max(), std::numeric_limits<long long>::min(), 0, 0};
+  long long* pin = (long long*)pinned_scratch();
+  memcpy(pin, init, 32);
+  GRB_HIP(hipMemcpyAsync(acc.p, pin, 32, hipMemcpyHostToDevice, stream()));
+  dispatch_type(code, [&]<class T>() {
+    if constexpr (std::is_same<T, int32_t>::value || std::is_same<T, int64_t>::value || std::is_same<T, float>::value || std::is_same<T, double>::value)
+      hipLaunchKernelGGL((k_value_range<T>), dim3(std::min(grid_for(n, 8), 512)), dim3(256), 0, stream(), n, (const T*)val, pres, acc.as<long long>());
+  });
+  GRB_HIP(hipMemcpyAsync(pin + 8, acc.p, 32, hipMemcpyDeviceToHost, stream()));      // (another part of the pinned block than the source of the copy above)
+  GRB_HIP(hipStreamSynchronize(stream()));
+  pin += 8;
+  *nonfinite = (uint64_t)pin[2]; *count = (uint64_t)pin[3];
+  if (*count > *nonfinite) {
+    dispatch_type(code, [&]<class T>() {
+      if constexpr (std::is_same<T, int32_t>::value || std::is_same<T, int64_t>::value || std::is_same<T, float>::value || std::is_same<T, double>::value) {
+        typedef typename RangeEnc<T>::E E;
+        const T a = RangeEnc<T>::dec((E)pin[0]), b = RangeEnc<T>::dec((E)pin[1]); memcpy(vmin, &a, sizeof(T)); memcpy(vmax, &b, sizeof(T));
+      }
+    });
+  }
+  return true;
+}
+// entries whose value lies on the far side of `thresh` were made of fill values only: they are not entries
+template <class T> __global__ void k_big_to_absent(uint64_t n, const T* __restrict__ val, uint8_t* __restrict__ pres, T thresh, bool keep_below) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) if (pres[i]) { const T v = val[i]; if (!(keep_below ? v < thresh : v > thresh)) pres[i] = 0; }
+}
+void big_to_absent(int code, uint64_t n, const void* val, uint8_t* pres, const void* thresh, bool keep_below) {
+  if (!n) return;
+  dispatch_type(code, [&]<class T>() {
+    if constexpr (std::is_same<T, int32_t>::value || std::is_same<T, int64_t>::value || std::is_same<T, float>::value || std::is_same<T, double>::value) {
+      T th; memcpy(&th, thresh, sizeof(T));
+      hipLaunchKernelGGL((k_big_to_absent<T>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (const T*)val, pres, th, keep_below);
+    }
+  });
+}
+
 // ---- mask -> allow bytes ------------------------------------------------------------------------------
 template <class M> __global__ void k_allow(uint64_t n, const M* __restrict__ mval, const uint8_t* __restrict__ mpres,
                                            bool structural, bool complement, uint8_t* __restrict__ allow) {

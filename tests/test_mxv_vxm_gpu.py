@@ -397,3 +397,44 @@ def test_reduce_bool_after_a_bool_product_reads_the_kernels_summary(gpu):
         v.vxm(A, mask=v, out=q, desc=D.RC)
         level += 1
     assert sum(sizes) == v.nvals and level > 2
+
+
+def test_min_plus_over_an_operand_with_holes_runs_the_full_operand_kernels(gpu):
+    """The sweeps of the reference's shortest-path loop (`v<accum MIN> = v MIN_PLUS A`, demo/Intro-Prez.ipynb:1034-1045): the operand
+    has no entry for vertices not reached yet.  grb_mxv.cpp fills the holes with a BIG value, runs a full-operand kernel and
+    drops the sums made of fill values only — exact when the values are small against the type's range, otherwise the bitmap
+    kernel runs as before.  Both directions of the decision, MIN and MAX, four types, rows fed by holes only, against the oracle."""
+    rng = np.random.default_rng(31)
+    n, nnz = 50000, 1300000
+    key = np.unique(rng.integers(0, n * n, size=nnz, dtype=np.int64))
+    I, J = np.divmod(key.astype(np.uint64), np.uint64(n))
+    # the second half of the vertices never carries an entry of u: rows gathering only from there have no entry in the result
+    for typ in ("INT64", "INT32", "FP64", "FP32"):
+        for sr_name in ("MIN_PLUS", "MAX_PLUS"):
+            for big_values in (False, True):
+                dt = O.NP[typ]
+                if typ.startswith("FP"):
+                    X = (rng.integers(-40, 400, len(key)) / 8.0).astype(dt)
+                    if big_values: X[7] = np.finfo(dt).max / 2                     # sums could overflow: the trick must not be used
+                else:
+                    X = rng.integers(-40, 400, len(key)).astype(dt)
+                    if big_values: X[7] = np.iinfo(dt).max // 2
+                A = O.Tuples(typ, n, n, I, J, X)
+                ui = np.sort(rng.choice(n // 2, size=n // 5, replace=False)).astype(np.uint64)
+                ux = (rng.integers(-100, 1000, len(ui)) / (8.0 if typ.startswith("FP") else 1)).astype(dt)
+                wi = np.sort(rng.choice(n, size=n // 3, replace=False)).astype(np.uint64)
+                wx = (rng.integers(-100, 1000, len(wi)) / (8.0 if typ.startswith("FP") else 1)).astype(dt)
+                for accum in (None, sr_name.split("_")[0]):
+                    gA, gu, gw = to_matrix(A), to_vector(typ, n, ui, ux), to_vector(typ, n, wi, wx)
+                    gA.mxv(gu, semiring=getattr(TYPE[typ], sr_name), out=gw, accum=getattr(TYPE[typ], accum) if accum else None)
+                    plan = gb.last_kernel_plan()
+                    add, mul = sr_name.split("_")
+                    exp = O.mxv(O.col_vector(typ, n, wi, wx), A, O.col_vector(typ, n, ui, ux), add, mul, typ, accum=accum, accum_type=typ)
+                    gi, gx = vector_pairs(gw)
+                    assert_same(typ, gi, gx, exp.I, exp.X, what=f"{typ}.{sr_name} accum={accum} big_values={big_values} plan={plan}")
+                    if accum is None:
+                        assert len(gi) < n                                          # some rows gather from holes only
+                    if not big_values:
+                        assert "k_spmv_wavepipe" in plan or "k_spmv_xcd" in plan, plan
+                    else:
+                        assert "k_spmv_wavepipe" not in plan and "k_spmv_xcd" not in plan, plan
