@@ -72,13 +72,14 @@ void merge_pairs_u64(const uint64_t* k1, const uint64_t* k2, uint64_t* kout, con
   GRB_HIP(rocprim::merge(t.p, tmp, k1, k2, kout, v1, v2, vout, (size_t)n1, (size_t)n2, rocprim::less<uint64_t>(), stream()));
 }
 
-// every segment [offsets[s], offsets[s+1]) sorted by key on its own (rows of a CSR put in column order)
-void segmented_sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n, uint32_t nseg, const uint32_t* offsets, int end_bit) {
+// every segment [begins[s], ends[s]) sorted by key on its own (rows of a CSR put in column order; ends = begins + 1 for all rows,
+// or a separate array in which the rows that need no sorting are empty)
+void segmented_sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n, uint32_t nseg, const uint32_t* begins, const uint32_t* ends, int end_bit) {
   if (!n || !nseg) return;
   size_t tmp = 0;
-  GRB_HIP(rocprim::segmented_radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, (unsigned)n, (unsigned)nseg, offsets, offsets + 1, 0u, (unsigned)end_bit, stream()));
+  GRB_HIP(rocprim::segmented_radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, (unsigned)n, (unsigned)nseg, begins, ends, 0u, (unsigned)end_bit, stream()));
   DevBuf t(tmp ? tmp : 16);
-  GRB_HIP(rocprim::segmented_radix_sort_pairs(t.p, tmp, kin, kout, vin, vout, (unsigned)n, (unsigned)nseg, offsets, offsets + 1, 0u, (unsigned)end_bit, stream()));
+  GRB_HIP(rocprim::segmented_radix_sort_pairs(t.p, tmp, kin, kout, vin, vout, (unsigned)n, (unsigned)nseg, begins, ends, 0u, (unsigned)end_bit, stream()));
 }
 
 }  // namespace grb

@@ -24,7 +24,7 @@
 
 namespace grb {
 
-void segmented_sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n, uint32_t nseg, const uint32_t* offsets, int end_bit);
+void segmented_sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n, uint32_t nseg, const uint32_t* begins, const uint32_t* ends, int end_bit);
 
 struct HashArgs {
   const uint32_t* arp; const uint32_t* acol; const uint32_t* brp; const uint32_t* bcol;
@@ -159,6 +159,150 @@ __global__ __launch_bounds__(1024) void k_spgemm_dense(const HashArgs a, const T
     __threadfence(); __syncthreads();
   }
 }
+// ---- rows beyond the LDS tables, when the column range is moderate: a dense accumulator IN LDS, one block of columns at a time ----
+// Round 3.  The HBM-resident dense accumulator above costs two global atomics per product (9.5e9 products of A@A on R-MAT-18:
+// 0.73 s numeric + 0.27 s symbolic of a 1.1 s call), and its rows leave in claim order, so the whole result goes through a
+// segmented sort.  Here a workgroup walks its row once per block of WD columns (8192 eight-byte / 16384 four-byte accumulators =
+// 64 KiB of LDS): where the blocks of every B row begin is computed once per call (k_spa_split: the rows are sorted by column),
+// the products of a block are dealt to the lanes of a wave whatever the lengths of the row parts are, they combine with LDS atomics, and the block is emitted by scanning its bitmap — in column order, straight into the
+// result: no claim list, no sort, no gather for these rows.  The symbolic pass marks a bitmap of all ncols bits in LDS (<= 2^20
+// columns).  Taken when ncols <= 64 blocks (2^19 columns for 8-byte types, 2^20 for 4-byte ones); the HBM path remains for wider results.
+template <class T> struct spa_cfg { static constexpr uint32_t WD = sizeof(typename acc_word<T>::type) >= 8 ? 8192u : 16384u; };
+constexpr uint32_t SPA_SYM_WORDS = 32768;      // 2^20 bits
+template <class T, class SR>
+__global__ __launch_bounds__(1024) void k_spgemm_spa_symbolic(const HashArgs a, uint32_t ncols) {
+  __shared__ uint32_t s_bits[SPA_SYM_WORDS];
+  __shared__ uint32_t s_cnt;
+  const uint32_t words = (ncols + 31) / 32;
+  const int t = threadIdx.x, lane16 = t & 15, grp = t >> 4; constexpr int NG = 1024 / 16;
+  for (uint32_t w = t; w < words; w += 1024) s_bits[w] = 0;
+  if (t == 0) s_cnt = 0;
+  __syncthreads();
+  for (uint32_t ridx = blockIdx.x; ridx < a.nrows_bin; ridx += gridDim.x) {
+    const uint32_t i = a.rows[ridx];
+    const uint32_t ab = a.arp[i], ae = a.arp[i + 1];
+    for (uint32_t pa = ab + grp; pa < ae; pa += NG) {
+      const uint32_t k = a.acol[pa]; const uint32_t bb = a.brp[k], be = a.brp[k + 1];
+      for (uint32_t pb = bb + lane16; pb < be; pb += 16) {
+        const uint32_t j = a.bcol[pb], bit = 1u << (j & 31);
+        if (!(s_bits[j >> 5] & bit)) atomicOr(&s_bits[j >> 5], bit);
+      }
+    }
+    __syncthreads();
+    uint32_t c = 0;
+    for (uint32_t w = t; w < words; w += 1024) { c += __popc(s_bits[w]); s_bits[w] = 0; }
+    for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((t & 63) == 0 && c) atomicAdd(&s_cnt, c);
+    __syncthreads();
+    if (t == 0) { a.rownnz[i] = s_cnt; s_cnt = 0; }
+    __syncthreads();
+  }
+}
+// where block c of row k of B begins: split[k * (nblk + 1) + c] = first position of B(k,:) whose column is >= c * WD (one wave per row;
+// the rows are sorted by column, so every boundary is written exactly once)
+static __global__ void k_spa_split(uint32_t nrows, const uint32_t* __restrict__ brp, const uint32_t* __restrict__ bcol, uint32_t wd_shift, uint32_t nblk, uint32_t* __restrict__ split) {
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t k = (blockIdx.x * 256u + threadIdx.x) >> 6; k < nrows; k += gridDim.x * 4u) {
+    const uint32_t bb = brp[k], be = brp[k + 1];
+    uint32_t* sp = split + (size_t)k * (nblk + 1);
+    for (uint32_t p = bb + lane; p < be; p += 64) {
+      const uint32_t blk = bcol[p] >> wd_shift, first = p == bb ? 0u : (bcol[p - 1] >> wd_shift) + 1;
+      for (uint32_t c = first; c <= blk; c++) sp[c] = p;
+    }
+    const uint32_t last = be > bb ? (bcol[be - 1] >> wd_shift) + 1 : 0u;
+    for (uint32_t c = last + lane; c <= nblk; c += 64) sp[c] = be;
+  }
+}
+template <class T, class SR>
+__global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, const T* __restrict__ aval, const T* __restrict__ bval, uint32_t* __restrict__ ocol, T* __restrict__ oval,
+                                                             uint32_t ncols, const uint32_t* __restrict__ split, const SR sr) {
+  typedef typename acc_word<T>::type W;
+  constexpr uint32_t WD = spa_cfg<T>::WD, WORDS = WD / 32;
+  __shared__ W s_acc[WD];
+  __shared__ uint32_t s_bits[WORDS];
+  __shared__ uint32_t s_wsum[16];
+  __shared__ uint32_t s_total;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool use_a = sr.uses_a(), use_b = sr.uses_u();
+  const W idw = to_word<T>(sr.identity);
+  for (uint32_t e = t; e < WD; e += 1024) s_acc[e] = idw;
+  for (uint32_t w = t; w < WORDS; w += 1024) s_bits[w] = 0;
+  __syncthreads();
+  const uint32_t nblk = (uint32_t)(((uint64_t)ncols + WD - 1) / WD);
+  for (uint32_t ridx = blockIdx.x; ridx < a.nrows_bin; ridx += gridDim.x) {
+    const uint32_t i = a.rows[ridx];
+    const uint32_t ab = a.arp[i], ae = a.arp[i + 1];
+    uint32_t obase = a.crp[i];
+    for (uint32_t c = 0; c < nblk; c++) {
+      const uint32_t lo = c * WD;
+      // A wave takes 64 entries k of A(i,:) at a time.  The parts of their B rows that fall into this block (split[]) have wildly
+      // different lengths — most are empty or a single entry, a hub's is thousands — so the wave flattens them: a scan of the
+      // lengths, and lane l of round r takes product number 64 r + l, finding its (k, position) by a binary search over the scan
+      // held in the lanes themselves (ds_bpermute reads, no LDS arrays).  Every lane has a product whatever the lengths are.
+      for (uint32_t base = ab + wave * 64; base < ae; base += 16 * 64) {
+        const uint32_t pa = base + lane;
+        uint32_t st = 0, len = 0; T av = T();
+        if (pa < ae) {
+          const uint32_t* sp = split + (size_t)a.acol[pa] * (nblk + 1) + c;
+          st = sp[0]; len = sp[1] - st; if (use_a) av = aval[pa];
+        }
+        uint32_t inc = len;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+        const uint32_t total = __shfl(inc, 63, 64);
+        if (!total) continue;
+        const uint32_t exc = inc - len, shift = st - exc;            // product q of entry v sits at shift_v + q
+        for (uint32_t q = lane; q - lane < total; q += 64) {
+          const bool live = q < total;
+          uint32_t vlo = 0, vhi = 64;                                // the last entry whose exclusive offset is <= q
+#pragma unroll
+          for (int s2 = 0; s2 < 6; s2++) { const uint32_t mid = (vlo + vhi) >> 1; const uint32_t e = __shfl(exc, (int)mid, 64); if (e <= q) vlo = mid; else vhi = mid; }
+          const uint32_t pb = __shfl(shift, (int)vlo, 64) + q;
+          const T avv = shfl_t<T>(av, (int)vlo);
+          if (live) {
+            const uint32_t rel = a.bcol[pb] - lo, bit = 1u << (rel & 31);
+            if (!(s_bits[rel >> 5] & bit)) atomicOr(&s_bits[rel >> 5], bit);
+            word_combine<T>(sr.add_op(), &s_acc[rel], sr.mult(avv, use_b ? bval[pb] : T()));
+          }
+        }
+      }
+      __syncthreads();
+      // emit the block in column order: exclusive prefix of the words' popcounts, then every word writes its own run
+      uint32_t mybits = 0, mycnt = 0;
+      if ((uint32_t)t < WORDS) { mybits = s_bits[t]; mycnt = (uint32_t)__popc(mybits); }
+      uint32_t inc = mycnt;
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+      if (lane == 63) s_wsum[wave] = inc;
+      __syncthreads();
+      if (t == 0) { uint32_t run = 0; for (int w = 0; w < 16; w++) { const uint32_t v = s_wsum[w]; s_wsum[w] = run; run += v; } s_total = run; }
+      __syncthreads();
+      if ((uint32_t)t < WORDS && mybits) {
+        uint32_t o = obase + s_wsum[wave] + inc - mycnt;
+        s_bits[t] = 0;
+        while (mybits) {
+          const uint32_t b = (uint32_t)__builtin_ctz(mybits), rel = (uint32_t)t * 32 + b;
+          ocol[o] = lo + rel; oval[o] = from_word<T>(s_acc[rel]); s_acc[rel] = idw; o++;
+          mybits &= mybits - 1;
+        }
+      }
+      obase += s_total;
+      __syncthreads();
+    }
+  }
+}
+// the table rows after their sort: columns and values move from the compact staging arrays (row pointers trp) into the result (orp);
+// one wave per row of the three LDS-table bins
+template <class T> __global__ void k_hash_place_rows(const uint32_t* __restrict__ rows, uint32_t nrows_list, const uint32_t* __restrict__ trp, const uint32_t* __restrict__ orp,
+                                                     const uint32_t* __restrict__ scol, const T* __restrict__ uval, const uint32_t* __restrict__ perm, uint32_t* __restrict__ ocol, T* __restrict__ oval) {
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t r = (blockIdx.x * 256u + threadIdx.x) >> 6; r < nrows_list; r += gridDim.x * 4u) {
+    const uint32_t i = rows[r]; const uint32_t tb = trp[i], n = trp[i + 1] - tb, ob = orp[i];
+    for (uint32_t q = lane; q < n; q += 64) { ocol[ob + q] = scol[tb + q]; oval[ob + q] = uval[perm[tb + q]]; }
+  }
+}
+// entry counts of the rows that go through the tables (the others are written in place by the LDS dense path); [nrows] = 0 for the scan
+static __global__ void k_table_counts(uint32_t nrows, const uint32_t* __restrict__ rownnz, uint32_t big_from, uint32_t* __restrict__ out) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i <= nrows; i += gridDim.x * 256ull) out[i] = (i < nrows && rownnz[i] <= big_from) ? rownnz[i] : 0u;
+}
 template <class W> __global__ void k_hash_gather(const W* __restrict__ in, const uint32_t* __restrict__ perm, uint64_t n, W* __restrict__ out) {
   for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) out[i] = in[perm[i]];
 }
@@ -193,13 +337,18 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
   // persistent workgroups of the dense paths: bounded by memory (bitmaps: ncols/8 bytes each; accumulators: ncols words each, <= 4 GiB in all)
   auto dense_blocks = [&](uint32_t rows, size_t per_block) { uint64_t fit = (4ull << 30) / (per_block ? per_block : 1); if (fit < 1) fit = 1; return (unsigned)std::min<uint64_t>(std::min<uint64_t>(rows, (uint64_t)ncu * 2), fit); };
   uint32_t hn[4] = {0, 0, 0, 0};
+  // the LDS dense-accumulator path for the rows beyond the tables (k_spgemm_spa_*): a moderate column range only
+  const bool no_spa = getenv("GRB_MI355X_SPGEMM_NO_SPA") != nullptr;             // measurement / test hook: the HBM accumulators of round 2
+  const bool spa = !no_spa && (uint64_t)ncols <= 64ull * spa_cfg<T>::WD && (uint64_t)ncols <= 32ull * SPA_SYM_WORDS;
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;
     HashArgs a{A.rowptr.as<uint32_t>(), A.col.as<uint32_t>(), B.rowptr.as<uint32_t>(), B.col.as<uint32_t>(), nullptr, 0, rownnz.as<uint32_t>(), nullptr, nullptr};
     const uint32_t* L = lists.as<uint32_t>();
     {
       DevBuf bm;
-      if (hs[3]) { const unsigned nb = dense_blocks(hs[3], (size_t)words * 4); bm.alloc((size_t)nb * words * 4); GRB_HIP(hipMemsetAsync(bm.p, 0, (size_t)nb * words * 4, stream()));
+      if (hs[3] && spa) { a.rows = L + (size_t)3 * nrows; a.nrows_bin = hs[3];
+                          hipLaunchKernelGGL((k_spgemm_spa_symbolic<T, SR>), dim3(std::min<unsigned>(hs[3], (unsigned)ncu)), dim3(1024), 0, stream(), a, ncols); }
+      else if (hs[3]) { const unsigned nb = dense_blocks(hs[3], (size_t)words * 4); bm.alloc((size_t)nb * words * 4); GRB_HIP(hipMemsetAsync(bm.p, 0, (size_t)nb * words * 4, stream()));
                    a.rows = L + (size_t)3 * nrows; a.nrows_bin = hs[3];
                    hipLaunchKernelGGL((k_spgemm_dense<T, SR, false>), dim3(nb), dim3(1024), 0, stream(), a, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, ncols, bm.as<uint32_t>(), (W*)nullptr, sr); }
       if (hs[2]) { a.rows = L + (size_t)2 * nrows; a.nrows_bin = hs[2]; hipLaunchKernelGGL((k_spgemm_hash<T, SR, 32768, 1024, 1024, false>), dim3(nblocks(hs[2], 1)), dim3(1024), 0, stream(), a, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, sr); }
@@ -220,9 +369,46 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
     const uint64_t total = out.nnz;
     out.col.alloc(total * 4 + 8); out.val.alloc(total * sizeof(T) + 8);
     if (total) {
-      DevBuf ucol(total * 4 + 8), uval(total * sizeof(T) + 8);
-      a.crp = out.rowptr.as<uint32_t>(); a.ccol = ucol.as<uint32_t>(); a.rownnz = nullptr;
       const T* av = (const T*)c.aval; const T* bv = (const T*)c.bval;
+      int cbits = 1; while ((1ull << cbits) < (unsigned long long)ncols) cbits++;
+      a.rownnz = nullptr;
+      if (spa) {
+        // The rows beyond the tables go through the LDS dense accumulator straight into the result, in column order.  Only the table
+        // rows (<= 4096 entries each) need the unordered staging arrays, the sort and the move: their own compact row pointers
+        // (16 B of temporaries per entry of THOSE rows — the 47 GB of the R-MAT-18 A@A were 94 GB of allocations per call).
+        DevBuf tcnt(((size_t)nrows + 1) * 4), trp(((size_t)nrows + 1) * 4);
+        hipLaunchKernelGGL(k_table_counts, dim3(grid_n(nrows + 1)), dim3(256), 0, stream(), nrows, rownnz.as<uint32_t>(), 4096u, tcnt.as<uint32_t>());
+        exclusive_scan_u32(tcnt.as<uint32_t>(), trp.as<uint32_t>(), (uint64_t)nrows + 1);
+        uint32_t ttotal = 0;
+        GRB_HIP(hipMemcpyAsync(&ttotal, trp.as<uint32_t>() + nrows, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+        DevBuf split;
+        if (hn[3]) {
+          constexpr uint32_t WD = spa_cfg<T>::WD; const uint32_t nblk = (uint32_t)(((uint64_t)ncols + WD - 1) / WD);
+          split.alloc((size_t)B.nrows * (nblk + 1) * 4 + 8);
+          hipLaunchKernelGGL(k_spa_split, dim3(std::min<unsigned>((B.nrows + 3) / 4, 65535u)), dim3(256), 0, stream(), B.nrows, B.rowptr.as<uint32_t>(), B.col.as<uint32_t>(),
+                             (uint32_t)__builtin_ctz(WD), nblk, split.as<uint32_t>());
+          a.crp = out.rowptr.as<uint32_t>(); a.ccol = nullptr; a.rows = L + (size_t)3 * nrows; a.nrows_bin = hn[3];
+          hipLaunchKernelGGL((k_spgemm_spa_numeric<T, SR>), dim3(std::min<unsigned>(hn[3], (unsigned)ncu * 2)), dim3(1024), 0, stream(), a, av, bv, out.col.as<uint32_t>(), out.val.as<T>(), ncols,
+                             split.as<uint32_t>(), sr);
+        }
+        if (ttotal) {
+          DevBuf ucol((size_t)ttotal * 4 + 8), uval((size_t)ttotal * sizeof(T) + 8), scol((size_t)ttotal * 4 + 8), perm0((size_t)ttotal * 4 + 8), perm((size_t)ttotal * 4 + 8);
+          a.crp = trp.as<uint32_t>(); a.ccol = ucol.as<uint32_t>();
+          if (hn[2]) { a.rows = L + (size_t)2 * nrows; a.nrows_bin = hn[2]; hipLaunchKernelGGL((k_spgemm_hash<T, SR, 8192, 1024, 1024, true>), dim3(nblocks(hn[2], 1)), dim3(1024), 0, stream(), a, av, bv, uval.as<T>(), sr); }
+          if (hn[1]) { a.rows = L + (size_t)1 * nrows; a.nrows_bin = hn[1]; hipLaunchKernelGGL((k_spgemm_hash<T, SR, 2048, 256, 256, true>), dim3(nblocks(hn[1], 1)), dim3(256), 0, stream(), a, av, bv, uval.as<T>(), sr); }
+          if (hn[0]) { a.rows = L; a.nrows_bin = hn[0]; hipLaunchKernelGGL((k_spgemm_hash<T, SR, 256, 64, 256, true>), dim3(nblocks(hn[0], 4)), dim3(256), 0, stream(), a, av, bv, uval.as<T>(), sr); }
+          GRB_HIP(hipGetLastError());
+          hipLaunchKernelGGL(k_iota32, dim3(grid_n(ttotal)), dim3(256), 0, stream(), perm0.as<uint32_t>(), (uint64_t)ttotal);
+          segmented_sort_pairs_u32(ucol.as<uint32_t>(), scol.as<uint32_t>(), perm0.as<uint32_t>(), perm.as<uint32_t>(), ttotal, nrows, trp.as<uint32_t>(), trp.as<uint32_t>() + 1, cbits);
+          for (int b = 0; b < 3; b++) if (hn[b])
+            hipLaunchKernelGGL((k_hash_place_rows<T>), dim3(std::min<unsigned>((hn[b] + 3) / 4, 65535u)), dim3(256), 0, stream(), L + (size_t)b * nrows, hn[b], trp.as<uint32_t>(), out.rowptr.as<uint32_t>(),
+                               scol.as<uint32_t>(), uval.as<T>(), perm.as<uint32_t>(), out.col.as<uint32_t>(), out.val.as<T>());
+          GRB_HIP(hipGetLastError());
+          GRB_HIP(hipStreamSynchronize(stream()));
+        }
+      } else {
+      DevBuf ucol(total * 4 + 8), uval(total * sizeof(T) + 8);
+      a.crp = out.rowptr.as<uint32_t>(); a.ccol = ucol.as<uint32_t>();
       DevBuf bm, accs;
       if (hn[3]) {
         const unsigned nb = dense_blocks(hn[3], (size_t)ncols * sizeof(W) + (size_t)words * 4);
@@ -239,11 +425,11 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
       // ---- column order inside every row ----------------------------------------------------------------------------------------
       DevBuf perm0(total * 4 + 8), perm(total * 4 + 8);
       hipLaunchKernelGGL(k_iota32, dim3(grid_n(total)), dim3(256), 0, stream(), perm0.as<uint32_t>(), total);
-      int cbits = 1; while ((1ull << cbits) < (unsigned long long)ncols) cbits++;
-      segmented_sort_pairs_u32(ucol.as<uint32_t>(), out.col.as<uint32_t>(), perm0.as<uint32_t>(), perm.as<uint32_t>(), total, nrows, out.rowptr.as<uint32_t>(), cbits);
+      segmented_sort_pairs_u32(ucol.as<uint32_t>(), out.col.as<uint32_t>(), perm0.as<uint32_t>(), perm.as<uint32_t>(), total, nrows, out.rowptr.as<uint32_t>(), out.rowptr.as<uint32_t>() + 1, cbits);
       hipLaunchKernelGGL((k_hash_gather<T>), dim3(grid_n(total)), dim3(256), 0, stream(), uval.as<T>(), perm.as<uint32_t>(), total, out.val.as<T>());
       GRB_HIP(hipGetLastError());
       GRB_HIP(hipStreamSynchronize(stream()));                        // the temporaries of this scope go back to the pool
+      }
     }
     g_last_plan += std::string("spgemm_hash<") + (sr.is_static ? "static" : "dynamic") + "> symbolic bins " + std::to_string(hs[0]) + "/" + std::to_string(hs[1]) + "/" + std::to_string(hs[2]) + "/" +
                    std::to_string(hs[3]) + " numeric bins " + std::to_string(hn[0]) + "/" + std::to_string(hn[1]) + "/" + std::to_string(hn[2]) + "/" + std::to_string(hn[3]) + " ";

@@ -228,14 +228,47 @@ def test_two_pass_hash_spgemm_every_bin_against_expand_sort_compress(gpu, typ, s
     E = A.mxm(A, semiring=getattr(TYPE[typ], sr))
     assert "spgemm_esc" in gb.last_kernel_plan()
     monkeypatch.setenv("GRB_MI355X_SPGEMM", "hash")
-    H = A.mxm(A, semiring=getattr(TYPE[typ], sr))
+    ei, ej, ex = E.to_arrays()
+    for no_spa in (False, True):             # rows beyond the tables: the dense accumulator in LDS (column blocks, in-order emission) / in HBM (round 2)
+        if no_spa:
+            monkeypatch.setenv("GRB_MI355X_SPGEMM_NO_SPA", "1")
+        H = A.mxm(A, semiring=getattr(TYPE[typ], sr))
+        plan = gb.last_kernel_plan()
+        assert "spgemm_hash" in plan
+        sym = [int(x) for x in plan.split("symbolic bins ")[1].split()[0].split("/")]
+        num = [int(x) for x in plan.split("numeric bins ")[1].split()[0].split("/")]
+        assert all(x > 0 for x in sym) and all(x > 0 for x in num), plan
+        hi_, hj, hx = H.to_arrays()
+        assert np.array_equal(ei, hi_) and np.array_equal(ej, hj), (plan, no_spa)
+        if typ.startswith("FP"):
+            assert np.allclose(hx, ex, rtol=1e-6, atol=0.0)
+        else:
+            assert np.array_equal(hx, ex), (plan, no_spa)
+
+
+@pytest.mark.parametrize("typ,sr", [("INT64", "PLUS_TIMES"), ("FP32", "MIN_PLUS"), ("FP64", "PLUS_TIMES")])
+def test_hash_spgemm_wide_rows_through_many_column_blocks(gpu, typ, sr, monkeypatch):
+    """Rows of the result with tens of thousands of entries over 70 000 columns: the LDS dense accumulator walks 9 (8-byte) / 5
+    (4-byte) column blocks per row with its cursors into the B rows; empty blocks, B rows that end inside a block, a last
+    partial block.  Against expand / sort / compress."""
+    rng = np.random.default_rng(9)
+    A, rp, col, vals = _rmat_matrix(12, typ, rng, 1, 3)
+    m, n = 1 << 12, 70001
+    nnz = 1200000
+    key = np.unique(rng.integers(0, m * n, size=nnz, dtype=np.int64))
+    key = key[(key % n < 20000) | (key % n > 30000)]                                 # a band of columns nobody has: empty blocks
+    I, J = np.divmod(key.astype(np.uint64), np.uint64(n))
+    X = rng.integers(1, 4, len(key)).astype(O.NP[typ])
+    B = gb.Matrix.from_arrays(I, J, X, m, n, TYPE[typ])
+    monkeypatch.setenv("GRB_MI355X_SPGEMM", "esc")
+    E = A.mxm(B, semiring=getattr(TYPE[typ], sr))
+    monkeypatch.setenv("GRB_MI355X_SPGEMM", "hash")
+    H = A.mxm(B, semiring=getattr(TYPE[typ], sr))
     plan = gb.last_kernel_plan()
-    assert "spgemm_hash" in plan
-    sym = [int(x) for x in plan.split("symbolic bins ")[1].split()[0].split("/")]
     num = [int(x) for x in plan.split("numeric bins ")[1].split()[0].split("/")]
-    assert all(x > 0 for x in sym) and all(x > 0 for x in num), plan
+    assert num[3] > 100, plan
     ei, ej, ex = E.to_arrays(); hi_, hj, hx = H.to_arrays()
-    assert np.array_equal(ei, hi_) and np.array_equal(ej, hj)
+    assert np.array_equal(ei, hi_) and np.array_equal(ej, hj), plan
     if typ.startswith("FP"):
         assert np.allclose(hx, ex, rtol=1e-6, atol=0.0)
     else:
