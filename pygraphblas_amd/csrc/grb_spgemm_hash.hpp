@@ -167,28 +167,59 @@ __global__ __launch_bounds__(1024) void k_spgemm_dense(const HashArgs a, const T
 // the products of a block are dealt to the lanes of a wave whatever the lengths of the row parts are, they combine with LDS atomics, and the block is emitted by scanning its bitmap — in column order, straight into the
 // result: no claim list, no sort, no gather for these rows.  The symbolic pass marks a bitmap of all ncols bits in LDS (<= 2^20
 // columns).  Taken when ncols <= 64 blocks (2^19 columns for 8-byte types, 2^20 for 4-byte ones); the HBM path remains for wider results.
-template <class T> struct spa_cfg { static constexpr uint32_t WD = sizeof(typename acc_word<T>::type) >= 8 ? 8192u : 16384u; };
+template <class T> struct spa_cfg { static constexpr uint32_t WD = sizeof(typename acc_word<T>::type) >= 8 ? 6144u : 12288u; };     // 48 KiB of accumulators
 constexpr uint32_t SPA_SYM_WORDS = 32768;      // 2^20 bits
+// The products of up to 1024 entries k of A(i,:) (one per thread: `len` entries of B starting at `st`), dealt evenly to the 16
+// waves of the workgroup whatever the lengths are — most are empty or a single entry, a hub's is tens of thousands: an exclusive
+// scan of the lengths in LDS, every wave takes a sixteenth of the product range in rounds of 64, and a lane finds the entry its
+// product belongs to by a binary search over the scan.  f(v, pb): entry v of the chunk, position pb in B.  (A group of 16 lanes
+// per entry, as the table kernels do it, left this kernel waiting 96 % of its cycles: rows with a few dozen entries pointing at
+// hub rows kept one group busy and 63 idle.)
+template <class F> __device__ __forceinline__ void spa_flat_walk(uint32_t st, uint32_t len, uint32_t* s_exc /* [1025] */, uint32_t* s_shift /* [1024] */, uint32_t* s_wtot /* [16] */, F&& f) {
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  uint32_t inc = len;
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += v; }
+  if (lane == 63) s_wtot[wave] = inc;
+  __syncthreads();
+  uint32_t woff = 0, total = 0;
+  for (uint32_t w = 0; w < 16; w++) { const uint32_t v = s_wtot[w]; if (w < wave) woff += v; total += v; }
+  const uint32_t exc = woff + inc - len;
+  s_exc[t] = exc; s_shift[t] = st - exc;
+  if (t == 0) s_exc[1024] = total;
+  __syncthreads();
+  if (total) {
+    const uint32_t q0 = (uint32_t)((uint64_t)total * wave / 16), q1 = (uint32_t)((uint64_t)total * (wave + 1) / 16);
+    for (uint32_t qb = q0; qb < q1; qb += 64) {
+      const uint32_t q = qb + lane; const bool live = q < q1;
+      uint32_t vlo = 0, vhi = 1024;                        // the last entry whose exclusive offset is <= q
+#pragma unroll
+      for (int s2 = 0; s2 < 10; s2++) { const uint32_t mid = (vlo + vhi) >> 1; if (s_exc[mid] <= q) vlo = mid; else vhi = mid; }
+      if (live) f(vlo, s_shift[vlo] + q);
+    }
+  }
+  __syncthreads();
+}
 template <class T, class SR>
 __global__ __launch_bounds__(1024) void k_spgemm_spa_symbolic(const HashArgs a, uint32_t ncols) {
   __shared__ uint32_t s_bits[SPA_SYM_WORDS];
+  __shared__ uint32_t s_exc[1025], s_shift[1024], s_wtot[16];
   __shared__ uint32_t s_cnt;
   const uint32_t words = (ncols + 31) / 32;
-  const int t = threadIdx.x, lane16 = t & 15, grp = t >> 4; constexpr int NG = 1024 / 16;
+  const uint32_t t = threadIdx.x;
   for (uint32_t w = t; w < words; w += 1024) s_bits[w] = 0;
   if (t == 0) s_cnt = 0;
   __syncthreads();
   for (uint32_t ridx = blockIdx.x; ridx < a.nrows_bin; ridx += gridDim.x) {
     const uint32_t i = a.rows[ridx];
     const uint32_t ab = a.arp[i], ae = a.arp[i + 1];
-    for (uint32_t pa = ab + grp; pa < ae; pa += NG) {
-      const uint32_t k = a.acol[pa]; const uint32_t bb = a.brp[k], be = a.brp[k + 1];
-      for (uint32_t pb = bb + lane16; pb < be; pb += 16) {
+    for (uint32_t base = ab; base < ae; base += 1024) {
+      const uint32_t pa = base + t; uint32_t st = 0, len = 0;
+      if (pa < ae) { const uint32_t k = a.acol[pa]; st = a.brp[k]; len = a.brp[k + 1] - st; }
+      spa_flat_walk(st, len, s_exc, s_shift, s_wtot, [&](uint32_t, uint32_t pb) {
         const uint32_t j = a.bcol[pb], bit = 1u << (j & 31);
         if (!(s_bits[j >> 5] & bit)) atomicOr(&s_bits[j >> 5], bit);
-      }
+      });
     }
-    __syncthreads();
     uint32_t c = 0;
     for (uint32_t w = t; w < words; w += 1024) { c += __popc(s_bits[w]); s_bits[w] = 0; }
     for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o, 64);
@@ -200,16 +231,16 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_symbolic(const HashArgs a, 
 }
 // where block c of row k of B begins: split[k * (nblk + 1) + c] = first position of B(k,:) whose column is >= c * WD (one wave per row;
 // the rows are sorted by column, so every boundary is written exactly once)
-static __global__ void k_spa_split(uint32_t nrows, const uint32_t* __restrict__ brp, const uint32_t* __restrict__ bcol, uint32_t wd_shift, uint32_t nblk, uint32_t* __restrict__ split) {
+static __global__ void k_spa_split(uint32_t nrows, const uint32_t* __restrict__ brp, const uint32_t* __restrict__ bcol, uint32_t wd, uint32_t nblk, uint32_t* __restrict__ split) {
   const uint32_t lane = threadIdx.x & 63;
   for (uint32_t k = (blockIdx.x * 256u + threadIdx.x) >> 6; k < nrows; k += gridDim.x * 4u) {
     const uint32_t bb = brp[k], be = brp[k + 1];
     uint32_t* sp = split + (size_t)k * (nblk + 1);
     for (uint32_t p = bb + lane; p < be; p += 64) {
-      const uint32_t blk = bcol[p] >> wd_shift, first = p == bb ? 0u : (bcol[p - 1] >> wd_shift) + 1;
+      const uint32_t blk = bcol[p] / wd, first = p == bb ? 0u : bcol[p - 1] / wd + 1;
       for (uint32_t c = first; c <= blk; c++) sp[c] = p;
     }
-    const uint32_t last = be > bb ? (bcol[be - 1] >> wd_shift) + 1 : 0u;
+    const uint32_t last = be > bb ? bcol[be - 1] / wd + 1 : 0u;
     for (uint32_t c = last + lane; c <= nblk; c += 64) sp[c] = be;
   }
 }
@@ -219,10 +250,12 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
   typedef typename acc_word<T>::type W;
   constexpr uint32_t WD = spa_cfg<T>::WD, WORDS = WD / 32;
   __shared__ W s_acc[WD];
+  __shared__ T s_av[1024];
   __shared__ uint32_t s_bits[WORDS];
+  __shared__ uint32_t s_exc[1025], s_shift[1024], s_wtot[16];
   __shared__ uint32_t s_wsum[16];
   __shared__ uint32_t s_total;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const bool use_a = sr.uses_a(), use_b = sr.uses_u();
   const W idw = to_word<T>(sr.identity);
   for (uint32_t e = t; e < WD; e += 1024) s_acc[e] = idw;
@@ -233,53 +266,45 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
     const uint32_t i = a.rows[ridx];
     const uint32_t ab = a.arp[i], ae = a.arp[i + 1];
     uint32_t obase = a.crp[i];
+    // a row of at most 1024 entries — nearly all of them — is one chunk: its B rows and A values stay in place over the blocks, and
+    // the next block's boundary is loaded while this block is worked on (consecutive blocks share a boundary)
+    const bool single = ae - ab <= 1024;
+    const uint32_t* sp0 = nullptr; uint32_t cur_st = 0, cur_en = 0;
+    if (single) {
+      if (ab + t < ae) { sp0 = split + (size_t)a.acol[ab + t] * (nblk + 1); cur_st = sp0[0]; cur_en = sp0[1]; if (use_a) s_av[t] = aval[ab + t]; }
+    }
     for (uint32_t c = 0; c < nblk; c++) {
       const uint32_t lo = c * WD;
-      // A wave takes 64 entries k of A(i,:) at a time.  The parts of their B rows that fall into this block (split[]) have wildly
-      // different lengths — most are empty or a single entry, a hub's is thousands — so the wave flattens them: a scan of the
-      // lengths, and lane l of round r takes product number 64 r + l, finding its (k, position) by a binary search over the scan
-      // held in the lanes themselves (ds_bpermute reads, no LDS arrays).  Every lane has a product whatever the lengths are.
-      for (uint32_t base = ab + wave * 64; base < ae; base += 16 * 64) {
-        const uint32_t pa = base + lane;
-        uint32_t st = 0, len = 0; T av = T();
-        if (pa < ae) {
+      for (uint32_t base = ab; base < ae; base += 1024) {
+        const uint32_t pa = base + t;
+        uint32_t st = 0, len = 0;
+        if (single) {
+          st = cur_st; len = cur_en - cur_st;
+          if (sp0 && c + 1 < nblk) { cur_st = cur_en; cur_en = sp0[c + 2]; }
+        } else if (pa < ae) {
           const uint32_t* sp = split + (size_t)a.acol[pa] * (nblk + 1) + c;
-          st = sp[0]; len = sp[1] - st; if (use_a) av = aval[pa];
+          st = sp[0]; len = sp[1] - st; if (use_a) s_av[t] = aval[pa];      // (read by other threads only behind the walk's first barrier)
         }
-        uint32_t inc = len;
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
-        const uint32_t total = __shfl(inc, 63, 64);
-        if (!total) continue;
-        const uint32_t exc = inc - len, shift = st - exc;            // product q of entry v sits at shift_v + q
-        for (uint32_t q = lane; q - lane < total; q += 64) {
-          const bool live = q < total;
-          uint32_t vlo = 0, vhi = 64;                                // the last entry whose exclusive offset is <= q
-#pragma unroll
-          for (int s2 = 0; s2 < 6; s2++) { const uint32_t mid = (vlo + vhi) >> 1; const uint32_t e = __shfl(exc, (int)mid, 64); if (e <= q) vlo = mid; else vhi = mid; }
-          const uint32_t pb = __shfl(shift, (int)vlo, 64) + q;
-          const T avv = shfl_t<T>(av, (int)vlo);
-          if (live) {
-            const uint32_t rel = a.bcol[pb] - lo, bit = 1u << (rel & 31);
-            if (!(s_bits[rel >> 5] & bit)) atomicOr(&s_bits[rel >> 5], bit);
-            word_combine<T>(sr.add_op(), &s_acc[rel], sr.mult(avv, use_b ? bval[pb] : T()));
-          }
-        }
+        spa_flat_walk(st, len, s_exc, s_shift, s_wtot, [&](uint32_t v, uint32_t pb) {
+          const uint32_t rel = a.bcol[pb] - lo, bit = 1u << (rel & 31);
+          if (!(s_bits[rel >> 5] & bit)) atomicOr(&s_bits[rel >> 5], bit);
+          word_combine<T>(sr.add_op(), &s_acc[rel], sr.mult(use_a ? s_av[v] : T(), use_b ? bval[pb] : T()));
+        });
       }
-      __syncthreads();
       // emit the block in column order: exclusive prefix of the words' popcounts, then every word writes its own run
       uint32_t mybits = 0, mycnt = 0;
-      if ((uint32_t)t < WORDS) { mybits = s_bits[t]; mycnt = (uint32_t)__popc(mybits); }
+      if (t < WORDS) { mybits = s_bits[t]; mycnt = (uint32_t)__popc(mybits); }
       uint32_t inc = mycnt;
-      for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += v; }
       if (lane == 63) s_wsum[wave] = inc;
       __syncthreads();
       if (t == 0) { uint32_t run = 0; for (int w = 0; w < 16; w++) { const uint32_t v = s_wsum[w]; s_wsum[w] = run; run += v; } s_total = run; }
       __syncthreads();
-      if ((uint32_t)t < WORDS && mybits) {
+      if (t < WORDS && mybits) {
         uint32_t o = obase + s_wsum[wave] + inc - mycnt;
         s_bits[t] = 0;
         while (mybits) {
-          const uint32_t b = (uint32_t)__builtin_ctz(mybits), rel = (uint32_t)t * 32 + b;
+          const uint32_t b = (uint32_t)__builtin_ctz(mybits), rel = t * 32 + b;
           ocol[o] = lo + rel; oval[o] = from_word<T>(s_acc[rel]); s_acc[rel] = idw; o++;
           mybits &= mybits - 1;
         }
@@ -386,7 +411,7 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
           constexpr uint32_t WD = spa_cfg<T>::WD; const uint32_t nblk = (uint32_t)(((uint64_t)ncols + WD - 1) / WD);
           split.alloc((size_t)B.nrows * (nblk + 1) * 4 + 8);
           hipLaunchKernelGGL(k_spa_split, dim3(std::min<unsigned>((B.nrows + 3) / 4, 65535u)), dim3(256), 0, stream(), B.nrows, B.rowptr.as<uint32_t>(), B.col.as<uint32_t>(),
-                             (uint32_t)__builtin_ctz(WD), nblk, split.as<uint32_t>());
+                             WD, nblk, split.as<uint32_t>());
           a.crp = out.rowptr.as<uint32_t>(); a.ccol = nullptr; a.rows = L + (size_t)3 * nrows; a.nrows_bin = hn[3];
           hipLaunchKernelGGL((k_spgemm_spa_numeric<T, SR>), dim3(std::min<unsigned>(hn[3], (unsigned)ncu * 2)), dim3(1024), 0, stream(), a, av, bv, out.col.as<uint32_t>(), out.val.as<T>(), ncols,
                              split.as<uint32_t>(), sr);
