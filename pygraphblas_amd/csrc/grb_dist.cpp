@@ -239,7 +239,7 @@ GrB_Info GrBX_Vector_allgatherv_bits(GrB_Vector full, const GrB_Vector local, co
                                   full->dpres.as<uint8_t>() + bounds[p]);
     }
     GRB_HIP(hipGetLastError());
-    vec_invalidate_host(full); full->dnvals_known = false; full->fe_lb = 0; full->fe_lb_key = nullptr;
+    vec_invalidate_host(full); full->dnvals_known = false; full->fe_lb = 0; full->fe_lb_key = 0;
   });
 }
 

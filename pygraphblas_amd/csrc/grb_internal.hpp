@@ -77,16 +77,18 @@ struct GrbError { int info; std::string msg; };
   ::grb::fail(GrB_PANIC, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 
 // owning device buffer
+uint64_t dev_alloc_serial();      // a number no other allocation of this process gets (the pool hands the same addresses out again)
 struct DevBuf {
   void* p = nullptr; size_t bytes = 0;
+  uint64_t serial = 0;              // identifies this allocation where a raw address could be a recycled one (Vector::fe_lb_key)
   DevBuf() {}
   explicit DevBuf(size_t n) { alloc(n); }
   DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
-  DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { reset(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; } return *this; }
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), serial(o.serial) { o.p = nullptr; o.bytes = 0; o.serial = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { reset(); p = o.p; bytes = o.bytes; serial = o.serial; o.p = nullptr; o.bytes = 0; o.serial = 0; } return *this; }
   ~DevBuf() { reset(); }
-  void alloc(size_t n) { reset(); if (n) { p = dev_alloc(n); bytes = n; } }
-  void reset() { if (p) dev_free(p); p = nullptr; bytes = 0; }
+  void alloc(size_t n) { reset(); if (n) { p = dev_alloc(n); bytes = n; serial = dev_alloc_serial(); } }
+  void reset() { if (p) dev_free(p); p = nullptr; bytes = 0; serial = 0; }
   template <class T> T* as() const { return (T*)p; }
 };
 
@@ -150,7 +152,7 @@ struct GrB_Vector_opaque {
   // a lower bound of the edges that leave the vector's entries in one matrix (keyed by its row-pointer buffer), valid while entries are
   // only added (scalar assign under a mask without replace — the `v[q] = level` of a BFS loop): a masked product whose operand was
   // already too heavy for a push step needs no recount to stay a pull step.  A stale value can only cost speed, never correctness.
-  uint64_t fe_lb = 0; const void* fe_lb_key = nullptr;
+  uint64_t fe_lb = 0; uint64_t fe_lb_key = 0;      // (key: the serial of the matrix's row-pointer allocation, 0 = none)
   // ---- non-blocking state (grb_lazy.cpp; the library is initialised GrB_NONBLOCKING by the reference, pygraphblas/__init__.py:251-256) ----
   // lazy == 1: `w(:) = lazy_fill` over every index was requested and nothing has been written yet (no buffers): a product that
   //            accumulates into w with its monoid's operator folds the fill into its own store; anything else materialises it.

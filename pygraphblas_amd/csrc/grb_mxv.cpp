@@ -55,11 +55,11 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   bool stays_pull = false;            // the operand was too heavy for a push step when it was last counted and has only grown since
   if (!u->dnvals_known && mask && method == SPMV_AUTO && spmspv_push_supported(sd) && u->n && (useT || A->csc.valid)) {      // (a masked product: frontier-like operand; never build a transpose just for this)
     const DevCSR& P0 = useT ? A->csr : mat_csc(A);
-    if (u->fe_lb_key == P0.rowptr.p && u->fe_lb * 16 >= P0.nnz + 16) stays_pull = true;      // no kernel, no host round trip
+    if (u->fe_lb_key == P0.rowptr.serial && P0.rowptr.serial && u->fe_lb * 16 >= P0.nnz + 16) stays_pull = true;      // no kernel, no host round trip
     else {
       uint64_t cnt = 0;
       fe_cached = frontier_edges_and_count(u->dpres.as<uint8_t>(), P0.rowptr.as<uint32_t>(), u->n, &cnt);
-      u->dnvals = cnt; u->dnvals_known = true; u->fe_lb = fe_cached; u->fe_lb_key = P0.rowptr.p;
+      u->dnvals = cnt; u->dnvals_known = true; u->fe_lb = fe_cached; u->fe_lb_key = P0.rowptr.serial;
     }
   }
   const uint64_t u_nvals = stays_pull ? (u->n ? u->n - 1 : 0) : vec_dev_nvals(u);             // (not counted: treated as "has holes")
@@ -196,7 +196,7 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
         w->dval = std::move(tval); w->dpres = std::move(tpres);
         w->dev_valid = true; w->host_valid = false; w->hi.clear(); w->hx.clear(); w->pending.clear();
       } else vec_invalidate_host(w);
-      w->dnvals = w->n; w->dnvals_known = true; w->fe_lb = 0; w->fe_lb_key = nullptr; w->holes_zero = false;
+      w->dnvals = w->n; w->dnvals_known = true; w->fe_lb = 0; w->fe_lb_key = 0; w->holes_zero = false;
       return;
     }
   }

@@ -113,7 +113,7 @@ inline const uint8_t* vector_allow(GrB_Vector mask, const DescView& dv, uint64_t
 inline void vector_write_back(GrB_Vector w, int tcode, DevBuf& tval, DevBuf& tpres, const uint8_t* allow, GrB_BinaryOp accum,
                               bool replace, bool t_only_allowed, uint64_t t_nvals = ~0ull) {
   const uint64_t n = w->n; const int wcode = w->type->code;
-  w->fe_lb = 0; w->fe_lb_key = nullptr;                       // entries may disappear: the bound of grb_mxv.cpp's direction choice is void
+  w->fe_lb = 0; w->fe_lb_key = 0;                       // entries may disappear: the bound of grb_mxv.cpp's direction choice is void
   const bool w_empty = w->lazy ? false : (w->host_valid ? (vec_nvals(w) == 0) : (w->dnvals_known && w->dnvals == 0));   // (deferred work pending on w: not known, and not worth completing for this)
   if (accum) check_binop(accum, "accum");
   if (!accum && (!allow || (t_only_allowed && (replace || w_empty)))) {

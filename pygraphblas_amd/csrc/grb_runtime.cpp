@@ -1,6 +1,7 @@
 // grb_runtime.cpp — process-wide state: HIP device, stream, pooled HBM allocator, timers,
 // and the built-in object registry.  (MI355X: one process drives one GPU; multi-GPU runs are
 // one process per GPU, see pygraphblas_amd/dist.py.)
+#include <atomic>
 #include "grb_internal.hpp"
 #include "grb_api.hpp"
 #include "grb_lazy.hpp"
@@ -68,6 +69,8 @@ void* dev_alloc(size_t bytes) {
   g_live[p] = sc; g_in_use += sc;
   return p;
 }
+
+uint64_t dev_alloc_serial() { static std::atomic<uint64_t> g_serial{0}; return ++g_serial; }
 
 void dev_free(void* p) {
   if (!p) return;

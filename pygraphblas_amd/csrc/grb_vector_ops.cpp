@@ -107,7 +107,7 @@ static void vec_assign(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const 
       vec_assign_scalar_masked(wcode0, n, w->dval.p, w->dpres.as<uint8_t>(), mask->type->code, mask->dval.p, mask->dpres.as<uint8_t>(), dv.mask_struct, dv.mask_comp, s0,
                                accum ? accum->opcode : -1, dv.replace);
       vec_invalidate_host(w);
-      if (dv.replace) { w->fe_lb = 0; w->fe_lb_key = nullptr; }
+      if (dv.replace) { w->fe_lb = 0; w->fe_lb_key = 0; }
       w->dnvals_known = false; w->dnvals = 0;
       return;
     }
@@ -140,7 +140,7 @@ static void vec_assign(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const 
     vec_cast_values(wcode, w->dval.p, ecode, wc.p, n);
   }
   vec_invalidate_host(w);
-  if (dv.replace) { w->fe_lb = 0; w->fe_lb_key = nullptr; }                      // (without replace a scalar assign only adds entries: the bound stays)
+  if (dv.replace) { w->fe_lb = 0; w->fe_lb_key = 0; }                      // (without replace a scalar assign only adds entries: the bound stays)
   w->dnvals_known = !allow && !reg; w->dnvals = w->dnvals_known ? n : 0;       // every index, no mask: the vector is full now
 }
 
