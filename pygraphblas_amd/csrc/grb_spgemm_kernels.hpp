@@ -343,6 +343,9 @@ __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T>
   // counters: 0 = no hit yet.  Generic accumulators start at the identity and carry a flag byte each (LCF words + LCF bytes in the same budget)
   constexpr uint32_t LCF = CNT32 ? LC : (uint32_t)(SPG_MAP_LDS_BYTES / (sizeof(LW) + 1));
   __shared__ uint32_t s_filter[SPG_FILTER_WORDS];
+  // bit of column j: a multiplicative hash (R-MAT labels are skewed bit by bit: `j mod 2^18` crowds the filter's low words)
+  constexpr int FSH = 32 - (__builtin_ctz(SPG_FILTER_WORDS) + 5);
+  auto fbit = [](const uint32_t j) -> uint32_t { return (uint32_t)__umul24(j, SPG_FILTER_MUL) >> FSH; };
   __shared__ LW s_acc[LC];
   uint8_t* const s_flag = (uint8_t*)(s_acc + LCF);
   constexpr uint32_t HL = 4096;                            // A-entries whose B row is huge: set aside by the waves, then walked by the whole block
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T>
         for (int u = 0; u < 2; u++) {
           const uint32_t jv[4] = {j4[u].x, j4[u].y, j4[u].z, j4[u].w};
 #pragma unroll
-          for (int c = 0; c < 4; c++) { const uint32_t j = jv[c]; ss[4 * u + c] = ((s_filter[(j >> 5) & (SPG_FILTER_WORDS - 1)] >> (j & 31)) & 1u) ? map[j] : 0u; }
+          for (int c = 0; c < 4; c++) { const uint32_t j = jv[c]; const uint32_t fb = fbit(j); ss[4 * u + c] = ((s_filter[fb >> 5] >> (fb & 31)) & 1u) ? map[j] : 0u; }
         }
         if (base + 16 * step <= be) {
 #pragma unroll
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T>
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const uint32_t pb = pb0 + step * u; const uint32_t j = ss[u];
-        const bool maybe = pb < be && ((s_filter[(j >> 5) & (SPG_FILTER_WORDS - 1)] >> (j & 31)) & 1u);
+        const uint32_t fb = fbit(j); const bool maybe = pb < be && ((s_filter[fb >> 5] >> (fb & 31)) & 1u);
         ss[u] = maybe ? map[j] : 0u;                                     // the survivors: exact position from the map
       }
 #pragma unroll
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T>
     __syncthreads();
     for (uint32_t p = mb + t; p < me; p += 1024) if (spgemm_mask_truth(a.mval, a.mcode, p, a.mstruct)) {
       const uint32_t j = a.mcol[p];
-      map[j] = p - mb + 1; atomicOr(&s_filter[(j >> 5) & (SPG_FILTER_WORDS - 1)], 1u << (j & 31));
+      map[j] = p - mb + 1; const uint32_t fb = fbit(j); atomicOr(&s_filter[fb >> 5], 1u << (fb & 31));
     }
     __threadfence_block(); __syncthreads();
     // one wave per entry k of A(i,:): these rows have thousands of k's, most with long B rows; the longest ones are kept
