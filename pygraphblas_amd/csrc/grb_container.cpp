@@ -10,6 +10,7 @@
 // handles is a successful no-op (reference __del__ checks the return code).
 #include "grb_api.hpp"
 #include "grb_device.hpp"
+#include "grb_matops.hpp"
 #include <algorithm>
 #include <numeric>
 #include <string.h>
@@ -59,7 +60,7 @@ void mat_host_assemble(GrB_Matrix A) {
 
 void mat_invalidate_device(GrB_Matrix A) { A->dev_valid = false; A->csr.clear(); A->csc.clear(); }
 void mat_invalidate_host(GrB_Matrix A) {
-  A->host_valid = false; A->hi.clear(); A->hj.clear(); A->hx.clear(); A->pending.clear();
+  A->host_valid = false; A->hi.clear(); A->hj.clear(); A->hx.clear(); A->pending.clear(); A->dev_elem_ops = 0;
   A->hi.shrink_to_fit(); A->hj.shrink_to_fit(); A->hx.shrink_to_fit();
   A->csc.clear(); A->csr.has_plan = false; A->csr.plan_blocks.reset(); A->csr.plan_aux.reset();
   A->csr.wp_rs.reset(); A->csr.wp_hot.reset(); A->csr.wp_pcol.reset(); A->csr.wp_tsize = 0; A->csr.xcd.reset();
@@ -375,9 +376,24 @@ static GrB_Info mat_build(GrB_Matrix C, const GrB_Index* I, const GrB_Index* J, 
     C->host_valid = true; mat_invalidate_device(C);
   });
 }
+// a matrix that lives in HBM only and is large (`paths[i, source] = 1` on a dense ns x n batch, gap/bcmark.py:23: bringing 134 MB to
+// the host mirror for one value was a third of the algorithm): the entry is looked up on the device; an existing one is read or
+// overwritten in place (what changes with the values — the transpose cache, a kernel-X plan's copy — is dropped)
+// (a caller that touches many elements one by one is better served by the host mirror: one transfer, then no round trips)
+static bool mat_device_only(GrB_Matrix A) { return A->dev_elem_ops++ < 32 && device_ok() && A->dev_valid && !A->host_valid && A->pending.empty() && !A->iso_full && A->csr.valid && A->csr.nnz >= (1u << 16) && A->type->code < T_FC32; }
 static GrB_Info mat_set(GrB_Matrix C, const void* x, int xcode, GrB_Index i, GrB_Index j) {
   CHECK_MAT(C); if (i >= C->nrows || j >= C->ncols) return GrB_INVALID_INDEX;
   return guarded(C, [&] {
+    if (mat_device_only(C)) {
+      const uint64_t pos = csr_find_entry(C->csr, (uint32_t)i, (uint32_t)j);
+      if (pos != ~0ull) {
+        uint8_t* pin = (uint8_t*)pinned_scratch() + 64; cast_scalar(C->type->code, pin, xcode, x);
+        GRB_HIP(hipMemcpyAsync((uint8_t*)C->csr.val.p + pos * C->type->size, pin, C->type->size, hipMemcpyHostToDevice, stream()));
+        GRB_HIP(hipStreamSynchronize(stream()));
+        C->csc.clear(); C->csr.xcd.reset(); C->csr.range_state = 0;
+        return;
+      }
+    }
     if (C->iso_full) fail(GrB_INSUFFICIENT_SPACE, ISO_MSG);
     if (!C->host_valid) mat_to_host(C);
     GrB_Matrix_opaque::Pending p{i, j, false, {0}}; cast_scalar(C->type->code, p.x, xcode, x);
@@ -394,6 +410,13 @@ static GrB_Info mat_get(void* x, int xcode, GrB_Matrix A, GrB_Index i, GrB_Index
   GrB_Info r = GrB_SUCCESS;
   GrB_Info info = guarded(A, [&] {
     if (A->iso_full) { cast_scalar(xcode, x, A->type->code, A->iso_val); return; }
+    if (mat_device_only(A)) {
+      const uint64_t pos = csr_find_entry(A->csr, (uint32_t)i, (uint32_t)j);
+      if (pos == ~0ull) { r = GrB_NO_VALUE; return; }
+      uint8_t* pin = (uint8_t*)pinned_scratch() + 64;
+      GRB_HIP(hipMemcpyAsync(pin, (const uint8_t*)A->csr.val.p + pos * A->type->size, A->type->size, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+      cast_scalar(xcode, x, A->type->code, pin); return;
+    }
     mat_to_host(A); size_t k = mat_find(A, i, j);
     if (k == SIZE_MAX) r = GrB_NO_VALUE; else cast_scalar(xcode, x, A->type->code, &A->hx[k * A->type->size]); });
   return info ? info : r;

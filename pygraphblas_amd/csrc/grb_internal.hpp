@@ -129,6 +129,7 @@ struct GrB_Matrix_opaque {
   bool iso_full = false; uint8_t iso_val[16] = {0};
   // device
   bool dev_valid = false;
+  uint32_t dev_elem_ops = 0; // element reads / writes served on the device in a row (grb_container.cpp: after a few dozen the host mirror takes over)
   grb::DevCSR csr;          // by-row
   grb::DevCSR csc;          // CSR of the transpose (cached; invalidated with csr)
   int format = 0;           // GxB_BY_ROW(0) / GxB_BY_COL(1): stored option only

@@ -8,6 +8,7 @@
 // 1-2 G entries/s on R-MAT-22.  The heavy lifting of the hot path is in grb_spgemm.hip / grb_spmv_kernels.hpp, not here.
 #include "grb_api.hpp"
 #include "grb_device.hpp"
+#include "grb_atomics.hpp"
 #include "grb_matops.hpp"
 
 namespace grb {
@@ -227,6 +228,51 @@ void csr_reduce_rows(int code, const DevCSR& A, const void* aval, int op, void* 
   GRB_HIP(hipGetLastError());
 }
 
+
+// ---- column-wise reduction of a stored-by-row matrix without its transpose (`bcu.reduce_vector(accum=PLUS, out=cent, desc=T0)` at
+// the end of gap/bcmark.py: an ns x n batch — building the n x ns transpose by a sort was 60 ms of the 0.28 s algorithm) ----------
+// Every entry combines into its column's accumulator with the monoid's atomic (native add / min / max, a CAS loop otherwise).
+template <class T> __global__ void k_reduce_cols(uint64_t nnz, const uint32_t* __restrict__ col, const T* __restrict__ val, int op, typename acc_word<T>::type* __restrict__ acc, uint8_t* __restrict__ tpres) {
+  for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < nnz; p += gridDim.x * 256ull) {
+    const uint32_t j = col[p];
+    word_combine<T>(op, &acc[j], val[p]);
+    if (!tpres[j]) tpres[j] = 1;
+  }
+}
+template <class W> __global__ void k_fill_typed(W* p, uint64_t n, W v) { for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) p[i] = v; }
+template <class T> __global__ void k_words_to_values(uint64_t n, const typename acc_word<T>::type* __restrict__ acc, T* __restrict__ out) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) out[i] = from_word<T>(acc[i]);
+}
+bool csr_reduce_cols(int code, const DevCSR& A, const void* aval, int op, const void* identity, void* tval, uint8_t* tpres) {
+  if (code != T_INT32 && code != T_UINT32 && code != T_INT64 && code != T_UINT64 && code != T_FP32 && code != T_FP64) return false;
+  if (!A.ncols) return true;
+  GRB_HIP(hipMemsetAsync(tpres, 0, A.ncols, stream()));
+  dispatch_type(code, [&]<class T>() {
+    if constexpr (sizeof(T) >= 4 && !is_bool<T>::value) {
+      typedef typename acc_word<T>::type W;                    // (4- and 8-byte types: the accumulator word IS the value)
+      T id; memcpy(&id, identity, sizeof(T));
+      uint64_t g = ((uint64_t)A.ncols + 255) / 256; if (g > 8192) g = 8192; if (g < 1) g = 1;
+      hipLaunchKernelGGL((k_fill_typed<W>), dim3((unsigned)g), dim3(256), 0, stream(), (W*)tval, (uint64_t)A.ncols, to_word<T>(id));
+      uint64_t ge = (A.nnz + 255) / 256; if (ge > 16384) ge = 16384; if (ge < 1) ge = 1;
+      if (A.nnz) hipLaunchKernelGGL((k_reduce_cols<T>), dim3((unsigned)ge), dim3(256), 0, stream(), A.nnz, A.col.as<uint32_t>(), (const T*)aval, op, (W*)tval, tpres);
+    }
+  });
+  GRB_HIP(hipGetLastError());
+  return true;
+}
+// position of entry (i, j) in a device CSR, ~0 when it is not stored: one thread walks the row's sorted columns by bisection
+static __global__ void k_find_entry(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, uint32_t i, uint32_t j, unsigned long long* __restrict__ out) {
+  uint32_t lo = rowptr[i], hi = rowptr[i + 1];
+  while (lo < hi) { const uint32_t m = lo + (hi - lo) / 2; if (col[m] < j) lo = m + 1; else hi = m; }
+  *out = (lo < rowptr[i + 1] && col[lo] == j) ? (unsigned long long)lo : ~0ull;
+}
+uint64_t csr_find_entry(const DevCSR& A, uint32_t i, uint32_t j) {
+  DevBuf out(8);
+  hipLaunchKernelGGL(k_find_entry, dim3(1), dim3(1), 0, stream(), A.rowptr.as<uint32_t>(), A.col.as<uint32_t>(), i, j, (unsigned long long*)out.p);
+  unsigned long long* pin = (unsigned long long*)pinned_scratch();
+  GRB_HIP(hipMemcpyAsync(pin, out.p, 8, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+  return pin[0];
+}
 
 // ---- a full one-valued matrix: `Matrix.dense(T, ns, n)` / `M[:, :] = x` (the ns x n batches of the BC sweeps, gap/bcmark.py:19-20, 48) ----
 // Built in HBM by one kernel (round 2 built the three arrays with numpy and uploaded 134 MB per batch: half of the algorithm's time).

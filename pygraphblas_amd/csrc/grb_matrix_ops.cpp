@@ -196,11 +196,24 @@ void do_reduce_vector(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Mon
   DevBuf allow_buf; bool nothing = false;
   const uint8_t* allow = vector_allow(mask, dv, r, allow_buf, &nothing);
   if (nothing) { if (dv.replace) GrB_Vector_clear(w); return; }
-  const DevCSR& S = operand(A, dv.tran0);
   const int mc = monoid->op->ztype->code;
   DevBuf ac, tval(r * type_size(mc) + 8), tpres(r + 1);
-  const void* av = cast_values(mc, A->type->code, S.val.p, S.nnz, ac);
-  csr_reduce_rows(mc, S, av, monoid->op->opcode, tval.p, tpres.as<uint8_t>());
+  // the columns of a large matrix whose transpose is not at hand (desc T0 on a by-row matrix): no transpose is built for this, every
+  // entry combines into its column's accumulator.  (Small matrices keep the row-wise reduction of the transpose: its fixed order
+  // is what the reference's docstring values were computed with.)
+  bool done = false;
+  if (dv.tran0) {
+    mat_to_device(A);
+    if (!A->csc.valid && A->csr.nnz >= (1u << 20)) {
+      const void* av = cast_values(mc, A->type->code, A->csr.val.p, A->csr.nnz, ac);
+      done = csr_reduce_cols(mc, A->csr, av, monoid->op->opcode, monoid->identity, tval.p, tpres.as<uint8_t>());
+    }
+  }
+  if (!done) {
+    const DevCSR& S = operand(A, dv.tran0);
+    const void* av = cast_values(mc, A->type->code, S.val.p, S.nnz, ac);
+    csr_reduce_rows(mc, S, av, monoid->op->opcode, tval.p, tpres.as<uint8_t>());
+  }
   vector_write_back(w, mc, tval, tpres, allow, accum, dv.replace, false);
 }
 

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
+from oracle import oracle as O
 import pygraphblas_amd as gb
 from pygraphblas_amd import descriptor as D
 from helpers import TYPE, rand_matrix, rand_vector, to_matrix, to_vector
@@ -267,3 +268,46 @@ def test_dense_matrix_is_filled_on_the_device(gb, gpu, tname, fill):
         assert np.all(X == typ._np(fill))
         rp, ci, vals = m.to_csr()
         assert np.array_equal(rp, np.arange(nr + 1, dtype=np.uint32) * np.uint32(nc))
+
+
+def test_column_reduce_and_element_access_of_a_large_device_matrix(gpu):
+    """The tail of gap/bcmark.py on an ns x n batch: `bcu.reduce_vector(accum=PLUS, out=cent, desc=T0)` reduces the columns of a
+    by-row matrix without building its transpose (atomics per column), and `paths[i, source] = 1` / `paths[i, j]` on a matrix that
+    lives in HBM only look the entry up on the device instead of bringing 10^7 tuples to the host mirror."""
+    rng = np.random.default_rng(3)
+    ns, n = 4, 300000
+    nnz = 1200000
+    key = np.unique(rng.integers(0, ns * n, size=nnz, dtype=np.int64))
+    I, J = np.divmod(key.astype(np.uint64), np.uint64(n))
+    for typ, acc in (("FP32", "PLUS"), ("INT64", "MIN"), ("FP64", "MAX")):
+        X = rng.integers(-20, 50, len(key)).astype(O.NP[typ])
+        M = gb.Matrix.from_arrays(I, J, X, ns, n, TYPE[typ])
+        w = gb.Vector.from_arrays(np.arange(n, dtype=np.uint64), np.full(n, 3, O.NP[typ]), n, TYPE[typ])
+        M.reduce_vector(getattr(TYPE[typ], acc + "_MONOID"), out=w, accum=getattr(TYPE[typ], "PLUS"), desc=D.T0)
+        exp = np.full(n, 3, np.float64)
+        red = np.zeros(n); has = np.zeros(n, bool)
+        Xf = X.astype(np.float64); Ji = J.astype(np.int64)
+        if acc == "PLUS": np.add.at(red, Ji, Xf)
+        elif acc == "MIN": red[:] = np.inf; np.minimum.at(red, Ji, Xf)
+        else: red[:] = -np.inf; np.maximum.at(red, Ji, Xf)
+        has[Ji] = True
+        exp[has] += red[has]
+        wi, wx = w.to_arrays()
+        assert len(wi) == n and np.array_equal(np.asarray(wx, np.float64), exp), (typ, acc)
+    # element access on the device: a dense batch made in HBM
+    P = gb.Matrix.dense(gb.FP32, ns, n, 0)
+    P[2, 12345] = 1
+    P[3, 0] = 7.5
+    assert P[2, 12345] == 1 and P[3, 0] == 7.5 and P[0, 5] == 0 and P.nvals == ns * n
+    r = gb.Vector.sparse(gb.FP32, n); P.reduce_vector(gb.FP32.PLUS_MONOID, out=r, desc=D.T0)
+    ri, rx = r.to_arrays()
+    assert rx[12345] == 1 and rx[0] == 7.5 and rx.sum() == 8.5
+    S = gb.Matrix.from_arrays(I, J, np.ones(len(key), np.float32), ns, n, gb.FP32)
+    S2 = S.apply(gb.FP32.AINV)                                  # a device-only result
+    i0, j0 = int(I[1000]), int(J[1000])
+    assert S2[i0, j0] == -1
+    S2[i0, j0] = 5                                              # an existing entry: in place
+    assert S2[i0, j0] == 5 and S2.nvals == len(key)
+    free = next(c for c in range(n) if not ((I == 0) & (J == c)).any())
+    S2[0, free] = 9                                             # a new entry: the host mirror takes over
+    assert S2[0, free] == 9 and S2.nvals == len(key) + 1 and S2[i0, j0] == 5
