@@ -165,6 +165,9 @@ struct GrB_Vector_opaque {
   // BOOL vectors: "is any stored value true", recorded by the product kernel that wrote the device buffers `lor_key`
   // (0 unknown, 1 in the device word of grb_container.cpp's any_true_*, 2 false, 3 true) — `while q.reduce_bool()` of a BFS loop
   uint8_t lor_state = 0; uint32_t lor_tag = 0; const void* lor_key = nullptr;
+  // an upper bound of |value| over the stored entries, left behind by the "big holes" product that wrote them (grb_mxv.cpp: the next
+  // sweep of a shortest-path loop needs no range kernel and no read-back); < 0 = unknown.  Reset wherever lor_state is.
+  double abs_bound = -1;
   int sparsity_control = 15;
   std::string err;
 };

@@ -109,7 +109,7 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   // bitmap variant of the row-block kernel runs, as before): |A's values| and |u's values| below a quarter of BIG (integers: BIG =
   // 2^(bits-2), so nothing wraps; floating point: BIG = infinity and every value finite, sums not overflowing), measured once per
   // matrix and once per call.  R-MAT-22 INT64: 1.0 -> 0.3 ms per sweep.
-  bool big_holes = false; uint8_t big_fill[16] = {0}, big_thresh[16] = {0};
+  bool big_holes = false; uint8_t big_fill[16] = {0}, big_thresh[16] = {0}; double big_uabs = 0, big_aabs = 0;
   if (!push && !u_full && !fill_holes && !allow && method == SPMV_AUTO && !sd.flip && sd.mulop == B_PLUS && (sd.addop == B_MIN || sd.addop == B_MAX) &&
       (sd.zcode == T_INT32 || sd.zcode == T_INT64 || sd.zcode == T_FP32 || sd.zcode == T_FP64) && A->type->code == sd.zcode && u->type->code == sd.zcode) {
     DevCSR& R = useT ? const_cast<DevCSR&>(mat_csc(A)) : A->csr;
@@ -128,13 +128,16 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
       }
       if (R.range_state == 1) {
         uint8_t mn[8], mx[8]; uint64_t bad = 0, cnt = 0;
-        if (value_range(sd.zcode, u->n, u->dval.p, u->dpres.as<uint8_t>(), mn, mx, &bad, &cnt) && bad == 0 && cnt) {
+        const bool bound_known = u->abs_bound >= 0 && u->lazy == 0 && u->dev_valid;          // left by the previous sweep: no kernel, no read-back
+        if (bound_known || (value_range(sd.zcode, u->n, u->dval.p, u->dpres.as<uint8_t>(), mn, mx, &bad, &cnt) && bad == 0 && cnt)) {
           double a = 0, b = 0; const bool is_min = sd.addop == B_MIN;
-          if (sd.zcode == T_INT32) { int32_t x, y; memcpy(&x, mn, 4); memcpy(&y, mx, 4); a = (double)x; b = (double)y; }
+          if (bound_known) a = b = u->abs_bound;
+          else if (sd.zcode == T_INT32) { int32_t x, y; memcpy(&x, mn, 4); memcpy(&y, mx, 4); a = (double)x; b = (double)y; }
           else if (sd.zcode == T_INT64) { int64_t x, y; memcpy(&x, mn, 8); memcpy(&y, mx, 8); a = (double)x; b = (double)y; }
           else if (sd.zcode == T_FP32) { float x, y; memcpy(&x, mn, 4); memcpy(&y, mx, 4); a = x; b = y; }
           else { memcpy(&a, mn, 8); memcpy(&b, mx, 8); }
           const double uabs = std::max(std::fabs(a), std::fabs(b));
+          big_uabs = uabs; big_aabs = R.range_abs;
           if (sd.zcode == T_INT32 && R.range_abs < 268435456.0 && uabs < 268435456.0) {            // 2^28: real sums within +-2^29, hole sums beyond +-(2^30 - 2^28)
             const int32_t f = is_min ? (1 << 30) : -(1 << 30), th = is_min ? (1 << 29) + (1 << 28) : -((1 << 29) + (1 << 28));
             memcpy(big_fill, &f, 4); memcpy(big_thresh, &th, 4); big_holes = true;
@@ -201,7 +204,11 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
     }
   }
   if (big_holes) big_to_absent(sd.zcode, mr, tval.p, tpres.as<uint8_t>(), big_thresh, sd.addop == B_MIN);       // sums made of fill values only are no entries
+  const bool w_is_u = w == u; const bool w_was_empty = !w_is_u && w->lazy == 0 && w->dnvals_known && w->dnvals == 0 && !w->host_valid;
   vector_write_back(w, sd.zcode, tval, tpres, allow, accum, dv.replace, /*t_only_allowed=*/true);
+  // every sum that survived the threshold is within |u| + |A|: the bound of the result when w held nothing else (w is u itself, with
+  // the accumulator of the loop `v<accum MIN> = v MIN_PLUS A`, or w was empty / is replaced as a whole)
+  if (big_holes && w->type->code == sd.zcode && (w_is_u || !accum || w_was_empty)) w->abs_bound = big_uabs + big_aabs;
   if (any_done) any_true_written(w->lazy == 0 && w->dev_valid && w->dval.p == tkey ? w : nullptr, tkey, call.any_true_tag);       // (adopted as they are: w is exactly T)
 }
 
