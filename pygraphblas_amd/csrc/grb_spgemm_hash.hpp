@@ -175,7 +175,7 @@ constexpr uint32_t SPA_SYM_WORDS = 32768;      // 2^20 bits
 // product belongs to by a binary search over the scan.  f(v, pb): entry v of the chunk, position pb in B.  (A group of 16 lanes
 // per entry, as the table kernels do it, left this kernel waiting 96 % of its cycles: rows with a few dozen entries pointing at
 // hub rows kept one group busy and 63 idle.)
-template <class F> __device__ __forceinline__ void spa_flat_walk(uint32_t st, uint32_t len, uint32_t* s_exc /* [1025] */, uint32_t* s_shift /* [1024] */, uint32_t* s_wtot /* [16] */, F&& f) {
+template <class F> __device__ __forceinline__ uint32_t spa_flat_walk(uint32_t st, uint32_t len, uint32_t* s_exc /* [1025] */, uint32_t* s_shift /* [1024] */, uint32_t* s_wtot /* [16] */, F&& f) {
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   uint32_t inc = len;
   for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += v; }
@@ -198,6 +198,7 @@ template <class F> __device__ __forceinline__ void spa_flat_walk(uint32_t st, ui
     }
   }
   __syncthreads();
+  return total;                                             // (the same in every thread)
 }
 template <class T, class SR>
 __global__ __launch_bounds__(1024) void k_spgemm_spa_symbolic(const HashArgs a, uint32_t ncols) {
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
     }
     for (uint32_t c = 0; c < nblk; c++) {
       const uint32_t lo = c * WD;
+      uint32_t products = 0;
       for (uint32_t base = ab; base < ae; base += 1024) {
         const uint32_t pa = base + t;
         uint32_t st = 0, len = 0;
@@ -285,12 +287,13 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
           const uint32_t* sp = split + (size_t)a.acol[pa] * (nblk + 1) + c;
           st = sp[0]; len = sp[1] - st; if (use_a) s_av[t] = aval[pa];      // (read by other threads only behind the walk's first barrier)
         }
-        spa_flat_walk(st, len, s_exc, s_shift, s_wtot, [&](uint32_t v, uint32_t pb) {
+        products |= spa_flat_walk(st, len, s_exc, s_shift, s_wtot, [&](uint32_t v, uint32_t pb) {
           const uint32_t rel = a.bcol[pb] - lo, bit = 1u << (rel & 31);
           if (!(s_bits[rel >> 5] & bit)) atomicOr(&s_bits[rel >> 5], bit);
           word_combine<T>(sr.add_op(), &s_acc[rel], sr.mult(use_a ? s_av[v] : T(), use_b ? bval[pb] : T()));
         });
       }
+      if (!products) continue;                              // nothing of this row falls into this block (the whole workgroup agrees): no emission, no barriers
       // emit the block in column order: exclusive prefix of the words' popcounts, then every word writes its own run
       uint32_t mybits = 0, mycnt = 0;
       if (t < WORDS) { mybits = s_bits[t]; mycnt = (uint32_t)__popc(mybits); }
