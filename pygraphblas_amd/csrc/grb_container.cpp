@@ -173,7 +173,7 @@ bool any_true_lookup(GrB_Vector u, bool* value) {
 
 void vec_invalidate_device(GrB_Vector v) { vec_overwritten(v); v->holes_zero = false; v->lor_state = 0; v->abs_bound = -1; v->dev_valid = false; v->dval.reset(); v->dpres.reset(); v->dnvals = 0; v->dnvals_known = true; v->fe_lb = 0; v->fe_lb_key = 0; }
 void vec_invalidate_host(GrB_Vector v) {
-  vec_overwritten(v); v->holes_zero = false; v->lor_state = 0; v->abs_bound = -1;
+  vec_overwritten(v); v->holes_zero = false; v->lor_state = 0; v->abs_bound = -1; v->dev_elem_ops = 0;
   v->host_valid = false; v->hi.clear(); v->hx.clear(); v->pending.clear(); v->hi.shrink_to_fit(); v->hx.shrink_to_fit();
 }
 void vec_to_host(GrB_Vector v) {
@@ -526,6 +526,17 @@ static GrB_Info vec_get(void* x, int xcode, GrB_Vector v, GrB_Index i) {
   GrB_Info r = GrB_SUCCESS;
   GrB_Info info = guarded(v, [&] {
     if (v->iso_full) { cast_scalar(xcode, x, v->type->code, v->iso_val); return; }
+    vec_gate(v);
+    // a large vector that lives in HBM only (`r[vertex]` after a PageRank): the presence byte and the value come over alone — a few
+    // dozen reads in a row, then the host mirror takes over (one transfer, no more round trips)
+    if (device_ok() && v->dev_valid && !v->host_valid && v->pending.empty() && v->n >= (1u << 16) && v->type->code < T_FC32 && v->dev_elem_ops++ < 32) {
+      uint8_t* pin = (uint8_t*)pinned_scratch() + 64; const size_t ts = v->type->size;
+      GRB_HIP(hipMemcpyAsync(pin, v->dpres.as<uint8_t>() + i, 1, hipMemcpyDeviceToHost, stream()));
+      GRB_HIP(hipMemcpyAsync(pin + 16, (const uint8_t*)v->dval.p + i * ts, ts, hipMemcpyDeviceToHost, stream()));
+      GRB_HIP(hipStreamSynchronize(stream()));
+      if (!pin[0]) r = GrB_NO_VALUE; else cast_scalar(xcode, x, v->type->code, pin + 16);
+      return;
+    }
     vec_to_host(v);
     auto it = std::lower_bound(v->hi.begin(), v->hi.end(), i);
     if (it == v->hi.end() || *it != i) r = GrB_NO_VALUE;

@@ -168,6 +168,7 @@ struct GrB_Vector_opaque {
   // an upper bound of |value| over the stored entries, left behind by the "big holes" product that wrote them (grb_mxv.cpp: the next
   // sweep of a shortest-path loop needs no range kernel and no read-back); < 0 = unknown.  Reset wherever lor_state is.
   double abs_bound = -1;
+  uint32_t dev_elem_ops = 0;   // element reads served on the device in a row (grb_container.cpp: after a few dozen the host mirror takes over)
   int sparsity_control = 15;
   std::string err;
 };

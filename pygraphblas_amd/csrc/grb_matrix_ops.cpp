@@ -206,7 +206,9 @@ void do_reduce_vector(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Mon
     mat_to_device(A);
     if (!A->csc.valid && A->csr.nnz >= (1u << 20)) {
       const void* av = cast_values(mc, A->type->code, A->csr.val.p, A->csr.nnz, ac);
-      done = csr_reduce_cols(mc, A->csr, av, monoid->op->opcode, monoid->identity, tval.p, tpres.as<uint8_t>());
+      uint8_t id[16]; memcpy(id, monoid->identity, 16);
+      fp_minmax_identity(mc, monoid->op->opcode, id);          // FP MIN / MAX start from NaN = from the column's first value (the one NaN rule, grb_opcommon.hpp)
+      done = csr_reduce_cols(mc, A->csr, av, monoid->op->opcode, id, tval.p, tpres.as<uint8_t>());
     }
   }
   if (!done) {

@@ -300,8 +300,14 @@ def test_column_reduce_and_element_access_of_a_large_device_matrix(gpu):
     P[3, 0] = 7.5
     assert P[2, 12345] == 1 and P[3, 0] == 7.5 and P[0, 5] == 0 and P.nvals == ns * n
     r = gb.Vector.sparse(gb.FP32, n); P.reduce_vector(gb.FP32.PLUS_MONOID, out=r, desc=D.T0)
+    assert r[12345] == 1 and r[0] == 7.5 and r[7] == 0                      # single elements of a vector that lives in HBM only
+    for k in range(40):                                                          # ... more than a few dozen in a row: the host mirror takes over
+        assert r[k + 1] == 0
     ri, rx = r.to_arrays()
     assert rx[12345] == 1 and rx[0] == 7.5 and rx.sum() == 8.5
+    sv = gb.Vector.from_arrays(np.array([3, 70000], np.uint64), np.array([1.5, 2.5], np.float32), n, gb.FP32)
+    sv2 = sv.apply(gb.FP32.AINV)                                                 # a device-only result with two entries
+    assert sv2[70000] == -2.5 and sv2.get(5) is None and sv2.nvals == 2
     S = gb.Matrix.from_arrays(I, J, np.ones(len(key), np.float32), ns, n, gb.FP32)
     S2 = S.apply(gb.FP32.AINV)                                  # a device-only result
     i0, j0 = int(I[1000]), int(J[1000])
