@@ -62,8 +62,14 @@ __device__ __forceinline__ spg_u4 spg_ld4(const uint32_t* __restrict__ p, uint32
   if constexpr (SPG_EXP == 1) { spg_u4 r; r.x = (i * 2654435761u) >> 10; r.y = ((i + 1) * 2654435761u) >> 10; r.z = ((i + 2) * 2654435761u) >> 10; r.w = ((i + 3) * 2654435761u) >> 10; return r; }
   else return *(const spg_u4*)(p + i);
 }
-constexpr int SPG_LIST = 512;       // k's staged per round (per team)
-constexpr uint32_t SPG_HUGE = 2048; // B rows at least this long are shared by the whole team
+#ifndef SPG_LIST_V
+#define SPG_LIST_V 512
+#endif
+#ifndef SPG_HUGE_V
+#define SPG_HUGE_V 2048
+#endif
+constexpr int SPG_LIST = SPG_LIST_V;       // k's staged per round (per team)           (measurement builds: -DSPG_LIST_V=..., -DSPG_HUGE_V=...)
+constexpr uint32_t SPG_HUGE = SPG_HUGE_V;  // B rows at least this long are shared by the whole team
 constexpr int SPG_QCAP = 128;       // survivor queue of a wave (flushed 64 at a time)
 constexpr uint32_t SPG_FILTER_MUL = 0x9E3779u;   // 24-bit multiplier: v_mul_u32_u24 runs at full rate, v_mul_lo_u32 at a quarter
 // Round 3, second half.  The measurement builds (SPG_EXP) showed what the kernel's time is: without any B-row load it still took
