@@ -66,10 +66,10 @@ __device__ __forceinline__ spg_u4 spg_ld4(const uint32_t* __restrict__ p, uint32
 #define SPG_LIST_V 512
 #endif
 #ifndef SPG_HUGE_V
-#define SPG_HUGE_V 2048
+#define SPG_HUGE_V 8192
 #endif
 constexpr int SPG_LIST = SPG_LIST_V;       // k's staged per round (per team)           (measurement builds: -DSPG_LIST_V=..., -DSPG_HUGE_V=...)
-constexpr uint32_t SPG_HUGE = SPG_HUGE_V;  // B rows at least this long are shared by the whole team
+constexpr uint32_t SPG_HUGE = SPG_HUGE_V;  // B rows at least this long are shared by the whole team (R-MAT-22 triangle count: 1024 -> 51.4 ms, 2048 -> 48.4, 4096 -> 46.1, 8192 -> 45.4, 32768 -> 45.9; lists of 256 / 1024 entries: 49.1 / 52.8 against 48.4 for 512)
 constexpr int SPG_QCAP = 128;       // survivor queue of a wave (flushed 64 at a time)
 constexpr uint32_t SPG_FILTER_MUL = 0x9E3779u;   // 24-bit multiplier: v_mul_u32_u24 runs at full rate, v_mul_lo_u32 at a quarter
 // Round 3, second half.  The measurement builds (SPG_EXP) showed what the kernel's time is: without any B-row load it still took
