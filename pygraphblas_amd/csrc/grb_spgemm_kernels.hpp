@@ -62,6 +62,21 @@ __device__ __forceinline__ spg_u4 spg_ld4(const uint32_t* __restrict__ p, uint32
   if constexpr (SPG_EXP == 1) { spg_u4 r; r.x = (i * 2654435761u) >> 10; r.y = ((i + 1) * 2654435761u) >> 10; r.z = ((i + 2) * 2654435761u) >> 10; r.w = ((i + 3) * 2654435761u) >> 10; return r; }
   else return *(const spg_u4*)(p + i);
 }
+#ifndef SPG_FBITS_V
+#define SPG_FBITS_V 32
+#endif
+#ifndef SPG_FBITS_SMALL_V
+#define SPG_FBITS_SMALL_V 0
+#endif
+#ifndef SPG_LONG_V
+#define SPG_LONG_V 64
+#endif
+#ifndef SPG_SLICE_V
+#define SPG_SLICE_V 2048
+#endif
+#ifndef SPG_HUBHUGE_V
+#define SPG_HUBHUGE_V 32768
+#endif
 #ifndef SPG_LIST_V
 #define SPG_LIST_V 512
 #endif
@@ -77,7 +92,7 @@ constexpr uint32_t SPG_FILTER_MUL = 0x9E3779u;   // 24-bit multiplier: v_mul_u32
 // VALU: eight waves per SIMD keep it 80 % busy (SQ_ACTIVE_INST_VALU = 10 % of wave cycles x 8), because a probe is a
 // quarter-rate integer multiply plus a linear-probing loop that the whole wave repeats until its unluckiest lane is done
 // (~2.75 rounds of 5 VALU + 5 SALU instructions at load 1/4), and 96 % of the products are misses that only had to learn "no".
-// Now a product first asks a BIT FILTER of the mask row (16 bits per table slot, one 24-bit multiply, one LDS read, no loop);
+// Now a product first asks a BIT FILTER of the mask row (32 bits per table slot, one 24-bit multiply, one LDS read, no loop);
 // the few lanes that pass (the 3.7 % hits + ~1-3 % false positives) append their column to the wave's queue in LDS (ballot +
 // mbcnt), and whenever the queue holds 64 columns the wave looks all of them up in the exact table with every lane busy.
 // When the multiply reads no value (PLUS_PAIR: the triangle count) the queue is carried from B row to B row; otherwise it is
@@ -92,7 +107,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
   // large ones, where the LDS goes to the filter and the queues instead — only survivors of the filter walk its chains now);
   // the accumulators are indexed by the mask position the slot carries and take only SLOTS / 2 words
   constexpr int KS = SLOTS <= 512 ? 2 * SLOTS : SLOTS, ML = SLOTS / 2;
-  constexpr int FBITS = 16 * SLOTS, FW = FBITS / 32;    // the filter: >= 32 bits per mask entry
+  constexpr int FBITS = (SPG_FBITS_SMALL_V && SLOTS <= 512 ? SPG_FBITS_SMALL_V : SPG_FBITS_V) * SLOTS, FW = FBITS / 32;    // the filter: >= 64 bits per mask entry (R-MAT-22 triangle count: 8 x SLOTS bits 47.2 ms, 16 x 45.0, 32 x 44.2; 64 / 128 x in the two small bins only: 44.9 / 45.8)
   constexpr int FSH = 32 - __builtin_ctz(FBITS);
   constexpr int WAVES = BLOCK / 64;
   __shared__ uint32_t s_key[TEAMS][KS];
@@ -213,7 +228,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
           const uint32_t hs = atomicAdd(&cnt[2], 1u);
           if (hs < (uint32_t)HCAP) { s_hpa[team][hs] = pa; s_hbb[team][hs] = bb; s_hbe[team][hs] = be; continue; }
         }
-        const bool lng = be - bb >= 64;
+        const bool lng = be - bb >= SPG_LONG_V;
         const uint32_t slot = lng ? (LCAP - 1 - atomicAdd(&cnt[1], 1u)) : atomicAdd(&cnt[0], 1u);
         lpa[slot] = pa; lbb[slot] = bb; lbe[slot] = be;
       }
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
 // comes out of the filter: 2^18 bits instead of 2^20 (a 30 000-entry mask row lets ~11 % of the misses through to the map).
 constexpr uint32_t SPG_FILTER_WORDS = 8192;         // 2^18 bits = 32 KiB of LDS
 constexpr uint32_t SPG_MAP_LDS_BYTES = 96 * 1024;   // accumulators of the first positions of the mask row
-constexpr uint32_t SPG_MAP_SLICE = 1024;            // entries of A(i,:) per task
+constexpr uint32_t SPG_MAP_SLICE = SPG_SLICE_V;            // entries of A(i,:) per task (1024: 44.2 ms, 2048: 43.4, 4096: 43.4, 8192: 43.1 for the R-MAT-22 triangle count)
 template <class T, class SR, bool CNT32>
 __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T> a, const uint32_t* __restrict__ rows, uint32_t nrows_bin, uint32_t nslices,
                                                             uint32_t* __restrict__ maps, uint32_t ncols, const SR sr) {
@@ -451,7 +466,7 @@ __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T>
     for (uint32_t pa = ab + (t >> 6); pa < ae; pa += 16) {
       const uint32_t k = a.acol[pa];
       const uint32_t bb = a.brp[k], be = a.brp[k + 1];
-      if (be - bb >= 4 * SPG_HUGE) {
+      if (be - bb >= SPG_HUBHUGE_V) {
         uint32_t slot = HL;
         if ((t & 63) == 0) slot = atomicAdd(&s_nh, 1u);
         slot = (uint32_t)__shfl((int)slot, 0, 64);
