@@ -68,6 +68,9 @@ __device__ __forceinline__ spg_u4 spg_ld4(const uint32_t* __restrict__ p, uint32
 #ifndef SPG_FBITS_SMALL_V
 #define SPG_FBITS_SMALL_V 0
 #endif
+#ifndef SPG_LIST_BIG_V
+#define SPG_LIST_BIG_V 1024
+#endif
 #ifndef SPG_LONG_V
 #define SPG_LONG_V 64
 #endif
@@ -101,7 +104,7 @@ template <class T, class SR, int SLOTS, int TEAM, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T> a, const uint32_t* __restrict__ rows, uint32_t nrows_bin, const SR sr) {
   typedef typename acc_word<T>::type W;
   constexpr int TEAMS = BLOCK / TEAM;
-  constexpr int LCAP = TEAM >= 256 ? SPG_LIST : 64;
+  constexpr int LCAP = TEAM >= 1024 ? SPG_LIST_BIG_V : (TEAM >= 256 ? SPG_LIST : 64);
   constexpr bool NOVAL = SR::pair_only;                 // the product is a constant: a queued survivor is its column alone
   // the exact table: open addressing, at most SLOTS / 2 mask entries in KS keys (load <= 1/4 in the two small bins, <= 1/2 in the
   // large ones, where the LDS goes to the filter and the queues instead — only survivors of the filter walk its chains now);
