@@ -162,12 +162,15 @@ __global__ __launch_bounds__(1024) void k_spgemm_dense(const HashArgs a, const T
 // ---- rows beyond the LDS tables, when the column range is moderate: a dense accumulator IN LDS, one block of columns at a time ----
 // Round 3.  The HBM-resident dense accumulator above costs two global atomics per product (9.5e9 products of A@A on R-MAT-18:
 // 0.73 s numeric + 0.27 s symbolic of a 1.1 s call), and its rows leave in claim order, so the whole result goes through a
-// segmented sort.  Here a workgroup walks its row once per block of WD columns (8192 eight-byte / 16384 four-byte accumulators =
-// 64 KiB of LDS): where the blocks of every B row begin is computed once per call (k_spa_split: the rows are sorted by column),
+// segmented sort.  Here a workgroup walks its row once per block of WD columns (16 384 eight-byte / 32 768 four-byte accumulators =
+// 128 KiB of LDS): where the blocks of every B row begin is computed once per call (k_spa_split: the rows are sorted by column),
 // the products of a block are dealt to the lanes of a wave whatever the lengths of the row parts are, they combine with LDS atomics, and the block is emitted by scanning its bitmap — in column order, straight into the
 // result: no claim list, no sort, no gather for these rows.  The symbolic pass marks a bitmap of all ncols bits in LDS (<= 2^20
-// columns).  Taken when ncols <= 64 blocks (2^19 columns for 8-byte types, 2^20 for 4-byte ones); the HBM path remains for wider results.
-template <class T> struct spa_cfg { static constexpr uint32_t WD = sizeof(typename acc_word<T>::type) >= 8 ? 6144u : 12288u; };     // 48 KiB of accumulators
+// columns).  Taken when ncols <= 64 blocks and <= 2^20 columns; the HBM path remains for wider results.
+#ifndef SPA_WD8_V
+#define SPA_WD8_V 16384
+#endif
+template <class T> struct spa_cfg { static constexpr uint32_t WD = sizeof(typename acc_word<T>::type) >= 8 ? (uint32_t)SPA_WD8_V : 2u * (uint32_t)SPA_WD8_V; };     // 128 KiB of accumulators: one workgroup per CU, but fewer, longer (row, block) steps win — A@A R-MAT-18: 4096 columns 0.252 s, 6144 0.227, 8192 0.210, 12288 0.190, 16384 0.184 (measurement builds: -DSPA_WD8_V=...)
 constexpr uint32_t SPA_SYM_WORDS = 32768;      // 2^20 bits
 // The products of up to 1024 entries k of A(i,:) (one per thread: `len` entries of B starting at `st`), dealt evenly to the 16
 // waves of the workgroup whatever the lengths are — most are empty or a single entry, a hub's is tens of thousands: an exclusive
