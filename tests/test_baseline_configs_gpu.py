@@ -77,6 +77,31 @@ def test_config1_rmat22_fp64_spmv(gb, torch_dev):
     assert np.array_equal(gy2[pres != 0], gy[pres != 0])
 
 
+@pytest.mark.parametrize("typ", ["INT64", "FP32", "INT32"])
+def test_rmat22_plus_times_spmv_other_types_exact(gb, torch_dev, typ):
+    """configs[1]'s product in the non-headline types, at the stated size.  Small integer values keep every row sum exactly
+    representable (hub rows: 10^5 terms of at most 21 < 2^24), so the panel pipeline's INT64 / INT32 / FP32 instantiations must
+    reproduce the oracle's FP64 sums of the same integers bit for bit, whatever order they add in."""
+    torch, dev = torch_dev
+    from pygraphblas_amd import rmat
+    n = 1 << SCALE
+    rowptr, col = rmat.csr_torch(SCALE, dev, seed=42)
+    nnz = int(col.numel())
+    tt = {"INT64": torch.int64, "FP32": torch.float32, "INT32": torch.int32}[typ]
+    vals_i = (rmat.values_torch(nnz, dev, seed=43) * 7).to(torch.int64) + 1           # 1 .. 7
+    xs_i = (rmat.values_torch(n, dev, seed=44) * 4).to(torch.int64)                   # 0 .. 3
+    vals, xs = vals_i.to(tt), xs_i.to(tt)
+    T = getattr(gb, typ)
+    A = gb.Matrix.from_csr(T, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+    x = gb.Vector.from_dense_array((xs.data_ptr(), n), T, device=True)
+    w = A.mxv(x, semiring=T.PLUS_TIMES)
+    assert "k_spmv_xcd" in gb.last_kernel_plan()
+    gy, gp = w.to_dense_arrays()
+    y, pres = O.fast_spmv(rowptr.cpu().numpy().view(np.uint32), col.cpu().numpy().view(np.uint32), vals_i.cpu().numpy().astype(np.float64), xs_i.cpu().numpy().astype(np.float64))
+    assert np.array_equal(gp != 0, pres != 0)
+    assert np.array_equal(np.asarray(gy, np.float64)[pres != 0], y[pres != 0])
+
+
 # ---- configs[2] ---------------------------------------------------------------------------------------------------------
 def _bfs(gb, A, start):
     from pygraphblas_amd import descriptor as D
