@@ -148,6 +148,39 @@ def test_config3_rmat22_triangle_count(gb, torch_dev):
     assert tri > 10**9
 
 
+def test_config3_rmat22_masked_products_that_read_values(gb, torch_dev):
+    """The masked product of configs[3] with multiplies that read the operands (the survivor queues then carry positions and are
+    flushed per B row): per entry, L*L under PLUS_TIMES with every value 2 is four times the count PLUS_PAIR gives, with FP64
+    values 0.5 a quarter of it (exact), and PLUS_FIRST / PLUS_SECOND with values 3 three times it — at the stated size, where
+    every bin and the hub-row kernel are populated."""
+    torch, dev = torch_dev
+    from pygraphblas_amd import rmat
+    n = 1 << SCALE
+    rowptr, col = rmat.csr_torch(SCALE, dev, seed=42, symmetric=True, drop_self_loops=True, lower=True)
+    nnz = int(col.numel())
+    ones = torch.ones(nnz, dtype=torch.int64, device=dev)
+    L1 = gb.Matrix.from_csr(gb.INT64, n, n, rowptr.data_ptr(), col.data_ptr(), (ones.data_ptr(), nnz), device=True)
+    C = L1.mxm(L1, semiring=gb.INT64.PLUS_PAIR, mask=L1)
+    ci, cj, cx = C.to_arrays()
+    twos = ones * 2
+    L2 = gb.Matrix.from_csr(gb.INT64, n, n, rowptr.data_ptr(), col.data_ptr(), (twos.data_ptr(), nnz), device=True)
+    D2 = L2.mxm(L2, semiring=gb.INT64.PLUS_TIMES, mask=L2)
+    di, dj, dx = D2.to_arrays()
+    assert np.array_equal(ci, di) and np.array_equal(cj, dj) and np.array_equal(dx, 4 * cx)
+    del D2, L2, di, dj, dx
+    threes = ones * 3
+    L3 = gb.Matrix.from_csr(gb.INT64, n, n, rowptr.data_ptr(), col.data_ptr(), (threes.data_ptr(), nnz), device=True)
+    for sr in (gb.INT64.PLUS_FIRST, gb.INT64.PLUS_SECOND):
+        E = L3.mxm(L3, semiring=sr, mask=L3); ei, ej, ex = E.to_arrays()
+        assert np.array_equal(ci, ei) and np.array_equal(cj, ej) and np.array_equal(ex, 3 * cx)
+        del E
+    del L3
+    halves = torch.full((nnz,), 0.5, dtype=torch.float64, device=dev)
+    Lh = gb.Matrix.from_csr(gb.FP64, n, n, rowptr.data_ptr(), col.data_ptr(), (halves.data_ptr(), nnz), device=True)
+    F = Lh.mxm(Lh, semiring=gb.FP64.PLUS_TIMES, mask=Lh); fi, fj, fx = F.to_arrays()
+    assert np.array_equal(ci, fi) and np.array_equal(cj, fj) and np.array_equal(fx, 0.25 * cx.astype(np.float64))
+
+
 # ---- configs[4], single-GPU step ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mtype", ["FP32", "BOOL"])
 def test_config4_rmat22_pagerank_step_fp32(gb, torch_dev, mtype):
