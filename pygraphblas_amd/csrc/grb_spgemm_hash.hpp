@@ -4,8 +4,8 @@
 //
 //   symbolic  nnz(T(i,:)) for every row: the columns of the products of row i go into a hash set in LDS (keys only:
 //             up to 32768 slots = 128 KB); the set's size is bounded by the row's product count
-//             ub(i) = sum_{k in A(i,:)} nnz(B(k,:)), by which the rows are binned (<= 128 / 1024 / 16384 products: 256 /
-//             2048 / 32768 slots, a wave / 256 / 1024 threads per row).  Rows with more products count into a bitmap of
+//             ub(i) = sum_{k in A(i,:)} nnz(B(k,:)), by which the rows are binned (<= 128 / 1024 / 4096 / 16384 products: 256 /
+//             2048 / 8192 / 32768 slots, a wave / 256 / 512 / 1024 threads per row).  Rows with more products count into a bitmap of
 //             ncols bits in HBM (one per persistent workgroup; atomicOr returns which bits were new).
 //   scan      row pointers of T (one host round trip: the size of T).
 //   numeric   the rows are binned again, now by their exact entry count (<= 128 / 1024 / 4096 entries: 256 / 2048 / 8192
@@ -42,6 +42,28 @@ static __global__ void k_hash_bin(uint32_t nrows, const unsigned long long* __re
     int b = -1;
     if (r < nrows) { const unsigned long long w = w64 ? w64[r] : w32[r]; if (w) b = w <= l0 ? 0 : (w <= l1 ? 1 : (w <= l2 ? 2 : 3)); }
     for (int bb = 0; bb < 4; bb++) {
+      const unsigned long long m = __ballot(b == bb);
+      if (!m) continue;
+      const int leader = __builtin_ctzll(m);
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(&counts[bb], (uint32_t)__popcll(m));
+      base = __shfl(base, leader, 64);
+      if (b == bb) lists[(size_t)bb * nrows + base + __popcll(m & ((1ull << lane) - 1))] = (uint32_t)r;
+    }
+  }
+}
+
+// the symbolic pass bins by product count into FIVE classes (<= l0 / l1 / l2 / l3, the rest): rows of 1025 ... 4096 products get a
+// table of their own (8192 slots, 512 threads, five workgroups per CU) instead of sharing the 32 768-slot one, whose 128 KiB are
+// cleared and counted per row by a workgroup that is alone on its CU (30 of the 190 ms of A@A on R-MAT-18)
+static __global__ void k_hash_bin5(uint32_t nrows, const unsigned long long* __restrict__ w64, unsigned long long l0, unsigned long long l1, unsigned long long l2, unsigned long long l3,
+                                   uint32_t* __restrict__ counts, uint32_t* __restrict__ lists /* 5 x nrows */) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t nround = ((uint64_t)nrows + 63) / 64 * 64;
+  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nround; r += (uint64_t)gridDim.x * 256ull) {
+    int b = -1;
+    if (r < nrows) { const unsigned long long w = w64[r]; if (w) b = w <= l0 ? 0 : (w <= l1 ? 1 : (w <= l2 ? 2 : (w <= l3 ? 3 : 4))); }
+    for (int bb = 0; bb < 5; bb++) {
       const unsigned long long m = __ballot(b == bb);
       if (!m) continue;
       const int leader = __builtin_ctzll(m);
@@ -357,13 +379,13 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
   const int ncu = device_cus() > 0 ? device_cus() : 256;
   auto nblocks = [&](uint32_t rows, int teams) { uint64_t b = ((uint64_t)rows + teams - 1) / teams; if (b > (uint64_t)ncu * 32) b = (uint64_t)ncu * 32; if (b < 1) b = 1; return (unsigned)b; };
   // ---- product counts, symbolic bins -----------------------------------------------------------------------------------------
-  DevBuf ub((size_t)nrows * 8 + 8), rownnz(((size_t)nrows + 1) * 4), counts(64), lists((size_t)4 * nrows * 4 + 4);
+  DevBuf ub((size_t)nrows * 8 + 8), rownnz(((size_t)nrows + 1) * 4), counts(64), lists((size_t)5 * nrows * 4 + 4);
   row_upper_bound(A, B, ub.as<unsigned long long>());
   GRB_HIP(hipMemsetAsync(rownnz.p, 0, ((size_t)nrows + 1) * 4, stream()));
   GRB_HIP(hipMemsetAsync(counts.p, 0, 64, stream()));
-  hipLaunchKernelGGL(k_hash_bin, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, ub.as<unsigned long long>(), (const uint32_t*)nullptr, 128ull, 1024ull, 16384ull, counts.as<uint32_t>(), lists.as<uint32_t>());
-  uint32_t hs[4];
-  GRB_HIP(hipMemcpyAsync(hs, counts.p, 16, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+  hipLaunchKernelGGL(k_hash_bin5, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, ub.as<unsigned long long>(), 128ull, 1024ull, 4096ull, 16384ull, counts.as<uint32_t>(), lists.as<uint32_t>());
+  uint32_t hs[5];
+  GRB_HIP(hipMemcpyAsync(hs, counts.p, 20, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
   const uint32_t words = (ncols + 31) / 32;
   // persistent workgroups of the dense paths: bounded by memory (bitmaps: ncols/8 bytes each; accumulators: ncols words each, <= 4 GiB in all)
   auto dense_blocks = [&](uint32_t rows, size_t per_block) { uint64_t fit = (4ull << 30) / (per_block ? per_block : 1); if (fit < 1) fit = 1; return (unsigned)std::min<uint64_t>(std::min<uint64_t>(rows, (uint64_t)ncu * 2), fit); };
@@ -377,12 +399,13 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
     const uint32_t* L = lists.as<uint32_t>();
     {
       DevBuf bm;
-      if (hs[3] && spa) { a.rows = L + (size_t)3 * nrows; a.nrows_bin = hs[3];
-                          hipLaunchKernelGGL((k_spgemm_spa_symbolic<T, SR>), dim3(std::min<unsigned>(hs[3], (unsigned)ncu)), dim3(1024), 0, stream(), a, ncols); }
-      else if (hs[3]) { const unsigned nb = dense_blocks(hs[3], (size_t)words * 4); bm.alloc((size_t)nb * words * 4); GRB_HIP(hipMemsetAsync(bm.p, 0, (size_t)nb * words * 4, stream()));
-                   a.rows = L + (size_t)3 * nrows; a.nrows_bin = hs[3];
+      if (hs[4] && spa) { a.rows = L + (size_t)4 * nrows; a.nrows_bin = hs[4];
+                          hipLaunchKernelGGL((k_spgemm_spa_symbolic<T, SR>), dim3(std::min<unsigned>(hs[4], (unsigned)ncu)), dim3(1024), 0, stream(), a, ncols); }
+      else if (hs[4]) { const unsigned nb = dense_blocks(hs[4], (size_t)words * 4); bm.alloc((size_t)nb * words * 4); GRB_HIP(hipMemsetAsync(bm.p, 0, (size_t)nb * words * 4, stream()));
+                   a.rows = L + (size_t)4 * nrows; a.nrows_bin = hs[4];
                    hipLaunchKernelGGL((k_spgemm_dense<T, SR, false>), dim3(nb), dim3(1024), 0, stream(), a, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, ncols, bm.as<uint32_t>(), (W*)nullptr, sr); }
-      if (hs[2]) { a.rows = L + (size_t)2 * nrows; a.nrows_bin = hs[2]; hipLaunchKernelGGL((k_spgemm_hash<T, SR, 32768, 1024, 1024, false>), dim3(nblocks(hs[2], 1)), dim3(1024), 0, stream(), a, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, sr); }
+      if (hs[3]) { a.rows = L + (size_t)3 * nrows; a.nrows_bin = hs[3]; hipLaunchKernelGGL((k_spgemm_hash<T, SR, 32768, 1024, 1024, false>), dim3(nblocks(hs[3], 1)), dim3(1024), 0, stream(), a, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, sr); }
+      if (hs[2]) { a.rows = L + (size_t)2 * nrows; a.nrows_bin = hs[2]; hipLaunchKernelGGL((k_spgemm_hash<T, SR, 8192, 512, 512, false>), dim3(nblocks(hs[2], 1)), dim3(512), 0, stream(), a, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, sr); }
       if (hs[1]) { a.rows = L + (size_t)1 * nrows; a.nrows_bin = hs[1]; hipLaunchKernelGGL((k_spgemm_hash<T, SR, 2048, 256, 256, false>), dim3(nblocks(hs[1], 1)), dim3(256), 0, stream(), a, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, sr); }
       if (hs[0]) { a.rows = L; a.nrows_bin = hs[0]; hipLaunchKernelGGL((k_spgemm_hash<T, SR, 256, 64, 256, false>), dim3(nblocks(hs[0], 4)), dim3(256), 0, stream(), a, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, sr); }
       GRB_HIP(hipGetLastError());
@@ -463,7 +486,7 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
       }
     }
     g_last_plan += std::string("spgemm_hash<") + (sr.is_static ? "static" : "dynamic") + "> symbolic bins " + std::to_string(hs[0]) + "/" + std::to_string(hs[1]) + "/" + std::to_string(hs[2]) + "/" +
-                   std::to_string(hs[3]) + " numeric bins " + std::to_string(hn[0]) + "/" + std::to_string(hn[1]) + "/" + std::to_string(hn[2]) + "/" + std::to_string(hn[3]) + " ";
+                   std::to_string(hs[3]) + "/" + std::to_string(hs[4]) + " numeric bins " + std::to_string(hn[0]) + "/" + std::to_string(hn[1]) + "/" + std::to_string(hn[2]) + "/" + std::to_string(hn[3]) + " ";
   });
   out.valid = true;
 }
