@@ -383,16 +383,17 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
   row_upper_bound(A, B, ub.as<unsigned long long>());
   GRB_HIP(hipMemsetAsync(rownnz.p, 0, ((size_t)nrows + 1) * 4, stream()));
   GRB_HIP(hipMemsetAsync(counts.p, 0, 64, stream()));
-  hipLaunchKernelGGL(k_hash_bin5, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, ub.as<unsigned long long>(), 128ull, 1024ull, 4096ull, 16384ull, counts.as<uint32_t>(), lists.as<uint32_t>());
+  // the LDS dense-accumulator path for the rows beyond the tables (k_spgemm_spa_*): a moderate column range only
+  const bool no_spa = getenv("GRB_MI355X_SPGEMM_NO_SPA") != nullptr;             // measurement / test hook: the HBM accumulators of round 2
+  const bool spa = !no_spa && (uint64_t)ncols <= 64ull * spa_cfg<T>::WD && (uint64_t)ncols <= 32ull * SPA_SYM_WORDS;
+  // (with the LDS bitmap at hand it also counts the rows of 4097 ... 16 384 products: marking bits beats clearing and counting a 32 768-slot table per row)
+  hipLaunchKernelGGL(k_hash_bin5, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, ub.as<unsigned long long>(), 128ull, 1024ull, 4096ull, spa ? 4096ull : 16384ull, counts.as<uint32_t>(), lists.as<uint32_t>());
   uint32_t hs[5];
   GRB_HIP(hipMemcpyAsync(hs, counts.p, 20, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
   const uint32_t words = (ncols + 31) / 32;
   // persistent workgroups of the dense paths: bounded by memory (bitmaps: ncols/8 bytes each; accumulators: ncols words each, <= 4 GiB in all)
   auto dense_blocks = [&](uint32_t rows, size_t per_block) { uint64_t fit = (4ull << 30) / (per_block ? per_block : 1); if (fit < 1) fit = 1; return (unsigned)std::min<uint64_t>(std::min<uint64_t>(rows, (uint64_t)ncu * 2), fit); };
   uint32_t hn[4] = {0, 0, 0, 0};
-  // the LDS dense-accumulator path for the rows beyond the tables (k_spgemm_spa_*): a moderate column range only
-  const bool no_spa = getenv("GRB_MI355X_SPGEMM_NO_SPA") != nullptr;             // measurement / test hook: the HBM accumulators of round 2
-  const bool spa = !no_spa && (uint64_t)ncols <= 64ull * spa_cfg<T>::WD && (uint64_t)ncols <= 32ull * SPA_SYM_WORDS;
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;
     HashArgs a{A.rowptr.as<uint32_t>(), A.col.as<uint32_t>(), B.rowptr.as<uint32_t>(), B.col.as<uint32_t>(), nullptr, 0, rownnz.as<uint32_t>(), nullptr, nullptr};

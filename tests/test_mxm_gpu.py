@@ -237,7 +237,9 @@ def test_two_pass_hash_spgemm_every_bin_against_expand_sort_compress(gpu, typ, s
         assert "spgemm_hash" in plan
         sym = [int(x) for x in plan.split("symbolic bins ")[1].split()[0].split("/")]
         num = [int(x) for x in plan.split("numeric bins ")[1].split()[0].split("/")]
-        assert all(x > 0 for x in sym) and all(x > 0 for x in num), plan
+        # (with the LDS dense path its bitmap also counts the rows of 4097 ... 16 384 products: the 32 768-slot table stays empty)
+        assert all(x > 0 for k, x in enumerate(sym) if no_spa or k != 3) and all(x > 0 for x in num), plan
+        assert (sym[3] > 0) == no_spa, plan
         hi_, hj, hx = H.to_arrays()
         assert np.array_equal(ei, hi_) and np.array_equal(ej, hj), (plan, no_spa)
         if typ.startswith("FP"):
