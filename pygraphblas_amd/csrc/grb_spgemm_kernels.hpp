@@ -582,7 +582,6 @@ template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDes
   out.clear(); out.nrows = nrows; out.ncols = B.ncols;
   out.rowptr.alloc(((size_t)nrows + 1) * 4);
   if (!mnz || !A.nnz || !B.nnz) { GRB_HIP(hipMemsetAsync(out.rowptr.p, 0, ((size_t)nrows + 1) * 4, stream())); out.nnz = 0; out.valid = true; return; }
-  auto grid_rows = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 65535u * 16) b = 65535u * 16; return (unsigned)b; };
   DevBuf cacc(mnz * sizeof(W)), cflag(mnz), counts(32), lists((size_t)5 * nrows * 4 + 4);
   GRB_HIP(hipMemsetAsync(cflag.p, 0, mnz, stream()));
   GRB_HIP(hipMemsetAsync(counts.p, 0, 32, stream()));
