@@ -133,6 +133,9 @@ def main():
             print(f"bench.py[{rank}]: RCCL data path unavailable ({why or 'another rank failed'}); falling back to host transport", file=sys.stderr)
             comm = gdist.Comm(rank, world, transport="host", share=share, tdist=tdist)
             transport_note = "host copies over gloo (RCCL set-up failed on some rank; NOT the designed data path: read this line as UNMEASURED)"
+        elif gdist.bound_transport().endswith("libfake_rccl.so"):
+            transport_note = ("rccl-abi (fake, hipIpc): the library's exchange path (grouped ncclSend/ncclRecv, second stream, ncclAllReduce) between ranks that "
+                              "SHARE ONE GPU, through tests/libfake_rccl.so — a test stand-in, host-synchronous, no xGMI: NOT a scaling number")
     else:
         comm = gdist.Comm(rank, world, transport=transport, share=share, tdist=tdist if world > 1 else None)
         if world > 1 and transport == "host":

@@ -43,8 +43,14 @@ struct Rccl {
 void rccl_bind() {
   if (R.h) return;
   const char* env = getenv("GRB_MI355X_RCCL");
-  const char* names[] = {env ? env : "librccl.so", "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
+  if (env && *env) {
+    // an explicit library (tests/libfake_rccl.so: two ranks on one GPU) is bound as named — never replaced by the copy of librccl a
+    // process that hosts PyTorch already carries.  dlsym on ITS handle finds its own definitions first.
+    h = dlopen(env, RTLD_LAZY | RTLD_LOCAL);
+    if (!h) fail(GrB_PANIC, std::string("GRB_MI355X_RCCL: cannot load ") + env + ": " + dlerror());
+  }
   for (int pass = 0; pass < 2 && !h; pass++)                 // first whatever copy the process already holds, then a fresh load
     for (const char* nm : names) { h = dlopen(nm, RTLD_LAZY | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0)); if (h) break; }
   if (!h) fail(GrB_PANIC, std::string("RCCL not found: ") + dlerror());
@@ -138,6 +144,15 @@ GrB_Info GrBX_dist_finalize(void) {
 }
 
 GrB_Info GrBX_dist_info(int* rank, int* world) { if (rank) *rank = g_rank; if (world) *world = g_world; return GrB_SUCCESS; }
+
+// which RCCL-ABI library carries the exchange: the file that defines the bound ncclSend ("" while nothing is bound yet)
+GrB_Info GrBX_dist_transport(char* buf, int len) {
+  if (!buf || len <= 0) return GrB_NULL_POINTER;
+  buf[0] = 0;
+  Dl_info di;
+  if (R.h && R.Send && dladdr((void*)R.Send, &di) && di.dli_fname) snprintf(buf, (size_t)len, "%s", di.dli_fname);
+  return GrB_SUCCESS;
+}
 
 // full[bounds[p], bounds[p+1]) <- rank p's `local` (length bounds[p+1]-bounds[p]) for every p.  `local` may be NULL when the
 // caller wrote its slice through the device view of `full` already.  presence != 0: the presence bytes travel too (operands

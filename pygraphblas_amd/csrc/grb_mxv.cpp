@@ -206,9 +206,12 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   if (big_holes) big_to_absent(sd.zcode, mr, tval.p, tpres.as<uint8_t>(), big_thresh, sd.addop == B_MIN);       // sums made of fill values only are no entries
   const bool w_is_u = w == u; const bool w_was_empty = !w_is_u && w->lazy == 0 && w->dnvals_known && w->dnvals == 0 && !w->host_valid;
   vector_write_back(w, sd.zcode, tval, tpres, allow, accum, dv.replace, /*t_only_allowed=*/true);
-  // every sum that survived the threshold is within |u| + |A|: the bound of the result when w held nothing else (w is u itself, with
-  // the accumulator of the loop `v<accum MIN> = v MIN_PLUS A`, or w was empty / is replaced as a whole)
-  if (big_holes && w->type->code == sd.zcode && (w_is_u || !accum || w_was_empty)) w->abs_bound = big_uabs + big_aabs;
+  // every sum that survived the threshold is within |u| + |A|: the bound of the result when w held nothing else (w was empty / is
+  // replaced as a whole), or when w is u itself and the accumulator SELECTS one of its arguments (`v<accum MIN> = v MIN_PLUS A`: MIN,
+  // MAX, FIRST, SECOND, ANY).  An arithmetic accumulator (PLUS, TIMES ...) can leave |w| beyond it: then no bound is recorded and the
+  // next sweep measures the range again.
+  const bool accum_selects = accum && check_obj(accum) && (accum->opcode == B_MIN || accum->opcode == B_MAX || accum->opcode == B_FIRST || accum->opcode == B_SECOND || accum->opcode == B_ANY);
+  if (big_holes && w->type->code == sd.zcode && (!accum || w_was_empty || (w_is_u && accum_selects))) w->abs_bound = big_uabs + big_aabs;
   if (any_done) any_true_written(w->lazy == 0 && w->dev_valid && w->dval.p == tkey ? w : nullptr, tkey, call.any_true_tag);       // (adopted as they are: w is exactly T)
 }
 

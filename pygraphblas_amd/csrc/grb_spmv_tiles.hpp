@@ -160,7 +160,9 @@ template <class T> struct XtPanel {
   const T* aval;             // their values (nullptr when the plan was built for multipliers that ignore them)
   const uint32_t* trow;      // 32-bit format: [ntiles] sub-row (numbered over all panels) of every tile's first entry
   const T* xhot;             // the LDS table's contents for this call, T[nhot] (k_xp_hot_gather)
-  uint32_t nnz, ntiles, tiles_per_chunk, nhot, static_pct, pad;
+  uint32_t nnz, ntiles, tiles_per_chunk, nhot, static_pct;
+  uint32_t interleave;       // 1: a wave's static chunks are strided over the stream (chunk i of wave w = w + i * waves) instead of one contiguous range —
+                             //    with sub-panels (XcdPlan::S > 1) all waves of the XCD must be in the same part of the stream at the same time
   // 16-bit format: bit 15 of a word = first entry of a sub-row; the low 15 bits are the slot in the LDS table, or H + (column >> 16)
   // for a column the table does not hold — whose low 16 bits are the next halfword of `extras`, the cold entries of all tiles in
   // entry order.  tinfo[2t] = sub-row of tile t's first entry, tinfo[2t + 1] = index in `extras` of its first cold entry.
@@ -215,9 +217,11 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
   const uint32_t nwg = gridDim.x >> 3, jwg = blockIdx.x >> 3;
   uint32_t s0 = (uint32_t)((uint64_t)nchunks * a.static_pct / 100 / (nwg * XT_WAVES_)); if (s0 > WP_MAX_STATIC) s0 = WP_MAX_STATIC;
   const uint32_t dyn0 = s0 * nwg * XT_WAVES_;
-  uint32_t st_next = ((uint32_t)__builtin_amdgcn_readfirstlane(wv) * nwg + jwg) * s0; const uint32_t st_end = st_next + s0;
+  const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane(wv) * nwg + jwg;
+  const uint32_t st_step = a.interleave ? nwg * XT_WAVES_ : 1u;
+  uint32_t st_next = a.interleave ? wid : wid * s0, st_left = s0;
   auto next_chunk = [&]() __attribute__((always_inline)) -> uint32_t {
-    if (st_next < st_end) return st_next++;
+    if (st_left) { st_left--; const uint32_t c = st_next; st_next += st_step; return c; }
     uint32_t v = 0; if (lane == 0) v = atomicAdd(&s_next, 1u);
     return dyn0 + (uint32_t)__builtin_amdgcn_readfirstlane(v) * nwg + jwg;
   };

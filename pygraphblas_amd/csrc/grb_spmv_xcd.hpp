@@ -31,7 +31,8 @@
 
 namespace grb {
 
-constexpr int XP = 8;                 // panels = XCDs
+constexpr int XP = 8;                 // physical panels = XCDs: eight entry streams, one tile pipeline each
+constexpr int XPMAX = 64;             // virtual panels at most: XP x the sub-panels an XCD's share of the columns is cut into (round 4)
 constexpr uint32_t XP_RB = 1024;      // rows per workgroup of the merge kernel
 constexpr int XP_CT = 512;            // its threads
 constexpr uint32_t XP_UNIT = 16384;   // entries per unit of the plan-building sweeps
@@ -56,6 +57,14 @@ struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per 
   DevBuf xhot, partial;   // per-call work buffers kept with the plan (xhot: T[XP*H], the LDS tables' contents)
   uint64_t ne[XP]; uint32_t tbase[XP + 1]; uint32_t ntiles[XP], nhot[XP];
   uint64_t F = 0; int tsize = 0; bool has_vals = false; float build_ms = 0;
+  // round 4: S sub-panels per XCD (virtual panel vp = k * S + s lives in physical panel k).  When an XCD's eighth of the operand does not
+  // fit its 4 MiB L2 (R-MAT-25 FP32: 16.8 MB; every rank of a row-partitioned run), the lines of u are dealt to XP * S virtual panels and a
+  // physical panel's stream holds its S sub-panels one after the other, each in row-major order: the waves of an XCD walk the stream
+  // front to back together, so at any time their cold gathers touch ONE sub-panel's lines — which fit.  Only COLD entries are bound to a
+  // sub-panel; an entry served by the LDS table (one table per XCD, as before) rides in a sub-panel where its row already has a cold
+  // entry, so sub-rows multiply by ~1.3 at S = 4 instead of ~2 (tools/subpanel_model.py).  The tile pipeline knows nothing of this.
+  int S = 1, NP = XP;
+  DevBuf vfirst;          // u32[NP + 1] first sub-row of every virtual panel (sub-rows are numbered in stream order)
 };
 extern float g_xcd_plan_build_ms;     // duration of the most recent plan build (grb_spmv.hip; read by GrBX_last_plan_build_ms)
 
@@ -79,37 +88,51 @@ static __global__ void k_xp_line_weights(const uint32_t* __restrict__ cnt, uint3
 }
 // the heavy head of the weight distribution (<= 4096 lines, heaviest first) is balanced exactly: each line to the panel with
 // the least load so far (LPT).  One workgroup; the loop itself is serial.
-static __global__ __launch_bounds__(256) void k_xp_lpt(const uint32_t* __restrict__ negw_sorted, uint32_t ntop, uint8_t* __restrict__ top_panel) {
+// Deal slot j of the np = XP * S slots is virtual panel (j % XP) * S + j / XP: consecutive slots go to different XCDs.
+__device__ __forceinline__ uint32_t xp_vp_of_slot(uint32_t j, uint32_t S) { return (j & (XP - 1)) * S + (j >> 3); }
+static __global__ __launch_bounds__(256) void k_xp_lpt(const uint32_t* __restrict__ negw_sorted, uint32_t ntop, uint32_t np, uint32_t S, uint8_t* __restrict__ top_panel) {
   __shared__ uint32_t w[4096];
+  __shared__ unsigned long long sload[XPMAX];
   for (uint32_t i = threadIdx.x; i < ntop; i += 256) w[i] = 0xFFFFFFFFu - negw_sorted[i];
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned long long load[XP];
-    for (int k = 0; k < XP; k++) load[k] = 0;
-    for (uint32_t i = 0; i < ntop; i++) {
-      int best = 0;
+    if (np == (uint32_t)XP) {
+      unsigned long long load[XP];
+      for (int k = 0; k < XP; k++) load[k] = 0;
+      for (uint32_t i = 0; i < ntop; i++) {
+        int best = 0;
 #pragma unroll
-      for (int k = 1; k < XP; k++) if (load[k] < load[best]) best = k;
+        for (int k = 1; k < XP; k++) if (load[k] < load[best]) best = k;
 #pragma unroll
-      for (int k = 0; k < XP; k++) if (k == best) load[k] += w[i];
-      top_panel[i] = (uint8_t)best;
+        for (int k = 0; k < XP; k++) if (k == best) load[k] += w[i];
+        top_panel[i] = (uint8_t)best;
+      }
+    } else {
+      for (uint32_t k = 0; k < np; k++) sload[k] = 0;
+      for (uint32_t i = 0; i < ntop; i++) {
+        uint32_t best = 0; unsigned long long lb = sload[0];
+        for (uint32_t k = 1; k < np; k++) { const unsigned long long l = sload[k]; if (l < lb) { lb = l; best = k; } }
+        sload[best] = lb + w[i];
+        top_panel[i] = (uint8_t)xp_vp_of_slot(best, S);
+      }
     }
   }
 }
 // lines in descending weight: the first `ntop` take the panel the LPT chose for them, the others are dealt in snake order
-static __global__ void k_xp_deal_lines(const uint32_t* __restrict__ sorted_line, uint32_t nlines, const uint8_t* __restrict__ top_panel, uint32_t ntop, uint8_t* __restrict__ panel_of_line) {
+static __global__ void k_xp_deal_lines(const uint32_t* __restrict__ sorted_line, uint32_t nlines, const uint8_t* __restrict__ top_panel, uint32_t ntop, uint32_t np, uint32_t S,
+                                       uint8_t* __restrict__ panel_of_line) {
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nlines; i += gridDim.x * 256) {
     uint32_t k;
-    if (i < ntop) k = top_panel[i]; else { const uint32_t m = (i - ntop) % (2 * XP); k = m < XP ? m : 2 * XP - 1 - m; }
-    panel_of_line[sorted_line[i]] = (uint8_t)k;
+    if (i < ntop) k = top_panel[i]; else { const uint32_t m = (i - ntop) % (2 * np); k = xp_vp_of_slot(m < np ? m : 2 * np - 1 - m, S); }
+    panel_of_line[sorted_line[i]] = (uint8_t)k;       // the line's virtual panel
   }
 }
 // key = panel | descending count (clamped to 20 bits: ties among the rarest and among the very hottest columns do not matter),
 // stable sort => a panel's columns in frequency order, ties by index
-static __global__ void k_xp_column_keys(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t line, const uint8_t* __restrict__ panel_of_line, uint32_t* __restrict__ key, uint32_t* __restrict__ colv) {
+static __global__ void k_xp_column_keys(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t line, const uint8_t* __restrict__ panel_of_line, uint32_t S, uint32_t* __restrict__ key, uint32_t* __restrict__ colv) {
   for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) {
     const uint32_t w = cnt[c] < 0xFFFFFu ? cnt[c] : 0xFFFFFu;
-    key[c] = ((uint32_t)panel_of_line[c / line] << 20) | (0xFFFFFu - w);
+    key[c] = (((uint32_t)panel_of_line[c / line] / S) << 20) | (0xFFFFFu - w);       // the PHYSICAL panel: one LDS table per XCD
     colv[c] = c;
   }
 }
@@ -145,16 +168,41 @@ static __global__ void k_xp_mark_rows(const uint32_t* __restrict__ rowptr, uint3
 //                    (index + 1 in the high word, so that an exclusive max-scan finds the nearest earlier unit that has one)
 //   SCATTER = true : every entry goes to its place in its panel; bit 31 of the column word = first entry of a sub-row
 //                    (the row changes, or a chunk of tiles begins); the rows of those entries go to rowtmp.
+// Buckets of the sweeps = the np virtual panels.  With S > 1 sub-panels per XCD the bucket of a COLD entry is its column's (the line
+// deal), the bucket of an entry the LDS table serves is a sub-panel of its XCD in which its row has a cold entry (rowmask: bit vp of
+// word r = row r has a cold entry in virtual panel vp; lowest such sub-panel) — or, failing that, sub-panel r mod S.
 template <class T> struct XpSweep {
   const uint32_t* col; const uint32_t* rowidx; const uint32_t* code; const T* val; uint64_t nnz; uint32_t nunits;
+  uint32_t np, S, H, lshift; const uint8_t* pol; const unsigned long long* rowmask;
   uint32_t* ne; unsigned long long* lastkey;
-  const uint32_t* escan; const unsigned long long* carry; uint64_t ebase[XP]; uint32_t chunk_entries[XP];
+  const uint32_t* escan; const unsigned long long* carry;
+  uint64_t ebase[XPMAX];            // where virtual panel vp starts in the store (its physical panel's base + the sub-panels before it)
+  uint32_t vpoff[XPMAX];            // ... and inside its physical panel's stream (chunks are cut on the physical stream)
+  uint32_t chunk_entries[XPMAX];
   uint32_t* pcol; T* pval; uint32_t* rowtmp;
 };
+template <class T> __device__ __forceinline__ uint32_t xp_bucket(const XpSweep<T>& a, uint32_t code, uint32_t c, uint32_t r) {
+  const uint32_t k = code & 7u;
+  if (a.S == 1u) return k;
+  if ((code >> 3) >= a.H) return (uint32_t)a.pol[c >> a.lshift];
+  const uint32_t bits = (uint32_t)(a.rowmask[r] >> (k * a.S)) & ((1u << a.S) - 1u);
+  return k * a.S + (bits ? (uint32_t)__builtin_ctz(bits) : (r & (a.S - 1u)));
+}
+static __global__ void k_xp_rowmask(const uint32_t* __restrict__ col, const uint32_t* __restrict__ rowidx, const uint32_t* __restrict__ code, const uint8_t* __restrict__ pol, uint64_t nnz, uint32_t H,
+                                    uint32_t lshift, unsigned long long* __restrict__ rowmask) {
+  for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < nnz; p += gridDim.x * 256ull) {
+    const uint32_t c = col[p];
+    if ((code[c] >> 3) < H) continue;
+    const uint32_t r = rowidx[p]; const unsigned long long m = 1ull << pol[c >> lshift];
+    // (read at the L2 first: a hub row's 10^5 cold entries would otherwise queue on one address, one atomic per ~80 ns)
+    if (!(__hip_atomic_load(&rowmask[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m)) atomicOr(&rowmask[r], m);
+  }
+}
 template <class T, bool SCATTER>
 __global__ __launch_bounds__(XP_ST) void k_xp_sweep(const XpSweep<T> a) {
-  __shared__ uint32_t s_cnt[XP_SW][XP], s_last[XP_SW][XP], s_cursor[XP], s_carry[XP];
+  __shared__ uint32_t s_cnt[XP_SW][XPMAX], s_last[XP_SW][XPMAX], s_cursor[XPMAX], s_carry[XPMAX];
   const uint32_t u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t XP = a.np;                    // (shadows the constant: the buckets of this kernel are the virtual panels)
   if (tid < XP) {
     s_cursor[tid] = 0; uint32_t cr = WP_NONE;
     if constexpr (SCATTER) {
@@ -168,9 +216,8 @@ __global__ __launch_bounds__(XP_ST) void k_xp_sweep(const XpSweep<T> a) {
   for (uint64_t sb = base; sb < end; sb += XP_ST) {
     const uint64_t p = sb + tid; const bool valid = p < end;
     const uint32_t c = valid ? a.col[p] : 0u, code = valid ? a.code[c] : 0u, r = valid ? a.rowidx[p] : 0u;
-    const uint32_t k = valid ? (code & 7u) : 8u;
+    const uint32_t k = valid ? xp_bucket(a, code, c, r) : 0xFFu;
     uint32_t myrank = 0; int plane = (int)lane; bool has_prev = false;
-#pragma unroll
     for (uint32_t kk = 0; kk < XP; kk++) {
       const unsigned long long m = __ballot(k == kk);
       if (lane == 0) { s_cnt[w][kk] = (uint32_t)__popcll(m); }
@@ -189,8 +236,8 @@ __global__ __launch_bounds__(XP_ST) void k_xp_sweep(const XpSweep<T> a) {
       uint32_t off = s_cursor[k], prow = has_prev ? prevrow : s_carry[k];
       for (uint32_t w2 = 0; w2 < w; w2++) { off += s_cnt[w2][k]; if (!has_prev && s_last[w2][k] != WP_NONE) prow = s_last[w2][k]; }
       if constexpr (SCATTER) {
-        const uint32_t rel = (a.escan[(size_t)k * a.nunits + u] - a.escan[(size_t)k * a.nunits]) + off + myrank;     // position in the panel
-        const bool flag = prow != r || rel % a.chunk_entries[k] == 0;       // (prow == WP_NONE is never a row)
+        const uint32_t rel = (a.escan[(size_t)k * a.nunits + u] - a.escan[(size_t)k * a.nunits]) + off + myrank;     // position in the virtual panel
+        const bool flag = prow != r || (a.vpoff[k] + rel) % a.chunk_entries[k] == 0;       // (prow == WP_NONE is never a row; chunks are cut on the physical stream)
         const uint64_t dest = a.ebase[k] + rel;
         a.pcol[dest] = (code >> 3) | (flag ? WP_ROWSTART : 0u);
         if (a.pval) a.pval[dest] = a.val[p];
@@ -212,8 +259,21 @@ __global__ __launch_bounds__(XP_ST) void k_xp_sweep(const XpSweep<T> a) {
     }
   }
 }
-static __global__ void k_xp_pick(const uint32_t* __restrict__ escan, uint32_t nunits, const uint32_t* __restrict__ cstart, uint32_t* __restrict__ out) {
-  if (threadIdx.x <= XP) { out[threadIdx.x] = escan[(size_t)threadIdx.x * nunits]; out[XP + 1 + threadIdx.x] = cstart[threadIdx.x]; }
+static __global__ void k_xp_pick(const uint32_t* __restrict__ escan, uint32_t nunits, uint32_t np, const uint32_t* __restrict__ cstart, uint32_t* __restrict__ out) {
+  if (threadIdx.x <= np) out[threadIdx.x] = escan[(size_t)threadIdx.x * nunits];           // entries before virtual panel t
+  if (threadIdx.x <= XP) out[XPMAX + 1 + threadIdx.x] = cstart[threadIdx.x];                 // columns before physical panel t (in its frequency order)
+}
+// first sub-row of every virtual panel = row-start flags before its first entry (a sub-panel may begin in the middle of a tile)
+struct XpStarts { unsigned long long v[XPMAX + 1]; };
+static __global__ __launch_bounds__(64) void k_xp_vp_first(const uint32_t* __restrict__ pcol, const uint32_t* __restrict__ E, const XpStarts st, uint32_t np, uint32_t ntiles, uint32_t* __restrict__ vfirst) {
+  const uint32_t vp = blockIdx.x, lane = threadIdx.x;
+  if (vp >= np) { if (lane == 0) vfirst[np] = E[ntiles]; return; }
+  const unsigned long long q = st.v[vp]; const uint32_t g = (uint32_t)(q / WP_ENT), off = (uint32_t)(q % WP_ENT);
+  uint32_t c = 0;
+  if (off)
+    for (uint32_t j = 0; j < (uint32_t)WP_PER; j++) { const uint32_t pos = lane * WP_PER + j; if (pos < off) c += pcol[(size_t)g * WP_ENT + pos] >> 31; }
+  const uint32_t tot = __builtin_amdgcn_wave_reduce_add_u32(c, 0);
+  if (lane == 0) vfirst[vp] = E[g] + tot;
 }
 // sub-row starts per tile (one wave per tile; the panels' streams are stored back to back in whole tiles, padding is zero)
 static __global__ __launch_bounds__(256) void k_xp_tile_flags(const uint32_t* __restrict__ pcol, uint32_t ntiles, uint32_t* __restrict__ tflags) {
@@ -243,12 +303,10 @@ static __global__ __launch_bounds__(256) void k_xp_subrows(const uint32_t* __res
     for (int j = 0; j < 4; j++) if (f[j]) { const uint32_t r = rowtmp[q0 + j]; subrow_row[s] = r; s++; }
   }
 }
-static __global__ void k_xp_block_starts(const uint32_t* __restrict__ subrow_row, uint32_t nblocks, const uint32_t* __restrict__ E, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3,
-                                         uint32_t t4, uint32_t t5, uint32_t t6, uint32_t t7, uint32_t t8, uint32_t* __restrict__ blockptr) {
-  const uint32_t tb[XP + 1] = {t0, t1, t2, t3, t4, t5, t6, t7, t8};
+static __global__ void k_xp_block_starts(const uint32_t* __restrict__ subrow_row, uint32_t nblocks, const uint32_t* __restrict__ vfirst, uint32_t* __restrict__ blockptr) {
   for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < (nblocks + 1) * XP; t += gridDim.x * 256) {
     const uint32_t b = t / XP, k = t % XP; const uint64_t target = (uint64_t)b * XP_RB;
-    uint32_t lo = E[tb[k]], hi = E[tb[k + 1]];                 // panel k's sub-rows; first one whose row is >= target
+    uint32_t lo = vfirst[k], hi = vfirst[k + 1];               // panel k's sub-rows; first one whose row is >= target
     while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (subrow_row[mid] < target) lo = mid + 1; else hi = mid; }
     blockptr[t] = lo;
   }
@@ -332,12 +390,10 @@ template <class T> __global__ void k_xp_hot_gather(const T* __restrict__ u, cons
 // costs nothing: the head adds its continuations, the continuations themselves do nothing.
 constexpr uint32_t XP_CONT = 0x8000u, XP_HEAD = 0x4000u, XP_LROW = 0x07FFu;
 static_assert(XP_RB <= XP_LROW + 1, "row id inside a block and the two flags share 16 bits");
-static __global__ void k_xp_cont_flags(const uint32_t* __restrict__ subrow_row, const uint32_t* __restrict__ E, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t t4, uint32_t t5,
-                                       uint32_t t6, uint32_t t7, uint32_t t8, uint16_t* __restrict__ lrow) {
-  const uint32_t tb[XP + 1] = {t0, t1, t2, t3, t4, t5, t6, t7, t8};
+static __global__ void k_xp_cont_flags(const uint32_t* __restrict__ subrow_row, const uint32_t* __restrict__ vfirst, uint16_t* __restrict__ lrow) {
   uint32_t pb[XP + 1];
 #pragma unroll
-  for (int k = 0; k <= XP; k++) pb[k] = E[tb[k]];                 // first sub-row of every panel
+  for (int k = 0; k <= XP; k++) pb[k] = vfirst[k];                // first sub-row of every panel (S = 1 only: virtual = physical)
   const uint32_t F = pb[XP];
   for (uint32_t s = blockIdx.x * 256 + threadIdx.x; s < F; s += gridDim.x * 256) {
     const uint32_t r = subrow_row[s];
@@ -452,12 +508,11 @@ static __global__ void k_xm_slots(const uint32_t* __restrict__ skey, const uint3
                                   const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ rfirst, uint16_t* __restrict__ slot) {
   for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < F; i += gridDim.x * 256ull) { const uint32_t r = skey[i], b = fscan[r] + f[r] - 1; slot[sidx[i]] = (uint16_t)((uint32_t)i - rfirst[bstart[b]]); }
 }
-static __global__ void k_xm_block_starts(const uint32_t* __restrict__ subrow_row, const uint32_t* __restrict__ bstart, uint32_t nblocks, const uint32_t* __restrict__ E, uint32_t t0, uint32_t t1, uint32_t t2,
-                                         uint32_t t3, uint32_t t4, uint32_t t5, uint32_t t6, uint32_t t7, uint32_t t8, uint32_t* __restrict__ blockptr) {
-  const uint32_t tb[XP + 1] = {t0, t1, t2, t3, t4, t5, t6, t7, t8};
-  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < (nblocks + 1) * XP; t += gridDim.x * 256) {
-    const uint32_t b = t / XP, k = t % XP; const uint32_t target = bstart[b];
-    uint32_t lo = E[tb[k]], hi = E[tb[k + 1]];
+static __global__ void k_xm_block_starts(const uint32_t* __restrict__ subrow_row, const uint32_t* __restrict__ bstart, uint32_t nblocks, const uint32_t* __restrict__ vfirst, uint32_t np,
+                                         uint32_t* __restrict__ blockptr) {
+  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < (nblocks + 1) * np; t += gridDim.x * 256) {
+    const uint32_t b = t / np, k = t % np; const uint32_t target = bstart[b];
+    uint32_t lo = vfirst[k], hi = vfirst[k + 1];               // virtual panel k's sub-rows (in row order): first one whose row is >= target
     while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (subrow_row[mid] < target) lo = mid + 1; else hi = mid; }
     blockptr[t] = lo;
   }
@@ -476,9 +531,13 @@ static __global__ void k_xm_max(const uint32_t* __restrict__ cnt, uint32_t nrows
 // EPI: 0 y = the row sums, ypres = "the row has entries";  1 y(r) = y(r) (+) sum where the row has entries (in place, ypres untouched: the
 // accumulate of a product into a full vector with the monoid's operator);  2 y(r) = fill (+) sum / fill, ypres = 1 (the same into a vector
 // whose pending `w(:) = fill` was never written: gap/prmark.py:21-23 `r[:] = teleport; r += A' (+).second w` is this one store)
-template <class T, class SR, int EPI = 0>
+// WIDE (round 4): the block's sub-rows come in np > XP runs, one per virtual panel (sub-panels, XcdPlan::S > 1): where the runs begin
+// and their prefix lengths sit in LDS and a thread finds the run of its position by bisection (6 LDS reads per load; the eight-run
+// form keeps both in registers).
+template <class T, class SR, int EPI = 0, bool WIDE = false>
 __global__ __launch_bounds__(XM_CT) void k_xp_merge(uint32_t nrows, uint32_t nblocks, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ blockptr, const uint16_t* __restrict__ slot,
-                                                    const uint16_t* __restrict__ rowoff, const T* __restrict__ partial, T* __restrict__ y, uint8_t* __restrict__ ypres, const SR sr, const T fill = T()) {
+                                                    const uint16_t* __restrict__ rowoff, const T* __restrict__ partial, T* __restrict__ y, uint8_t* __restrict__ ypres, const SR sr, const T fill = T(),
+                                                    const uint32_t np = XP) {
   extern __shared__ __attribute__((aligned(16))) unsigned char xm_lds[];      // m_slots values: XM_SLOTS unless some row has very many sub-rows
   T* const vals = (T*)xm_lds;
   // workgroup w runs on XCD w % 8 (observed, grb_spmv.hip): give every XCD a contiguous eighth of the row blocks, so that the 128-byte
@@ -488,24 +547,53 @@ __global__ __launch_bounds__(XM_CT) void k_xp_merge(uint32_t nrows, uint32_t nbl
   const uint32_t tid = threadIdx.x;
   if (b >= nblocks) return;
   const uint32_t r0 = bstart[b], r1 = bstart[b + 1];
-  uint32_t lo[XP], pre[XP + 1];
-  pre[0] = 0;
+  uint32_t total;
+  if constexpr (!WIDE) {
+    uint32_t lo[XP], pre[XP + 1];
+    pre[0] = 0;
 #pragma unroll
-  for (int k = 0; k < XP; k++) { lo[k] = blockptr[b * XP + k]; pre[k + 1] = pre[k] + (blockptr[(b + 1) * XP + k] - lo[k]); }
-  const uint32_t total = pre[XP];
-  // the block's sub-rows as one index space over the eight runs; XM_INFL pairs of loads in flight per thread before the first LDS write
-  for (uint32_t t0 = tid; t0 < total; t0 += XM_INFL * XM_CT) {
-    T v[XM_INFL]; uint32_t sl[XM_INFL];
+    for (int k = 0; k < XP; k++) { lo[k] = blockptr[b * XP + k]; pre[k + 1] = pre[k] + (blockptr[(b + 1) * XP + k] - lo[k]); }
+    total = pre[XP];
+    // the block's sub-rows as one index space over the eight runs; XM_INFL pairs of loads in flight per thread before the first LDS write
+    for (uint32_t t0 = tid; t0 < total; t0 += XM_INFL * XM_CT) {
+      T v[XM_INFL]; uint32_t sl[XM_INFL];
 #pragma unroll
-    for (int u = 0; u < XM_INFL; u++) {
-      const uint32_t t = t0 + u * XM_CT; const bool ok = t < total;
-      uint32_t s = 0;
+      for (int u = 0; u < XM_INFL; u++) {
+        const uint32_t t = t0 + u * XM_CT; const bool ok = t < total;
+        uint32_t s = 0;
 #pragma unroll
-      for (int k = 0; k < XP; k++) if (t >= pre[k] && t < pre[k + 1]) s = lo[k] + (t - pre[k]);
-      v[u] = ok ? partial[s] : T(); sl[u] = ok ? (uint32_t)slot[s] : 0xFFFFFFFFu;
+        for (int k = 0; k < XP; k++) if (t >= pre[k] && t < pre[k + 1]) s = lo[k] + (t - pre[k]);
+        v[u] = ok ? partial[s] : T(); sl[u] = ok ? (uint32_t)slot[s] : 0xFFFFFFFFu;
+      }
+#pragma unroll
+      for (int u = 0; u < XM_INFL; u++) if (sl[u] != 0xFFFFFFFFu) vals[sl[u]] = v[u];
     }
+  } else {
+    __shared__ uint32_t s_lo[XPMAX], s_pre[XPMAX + 1];       // s_pre[k] = sub-rows of the block in the runs before run k; s_pre[np] = all of them
+    if (tid < 64u) {                                          // the first wave: run lengths, then their exclusive prefix by a wave scan
+      const bool in = tid < np;
+      const uint32_t l0 = in ? blockptr[b * np + tid] : 0u, l1 = in ? blockptr[(b + 1) * np + tid] : 0u;
+      uint32_t incl = l1 - l0;
 #pragma unroll
-    for (int u = 0; u < XM_INFL; u++) if (sl[u] != 0xFFFFFFFFu) vals[sl[u]] = v[u];
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)tid >= d) incl += o; }
+      if (in) { s_lo[tid] = l0; s_pre[tid] = incl - (l1 - l0); }
+      if (tid == 63u) s_pre[np] = incl;                       // (lanes >= np add nothing: lane 63 holds the total)
+    }
+    __syncthreads();
+    total = s_pre[np];
+    for (uint32_t t0 = tid; t0 < total; t0 += XM_INFL * XM_CT) {
+      T v[XM_INFL]; uint32_t sl[XM_INFL];
+#pragma unroll
+      for (int u = 0; u < XM_INFL; u++) {
+        const uint32_t t = t0 + u * XM_CT; const bool ok = t < total;
+        uint32_t klo = 0, khi = np;                           // the last run k with s_pre[k] <= t (runs may be empty: ties resolve to the non-empty one)
+        while (khi - klo > 1u) { const uint32_t mid = (klo + khi) >> 1; if (s_pre[mid] <= t) klo = mid; else khi = mid; }
+        const uint32_t s = ok ? s_lo[klo] + (t - s_pre[klo]) : 0u;
+        v[u] = ok ? partial[s] : T(); sl[u] = ok ? (uint32_t)slot[s] : 0xFFFFFFFFu;
+      }
+#pragma unroll
+      for (int u = 0; u < XM_INFL; u++) if (sl[u] != 0xFFFFFFFFu) vals[sl[u]] = v[u];
+    }
   }
   __syncthreads();
   const int lane = tid & 63;
@@ -544,15 +632,27 @@ inline XtVariant xt_variant() {
   return v;
 }
 
-template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals) {
+// sub-panels per XCD: 1 while an XCD's eighth of the operand (ncols * sizeof(T) / 8) fits what its L2 can keep of it, else the power of
+// two that brings a sub-panel under GRB_MI355X_XS_TARGET_KB (default 3072); GRB_MI355X_XS forces a value (1, 2, 4, 8)
+template <class T> int xp_subpanels(uint64_t ncols) {
+  const uint32_t forced = wp_env("GRB_MI355X_XS", 0);
+  if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return (int)forced;
+  const uint64_t target = (uint64_t)wp_env("GRB_MI355X_XS_TARGET_KB", 3072) << 10, share = ncols * sizeof(T) / XP;
+  int S = 1; while (S < XPMAX / XP && share / S > target) S *= 2;
+  return S;
+}
+template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int force_S = 0) {
   auto grid_n = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 8192) b = 8192; return (unsigned)b; };
   hipEvent_t ev0, ev1; GRB_HIP(hipEventCreate(&ev0)); GRB_HIP(hipEventCreate(&ev1)); GRB_HIP(hipEventRecord(ev0, stream()));
   auto* P = new XcdPlan(); M.xcd.reset(P);
   const uint32_t n = M.ncols; const uint64_t nnz = M.nnz;
   constexpr uint32_t H = xt_hot<T>::H;
-  // 1. column counts; the 128-byte lines of u dealt to the panels (equal entry counts); every panel's columns ranked by frequency
+  const int S = force_S ? force_S : xp_subpanels<T>(n); const uint32_t NP = (uint32_t)(XP * S);
+  P->S = S; P->NP = (int)NP;
+  // 1. column counts; the 128-byte lines of u dealt to the (virtual) panels (equal entry counts); every XCD's columns ranked by frequency
   const uint32_t line = 128 / (uint32_t)sizeof(T), nlines = (n + line - 1) / line;
-  DevBuf cnt((size_t)n * 4 + 4), code((size_t)n * 4 + 4), cstart((XP + 1) * 4);
+  uint32_t lshift = 0; while ((1u << lshift) < line) lshift++;
+  DevBuf cnt((size_t)n * 4 + 4), code((size_t)n * 4 + 4), cstart((XP + 1) * 4), pol((size_t)nlines + 8);
   P->hot_cols.alloc((size_t)XP * H * 4 + 4);
   GRB_HIP(hipMemsetAsync(cnt.p, 0, (size_t)n * 4 + 4, stream()));
   GRB_HIP(hipMemsetAsync(P->hot_cols.p, 0, (size_t)XP * H * 4 + 4, stream()));
@@ -562,15 +662,16 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals) {
     hipLaunchKernelGGL(k_xp_run_starts, dim3(grid_n(nnz)), dim3(256), 0, stream(), sorted.as<uint32_t>(), nnz, first.as<uint32_t>());
     hipLaunchKernelGGL(k_xp_run_lengths, dim3(grid_n(nnz)), dim3(256), 0, stream(), sorted.as<uint32_t>(), nnz, first.as<uint32_t>(), cnt.as<uint32_t>()); }
   {
-    DevBuf negw((size_t)nlines * 4 + 4), lid((size_t)nlines * 4 + 4), negw2((size_t)nlines * 4 + 4), lsorted((size_t)nlines * 4 + 4), pol((size_t)nlines + 8);
+    DevBuf negw((size_t)nlines * 4 + 4), lid((size_t)nlines * 4 + 4), negw2((size_t)nlines * 4 + 4), lsorted((size_t)nlines * 4 + 4);
     hipLaunchKernelGGL(k_xp_line_weights, dim3(grid_n(nlines)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, line, nlines, negw.as<uint32_t>(), lid.as<uint32_t>());
     sort_pairs_u32(negw.as<uint32_t>(), negw2.as<uint32_t>(), lid.as<uint32_t>(), lsorted.as<uint32_t>(), nlines, 32);
-    const uint32_t ntop = nlines < 4096u ? nlines : 4096u;
+    const uint32_t top_cap = 4096u * (uint32_t)XP / NP;          // (the exact deal is a serial loop over the slots: fewer lines when there are more slots)
+    const uint32_t ntop = nlines < top_cap ? nlines : top_cap;
     DevBuf dtop((size_t)ntop + 8);
-    hipLaunchKernelGGL(k_xp_lpt, dim3(1), dim3(256), 0, stream(), negw2.as<uint32_t>(), ntop, (uint8_t*)dtop.p);
-    hipLaunchKernelGGL(k_xp_deal_lines, dim3(grid_n(nlines)), dim3(256), 0, stream(), lsorted.as<uint32_t>(), nlines, (const uint8_t*)dtop.p, ntop, (uint8_t*)pol.p);
+    hipLaunchKernelGGL(k_xp_lpt, dim3(1), dim3(256), 0, stream(), negw2.as<uint32_t>(), ntop, NP, (uint32_t)S, (uint8_t*)dtop.p);
+    hipLaunchKernelGGL(k_xp_deal_lines, dim3(grid_n(nlines)), dim3(256), 0, stream(), lsorted.as<uint32_t>(), nlines, (const uint8_t*)dtop.p, ntop, NP, (uint32_t)S, (uint8_t*)pol.p);
     DevBuf k32((size_t)n * 4 + 4), k32o((size_t)n * 4 + 4), cin((size_t)n * 4 + 4), cout((size_t)n * 4 + 4);
-    hipLaunchKernelGGL(k_xp_column_keys, dim3(grid_n(n)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, line, (const uint8_t*)pol.p, k32.as<uint32_t>(), cin.as<uint32_t>());
+    hipLaunchKernelGGL(k_xp_column_keys, dim3(grid_n(n)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, line, (const uint8_t*)pol.p, (uint32_t)S, k32.as<uint32_t>(), cin.as<uint32_t>());
     sort_pairs_u32(k32.as<uint32_t>(), k32o.as<uint32_t>(), cin.as<uint32_t>(), cout.as<uint32_t>(), n, 23);
     GRB_HIP(hipMemsetAsync(cstart.p, 0xFF, (XP + 1) * 4, stream()));
     hipLaunchKernelGGL(k_xp_panel_starts, dim3(grid_n(n)), dim3(256), 0, stream(), k32o.as<uint32_t>(), n, cstart.as<uint32_t>());
@@ -582,31 +683,47 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals) {
   GRB_HIP(hipMemsetAsync(rowidx.p, 0, nnz * 4 + 4, stream()));
   hipLaunchKernelGGL(k_xp_mark_rows, dim3(grid_n(M.nrows)), dim3(256), 0, stream(), M.rowptr.as<uint32_t>(), M.nrows, rowidx.as<uint32_t>());
   inclusive_scan_max_u32(rowidx.as<uint32_t>(), rowidx.as<uint32_t>(), nnz);
+  // 2b. sub-panels: in which virtual panels every row has cold entries (the entries the LDS tables serve then ride with them)
+  DevBuf rowmask;
+  if (S > 1) {
+    rowmask.alloc(((size_t)M.nrows + 1) * 8);
+    GRB_HIP(hipMemsetAsync(rowmask.p, 0, ((size_t)M.nrows + 1) * 8, stream()));
+    hipLaunchKernelGGL(k_xp_rowmask, dim3(grid_n(nnz)), dim3(256), 0, stream(), M.col.as<uint32_t>(), rowidx.as<uint32_t>(), code.as<uint32_t>(), (const uint8_t*)pol.p, nnz, H, lshift,
+                       (unsigned long long*)rowmask.p);
+  }
   // 3. counting sweep, scans, the sizes (first host round trip)
   const uint32_t nunits = (uint32_t)((nnz + XP_UNIT - 1) / XP_UNIT);
-  const size_t nslots = (size_t)XP * nunits;
-  DevBuf ne((nslots + 1) * 4), escan((nslots + 1) * 4), lastkey(nslots * 8 + 8), carry(nslots * 8 + 8), picked(2 * (XP + 1) * 4);
+  const size_t nslots = (size_t)NP * nunits;
+  DevBuf ne((nslots + 1) * 4), escan((nslots + 1) * 4), lastkey(nslots * 8 + 8), carry(nslots * 8 + 8), picked((XPMAX + 1 + XP + 1) * 4);
   XpSweep<T> sw{};
   sw.col = M.col.as<uint32_t>(); sw.rowidx = rowidx.as<uint32_t>(); sw.code = code.as<uint32_t>(); sw.val = with_vals ? M.val.as<T>() : nullptr; sw.nnz = nnz; sw.nunits = nunits;
+  sw.np = NP; sw.S = (uint32_t)S; sw.H = H; sw.lshift = lshift; sw.pol = (const uint8_t*)pol.p; sw.rowmask = (const unsigned long long*)rowmask.p;
   sw.ne = ne.as<uint32_t>(); sw.lastkey = (unsigned long long*)lastkey.p; sw.escan = escan.as<uint32_t>(); sw.carry = (const unsigned long long*)carry.p;
   GRB_HIP(hipMemsetAsync(ne.as<uint32_t>() + nslots, 0, 4, stream()));
   hipLaunchKernelGGL((k_xp_sweep<T, false>), dim3(nunits), dim3(XP_ST), 0, stream(), sw);
   exclusive_scan_u32(ne.as<uint32_t>(), escan.as<uint32_t>(), nslots + 1);
   exclusive_scan_max_u64((const uint64_t*)lastkey.p, (uint64_t*)carry.p, nslots);
-  hipLaunchKernelGGL(k_xp_pick, dim3(1), dim3(64), 0, stream(), escan.as<uint32_t>(), nunits, cstart.as<uint32_t>(), picked.as<uint32_t>());
-  uint32_t hp[2 * (XP + 1)];
+  hipLaunchKernelGGL(k_xp_pick, dim3(1), dim3(128), 0, stream(), escan.as<uint32_t>(), nunits, NP, cstart.as<uint32_t>(), picked.as<uint32_t>());
+  uint32_t hp[XPMAX + 1 + XP + 1];
   GRB_HIP(hipMemcpyAsync(hp, picked.p, sizeof(hp), hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
   const uint32_t wpp = (uint32_t)(ncu / XP) * xt_variant().waves;       // waves per panel
   uint32_t kt[XP]; uint64_t nchunks_total = 0;
+  XpStarts vstart{};                                                     // where every virtual panel begins in the store
   P->tbase[0] = 0;
   for (int k = 0; k < XP; k++) {
-    P->ne[k] = hp[k + 1] - hp[k];
+    P->ne[k] = hp[(k + 1) * S] - hp[k * S];                              // a physical panel = its S sub-panels, one after the other
     P->ntiles[k] = (uint32_t)((P->ne[k] + WP_ENT - 1) / WP_ENT);
     P->tbase[k + 1] = P->tbase[k] + P->ntiles[k];
-    const uint32_t nk = hp[XP + 1 + k + 1] - hp[XP + 1 + k]; P->nhot[k] = nk < H ? nk : H;
-    kt[k] = wp_chunk_tasks(P->ntiles[k], wpp); sw.chunk_entries[k] = kt[k] * (uint32_t)WP_ENT; sw.ebase[k] = (uint64_t)P->tbase[k] * WP_ENT;
+    const uint32_t nk = hp[XPMAX + 1 + k + 1] - hp[XPMAX + 1 + k]; P->nhot[k] = nk < H ? nk : H;
+    kt[k] = wp_chunk_tasks(P->ntiles[k], wpp);
     nchunks_total += (P->ntiles[k] + kt[k] - 1) / kt[k];
+    for (int sp = 0; sp < S; sp++) {
+      const int vp = k * S + sp;
+      sw.vpoff[vp] = hp[vp] - hp[k * S]; sw.ebase[vp] = (uint64_t)P->tbase[k] * WP_ENT + sw.vpoff[vp]; sw.chunk_entries[vp] = kt[k] * (uint32_t)WP_ENT;
+      vstart.v[vp] = sw.ebase[vp];
+    }
   }
+  vstart.v[NP] = (uint64_t)P->tbase[XP] * WP_ENT;
   const uint32_t ntiles = P->tbase[XP];
   const size_t nstore = (size_t)ntiles * WP_ENT + 64;
   // 4. scattering sweep
@@ -630,13 +747,15 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals) {
   { unsigned nb = (ntiles + 3) / 4; if (nb < 1) nb = 1; if (nb > 16384) nb = 16384;
     hipLaunchKernelGGL(k_xp_subrows, dim3(nb), dim3(256), 0, stream(), P->pcol.as<uint32_t>(), rowtmp.as<uint32_t>(), E.as<uint32_t>(), ntiles, P->trow.as<uint32_t>(),
                        subrow_row.as<uint32_t>()); }
-  hipLaunchKernelGGL(k_xp_cont_flags, dim3(grid_n(P->F)), dim3(256), 0, stream(), subrow_row.as<uint32_t>(), E.as<uint32_t>(), P->tbase[0], P->tbase[1], P->tbase[2], P->tbase[3], P->tbase[4],
-                     P->tbase[5], P->tbase[6], P->tbase[7], P->tbase[8], P->lrow.as<uint16_t>());
-  // 6. row blocks of the merge kernel: where each block's run of sub-rows starts in every panel
+  P->vfirst.alloc((XPMAX + 2) * 4);
+  hipLaunchKernelGGL(k_xp_vp_first, dim3(NP + 1), dim3(64), 0, stream(), P->pcol.as<uint32_t>(), E.as<uint32_t>(), vstart, NP, ntiles, P->vfirst.as<uint32_t>());
+  // 6. row blocks of the per-panel merge kernel (the fallback; eight runs: S = 1 only): where each block's run of sub-rows starts in every panel
   const uint32_t nblocks = (uint32_t)(((uint64_t)M.nrows + XP_RB - 1) / XP_RB);
-  P->blockptr.alloc(((size_t)nblocks + 1) * XP * 4 + 4);
-  hipLaunchKernelGGL(k_xp_block_starts, dim3(grid_n(((uint64_t)nblocks + 1) * XP)), dim3(256), 0, stream(), subrow_row.as<uint32_t>(), nblocks, E.as<uint32_t>(), P->tbase[0], P->tbase[1],
-                     P->tbase[2], P->tbase[3], P->tbase[4], P->tbase[5], P->tbase[6], P->tbase[7], P->tbase[8], P->blockptr.as<uint32_t>());
+  if (S == 1) {
+    hipLaunchKernelGGL(k_xp_cont_flags, dim3(grid_n(P->F)), dim3(256), 0, stream(), subrow_row.as<uint32_t>(), P->vfirst.as<uint32_t>(), P->lrow.as<uint16_t>());
+    P->blockptr.alloc(((size_t)nblocks + 1) * XP * 4 + 4);
+    hipLaunchKernelGGL(k_xp_block_starts, dim3(grid_n(((uint64_t)nblocks + 1) * XP)), dim3(256), 0, stream(), subrow_row.as<uint32_t>(), nblocks, P->vfirst.as<uint32_t>(), P->blockptr.as<uint32_t>());
+  }
   // 6b. the merge in row-major slot order: sub-rows sorted by row (stable: panel, then chain order inside a row), rows per
   //     sub-row count, variable row blocks, slots and row offsets inside the blocks (third host round trip: the block count)
   {
@@ -662,14 +781,19 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals) {
     P->m_slots = need <= XM_SLOTS ? XM_SLOTS : (uint32_t)((need + 255) / 256 * 256);
     P->m_nblocks = hnb; P->m_ok = hnb > 0 && (uint64_t)P->m_slots * sizeof(T) <= 64u * 1024u && P->m_slots < 65536u && F < 0xFFFFFFF0ull;      // (16-bit slots; 64 KB of LDS at most)
     if (P->m_ok) {
-      P->m_bstart.alloc(((size_t)hnb + 1) * 4 + 4); P->m_blockptr.alloc(((size_t)hnb + 1) * XP * 4 + 4); P->m_slot.alloc(F * 2 + 4); P->m_rowoff.alloc((size_t)nr * 2 + 4);
+      P->m_bstart.alloc(((size_t)hnb + 1) * 4 + 4); P->m_blockptr.alloc(((size_t)hnb + 1) * NP * 4 + 4); P->m_slot.alloc(F * 2 + 4); P->m_rowoff.alloc((size_t)nr * 2 + 4);
       hipLaunchKernelGGL(k_xm_bstart, dim3(grid_n((uint64_t)nr + 1)), dim3(256), 0, stream(), nf.as<uint32_t>(), nfs.as<uint32_t>(), nr, hnb, P->m_bstart.as<uint32_t>());
       hipLaunchKernelGGL(k_xm_rowoff, dim3(grid_n(nr)), dim3(256), 0, stream(), nf.as<uint32_t>(), nfs.as<uint32_t>(), P->m_bstart.as<uint32_t>(), rfirst.as<uint32_t>(), nr, P->m_rowoff.as<uint16_t>());
       hipLaunchKernelGGL(k_xm_slots, dim3(grid_n(F)), dim3(256), 0, stream(), skey.as<uint32_t>(), sidx.as<uint32_t>(), F, nf.as<uint32_t>(), nfs.as<uint32_t>(), P->m_bstart.as<uint32_t>(),
                          rfirst.as<uint32_t>(), P->m_slot.as<uint16_t>());
-      hipLaunchKernelGGL(k_xm_block_starts, dim3(grid_n(((uint64_t)hnb + 1) * XP)), dim3(256), 0, stream(), subrow_row.as<uint32_t>(), P->m_bstart.as<uint32_t>(), hnb, E.as<uint32_t>(), P->tbase[0], P->tbase[1],
-                         P->tbase[2], P->tbase[3], P->tbase[4], P->tbase[5], P->tbase[6], P->tbase[7], P->tbase[8], P->m_blockptr.as<uint32_t>());
+      hipLaunchKernelGGL(k_xm_block_starts, dim3(grid_n(((uint64_t)hnb + 1) * NP)), dim3(256), 0, stream(), subrow_row.as<uint32_t>(), P->m_bstart.as<uint32_t>(), hnb, P->vfirst.as<uint32_t>(), NP,
+                         P->m_blockptr.as<uint32_t>());
     }
+  }
+  if (S > 1 && !P->m_ok) {        // a row with more sub-rows than a merge block holds: only the eight-run fallback can add it — start over without sub-panels
+    GRB_HIP(hipStreamSynchronize(stream())); (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+    build_xcd_plan<T>(M, ncu, with_vals, 1);
+    return;
   }
   // 6c. the 16-bit column plane (fourth host round trip: the number of cold entries); the 32-bit words are dropped
   constexpr bool c16 = xt_fmt<T>::C16;
@@ -707,12 +831,13 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals) {
     a.col16 = c16 ? P->col16.as<uint16_t>() + (size_t)P->tbase[k] * WP_ENT : nullptr; a.tinfo = c16 ? P->tinfo.as<uint32_t>() + 2 * (size_t)P->tbase[k] : nullptr;
     a.extras = c16 ? P->extras.as<uint16_t>() : nullptr; a.nextras = P->ncold;
     a.nnz = (uint32_t)P->ne[k]; a.ntiles = P->ntiles[k]; a.tiles_per_chunk = kt[k]; a.nhot = P->nhot[k];
-    a.static_pct = wp_env("GRB_MI355X_WP_STATIC", WP_STATIC_PCT); a.pad = 0;
+    a.static_pct = wp_env("GRB_MI355X_WP_STATIC", WP_STATIC_PCT);
+    a.interleave = wp_env("GRB_MI355X_XT_INTERLEAVE", S > 1 ? 1u : 0u);      // sub-panels: the waves of the XCD must walk the stream front to back together
   }
   if (getenv("GRB_MI355X_VERBOSE"))
     for (int k = 0; k < XP; k++)
-      fprintf(stderr, "[grb] xcd plan panel %d: entries %llu tiles %u chunk %u hot %u (sub-rows in all %llu, chunks %llu)\n", k, (unsigned long long)P->ne[k], P->ntiles[k], kt[k], P->nhot[k],
-              (unsigned long long)P->F, (unsigned long long)nchunks_total);
+      fprintf(stderr, "[grb] xcd plan panel %d: entries %llu tiles %u chunk %u hot %u (sub-rows in all %llu, chunks %llu, sub-panels per XCD %d)\n", k, (unsigned long long)P->ne[k], P->ntiles[k], kt[k],
+              P->nhot[k], (unsigned long long)P->F, (unsigned long long)nchunks_total, S);
   GRB_HIP(hipMemcpyAsync(P->args.p, ha, sizeof(ha), hipMemcpyHostToDevice, stream()));
   P->tsize = (int)sizeof(T); P->has_vals = with_vals;
   GRB_HIP(hipEventRecord(ev1, stream()));
@@ -750,24 +875,27 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
     if (!launched) hipLaunchKernelGGL((k_spmv_tiles<T, SR>), dim3(ncu), dim3(XT_WAVES * 64), 0, stream(), call, (const XtPanel<T>*)P->args.p, sr);
     const uint32_t nblocks = (uint32_t)(((uint64_t)M.nrows + XP_RB - 1) / XP_RB);
     static const bool old_merge = wp_env("GRB_MI355X_XP_OLD_MERGE", 0) != 0;       // measurement hook: the per-panel merge kernel
-    if (P->m_ok && !old_merge) {
+    if (P->m_ok && (!old_merge || P->S > 1)) {
       const dim3 mg((P->m_nblocks + XP - 1) / XP * XP), mb(XM_CT); const size_t ml = (size_t)P->m_slots * sizeof(T);
+      const uint32_t np = (uint32_t)P->NP;
+#define XM_LAUNCH(EPI_, Y_, YP_, FILL_) { \
+        if (P->S > 1) hipLaunchKernelGGL((k_xp_merge<T, SR, EPI_, true>), mg, mb, ml, stream(), M.nrows, P->m_nblocks, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), P->m_slot.as<uint16_t>(), \
+                                         P->m_rowoff.as<uint16_t>(), P->partial.as<T>(), (Y_), (YP_), sr, (FILL_), np); \
+        else hipLaunchKernelGGL((k_xp_merge<T, SR, EPI_, false>), mg, mb, ml, stream(), M.nrows, P->m_nblocks, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), P->m_slot.as<uint16_t>(), \
+                                P->m_rowoff.as<uint16_t>(), P->partial.as<T>(), (Y_), (YP_), sr, (FILL_), np); }
       if (c.epi == 1 && c.epi_done) {
-        hipLaunchKernelGGL((k_xp_merge<T, SR, 1>), mg, mb, ml, stream(), M.nrows, P->m_nblocks, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), P->m_slot.as<uint16_t>(),
-                           P->m_rowoff.as<uint16_t>(), P->partial.as<T>(), (T*)c.epi_w, (uint8_t*)nullptr, sr, T());
+        XM_LAUNCH(1, (T*)c.epi_w, (uint8_t*)nullptr, T())
         *c.epi_done = true;
       } else if (c.epi == 2 && c.epi_done) {
         T fill; memcpy(&fill, c.epi_fill, sizeof(T));
-        hipLaunchKernelGGL((k_xp_merge<T, SR, 2>), mg, mb, ml, stream(), M.nrows, P->m_nblocks, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), P->m_slot.as<uint16_t>(),
-                           P->m_rowoff.as<uint16_t>(), P->partial.as<T>(), (T*)c.tval, c.tpres, sr, fill);
+        XM_LAUNCH(2, (T*)c.tval, c.tpres, fill)
         *c.epi_done = true;
-      } else
-      hipLaunchKernelGGL((k_xp_merge<T, SR, 0>), mg, mb, ml, stream(), M.nrows, P->m_nblocks, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), P->m_slot.as<uint16_t>(),
-                         P->m_rowoff.as<uint16_t>(), P->partial.as<T>(), (T*)c.tval, c.tpres, sr, T());
+      } else XM_LAUNCH(0, (T*)c.tval, c.tpres, T())
+#undef XM_LAUNCH
     } else
       hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3(nblocks), dim3(XP_CT), 0, stream(), M.nrows, P->blockptr.as<uint32_t>(), P->lrow.as<uint16_t>(), P->partial.as<T>(),
                          (T*)c.tval, c.tpres, sr);
-    g_last_plan += std::string("k_spmv_xcd<") + (sr.is_static ? "static" : "dynamic") + ",subrows=" + std::to_string(P->F) + "," + xcd_mapping() + "> ";
+    g_last_plan += std::string("k_spmv_xcd<") + (sr.is_static ? "static" : "dynamic") + ",subrows=" + std::to_string(P->F) + (P->S > 1 ? ",subpanels=" + std::to_string(P->S) : std::string()) + "," + xcd_mapping() + "> ";
   });
   return true;
 }

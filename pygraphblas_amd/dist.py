@@ -174,6 +174,15 @@ class Comm:
         _check(self.lib.GrBX_Vector_device_touch(full._h), full)
 
 
+def bound_transport():
+    """File name of the RCCL-ABI library the exchange is bound to ("" while nothing is bound): librccl on a multi-GPU node, or the
+    test stand-in GRB_MI355X_RCCL names (tests/libfake_rccl.so: two ranks on one GPU, hipIpc copies)."""
+    from . import lib
+    buf = C.create_string_buffer(512)
+    lib.GrBX_dist_transport(buf, C.c_int(512))
+    return buf.value.decode()
+
+
 def _check(info, obj=None):
     from .base import check
     check(info, obj)

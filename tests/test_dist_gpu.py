@@ -49,11 +49,17 @@ def _single_process_reference(gb):
     return {"pr": pr, "its": its, "lev": lev, "depth": level - 1, "src": src, "tri": tri}
 
 
-def _worker(rank, world, port, q):
+FAKE_RCCL = os.path.join(ROOT, "tests", "libfake_rccl.so")
+
+
+def _worker(rank, world, port, q, transport="host"):
     try:
         sys.path.insert(0, ROOT)
         os.environ["GRB_MI355X_DEVICE"] = "0"
         os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # the host driver supports dmabuf IPC only
+        if transport == "rccl":
+            os.environ["GRB_MI355X_RCCL"] = FAKE_RCCL                      # grb_dist.cpp binds the stand-in instead of librccl
         import torch
         import torch.distributed as tdist
         tdist.init_process_group("gloo", rank=rank, world_size=world)
@@ -61,8 +67,13 @@ def _worker(rank, world, port, q):
         from pygraphblas_amd import rmat, dist as gdist
         assert gb.device_info()["ok"]
         n = 1 << SCALE
-        comm = gdist.Comm(rank, world, transport="host", tdist=tdist)
-        out = {}
+
+        def share(ident):
+            box = [ident]
+            tdist.broadcast_object_list(box, src=0)
+            return box[0]
+        comm = gdist.Comm(rank, world, transport=transport, share=share, tdist=tdist)
+        out = {"transport": gdist.bound_transport()}
         # ---- PageRank: rows of A' balanced by entries, split into diagonal / off-diagonal columns
         rp_all, _ = rmat.csr_numpy(SCALE, transpose=True)
         bounds = gdist.balanced_row_blocks(rp_all.astype(np.int64), world)
@@ -94,6 +105,7 @@ def _worker(rank, world, port, q):
         e0, e1 = int(rpl[t0]), int(rpl[t1])
         Lrows = gb.Matrix.from_csr(gb.INT64, t1 - t0, n, (rpl[t0:t1 + 1] - rpl[t0]).astype(np.uint32), coll[e0:e1], np.ones(e1 - e0, np.int64))
         out["tri"] = (gdist.triangle_count(comm, Lrows, L), t0, t1)
+        comm.close()
         q.put((rank, out))
         tdist.destroy_process_group()
     except Exception as e:          # noqa: BLE001 — surface the failure in the parent
@@ -101,13 +113,35 @@ def _worker(rank, world, port, q):
         q.put((rank, {"error": traceback.format_exc() + repr(e)}))
 
 
+def _ensure_fake_rccl():
+    src = os.path.join(ROOT, "tests", "fake_rccl.cpp")
+    if not os.path.exists(FAKE_RCCL) or os.path.getmtime(FAKE_RCCL) < os.path.getmtime(src):
+        import subprocess
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-shared", "-fPIC", "-o", FAKE_RCCL, src, "-lrt"])
+
+
 def test_two_ranks_on_one_gpu_match_the_single_process_results(gb, gpu):
+    _two_ranks(gb, "host")
+
+
+def test_two_ranks_on_one_gpu_through_the_library_exchange_path(gb, gpu):
+    """The same three workloads with the slices moving through the LIBRARY's exchange (grb_dist.cpp: grouped ncclSend / ncclRecv on its
+    second stream, ready / done events, presence bytes, the bit frontier, ncclAllReduce) between two real ranks.  RCCL refuses two ranks on
+    one device, so the nine entry points it binds come from tests/libfake_rccl.so, which moves the DEVICE pointers it is handed between
+    the two processes with hipIpc memory handles — everything but xGMI."""
+    _ensure_fake_rccl()
+    res = _two_ranks(gb, "rccl")
+    for r in (0, 1):
+        assert res[r]["transport"].endswith("libfake_rccl.so"), res[r]["transport"]
+
+
+def _two_ranks(gb, transport):
     import torch.multiprocessing as mp
     ref = _single_process_reference(gb)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29600 + (os.getpid() % 2000) + (11 if transport == "rccl" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, transport)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in range(2))
@@ -127,6 +161,7 @@ def test_two_ranks_on_one_gpu_match_the_single_process_results(gb, gpu):
     assert np.array_equal(lev, ref["lev"])                                              # bit-exact level vector
     assert res[0]["tri"][0] == res[1]["tri"][0] == ref["tri"]                           # INT64, exact
     assert 0 < res[0]["tri"][2] < n
+    return res
 
 
 def test_library_rccl_path_with_a_communicator_of_one(gb, gpu):
@@ -162,7 +197,7 @@ def test_library_rccl_path_with_a_communicator_of_one(gb, gpu):
         assert lib.GrBX_dist_finalize() == 0
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
+@pytest.mark.parametrize("scaling", ["weak", "strong", "weak-through-the-library-exchange-path"])
 def test_bench_py_runs_its_two_rank_path_on_one_gpu(gpu, scaling):
     """`bench.py --gpus 2` — what the driver launches for the scaling curve — end to end on this box: two ranks on GPU 0
     (BENCH_DEVICE_OVERRIDE), the exchange through the host transport (RCCL cannot put two ranks on one device), at R-MAT-17.
@@ -171,7 +206,12 @@ def test_bench_py_runs_its_two_rank_path_on_one_gpu(gpu, scaling):
     count and the oracle, level vector bit-exact on every rank's slice, PageRank converging in the single-process count)."""
     import json, subprocess
     env = dict(os.environ, BENCH_DEVICE_OVERRIDE="0", BENCH_TRANSPORT="host", MASTER_ADDR="127.0.0.1")
-    port = 29800 + (os.getpid() % 1000) + (7 if scaling == "strong" else 0)
+    fake = scaling.endswith("exchange-path")           # the third case: `Comm("rccl")` bound to tests/libfake_rccl.so (hipIpc between the two ranks)
+    if fake:
+        _ensure_fake_rccl()
+        env.update(BENCH_TRANSPORT="rccl", GRB_MI355X_RCCL=FAKE_RCCL, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        scaling = "weak"
+    port = 29800 + (os.getpid() % 1000) + (7 if scaling == "strong" else 0) + (13 if fake else 0)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--blocks", "2", "--scale", "17", "--pr-scale", "16", "--scaling", scaling],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
@@ -180,7 +220,7 @@ def test_bench_py_runs_its_two_rank_path_on_one_gpu(gpu, scaling):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == scaling and d["value"] > 0
     assert d["config"]["n"] == (1 << 18 if scaling == "weak" else 1 << 17)
-    assert len(d["ms_per_step_blocks"]) == 2 and "host copies" in d["config"]["transport"]
+    assert len(d["ms_per_step_blocks"]) == 2 and ("rccl-abi (fake, hipIpc)" if fake else "host copies") in d["config"]["transport"]
     other = d["spmv_strong" if scaling == "weak" else "spmv_weak"]
     assert other["n"] == (1 << 17 if scaling == "weak" else 1 << 18) and other["GFLOPS"] > 0
     for ph in (d["phases"], other["phases"]):

@@ -492,6 +492,7 @@ GrB_Info GrBX_dist_unique_id(void *id, int len);      /* 128 bytes, made on one 
 GrB_Info GrBX_dist_init(int rank, int world, const void *id, int len);   /* ncclCommInitRank on this process's GPU */
 GrB_Info GrBX_dist_finalize(void);
 GrB_Info GrBX_dist_info(int *rank, int *world);
+GrB_Info GrBX_dist_transport(char *buf, int len);      /* file name of the RCCL-ABI library bound for the exchange (librccl, or a test stand-in named by GRB_MI355X_RCCL); "" before the first use */
 GrB_Info GrBX_Vector_allgatherv_start(GrB_Vector full, const GrB_Vector local, const GrB_Index *bounds, int presence);
 GrB_Info GrBX_dist_wait(void);                        /* the compute stream waits for the exchange started above */
 GrB_Info GrBX_Vector_allgatherv(GrB_Vector full, const GrB_Vector local, const GrB_Index *bounds, int presence);
