@@ -436,6 +436,78 @@ int NAME(uint32_t n, const uint32_t* rp, const uint32_t* col, const T* val, uint
 #define SSSP_LESS(a, b) ((a) < (b))
 FAST_SSSP(fast_sssp_min_plus_int64, int64_t, SSSP_ADD_I64, SSSP_LESS)
 FAST_SSSP(fast_sssp_min_plus_fp64, double, SSSP_ADD_F64, SSSP_LESS)
+/* C(i,j) for every (i,j) in L of  C<L> = L (+).(x) L  — the per-entry form of the triangle count (demo/TriangleCentrality.ipynb cell 17,
+ * pygraphblas/matrix.py:2401-2584 with mask = L): val == NULL  -> PLUS_PAIR (C(i,j) = |L(i,:) ∩ L(:,j)| as a double, exact below 2^53),
+ * val != NULL -> PLUS_TIMES on doubles, products added in ascending k (the Gustavson order).  out / has are aligned with L's entries:
+ * has[p] = 0 where no product met mask entry p (C has no entry there). */
+void fast_masked_mxm_LL(uint32_t n, const uint32_t* rp, const uint32_t* col, const double* val, double* out, uint8_t* has) {
+#pragma omp parallel
+  {
+    uint32_t* pos = (uint32_t*)calloc((size_t)n + 1, 4);
+#pragma omp for schedule(dynamic, 256)
+    for (int64_t i = 0; i < (int64_t)n; i++) {
+      for (uint32_t p = rp[i]; p < rp[i + 1]; p++) { pos[col[p]] = p + 1; out[p] = 0.0; has[p] = 0; }
+      for (uint32_t p = rp[i]; p < rp[i + 1]; p++) { const uint32_t k = col[p]; const double a = val ? val[p] : 1.0;
+        for (uint32_t q = rp[k]; q < rp[k + 1]; q++) { const uint32_t t = pos[col[q]]; if (t) { out[t - 1] += val ? a * val[q] : 1.0; has[t - 1] = 1; } } }
+      for (uint32_t p = rp[i]; p < rp[i + 1]; p++) pos[col[p]] = 0;
+    }
+    free(pos);
+  }
+}
+/* The batched betweenness centrality of the reference's GAP driver, gap/bcmark.py:16-67, statement for statement on dense ns x n
+ * batches of doubles with presence bytes (the driver computes in FP32; this is what its arithmetic means):
+ *   paths = 0; paths[s, src_s] = 1; frontier[s, src_s] = 1
+ *   frontier<!paths,replace> = frontier (+).first A                       (pull along AT: rows of the transpose)
+ *   while frontier has entries: S[d] = pattern(frontier); paths += frontier; frontier<!paths,replace> = frontier (+).first A
+ *   bcu = 1; for i = depth-1 .. 1:  W<S[i],replace> = bcu ./ paths;  W<S[i-1],replace> = W (+).first AT;  bcu += W .* paths
+ *   centrality(j) = -ns + sum_s bcu(s, j)
+ * A = (rp, col), AT = (rpT, colT), both CSR of the directed graph.  level_nvals[d] = entries of the frontier at level d (d < max_levels).
+ * Returns the depth (number of levels whose frontier had entries). */
+int fast_bc_batch(uint32_t n, const uint32_t* rp, const uint32_t* col, const uint32_t* rpT, const uint32_t* colT, const uint32_t* sources, int ns,
+                  double* cent, int64_t* level_nvals, int max_levels) {
+  const size_t N = (size_t)ns * n;
+  double* paths = (double*)calloc(N, 8); double* f = (double*)calloc(N, 8); double* g = (double*)calloc(N, 8);
+  uint8_t* fp = (uint8_t*)calloc(N, 1); uint8_t* gp = (uint8_t*)calloc(N, 1);
+  uint8_t** S = (uint8_t**)calloc((size_t)max_levels + 1, sizeof(uint8_t*));
+  for (int s = 0; s < ns; s++) { paths[(size_t)s * n + sources[s]] = 1.0; f[(size_t)s * n + sources[s]] = 1.0; fp[(size_t)s * n + sources[s]] = 1; }
+  int depth = 0;
+  for (int round = 0;; round++) {
+    /* g<!paths,replace> = f (+).first A : g(s,j) = sum over k in AT(j,:) with f(s,k) present, where paths(s,j) == 0 */
+    int64_t nv = 0;
+#pragma omp parallel for schedule(dynamic, 4096) reduction(+ : nv)
+    for (int64_t j = 0; j < (int64_t)n; j++)
+      for (int s = 0; s < ns; s++) {
+        const size_t o = (size_t)s * n; double acc = 0.0; uint8_t has = 0;
+        if (paths[o + j] == 0.0) for (uint32_t q = rpT[j]; q < rpT[j + 1]; q++) { const uint32_t k = colT[q]; if (fp[o + k]) { acc += f[o + k]; has = 1; } }
+        g[o + j] = acc; gp[o + j] = has; nv += has;
+      }
+    { double* t = f; f = g; g = t; uint8_t* tp = fp; fp = gp; gp = tp; }
+    if (round > 0) depth = round;       /* (the first product precedes the loop of the driver) */
+    if (nv == 0 || depth >= max_levels) break;
+    if (depth < max_levels) level_nvals[depth] = nv;
+    S[depth] = (uint8_t*)malloc(N); memcpy(S[depth], fp, N);
+    for (size_t t = 0; t < N; t++) if (fp[t]) paths[t] += f[t];
+  }
+  /* at this point S[0..depth-1] hold the frontiers' patterns (S[d] = the frontier found by product d) */
+  double* bcu = (double*)malloc(N * 8); for (size_t t = 0; t < N; t++) bcu[t] = 1.0;
+  double* W = f; uint8_t* Wp = fp; double* W2 = g; uint8_t* W2p = gp;
+  for (int i = depth - 1; i > 0; i--) {
+    for (size_t t = 0; t < N; t++) { Wp[t] = S[i][t]; W[t] = S[i][t] ? bcu[t] / paths[t] : 0.0; }
+    /* W2<S[i-1],replace> = W (+).first AT : W2(s,j) = sum over k in A(j,:) with W(s,k) present */
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int64_t j = 0; j < (int64_t)n; j++)
+      for (int s = 0; s < ns; s++) {
+        const size_t o = (size_t)s * n; double acc = 0.0; uint8_t has = 0;
+        if (S[i - 1][o + j]) for (uint32_t q = rp[j]; q < rp[j + 1]; q++) { const uint32_t k = col[q]; if (Wp[o + k]) { acc += W[o + k]; has = 1; } }
+        W2[o + j] = acc; W2p[o + j] = has;
+      }
+    for (size_t t = 0; t < N; t++) if (W2p[t]) bcu[t] += W2[t] * paths[t];
+  }
+  for (uint32_t j = 0; j < n; j++) { double c = -(double)ns; for (int s = 0; s < ns; s++) c += bcu[(size_t)s * n + j]; cent[j] = c; }
+  for (int d = 0; d <= max_levels; d++) free(S[d]);
+  free(S); free(paths); free(f); free(g); free(fp); free(gp); free(bcu);
+  return depth;
+}
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -184,6 +184,29 @@ def fast_tricount(rowptr, col):
     return int(lib().fast_tricount_LL_maskL(C.c_uint32(len(rowptr) - 1), _p(rowptr), _p(col)))
 
 
+def fast_masked_mxm(rowptr, col, val=None):
+    """Per-entry C<L> = L (+).(x) L on the CSR of L: (out, has) aligned with L's entries — val None: PLUS_PAIR counts (as doubles, exact),
+    else PLUS_TIMES on doubles; has[p] = 0 where C has no entry at mask entry p."""
+    rowptr, col = _arr(rowptr, np.uint32), _arr(col, np.uint32)
+    n = len(rowptr) - 1
+    out = np.zeros(len(col), np.float64); has = np.zeros(len(col), np.uint8)
+    v = _arr(val, np.float64) if val is not None else None
+    lib().fast_masked_mxm_LL(C.c_uint32(n), _p(rowptr), _p(col), _p(v) if v is not None else None, _p(out), _p(has))
+    return out, has
+
+
+def fast_bc(rowptr, col, rowptr_t, col_t, sources, max_levels=64):
+    """gap/bcmark.py:16-67 on the directed graph A = (rowptr, col), AT = its transpose: (centrality float64[n], depth, frontier sizes)."""
+    rowptr, col, rowptr_t, col_t = _arr(rowptr, np.uint32), _arr(col, np.uint32), _arr(rowptr_t, np.uint32), _arr(col_t, np.uint32)
+    n = len(rowptr) - 1
+    src = _arr(sources, np.uint32)
+    cent = np.zeros(n, np.float64); lv = np.zeros(max_levels + 1, np.int64)
+    f = lib().fast_bc_batch
+    f.restype = C.c_int
+    depth = f(C.c_uint32(n), _p(rowptr), _p(col), _p(rowptr_t), _p(col_t), _p(src), C.c_int(len(src)), _p(cent), _p(lv), C.c_int(max_levels))
+    return cent, int(depth), lv[:depth].tolist()
+
+
 def fast_bfs(rowptr, col, src):
     rowptr, col = _arr(rowptr, np.uint32), _arr(col, np.uint32)
     n = len(rowptr) - 1

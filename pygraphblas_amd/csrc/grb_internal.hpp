@@ -106,9 +106,10 @@ struct DevCSR {
   // kernel-W plan (grb_spmv_wavepipe.hpp): per-task first row, hot-column list, remapped column array, per-wave carries
   DevBuf wp_rs, wp_hot, wp_pcol, wp_carry; uint32_t wp_nhot = 0, wp_ntasks = 0, wp_nwarm = 0; int wp_tsize = 0;
   std::shared_ptr<void> xcd;    // kernel-X plan (grb_spmv_xcd.hpp: XcdPlan), panel-major copy of the matrix
+  uint32_t pipe_uses = 0;       // full-operand pull products this matrix has served: the first runs kernel W (cheap plan), kernel X's plan is built for the second
   bool valid = false;
   void clear() { rowptr.reset(); col.reset(); val.reset(); plan_blocks.reset(); plan_aux.reset();
-                 wp_rs.reset(); wp_hot.reset(); wp_pcol.reset(); wp_carry.reset(); wp_nhot = wp_ntasks = 0; wp_tsize = 0; xcd.reset();
+                 wp_rs.reset(); wp_hot.reset(); wp_pcol.reset(); wp_carry.reset(); wp_nhot = wp_ntasks = 0; wp_tsize = 0; xcd.reset(); pipe_uses = 0;
                  nnz = 0; has_plan = false; locality_pct = -1; range_state = 0; valid = false; plan_nblocks = plan_nlong = 0; }
 };
 

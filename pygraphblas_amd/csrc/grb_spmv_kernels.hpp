@@ -443,7 +443,24 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
       const bool want_x = c.method == SPMV_XCD || (c.method == SPMV_AUTO && M.nnz >= (1u << 22));
       // (32-bit byte offsets into a panel's streams and into u: a panel holds ~nnz/8 entries)
       if (want_x && full && !c.allow && M.ncols < 0x0F000000u && M.nnz >= (uint64_t)WP_ENT * 64 && M.nnz * sizeof(T) < (7ull << 30) && device_cus() > 0) {
-        if (run_xcd<T>(c, d, device_cus())) return;
+        // Plan policy (round 4): kernel X's plan is a panel-major copy of the matrix, 6-7 ms at R-MAT-22 — 27 products.  A caller that
+        // multiplies ONCE (the literal `Matrix.mxv`, pygraphblas/matrix.py:2714-2725) must not pay it: the first `GRB_MI355X_XPLAN_AFTER`
+        // (default 1) full-operand products of a matrix run kernel W, whose plan is a sampled ranking + one pass (< 1 ms); the product
+        // after them builds X's plan, and W's is dropped.  0 = build X's plan at the first product, as rounds 1-3 did.
+        // FP32 keeps the eager plan: kernel W adds the 256-entry tasks of a long row one after the other, kernel X in blocks (sub-rows, then
+        // the merge) — over the 3.7e5 terms of an R-MAT-25 hub row W's FP32 sum drifts past the 1e-6 the north star allows, X's does not
+        // (tests/test_baseline_configs_gpu.py::test_config4_rmat25_pagerank_single_gpu).
+        static const uint32_t after_env = wp_env("GRB_MI355X_XPLAN_AFTER", 1);
+        const uint32_t after = std::is_same<T, float>::value ? 0u : after_env;
+        const XcdPlan* have = static_cast<const XcdPlan*>(M.xcd.get());
+        const bool planned = have && have->tsize == (int)sizeof(T);
+        if (planned || c.method == SPMV_XCD || M.pipe_uses >= after) {
+          if (run_xcd<T>(c, d, device_cus())) {
+            if (!planned && M.wp_tsize) { M.wp_rs.reset(); M.wp_hot.reset(); M.wp_pcol.reset(); M.wp_carry.reset(); M.wp_nhot = M.wp_ntasks = 0; M.wp_tsize = 0; }
+            return;
+          }
+        }
+        M.pipe_uses++;
       }
       const bool want = c.method == SPMV_WAVEPIPE || c.method == SPMV_XCD || (c.method == SPMV_AUTO && M.nnz >= (1u << 20));
       if (want && full && !c.allow && M.ncols < 0x70000000u && M.nnz >= (uint64_t)WP_ENT && device_cus() > 0) {

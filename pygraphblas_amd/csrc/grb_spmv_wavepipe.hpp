@@ -354,11 +354,19 @@ static __global__ void k_wp_task_starts(const uint32_t* __restrict__ rowptr, uin
   }
 }
 static __global__ void k_iota_u32_wp(uint32_t* p, uint64_t n) { for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) p[i] = (uint32_t)i; }
-static __global__ void k_wp_col_hist(const uint32_t* __restrict__ col, uint64_t nnz, uint32_t* __restrict__ cnt) {
-  for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < nnz; p += gridDim.x * 256ull) atomicAdd(&cnt[col[p]], 1u);
+// counts = run lengths of a sorted key array (the column counts of kernel X's plan, the sampled ones of kernel W's)
+static __global__ void k_xp_run_starts(const uint32_t* __restrict__ sorted, uint64_t nnz, uint32_t* __restrict__ first) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < nnz; i += gridDim.x * 256ull) if (i == 0 || sorted[i] != sorted[i - 1]) first[sorted[i]] = (uint32_t)i;
 }
-static __global__ void k_wp_neg_keys(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* __restrict__ key, uint32_t* __restrict__ id) {
-  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) { key[j] = 0xFFFFFFFFu - cnt[j]; id[j] = j; }   // ascending sort = descending count, ties by column
+static __global__ void k_xp_run_lengths(const uint32_t* __restrict__ sorted, uint64_t nnz, const uint32_t* __restrict__ first, uint32_t* __restrict__ cnt) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < nnz; i += gridDim.x * 256ull) if (i + 1 == nnz || sorted[i] != sorted[i + 1]) { const uint32_t c = sorted[i]; cnt[c] = (uint32_t)(i + 1) - first[c]; }
+}
+// every stride-th entry's column (the sample the hot / warm ranking is taken from)
+static __global__ void k_wp_sample(const uint32_t* __restrict__ col, uint64_t nnz, uint64_t stride, uint64_t m, uint32_t* __restrict__ out) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < m; i += gridDim.x * 256ull) { const uint64_t p = i * stride; out[i] = col[p < nnz ? p : nnz - 1]; }
+}
+static __global__ void k_wp_neg_keys(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t top, uint32_t* __restrict__ key, uint32_t* __restrict__ id) {
+  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) { key[j] = top - (cnt[j] < top ? cnt[j] : top); id[j] = j; }   // ascending sort = descending count, ties by column
 }
 static __global__ void k_wp_rank(const uint32_t* __restrict__ sorted_id, uint32_t n, uint32_t* __restrict__ rank) {
   for (uint32_t h = blockIdx.x * 256 + threadIdx.x; h < n; h += gridDim.x * 256) rank[sorted_id[h]] = h;
@@ -384,9 +392,21 @@ template <class T> void build_wavepipe_plan(DevCSR& M) {
                      M.wp_rs.as<uint32_t>(), M.wp_rs.as<uint32_t>() + (ntasks + 1));
   DevBuf cnt((size_t)n * 4 + 4), key((size_t)n * 4 + 4), id((size_t)n * 4 + 4), key2((size_t)n * 4 + 4), id2((size_t)n * 4 + 4), rank((size_t)n * 4 + 4);
   GRB_HIP(hipMemsetAsync(cnt.p, 0, (size_t)n * 4 + 4, stream()));
-  hipLaunchKernelGGL(k_wp_col_hist, dim3(grid_n(M.nnz)), dim3(256), 0, stream(), M.col.as<uint32_t>(), M.nnz, cnt.as<uint32_t>());
-  hipLaunchKernelGGL(k_wp_neg_keys, dim3(grid_n(n)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, key.as<uint32_t>(), id.as<uint32_t>());
-  sort_pairs_u32(key.as<uint32_t>(), key2.as<uint32_t>(), id.as<uint32_t>(), id2.as<uint32_t>(), n, 32);
+  // Column frequencies from a SAMPLE of ~2^21 entries (round 4).  The ranking only decides which columns sit in the LDS table and in the
+  // rank-ordered warm copy — any choice is correct, and the columns that matter are those a sample finds.  Counting every entry cost
+  // 4.5 ms at R-MAT-22 (device atomics; the hottest columns serialise), most of this plan; the sample is sorted (a radix sort of 2 M
+  // keys) and counted as run lengths — no atomics.  This is what makes kernel W the product a matrix runs FIRST (grb_spmv_kernels.hpp).
+  { const uint64_t target = (uint64_t)wp_env("GRB_MI355X_WP_SAMPLE", 1u << 21);
+    const uint64_t stride = M.nnz > target ? M.nnz / target : 1, m = (M.nnz + stride - 1) / stride;
+    DevBuf samp(m * 4 + 4), sorted(m * 4 + 4), first((size_t)n * 4 + 4);
+    int cb = 1; while ((1ull << cb) < (unsigned long long)n) cb++;
+    hipLaunchKernelGGL(k_wp_sample, dim3(grid_n(m)), dim3(256), 0, stream(), M.col.as<uint32_t>(), M.nnz, stride, m, samp.as<uint32_t>());
+    sort_keys_u32(samp.as<uint32_t>(), sorted.as<uint32_t>(), m, cb);
+    hipLaunchKernelGGL(k_xp_run_starts, dim3(grid_n(m)), dim3(256), 0, stream(), sorted.as<uint32_t>(), m, first.as<uint32_t>());
+    hipLaunchKernelGGL(k_xp_run_lengths, dim3(grid_n(m)), dim3(256), 0, stream(), sorted.as<uint32_t>(), m, first.as<uint32_t>(), cnt.as<uint32_t>());
+    uint32_t top = 1; int kb = 1; while ((uint64_t)top < m + 1 && kb < 32) { top <<= 1; kb++; }       // counts <= m: keys of kb bits
+    hipLaunchKernelGGL(k_wp_neg_keys, dim3(grid_n(n)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, top, key.as<uint32_t>(), id.as<uint32_t>());
+    sort_pairs_u32(key.as<uint32_t>(), key2.as<uint32_t>(), id.as<uint32_t>(), id2.as<uint32_t>(), n, kb); }
   const uint32_t nhot = n < H ? n : H;   // (nwarm >= nhot always: H*sizeof(T) <= 96 KiB)
   // the `nwarm` most frequent columns (two XCD-L2s' worth of u) are gathered from a rank-ordered copy made per call;
   // rarer ones straight from u

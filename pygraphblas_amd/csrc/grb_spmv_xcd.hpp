@@ -73,12 +73,7 @@ extern float g_xcd_plan_build_ms;     // duration of the most recent plan build 
 // straight into HBM — took 4.5-4.7 ms at R-MAT-22 whatever the grid: ~40 M of the 65 M entries belong to columns too cold
 // for a workgroup's LDS table, and the chip completes ~9 G device-scope atomics per second.  One 22-bit radix sort of the
 // keys and two streaming passes take about a third of that.)
-static __global__ void k_xp_run_starts(const uint32_t* __restrict__ sorted, uint64_t nnz, uint32_t* __restrict__ first) {
-  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < nnz; i += gridDim.x * 256ull) if (i == 0 || sorted[i] != sorted[i - 1]) first[sorted[i]] = (uint32_t)i;
-}
-static __global__ void k_xp_run_lengths(const uint32_t* __restrict__ sorted, uint64_t nnz, const uint32_t* __restrict__ first, uint32_t* __restrict__ cnt) {
-  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < nnz; i += gridDim.x * 256ull) if (i + 1 == nnz || sorted[i] != sorted[i + 1]) { const uint32_t c = sorted[i]; cnt[c] = (uint32_t)(i + 1) - first[c]; }
-}
+// (k_xp_run_starts / k_xp_run_lengths: grb_spmv_wavepipe.hpp — kernel W's sampled column counts use them too)
 // weight of a line of u = entries in its columns
 static __global__ void k_xp_line_weights(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t line, uint32_t nlines, uint32_t* __restrict__ negw, uint32_t* __restrict__ id) {
   for (uint32_t l = blockIdx.x * 256 + threadIdx.x; l < nlines; l += gridDim.x * 256) {
@@ -632,12 +627,14 @@ inline XtVariant xt_variant() {
   return v;
 }
 
-// sub-panels per XCD: 1 while an XCD's eighth of the operand (ncols * sizeof(T) / 8) fits what its L2 can keep of it, else the power of
-// two that brings a sub-panel under GRB_MI355X_XS_TARGET_KB (default 3072); GRB_MI355X_XS forces a value (1, 2, 4, 8)
+// sub-panels per XCD: GRB_MI355X_XS forces a value (1, 2, 4, 8); otherwise the power of two that brings an XCD's share of the operand
+// (ncols * sizeof(T) / 8) under GRB_MI355X_XS_TARGET_KB — whose default (0 = never) keeps S = 1: measured (profiles/r04_subpanels_scale25.txt)
+// S = 8 cuts the R-MAT-25 pipeline's memory-side reads from 7.2 to 2.6 GB and its time by only 8 %, which the longer merge gives back
 template <class T> int xp_subpanels(uint64_t ncols) {
   const uint32_t forced = wp_env("GRB_MI355X_XS", 0);
   if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return (int)forced;
-  const uint64_t target = (uint64_t)wp_env("GRB_MI355X_XS_TARGET_KB", 3072) << 10, share = ncols * sizeof(T) / XP;
+  const uint64_t target = (uint64_t)wp_env("GRB_MI355X_XS_TARGET_KB", 0) << 10, share = ncols * sizeof(T) / XP;
+  if (!target) return 1;
   int S = 1; while (S < XPMAX / XP && share / S > target) S *= 2;
   return S;
 }

@@ -180,7 +180,7 @@ print(json.dumps({"its": its, "rdiff": rdiff, "full": bool(p.all()), "stats": [v
     chains, nodes, fills, reduces = lazy[0]["stats"]
     its = lazy[0]["its"]
     assert blocking[0]["stats"] == [0, 0, 0, 0]
-    assert fills == its                      # every `r[:] = teleport` folded into the product's store
+    assert fills == its                      # every `r[:] = teleport` folded into the product's store (FP32: kernel X from the first product on)
     assert reduces == its                    # every `t.reduce_float()` produced by the chain kernel of `t -= r; abs`
     assert chains == 2 * its and nodes == 3 * its
 

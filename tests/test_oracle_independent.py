@@ -190,3 +190,42 @@ def test_sssp_fast_path_matches_generic_and_scipy(wtype):
             break
     assert k == sweeps
     assert np.array_equal(np.flatnonzero(pres), v.J.astype(int)) and np.array_equal(dist[pres != 0], v.X)
+
+
+def test_per_entry_masked_product_fast_path_matches_generic():
+    """fast_masked_mxm (the at-scale checker of configs[3]'s C, entry by entry) against the generic restatement: PLUS_PAIR counts
+    exactly, PLUS_TIMES on doubles to 1e-12, same pattern (mask entries no product meets are no entries)."""
+    rp, col = rmat.csr_numpy(9, symmetric=True, drop_self_loops=True, lower=True)
+    n = 1 << 9
+    rows = np.repeat(np.arange(n, dtype=np.uint64), np.diff(rp.astype(np.int64)))
+    rng = np.random.default_rng(3)
+    vals = rng.random(len(col))
+    Li = O.Tuples("INT64", n, n, rows, col, np.ones(len(col), np.int64))
+    Ci = O.mxm(O.Tuples("INT64", n, n), Li, Li, "PLUS", "PAIR", "INT64", mask=Li)
+    out, has = O.fast_masked_mxm(rp, col)
+    assert 0 < has.sum() < len(col)
+    assert np.array_equal(rows[has != 0], Ci.I) and np.array_equal(col[has != 0], Ci.J) and np.array_equal(out[has != 0].astype(np.int64), Ci.X)
+    Lf = O.Tuples("FP64", n, n, rows, col, vals)
+    Cf = O.mxm(O.Tuples("FP64", n, n), Lf, Lf, "PLUS", "TIMES", "FP64", mask=Lf)
+    out, has2 = O.fast_masked_mxm(rp, col, vals)
+    assert np.array_equal(has, has2) and np.array_equal(col[has2 != 0], Cf.J) and np.allclose(out[has2 != 0], Cf.X, rtol=1e-12, atol=0)
+
+
+def test_batched_bc_fast_path_matches_networkx():
+    """fast_bc (the at-scale checker of the gap/bcmark.py algorithm) against networkx's Brandes on the directed R-MAT-9: every vertex
+    that is not a source holds the sum over the sources of its dependency."""
+    nx = pytest.importorskip("networkx")
+    scale, ns = 9, 4
+    n = 1 << scale
+    rp, col = rmat.csr_numpy(scale, drop_self_loops=True)
+    rpt, colt = rmat.csr_numpy(scale, drop_self_loops=True, transpose=True)
+    rows = np.repeat(np.arange(n), np.diff(rp.astype(np.int64)))
+    deg = np.diff(rp.astype(np.int64))
+    sources = [int(x) for x in np.argsort(-deg, kind="stable")[:ns]]
+    cent, depth, sizes = O.fast_bc(rp, col, rpt, colt, sources)
+    G = nx.DiGraph(); G.add_nodes_from(range(n)); G.add_edges_from(zip(rows.tolist(), col.astype(np.int64).tolist()))
+    want = nx.betweenness_centrality_subset(G, sources=sources, targets=list(range(n)), normalized=False)
+    others = np.array([v for v in range(n) if v not in sources])
+    w = np.array([want[v] for v in others])
+    assert depth >= 3 and len(sizes) == depth and all(x > 0 for x in sizes) and w.max() > 1.0
+    assert np.allclose(cent[others], w, rtol=1e-9, atol=1e-9), np.abs(cent[others] - w).max()

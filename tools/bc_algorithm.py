@@ -3,7 +3,8 @@ pygraphblas_amd mirror.  The driver itself is written against descriptor names t
 `TransposeA`: stale API); they are RC, R and T0 in its current descriptor.py.  Shared by tests and tools."""
 
 
-def bc(gb, sources, AT, A):
+def bc(gb, sources, AT, A, sizes=None):
+    """`sizes` (a list) receives the entry count of every level's frontier (the at-scale parity test compares them with the oracle's)."""
     from pygraphblas_amd import descriptor as D
     Matrix, Vector, FP32, BOOL = gb.Matrix, gb.Vector, gb.FP32, gb.BOOL
     n = A.nrows
@@ -19,6 +20,8 @@ def bc(gb, sources, AT, A):
     for depth in range(n):
         if frontier.nvals == 0:
             break
+        if sizes is not None:
+            sizes.append(frontier.nvals)
         s = Matrix.sparse(BOOL, ns, n)
         frontier.apply(BOOL.ONE, out=s)
         S.append(s)

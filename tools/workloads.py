@@ -231,5 +231,10 @@ if "bcfull" in args.what:
     for rep in range(2):
         torch.cuda.synchronize(); t = time.perf_counter(); cent, depth = bc_full(gb, sources, AT, A); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t)
     cv = cent.to_dense_arrays()[0]
+    # parity: the oracle's restatement of the same algorithm in doubles (oracle/grb_oracle.c fast_bc_batch) — depth exact, values to 1e-4 (the driver is FP32)
+    from oracle import oracle as O
+    rpt, colt = AT.to_csr()[:2]
+    want, odepth, _ = O.fast_bc(rowptr.cpu().numpy().view(np.uint32), col.cpu().numpy().view(np.uint32), rpt, colt, sources)
+    ok = depth == odepth and bool(np.allclose(cv.astype(np.float64), want, rtol=1e-4, atol=1e-3))
     print(json.dumps({"workload": f"batched betweenness centrality, gap/bcmark.py:16-67, R-MAT-{args.scale} directed, ns=4", "n": n, "nnz": nnz, "depth": depth, "seconds": round(best, 4),
-                      "max_centrality": float(cv.max()), "plan": gb.last_kernel_plan()}), flush=True)
+                      "max_centrality": float(cv.max()), "parity_vs_oracle": "ok (depth exact, centrality rtol 1e-4 vs the FP64 restatement)" if ok else "MISMATCH", "plan": gb.last_kernel_plan()}), flush=True)
