@@ -168,7 +168,7 @@ template <class T> struct XtPanel {
   // entry order.  tinfo[2t] = sub-row of tile t's first entry, tinfo[2t + 1] = index in `extras` of its first cold entry.
   const uint16_t* col16; const uint32_t* tinfo; const uint16_t* extras; uint64_t nextras;
 };
-template <class T> struct XtCall { const T* u; uint32_t ulen; uint32_t pad; T* partial; };     // what changes from call to call
+template <class T> struct XtCall { const T* u; uint32_t ulen; uint32_t sps; T* partial; };     // what changes from call to call (sps: streams per XCD — a plan constant that rides along)
 
 template <class T> struct XtStage {       // what one tile has in flight
   uint32_t c[WP_PER]; T v[WP_PER], g[WP_PER]; uint32_t rf; uint32_t tile;   // column words (32-bit form), values, gathered operands; rf: sub-row of its first entry
@@ -191,18 +191,22 @@ template <class F, int... I> __device__ __forceinline__ bool xt_unroll_steps(F&&
 // only), 2 = loads only (no scan, no stores: what the load side of the pipeline can deliver)
 template <class T, class SR, int D = XT_DEPTH, int W = XT_WAVES, int EXP = 0, bool C16 = xt_fmt<T>::C16>
 __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, const XtPanel<T>* __restrict__ panels, const SR sr) {
-  const XtPanel<T> a = panels[blockIdx.x & 7];          // workgroup b works on column panel b % 8 — the XCD it is observed to run on
   constexpr int H = xt_hot<T>::H;
   constexpr int NS = D + 3;
   constexpr int XT_WAVES_ = W;
   __shared__ T s_hot[H];
   __shared__ T s_stage[W][64];                          // per wave: sub-row sums on their way out
   __shared__ uint32_t s_next;                           // next dynamic chunk of this workgroup
-  if (threadIdx.x == 0) s_next = 0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   T* const stage = s_stage[wv];
-  const bool use_a = sr.uses_a() && a.aval != nullptr, use_u = sr.uses_u();
   const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)call.u, (short)0, (int)(call.ulen * (uint32_t)sizeof(T)), 0x00020000);
+  // workgroup b works on the column panel(s) of XCD b % 8 — the XCD it is observed to run on: one stream, or (a table per sub-panel,
+  // XcdPlan::own) its `sps` streams one after the other, the LDS table refilled in between
+  for (uint32_t sp = 0; sp < call.sps; sp++) {
+  const XtPanel<T> a = panels[(blockIdx.x & 7) * call.sps + sp];
+  __syncthreads();                                      // (every wave is done with the table and the chunk counter of the stream before)
+  if (threadIdx.x == 0) s_next = 0;
+  const bool use_a = sr.uses_a() && a.aval != nullptr, use_u = sr.uses_u();
   if (use_u) for (uint32_t h = threadIdx.x; h < a.nhot; h += XT_WAVES_ * 64) s_hot[h] = wp_ld(a.xhot + h);      // the table's contents, gathered from u once per call
   // (16-bit words: the range covers whole tiles — the plan pads them with zeros — because the range check works on dwords and an
   //  odd entry count would otherwise cut the panel's last word off)
@@ -428,6 +432,7 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
 #ifdef XT_PROFILE
   if (lane == 0) { pf[5] = __builtin_amdgcn_s_memtime() - pf_start; for (int k = 0; k < 6; k++) g_xt_prof[((size_t)blockIdx.x * W + wv) * 8 + k] = pf[k]; }
 #endif
+  }     // streams of this XCD
 }
 
 }  // namespace grb

@@ -55,7 +55,7 @@ struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per 
   uint32_t m_nblocks = 0, m_slots = 0; bool m_ok = false;      // m_slots: LDS slots a block may need (XM_TARGET + the longest row's sub-rows)
   DevBuf args;            // XtPanel<T>[XP] in HBM; never changes between calls (u and the partial array arrive as kernel arguments)
   DevBuf xhot, partial;   // per-call work buffers kept with the plan (xhot: T[XP*H], the LDS tables' contents)
-  uint64_t ne[XP]; uint32_t tbase[XP + 1]; uint32_t ntiles[XP], nhot[XP];
+  uint64_t ne[XPMAX]; uint32_t tbase[XPMAX + 1]; uint32_t ntiles[XPMAX], nhot[XPMAX];      // per stream (NS of them: tile-aligned, one XtPanel and one LDS table each)
   uint64_t F = 0; int tsize = 0; bool has_vals = false; float build_ms = 0;
   // round 4: S sub-panels per XCD (virtual panel vp = k * S + s lives in physical panel k).  When an XCD's eighth of the operand does not
   // fit its 4 MiB L2 (R-MAT-25 FP32: 16.8 MB; every rank of a row-partitioned run), the lines of u are dealt to XP * S virtual panels and a
@@ -63,7 +63,11 @@ struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per 
   // front to back together, so at any time their cold gathers touch ONE sub-panel's lines — which fit.  Only COLD entries are bound to a
   // sub-panel; an entry served by the LDS table (one table per XCD, as before) rides in a sub-panel where its row already has a cold
   // entry, so sub-rows multiply by ~1.3 at S = 4 instead of ~2 (tools/subpanel_model.py).  The tile pipeline knows nothing of this.
-  int S = 1, NP = XP;
+  // `own` (GRB_MI355X_XOWN=1): every sub-panel is a stream of its own WITH ITS OWN LDS TABLE — the pipeline's workgroups walk the S
+  // streams of their XCD one after the other, refilling the table in between.  S times the table slots: fewer cold gathers (each costs the
+  // CU a 128-byte L2->L1 line fill, which is what bounds the pipeline once a third of the entries are cold: R-MAT-25, 37 %), more sub-rows
+  // (an entry the table serves is now bound to its column's sub-panel as well).
+  int S = 1, NP = XP, NS = XP; bool own = false;
   DevBuf vfirst;          // u32[NP + 1] first sub-row of every virtual panel (sub-rows are numbered in stream order)
 };
 extern float g_xcd_plan_build_ms;     // duration of the most recent plan build (grb_spmv.hip; read by GrBX_last_plan_build_ms)
@@ -137,15 +141,15 @@ static __global__ void k_xp_panel_starts(const uint32_t* __restrict__ key, uint3
     if (i == 0 || (key[i - 1] >> 20) != k) start[k] = i;
   }
 }
-static __global__ void k_xp_fix_starts(uint32_t* __restrict__ start, uint32_t n) {      // a panel without columns starts where the next one does
-  if (blockIdx.x == 0 && threadIdx.x == 0) { start[XP] = n; for (int k = XP - 1; k >= 0; k--) if (start[k] == 0xFFFFFFFFu) start[k] = start[k + 1]; }
+static __global__ void k_xp_fix_starts(uint32_t* __restrict__ start, uint32_t n, uint32_t ns) {      // a panel without columns starts where the next one does
+  if (blockIdx.x == 0 && threadIdx.x == 0) { start[ns] = n; for (int k = (int)ns - 1; k >= 0; k--) if (start[k] == 0xFFFFFFFFu) start[k] = start[k + 1]; }
 }
 // code word of a column: (slot or H + column) << 3 | panel; the panel's hot-column list
 static __global__ void k_xp_column_codes(const uint32_t* __restrict__ key, const uint32_t* __restrict__ cols, uint32_t n, uint32_t H, const uint32_t* __restrict__ start,
                                          uint32_t* __restrict__ code, uint32_t* __restrict__ hot_cols) {
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const uint32_t k = key[i] >> 20, c = cols[i], local = i - start[k];
-    code[c] = ((local < H ? local : H + c) << 3) | k;
+    code[c] = ((local < H ? local : H + c) << 3) | (k & 7u);      // (the low bits name the XCD when tables are per XCD; with a table per sub-panel the bucket comes from the line deal)
     if (local < H) hot_cols[(size_t)k * H + local] = c;
   }
 }
@@ -168,7 +172,7 @@ static __global__ void k_xp_mark_rows(const uint32_t* __restrict__ rowptr, uint3
 // word r = row r has a cold entry in virtual panel vp; lowest such sub-panel) — or, failing that, sub-panel r mod S.
 template <class T> struct XpSweep {
   const uint32_t* col; const uint32_t* rowidx; const uint32_t* code; const T* val; uint64_t nnz; uint32_t nunits;
-  uint32_t np, S, H, lshift; const uint8_t* pol; const unsigned long long* rowmask;
+  uint32_t np, S, H, lshift, own; const uint8_t* pol; const unsigned long long* rowmask;
   uint32_t* ne; unsigned long long* lastkey;
   const uint32_t* escan; const unsigned long long* carry;
   uint64_t ebase[XPMAX];            // where virtual panel vp starts in the store (its physical panel's base + the sub-panels before it)
@@ -179,7 +183,7 @@ template <class T> struct XpSweep {
 template <class T> __device__ __forceinline__ uint32_t xp_bucket(const XpSweep<T>& a, uint32_t code, uint32_t c, uint32_t r) {
   const uint32_t k = code & 7u;
   if (a.S == 1u) return k;
-  if ((code >> 3) >= a.H) return (uint32_t)a.pol[c >> a.lshift];
+  if (a.own || (code >> 3) >= a.H) return (uint32_t)a.pol[c >> a.lshift];
   const uint32_t bits = (uint32_t)(a.rowmask[r] >> (k * a.S)) & ((1u << a.S) - 1u);
   return k * a.S + (bits ? (uint32_t)__builtin_ctz(bits) : (r & (a.S - 1u)));
 }
@@ -254,9 +258,9 @@ __global__ __launch_bounds__(XP_ST) void k_xp_sweep(const XpSweep<T> a) {
     }
   }
 }
-static __global__ void k_xp_pick(const uint32_t* __restrict__ escan, uint32_t nunits, uint32_t np, const uint32_t* __restrict__ cstart, uint32_t* __restrict__ out) {
+static __global__ void k_xp_pick(const uint32_t* __restrict__ escan, uint32_t nunits, uint32_t np, const uint32_t* __restrict__ cstart, uint32_t ns, uint32_t* __restrict__ out) {
   if (threadIdx.x <= np) out[threadIdx.x] = escan[(size_t)threadIdx.x * nunits];           // entries before virtual panel t
-  if (threadIdx.x <= XP) out[XPMAX + 1 + threadIdx.x] = cstart[threadIdx.x];                 // columns before physical panel t (in its frequency order)
+  if (threadIdx.x <= ns) out[XPMAX + 1 + threadIdx.x] = cstart[threadIdx.x];                 // columns before stream t (in its frequency order)
 }
 // first sub-row of every virtual panel = row-start flags before its first entry (a sub-panel may begin in the middle of a tile)
 struct XpStarts { unsigned long long v[XPMAX + 1]; };
@@ -484,11 +488,11 @@ constexpr int XM_CT = 256;
 #define XM_INFL 4                     // pairs of loads in flight per thread of the merge kernel (8: no faster)
 #endif
 static __global__ void k_xm_iota(uint32_t* p, uint64_t n) { for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) p[i] = (uint32_t)i; }
-static __global__ void k_xm_weights(const uint32_t* __restrict__ cnt, uint32_t nrows, uint32_t* __restrict__ w) {
-  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r <= nrows; r += gridDim.x * 256) w[r] = r < nrows ? cnt[r] + XM_TARGET / XM_ROWS : 0u;
+static __global__ void k_xm_weights(const uint32_t* __restrict__ cnt, uint32_t nrows, uint32_t perrow, uint32_t* __restrict__ w) {
+  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r <= nrows; r += gridDim.x * 256) w[r] = r < nrows ? cnt[r] + perrow : 0u;
 }
-static __global__ void k_xm_newblock(const uint32_t* __restrict__ P, uint32_t nrows, uint32_t* __restrict__ f) {
-  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r <= nrows; r += gridDim.x * 256) f[r] = r < nrows && (r == 0 || P[r] / XM_TARGET != P[r - 1] / XM_TARGET) ? 1u : 0u;
+static __global__ void k_xm_newblock(const uint32_t* __restrict__ P, uint32_t nrows, uint32_t target, uint32_t* __restrict__ f) {
+  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r <= nrows; r += gridDim.x * 256) f[r] = r < nrows && (r == 0 || P[r] / target != P[r - 1] / target) ? 1u : 0u;
 }
 // bid = exclusive scan of the flags + flag - 1 (the block of row r); first rows of the blocks
 static __global__ void k_xm_bstart(const uint32_t* __restrict__ f, const uint32_t* __restrict__ fscan, uint32_t nrows, uint32_t nblocks, uint32_t* __restrict__ bstart) {
@@ -526,13 +530,9 @@ static __global__ void k_xm_max(const uint32_t* __restrict__ cnt, uint32_t nrows
 // EPI: 0 y = the row sums, ypres = "the row has entries";  1 y(r) = y(r) (+) sum where the row has entries (in place, ypres untouched: the
 // accumulate of a product into a full vector with the monoid's operator);  2 y(r) = fill (+) sum / fill, ypres = 1 (the same into a vector
 // whose pending `w(:) = fill` was never written: gap/prmark.py:21-23 `r[:] = teleport; r += A' (+).second w` is this one store)
-// WIDE (round 4): the block's sub-rows come in np > XP runs, one per virtual panel (sub-panels, XcdPlan::S > 1): where the runs begin
-// and their prefix lengths sit in LDS and a thread finds the run of its position by bisection (6 LDS reads per load; the eight-run
-// form keeps both in registers).
-template <class T, class SR, int EPI = 0, bool WIDE = false>
+template <class T, class SR, int EPI = 0>
 __global__ __launch_bounds__(XM_CT) void k_xp_merge(uint32_t nrows, uint32_t nblocks, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ blockptr, const uint16_t* __restrict__ slot,
-                                                    const uint16_t* __restrict__ rowoff, const T* __restrict__ partial, T* __restrict__ y, uint8_t* __restrict__ ypres, const SR sr, const T fill = T(),
-                                                    const uint32_t np = XP) {
+                                                    const uint16_t* __restrict__ rowoff, const T* __restrict__ partial, T* __restrict__ y, uint8_t* __restrict__ ypres, const SR sr, const T fill = T()) {
   extern __shared__ __attribute__((aligned(16))) unsigned char xm_lds[];      // m_slots values: XM_SLOTS unless some row has very many sub-rows
   T* const vals = (T*)xm_lds;
   // workgroup w runs on XCD w % 8 (observed, grb_spmv.hip): give every XCD a contiguous eighth of the row blocks, so that the 128-byte
@@ -542,53 +542,24 @@ __global__ __launch_bounds__(XM_CT) void k_xp_merge(uint32_t nrows, uint32_t nbl
   const uint32_t tid = threadIdx.x;
   if (b >= nblocks) return;
   const uint32_t r0 = bstart[b], r1 = bstart[b + 1];
-  uint32_t total;
-  if constexpr (!WIDE) {
-    uint32_t lo[XP], pre[XP + 1];
-    pre[0] = 0;
+  uint32_t lo[XP], pre[XP + 1];
+  pre[0] = 0;
 #pragma unroll
-    for (int k = 0; k < XP; k++) { lo[k] = blockptr[b * XP + k]; pre[k + 1] = pre[k] + (blockptr[(b + 1) * XP + k] - lo[k]); }
-    total = pre[XP];
-    // the block's sub-rows as one index space over the eight runs; XM_INFL pairs of loads in flight per thread before the first LDS write
-    for (uint32_t t0 = tid; t0 < total; t0 += XM_INFL * XM_CT) {
-      T v[XM_INFL]; uint32_t sl[XM_INFL];
+  for (int k = 0; k < XP; k++) { lo[k] = blockptr[b * XP + k]; pre[k + 1] = pre[k] + (blockptr[(b + 1) * XP + k] - lo[k]); }
+  const uint32_t total = pre[XP];
+  // the block's sub-rows as one index space over the eight runs; XM_INFL pairs of loads in flight per thread before the first LDS write
+  for (uint32_t t0 = tid; t0 < total; t0 += XM_INFL * XM_CT) {
+    T v[XM_INFL]; uint32_t sl[XM_INFL];
 #pragma unroll
-      for (int u = 0; u < XM_INFL; u++) {
-        const uint32_t t = t0 + u * XM_CT; const bool ok = t < total;
-        uint32_t s = 0;
+    for (int u = 0; u < XM_INFL; u++) {
+      const uint32_t t = t0 + u * XM_CT; const bool ok = t < total;
+      uint32_t s = 0;
 #pragma unroll
-        for (int k = 0; k < XP; k++) if (t >= pre[k] && t < pre[k + 1]) s = lo[k] + (t - pre[k]);
-        v[u] = ok ? partial[s] : T(); sl[u] = ok ? (uint32_t)slot[s] : 0xFFFFFFFFu;
-      }
-#pragma unroll
-      for (int u = 0; u < XM_INFL; u++) if (sl[u] != 0xFFFFFFFFu) vals[sl[u]] = v[u];
+      for (int k = 0; k < XP; k++) if (t >= pre[k] && t < pre[k + 1]) s = lo[k] + (t - pre[k]);
+      v[u] = ok ? partial[s] : T(); sl[u] = ok ? (uint32_t)slot[s] : 0xFFFFFFFFu;
     }
-  } else {
-    __shared__ uint32_t s_lo[XPMAX], s_pre[XPMAX + 1];       // s_pre[k] = sub-rows of the block in the runs before run k; s_pre[np] = all of them
-    if (tid < 64u) {                                          // the first wave: run lengths, then their exclusive prefix by a wave scan
-      const bool in = tid < np;
-      const uint32_t l0 = in ? blockptr[b * np + tid] : 0u, l1 = in ? blockptr[(b + 1) * np + tid] : 0u;
-      uint32_t incl = l1 - l0;
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)tid >= d) incl += o; }
-      if (in) { s_lo[tid] = l0; s_pre[tid] = incl - (l1 - l0); }
-      if (tid == 63u) s_pre[np] = incl;                       // (lanes >= np add nothing: lane 63 holds the total)
-    }
-    __syncthreads();
-    total = s_pre[np];
-    for (uint32_t t0 = tid; t0 < total; t0 += XM_INFL * XM_CT) {
-      T v[XM_INFL]; uint32_t sl[XM_INFL];
-#pragma unroll
-      for (int u = 0; u < XM_INFL; u++) {
-        const uint32_t t = t0 + u * XM_CT; const bool ok = t < total;
-        uint32_t klo = 0, khi = np;                           // the last run k with s_pre[k] <= t (runs may be empty: ties resolve to the non-empty one)
-        while (khi - klo > 1u) { const uint32_t mid = (klo + khi) >> 1; if (s_pre[mid] <= t) klo = mid; else khi = mid; }
-        const uint32_t s = ok ? s_lo[klo] + (t - s_pre[klo]) : 0u;
-        v[u] = ok ? partial[s] : T(); sl[u] = ok ? (uint32_t)slot[s] : 0xFFFFFFFFu;
-      }
-#pragma unroll
-      for (int u = 0; u < XM_INFL; u++) if (sl[u] != 0xFFFFFFFFu) vals[sl[u]] = v[u];
-    }
+    for (int u = 0; u < XM_INFL; u++) if (sl[u] != 0xFFFFFFFFu) vals[sl[u]] = v[u];
   }
   __syncthreads();
   const int lane = tid & 63;
@@ -613,6 +584,152 @@ __global__ __launch_bounds__(XM_CT) void k_xp_merge(uint32_t nrows, uint32_t nbl
     else if constexpr (EPI == 1) { if (live && o1 > o0) y[r] = sr.add(y[r], acc); }
     else { if (live) { y[r] = o1 > o0 ? sr.add(fill, acc) : fill; ypres[r] = 1; } }
   }
+}
+
+// ---- the merge for plans with sub-panels (round 4): np = 16 ... 64 runs per block, rows of 1 ... np (and more) sub-rows ------------------
+// What this kernel costs is INSTRUCTIONS (measured at R-MAT-25, a table per sub-panel, 1.08e8 sub-rows, 4.3e4 blocks: ~1080 VALU
+// instructions per wave and block, the SIMDs busy, 400-560 us whether blocks are launched one per workgroup or walked by persistent
+// workgroups, with the bounds of the next block prefetched or not) — so it is written to issue few:
+//   * a thread takes FOUR consecutive positions of the block's index space per step (one 6-step branch-free bisection over the runs'
+//     prefix lengths in LDS serves all four when they lie in one run — runs average 128 sub-rows), two steps in flight;
+//   * the row sums do not go "one thread per row" (rows have 1 ... np ... sub-rows: a wave would wait for its longest row): the SLOTS
+//     are dealt to the threads — thread t scans `chunk` consecutive slots front to back, branch-free: a flag per slot marks where a row
+//     begins, the running sum restarts there and is written back to every slot, so a row's sum ends up in its LAST slot; what flows
+//     into a chunk from the chunks before it (a row that began earlier) is added to the last slot of the chunk's leading piece after a
+//     barrier, by walking back over the chunk totals.  Every order is fixed: reproducible.
+//   * persistent workgroups (a few per CU) over an XCD's contiguous eighth of the blocks, the next block's bounds fetched a block ahead.
+// LDS: m_slots values + m_slots flag bytes.
+constexpr uint32_t XMW_TARGET = 4096, XMW_ROWS = 2048;
+constexpr int XMW_RPT = XMW_ROWS / XM_CT;
+template <class T, class SR, int EPI = 0>
+__global__ __launch_bounds__(XM_CT) void k_xp_merge_wide(uint32_t nrows, uint32_t nblocks, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ blockptr, const uint16_t* __restrict__ slot,
+                                                         const uint16_t* __restrict__ rowoff, const T* __restrict__ partial, T* __restrict__ y, uint8_t* __restrict__ ypres, const SR sr, const T fill,
+                                                         const uint32_t np, const uint32_t m_slots) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char xm_lds[];
+  T* const vals = (T*)xm_lds;
+  uint8_t* const flag = xm_lds + (size_t)m_slots * sizeof(T);          // (m_slots is a multiple of 256: the byte array starts 16-byte aligned)
+  __shared__ uint32_t s_lo[XPMAX], s_pre[XPMAX + 1];                   // s_pre[k] = sub-rows of the block in the runs before run k; s_pre[np] = all of them; beyond np: 0xFFFFFFFF
+  __shared__ T s_tsum[XM_CT];                                          // the running sum at the end of thread t's chunk (since its last row start, or over the whole chunk)
+  __shared__ uint8_t s_hasflag[XM_CT];                                 // a row starts inside thread t's chunk
+  const uint32_t per = (nblocks + XP - 1) / XP, tid = threadIdx.x, stride = gridDim.x >> 3;
+  auto block_of = [&](uint32_t bb) -> uint32_t { const uint32_t b = (blockIdx.x & (XP - 1)) * per + bb; return bb < per && b < nblocks ? b : 0xFFFFFFFFu; };
+  uint32_t bb = blockIdx.x >> 3, b = block_of(bb);
+  uint32_t n_r0 = 0, n_r1 = 0, n_l0 = 0, n_len = 0;
+  auto fetch_bounds = [&](uint32_t bn) __attribute__((always_inline)) {
+    if (bn == 0xFFFFFFFFu) return;
+    n_r0 = bstart[bn]; n_r1 = bstart[bn + 1];
+    if (tid < np) { n_l0 = blockptr[bn * np + tid]; n_len = blockptr[(bn + 1) * np + tid] - n_l0; }
+  };
+  fetch_bounds(b);
+  for (; b != 0xFFFFFFFFu; ) {
+  __syncthreads();                                                     // (the LDS arrays of the block before are free)
+  const uint32_t r0 = n_r0, r1 = n_r1, nr = r1 - r0;
+  if (tid < 64u) {                                                     // the first wave: run lengths, their exclusive prefix by a wave scan
+    const bool in = tid < np;
+    const uint32_t l0 = in ? n_l0 : 0u, len = in ? n_len : 0u;
+    uint32_t incl = len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)tid >= d) incl += o; }
+    s_lo[tid] = l0; s_pre[tid] = in ? incl - len : 0xFFFFFFFFu;
+    if (tid == 63u) { if (np < 64u) s_pre[np] = incl; s_pre[XPMAX] = np < 64u ? 0xFFFFFFFFu : incl; }     // (lanes >= np add nothing: lane 63 holds the total)
+  }
+  for (uint32_t q = tid * 4u; q < m_slots; q += XM_CT * 4u) *(uint32_t*)(flag + q) = 0u;
+  // the offsets of this thread's rows (rows tid, tid + 256, ...): loaded now, used after the partials are in LDS
+  uint32_t o0[XMW_RPT], o1[XMW_RPT];
+#pragma unroll
+  for (int j = 0; j < XMW_RPT; j++) {
+    const uint32_t i = tid + (uint32_t)j * XM_CT; const bool live = i < nr;
+    o0[j] = live ? (uint32_t)rowoff[r0 + i] : 0u;
+    o1[j] = live && i + 1 < nr ? (uint32_t)rowoff[r0 + i + 1] : 0u;   // (the block's last row ends at `total`: patched below)
+  }
+  __syncthreads();
+  const uint32_t total = s_pre[np];
+  bb += stride; const uint32_t b_next = block_of(bb);
+  fetch_bounds(b_next);                                                // (in flight together with this block's partials; consumed at the top of the next round)
+  // phase 1: the block's sub-rows as one index space over the np runs, four consecutive positions per thread and step, two steps in flight
+  auto run_of = [&](uint32_t t) __attribute__((always_inline)) -> uint32_t {      // the last run k with s_pre[k] <= t (t < total)
+    uint32_t k = 0;
+#pragma unroll
+    for (uint32_t step = 32u; step; step >>= 1) { const uint32_t cand = k + step; k = s_pre[cand] <= t ? cand : k; }
+    return k;
+  };
+  for (uint32_t base = 0; base < total; base += 2u * XM_CT * 4u) {
+    T v[2][4]; uint32_t sl[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+      const uint32_t t = base + (tid + (uint32_t)g * XM_CT) * 4u;
+      uint32_t src[4]; bool ok[4];
+      if (t < total) {
+        const uint32_t k = run_of(t), s0 = s_lo[k] + (t - s_pre[k]);
+        if (t + 3u < s_pre[k + 1]) {                                   // all four in run k (the common case)
+#pragma unroll
+          for (int e = 0; e < 4; e++) { src[e] = s0 + (uint32_t)e; ok[e] = true; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) { const uint32_t te = t + (uint32_t)e; ok[e] = te < total; const uint32_t ke = ok[e] ? run_of(te) : 0u; src[e] = ok[e] ? s_lo[ke] + (te - s_pre[ke]) : 0u; }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) { src[e] = 0u; ok[e] = false; }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) { v[g][e] = ok[e] ? partial[src[e]] : T(); sl[g][e] = ok[e] ? (uint32_t)slot[src[e]] : 0xFFFFFFFFu; }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; g++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) if (sl[g][e] != 0xFFFFFFFFu) vals[sl[g][e]] = v[g][e];
+  }
+  // ... and the row starts
+#pragma unroll
+  for (int j = 0; j < XMW_RPT; j++) {
+    const uint32_t i = tid + (uint32_t)j * XM_CT;
+    if (i < nr && i + 1 == nr) o1[j] = total;
+    if (i < nr && o1[j] > o0[j]) flag[o0[j]] = 1;
+  }
+  __syncthreads();
+  // phase 2: thread t scans the slots [q0, q1) of its chunk front to back (an odd chunk length: the threads' accesses fall in different banks)
+  const uint32_t chunk = ((total + XM_CT - 1) / XM_CT) | 1u;
+  const uint32_t q0 = tid * chunk < total ? tid * chunk : total, q1 = q0 + chunk < total ? q0 + chunk : total;
+  uint32_t first = WP_NONE;                                            // the first row start inside my chunk
+  {
+    T acc = sr.identity;
+    for (uint32_t q = q0; q < q1; q++) {
+      const T v = vals[q]; const bool f = flag[q] != 0;
+      acc = f ? v : sr.add(acc, v);
+      vals[q] = acc;
+      first = f && first == WP_NONE ? q : first;
+    }
+    s_tsum[tid] = acc; s_hasflag[tid] = first != WP_NONE ? 1 : 0;
+  }
+  __syncthreads();
+  // a chunk that begins inside a row: its leading piece — up to its first row start, or all of it — continues a row of the chunks before.
+  // If the row ENDS with that piece (the next slot starts a row, or the block ends), its last slot must hold the whole row: what the chunks
+  // before hold of it (their totals, walking back to the chunk the row starts in) is added there.  If the row goes on, the chunk's total
+  // carries it.
+  {
+    const uint32_t lead_end = first != WP_NONE ? first : q1;
+    const bool ends_row = lead_end == total || flag[lead_end < total ? lead_end : 0u] != 0;
+    if (q1 > q0 && first != q0 && ends_row) {
+      T c = sr.identity;
+      for (uint32_t t = tid; t > 0;) { t--; c = sr.add(s_tsum[t], c); if (s_hasflag[t]) break; }
+      vals[lead_end - 1u] = sr.add(c, vals[lead_end - 1u]);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < XMW_RPT; j++) {
+    const uint32_t i = tid + (uint32_t)j * XM_CT;
+    if (i < nr) {
+      const uint32_t r = r0 + i;
+      const bool has = o1[j] > o0[j]; const T acc = has ? vals[o1[j] - 1u] : T();
+      if constexpr (EPI == 0) { y[r] = acc; ypres[r] = has ? 1 : 0; }
+      else if constexpr (EPI == 1) { if (has) y[r] = sr.add(y[r], acc); }
+      else { y[r] = has ? sr.add(fill, acc) : fill; ypres[r] = 1; }
+    }
+  }
+  b = b_next;
+  }     // blocks of this workgroup
 }
 
 // which instantiation of the tile pipeline runs.  The product uses the defaults; GRB_MI355X_XT=d<depth>w<waves>[e<exp>] picks
@@ -645,14 +762,16 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
   const uint32_t n = M.ncols; const uint64_t nnz = M.nnz;
   constexpr uint32_t H = xt_hot<T>::H;
   const int S = force_S ? force_S : xp_subpanels<T>(n); const uint32_t NP = (uint32_t)(XP * S);
-  P->S = S; P->NP = (int)NP;
+  const bool own = S > 1 && wp_env("GRB_MI355X_XOWN", 0) != 0;
+  const uint32_t NS = own ? NP : (uint32_t)XP, vps = NP / NS;       // streams, virtual panels per stream
+  P->S = S; P->NP = (int)NP; P->NS = (int)NS; P->own = own;
   // 1. column counts; the 128-byte lines of u dealt to the (virtual) panels (equal entry counts); every XCD's columns ranked by frequency
   const uint32_t line = 128 / (uint32_t)sizeof(T), nlines = (n + line - 1) / line;
   uint32_t lshift = 0; while ((1u << lshift) < line) lshift++;
-  DevBuf cnt((size_t)n * 4 + 4), code((size_t)n * 4 + 4), cstart((XP + 1) * 4), pol((size_t)nlines + 8);
-  P->hot_cols.alloc((size_t)XP * H * 4 + 4);
+  DevBuf cnt((size_t)n * 4 + 4), code((size_t)n * 4 + 4), cstart((XPMAX + 1) * 4), pol((size_t)nlines + 8);
+  P->hot_cols.alloc((size_t)NS * H * 4 + 4);
   GRB_HIP(hipMemsetAsync(cnt.p, 0, (size_t)n * 4 + 4, stream()));
-  GRB_HIP(hipMemsetAsync(P->hot_cols.p, 0, (size_t)XP * H * 4 + 4, stream()));
+  GRB_HIP(hipMemsetAsync(P->hot_cols.p, 0, (size_t)NS * H * 4 + 4, stream()));
   { DevBuf sorted(nnz * 4 + 4), first((size_t)n * 4 + 4);
     int cb = 1; while ((1ull << cb) < (unsigned long long)n) cb++;
     sort_keys_u32(M.col.as<uint32_t>(), sorted.as<uint32_t>(), nnz, cb);
@@ -668,11 +787,12 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
     hipLaunchKernelGGL(k_xp_lpt, dim3(1), dim3(256), 0, stream(), negw2.as<uint32_t>(), ntop, NP, (uint32_t)S, (uint8_t*)dtop.p);
     hipLaunchKernelGGL(k_xp_deal_lines, dim3(grid_n(nlines)), dim3(256), 0, stream(), lsorted.as<uint32_t>(), nlines, (const uint8_t*)dtop.p, ntop, NP, (uint32_t)S, (uint8_t*)pol.p);
     DevBuf k32((size_t)n * 4 + 4), k32o((size_t)n * 4 + 4), cin((size_t)n * 4 + 4), cout((size_t)n * 4 + 4);
-    hipLaunchKernelGGL(k_xp_column_keys, dim3(grid_n(n)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, line, (const uint8_t*)pol.p, (uint32_t)S, k32.as<uint32_t>(), cin.as<uint32_t>());
-    sort_pairs_u32(k32.as<uint32_t>(), k32o.as<uint32_t>(), cin.as<uint32_t>(), cout.as<uint32_t>(), n, 23);
-    GRB_HIP(hipMemsetAsync(cstart.p, 0xFF, (XP + 1) * 4, stream()));
+    hipLaunchKernelGGL(k_xp_column_keys, dim3(grid_n(n)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, line, (const uint8_t*)pol.p, vps, k32.as<uint32_t>(), cin.as<uint32_t>());
+    int kbits = 20; while ((1u << (kbits - 20)) < NS) kbits++;                 // stream id above the 20 count bits
+    sort_pairs_u32(k32.as<uint32_t>(), k32o.as<uint32_t>(), cin.as<uint32_t>(), cout.as<uint32_t>(), n, kbits);
+    GRB_HIP(hipMemsetAsync(cstart.p, 0xFF, (XPMAX + 1) * 4, stream()));
     hipLaunchKernelGGL(k_xp_panel_starts, dim3(grid_n(n)), dim3(256), 0, stream(), k32o.as<uint32_t>(), n, cstart.as<uint32_t>());
-    hipLaunchKernelGGL(k_xp_fix_starts, dim3(1), dim3(1), 0, stream(), cstart.as<uint32_t>(), n);
+    hipLaunchKernelGGL(k_xp_fix_starts, dim3(1), dim3(1), 0, stream(), cstart.as<uint32_t>(), n, NS);
     hipLaunchKernelGGL(k_xp_column_codes, dim3(grid_n(n)), dim3(256), 0, stream(), k32o.as<uint32_t>(), cout.as<uint32_t>(), n, H, cstart.as<uint32_t>(), code.as<uint32_t>(), P->hot_cols.as<uint32_t>());
   }   // (the temporaries return to the pool; reuse is stream-ordered)
   // 2. row of every entry
@@ -682,7 +802,7 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
   inclusive_scan_max_u32(rowidx.as<uint32_t>(), rowidx.as<uint32_t>(), nnz);
   // 2b. sub-panels: in which virtual panels every row has cold entries (the entries the LDS tables serve then ride with them)
   DevBuf rowmask;
-  if (S > 1) {
+  if (S > 1 && !own) {
     rowmask.alloc(((size_t)M.nrows + 1) * 8);
     GRB_HIP(hipMemsetAsync(rowmask.p, 0, ((size_t)M.nrows + 1) * 8, stream()));
     hipLaunchKernelGGL(k_xp_rowmask, dim3(grid_n(nnz)), dim3(256), 0, stream(), M.col.as<uint32_t>(), rowidx.as<uint32_t>(), code.as<uint32_t>(), (const uint8_t*)pol.p, nnz, H, lshift,
@@ -691,37 +811,37 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
   // 3. counting sweep, scans, the sizes (first host round trip)
   const uint32_t nunits = (uint32_t)((nnz + XP_UNIT - 1) / XP_UNIT);
   const size_t nslots = (size_t)NP * nunits;
-  DevBuf ne((nslots + 1) * 4), escan((nslots + 1) * 4), lastkey(nslots * 8 + 8), carry(nslots * 8 + 8), picked((XPMAX + 1 + XP + 1) * 4);
+  DevBuf ne((nslots + 1) * 4), escan((nslots + 1) * 4), lastkey(nslots * 8 + 8), carry(nslots * 8 + 8), picked(2 * (XPMAX + 1) * 4);
   XpSweep<T> sw{};
   sw.col = M.col.as<uint32_t>(); sw.rowidx = rowidx.as<uint32_t>(); sw.code = code.as<uint32_t>(); sw.val = with_vals ? M.val.as<T>() : nullptr; sw.nnz = nnz; sw.nunits = nunits;
-  sw.np = NP; sw.S = (uint32_t)S; sw.H = H; sw.lshift = lshift; sw.pol = (const uint8_t*)pol.p; sw.rowmask = (const unsigned long long*)rowmask.p;
+  sw.np = NP; sw.S = (uint32_t)S; sw.H = H; sw.lshift = lshift; sw.own = own ? 1u : 0u; sw.pol = (const uint8_t*)pol.p; sw.rowmask = (const unsigned long long*)rowmask.p;
   sw.ne = ne.as<uint32_t>(); sw.lastkey = (unsigned long long*)lastkey.p; sw.escan = escan.as<uint32_t>(); sw.carry = (const unsigned long long*)carry.p;
   GRB_HIP(hipMemsetAsync(ne.as<uint32_t>() + nslots, 0, 4, stream()));
   hipLaunchKernelGGL((k_xp_sweep<T, false>), dim3(nunits), dim3(XP_ST), 0, stream(), sw);
   exclusive_scan_u32(ne.as<uint32_t>(), escan.as<uint32_t>(), nslots + 1);
   exclusive_scan_max_u64((const uint64_t*)lastkey.p, (uint64_t*)carry.p, nslots);
-  hipLaunchKernelGGL(k_xp_pick, dim3(1), dim3(128), 0, stream(), escan.as<uint32_t>(), nunits, NP, cstart.as<uint32_t>(), picked.as<uint32_t>());
-  uint32_t hp[XPMAX + 1 + XP + 1];
+  hipLaunchKernelGGL(k_xp_pick, dim3(1), dim3(128), 0, stream(), escan.as<uint32_t>(), nunits, NP, cstart.as<uint32_t>(), NS, picked.as<uint32_t>());
+  uint32_t hp[2 * (XPMAX + 1)];
   GRB_HIP(hipMemcpyAsync(hp, picked.p, sizeof(hp), hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
   const uint32_t wpp = (uint32_t)(ncu / XP) * xt_variant().waves;       // waves per panel
-  uint32_t kt[XP]; uint64_t nchunks_total = 0;
+  uint32_t kt[XPMAX]; uint64_t nchunks_total = 0;
   XpStarts vstart{};                                                     // where every virtual panel begins in the store
   P->tbase[0] = 0;
-  for (int k = 0; k < XP; k++) {
-    P->ne[k] = hp[(k + 1) * S] - hp[k * S];                              // a physical panel = its S sub-panels, one after the other
+  for (uint32_t k = 0; k < NS; k++) {
+    P->ne[k] = hp[(k + 1) * vps] - hp[k * vps];                          // a stream = its virtual panels, one after the other
     P->ntiles[k] = (uint32_t)((P->ne[k] + WP_ENT - 1) / WP_ENT);
     P->tbase[k + 1] = P->tbase[k] + P->ntiles[k];
     const uint32_t nk = hp[XPMAX + 1 + k + 1] - hp[XPMAX + 1 + k]; P->nhot[k] = nk < H ? nk : H;
     kt[k] = wp_chunk_tasks(P->ntiles[k], wpp);
     nchunks_total += (P->ntiles[k] + kt[k] - 1) / kt[k];
-    for (int sp = 0; sp < S; sp++) {
-      const int vp = k * S + sp;
-      sw.vpoff[vp] = hp[vp] - hp[k * S]; sw.ebase[vp] = (uint64_t)P->tbase[k] * WP_ENT + sw.vpoff[vp]; sw.chunk_entries[vp] = kt[k] * (uint32_t)WP_ENT;
+    for (uint32_t sp = 0; sp < vps; sp++) {
+      const uint32_t vp = k * vps + sp;
+      sw.vpoff[vp] = hp[vp] - hp[k * vps]; sw.ebase[vp] = (uint64_t)P->tbase[k] * WP_ENT + sw.vpoff[vp]; sw.chunk_entries[vp] = kt[k] * (uint32_t)WP_ENT;
       vstart.v[vp] = sw.ebase[vp];
     }
   }
-  vstart.v[NP] = (uint64_t)P->tbase[XP] * WP_ENT;
-  const uint32_t ntiles = P->tbase[XP];
+  vstart.v[NP] = (uint64_t)P->tbase[NS] * WP_ENT;
+  const uint32_t ntiles = P->tbase[NS];
   const size_t nstore = (size_t)ntiles * WP_ENT + 64;
   // 4. scattering sweep
   DevBuf rowtmp(nstore * 4);
@@ -766,17 +886,20 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
     hipLaunchKernelGGL(k_xp_run_starts, dim3(grid_n(F)), dim3(256), 0, stream(), skey.as<uint32_t>(), F, first.as<uint32_t>());
     hipLaunchKernelGGL(k_xp_run_lengths, dim3(grid_n(F)), dim3(256), 0, stream(), skey.as<uint32_t>(), F, first.as<uint32_t>(), rcnt.as<uint32_t>());
     exclusive_scan_u32(rcnt.as<uint32_t>(), rfirst.as<uint32_t>(), (uint64_t)nr + 1);                 // row-major position of every row's first sub-row
-    hipLaunchKernelGGL(k_xm_weights, dim3(grid_n((uint64_t)nr + 1)), dim3(256), 0, stream(), rcnt.as<uint32_t>(), nr, w.as<uint32_t>());
+    // block size: XM_TARGET sub-rows in <= XM_ROWS rows for eight runs (k_xp_merge), XMW_TARGET in <= XMW_ROWS with sub-panels (k_xp_merge_wide)
+    const uint32_t m_target = NP <= (uint32_t)XP ? XM_TARGET : XMW_TARGET;
+    const uint32_t m_perrow = NP <= (uint32_t)XP ? XM_TARGET / XM_ROWS : XMW_TARGET / XMW_ROWS;       // weight of a row beside its sub-rows (caps the rows of a block at target / perrow)
+    hipLaunchKernelGGL(k_xm_weights, dim3(grid_n((uint64_t)nr + 1)), dim3(256), 0, stream(), rcnt.as<uint32_t>(), nr, m_perrow, w.as<uint32_t>());
     exclusive_scan_u32(w.as<uint32_t>(), Pw.as<uint32_t>(), (uint64_t)nr + 1);
-    hipLaunchKernelGGL(k_xm_newblock, dim3(grid_n((uint64_t)nr + 1)), dim3(256), 0, stream(), Pw.as<uint32_t>(), nr, nf.as<uint32_t>());
+    hipLaunchKernelGGL(k_xm_newblock, dim3(grid_n((uint64_t)nr + 1)), dim3(256), 0, stream(), Pw.as<uint32_t>(), nr, m_target, nf.as<uint32_t>());
     exclusive_scan_u32(nf.as<uint32_t>(), nfs.as<uint32_t>(), (uint64_t)nr + 1);
     hipLaunchKernelGGL(k_xm_max, dim3(grid_n(nr) > 1024u ? 1024u : grid_n(nr)), dim3(256), 0, stream(), rcnt.as<uint32_t>(), nr, dmax.as<uint32_t>());
     uint32_t hnb = 0, hmax = 0;
     GRB_HIP(hipMemcpyAsync(&hnb, nfs.as<uint32_t>() + nr, 4, hipMemcpyDeviceToHost, stream()));
     GRB_HIP(hipMemcpyAsync(&hmax, dmax.p, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
-    const uint64_t need = (uint64_t)XM_TARGET + hmax + XM_TARGET / XM_ROWS;
+    const uint64_t need = (uint64_t)m_target + hmax + m_perrow;
     P->m_slots = need <= XM_SLOTS ? XM_SLOTS : (uint32_t)((need + 255) / 256 * 256);
-    P->m_nblocks = hnb; P->m_ok = hnb > 0 && (uint64_t)P->m_slots * sizeof(T) <= 64u * 1024u && P->m_slots < 65536u && F < 0xFFFFFFF0ull;      // (16-bit slots; 64 KB of LDS at most)
+    P->m_nblocks = hnb; P->m_ok = hnb > 0 && (uint64_t)P->m_slots * (sizeof(T) + (S > 1 ? 1 : 0)) <= 64u * 1024u && P->m_slots < 65536u && F < 0xFFFFFFF0ull;      // (16-bit slots; 64 KB of LDS at most)
     if (P->m_ok) {
       P->m_bstart.alloc(((size_t)hnb + 1) * 4 + 4); P->m_blockptr.alloc(((size_t)hnb + 1) * NP * 4 + 4); P->m_slot.alloc(F * 2 + 4); P->m_rowoff.alloc((size_t)nr * 2 + 4);
       hipLaunchKernelGGL(k_xm_bstart, dim3(grid_n((uint64_t)nr + 1)), dim3(256), 0, stream(), nf.as<uint32_t>(), nfs.as<uint32_t>(), nr, hnb, P->m_bstart.as<uint32_t>());
@@ -818,10 +941,11 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
     if (!keep32) { P->pcol.reset(); P->trow.reset(); }
   }
   // 7. the panels' argument block and the per-call buffers
-  P->args.alloc(XP * sizeof(XtPanel<T>));
-  P->xhot.alloc((size_t)XP * H * sizeof(T) + 8); P->partial.alloc(P->F * sizeof(T) + 8);
-  XtPanel<T> ha[XP];
-  for (int k = 0; k < XP; k++) {
+  P->args.alloc(XPMAX * sizeof(XtPanel<T>));
+  P->xhot.alloc((size_t)NS * H * sizeof(T) + 8); P->partial.alloc(P->F * sizeof(T) + 8);
+  XtPanel<T> ha[XPMAX];
+  memset((void*)ha, 0, sizeof(ha));
+  for (uint32_t k = 0; k < NS; k++) {
     XtPanel<T>& a = ha[k];
     a.pcol = keep32 ? P->pcol.as<uint32_t>() + (size_t)P->tbase[k] * WP_ENT : nullptr; a.aval = with_vals ? P->pval.as<T>() + (size_t)P->tbase[k] * WP_ENT : nullptr;
     a.trow = keep32 ? P->trow.as<uint32_t>() + P->tbase[k] : nullptr; a.xhot = P->xhot.as<T>() + (size_t)k * H;
@@ -829,12 +953,12 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
     a.extras = c16 ? P->extras.as<uint16_t>() : nullptr; a.nextras = P->ncold;
     a.nnz = (uint32_t)P->ne[k]; a.ntiles = P->ntiles[k]; a.tiles_per_chunk = kt[k]; a.nhot = P->nhot[k];
     a.static_pct = wp_env("GRB_MI355X_WP_STATIC", WP_STATIC_PCT);
-    a.interleave = wp_env("GRB_MI355X_XT_INTERLEAVE", S > 1 ? 1u : 0u);      // sub-panels: the waves of the XCD must walk the stream front to back together
+    a.interleave = wp_env("GRB_MI355X_XT_INTERLEAVE", vps > 1 ? 1u : 0u);    // sub-panels inside a stream: the waves of the XCD must walk it front to back together
   }
   if (getenv("GRB_MI355X_VERBOSE"))
-    for (int k = 0; k < XP; k++)
-      fprintf(stderr, "[grb] xcd plan panel %d: entries %llu tiles %u chunk %u hot %u (sub-rows in all %llu, chunks %llu, sub-panels per XCD %d)\n", k, (unsigned long long)P->ne[k], P->ntiles[k], kt[k],
-              P->nhot[k], (unsigned long long)P->F, (unsigned long long)nchunks_total, S);
+    for (uint32_t k = 0; k < NS; k++)
+      fprintf(stderr, "[grb] xcd plan stream %u: entries %llu tiles %u chunk %u hot %u (sub-rows in all %llu, chunks %llu, sub-panels per XCD %d, %s)\n", k, (unsigned long long)P->ne[k], P->ntiles[k], kt[k],
+              P->nhot[k], (unsigned long long)P->F, (unsigned long long)nchunks_total, S, own ? "a table per sub-panel" : "a table per XCD");
   GRB_HIP(hipMemcpyAsync(P->args.p, ha, sizeof(ha), hipMemcpyHostToDevice, stream()));
   P->tsize = (int)sizeof(T); P->has_vals = with_vals;
   GRB_HIP(hipEventRecord(ev1, stream()));
@@ -853,8 +977,8 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
   if (!P || P->tsize != (int)sizeof(T) || (need_vals && !P->has_vals)) { build_xcd_plan<T>(M, ncu, need_vals); P = static_cast<XcdPlan*>(M.xcd.get()); }
   const bool uses_u = d.flip ? binop_uses_x(d.mulop) : binop_uses_y(d.mulop);
   constexpr uint32_t H = xt_hot<T>::H;
-  XtCall<T> call{(const T*)c.uval, M.ncols, 0u, P->partial.as<T>()};
-  if (uses_u) hipLaunchKernelGGL((k_xp_hot_gather<T>), dim3((XP * H + 255) / 256), dim3(256), 0, stream(), (const T*)c.uval, P->hot_cols.as<uint32_t>(), (uint32_t)(XP * H), P->xhot.as<T>());
+  XtCall<T> call{(const T*)c.uval, M.ncols, (uint32_t)(P->NS / XP), P->partial.as<T>()};
+  if (uses_u) hipLaunchKernelGGL((k_xp_hot_gather<T>), dim3(((uint32_t)P->NS * H + 255) / 256), dim3(256), 0, stream(), (const T*)c.uval, P->hot_cols.as<uint32_t>(), (uint32_t)P->NS * H, P->xhot.as<T>());
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;
     bool launched = false;
@@ -875,11 +999,13 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
     if (P->m_ok && (!old_merge || P->S > 1)) {
       const dim3 mg((P->m_nblocks + XP - 1) / XP * XP), mb(XM_CT); const size_t ml = (size_t)P->m_slots * sizeof(T);
       const uint32_t np = (uint32_t)P->NP;
+      static const uint32_t wg_per_cu = wp_env("GRB_MI355X_XMW_WGS", 6);
+      const dim3 mgw(std::min<uint32_t>(mg.x, (uint32_t)ncu * wg_per_cu / XP * XP));             // the wide merge is persistent
 #define XM_LAUNCH(EPI_, Y_, YP_, FILL_) { \
-        if (P->S > 1) hipLaunchKernelGGL((k_xp_merge<T, SR, EPI_, true>), mg, mb, ml, stream(), M.nrows, P->m_nblocks, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), P->m_slot.as<uint16_t>(), \
-                                         P->m_rowoff.as<uint16_t>(), P->partial.as<T>(), (Y_), (YP_), sr, (FILL_), np); \
-        else hipLaunchKernelGGL((k_xp_merge<T, SR, EPI_, false>), mg, mb, ml, stream(), M.nrows, P->m_nblocks, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), P->m_slot.as<uint16_t>(), \
-                                P->m_rowoff.as<uint16_t>(), P->partial.as<T>(), (Y_), (YP_), sr, (FILL_), np); }
+        if (P->S > 1) hipLaunchKernelGGL((k_xp_merge_wide<T, SR, EPI_>), mgw, mb, ml + P->m_slots, stream(), M.nrows, P->m_nblocks, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), \
+                                         P->m_slot.as<uint16_t>(), P->m_rowoff.as<uint16_t>(), P->partial.as<T>(), (Y_), (YP_), sr, (FILL_), np, P->m_slots); \
+        else hipLaunchKernelGGL((k_xp_merge<T, SR, EPI_>), mg, mb, ml, stream(), M.nrows, P->m_nblocks, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), P->m_slot.as<uint16_t>(), \
+                                P->m_rowoff.as<uint16_t>(), P->partial.as<T>(), (Y_), (YP_), sr, (FILL_)); }
       if (c.epi == 1 && c.epi_done) {
         XM_LAUNCH(1, (T*)c.epi_w, (uint8_t*)nullptr, T())
         *c.epi_done = true;
@@ -892,7 +1018,7 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
     } else
       hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3(nblocks), dim3(XP_CT), 0, stream(), M.nrows, P->blockptr.as<uint32_t>(), P->lrow.as<uint16_t>(), P->partial.as<T>(),
                          (T*)c.tval, c.tpres, sr);
-    g_last_plan += std::string("k_spmv_xcd<") + (sr.is_static ? "static" : "dynamic") + ",subrows=" + std::to_string(P->F) + (P->S > 1 ? ",subpanels=" + std::to_string(P->S) : std::string()) + "," + xcd_mapping() + "> ";
+    g_last_plan += std::string("k_spmv_xcd<") + (sr.is_static ? "static" : "dynamic") + ",subrows=" + std::to_string(P->F) + (P->S > 1 ? ",subpanels=" + std::to_string(P->S) + (P->own ? "/own-tables" : "") : std::string()) + "," + xcd_mapping() + "> ";
   });
   return true;
 }

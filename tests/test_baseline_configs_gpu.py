@@ -246,7 +246,7 @@ def test_batched_bc_rmat22_against_the_oracle(gb, torch_dev):
     want, odepth, osizes = O.fast_bc(rowptr.cpu().numpy().view(np.uint32), col.cpu().numpy().view(np.uint32), trp.cpu().numpy().view(np.uint32), tcol.cpu().numpy().view(np.uint32), sources)
     assert depth == odepth and depth >= 4
     assert sizes == osizes                                                       # the frontiers' patterns have the oracle's sizes, level by level
-    assert want.max() > 1e6
+    assert want.max() > 1e3
     assert np.allclose(got, want, rtol=1e-4, atol=1e-3), float(np.abs(got - want).max())
 
 

@@ -53,7 +53,9 @@ def part_a(scale, permute_seed=None):
         xs = rmat.values_torch(n, dev, seed=44, dtype=tdt)
         x = gb.Vector.from_dense_array((xs.data_ptr(), n), T, device=True)
         base = None
-        for S in [int(v) for v in args.subpanels.split(",")]:
+        for S in args.subpanels.split(","):
+            os.environ["GRB_MI355X_XOWN"] = "1" if S.endswith("o") else "0"      # "4o": four sub-panels per XCD, each with its own LDS table
+            own = S.endswith("o"); S = int(S.rstrip("o"))
             os.environ["GRB_MI355X_XS"] = str(S)
             A = gb.Matrix.from_csr(T, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
             w = gb.Vector.sparse(T, n)
@@ -61,7 +63,7 @@ def part_a(scale, permute_seed=None):
             t = timed(lambda: A.mxv(x, semiring=sr, out=w), args.reps)
             plan = gb.last_kernel_plan()
             y, pres = w.to_dense_arrays()
-            rec = {"part": "A", "scale": scale, "permuted": permute_seed is not None, "type": tname, "semiring": srname, "S": S, "ms": round(t, 4), "plan_build_ms": plan_ms(), "plan": plan}
+            rec = {"part": "A", "scale": scale, "permuted": permute_seed is not None, "type": tname, "semiring": srname, "S": S, "own_tables": own, "ms": round(t, 4), "plan_build_ms": plan_ms(), "plan": plan}
             uses_vals = srname == "PLUS_TIMES"
             alg = nnz * ((ts if uses_vals else 0) + 4) + (n + 1) * 4 + 2 * n * ts
             rec["alg_GBps"] = round(alg / t / 1e6, 1); rec["frac_of_8TBps"] = round(alg / t / 1e6 / 8000, 4)
@@ -90,7 +92,9 @@ def part_b(scale):
     torch.cuda.synchronize()
     print(json.dumps({"part": "B", "scale": scale, "nnz": nnz, "graph_build_s": round(time.perf_counter() - t0, 2)}), flush=True)
     base = None
-    for S in [int(v) for v in args.pr_subpanels.split(",")]:
+    for S in args.pr_subpanels.split(","):
+        os.environ["GRB_MI355X_XOWN"] = "1" if S.endswith("o") else "0"
+        own = S.endswith("o"); S = int(S.rstrip("o"))
         os.environ["GRB_MI355X_XS"] = str(S)
         A = gb.Matrix.from_csr(gb.FP32, n, n, rowptr.data_ptr(), col.data_ptr(), (ones.data_ptr(), nnz), device=True)
 
@@ -106,7 +110,7 @@ def part_b(scale):
         ms = sorted(times)[1] * 1e3
         alg = nnz * 4 + (n + 1) * 4 + n * 4 + n * 4 + 6 * n * 4
         rv = r.to_dense_arrays()[0]
-        rec = {"part": "B", "scale": scale, "S": S, "ms_per_iteration": round(ms, 4), "frac_of_8TBps": round(alg / ms / 1e6 / 8000, 4), "first_two_iterations_s": round(first, 3), "plan_build_ms": pm,
+        rec = {"part": "B", "scale": scale, "S": S, "own_tables": own, "ms_per_iteration": round(ms, 4), "frac_of_8TBps": round(alg / ms / 1e6 / 8000, 4), "first_two_iterations_s": round(first, 3), "plan_build_ms": pm,
                "plan": gb.last_kernel_plan()}
         if base is None:
             base = rv
