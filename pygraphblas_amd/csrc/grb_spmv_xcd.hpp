@@ -744,16 +744,25 @@ inline XtVariant xt_variant() {
   return v;
 }
 
-// sub-panels per XCD: GRB_MI355X_XS forces a value (1, 2, 4, 8); otherwise the power of two that brings an XCD's share of the operand
-// (ncols * sizeof(T) / 8) under GRB_MI355X_XS_TARGET_KB — whose default (0 = never) keeps S = 1: measured (profiles/r04_subpanels_scale25.txt)
-// S = 8 cuts the R-MAT-25 pipeline's memory-side reads from 7.2 to 2.6 GB and its time by only 8 %, which the longer merge gives back
-template <class T> int xp_subpanels(uint64_t ncols) {
+// sub-panels per XCD (each with its own LDS table).  GRB_MI355X_XS forces a value (1, 2, 4, 8).  Otherwise by the operand's length, from
+// the R-MAT measurements of round 4 (profiles/r04_subpanels.txt; ms per product S = 1 -> best S): 4-byte pattern product 2^23 columns
+// 0.294 -> 0.275 (S = 2), 2^24 0.702 -> 0.583 (4), 2^25 1.46 -> 0.95 (4; 8: 0.83 with a merge twice as long); 8-byte PLUS_TIMES 2^23
+// 0.557 -> 0.570 (worse), 2^24 1.270 -> 1.173 (4).  Below those sizes an XCD's share of the operand fits its L2 and the table covers most
+// entries: sub-panels only add sub-rows (R-MAT-22: +8 %).  The candidate is then CHECKED against the matrix (build_xcd_plan): it is taken
+// only if the larger tables would serve >= 8 % more of the entries — a matrix without popular columns gains nothing from them.
+template <class T> int xp_subpanels(uint64_t ncols, bool* forced_out) {
   const uint32_t forced = wp_env("GRB_MI355X_XS", 0);
-  if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return (int)forced;
-  const uint64_t target = (uint64_t)wp_env("GRB_MI355X_XS_TARGET_KB", 0) << 10, share = ncols * sizeof(T) / XP;
-  if (!target) return 1;
-  int S = 1; while (S < XPMAX / XP && share / S > target) S *= 2;
-  return S;
+  *forced_out = forced == 1 || forced == 2 || forced == 4 || forced == 8;
+  if (*forced_out) return (int)forced;
+  if (ncols >= (1ull << 24)) return 4;
+  if (sizeof(T) <= 4 && ncols >= (1ull << 23)) return 2;
+  return 1;
+}
+static __global__ void k_xp_neg(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* __restrict__ key) {
+  for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) key[c] = 0xFFFFFFFFu - cnt[c];
+}
+static __global__ void k_xp_unneg(uint32_t* __restrict__ key, uint32_t n) {
+  for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) key[c] = 0xFFFFFFFFu - key[c];
 }
 template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int force_S = 0) {
   auto grid_n = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 8192) b = 8192; return (unsigned)b; };
@@ -761,22 +770,39 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
   auto* P = new XcdPlan(); M.xcd.reset(P);
   const uint32_t n = M.ncols; const uint64_t nnz = M.nnz;
   constexpr uint32_t H = xt_hot<T>::H;
-  const int S = force_S ? force_S : xp_subpanels<T>(n); const uint32_t NP = (uint32_t)(XP * S);
-  const bool own = S > 1 && wp_env("GRB_MI355X_XOWN", 0) != 0;
-  const uint32_t NS = own ? NP : (uint32_t)XP, vps = NP / NS;       // streams, virtual panels per stream
-  P->S = S; P->NP = (int)NP; P->NS = (int)NS; P->own = own;
-  // 1. column counts; the 128-byte lines of u dealt to the (virtual) panels (equal entry counts); every XCD's columns ranked by frequency
+  bool forced = false;
+  int S = force_S ? force_S : xp_subpanels<T>(n, &forced);
+  // 1. column counts; the 128-byte lines of u dealt to the (virtual) panels (equal entry counts); every stream's columns ranked by frequency
   const uint32_t line = 128 / (uint32_t)sizeof(T), nlines = (n + line - 1) / line;
   uint32_t lshift = 0; while ((1u << lshift) < line) lshift++;
   DevBuf cnt((size_t)n * 4 + 4), code((size_t)n * 4 + 4), cstart((XPMAX + 1) * 4), pol((size_t)nlines + 8);
-  P->hot_cols.alloc((size_t)NS * H * 4 + 4);
   GRB_HIP(hipMemsetAsync(cnt.p, 0, (size_t)n * 4 + 4, stream()));
-  GRB_HIP(hipMemsetAsync(P->hot_cols.p, 0, (size_t)NS * H * 4 + 4, stream()));
   { DevBuf sorted(nnz * 4 + 4), first((size_t)n * 4 + 4);
     int cb = 1; while ((1ull << cb) < (unsigned long long)n) cb++;
     sort_keys_u32(M.col.as<uint32_t>(), sorted.as<uint32_t>(), nnz, cb);
     hipLaunchKernelGGL(k_xp_run_starts, dim3(grid_n(nnz)), dim3(256), 0, stream(), sorted.as<uint32_t>(), nnz, first.as<uint32_t>());
     hipLaunchKernelGGL(k_xp_run_lengths, dim3(grid_n(nnz)), dim3(256), 0, stream(), sorted.as<uint32_t>(), nnz, first.as<uint32_t>(), cnt.as<uint32_t>()); }
+  if (S > 1 && !forced && !force_S) {
+    // would S times the table slots serve noticeably more entries?  The counts in descending order, their running sum at 8 H and at 8 S H
+    // columns (the deal balances the panels, so a stream's H hottest columns are about the matrix's 8 S H hottest ones)
+    DevBuf k0((size_t)n * 4 + 4), k1((size_t)n * 4 + 4), ps((size_t)n * 4 + 4);
+    hipLaunchKernelGGL(k_xp_neg, dim3(grid_n(n)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, k0.as<uint32_t>());
+    sort_keys_u32(k0.as<uint32_t>(), k1.as<uint32_t>(), n, 32);
+    hipLaunchKernelGGL(k_xp_unneg, dim3(grid_n(n)), dim3(256), 0, stream(), k1.as<uint32_t>(), n);
+    exclusive_scan_u32(k1.as<uint32_t>(), ps.as<uint32_t>(), n);
+    const uint64_t a1 = std::min<uint64_t>((uint64_t)XP * H, n - 1), aS = std::min<uint64_t>((uint64_t)XP * S * H, n - 1);
+    uint32_t c1 = 0, cS = 0;
+    GRB_HIP(hipMemcpyAsync(&c1, ps.as<uint32_t>() + a1, 4, hipMemcpyDeviceToHost, stream()));
+    GRB_HIP(hipMemcpyAsync(&cS, ps.as<uint32_t>() + aS, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+    if ((double)(cS - c1) < 0.08 * (double)nnz) S = 1;
+    if (getenv("GRB_MI355X_VERBOSE")) fprintf(stderr, "[grb] xcd plan: tables serve %.1f %% of the entries with one per XCD, %.1f %% with %d per XCD -> S = %d\n", 100.0 * c1 / nnz, 100.0 * cS / nnz, (int)(aS / ((uint64_t)XP * H)), S);
+  }
+  const uint32_t NP = (uint32_t)(XP * S);
+  const bool own = S > 1 && wp_env("GRB_MI355X_XOWN", 1) != 0;      // a table per sub-panel (0: one per XCD, the entries it serves ride with their row's cold ones)
+  const uint32_t NS = own ? NP : (uint32_t)XP, vps = NP / NS;       // streams, virtual panels per stream
+  P->S = S; P->NP = (int)NP; P->NS = (int)NS; P->own = own;
+  P->hot_cols.alloc((size_t)NS * H * 4 + 4);
+  GRB_HIP(hipMemsetAsync(P->hot_cols.p, 0, (size_t)NS * H * 4 + 4, stream()));
   {
     DevBuf negw((size_t)nlines * 4 + 4), lid((size_t)nlines * 4 + 4), negw2((size_t)nlines * 4 + 4), lsorted((size_t)nlines * 4 + 4);
     hipLaunchKernelGGL(k_xp_line_weights, dim3(grid_n(nlines)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, line, nlines, negw.as<uint32_t>(), lid.as<uint32_t>());

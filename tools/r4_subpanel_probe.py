@@ -54,9 +54,12 @@ def part_a(scale, permute_seed=None):
         x = gb.Vector.from_dense_array((xs.data_ptr(), n), T, device=True)
         base = None
         for S in args.subpanels.split(","):
-            os.environ["GRB_MI355X_XOWN"] = "1" if S.endswith("o") else "0"      # "4o": four sub-panels per XCD, each with its own LDS table
-            own = S.endswith("o"); S = int(S.rstrip("o"))
-            os.environ["GRB_MI355X_XS"] = str(S)
+            if S == "a":                                                         # "a": the library's own choice
+                os.environ.pop("GRB_MI355X_XOWN", None); os.environ.pop("GRB_MI355X_XS", None); own = None
+            else:
+                os.environ["GRB_MI355X_XOWN"] = "1" if S.endswith("o") else "0"      # "4o": four sub-panels per XCD, each with its own LDS table
+                own = S.endswith("o"); S = int(S.rstrip("o"))
+                os.environ["GRB_MI355X_XS"] = str(S)
             A = gb.Matrix.from_csr(T, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
             w = gb.Vector.sparse(T, n)
             sr = getattr(T, srname)
@@ -93,9 +96,12 @@ def part_b(scale):
     print(json.dumps({"part": "B", "scale": scale, "nnz": nnz, "graph_build_s": round(time.perf_counter() - t0, 2)}), flush=True)
     base = None
     for S in args.pr_subpanels.split(","):
-        os.environ["GRB_MI355X_XOWN"] = "1" if S.endswith("o") else "0"
-        own = S.endswith("o"); S = int(S.rstrip("o"))
-        os.environ["GRB_MI355X_XS"] = str(S)
+        if S == "a":
+            os.environ.pop("GRB_MI355X_XOWN", None); os.environ.pop("GRB_MI355X_XS", None); own = None
+        else:
+            os.environ["GRB_MI355X_XOWN"] = "1" if S.endswith("o") else "0"
+            own = S.endswith("o"); S = int(S.rstrip("o"))
+            os.environ["GRB_MI355X_XS"] = str(S)
         A = gb.Matrix.from_csr(gb.FP32, n, n, rowptr.data_ptr(), col.data_ptr(), (ones.data_ptr(), nnz), device=True)
 
         def degrees():
