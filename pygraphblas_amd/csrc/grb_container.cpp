@@ -171,9 +171,9 @@ bool any_true_lookup(GrB_Vector u, bool* value) {
   *value = u->lor_state == 3; return true;
 }
 
-void vec_invalidate_device(GrB_Vector v) { vec_overwritten(v); v->holes_zero = false; v->lor_state = 0; v->abs_bound = -1; v->dev_valid = false; v->dval.reset(); v->dpres.reset(); v->dnvals = 0; v->dnvals_known = true; v->fe_lb = 0; v->fe_lb_key = 0; }
+void vec_invalidate_device(GrB_Vector v) { vec_overwritten(v); v->holes_zero = false; v->lor_state = 0; v->abs_bound = -1; v->small_valid = false; v->dev_valid = false; v->dval.reset(); v->dpres.reset(); v->dnvals = 0; v->dnvals_known = true; v->fe_lb = 0; v->fe_lb_key = 0; }
 void vec_invalidate_host(GrB_Vector v) {
-  vec_overwritten(v); v->holes_zero = false; v->lor_state = 0; v->abs_bound = -1; v->dev_elem_ops = 0;
+  vec_overwritten(v); v->holes_zero = false; v->lor_state = 0; v->abs_bound = -1; v->small_valid = false; v->dev_elem_ops = 0;
   v->host_valid = false; v->hi.clear(); v->hx.clear(); v->pending.clear(); v->hi.shrink_to_fit(); v->hx.shrink_to_fit();
 }
 void vec_to_host(GrB_Vector v) {
@@ -205,7 +205,8 @@ void vec_to_device(GrB_Vector v) {
     // staging n zero bytes on the host and copying them cost 2 x 15 ms per PageRank run at R-MAT-25 and half of a BFS at R-MAT-22
     const uint32_t k = (uint32_t)v->hi.size();
     GRB_HIP(hipMemsetAsync(v->dval.p, 0, n * ts, stream())); GRB_HIP(hipMemsetAsync(v->dpres.p, 0, n, stream()));
-    if (k) {
+    if (k && k <= 16 && ts <= 8) scatter_entries_small(k, v->hi.data(), v->hx.data(), ts, v->dval.p, v->dpres.as<uint8_t>());
+    else if (k) {
       std::vector<uint32_t> i32(k); for (uint32_t e = 0; e < k; e++) i32[e] = (uint32_t)v->hi[e];
       DevBuf di((size_t)k * 4), dx((size_t)k * ts);
       GRB_HIP(hipMemcpyAsync(di.p, i32.data(), (size_t)k * 4, hipMemcpyHostToDevice, stream()));
@@ -214,6 +215,15 @@ void vec_to_device(GrB_Vector v) {
       GRB_HIP(hipStreamSynchronize(stream()));                          // the host staging vectors go out of scope
     }
     v->dnvals = k; v->dnvals_known = true; v->dev_valid = true;
+    if (k <= 64) {                                                       // the entries as a list (see small_idx)
+      v->small_idx.assign(k, 0); bool truthy = true;
+      for (uint32_t e = 0; e < k; e++) {
+        v->small_idx[e] = (uint32_t)v->hi[e];
+        bool nz = false; for (size_t b = 0; b < ts; b++) nz = nz || v->hx[(size_t)e * ts + b] != 0;
+        truthy = truthy && nz;
+      }
+      v->small_valid = true; v->small_truthy = truthy;
+    }
     return;
   }
   std::vector<uint8_t> val(n * ts, 0), pres(n, 0);

@@ -169,6 +169,11 @@ struct GrB_Vector_opaque {
   // an upper bound of |value| over the stored entries, left behind by the "big holes" product that wrote them (grb_mxv.cpp: the next
   // sweep of a shortest-path loop needs no range kernel and no read-back); < 0 = unknown.  Reset wherever lor_state is.
   double abs_bound = -1;
+  // the device image's entries as a list, when it has at most 64 of them and the list is known for free (uploaded from a small host mirror;
+  // `v(q) = s` over the entries of such a q): the first level of a BFS then pushes from the list — no frontier compaction (a flag pass,
+  // a scan and a scatter over all n positions), no counting kernel, no read-back.  small_truthy: every listed value is non-zero.
+  // Reset wherever lor_state is.
+  std::vector<uint32_t> small_idx; bool small_valid = false, small_truthy = false;
   uint32_t dev_elem_ops = 0;   // element reads served on the device in a row (grb_container.cpp: after a few dozen the host mirror takes over)
   int sparsity_control = 15;
   std::string err;
@@ -233,6 +238,8 @@ void vec_cast_fill_values(int dst_code, void* dst, int src_code, const void* src
 void build_allow(uint64_t n, int mcode, const void* mval, const uint8_t* mpres, bool structural,
                  bool complement, uint8_t* allow);
 uint64_t count_present(const uint8_t* pres, uint64_t n);
+void scatter_entries_small(uint32_t k, const uint64_t* idx_host, const uint8_t* vals_host, size_t ts, void* val, uint8_t* pres);   // k <= 16, ts <= 8: entries passed as kernel arguments (no staging, no synchronisation)
+void write_small_list(uint32_t k, const uint32_t* idx_host, uint32_t* out_dev);   // k <= 64 indices passed as kernel arguments
 void scatter_entries(uint32_t k, const uint32_t* idx_dev, const void* vals_dev, size_t ts, void* val, uint8_t* pres);   // val[idx[e]] = vals[e], pres[idx[e]] = 1
 uint64_t frontier_edges(const uint8_t* pres, const uint32_t* rowptr, uint64_t n);
 uint64_t frontier_edges_and_count(const uint8_t* pres, const uint32_t* rowptr, uint64_t n, uint64_t* count);

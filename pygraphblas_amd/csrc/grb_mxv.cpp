@@ -36,14 +36,12 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
 
   DevBuf allow_buf, ubool; bool nothing = false;
   const uint8_t* allow = nullptr;
-  if (mask && mask == u && sd.zcode == T_BOOL && u->type->code != T_BOOL && mr) {
-    // the mask is also the operand and the semiring is Boolean (`v.vxm(A, mask=v, desc=RC)` on the UINT8 level vector of a BFS): its
-    // allow bytes and its values as BOOL come out of ONE pass instead of a k_allow and a k_cast
-    vec_to_device(u);
-    allow_buf.alloc(mr); ubool.alloc(mr + 1);
-    build_allow_and_bool(mr, u->type->code, u->dval.p, u->dpres.as<uint8_t>(), dv.mask_struct, dv.mask_comp, allow_buf.as<uint8_t>(), ubool.as<uint8_t>());
-    allow = allow_buf.as<uint8_t>();
-  } else allow = vector_allow(mask, dv, mr, allow_buf, &nothing);
+  // the mask is also the operand and the semiring is Boolean (`v.vxm(A, mask=v, desc=RC)` on the UINT8 level vector of a BFS): its allow
+  // bytes and its values as BOOL come out of ONE pass instead of a k_allow and a k_cast — made below, once the direction is known: the
+  // masked pull of a one-byte vector reads the vector itself and needs neither (SpmvCall::fm_val)
+  const bool mask_is_u = mask && mask == u && sd.zcode == T_BOOL && u->type->code != T_BOOL && mr;
+  if (mask_is_u) vec_to_device(u);
+  else allow = vector_allow(mask, dv, mr, allow_buf, &nothing);
   if (nothing) {   // no mask + complement: nothing may be written; replace clears w
     if (dv.replace) { w->hi.clear(); w->hx.clear(); w->pending.clear(); w->host_valid = true; vec_invalidate_device(w); }
     return;
@@ -73,13 +71,29 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   // considered only for a sparse operand and a monoid with a native atomic; it is taken when the edges leaving the
   // frontier (an exact count on the device) are < 1/16 of all entries.
   bool push = false;
+  // an operand of at most 64 entries known as a list on the host (the first level of a BFS): push without counting its edges — 64 rows,
+  // the long ones split over all workgroups, are never worth a pull over every row of a large matrix
+  const bool tiny = u->small_valid && u->small_idx.size() == u_nvals && u_nvals <= 64 && (uint64_t)A->csr.nnz >= (1u << 20) && (useT || A->csc.valid);
   if (method == SPMV_PUSH) push = spmspv_push_supported(sd);
   else if (method == SPMV_AUTO && !stays_pull && spmspv_push_supported(sd) && !u_full && u_nvals * 16 < (uint64_t)A->csr.nnz + 16) {
-    const DevCSR& P = useT ? A->csr : mat_csc(A);
-    const uint64_t fe = fe_cached != ~0ull ? fe_cached : frontier_edges(u->dpres.as<uint8_t>(), P.rowptr.as<uint32_t>(), u->n);
-    push = fe * 16 < P.nnz + 16;
+    if (tiny) push = true;
+    else {
+      const DevCSR& P = useT ? A->csr : mat_csc(A);
+      const uint64_t fe = fe_cached != ~0ull ? fe_cached : frontier_edges(u->dpres.as<uint8_t>(), P.rowptr.as<uint32_t>(), u->n);
+      push = fe * 16 < P.nnz + 16;
+    }
   }
 
+  bool fused_mask = false;
+  if (mask_is_u) {
+    const DevCSR& R0 = useT ? mat_csc(A) : A->csr;
+    fused_mask = !push && !accum && dv.replace && type_size(u->type->code) == 1 && spmv_rowlane_applies(R0, sd, method);
+    if (!fused_mask) {
+      allow_buf.alloc(mr); ubool.alloc(mr + 1);
+      build_allow_and_bool(mr, u->type->code, u->dval.p, u->dpres.as<uint8_t>(), dv.mask_struct, dv.mask_comp, allow_buf.as<uint8_t>(), ubool.as<uint8_t>());
+      allow = allow_buf.as<uint8_t>();
+    }
+  }
   const size_t zs = type_size(sd.zcode);
   DevBuf tval(mr * zs + 1), tpres(mr + 1), ucast, acast;
   // An operand with holes whose product is accumulated into a full vector with the monoid's own operator, no mask (PageRank:
@@ -165,7 +179,8 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
     ucast.alloc(u->n * zs + 1);
     vec_cast_fill_values(sd.zcode, ucast.p, u->type->code, u->dval.p, u->dpres.as<uint8_t>(), u->n, sd.identity);   // (identity of PLUS / LOR is the 0 / false the two other cases need)
     uval = ucast.p;
-  } else if (uses_u) uval = ubool.p ? ubool.p : cast_values(sd.zcode, u->type->code, u->dval.p, u->n, ucast);
+  } else if (uses_u && fused_mask) uval = nullptr;                 // (the kernel reads the vector's own bytes)
+  else if (uses_u) uval = ubool.p ? ubool.p : cast_values(sd.zcode, u->type->code, u->dval.p, u->n, ucast);
 
   SpmvCall call{};
   call.uval = uval; call.allow = allow; call.tval = tval.p; call.tpres = tpres.as<uint8_t>(); call.method = method;
@@ -178,11 +193,13 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
     // push walks rows of M^T:  M^T = useT ? A : A^T
     DevCSR& P = useT ? A->csr : const_cast<DevCSR&>(mat_csc(A));
     call.M = &P; call.upres = u->dpres.as<uint8_t>();
+    if (u->small_valid && u->small_idx.size() == u_nvals) { call.small_idx = u->small_idx.data(); call.small_n = (uint32_t)u_nvals; }
     call.aval = uses_a ? cast_values(sd.zcode, A->type->code, P.val.p, P.nnz, acast) : nullptr;
     spmspv_push(call, sd, u_nvals);
   } else {
     DevCSR& R = useT ? const_cast<DevCSR&>(mat_csc(A)) : A->csr;
     call.M = &R; call.upres = (u_full || fill_holes || big_holes) ? nullptr : u->dpres.as<uint8_t>();
+    if (fused_mask) { call.upres = u->dpres.as<uint8_t>(); call.fm_val = u->dval.as<uint8_t>(); call.fm_flags = (uint8_t)((dv.mask_struct ? 1 : 0) | (dv.mask_comp ? 2 : 0)); }
     call.aval = uses_a ? cast_values(sd.zcode, A->type->code, R.val.p, R.nnz, acast) : nullptr;
     // `w += M (+).(x) u` with the monoid's own operator into a full w, no mask: the kernel that writes the row sums can apply the
     // accumulator in the same store — and when w is a fill that was never written (`r[:] = teleport` before the product of

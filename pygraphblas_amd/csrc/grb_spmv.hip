@@ -69,6 +69,13 @@ void spmv_build_plan(DevCSR& M) {
   M.has_plan = true;
 }
 
+bool spmv_rowlane_applies(const DevCSR& M, const SemiringDesc& d, int method) {
+  if (method != SPMV_AUTO || !d.has_terminal) return false;
+  const double avg = M.nrows ? (double)M.nnz / M.nrows : 0;
+  static const bool no_lane = getenv("GRB_MI355X_NO_ROWLANE") && atoi(getenv("GRB_MI355X_NO_ROWLANE")) != 0;
+  return avg <= 96 && !no_lane;
+}
+
 void spmv_pull(const SpmvCall& c, const SemiringDesc& d) {
   dispatch_type(d.zcode, [&]<class T>() { run_pull<T>(c, d); });
   GRB_HIP(hipGetLastError());
@@ -93,11 +100,16 @@ void spmspv_push(const SpmvCall& c, const SemiringDesc& d, uint64_t u_nvals) {
   // c.M here is the CSR whose ROWS are indexed like u (i.e. the transpose of the pull operand)
   DevCSR& M = *c.M; const uint64_t nu = M.nrows, nout = M.ncols;
   auto grid_of = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 4096) b = 4096; return (unsigned)b; };
-  DevBuf flags(nu * 4 + 4), pos(nu * 4 + 4), fidx((u_nvals + 1) * 4), longlist((u_nvals + 2) * 4);
+  DevBuf flags, pos, fidx((u_nvals + 1) * 4), longlist((u_nvals + 2) * 4);
   GRB_HIP(hipMemsetAsync(longlist.p, 0, 4, stream()));
-  hipLaunchKernelGGL(k_flag_to_u32, dim3(grid_of(nu)), dim3(256), 0, stream(), c.upres, nu, flags.as<uint32_t>());
-  exclusive_scan_u32(flags.as<uint32_t>(), pos.as<uint32_t>(), nu);
-  hipLaunchKernelGGL(k_compact_idx, dim3(grid_of(nu)), dim3(256), 0, stream(), c.upres, pos.as<uint32_t>(), nu, fidx.as<uint32_t>());
+  if (c.small_idx && c.small_n == u_nvals && u_nvals <= 64) {
+    write_small_list((uint32_t)u_nvals, c.small_idx, fidx.as<uint32_t>());      // the frontier is known on the host: its list travels as kernel arguments
+  } else {
+    flags.alloc(nu * 4 + 4); pos.alloc(nu * 4 + 4);
+    hipLaunchKernelGGL(k_flag_to_u32, dim3(grid_of(nu)), dim3(256), 0, stream(), c.upres, nu, flags.as<uint32_t>());
+    exclusive_scan_u32(flags.as<uint32_t>(), pos.as<uint32_t>(), nu);
+    hipLaunchKernelGGL(k_compact_idx, dim3(grid_of(nu)), dim3(256), 0, stream(), c.upres, pos.as<uint32_t>(), nu, fidx.as<uint32_t>());
+  }
   GRB_HIP(hipMemsetAsync(c.tpres, 0, nout ? nout : 1, stream()));
   dispatch_type(d.zcode, [&]<class T>() { run_push<T>(c, d, fidx.as<uint32_t>(), u_nvals, longlist.as<uint32_t>()); });
   GRB_HIP(hipGetLastError());

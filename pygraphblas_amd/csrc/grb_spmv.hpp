@@ -34,7 +34,15 @@ struct SpmvCall {
   // (`while q.reduce_bool()` of a BFS loop then needs no kernel of its own; a fresh tag per product, so the word is never
   // cleared).  A kernel that honours it sets *any_true_done.
   uint32_t* any_true = nullptr; uint32_t any_true_tag = 0; bool* any_true_done = nullptr;
+  // The mask IS the operand, of a one-byte type, under a Boolean semiring (`v.vxm(A, mask=v, out=q, desc=RC)` on the level vector of the
+  // reference's BFS loop): the row-lane kernel can read the vector itself — allowed(r) = (pres[r] && (structural || val[r])) != complement,
+  // operand value = (val[c] != 0) — where the caller would otherwise make allow bytes and BOOL values in a pass of its own (11 us per
+  // level at R-MAT-22).  fm_val = the vector's raw value bytes, upres its presence bytes, fm_flags bit 0 structural, bit 1 complement.
+  const uint8_t* fm_val = nullptr; uint8_t fm_flags = 0;
+  // push: the operand's entries as a host list of <= 64 ascending indices (GrB_Vector_opaque::small_idx) — no frontier compaction
+  const uint32_t* small_idx = nullptr; uint32_t small_n = 0;
 };
+bool spmv_rowlane_applies(const DevCSR& M, const SemiringDesc& d, int method);      // would a masked pull of this matrix run the row-lane kernel?
 
 const std::string& xcd_mapping();   // "roundrobin8" when workgroup b of a full-chip launch runs on XCD b % 8 (probed once)
 void spmv_build_plan(DevCSR& M);

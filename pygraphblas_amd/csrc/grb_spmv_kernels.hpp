@@ -49,6 +49,7 @@ template <class T> struct SpmvKArgs {
   const SpmvBlock* blocks; uint32_t* tickets; T* partial; uint8_t* pflag;
   uint32_t nrows;
   uint32_t* any_true; uint32_t any_true_tag;      // BOOL results only (nullptr otherwise): set to the tag when an entry with value true is written
+  const uint8_t* fm_val; uint32_t fm_flags;       // SpmvCall::fm_val / fm_flags (row-lane kernel, FUSED instantiation)
 };
 template <class T> __device__ __forceinline__ bool spmv_truthy(T v) { if constexpr (is_bool<T>::value) return v.v != 0; else return v != T(); }
 
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void k_spmv_rowgroup(const SpmvKArgs<T> a, con
 // entries; the rows that are neither finished nor at their monoid's terminal value by then (hub rows) are completed by the
 // whole wave, 64 entries per step, starting from the lane's partial result.
 constexpr uint32_t SPMV_LANE_E = 8;
-template <class T, class SR, bool U_FULL>
+template <class T, class SR, bool U_FULL, bool FUSED = false>
 __global__ __launch_bounds__(256) void k_spmv_rowlane(const SpmvKArgs<T> a, const SR sr) {
   const int lane = threadIdx.x & 63;
   const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = (uint64_t)gridDim.x * 4;
@@ -248,9 +249,16 @@ __global__ __launch_bounds__(256) void k_spmv_rowlane(const SpmvKArgs<T> a, cons
   const uint64_t nround = ((uint64_t)a.nrows + 63) / 64 * 64;
   for (uint64_t base = wave * 64; base < nround; base += nwaves * 64) {
     const uint64_t r = base + lane;
-    const bool valid = r < a.nrows, allowed = valid && (!a.allow || a.allow[r]);
+    const bool valid = r < a.nrows;
+    bool allowed;
+    if constexpr (FUSED) allowed = valid && ((a.upres[r] != 0 && ((a.fm_flags & 1u) || a.fm_val[r] != 0)) != ((a.fm_flags & 2u) != 0));     // the mask vector itself
+    else allowed = valid && (!a.allow || a.allow[r]);
+    // operand value at column c: the vector's own byte as BOOL when fused
+    auto uat = [&](uint32_t c) __attribute__((always_inline)) -> T { if constexpr (FUSED) { T t; t = T(a.fm_val[c] != 0); return t; } else return a.uval[c]; };
+    // (the row pointers are fetched whether or not the row is allowed: one dependent round trip less per wave — the late levels of a BFS,
+    //  where half of the 4 M rows are empty and unvisited, are a chain of such trips and little else)
     uint32_t pb = 0, pe = 0;
-    if (allowed) { pb = a.rowptr[r]; pe = a.rowptr[r + 1]; }
+    if (FUSED ? valid : allowed) { pb = a.rowptr[r]; pe = a.rowptr[r + 1]; }
     T acc = sr.identity; bool has = false, done = !allowed;
     if (allowed) {
       const uint32_t e = pe - pb > SPMV_LANE_E ? pb + SPMV_LANE_E : pe;
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(256) void k_spmv_rowlane(const SpmvKArgs<T> a, cons
         bool pr = true;
         if constexpr (!U_FULL) pr = a.upres[c] != 0;
         if (pr) {
-          const T m = sr.mult(use_a ? a.aval[p] : T(), use_u ? a.uval[c] : T());
+          const T m = sr.mult(use_a ? a.aval[p] : T(), use_u ? uat(c) : T());
           acc = has ? sr.add(acc, m) : m; has = true;
           if (sr.has_terminal && memcmp_eq(acc, sr.terminal)) { done = true; break; }
         }
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(256) void k_spmv_rowlane(const SpmvKArgs<T> a, cons
           const uint32_t c = a.col[p];
           bool pr = true;
           if constexpr (!U_FULL) pr = a.upres[c] != 0;
-          if (pr) { const T m = sr.mult(use_a ? a.aval[p] : T(), use_u ? a.uval[c] : T()); part = phas ? sr.add(part, m) : m; phas = true; }
+          if (pr) { const T m = sr.mult(use_a ? a.aval[p] : T(), use_u ? uat(c) : T()); part = phas ? sr.add(part, m) : m; phas = true; }
         }
         if (sr.has_terminal && __ballot(phas && memcmp_eq(part, sr.terminal))) break;      // some lane is at the terminal value: so is the row
       }
@@ -409,7 +417,7 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
     a.uval = (const T*)c.uval; a.upres = c.upres; a.allow = c.allow; a.tval = (T*)c.tval; a.tpres = c.tpres; a.nrows = M.nrows; a.any_true = nullptr;
     const bool full = c.upres == nullptr;
     // masked pull with a terminal monoid (BFS) -> row-group kernel with early exit; otherwise the row-block kernel
-    const bool prefer_rowgroup = c.method == SPMV_ROWGROUP || (c.method == SPMV_AUTO && c.allow && d.has_terminal);
+    const bool prefer_rowgroup = c.method == SPMV_ROWGROUP || (c.method == SPMV_AUTO && (c.allow || c.fm_val) && d.has_terminal);
     if (prefer_rowgroup) {
       const double avg = M.nrows ? (double)M.nnz / M.nrows : 0;
       const int G = avg > 96 ? 64 : 8;        // 8 lanes per row unless rows are long on average: most rows of a power-law graph are short
@@ -423,6 +431,14 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
       if (G == 8 && !no_lane && c.method == SPMV_AUTO) {                          // short rows on average: a lane per row (kernel B')
         uint64_t nbl = ((uint64_t)M.nrows + 255) / 256; if (nbl < 1) nbl = 1; if (nbl > 65536) nbl = 65536;
         if (c.any_true && c.any_true_done && is_bool<T>::value) { a.any_true = c.any_true; a.any_true_tag = c.any_true_tag; *c.any_true_done = true; }
+        if constexpr (is_bool<T>::value) {
+          if (c.fm_val) {                                                       // the mask is the operand itself: no allow / BOOL-value arrays were made
+            a.fm_val = c.fm_val; a.fm_flags = c.fm_flags;
+            hipLaunchKernelGGL((k_spmv_rowlane<T, SR, false, true>), dim3((unsigned)nbl), dim3(256), 0, stream(), a, sr);
+            g_last_plan += std::string("k_spmv_rowlane<") + (sr.is_static ? "static" : "dynamic") + ",mask=operand> ";
+            return;
+          }
+        }
         if (full) hipLaunchKernelGGL((k_spmv_rowlane<T, SR, true>), dim3((unsigned)nbl), dim3(256), 0, stream(), a, sr);
         else hipLaunchKernelGGL((k_spmv_rowlane<T, SR, false>), dim3((unsigned)nbl), dim3(256), 0, stream(), a, sr);
         g_last_plan += std::string("k_spmv_rowlane<") + (sr.is_static ? "static>" : "dynamic>") + " ";

@@ -170,6 +170,26 @@ __global__ void k_scatter_entries(uint32_t k, const uint32_t* __restrict__ idx, 
     pres[i] = 1;
   }
 }
+// the same for up to 16 entries handed over BY VALUE (kernel arguments): no staging buffers, no host synchronisation — the one-entry
+// frontier `q[start] = True` of a BFS loop reaches HBM this way
+struct SmallEntries { uint32_t idx[16]; uint8_t x[16][8]; };
+__global__ void k_scatter_small(uint32_t k, const SmallEntries e, uint32_t ts, uint8_t* __restrict__ val, uint8_t* __restrict__ pres) {
+  const uint32_t t = threadIdx.x;
+  if (t < k) { for (uint32_t b = 0; b < ts; b++) val[(size_t)e.idx[t] * ts + b] = e.x[t][b]; pres[e.idx[t]] = 1; }
+}
+void scatter_entries_small(uint32_t k, const uint64_t* idx_host, const uint8_t* vals_host, size_t ts, void* val, uint8_t* pres) {
+  SmallEntries e; memset(&e, 0, sizeof e);
+  for (uint32_t i = 0; i < k; i++) { e.idx[i] = (uint32_t)idx_host[i]; memcpy(e.x[i], vals_host + (size_t)i * ts, ts); }
+  hipLaunchKernelGGL(k_scatter_small, dim3(1), dim3(64), 0, stream(), k, e, (uint32_t)ts, (uint8_t*)val, pres);
+}
+// a list of up to 64 indices handed over by value -> an index array in HBM (the frontier list of a push step whose operand's entries are known on the host)
+struct SmallList { uint32_t idx[64]; };
+__global__ void k_write_small_list(uint32_t k, const SmallList l, uint32_t* __restrict__ out) { if (threadIdx.x < k) out[threadIdx.x] = l.idx[threadIdx.x]; }
+void write_small_list(uint32_t k, const uint32_t* idx_host, uint32_t* out_dev) {
+  SmallList l; memset(&l, 0, sizeof l);
+  for (uint32_t i = 0; i < k && i < 64; i++) l.idx[i] = idx_host[i];
+  hipLaunchKernelGGL(k_write_small_list, dim3(1), dim3(64), 0, stream(), k, l, out_dev);
+}
 void scatter_entries(uint32_t k, const uint32_t* idx_dev, const void* vals_dev, size_t ts, void* val, uint8_t* pres) {
   if (!k) return;
   hipLaunchKernelGGL(k_scatter_entries, dim3(grid_for(k)), dim3(256), 0, stream(), k, idx_dev, (const uint8_t*)vals_dev, (uint32_t)ts, (uint8_t*)val, pres);
@@ -406,8 +426,40 @@ template <class T, bool MATH> __global__ void k_vec_assign_scalar_masked(uint64_
     } else if (replace) wpres[i] = 0;
   }
 }
+// the same with one-byte values on both sides and no accumulator (`v[q] = level`: UINT8 levels under a BOOL frontier, once per BFS level):
+// 16 positions per thread — 16-byte loads and stores, the mask test and the select done on four bytes at a time — instead of a byte per
+// thread and instruction (7-13 us for 4 M positions; the bytes alone are 6 streams of 4 MB)
+__device__ __forceinline__ uint32_t nz_bytes(uint32_t x) { return ((x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) & 0x80808080u) >> 7; }      // 0x01 in every byte of x that is not zero
+__global__ void k_assign_masked_bytes(uint64_t n, uint8_t* __restrict__ wval, uint8_t* __restrict__ wpres, const uint8_t* __restrict__ mval, const uint8_t* __restrict__ mpres,
+                                      bool mstruct, bool mcomp, uint8_t s, bool replace) {
+  const uint64_t nv = n / 16; const uint32_t s4 = (uint32_t)s * 0x01010101u;
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < nv; i += gridDim.x * 256ull) {
+    const uint4 mp = ((const uint4*)mpres)[i]; uint4 mv = make_uint4(0, 0, 0, 0);
+    if (!mstruct) mv = ((const uint4*)mval)[i];
+    uint4 wv = ((const uint4*)wval)[i], wp = ((const uint4*)wpres)[i];
+    uint32_t* pmp = (uint32_t*)&mp; uint32_t* pmv = (uint32_t*)&mv; uint32_t* pwv = (uint32_t*)&wv; uint32_t* pwp = (uint32_t*)&wp;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint32_t ok = nz_bytes(pmp[k]) & (mstruct ? 0x01010101u : nz_bytes(pmv[k]));
+      if (mcomp) ok ^= 0x01010101u;
+      const uint32_t m = ok * 0xFFu;                                        // 0xFF in the bytes that are written
+      pwv[k] = (pwv[k] & ~m) | (s4 & m);
+      pwp[k] = replace ? ok : (nz_bytes(pwp[k]) | ok);
+    }
+    ((uint4*)wval)[i] = wv; ((uint4*)wpres)[i] = wp;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (uint64_t i = nv * 16; i < n; i++) {
+      const bool ok = (mpres[i] != 0 && (mstruct || mval[i] != 0)) != mcomp;
+      if (ok) { wval[i] = s; wpres[i] = 1; } else if (replace) wpres[i] = 0;
+    }
+}
 void vec_assign_scalar_masked(int code, uint64_t n, void* wval, uint8_t* wpres, int mcode, const void* mval, const uint8_t* mpres, bool mstruct, bool mcomp, const void* scalar, int accum, bool replace) {
   if (!n) return;
+  if (accum < 0 && type_size(code) == 1 && type_size(mcode) == 1 && n >= 4096) {      // (the truth of a one-byte value of any type is "not zero")
+    hipLaunchKernelGGL(k_assign_masked_bytes, dim3(grid_for(n / 16)), dim3(256), 0, stream(), n, (uint8_t*)wval, wpres, (const uint8_t*)mval, mpres, mstruct, mcomp, *(const uint8_t*)scalar, replace);
+    return;
+  }
   dispatch_type(code, [&]<class T>() {
     T s; memcpy(&s, scalar, sizeof(T));
     if (accum >= 0 && binop_needs_math(accum)) hipLaunchKernelGGL((k_vec_assign_scalar_masked<T, true>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (T*)wval, wpres, mcode, mval, mpres, mstruct, mcomp, s, accum, replace);

@@ -5,6 +5,7 @@
 //   GrB_Vector_assign_<T>            <- Vector.assign_scalar           (pygraphblas/vector.py:1494-1524)
 //   GrB_Vector_eWiseAdd/eWiseMult_*  <- Vector.eadd / emult            (pygraphblas/vector.py:604-833)
 //   GrB_Vector_apply, GxB_Vector_apply_BinaryOp1st/2nd, GxB_Vector_select  (pygraphblas/vector.py:1204-1340)
+#include <algorithm>
 #include "grb_opcommon.hpp"
 #include "grb_lazy.hpp"
 
@@ -104,11 +105,21 @@ static void vec_assign(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const 
     if (ecode0 == wcode0) {
       vec_to_device(mask); vec_to_device(w);
       uint8_t s0[16]; cast_scalar(wcode0, s0, xcode, x);
+      // when both the mask's and w's entries are known as short lists (the first level of a BFS: `v[q] = 1` with q = {start}), so are
+      // the result's: w's entries and the positions the mask allows
+      std::vector<uint32_t> merged; bool keep_list = false, truthy = false;
+      if (!accum && !dv.replace && !dv.mask_comp && w->small_valid && mask->small_valid && (dv.mask_struct || mask->small_truthy)) {
+        merged.resize(w->small_idx.size() + mask->small_idx.size());
+        merged.resize(std::set_union(w->small_idx.begin(), w->small_idx.end(), mask->small_idx.begin(), mask->small_idx.end(), merged.begin()) - merged.begin());
+        bool snz = false; for (size_t b = 0; b < type_size(wcode0); b++) snz = snz || s0[b] != 0;
+        keep_list = merged.size() <= 64; truthy = snz && (w->small_truthy || w->small_idx.empty());
+      }
       vec_assign_scalar_masked(wcode0, n, w->dval.p, w->dpres.as<uint8_t>(), mask->type->code, mask->dval.p, mask->dpres.as<uint8_t>(), dv.mask_struct, dv.mask_comp, s0,
                                accum ? accum->opcode : -1, dv.replace);
       vec_invalidate_host(w);
       if (dv.replace) { w->fe_lb = 0; w->fe_lb_key = 0; }
       w->dnvals_known = false; w->dnvals = 0;
+      if (keep_list) { w->small_idx.swap(merged); w->small_valid = true; w->small_truthy = truthy; w->dnvals = w->small_idx.size(); w->dnvals_known = true; }
       return;
     }
   }
