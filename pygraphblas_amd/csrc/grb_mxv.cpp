@@ -51,16 +51,18 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   // trip when the count is not known yet — the usual state inside a BFS loop, where u was just updated under a mask
   uint64_t fe_cached = ~0ull;
   bool stays_pull = false;            // the operand was too heavy for a push step when it was last counted and has only grown since
-  if (!u->dnvals_known && mask && method == SPMV_AUTO && spmspv_push_supported(sd) && u->n && (useT || A->csc.valid)) {      // (a masked product: frontier-like operand; never build a transpose just for this)
+  // (masked products — the frontier-like operands of a BFS — and, since round 4, unmasked ones whose operand has an unknown count: the
+  //  sweeps of the shortest-path loop, whose operand only gains entries; never build a transpose just for this)
+  if (method == SPMV_AUTO && spmspv_push_supported(sd) && u->n && (useT || A->csc.valid)) {
     const DevCSR& P0 = useT ? A->csr : mat_csc(A);
-    if (u->fe_lb_key == P0.rowptr.serial && P0.rowptr.serial && u->fe_lb * 16 >= P0.nnz + 16) stays_pull = true;      // no kernel, no host round trip
-    else {
+    if (u->fe_lb_key == P0.rowptr.serial && P0.rowptr.serial && u->fe_lb * 16 >= P0.nnz + 16) stays_pull = true;      // no kernel, no host round trip (whether or not the count is known: `w.iseq(v)` of the shortest-path loop counts v)
+    else if (!u->dnvals_known) {
       uint64_t cnt = 0;
       fe_cached = frontier_edges_and_count(u->dpres.as<uint8_t>(), P0.rowptr.as<uint32_t>(), u->n, &cnt);
       u->dnvals = cnt; u->dnvals_known = true; u->fe_lb = fe_cached; u->fe_lb_key = P0.rowptr.serial;
     }
   }
-  const uint64_t u_nvals = stays_pull ? (u->n ? u->n - 1 : 0) : vec_dev_nvals(u);             // (not counted: treated as "has holes")
+  const uint64_t u_nvals = stays_pull && !u->dnvals_known ? (u->n ? u->n - 1 : 0) : vec_dev_nvals(u);             // (not counted: treated as "has holes")
   const bool u_full = u_nvals == u->n;
 
   // does the multiply read the matrix / vector values at all?
@@ -81,6 +83,7 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
       const DevCSR& P = useT ? A->csr : mat_csc(A);
       const uint64_t fe = fe_cached != ~0ull ? fe_cached : frontier_edges(u->dpres.as<uint8_t>(), P.rowptr.as<uint32_t>(), u->n);
       push = fe * 16 < P.nnz + 16;
+      u->fe_lb = fe; u->fe_lb_key = P.rowptr.serial;                       // (exact now, a lower bound while entries are only added)
     }
   }
 
@@ -205,11 +208,25 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
     // accumulator in the same store — and when w is a fill that was never written (`r[:] = teleport` before the product of
     // gap/prmark.py:21-23), the fill folds into that store too and w is never read
     bool epi_done = false;
-    if (accum_is_monoid && w_full && method == SPMV_AUTO && !big_holes) {       // (with big holes every row has a sum: the threshold pass must see T first)
+    if (accum_is_monoid && w_full && method == SPMV_AUTO && !big_holes) {       // (with big holes every row has a sum: the threshold must see it first — epi 3)
       call.epi = w_fill ? 2 : 1; call.epi_w = w_fill ? nullptr : w->dval.p; call.epi_done = &epi_done;
       if (w_fill) memcpy(call.epi_fill, w->lazy_fill, 16);
     }
+    // big holes + `w<accum MIN> = ...` with the monoid's own operator (the sweeps of the shortest-path loop, `v.vxm(A, MIN_PLUS, accum=MIN, out=v)`):
+    // the merge kernel applies the threshold and the accumulator in its store — no threshold pass over T, no accumulate epilogue, no T at all
+    const bool big_epi = big_holes && accum_is_monoid && method == SPMV_AUTO && w->lazy == 0 && !w->q_reads;
+    if (big_epi) {
+      vec_to_device(w);
+      call.epi = 3; call.epi_w = w->dval.p; call.epi_wpres = w->dpres.as<uint8_t>(); memcpy(call.epi_fill, big_thresh, 16); call.epi_done = &epi_done;
+    }
     spmv_pull(call, sd);
+    if (epi_done && call.epi == 3) {
+      vec_invalidate_host(w);
+      w->dnvals_known = false; w->dnvals = 0; w->holes_zero = false;      // (entries were only added: the lower bound fe_lb of the edges leaving them stays valid — the next sweep needs no count)
+      w->abs_bound = big_uabs + big_aabs;       // every sum that passed the threshold is within |u| + |A|; MIN / MAX select among such values and w's own (w is u, or held values of an earlier sweep)
+      if (w != u) w->abs_bound = -1;
+      return;
+    }
     if (epi_done) {
       if (w_fill) {
         lazy_fill_consumed(w);

@@ -29,7 +29,10 @@ struct SpmvCall {
   //   epi == 1: w's values are `epi_w` (in place: rows with products become w (+) sum, the others stay), presence bytes untouched
   //   epi == 2: w is the pending fill `epi_fill` everywhere (`w(:) = s` not yet written): tval = s (+) sum / s, tpres = 1
   // A kernel that honours it sets *epi_done; otherwise the product lands in tval/tpres as usual and the caller runs the epilogue.
-  int epi = 0; void* epi_w = nullptr; uint8_t epi_fill[16] = {0}; bool* epi_done = nullptr;
+  //   epi == 3: "big holes" (grb_mxv.cpp): `w<accum MIN / MAX> = ...` with the monoid's own operator into w = (epi_w, epi_wpres), which has holes:
+  //             a row sum on the far side of the threshold `epi_fill` was made of fill values only and is no entry; a real one is combined
+  //             with w(r) or becomes its entry.  In place (the sweeps of the reference's shortest-path loop: no threshold pass, no epilogue).
+  int epi = 0; void* epi_w = nullptr; uint8_t* epi_wpres = nullptr; uint8_t epi_fill[16] = {0}; bool* epi_done = nullptr;
   // optional summary of a BOOL result: a device word the kernel sets to `any_true_tag` when it writes an entry whose value is true
   // (`while q.reduce_bool()` of a BFS loop then needs no kernel of its own; a fresh tag per product, so the word is never
   // cleared).  A kernel that honours it sets *any_true_done.

@@ -582,7 +582,12 @@ __global__ __launch_bounds__(XM_CT) void k_xp_merge(uint32_t nrows, uint32_t nbl
     }
     if constexpr (EPI == 0) { if (live) { y[r] = acc; ypres[r] = o1 > o0 ? 1 : 0; } }
     else if constexpr (EPI == 1) { if (live && o1 > o0) y[r] = sr.add(y[r], acc); }
-    else { if (live) { y[r] = o1 > o0 ? sr.add(fill, acc) : fill; ypres[r] = 1; } }
+    else if constexpr (EPI == 2) { if (live) { y[r] = o1 > o0 ? sr.add(fill, acc) : fill; ypres[r] = 1; } }
+    else {                                                            // EPI 3: SpmvCall::epi == 3 (y / ypres = the accumulated vector, fill = the threshold)
+      if constexpr (std::is_arithmetic<T>::value) {
+        if (live && o1 > o0 && (sr.add_op() == B_MIN ? acc < fill : acc > fill)) { if (ypres[r]) y[r] = sr.add(y[r], acc); else { y[r] = acc; ypres[r] = 1; } }
+      }
+    }
   }
 }
 
@@ -725,7 +730,12 @@ __global__ __launch_bounds__(XM_CT) void k_xp_merge_wide(uint32_t nrows, uint32_
       const bool has = o1[j] > o0[j]; const T acc = has ? vals[o1[j] - 1u] : T();
       if constexpr (EPI == 0) { y[r] = acc; ypres[r] = has ? 1 : 0; }
       else if constexpr (EPI == 1) { if (has) y[r] = sr.add(y[r], acc); }
-      else { y[r] = has ? sr.add(fill, acc) : fill; ypres[r] = 1; }
+      else if constexpr (EPI == 2) { y[r] = has ? sr.add(fill, acc) : fill; ypres[r] = 1; }
+      else {                                                          // EPI 3: SpmvCall::epi == 3
+        if constexpr (std::is_arithmetic<T>::value) {
+          if (has && (sr.add_op() == B_MIN ? acc < fill : acc > fill)) { if (ypres[r]) y[r] = sr.add(y[r], acc); else { y[r] = acc; ypres[r] = 1; } }
+        }
+      }
     }
   }
   b = b_next;
@@ -1038,6 +1048,10 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
       } else if (c.epi == 2 && c.epi_done) {
         T fill; memcpy(&fill, c.epi_fill, sizeof(T));
         XM_LAUNCH(2, (T*)c.tval, c.tpres, fill)
+        *c.epi_done = true;
+      } else if (c.epi == 3 && c.epi_done && std::is_arithmetic<T>::value) {
+        T th; memcpy(&th, c.epi_fill, sizeof(T));
+        XM_LAUNCH(3, (T*)c.epi_w, c.epi_wpres, th)
         *c.epi_done = true;
       } else XM_LAUNCH(0, (T*)c.tval, c.tpres, T())
 #undef XM_LAUNCH
