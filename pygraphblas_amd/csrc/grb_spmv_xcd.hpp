@@ -52,6 +52,7 @@ struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per 
   DevBuf m_blockptr;      // u32[(m_nblocks+1)*XP] first sub-row of panel k in block b
   DevBuf m_slot;          // u16[F]  slot of every sub-row in its block's row-major order (row, then panel, then position in a chain)
   DevBuf m_rowoff;        // u16[nrows] slot of every row's first sub-row in its block
+  bool m_wide = false;    // the blocks were cut for k_xp_merge_wide (always with sub-panels; GRB_MI355X_XM_WIDE=1: also without)
   uint32_t m_nblocks = 0, m_slots = 0; bool m_ok = false;      // m_slots: LDS slots a block may need (XM_TARGET + the longest row's sub-rows)
   DevBuf args;            // XtPanel<T>[XP] in HBM; never changes between calls (u and the partial array arrive as kernel arguments)
   DevBuf xhot, partial;   // per-call work buffers kept with the plan (xhot: T[XP*H], the LDS tables' contents)
@@ -89,32 +90,20 @@ static __global__ void k_xp_line_weights(const uint32_t* __restrict__ cnt, uint3
 // the least load so far (LPT).  One workgroup; the loop itself is serial.
 // Deal slot j of the np = XP * S slots is virtual panel (j % XP) * S + j / XP: consecutive slots go to different XCDs.
 __device__ __forceinline__ uint32_t xp_vp_of_slot(uint32_t j, uint32_t S) { return (j & (XP - 1)) * S + (j >> 3); }
-static __global__ __launch_bounds__(256) void k_xp_lpt(const uint32_t* __restrict__ negw_sorted, uint32_t ntop, uint32_t np, uint32_t S, uint8_t* __restrict__ top_panel) {
+// (round 4: the deal runs on one WAVE — lane j holds the load of slot j, the lightest slot is a wave minimum + a ballot — instead of one
+//  thread comparing the slots one after the other: 1.3 ms -> ~0.1 ms of the plan's 6 ms at R-MAT-22.  Loads are 32-bit: a slot never
+//  holds more than the matrix's entries, which a 32-bit count addresses anyway.)
+static __global__ __launch_bounds__(64) void k_xp_lpt(const uint32_t* __restrict__ negw_sorted, uint32_t ntop, uint32_t np, uint32_t S, uint8_t* __restrict__ top_panel) {
   __shared__ uint32_t w[4096];
-  __shared__ unsigned long long sload[XPMAX];
-  for (uint32_t i = threadIdx.x; i < ntop; i += 256) w[i] = 0xFFFFFFFFu - negw_sorted[i];
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t i = lane; i < ntop; i += 64) w[i] = 0xFFFFFFFFu - negw_sorted[i];
   __syncthreads();
-  if (threadIdx.x == 0) {
-    if (np == (uint32_t)XP) {
-      unsigned long long load[XP];
-      for (int k = 0; k < XP; k++) load[k] = 0;
-      for (uint32_t i = 0; i < ntop; i++) {
-        int best = 0;
-#pragma unroll
-        for (int k = 1; k < XP; k++) if (load[k] < load[best]) best = k;
-#pragma unroll
-        for (int k = 0; k < XP; k++) if (k == best) load[k] += w[i];
-        top_panel[i] = (uint8_t)best;
-      }
-    } else {
-      for (uint32_t k = 0; k < np; k++) sload[k] = 0;
-      for (uint32_t i = 0; i < ntop; i++) {
-        uint32_t best = 0; unsigned long long lb = sload[0];
-        for (uint32_t k = 1; k < np; k++) { const unsigned long long l = sload[k]; if (l < lb) { lb = l; best = k; } }
-        sload[best] = lb + w[i];
-        top_panel[i] = (uint8_t)xp_vp_of_slot(best, S);
-      }
-    }
+  uint32_t load = lane < np ? 0u : 0xFFFFFFFFu;           // (lanes beyond the slots never win)
+  for (uint32_t i = 0; i < ntop; i++) {
+    const uint32_t m = wave_reduce_dpp<uint32_t, false>(B_MIN, load, 0xFFFFFFFFu);       // (DPP steps; the compiler's wave_reduce builtin walks the lanes one by one: 7.5 ms for this loop)
+    const uint32_t best = (uint32_t)__builtin_ctzll(__ballot(load == m));      // the first slot with the least load (ties: lowest index, as the serial loop chose)
+    if (lane == best) { const uint32_t nl = load + w[i]; load = nl < load || nl == 0xFFFFFFFFu ? 0xFFFFFFFEu : nl; }
+    if (lane == 0) top_panel[i] = (uint8_t)xp_vp_of_slot(best, S);
   }
 }
 // lines in descending weight: the first `ntop` take the panel the LPT chose for them, the others are dealt in snake order
@@ -817,10 +806,9 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
     DevBuf negw((size_t)nlines * 4 + 4), lid((size_t)nlines * 4 + 4), negw2((size_t)nlines * 4 + 4), lsorted((size_t)nlines * 4 + 4);
     hipLaunchKernelGGL(k_xp_line_weights, dim3(grid_n(nlines)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, line, nlines, negw.as<uint32_t>(), lid.as<uint32_t>());
     sort_pairs_u32(negw.as<uint32_t>(), negw2.as<uint32_t>(), lid.as<uint32_t>(), lsorted.as<uint32_t>(), nlines, 32);
-    const uint32_t top_cap = 4096u * (uint32_t)XP / NP;          // (the exact deal is a serial loop over the slots: fewer lines when there are more slots)
-    const uint32_t ntop = nlines < top_cap ? nlines : top_cap;
+    const uint32_t ntop = nlines < 4096u ? nlines : 4096u;
     DevBuf dtop((size_t)ntop + 8);
-    hipLaunchKernelGGL(k_xp_lpt, dim3(1), dim3(256), 0, stream(), negw2.as<uint32_t>(), ntop, NP, (uint32_t)S, (uint8_t*)dtop.p);
+    hipLaunchKernelGGL(k_xp_lpt, dim3(1), dim3(64), 0, stream(), negw2.as<uint32_t>(), ntop, NP, (uint32_t)S, (uint8_t*)dtop.p);
     hipLaunchKernelGGL(k_xp_deal_lines, dim3(grid_n(nlines)), dim3(256), 0, stream(), lsorted.as<uint32_t>(), nlines, (const uint8_t*)dtop.p, ntop, NP, (uint32_t)S, (uint8_t*)pol.p);
     DevBuf k32((size_t)n * 4 + 4), k32o((size_t)n * 4 + 4), cin((size_t)n * 4 + 4), cout((size_t)n * 4 + 4);
     hipLaunchKernelGGL(k_xp_column_keys, dim3(grid_n(n)), dim3(256), 0, stream(), cnt.as<uint32_t>(), n, line, (const uint8_t*)pol.p, vps, k32.as<uint32_t>(), cin.as<uint32_t>());
@@ -923,8 +911,9 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
     hipLaunchKernelGGL(k_xp_run_lengths, dim3(grid_n(F)), dim3(256), 0, stream(), skey.as<uint32_t>(), F, first.as<uint32_t>(), rcnt.as<uint32_t>());
     exclusive_scan_u32(rcnt.as<uint32_t>(), rfirst.as<uint32_t>(), (uint64_t)nr + 1);                 // row-major position of every row's first sub-row
     // block size: XM_TARGET sub-rows in <= XM_ROWS rows for eight runs (k_xp_merge), XMW_TARGET in <= XMW_ROWS with sub-panels (k_xp_merge_wide)
-    const uint32_t m_target = NP <= (uint32_t)XP ? XM_TARGET : XMW_TARGET;
-    const uint32_t m_perrow = NP <= (uint32_t)XP ? XM_TARGET / XM_ROWS : XMW_TARGET / XMW_ROWS;       // weight of a row beside its sub-rows (caps the rows of a block at target / perrow)
+    P->m_wide = NP > (uint32_t)XP || wp_env("GRB_MI355X_XM_WIDE", 0) != 0;
+    const uint32_t m_target = !P->m_wide ? XM_TARGET : XMW_TARGET;
+    const uint32_t m_perrow = !P->m_wide ? XM_TARGET / XM_ROWS : XMW_TARGET / XMW_ROWS;       // weight of a row beside its sub-rows (caps the rows of a block at target / perrow)
     hipLaunchKernelGGL(k_xm_weights, dim3(grid_n((uint64_t)nr + 1)), dim3(256), 0, stream(), rcnt.as<uint32_t>(), nr, m_perrow, w.as<uint32_t>());
     exclusive_scan_u32(w.as<uint32_t>(), Pw.as<uint32_t>(), (uint64_t)nr + 1);
     hipLaunchKernelGGL(k_xm_newblock, dim3(grid_n((uint64_t)nr + 1)), dim3(256), 0, stream(), Pw.as<uint32_t>(), nr, m_target, nf.as<uint32_t>());
@@ -935,7 +924,7 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
     GRB_HIP(hipMemcpyAsync(&hmax, dmax.p, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
     const uint64_t need = (uint64_t)m_target + hmax + m_perrow;
     P->m_slots = need <= XM_SLOTS ? XM_SLOTS : (uint32_t)((need + 255) / 256 * 256);
-    P->m_nblocks = hnb; P->m_ok = hnb > 0 && (uint64_t)P->m_slots * (sizeof(T) + (S > 1 ? 1 : 0)) <= 64u * 1024u && P->m_slots < 65536u && F < 0xFFFFFFF0ull;      // (16-bit slots; 64 KB of LDS at most)
+    P->m_nblocks = hnb; P->m_ok = hnb > 0 && (uint64_t)P->m_slots * (sizeof(T) + (P->m_wide ? 1 : 0)) <= 64u * 1024u && P->m_slots < 65536u && F < 0xFFFFFFF0ull;      // (16-bit slots; 64 KB of LDS at most)
     if (P->m_ok) {
       P->m_bstart.alloc(((size_t)hnb + 1) * 4 + 4); P->m_blockptr.alloc(((size_t)hnb + 1) * NP * 4 + 4); P->m_slot.alloc(F * 2 + 4); P->m_rowoff.alloc((size_t)nr * 2 + 4);
       hipLaunchKernelGGL(k_xm_bstart, dim3(grid_n((uint64_t)nr + 1)), dim3(256), 0, stream(), nf.as<uint32_t>(), nfs.as<uint32_t>(), nr, hnb, P->m_bstart.as<uint32_t>());
@@ -1032,13 +1021,13 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
     if (!launched) hipLaunchKernelGGL((k_spmv_tiles<T, SR>), dim3(ncu), dim3(XT_WAVES * 64), 0, stream(), call, (const XtPanel<T>*)P->args.p, sr);
     const uint32_t nblocks = (uint32_t)(((uint64_t)M.nrows + XP_RB - 1) / XP_RB);
     static const bool old_merge = wp_env("GRB_MI355X_XP_OLD_MERGE", 0) != 0;       // measurement hook: the per-panel merge kernel
-    if (P->m_ok && (!old_merge || P->S > 1)) {
+    if (P->m_ok && (!old_merge || P->m_wide)) {
       const dim3 mg((P->m_nblocks + XP - 1) / XP * XP), mb(XM_CT); const size_t ml = (size_t)P->m_slots * sizeof(T);
       const uint32_t np = (uint32_t)P->NP;
       static const uint32_t wg_per_cu = wp_env("GRB_MI355X_XMW_WGS", 6);
       const dim3 mgw(std::min<uint32_t>(mg.x, (uint32_t)ncu * wg_per_cu / XP * XP));             // the wide merge is persistent
 #define XM_LAUNCH(EPI_, Y_, YP_, FILL_) { \
-        if (P->S > 1) hipLaunchKernelGGL((k_xp_merge_wide<T, SR, EPI_>), mgw, mb, ml + P->m_slots, stream(), M.nrows, P->m_nblocks, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), \
+        if (P->m_wide) hipLaunchKernelGGL((k_xp_merge_wide<T, SR, EPI_>), mgw, mb, ml + P->m_slots, stream(), M.nrows, P->m_nblocks, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), \
                                          P->m_slot.as<uint16_t>(), P->m_rowoff.as<uint16_t>(), P->partial.as<T>(), (Y_), (YP_), sr, (FILL_), np, P->m_slots); \
         else hipLaunchKernelGGL((k_xp_merge<T, SR, EPI_>), mg, mb, ml, stream(), M.nrows, P->m_nblocks, P->m_bstart.as<uint32_t>(), P->m_blockptr.as<uint32_t>(), P->m_slot.as<uint16_t>(), \
                                 P->m_rowoff.as<uint16_t>(), P->partial.as<T>(), (Y_), (YP_), sr, (FILL_)); }
