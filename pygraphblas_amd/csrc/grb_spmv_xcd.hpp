@@ -652,19 +652,17 @@ __global__ __launch_bounds__(XM_CT) void k_xp_merge_wide(uint32_t nrows, uint32_
 #pragma unroll
     for (int g = 0; g < 2; g++) {
       const uint32_t t = base + (tid + (uint32_t)g * XM_CT) * 4u;
+      // (the four positions mostly lie in one run; where they straddle runs the run index ADVANCES — a loop that only the straddling lanes
+      //  enter, one or two short rounds.  A second bisection per element for those lanes made every wave pay for it: a wave's 256
+      //  positions straddle a run boundary almost always — 67 VALU instructions per sub-row, half of them in that path.)
       uint32_t src[4]; bool ok[4];
-      if (t < total) {
-        const uint32_t k = run_of(t), s0 = s_lo[k] + (t - s_pre[k]);
-        if (t + 3u < s_pre[k + 1]) {                                   // all four in run k (the common case)
+      uint32_t k = t < total ? run_of(t) : 0u;
+      uint32_t base = s_lo[k] - s_pre[k], end = s_pre[k + 1];
 #pragma unroll
-          for (int e = 0; e < 4; e++) { src[e] = s0 + (uint32_t)e; ok[e] = true; }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; e++) { const uint32_t te = t + (uint32_t)e; ok[e] = te < total; const uint32_t ke = ok[e] ? run_of(te) : 0u; src[e] = ok[e] ? s_lo[ke] + (te - s_pre[ke]) : 0u; }
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; e++) { src[e] = 0u; ok[e] = false; }
+      for (int e = 0; e < 4; e++) {
+        const uint32_t te = t + (uint32_t)e; ok[e] = te < total;
+        while (ok[e] && te >= end) { k++; base = s_lo[k] - s_pre[k]; end = s_pre[k + 1]; }
+        src[e] = ok[e] ? base + te : 0u;
       }
 #pragma unroll
       for (int e = 0; e < 4; e++) { v[g][e] = ok[e] ? partial[src[e]] : T(); sl[g][e] = ok[e] ? (uint32_t)slot[src[e]] : 0xFFFFFFFFu; }
