@@ -358,6 +358,7 @@ GrB_Info GrB_Row_assign(GrB_Matrix C, const GrB_Vector mask, const GrB_BinaryOp 
       replace_line(C, true, i, assigned_line(cur, C->type->code, u, accum));
       return;
     }
+    if (J == GrB_ALL && u->n != C->ncols) fail(GrB_DIMENSION_MISMATCH, "assign: the vector's size must equal the number of column indices");   // (before the list is asked for: GrB_ALL over 2^60 columns is never materialised)
     const auto ci = indices(J, nj, C->ncols, "assign");
     if (u->n != ci.size() || (mask && mask->n != C->ncols)) fail(GrB_DIMENSION_MISMATCH, "assign: the vector's size must equal the number of column indices");
     Map Cm = load(C, false), U = load(u), Ut, Mm; if (mask) Mm = load(mask);
@@ -378,6 +379,7 @@ GrB_Info GrB_Col_assign(GrB_Matrix C, const GrB_Vector mask, const GrB_BinaryOp 
       replace_line(C, false, j, assigned_line(line_of(C, false, j), C->type->code, u, accum));
       return;
     }
+    if (I == GrB_ALL && u->n != C->nrows) fail(GrB_DIMENSION_MISMATCH, "assign: the vector's size must equal the number of row indices");   // (as in GrB_Row_assign: before the list is asked for)
     const auto ri = indices(I, ni, C->nrows, "assign");
     if (u->n != ri.size() || (mask && mask->n != C->nrows)) fail(GrB_DIMENSION_MISMATCH, "assign: the vector's size must equal the number of row indices");
     Map Cm = load(C, false), U = load(u), Mm; if (mask) Mm = load(mask);

@@ -204,7 +204,12 @@ void do_reduce_vector(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Mon
   bool done = false;
   if (dv.tran0) {
     mat_to_device(A);
-    if (!A->csc.valid && A->csr.nnz >= (1u << 20)) {
+    // (only where the order the entries land in cannot show: integer / Boolean monoids and MIN / MAX.  A floating-point PLUS or TIMES keeps
+    //  ONE fixed-order algorithm — the row reduction of the transpose — whatever the cache holds: the same call must not return different
+    //  bits depending on whether an earlier operation happened to build the transpose)
+    const int rop = monoid->op->opcode;
+    const bool order_free = !(mc == T_FP32 || mc == T_FP64) || rop == B_MIN || rop == B_MAX || rop == B_ANY;
+    if (!A->csc.valid && A->csr.nnz >= (1u << 20) && order_free) {
       const void* av = cast_values(mc, A->type->code, A->csr.val.p, A->csr.nnz, ac);
       uint8_t id[16]; memcpy(id, monoid->identity, 16);
       fp_minmax_identity(mc, monoid->op->opcode, id);          // FP MIN / MAX start from NaN = from the column's first value (the one NaN rule, grb_opcommon.hpp)
