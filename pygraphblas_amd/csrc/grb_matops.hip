@@ -243,6 +243,35 @@ template <class W> __global__ void k_fill_typed(W* p, uint64_t n, W v) { for (ui
 template <class T> __global__ void k_words_to_values(uint64_t n, const typename acc_word<T>::type* __restrict__ acc, T* __restrict__ out) {
   for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) out[i] = from_word<T>(acc[i]);
 }
+// The same for a matrix of FEW rows (the ns x n batches of gap/bcmark.py), in a FIXED order: row after row — a row's entries have
+// distinct columns, so a launch per row needs no atomics, and column j's terms are added in row order whatever the hardware does
+// (a floating-point PLUS stays reproducible: ADVICE round 3).
+template <class T> __global__ void k_reduce_cols_row(uint32_t e0, uint32_t e1, const uint32_t* __restrict__ col, const T* __restrict__ val, int op, T* __restrict__ acc, uint8_t* __restrict__ tpres) {
+  for (uint64_t p = e0 + blockIdx.x * 256ull + threadIdx.x; p < e1; p += gridDim.x * 256ull) {
+    const uint32_t j = col[p];
+    acc[j] = tpres[j] ? apply_binop<T, false>(op, acc[j], val[p]) : val[p];
+    tpres[j] = 1;
+  }
+}
+bool csr_reduce_cols_few_rows(int code, const DevCSR& A, const void* aval, int op, void* tval, uint8_t* tpres) {
+  if (A.nrows > 64 || (code != T_FP32 && code != T_FP64)) return false;
+  if (!A.ncols) return true;
+  std::vector<uint32_t> rp((size_t)A.nrows + 1);
+  GRB_HIP(hipMemcpyAsync(rp.data(), A.rowptr.p, rp.size() * 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+  GRB_HIP(hipMemsetAsync(tpres, 0, A.ncols, stream()));
+  dispatch_type(code, [&]<class T>() {
+    if constexpr (std::is_same<T, float>::value || std::is_same<T, double>::value) {
+      GRB_HIP(hipMemsetAsync(tval, 0, (size_t)A.ncols * sizeof(T), stream()));
+      for (uint32_t r = 0; r < A.nrows; r++) {
+        const uint32_t e0 = rp[r], e1 = rp[r + 1]; if (e1 == e0) continue;
+        uint64_t g = ((uint64_t)(e1 - e0) + 255) / 256; if (g > 16384) g = 16384;
+        hipLaunchKernelGGL((k_reduce_cols_row<T>), dim3((unsigned)g), dim3(256), 0, stream(), e0, e1, A.col.as<uint32_t>(), (const T*)aval, op, (T*)tval, tpres);
+      }
+    }
+  });
+  GRB_HIP(hipGetLastError());
+  return true;
+}
 bool csr_reduce_cols(int code, const DevCSR& A, const void* aval, int op, const void* identity, void* tval, uint8_t* tpres) {
   if (code != T_INT32 && code != T_UINT32 && code != T_INT64 && code != T_UINT64 && code != T_FP32 && code != T_FP64) return false;
   if (!A.ncols) return true;

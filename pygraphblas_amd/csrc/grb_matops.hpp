@@ -15,6 +15,7 @@ void mask_flags(const DevCSR& Tm, const DevCSR& M, int mcode, bool mstruct, bool
 void csr_reduce_rows(int code, const DevCSR& A, const void* aval, int op, void* tval, uint8_t* tpres);
 // the same per COLUMN of A, without the transpose: every entry combines into its column's accumulator (atomics); false for 1- and 2-byte types
 bool csr_reduce_cols(int code, const DevCSR& A, const void* aval, int op, const void* identity, void* tval, uint8_t* tpres);
+bool csr_reduce_cols_few_rows(int code, const DevCSR& A, const void* aval, int op, void* tval, uint8_t* tpres);   // <= 64 rows, FP types: row after row, fixed order, no atomics
 uint64_t csr_find_entry(const DevCSR& A, uint32_t i, uint32_t j);        // position of (i, j) in col / val, ~0 when not stored (one host round trip)
 void csr_row_indices(const DevCSR& A, uint32_t* rowidx);
 void csr_dense_fill(uint32_t nrows, uint32_t ncols, const void* scalar, size_t ts, DevCSR& out);     // every position holds `scalar`: rowptr[i] = i ncols, col[e] = e mod ncols

@@ -209,7 +209,11 @@ void do_reduce_vector(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Mon
     //  bits depending on whether an earlier operation happened to build the transpose)
     const int rop = monoid->op->opcode;
     const bool order_free = !(mc == T_FP32 || mc == T_FP64) || rop == B_MIN || rop == B_MAX || rop == B_ANY;
-    if (!A->csc.valid && A->csr.nnz >= (1u << 20) && order_free) {
+    if (!A->csc.valid && A->csr.nnz >= (1u << 20) && !order_free && A->csr.nrows <= 64) {      // a few long rows (a batch of the BC sweeps): row after row, no atomics, fixed order
+      const void* av = cast_values(mc, A->type->code, A->csr.val.p, A->csr.nnz, ac);
+      done = csr_reduce_cols_few_rows(mc, A->csr, av, rop, tval.p, tpres.as<uint8_t>());
+    }
+    if (!done && !A->csc.valid && A->csr.nnz >= (1u << 20) && order_free) {
       const void* av = cast_values(mc, A->type->code, A->csr.val.p, A->csr.nnz, ac);
       uint8_t id[16]; memcpy(id, monoid->identity, 16);
       fp_minmax_identity(mc, monoid->op->opcode, id);          // FP MIN / MAX start from NaN = from the column's first value (the one NaN rule, grb_opcommon.hpp)
