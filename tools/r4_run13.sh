@@ -1,5 +1,5 @@
 #!/bin/bash
-out=gpurun_out/r4o; mkdir -p $out
+out=gpurun_out/r4y; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 timeout 1200 python -m pytest tests/test_mxv_vxm_gpu.py tests/test_baseline_configs_gpu.py tests/test_companion_ops_gpu.py tests/test_reference_suite_gpu.py tests/test_dist_gpu.py -x -q -k "not rmat25" > $out/tests.log 2>&1; echo "tests rc=$?"
 tail -n 4 $out/tests.log
