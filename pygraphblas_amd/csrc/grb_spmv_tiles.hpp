@@ -40,11 +40,23 @@ namespace grb {
 // The 16-bit plane is used for 8-byte types only: with 4-byte values the table would shrink from 39932 to 24576 slots, and the
 // pattern-only FP32 product (PageRank's PLUS_SECOND) measured 130 us with it against 105 us with 32-bit words.
 template <class T> struct xt_fmt { static constexpr bool C16 = XT_C16 != 0 && sizeof(T) >= 8; };
+// 32-bit entry words (round 4): bit 31 first entry of a sub-row, bit 30 (XT_COLD) the column is not in the table, bits 29..0 the slot in the LDS
+// table or the column itself.  `word << 2` (4-byte values) then IS the byte offset — into the table for a hot entry, into u for a cold one —
+// with both flags shifted out.  The table's LAST slot holds zero bits and is never given to a column (HOT = H - 1): a cold lane reads it, a hot
+// lane's gather is suppressed and returns zero bits, and the operand's value is the OR of the two — no test, no select at consume time.
+constexpr uint32_t XT_COLD = 0x40000000u, XT_IDXMASK = 0x3FFFFFFFu;
 template <class T> struct xt_hot {
   static constexpr int HLDS = (WP_LDS_BYTES - 16 - WP_WAVES * 64 * (int)sizeof(T)) / (int)sizeof(T);
   static constexpr int H = xt_fmt<T>::C16 ? (HLDS < 24576 ? HLDS : 24576) : HLDS;
-  static constexpr uint64_t MAXCOLS = xt_fmt<T>::C16 ? ((uint64_t)(32768 - H) << 16) : 0x7FFFFFFFull - (uint64_t)H;
+  static constexpr int HOT = xt_fmt<T>::C16 ? H : H - 1;          // columns a table serves
+  static constexpr uint64_t MAXCOLS = xt_fmt<T>::C16 ? ((uint64_t)(32768 - H) << 16) : (uint64_t)XT_IDXMASK;
 };
+template <class E> __device__ __forceinline__ E xt_or_bits(E a, E b) {
+  if constexpr (sizeof(E) == 8) { union { E e; unsigned long long u; } x, y; x.e = a; y.e = b; x.u |= y.u; return x.e; }
+  else if constexpr (sizeof(E) == 4) { union { E e; uint32_t u; } x, y; x.e = a; y.e = b; x.u |= y.u; return x.e; }
+  else if constexpr (sizeof(E) == 2) { union { E e; uint16_t u; } x, y; x.e = a; y.e = b; x.u |= y.u; return x.e; }
+  else { union { E e; uint8_t u; } x, y; x.e = a; y.e = b; x.u |= y.u; return x.e; }
+}
 
 // the segmented scan of the sums and the prefix count of the row starts in one pass: x = flag << 31 | count
 template <class T, class SR> __device__ __forceinline__ void xt_seg_scan_count(T& v, uint32_t& x, int lane, const SR& sr) {
@@ -172,6 +184,7 @@ template <class T> struct XtCall { const T* u; uint32_t ulen; uint32_t sps; T* p
 
 template <class T> struct XtStage {       // what one tile has in flight
   uint32_t c[WP_PER]; T v[WP_PER], g[WP_PER]; uint32_t rf; uint32_t tile;   // column words (32-bit form), values, gathered operands; rf: sub-row of its first entry
+  T hl[WP_PER];                             // 32-bit format: what the LDS table holds for the entry (its zero slot for a cold one), read when the gather is issued
   uint32_t h[2], xq[3], cb, xr;             // 16-bit format: the four raw words, three dwords of extras, the tile's base in `extras`, index of the lane's first extra
 };
 typedef uint32_t xt_v3u __attribute__((ext_vector_type(3)));
@@ -208,6 +221,8 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
   if (threadIdx.x == 0) s_next = 0;
   const bool use_a = sr.uses_a() && a.aval != nullptr, use_u = sr.uses_u();
   if (use_u) for (uint32_t h = threadIdx.x; h < a.nhot; h += XT_WAVES_ * 64) s_hot[h] = wp_ld(a.xhot + h);      // the table's contents, gathered from u once per call
+  constexpr bool ZSLOT = !xt_fmt<T>::C16;               // the plan left the table's last slot free (32-bit entry words are this type's own format, not a measurement variant)
+  if constexpr (!C16 && ZSLOT) { if (threadIdx.x == 0) { T z; __builtin_memset(&z, 0, sizeof(T)); s_hot[H - 1] = z; } }      // the zero slot (nhot <= H - 1)
   // (16-bit words: the range covers whole tiles — the plan pads them with zeros — because the range check works on dwords and an
   //  odd entry count would otherwise cut the panel's last word off)
   const __amdgpu_buffer_rsrc_t c_rsrc = C16 ? __builtin_amdgcn_make_buffer_rsrc((void*)a.col16, (short)0, (int)(a.ntiles * (uint32_t)WP_ENT * 2u), 0x00020000)
@@ -296,10 +311,16 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
         wl = __builtin_amdgcn_alignbit(wh, wl, adv); wh >>= adv;
       }
     } else {
+      // (entries behind the end of the panel are zero words — the plan pads with zeros, the descriptor's range ends with the panel — i.e. slot 0
+      //  of the table: they fetch nothing and are never looked at)
 #pragma unroll
       for (int u = 0; u < WP_PER; u++) {
-        const uint32_t cc = (uint32_t)(lane * WP_PER + u) < cnt ? (s.c[u] & WP_COLMASK) : 0u;   // slot in the LDS table, or H + column
-        s.g[u] = (use_u && EXP != 1) ? xt_buf_load<T>(u_rsrc, cc >= (uint32_t)H ? (cc - (uint32_t)H) * (uint32_t)sizeof(T) : 0xFFFFFFFFu) : T();   // only the columns the table does not hold are fetched
+        const uint32_t w = s.c[u];
+        const bool cold = (w & XT_COLD) != 0;
+        const uint32_t off = (w & XT_IDXMASK) * (uint32_t)sizeof(T);                              // (4-byte values: w << 2)
+        s.g[u] = (use_u && EXP != 1) ? xt_buf_load<T>(u_rsrc, cold ? off : 0xFFFFFFFFu) : T();      // only the columns the table does not hold are fetched (the others return zero bits)
+        if constexpr (ZSLOT) s.hl[u] = use_u ? *(const T*)((const char*)s_hot + (cold ? (uint32_t)(H - 1) * (uint32_t)sizeof(T) : off)) : T();
+        else s.hl[u] = T();
       }
     }
   };
@@ -330,8 +351,12 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
     T p[WP_PER];
 #pragma unroll
     for (int u = 0; u < WP_PER; u++) {
-      const uint32_t cc = C16 ? (A.h[u >> 1] >> (16 * (u & 1))) & 0x7FFFu : A.c[u] & WP_COLMASK;
-      const T uvv = use_u ? (cc < (uint32_t)H ? s_hot[cc < (uint32_t)H ? cc : 0] : A.g[u]) : T();
+      T uvv;
+      if constexpr (C16) {
+        const uint32_t cc = (A.h[u >> 1] >> (16 * (u & 1))) & 0x7FFFu;
+        uvv = use_u ? (cc < (uint32_t)H ? s_hot[cc < (uint32_t)H ? cc : 0] : A.g[u]) : T();
+      } else if constexpr (ZSLOT) uvv = use_u ? xt_or_bits<T>(A.g[u], A.hl[u]) : T();   // one of the two is zero bits (see XT_COLD)
+      else { const uint32_t w = A.c[u]; uvv = use_u ? ((w & XT_COLD) ? A.g[u] : s_hot[w & XT_IDXMASK]) : T(); }      // (measurement variant: 32-bit words for an 8-byte type)
       p[u] = sr.mult(A.v[u], uvv);                             // entries past cnt hold junk: a forward scan never lets it reach a live position
     }
 #ifdef XT_PROFILE

@@ -133,13 +133,15 @@ static __global__ void k_xp_panel_starts(const uint32_t* __restrict__ key, uint3
 static __global__ void k_xp_fix_starts(uint32_t* __restrict__ start, uint32_t n, uint32_t ns) {      // a panel without columns starts where the next one does
   if (blockIdx.x == 0 && threadIdx.x == 0) { start[ns] = n; for (int k = (int)ns - 1; k >= 0; k--) if (start[k] == 0xFFFFFFFFu) start[k] = start[k + 1]; }
 }
-// code word of a column: (slot or H + column) << 3 | panel; the panel's hot-column list
-static __global__ void k_xp_column_codes(const uint32_t* __restrict__ key, const uint32_t* __restrict__ cols, uint32_t n, uint32_t H, const uint32_t* __restrict__ start,
+// code word of a column (round 4): its slot in its stream's LDS table when it is one of the `hot` most frequent columns there, XT_COLD | column
+// otherwise (bit 31 is left for the row-start flag of the entry words); the stream's hot-column list.  The stream of a column comes from the
+// line deal (pol[]), not from the word.
+static __global__ void k_xp_column_codes(const uint32_t* __restrict__ key, const uint32_t* __restrict__ cols, uint32_t n, uint32_t H, uint32_t hot, const uint32_t* __restrict__ start,
                                          uint32_t* __restrict__ code, uint32_t* __restrict__ hot_cols) {
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const uint32_t k = key[i] >> 20, c = cols[i], local = i - start[k];
-    code[c] = ((local < H ? local : H + c) << 3) | (k & 7u);      // (the low bits name the XCD when tables are per XCD; with a table per sub-panel the bucket comes from the line deal)
-    if (local < H) hot_cols[(size_t)k * H + local] = c;
+    code[c] = local < hot ? local : (XT_COLD | c);
+    if (local < hot) hot_cols[(size_t)k * H + local] = c;
   }
 }
 // row of every entry: the non-empty rows mark their first entry, an inclusive max-scan fills the rest
@@ -170,9 +172,9 @@ template <class T> struct XpSweep {
   uint32_t* pcol; T* pval; uint32_t* rowtmp;
 };
 template <class T> __device__ __forceinline__ uint32_t xp_bucket(const XpSweep<T>& a, uint32_t code, uint32_t c, uint32_t r) {
-  const uint32_t k = code & 7u;
-  if (a.S == 1u) return k;
-  if (a.own || (code >> 3) >= a.H) return (uint32_t)a.pol[c >> a.lshift];
+  const uint32_t vp = (uint32_t)a.pol[c >> a.lshift];                // the virtual panel of the column's line
+  if (a.S == 1u || a.own || (code & XT_COLD)) return vp;
+  const uint32_t k = vp / a.S;
   const uint32_t bits = (uint32_t)(a.rowmask[r] >> (k * a.S)) & ((1u << a.S) - 1u);
   return k * a.S + (bits ? (uint32_t)__builtin_ctz(bits) : (r & (a.S - 1u)));
 }
@@ -180,7 +182,7 @@ static __global__ void k_xp_rowmask(const uint32_t* __restrict__ col, const uint
                                     uint32_t lshift, unsigned long long* __restrict__ rowmask) {
   for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < nnz; p += gridDim.x * 256ull) {
     const uint32_t c = col[p];
-    if ((code[c] >> 3) < H) continue;
+    if (!(code[c] & XT_COLD)) continue;
     const uint32_t r = rowidx[p]; const unsigned long long m = 1ull << pol[c >> lshift];
     // (read at the L2 first: a hub row's 10^5 cold entries would otherwise queue on one address, one atomic per ~80 ns)
     if (!(__hip_atomic_load(&rowmask[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m)) atomicOr(&rowmask[r], m);
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(XP_ST) void k_xp_sweep(const XpSweep<T> a) {
         const uint32_t rel = (a.escan[(size_t)k * a.nunits + u] - a.escan[(size_t)k * a.nunits]) + off + myrank;     // position in the virtual panel
         const bool flag = prow != r || (a.vpoff[k] + rel) % a.chunk_entries[k] == 0;       // (prow == WP_NONE is never a row; chunks are cut on the physical stream)
         const uint64_t dest = a.ebase[k] + rel;
-        a.pcol[dest] = (code >> 3) | (flag ? WP_ROWSTART : 0u);
+        a.pcol[dest] = code | (flag ? WP_ROWSTART : 0u);
         if (a.pval) a.pval[dest] = a.val[p];
         if (flag) a.rowtmp[dest] = r;
       }
@@ -304,7 +306,7 @@ static __global__ __launch_bounds__(256) void k_xc_count(const uint32_t* __restr
   const uint32_t lane = threadIdx.x & 63;
   for (uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6); g < ntiles; g += gridDim.x * 4) {
     const uint4 wd = *(const uint4*)(pcol + (size_t)g * WP_ENT + lane * 4);
-    const uint32_t c = ((wd.x & WP_COLMASK) >= H) + ((wd.y & WP_COLMASK) >= H) + ((wd.z & WP_COLMASK) >= H) + ((wd.w & WP_COLMASK) >= H);
+    const uint32_t c = ((wd.x >> 30) & 1u) + ((wd.y >> 30) & 1u) + ((wd.z >> 30) & 1u) + ((wd.w >> 30) & 1u);      // XT_COLD
     const uint32_t tot = __builtin_amdgcn_wave_reduce_add_u32(c, 0);
     if (lane == 0) tcnt[g] = tot;
   }
@@ -318,7 +320,7 @@ static __global__ __launch_bounds__(256) void k_xc_pack(const uint32_t* __restri
     const uint32_t w[4] = {wd.x, wd.y, wd.z, wd.w};
     uint32_t mine = 0; bool cold[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { cold[j] = (w[j] & WP_COLMASK) >= H; mine += cold[j] ? 1u : 0u; }
+    for (int j = 0; j < 4; j++) { cold[j] = (w[j] & XT_COLD) != 0; mine += cold[j] ? 1u : 0u; }
     uint32_t incl = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += o; }
@@ -326,8 +328,8 @@ static __global__ __launch_bounds__(256) void k_xc_pack(const uint32_t* __restri
     uint32_t o16[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const uint32_t v = w[j] & WP_COLMASK, flag = (w[j] >> 31) << 15;
-      if (cold[j]) { const uint32_t c = v - H; o16[j] = flag | (H + (c >> 16)); extras[x++] = (uint16_t)(c & 0xFFFFu); }
+      const uint32_t v = w[j] & XT_IDXMASK, flag = (w[j] >> 31) << 15;
+      if (cold[j]) { const uint32_t c = v; o16[j] = flag | (H + (c >> 16)); extras[x++] = (uint16_t)(c & 0xFFFFu); }
       else o16[j] = flag | v;
     }
     *(uint2*)(col16 + q0) = make_uint2(o16[0] | (o16[1] << 16), o16[2] | (o16[3] << 16));
@@ -357,7 +359,7 @@ static __global__ __launch_bounds__(256) void k_xc_verify(const uint32_t* __rest
       const uint32_t w16 = (h[u >> 1] >> (16 * (u & 1))) & 0xFFFFu, code = w16 & 0x7FFFu, flag = (w16 & 0x8000u) << 16;
       const bool cold = code >= H;
       const uint32_t lo = (uint32_t)((q < 2u ? wa >> (16u * q) : wb >> (16u * (q - 2u)))) & 0xFFFFu;
-      const uint32_t c = flag | (cold ? H + (((code - H) << 16) | lo) : code);
+      const uint32_t c = flag | (cold ? XT_COLD | (((code - H) << 16) | lo) : code);
       q += cold ? 1u : 0u;
       if (c != pcol[q0 + u]) { const unsigned long long n = atomicAdd(bad, 1ull); if (n == 0) { bad[1] = q0 + u; bad[2] = ((unsigned long long)c << 32) | pcol[q0 + u]; } }
     }
@@ -751,6 +753,7 @@ template <class T> int xp_subpanels(uint64_t ncols, bool* forced_out) {
   const uint32_t forced = wp_env("GRB_MI355X_XS", 0);
   *forced_out = forced == 1 || forced == 2 || forced == 4 || forced == 8;
   if (*forced_out) return (int)forced;
+  if (sizeof(T) <= 4 && ncols >= (1ull << 25)) return 8;       // (R-MAT-25 FP32 PageRank: 1.54 ms per iteration with S = 4, 1.45 with S = 8)
   if (ncols >= (1ull << 24)) return 4;
   if (sizeof(T) <= 4 && ncols >= (1ull << 23)) return 2;
   return 1;
@@ -815,7 +818,7 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
     GRB_HIP(hipMemsetAsync(cstart.p, 0xFF, (XPMAX + 1) * 4, stream()));
     hipLaunchKernelGGL(k_xp_panel_starts, dim3(grid_n(n)), dim3(256), 0, stream(), k32o.as<uint32_t>(), n, cstart.as<uint32_t>());
     hipLaunchKernelGGL(k_xp_fix_starts, dim3(1), dim3(1), 0, stream(), cstart.as<uint32_t>(), n, NS);
-    hipLaunchKernelGGL(k_xp_column_codes, dim3(grid_n(n)), dim3(256), 0, stream(), k32o.as<uint32_t>(), cout.as<uint32_t>(), n, H, cstart.as<uint32_t>(), code.as<uint32_t>(), P->hot_cols.as<uint32_t>());
+    hipLaunchKernelGGL(k_xp_column_codes, dim3(grid_n(n)), dim3(256), 0, stream(), k32o.as<uint32_t>(), cout.as<uint32_t>(), n, H, (uint32_t)xt_hot<T>::HOT, cstart.as<uint32_t>(), code.as<uint32_t>(), P->hot_cols.as<uint32_t>());
   }   // (the temporaries return to the pool; reuse is stream-ordered)
   // 2. row of every entry
   DevBuf rowidx(nnz * 4 + 4);
@@ -853,7 +856,7 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
     P->ne[k] = hp[(k + 1) * vps] - hp[k * vps];                          // a stream = its virtual panels, one after the other
     P->ntiles[k] = (uint32_t)((P->ne[k] + WP_ENT - 1) / WP_ENT);
     P->tbase[k + 1] = P->tbase[k] + P->ntiles[k];
-    const uint32_t nk = hp[XPMAX + 1 + k + 1] - hp[XPMAX + 1 + k]; P->nhot[k] = nk < H ? nk : H;
+    const uint32_t nk = hp[XPMAX + 1 + k + 1] - hp[XPMAX + 1 + k]; P->nhot[k] = nk < (uint32_t)xt_hot<T>::HOT ? nk : (uint32_t)xt_hot<T>::HOT;
     kt[k] = wp_chunk_tasks(P->ntiles[k], wpp);
     nchunks_total += (P->ntiles[k] + kt[k] - 1) / kt[k];
     for (uint32_t sp = 0; sp < vps; sp++) {
