@@ -392,11 +392,11 @@ template <class T> void build_wavepipe_plan(DevCSR& M) {
                      M.wp_rs.as<uint32_t>(), M.wp_rs.as<uint32_t>() + (ntasks + 1));
   DevBuf cnt((size_t)n * 4 + 4), key((size_t)n * 4 + 4), id((size_t)n * 4 + 4), key2((size_t)n * 4 + 4), id2((size_t)n * 4 + 4), rank((size_t)n * 4 + 4);
   GRB_HIP(hipMemsetAsync(cnt.p, 0, (size_t)n * 4 + 4, stream()));
-  // Column frequencies from a SAMPLE of ~2^21 entries (round 4).  The ranking only decides which columns sit in the LDS table and in the
+  // Column frequencies from a SAMPLE of ~2^22 entries (round 4).  The ranking only decides which columns sit in the LDS table and in the
   // rank-ordered warm copy — any choice is correct, and the columns that matter are those a sample finds.  Counting every entry cost
-  // 4.5 ms at R-MAT-22 (device atomics; the hottest columns serialise), most of this plan; the sample is sorted (a radix sort of 2 M
+  // 4.5 ms at R-MAT-22 (device atomics; the hottest columns serialise), most of this plan; the sample is sorted (a radix sort of 4 M
   // keys) and counted as run lengths — no atomics.  This is what makes kernel W the product a matrix runs FIRST (grb_spmv_kernels.hpp).
-  { const uint64_t target = (uint64_t)wp_env("GRB_MI355X_WP_SAMPLE", 1u << 21);
+  { const uint64_t target = (uint64_t)wp_env("GRB_MI355X_WP_SAMPLE", 1u << 22);
     const uint64_t stride = M.nnz > target ? M.nnz / target : 1, m = (M.nnz + stride - 1) / stride;
     DevBuf samp(m * 4 + 4), sorted(m * 4 + 4), first((size_t)n * 4 + 4);
     int cb = 1; while ((1ull << cb) < (unsigned long long)n) cb++;
