@@ -10,6 +10,10 @@
 // peer inside the group; the matching receive opens the handle, copies device-to-device ON THE STREAM IT WAS GIVEN, synchronises that
 // stream and marks the slot consumed; the sender returns from ncclGroupEnd once its sends were consumed.  An all-reduce stages the
 // ranks' buffers through the control block and every rank reduces them in rank order.
+// With more than two ranks a buffer would be imported by several peers at once, which the dmabuf IPC of this driver refuses
+// (hipIpcOpenMemHandle: invalid device pointer — an exported handle serves one importer): there the bytes are staged through a POSIX
+// shared-memory file per transfer (device -> shm by the sender, shm -> device on the receiver's stream).  Matching, ordering and the
+// library's code path are the same; only the copy engine differs.
 // Unlike RCCL the calls are host-synchronous (the stream is drained at ncclGroupEnd): ordering bugs that only show with asynchronous
 // progress are not provoked, data movement and matching are.  Every wait has a deadline (FAKE_RCCL_TIMEOUT_S, default 60 s) and fails
 // with ncclSystemError instead of hanging the box.
@@ -31,6 +35,7 @@ constexpr int MAXR = 8, MAXK = 8, AR_BYTES = 1 << 16;
 struct Slot {
   volatile uint64_t posted, done;       // sequence numbers of the last transfer posted by the sender / consumed by the receiver
   hipIpcMemHandle_t h; uint64_t offset, bytes;
+  int staged; char shm[96];            // staged != 0: the bytes are in the shared-memory file `shm` instead of behind the handle
 };
 struct Ctl {
   volatile int arrived, left;
@@ -110,15 +115,26 @@ ncclResult_t run_group() {
     Slot* s = &m->c->p2p[m->rank][o.peer][k];
     const uint64_t n = ++m->scount[o.peer][k];
     if (!wait_until([&] { return s->done == n - 1; })) { fprintf(stderr, "[fake_rccl] rank %d: the previous send to %d was never consumed\n", m->rank, o.peer); return ncclSystemError; }
-    hipDeviceptr_t base = nullptr; size_t span = 0;
-    FK_HIP(hipMemGetAddressRange(&base, &span, (hipDeviceptr_t)o.buf));
-    FK_HIP(hipIpcGetMemHandle(&s->h, base));
-    s->offset = (uint64_t)((const char*)o.buf - (const char*)base); s->bytes = o.bytes;
+    if (m->world > 2) {                              // several importers per buffer: stage through shared memory
+      snprintf(s->shm, sizeof s->shm, "%s_x%d_%d_%d_%llu", m->name, m->rank, o.peer, k, (unsigned long long)n);
+      const int fd = shm_open(s->shm, O_CREAT | O_EXCL | O_RDWR, 0600);
+      if (fd < 0 || ftruncate(fd, (off_t)(o.bytes ? o.bytes : 1)) != 0) { perror("[fake_rccl] shm staging"); if (fd >= 0) close(fd); return ncclSystemError; }
+      void* hp = mmap(nullptr, o.bytes ? o.bytes : 1, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0); close(fd);
+      if (hp == MAP_FAILED) { perror("[fake_rccl] mmap staging"); return ncclSystemError; }
+      FK_HIP(hipMemcpy(hp, o.buf, o.bytes, hipMemcpyDeviceToHost));
+      munmap(hp, o.bytes ? o.bytes : 1);
+      s->staged = 1; s->offset = 0; s->bytes = o.bytes;
+    } else {
+      hipDeviceptr_t base = nullptr; size_t span = 0;
+      FK_HIP(hipMemGetAddressRange(&base, &span, (hipDeviceptr_t)o.buf));
+      FK_HIP(hipIpcGetMemHandle(&s->h, base));
+      s->staged = 0; s->offset = (uint64_t)((const char*)o.buf - (const char*)base); s->bytes = o.bytes;
+    }
     __sync_synchronize(); s->posted = n; __sync_synchronize();
     mine.push_back({s, n});
   }
   std::vector<hipStream_t> rstreams;
-  struct Got { Slot* s; uint64_t n; void* mapped; };
+  struct Got { Slot* s; uint64_t n; void* mapped; void* host; size_t host_bytes; };
   std::vector<Got> got;
   for (const Op& o : ops) if (!o.send) {           // 2. every receive: open the peer's allocation, copy on the caller's stream
     Comm* m = o.comm; const int k = kr[o.peer]++;
@@ -127,14 +143,26 @@ ncclResult_t run_group() {
     const uint64_t n = ++m->rcount[o.peer][k];
     if (!wait_until([&] { return s->posted == n; })) { fprintf(stderr, "[fake_rccl] rank %d: no matching send from %d (receive %d of the group)\n", m->rank, o.peer, k); return ncclSystemError; }
     if (s->bytes != o.bytes) { fprintf(stderr, "[fake_rccl] rank %d: receive of %zu bytes from %d meets a send of %llu\n", m->rank, o.bytes, o.peer, (unsigned long long)s->bytes); return ncclInvalidArgument; }
-    void* mapped = nullptr;
-    hipIpcMemHandle_t h; memcpy(&h, (const void*)&s->h, sizeof h);
-    FK_HIP(hipIpcOpenMemHandle(&mapped, h, hipIpcMemLazyEnablePeerAccess));
-    FK_HIP(hipMemcpyAsync(o.buf, (const char*)mapped + s->offset, o.bytes, hipMemcpyDeviceToDevice, o.stream));
-    rstreams.push_back(o.stream); got.push_back({s, n, mapped});
+    void* mapped = nullptr; void* hp = nullptr;
+    if (s->staged) {
+      const int fd = shm_open(s->shm, O_RDWR, 0600);
+      if (fd < 0) { perror("[fake_rccl] shm staging (open)"); return ncclSystemError; }
+      hp = mmap(nullptr, o.bytes ? o.bytes : 1, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0); close(fd);
+      if (hp == MAP_FAILED) { perror("[fake_rccl] mmap staging (open)"); return ncclSystemError; }
+      FK_HIP(hipMemcpyAsync(o.buf, hp, o.bytes, hipMemcpyHostToDevice, o.stream));
+    } else {
+      hipIpcMemHandle_t h; memcpy(&h, (const void*)&s->h, sizeof h);
+      FK_HIP(hipIpcOpenMemHandle(&mapped, h, hipIpcMemLazyEnablePeerAccess));
+      FK_HIP(hipMemcpyAsync(o.buf, (const char*)mapped + s->offset, o.bytes, hipMemcpyDeviceToDevice, o.stream));
+    }
+    rstreams.push_back(o.stream); got.push_back({s, n, mapped, hp, o.bytes ? o.bytes : 1});
   }
   for (hipStream_t st : rstreams) FK_HIP(hipStreamSynchronize(st));
-  for (const Got& g : got) { FK_HIP(hipIpcCloseMemHandle(g.mapped)); __sync_synchronize(); g.s->done = g.n; }
+  for (const Got& g : got) {
+    if (g.mapped) FK_HIP(hipIpcCloseMemHandle(g.mapped));
+    if (g.host) { munmap(g.host, g.host_bytes); shm_unlink(g.s->shm); }
+    __sync_synchronize(); g.s->done = g.n;
+  }
   __sync_synchronize();
   for (const Posted& p : mine)                      // 3. my buffers may be reused once the receivers have copied them
     if (!wait_until([&] { return p.s->done == p.n; })) { fprintf(stderr, "[fake_rccl] a send was never consumed\n"); return ncclSystemError; }

@@ -135,31 +135,42 @@ def test_two_ranks_on_one_gpu_through_the_library_exchange_path(gb, gpu):
         assert res[r]["transport"].endswith("libfake_rccl.so"), res[r]["transport"]
 
 
-def _two_ranks(gb, transport):
+def test_four_ranks_on_one_gpu_through_the_library_exchange_path(gb, gpu):
+    """World size 4 (what the driver's N = 4 run executes per rank, minus xGMI): every rank sends its slice to three peers and receives three in
+    one group — the rotating peer order of GrBX_Vector_allgatherv_start, four slices of the bit frontier, a four-way all-reduce."""
+    _ensure_fake_rccl()
+    res = _two_ranks(gb, "rccl", world=4)
+    for r in range(4):
+        assert res[r]["transport"].endswith("libfake_rccl.so"), res[r]["transport"]
+
+
+def _two_ranks(gb, transport, world=2):
     import torch.multiprocessing as mp
     ref = _single_process_reference(gb)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 2000) + (11 if transport == "rccl" else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, transport)) for r in range(2)]
+    port = 29600 + (os.getpid() % 2000) + (11 if transport == "rccl" else 0) + (5 if world != 2 else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=600) for _ in range(2))
+    res = dict(q.get(timeout=600) for _ in range(world))
     for p in procs:
         p.join(60)
-    for r in (0, 1):
+    for r in range(world):
         assert "error" not in res[r], res[r]["error"]
     n = 1 << SCALE
     pr = np.zeros(n, np.float32); lev = np.zeros(n, np.uint8)
-    for r in (0, 1):
+    for r in range(world):
         a, b, x, its = res[r]["pr"]; pr[a:b] = x
         assert its == ref["its"]
         a, b, x, depth = res[r]["bfs"]; lev[a:b] = x
         assert depth == ref["depth"]
-    assert res[0]["pr"][1] == res[1]["pr"][0] and 0 < res[0]["pr"][1] < n            # two non-empty blocks
+    for r in range(world - 1):
+        assert res[r]["pr"][1] == res[r + 1]["pr"][0]                                  # contiguous blocks ...
+    assert 0 < res[0]["pr"][1] < n                                                      # ... more than one of them non-empty
     assert np.allclose(pr, ref["pr"], rtol=1e-6, atol=0.0)
     assert np.array_equal(lev, ref["lev"])                                              # bit-exact level vector
-    assert res[0]["tri"][0] == res[1]["tri"][0] == ref["tri"]                           # INT64, exact
+    assert all(res[r]["tri"][0] == ref["tri"] for r in range(world))                    # INT64, exact
     assert 0 < res[0]["tri"][2] < n
     return res
 
