@@ -196,33 +196,103 @@ template <class T> struct spa_cfg { static constexpr uint32_t WD = sizeof(typena
 constexpr uint32_t SPA_SYM_WORDS = 32768;      // 2^20 bits
 // The products of up to 1024 entries k of A(i,:) (one per thread: `len` entries of B starting at `st`), dealt evenly to the 16
 // waves of the workgroup whatever the lengths are — most are empty or a single entry, a hub's is tens of thousands: an exclusive
-// scan of the lengths in LDS, every wave takes a sixteenth of the product range in rounds of 64, and a lane finds the entry its
-// product belongs to by a binary search over the scan.  f(v, pb): entry v of the chunk, position pb in B.  (A group of 16 lanes
-// per entry, as the table kernels do it, left this kernel waiting 96 % of its cycles: rows with a few dozen entries pointing at
-// hub rows kept one group busy and 63 idle.)
-template <class F> __device__ __forceinline__ uint32_t spa_flat_walk(uint32_t st, uint32_t len, uint32_t* s_exc /* [1025] */, uint32_t* s_shift /* [1024] */, uint32_t* s_wtot /* [16] */, F&& f) {
-  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  uint32_t inc = len;
-  for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += v; }
+// scan of the lengths in LDS, the product range is cut into batches of up to SPA_R rounds of 64, and a lane finds the entry its
+// product belongs to by a binary search over the scan.  load(v, pb): entry v of the chunk, position pb in B; apply(item).  (A group
+// of 16 lanes per entry, as the table kernels do it, left this kernel waiting 96 % of its cycles: rows with a few dozen entries
+// pointing at hub rows kept one group busy and 63 idle.)
+// Round 4: a lane's products were one dependent chain each — ten LDS reads of the search, the B entry from the L2, the bitmap word, the
+// atomic — and a wave walked its rounds one after the other: ~2 700 clocks per round of 64 products with nothing else in flight (A@A on
+// R-MAT-18: 36 000 rounds per wave, 46 ms symbolic; the numeric pass 108 ms).  Now
+//  (a) the rounds of a batch are searched, loaded and combined together — `load` fetches, `apply` combines: up to SPA_R independent
+//      chains per lane, every load of the batch in one basic block (46 -> 25 ms, 108 -> 73 ms with four);
+//  (b) the search runs over the entries the batch begins and ends in only — the entries of a hub's row cover whole rounds and need no
+//      step at all.  Those two entries cost two LDS reads and four ballots: the sixteen wave totals sit in the lanes of a register (which
+//      64-entry chunk), the chunk's 64 offsets are read one per lane (which entry);
+//  (c) the batches go round the waves instead of every wave taking a sixteenth of the range: the first entries of a row of a power-law
+//      graph are its hubs (long parts, no search, consecutive loads), the last ones its tail (a part per product) — thread 0's wave
+//      spent 6 400 clocks per (row, block) step in its rounds and 4 500 waiting for the others (SPA_PROFILE build);
+//  (d) the scans are DPP scans (six VALU steps instead of six trips through the LDS crossbar).
+#ifndef SPA_R_V
+#define SPA_R_V 8
+#endif
+#ifdef SPA_PROFILE
+// measurement build (make BUILD=build_spa LIB=../libgrb_spa.so XTFLAGS=-DSPA_PROFILE): clocks of thread 0 of every workgroup of the last numeric launch by phase —
+// [0] scan of the lengths + two barriers, [1] its rounds, [2] waiting for the other waves' rounds, [3] scan of the bitmap, [4] emission, [5] the last barrier,
+// [6] (row, block) steps with products, [7] the kernel, [8] steps without products.  tools/spa_phase_probe.py reads them.
+static __device__ unsigned long long g_spa_prof[1024 * 16];
+#define SPA_PF(K) { if (pf) { const unsigned long long pf_t = __builtin_amdgcn_s_memtime(); pf[K] += pf_t - pf[15]; pf[15] = pf_t; } }
+#else
+#define SPA_PF(K)
+#endif
+constexpr int SPA_R = SPA_R_V;
+__device__ __forceinline__ uint32_t spa_wave_incl_add(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);      // row_shr:1 (lanes without a source add 0)
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+  return v;
+}
+// the sixteen per-wave counts in s_w[16] (written before the last barrier): their sum, and the sum of those before `wave`; the exclusive
+// offset of chunk (lane & 15) is left in `pre`
+__device__ __forceinline__ void spa_wave_offsets(const uint32_t* s_w, uint32_t lane, uint32_t wave, uint32_t& woff, uint32_t& total, uint32_t& pre) {
+  const uint32_t wt = s_w[lane & 15];
+  uint32_t v = wt;                                                                       // inclusive scan inside every row of 16 lanes
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+  pre = v - wt;
+  total = (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+  woff = (uint32_t)__builtin_amdgcn_readlane((int)pre, (int)wave);
+}
+template <class L, class A> __device__ __forceinline__ uint32_t spa_flat_walk(uint32_t st, uint32_t len, uint32_t* s_exc /* [1025] */, uint32_t* s_shift /* [1024] */, uint32_t* s_wtot /* [16] */, L&& load, A&& apply, unsigned long long* pf = nullptr) {
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
+  const uint32_t inc = spa_wave_incl_add(len);
   if (lane == 63) s_wtot[wave] = inc;
   __syncthreads();
-  uint32_t woff = 0, total = 0;
-  for (uint32_t w = 0; w < 16; w++) { const uint32_t v = s_wtot[w]; if (w < wave) woff += v; total += v; }
+  uint32_t woff, total, cpre;                                // cpre: first product of the 64-entry chunk (lane & 15)
+  spa_wave_offsets(s_wtot, lane, wave, woff, total, cpre);
   const uint32_t exc = woff + inc - len;
   s_exc[t] = exc; s_shift[t] = st - exc;
   if (t == 0) s_exc[1024] = total;
   __syncthreads();
-  if (total) {
-    const uint32_t q0 = (uint32_t)((uint64_t)total * wave / 16), q1 = (uint32_t)((uint64_t)total * (wave + 1) / 16);
-    for (uint32_t qb = q0; qb < q1; qb += 64) {
-      const uint32_t q = qb + lane; const bool live = q < q1;
-      uint32_t vlo = 0, vhi = 1024;                        // the last entry whose exclusive offset is <= q
+  SPA_PF(0)
+  // entry(q) = the last entry whose exclusive offset is <= q (the entries before it with the same offset are empty)
+  auto entry_of = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t {
+    const uint32_t chunk = (uint32_t)__popc((uint32_t)__ballot(cpre <= q) & 0xFFFFu) - 1u;          // (chunk 0 begins at 0 <= q)
+    const uint32_t x = s_exc[chunk * 64u + lane];
+    return chunk * 64u + (uint32_t)__popcll(__ballot(x <= q)) - 1u;                                  // (the chunk's first offset is <= q)
+  };
+  uint32_t rpb = (total + 1023u) >> 10; rpb = rpb < 1u ? 1u : (rpb > (uint32_t)SPA_R ? (uint32_t)SPA_R : rpb);      // rounds per batch: one batch per wave while that fits
+  const uint32_t bsz = 64u * rpb, nb = (total + bsz - 1u) / bsz;
+  for (uint32_t b = wave; b < nb; b += 16u) {
+    const uint32_t qb = b * bsz, qe = qb + bsz < total ? qb + bsz : total;
+    const uint32_t vbase = entry_of(qb), vlast = entry_of(qe - 1u);
+    uint32_t q[SPA_R], vlo[SPA_R], vhi[SPA_R];
 #pragma unroll
-      for (int s2 = 0; s2 < 10; s2++) { const uint32_t mid = (vlo + vhi) >> 1; if (s_exc[mid] <= q) vlo = mid; else vhi = mid; }
-      if (live) f(vlo, s_shift[vlo] + q);
+    for (int r = 0; r < SPA_R; r++) { q[r] = qb + 64u * r + lane; vlo[r] = vbase; vhi[r] = vlast + 1; }      // exc[vbase] <= q < exc[vlast + 1] for every live q
+    const uint32_t span = vlast - vbase;
+    const int steps = span ? 32 - __builtin_clz(span) : 0;                                                    // span + 1 candidates; wave-uniform
+    for (int s2 = 0; s2 < steps; s2++) {
+#pragma unroll
+      for (int r = 0; r < SPA_R; r++) { const uint32_t mid = (vlo[r] + vhi[r]) >> 1; if (s_exc[mid] <= q[r]) vlo[r] = mid; else vhi[r] = mid; }
     }
+    uint32_t pb[SPA_R];
+#pragma unroll
+    for (int r = 0; r < SPA_R; r++) { const uint32_t sh = s_shift[vlo[r]]; pb[r] = q[r] < qe ? sh + q[r] : 0u; }      // (lanes behind the batch load B's entry 0 — every load of the batch in one basic block — and drop it)
+    decltype(load(0u, 0u)) item[SPA_R];
+#pragma unroll
+    for (int r = 0; r < SPA_R; r++) item[r] = load(vlo[r], pb[r]);
+    // (the bitmap words are read round by round, not together before the batch's atomics: a hub's part sets the bits of its 32-column
+    //  words in its first round and the later rounds see them — reading all of them first meant more same-word atomics: 56.9 -> 61.1 ms)
+#pragma unroll
+    for (int r = 0; r < SPA_R; r++) if (q[r] < qe) apply(item[r]);
   }
+  SPA_PF(1)
   __syncthreads();
+  SPA_PF(2)
   return total;                                             // (the same in every thread)
 }
 template <class T, class SR>
@@ -241,10 +311,8 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_symbolic(const HashArgs a, 
     for (uint32_t base = ab; base < ae; base += 1024) {
       const uint32_t pa = base + t; uint32_t st = 0, len = 0;
       if (pa < ae) { const uint32_t k = a.acol[pa]; st = a.brp[k]; len = a.brp[k + 1] - st; }
-      spa_flat_walk(st, len, s_exc, s_shift, s_wtot, [&](uint32_t, uint32_t pb) {
-        const uint32_t j = a.bcol[pb], bit = 1u << (j & 31);
-        if (!(s_bits[j >> 5] & bit)) atomicOr(&s_bits[j >> 5], bit);
-      });
+      spa_flat_walk(st, len, s_exc, s_shift, s_wtot, [&](uint32_t, uint32_t pb) { return a.bcol[pb]; },
+                    [&](uint32_t j) { const uint32_t bit = 1u << (j & 31); if (!(s_bits[j >> 5] & bit)) atomicOr(&s_bits[j >> 5], bit); });
     }
     uint32_t c = 0;
     for (uint32_t w = t; w < words; w += 1024) { c += __popc(s_bits[w]); s_bits[w] = 0; }
@@ -280,10 +348,14 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
   __shared__ uint32_t s_bits[WORDS];
   __shared__ uint32_t s_exc[1025], s_shift[1024], s_wtot[16];
   __shared__ uint32_t s_wsum[16];
-  __shared__ uint32_t s_total;
-  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
   const bool use_a = sr.uses_a(), use_b = sr.uses_u();
   const W idw = to_word<T>(sr.identity);
+#ifdef SPA_PROFILE
+  unsigned long long pfa[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long* const pf = pfa; const unsigned long long pf_start = __builtin_amdgcn_s_memtime(); pf[15] = pf_start;
+#else
+  unsigned long long* const pf = nullptr;
+#endif
   for (uint32_t e = t; e < WD; e += 1024) s_acc[e] = idw;
   for (uint32_t w = t; w < WORDS; w += 1024) s_bits[w] = 0;
   __syncthreads();
@@ -312,35 +384,52 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
           const uint32_t* sp = split + (size_t)a.acol[pa] * (nblk + 1) + c;
           st = sp[0]; len = sp[1] - st; if (use_a) s_av[t] = aval[pa];      // (read by other threads only behind the walk's first barrier)
         }
-        products |= spa_flat_walk(st, len, s_exc, s_shift, s_wtot, [&](uint32_t v, uint32_t pb) {
-          const uint32_t rel = a.bcol[pb] - lo, bit = 1u << (rel & 31);
-          if (!(s_bits[rel >> 5] & bit)) atomicOr(&s_bits[rel >> 5], bit);
-          word_combine<T>(sr.add_op(), &s_acc[rel], sr.mult(use_a ? s_av[v] : T(), use_b ? bval[pb] : T()));
-        });
+        struct Prod { uint32_t rel; T x; };
+        products |= spa_flat_walk(st, len, s_exc, s_shift, s_wtot,
+          [&](uint32_t v, uint32_t pb) { Prod p; p.rel = a.bcol[pb] - lo; p.x = sr.mult(use_a ? s_av[v] : T(), use_b ? bval[pb] : T()); return p; },
+          [&](const Prod& p) {
+            const uint32_t bit = 1u << (p.rel & 31);
+            if (!(s_bits[p.rel >> 5] & bit)) atomicOr(&s_bits[p.rel >> 5], bit);      // (32 consecutive columns of a hub's part share a word: the read is a broadcast, the atomic would serialise)
+            word_combine<T>(sr.add_op(), &s_acc[p.rel], p.x);
+          }, pf);
       }
+#ifdef SPA_PROFILE
+      pf[products ? 6 : 8]++;
+#endif
       if (!products) continue;                              // nothing of this row falls into this block (the whole workgroup agrees): no emission, no barriers
-      // emit the block in column order: exclusive prefix of the words' popcounts, then every word writes its own run
-      uint32_t mybits = 0, mycnt = 0;
-      if (t < WORDS) { mybits = s_bits[t]; mycnt = (uint32_t)__popc(mybits); }
-      uint32_t inc = mycnt;
-      for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += v; }
+      // emit the block in column order: every thread owns 16 columns; exclusive prefix of their counts, then every thread writes its own run —
+      // four accumulators in flight.  (Round 4: 32 columns on half the threads, thread 0 adding up the wave sums between two barriers and a
+      // barrier behind the emission took 6 500 of a step's 19 700 clocks; the next walk's two barriers already stand between this emission's
+      // resets and the next block's atomics.)
+      constexpr uint32_t BPT = WD / 1024u, TPW = 32u / BPT; static_assert(BPT == 8u || BPT == 16u || BPT == 32u, "a thread emits a whole bitmap word, a half or a quarter");
+      uint32_t mybits = BPT == 32u ? s_bits[t] : (s_bits[t / TPW] >> (BPT * (t % TPW))) & ((1u << (BPT & 31u)) - 1u);
+      const uint32_t mycnt = (uint32_t)__popc(mybits);
+      const uint32_t inc = spa_wave_incl_add(mycnt);
       if (lane == 63) s_wsum[wave] = inc;
       __syncthreads();
-      if (t == 0) { uint32_t run = 0; for (int w = 0; w < 16; w++) { const uint32_t v = s_wsum[w]; s_wsum[w] = run; run += v; } s_total = run; }
-      __syncthreads();
-      if (t < WORDS && mybits) {
-        uint32_t o = obase + s_wsum[wave] + inc - mycnt;
-        s_bits[t] = 0;
-        while (mybits) {
-          const uint32_t b = (uint32_t)__builtin_ctz(mybits), rel = t * 32 + b;
-          ocol[o] = lo + rel; oval[o] = from_word<T>(s_acc[rel]); s_acc[rel] = idw; o++;
-          mybits &= mybits - 1;
-        }
+      uint32_t woff, etotal, unused;
+      spa_wave_offsets(s_wsum, lane, wave, woff, etotal, unused);
+      SPA_PF(3)
+      if (t % TPW == 0) s_bits[t / TPW] = 0;                                     // (all owners of a word read it before the barrier)
+      uint32_t o = obase + woff + inc - mycnt;
+      const uint32_t rel0 = t * BPT;
+      while (mybits) {
+        uint32_t bb[4]; bool has[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { has[j] = mybits != 0; bb[j] = has[j] ? (uint32_t)__builtin_ctz(mybits) : 0u; mybits &= mybits - 1u; }
+        W acc4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc4[j] = s_acc[rel0 + bb[j]];
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (has[j]) { ocol[o] = lo + rel0 + bb[j]; oval[o] = from_word<T>(acc4[j]); s_acc[rel0 + bb[j]] = idw; o++; }
       }
-      obase += s_total;
-      __syncthreads();
+      obase += etotal;
+      SPA_PF(4)
     }
   }
+#ifdef SPA_PROFILE
+  if (t == 0) { pf[7] = __builtin_amdgcn_s_memtime() - pf_start; for (int k = 0; k < 16; k++) g_spa_prof[(size_t)(blockIdx.x & 1023) * 16 + k] = pf[k]; }
+#endif
 }
 // the table rows after their sort: columns and values move from the compact staging arrays (row pointers trp) into the result (orp);
 // one wave per row of the three LDS-table bins

@@ -595,7 +595,10 @@ __global__ __launch_bounds__(XM_CT) void k_xp_merge(uint32_t nrows, uint32_t nbl
 //     barrier, by walking back over the chunk totals.  Every order is fixed: reproducible.
 //   * persistent workgroups (a few per CU) over an XCD's contiguous eighth of the blocks, the next block's bounds fetched a block ahead.
 // LDS: m_slots values + m_slots flag bytes.
-constexpr uint32_t XMW_TARGET = 4096, XMW_ROWS = 2048;
+#ifndef XMW_TARGET_V
+#define XMW_TARGET_V 4096          // sub-rows per block of the wide merge (measurement builds: make XTFLAGS=-DXMW_TARGET_V=8192)
+#endif
+constexpr uint32_t XMW_TARGET = XMW_TARGET_V, XMW_ROWS = XMW_TARGET_V / 2;
 constexpr int XMW_RPT = XMW_ROWS / XM_CT;
 template <class T, class SR, int EPI = 0>
 __global__ __launch_bounds__(XM_CT) void k_xp_merge_wide(uint32_t nrows, uint32_t nblocks, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ blockptr, const uint16_t* __restrict__ slot,
