@@ -192,8 +192,15 @@ __global__ __launch_bounds__(1024) void k_spgemm_dense(const HashArgs a, const T
 #ifndef SPA_WD8_V
 #define SPA_WD8_V 16384
 #endif
-template <class T> struct spa_cfg { static constexpr uint32_t WD = sizeof(typename acc_word<T>::type) >= 8 ? (uint32_t)SPA_WD8_V : 2u * (uint32_t)SPA_WD8_V; };     // 128 KiB of accumulators: one workgroup per CU, but fewer, longer (row, block) steps win — A@A R-MAT-18: 4096 columns 0.252 s, 6144 0.227, 8192 0.210, 12288 0.190, 16384 0.184 (measurement builds: -DSPA_WD8_V=...)
+#ifndef SPA_WD4_V
+#define SPA_WD4_V 28672
+#endif
+// LDS of the numeric kernel: WD accumulators + WD flag bytes + 16.1 KiB of walk state <= 160 KiB.  One workgroup per CU, but fewer, longer (row, block) steps
+// win — A@A R-MAT-18: 4096 columns 0.252 s, 6144 0.227, 8192 0.210, 12288 0.190, 16384 0.184 (measurement builds: -DSPA_WD8_V=...; again in round 4 with the
+// faster walk, two workgroups of 8192 columns per CU: numeric pass 57 -> 78 ms)
+template <class T> struct spa_cfg { static constexpr uint32_t WD = sizeof(typename acc_word<T>::type) >= 8 ? (uint32_t)SPA_WD8_V : (uint32_t)SPA_WD4_V; };
 constexpr uint32_t SPA_SYM_WORDS = 32768;      // 2^20 bits
+constexpr uint32_t SPA_CHUNK = 992;             // entries of A(i,:) per walk of the numeric kernel (the last 32 threads carry none: their share of the walk's arrays is the room the flag bytes need)
 // The products of up to 1024 entries k of A(i,:) (one per thread: `len` entries of B starting at `st`), dealt evenly to the 16
 // waves of the workgroup whatever the lengths are — most are empty or a single entry, a hub's is tens of thousands: an exclusive
 // scan of the lengths in LDS, the product range is cut into batches of up to SPA_R rounds of 64, and a lane finds the entry its
@@ -212,6 +219,14 @@ constexpr uint32_t SPA_SYM_WORDS = 32768;      // 2^20 bits
 //      graph are its hubs (long parts, no search, consecutive loads), the last ones its tail (a part per product) — thread 0's wave
 //      spent 6 400 clocks per (row, block) step in its rounds and 4 500 waiting for the others (SPA_PROFILE build);
 //  (d) the scans are DPP scans (six VALU steps instead of six trips through the LDS crossbar).
+// Measured and dropped in round 4 (A@A R-MAT-18, numeric + symbolic pass in ms; this walk: 55.5 + 13.8):
+//  * parts of up to eight entries handled by their own lane (no scan, no search), only the longer ones listed in LDS and dealt by ballots and
+//    readlanes: 58-63 + 17-18 — the search's LDS chain became VALU work of the same length (SQ counters of that version: VALU 36 %, SALU 29 %,
+//    LDS 37 % busy, a wave waiting 53 % of its cycles: no unit is the limit, the step's dependent chain is — four barriers, one memory latency,
+//    the emission loop — and a (row, block) step has only ~5 150 products and ~1 600 results to hide it behind);
+//  * reading the batch's bitmap words together before its atomics: 57 -> 61 (later rounds no longer see the bits the earlier ones set);
+//  * 512 threads per workgroup (half the fixed per-wave work of a step): 63 -> 75 + 30; two workgroups of 8192 columns per CU: 57 -> 78;
+//  * barriers that wait for the LDS only (s_waitcnt lgkmcnt(0); s_barrier — not for the stores on their way to the HBM): no change.
 #ifndef SPA_R_V
 #define SPA_R_V 8
 #endif
@@ -255,7 +270,7 @@ template <class L, class A> __device__ __forceinline__ uint32_t spa_flat_walk(ui
   uint32_t woff, total, cpre;                                // cpre: first product of the 64-entry chunk (lane & 15)
   spa_wave_offsets(s_wtot, lane, wave, woff, total, cpre);
   const uint32_t exc = woff + inc - len;
-  s_exc[t] = exc; s_shift[t] = st - exc;
+  s_exc[t] = exc; if (len) s_shift[t] = st - exc;          // (an empty part is never the answer of a search)
   if (t == 0) s_exc[1024] = total;
   __syncthreads();
   SPA_PF(0)
@@ -342,11 +357,12 @@ template <class T, class SR>
 __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, const T* __restrict__ aval, const T* __restrict__ bval, uint32_t* __restrict__ ocol, T* __restrict__ oval,
                                                              uint32_t ncols, const uint32_t* __restrict__ split, const SR sr) {
   typedef typename acc_word<T>::type W;
-  constexpr uint32_t WD = spa_cfg<T>::WD, WORDS = WD / 32;
+  constexpr uint32_t WD = spa_cfg<T>::WD;
   __shared__ W s_acc[WD];
-  __shared__ T s_av[1024];
-  __shared__ uint32_t s_bits[WORDS];
-  __shared__ uint32_t s_exc[1025], s_shift[1024], s_wtot[16];
+  __shared__ uint32_t s_flag[WD / 4];                  // one byte per column of the block: 1 = the accumulator holds a product.  (Round 4; a bitmap before: a read, a test and an
+                                                       //  atomic OR per product — an LDS latency in every combine, eight of them one after the other per batch.  A byte is a plain store.)
+  __shared__ T s_av[SPA_CHUNK];
+  __shared__ uint32_t s_exc[1025], s_shift[SPA_CHUNK], s_wtot[16];
   __shared__ uint32_t s_wsum[16];
   const uint32_t t = threadIdx.x, lane = t & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
   const bool use_a = sr.uses_a(), use_b = sr.uses_u();
@@ -357,52 +373,32 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
   unsigned long long* const pf = nullptr;
 #endif
   for (uint32_t e = t; e < WD; e += 1024) s_acc[e] = idw;
-  for (uint32_t w = t; w < WORDS; w += 1024) s_bits[w] = 0;
+  for (uint32_t w = t; w < WD / 4; w += 1024) s_flag[w] = 0;
   __syncthreads();
   const uint32_t nblk = (uint32_t)(((uint64_t)ncols + WD - 1) / WD);
   for (uint32_t ridx = blockIdx.x; ridx < a.nrows_bin; ridx += gridDim.x) {
     const uint32_t i = a.rows[ridx];
     const uint32_t ab = a.arp[i], ae = a.arp[i + 1];
     uint32_t obase = a.crp[i];
-    // a row of at most 1024 entries — nearly all of them — is one chunk: its B rows and A values stay in place over the blocks, and
-    // the next block's boundary is loaded while this block is worked on (consecutive blocks share a boundary)
-    const bool single = ae - ab <= 1024;
-    const uint32_t* sp0 = nullptr; uint32_t cur_st = 0, cur_en = 0;
-    if (single) {
-      if (ab + t < ae) { sp0 = split + (size_t)a.acol[ab + t] * (nblk + 1); cur_st = sp0[0]; cur_en = sp0[1]; if (use_a) s_av[t] = aval[ab + t]; }
-    }
-    for (uint32_t c = 0; c < nblk; c++) {
-      const uint32_t lo = c * WD;
-      uint32_t products = 0;
-      for (uint32_t base = ab; base < ae; base += 1024) {
-        const uint32_t pa = base + t;
-        uint32_t st = 0, len = 0;
-        if (single) {
-          st = cur_st; len = cur_en - cur_st;
-          if (sp0 && c + 1 < nblk) { cur_st = cur_en; cur_en = sp0[c + 2]; }
-        } else if (pa < ae) {
-          const uint32_t* sp = split + (size_t)a.acol[pa] * (nblk + 1) + c;
-          st = sp[0]; len = sp[1] - st; if (use_a) s_av[t] = aval[pa];      // (read by other threads only behind the walk's first barrier)
-        }
-        struct Prod { uint32_t rel; T x; };
-        products |= spa_flat_walk(st, len, s_exc, s_shift, s_wtot,
-          [&](uint32_t v, uint32_t pb) { Prod p; p.rel = a.bcol[pb] - lo; p.x = sr.mult(use_a ? s_av[v] : T(), use_b ? bval[pb] : T()); return p; },
-          [&](const Prod& p) {
-            const uint32_t bit = 1u << (p.rel & 31);
-            if (!(s_bits[p.rel >> 5] & bit)) atomicOr(&s_bits[p.rel >> 5], bit);      // (32 consecutive columns of a hub's part share a word: the read is a broadcast, the atomic would serialise)
-            word_combine<T>(sr.add_op(), &s_acc[p.rel], p.x);
-          }, pf);
+    // one chunk of the row's entries (their A values in s_av) against block c (columns lo ...): returns the number of products
+    struct Prod { uint32_t rel; T x; };
+    auto walk = [&](uint32_t lo, uint32_t st, uint32_t len) __attribute__((always_inline)) -> uint32_t {
+      return spa_flat_walk(st, len, s_exc, s_shift, s_wtot,
+        [&](uint32_t v, uint32_t pb) { Prod p; p.rel = a.bcol[pb] - lo; p.x = sr.mult(use_a ? s_av[v] : T(), use_b ? bval[pb] : T()); return p; },
+        [&](const Prod& p) { ((unsigned char*)s_flag)[p.rel] = 1; word_combine<T>(sr.add_op(), &s_acc[p.rel], p.x); }, pf);
+    };
+    // emit the block in column order: every thread owns WD / 1024 columns; exclusive prefix of their counts, then every thread writes its own run —
+    // four accumulators in flight.  (Round 4: 32 columns on half the threads, thread 0 adding up the wave sums between two barriers and a
+    // barrier behind the emission took 6 500 of a step's 19 700 clocks; the next walk's two barriers already stand between this emission's
+    // resets and the next block's atomics.)
+    auto emit = [&](uint32_t lo) __attribute__((always_inline)) {
+      constexpr uint32_t BPT = WD / 1024u; static_assert(BPT % 4u == 0 && BPT <= 32u && BPT * 1024u == WD, "a thread emits up to 32 columns, whole flag words");
+      uint32_t mybits = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < BPT / 4u; w++) {                                  // four flag bytes (0 / 1) -> four bits: the partial products of the multiply land on distinct bits, the wanted ones on 24..27
+        const uint32_t f = s_flag[t * (BPT / 4u) + w];
+        mybits |= ((f * 0x01020408u) >> 24) << (4u * w);
       }
-#ifdef SPA_PROFILE
-      pf[products ? 6 : 8]++;
-#endif
-      if (!products) continue;                              // nothing of this row falls into this block (the whole workgroup agrees): no emission, no barriers
-      // emit the block in column order: every thread owns 16 columns; exclusive prefix of their counts, then every thread writes its own run —
-      // four accumulators in flight.  (Round 4: 32 columns on half the threads, thread 0 adding up the wave sums between two barriers and a
-      // barrier behind the emission took 6 500 of a step's 19 700 clocks; the next walk's two barriers already stand between this emission's
-      // resets and the next block's atomics.)
-      constexpr uint32_t BPT = WD / 1024u, TPW = 32u / BPT; static_assert(BPT == 8u || BPT == 16u || BPT == 32u, "a thread emits a whole bitmap word, a half or a quarter");
-      uint32_t mybits = BPT == 32u ? s_bits[t] : (s_bits[t / TPW] >> (BPT * (t % TPW))) & ((1u << (BPT & 31u)) - 1u);
       const uint32_t mycnt = (uint32_t)__popc(mybits);
       const uint32_t inc = spa_wave_incl_add(mycnt);
       if (lane == 63) s_wsum[wave] = inc;
@@ -410,7 +406,11 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
       uint32_t woff, etotal, unused;
       spa_wave_offsets(s_wsum, lane, wave, woff, etotal, unused);
       SPA_PF(3)
-      if (t % TPW == 0) s_bits[t / TPW] = 0;                                     // (all owners of a word read it before the barrier)
+      if (mybits) {
+        uint32_t zero; asm volatile("v_mov_b32 %0, 0" : "=v"(zero));            // (made here: hoisted out of the loops the compiler spilled the zeros to scratch and reloaded them for every block)
+#pragma unroll
+        for (uint32_t w = 0; w < BPT / 4u; w++) s_flag[t * (BPT / 4u) + w] = zero;
+      }
       uint32_t o = obase + woff + inc - mycnt;
       const uint32_t rel0 = t * BPT;
       while (mybits) {
@@ -425,6 +425,43 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
       }
       obase += etotal;
       SPA_PF(4)
+    };
+    if (ae - ab <= SPA_CHUNK) {
+      // a row of at most SPA_CHUNK entries — nearly all of them — is one chunk: its B rows and A values stay in place over the blocks, and the
+      // boundary of the block after the next is loaded while this block is worked on (consecutive blocks share a boundary).  `nxt` is only
+      // looked at a whole step later; loaded into the variable the step itself reads — or under a branch, or in a loop shared with the
+      // long rows' path — the compiler copied it into place, and waited for it, on the spot: a memory latency per step.
+      const bool has = t < SPA_CHUNK && ab + t < ae;
+      const uint32_t* const sp0 = has ? split + (size_t)a.acol[ab + t] * (nblk + 1) : split;
+      uint32_t cur_st = sp0[0], cur_en = sp0[1], nxt = sp0[nblk > 1 ? 2 : 1];
+      if (has && use_a) s_av[t] = aval[ab + t];                                  // (read by other threads only behind the walk's first barrier)
+      for (uint32_t c = 0; c < nblk; c++) {
+        const uint32_t st = cur_st, len = has ? cur_en - cur_st : 0u;
+        cur_st = cur_en; cur_en = nxt;
+        nxt = sp0[c + 3 <= nblk ? c + 3 : nblk];
+        const uint32_t products = walk(c * WD, st, len);
+#ifdef SPA_PROFILE
+        pf[products ? 6 : 8]++;
+#endif
+        if (products) emit(c * WD);                         // (else nothing of this row falls into this block — the whole workgroup agrees: no emission, no barrier)
+      }
+    } else {
+      for (uint32_t c = 0; c < nblk; c++) {
+        uint32_t products = 0;
+        for (uint32_t base = ab; base < ae; base += SPA_CHUNK) {
+          const uint32_t pa = base + t;
+          uint32_t st = 0, len = 0;
+          if (t < SPA_CHUNK && pa < ae) {
+            const uint32_t* sp = split + (size_t)a.acol[pa] * (nblk + 1) + c;
+            st = sp[0]; len = sp[1] - st; if (use_a) s_av[t] = aval[pa];        // (read by other threads only behind the walk's first barrier)
+          }
+          products |= walk(c * WD, st, len);
+        }
+#ifdef SPA_PROFILE
+        pf[products ? 6 : 8]++;
+#endif
+        if (products) emit(c * WD);
+      }
     }
   }
 #ifdef SPA_PROFILE

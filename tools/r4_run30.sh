@@ -1,8 +1,8 @@
 #!/bin/bash
-out=gpurun_out/r4af; mkdir -p $out
+out=gpurun_out/r4am; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 timeout 600 python -m pytest tests/test_mxm_gpu.py -x -q -k "hash_spgemm" 2>&1 | tail -4
-for L in mi355x w8; do
+for L in mi355x; do
 GRB_MI355X_LIB=$GRAFT_REPO_ROOT/pygraphblas_amd/libgrb_$L.so timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/aa_$L -o aa -- python tools/workloads.py --what aa --aa-methods hash > $out/aa_$L.log 2>&1
 grep -h '^{' $out/aa_$L.log | cut -c1-330
 done
