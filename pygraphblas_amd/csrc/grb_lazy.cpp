@@ -30,6 +30,8 @@ bool nonblocking() {
   return g_nonblocking && !g_env_blocking;
 }
 
+static bool g_env_store_reduced() { static const int e = getenv("GRB_MI355X_LAZY_STORE_REDUCED") ? atoi(getenv("GRB_MI355X_LAZY_STORE_REDUCED")) : 0; return e != 0; }      // 1: a reduced chain is stored at once (round 3's behaviour)
+
 void vec_chain_launch(const ChainLaunch& L, void* red_result) {
   if (!L.n || !L.nsteps) return;
   dispatch_type(L.tcode, [&]<class T>() { vec_chain_launch_t<T>(L, red_result); });
@@ -54,8 +56,11 @@ bool is_full(GrB_Vector v) { return v->dnvals_known && v->dnvals == v->n; }
 
 void release_reads() { for (auto& nd : g_q) for (int k = 0; k < 2; k++) if (nd.in[k]) nd.in[k]->q_reads = 0; }
 
-// run the queue as one kernel; `red`: also reduce the last step's result
-void run_queue(const ChainReduce* red, void* red_result) {
+// run the queue as one kernel; `red`: also reduce the last step's result.  `keep` (with `red`): only the reduction is wanted now — nothing is
+// stored and the queue stays as it is.  `t -= r; t = abs(t); t.reduce_float()` (gap/prmark.py:24-26) then never writes t at all: the next
+// iteration assigns the vector as a whole (`r[:] = teleport` after the swap) and vec_overwritten() drops the two steps — a third of that pass's
+// traffic.  Whoever looks at t first runs the queue in full.
+void run_queue(const ChainReduce* red, void* red_result, bool keep = false) {
   if (g_q.empty()) return;
   g_flushing = true;
   struct Restore { ~Restore() { g_flushing = false; } } restore;
@@ -79,7 +84,7 @@ void run_queue(const ChainReduce* red, void* red_result) {
     if (nd.kind == 0) { full_prev = nd.is_union ? (f[0] || f[1]) : (f[0] && f[1]); math = math || binop_needs_math(nd.op); }
     else { full_prev = f[0]; math = math || (nd.mode == 0 ? unop_needs_math_host(nd.op) : binop_needs_math(nd.op)); }
     st.out = -1;
-    if (nd.out && last_writer[i]) { st.out = (int)outs.size(); outs.push_back(nd.out); out_full.push_back(full_prev); }
+    if (nd.out && last_writer[i] && !keep) { st.out = (int)outs.size(); outs.push_back(nd.out); out_full.push_back(full_prev); }
   }
   L.math = math;
   L.next = (int)ext.size();
@@ -106,6 +111,7 @@ void run_queue(const ChainReduce* red, void* red_result) {
   if (red) L.red = *red;
   vec_chain_launch(L, red_result);
   g_stat_chains++; g_stat_nodes += g_q.size(); if (red) g_stat_reduces_fused++;
+  if (keep) return;
   release_reads();
   for (size_t o = 0; o < outs.size(); o++) {
     GrB_Vector w = outs[o];
@@ -136,16 +142,32 @@ void vec_resolve(GrB_Vector v) {
   if (v->lazy == 1) materialise_fill(v);
 }
 
+// drop the steps nothing needs any more: a step is needed when its result is stored, or when the step after it is needed and reads it
+static void prune_queue() {
+  if (g_q.empty()) return;
+  std::vector<char> need(g_q.size(), 0);
+  for (size_t i = g_q.size(); i-- > 0;) {
+    const bool next_reads = i + 1 < g_q.size() && need[i + 1] && (g_q[i + 1].prev[0] || g_q[i + 1].prev[1]);
+    need[i] = g_q[i].out != nullptr || next_reads;
+  }
+  size_t w = 0;
+  for (size_t i = 0; i < g_q.size(); i++) {
+    if (need[i]) { if (w != i) g_q[w] = g_q[i]; w++; }
+    else for (int k = 0; k < 2; k++) if (g_q[i].in[k] && g_q[i].in[k]->q_reads) g_q[i].in[k]->q_reads--;
+  }
+  g_q.resize(w);
+  if (g_q.empty()) { g_q_type = -1; g_q_n = 0; }
+}
+
 void vec_overwritten(GrB_Vector v) {
   if (!(v->lazy | v->q_reads)) return;
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   if (g_flushing) return;
-  if (v->q_reads) run_queue(nullptr, nullptr);          // queued work reads the value that is about to go: it runs first
-  if (v->lazy == 2) {                                   // queued work only produced it: the stores are dropped (later steps may still use the value in registers)
-    for (auto& nd : g_q) if (nd.out == v) nd.out = nullptr;
-    bool any = false; for (auto& nd : g_q) if (nd.out) any = true;
-    if (!any) { release_reads(); g_q.clear(); g_q_type = -1; g_q_n = 0; }
+  if (v->lazy == 2) {                                   // queued work produced it: the stores are dropped (later steps may still use the value in registers),
+    for (auto& nd : g_q) if (nd.out == v) nd.out = nullptr;      // and with them the steps nothing else needs — which may have been the only readers of v's stored value
+    prune_queue();
   }
+  if (v->q_reads) run_queue(nullptr, nullptr);          // queued work still reads the value that is about to go: it runs first
   v->lazy = 0;
 }
 
@@ -236,7 +258,7 @@ bool lazy_apply(GrB_Vector w, int mode, int opcode, int xcode, int zcode, const 
 }
 
 // `reduce(u)` when u is the result of the queue's last step: the chain kernel reduces it on the way
-bool lazy_reduce(GrB_Vector u, int mop, int mcode, const void* identity, void* result_in_mcode) {
+bool lazy_reduce(GrB_Vector u, int mop, int mcode, const void* identity, void* result_in_mcode, bool may_keep) {
   if (u->lazy != 2) return false;
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   if (g_flushing || g_q.empty() || g_q.back().out != u) return false;
@@ -246,7 +268,7 @@ bool lazy_reduce(GrB_Vector u, int mop, int mcode, const void* identity, void* r
   if (!(mop == B_PLUS || mop == B_MIN || mop == B_MAX || mop == B_TIMES || mop == B_LOR || mop == B_LAND || mop == B_LXOR || mop == B_ANY)) return false;
   if (tc == T_BOOL && !(mop == B_LOR || mop == B_LAND || mop == B_LXOR)) return false;
   ChainReduce r{}; r.on = 1; r.op = mop; r.widen = widen ? 1 : 0; memcpy(r.identity, identity, 16);
-  run_queue(&r, result_in_mcode);
+  run_queue(&r, result_in_mcode, may_keep && !g_env_store_reduced());
   return true;
 }
 

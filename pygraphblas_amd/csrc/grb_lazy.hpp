@@ -35,6 +35,6 @@ bool lazy_fill(GrB_Vector w, const void* s_in_w_type);
 void lazy_fill_consumed(GrB_Vector w);
 bool lazy_ewise(GrB_Vector w, GrB_BinaryOp op, GrB_Vector u, GrB_Vector v, bool is_union);
 bool lazy_apply(GrB_Vector w, int mode, int opcode, int xcode, int zcode, const void* scalar_in_x_type, GrB_Vector u);
-bool lazy_reduce(GrB_Vector u, int mop, int mcode, const void* identity, void* result_in_mcode);
+bool lazy_reduce(GrB_Vector u, int mop, int mcode, const void* identity, void* result_in_mcode, bool may_keep);      // may_keep: u may stay unmaterialised (the caller does not look at its buffers)
 
 }  // namespace grb

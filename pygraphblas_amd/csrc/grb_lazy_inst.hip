@@ -6,6 +6,7 @@
 // written once — zeros where a result has no entry, so that a later product may gather from the values without a fill pass.
 // `t -= r; t = abs(t); t.reduce_float()` (gap/prmark.py:24-26) moves 3 x 4 B per vertex instead of 8 x 4 + 6 x 1 in four kernels.
 // The operator codes are wave-uniform kernel arguments: one scalar branch per step, as in the runtime-opcode semirings.
+#include <type_traits>
 #include "grb_api.hpp"
 #include "grb_device.hpp"
 #include "grb_lazy.hpp"
@@ -70,25 +71,44 @@ template <class R, int N> __device__ __forceinline__ R chain_reduce_vec(int op, 
 template <class T, int VEC> struct alignas(sizeof(T) * VEC >= 16 ? 16 : sizeof(T) * VEC) ChainPack { T v[VEC]; };
 template <int VEC> struct alignas(VEC) ChainBytes { uint8_t v[VEC]; };
 
-template <class T, int RED, class R, int NIN, int VEC>
+// SPEC (round 4): the queue is an interpreter — per pack of VEC positions it walks the step descriptors through scalar compares and branches, ~100
+// instructions per position, and the two passes of a PageRank iteration at 2^25 vertices ran at 2.5 and 4.9 TB/s bound by instruction issue, not by
+// the HBM.  The two shapes of gap/prmark.py:21-26 are compiled as they stand (the same loads, stores, reduction tree and grid as the interpreter's):
+//   1  reduce(+, abs(x - y)), x and y stored and full (`t -= r; t = abs(t); t.reduce_float()`), stored or not
+//   2  z = x / y on the intersection of two stored operands (`w = t / d`)
+template <class T, int RED, class R, int NIN, int VEC, int SPEC = 0>
 __global__ __launch_bounds__(256) void k_vec_chain(const ChainK<T> a, const R rid, R* __restrict__ partial) {
   R racc = rid;
   const uint64_t stride = gridDim.x * 256ull * VEC;
+  // the loads of a lane's NEXT pack are issued before this one is worked on (round 4: with one pack in flight per lane the pass that only reduces —
+  // `t -= r; abs; reduce`, 268 MB — ran at 2.5 TB/s); a lane whose next pack is the vector's tail, or nothing, loads the current one again
+  ChainPack<T, VEC> ve[NIN], vn[NIN]; ChainBytes<VEC> vp[NIN], vpn[NIN];
+  auto load_pack = [&](uint64_t b, ChainPack<T, VEC>* pe, ChainBytes<VEC>* pp) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NIN; k++) pe[k] = *(const ChainPack<T, VEC>*)(a.ev[k] + b);
+    if constexpr (SPEC != 1) {                                           // (shape 1: both operands full, nobody looks at presence bytes)
+#pragma unroll
+      for (int k = 0; k < NIN; k++) pp[k] = *(const ChainBytes<VEC>*)(a.ep[k] + b);
+    }
+  };
+  {
+    const uint64_t b0 = (blockIdx.x * 256ull + threadIdx.x) * VEC;
+    if (b0 + VEC <= a.n) load_pack(b0, ve, vp);
+  }
   for (uint64_t base = (blockIdx.x * 256ull + threadIdx.x) * VEC; base < a.n; base += stride) {
     const int nv = a.n - base >= (uint64_t)VEC ? VEC : (int)(a.n - base);       // < VEC only for the lane that holds the vector's tail
     T e[VEC][NIN]; bool p[VEC][NIN];
     if (nv == VEC) {
-      ChainPack<T, VEC> ve[NIN]; ChainBytes<VEC> vp[NIN];
-#pragma unroll
-      for (int k = 0; k < NIN; k++) ve[k] = *(const ChainPack<T, VEC>*)(a.ev[k] + base);
-#pragma unroll
-      for (int k = 0; k < NIN; k++) vp[k] = *(const ChainBytes<VEC>*)(a.ep[k] + base);
+      const uint64_t nb = base + stride;
+      load_pack(nb + VEC <= a.n ? nb : base, vn, vpn);
 #pragma unroll
       for (int k = 0; k < NIN; k++) {
         const bool used = (a.used_mask >> k) & 1u, full = (a.full_mask >> k) & 1u;
 #pragma unroll
-        for (int h = 0; h < VEC; h++) { e[h][k] = ve[k].v[h]; p[h][k] = used && (full || vp[k].v[h] != 0); }
+        for (int h = 0; h < VEC; h++) { e[h][k] = ve[k].v[h]; if constexpr (SPEC == 1) p[h][k] = true; else p[h][k] = used && (full || vp[k].v[h] != 0); }
       }
+#pragma unroll
+      for (int k = 0; k < NIN; k++) { ve[k] = vn[k]; vp[k] = vpn[k]; }
     } else {
 #pragma unroll
       for (int k = 0; k < NIN; k++) {
@@ -105,6 +125,13 @@ __global__ __launch_bounds__(256) void k_vec_chain(const ChainK<T> a, const R ri
     T acc[VEC]; bool ap[VEC];
 #pragma unroll
     for (int h = 0; h < VEC; h++) { acc[h] = T(); ap[h] = false; }
+    if constexpr (SPEC == 1) {
+#pragma unroll
+      for (int h = 0; h < VEC; h++) { acc[h] = apply_unop<T, false>(U_ABS, apply_binop<T, false, false>(B_MINUS, e[h][0], e[h][1])); ap[h] = true; ov[0][h] = acc[h]; opv[0][h] = true; }
+    } else if constexpr (SPEC == 2) {
+#pragma unroll
+      for (int h = 0; h < VEC; h++) { const bool both = p[h][0] && p[h][1]; acc[h] = both ? apply_binop<T, false, false>(B_DIV, e[h][0], e[h][1]) : T(); ap[h] = both; ov[0][h] = acc[h]; opv[0][h] = both; }
+    } else {
 #pragma unroll 1
     for (int s = 0; s < a.nsteps; s++) {                                 // (not unrolled: the step descriptors are scalar loads, the operator switches exist VEC times)
       // one operator evaluation per step: eWise f(x, y) on stored operands / the previous result; apply with a bound scalar is the
@@ -142,6 +169,7 @@ __global__ __launch_bounds__(256) void k_vec_chain(const ChainK<T> a, const R ri
 #pragma unroll
         for (int h = 0; h < VEC; h++) { ov[oo][h] = acc[h]; opv[oo][h] = ap[h]; }
       }
+    }
     }
 #pragma unroll
     for (int oo = 0; oo < CHAIN_MAX_OUT; oo++) {
@@ -231,8 +259,28 @@ template <class T, int RED, class R, int NIN> static void launch_chain(const Cha
     memcpy(&rid, L.red.identity, sizeof(R));
     result = (R*)work.p; partial = (R*)((char*)work.p + 16);
   }
-  if (aligned) hipLaunchKernelGGL((k_vec_chain<T, RED, R, NIN, 4>), dim3((unsigned)g), dim3(256), 0, stream(), a, rid, partial);
-  else hipLaunchKernelGGL((k_vec_chain<T, RED, R, NIN, 1>), dim3((unsigned)g), dim3(256), 0, stream(), a, rid, partial);
+  // the compiled shapes (see SPEC at the kernel): same grid as the interpreter's
+  int spec = 0;
+  if constexpr (std::is_floating_point<T>::value && NIN == 2) {
+    static const bool no_spec = getenv("GRB_MI355X_CHAIN_NO_SPEC") && atoi(getenv("GRB_MI355X_CHAIN_NO_SPEC")) != 0;
+    const ChainStepDesc& s0 = L.st[0]; const ChainStepDesc& s1 = L.st[1];
+    if (!no_spec && RED != 0 && L.nsteps == 2 && L.next == 2 && s0.kind == 0 && s0.op == B_MINUS && s0.is_union && s0.src[0] == 0 && s0.src[1] == 1 && s1.kind == 1 && s1.mode == 0 &&
+        s1.op == U_ABS && s1.src[0] == CHAIN_PREV && L.red.op == B_PLUS && a.full_mask == 3u && s0.out == -1 && (L.nout == 0 || (L.nout == 1 && s1.out == 0 && L.op[0] == nullptr))) spec = 1;
+    if (!no_spec && RED == 0 && L.nsteps == 1 && L.next == 2 && s0.kind == 0 && s0.op == B_DIV && !s0.is_union && s0.src[0] == 0 && s0.src[1] == 1 && L.nout == 1 && s0.out == 0 && L.op[0] != nullptr) spec = 2;
+  }
+  bool launched = false;
+  if constexpr (std::is_floating_point<T>::value && NIN == 2 && RED != 0) {
+    if (spec == 1) { if (aligned) hipLaunchKernelGGL((k_vec_chain<T, RED, R, NIN, 4, 1>), dim3((unsigned)g), dim3(256), 0, stream(), a, rid, partial);
+                     else hipLaunchKernelGGL((k_vec_chain<T, RED, R, NIN, 1, 1>), dim3((unsigned)g), dim3(256), 0, stream(), a, rid, partial); launched = true; }
+  }
+  if constexpr (std::is_floating_point<T>::value && NIN == 2 && RED == 0) {
+    if (spec == 2) { if (aligned) hipLaunchKernelGGL((k_vec_chain<T, RED, R, NIN, 4, 2>), dim3((unsigned)g), dim3(256), 0, stream(), a, rid, partial);
+                     else hipLaunchKernelGGL((k_vec_chain<T, RED, R, NIN, 1, 2>), dim3((unsigned)g), dim3(256), 0, stream(), a, rid, partial); launched = true; }
+  }
+  if (!launched) {
+    if (aligned) hipLaunchKernelGGL((k_vec_chain<T, RED, R, NIN, 4>), dim3((unsigned)g), dim3(256), 0, stream(), a, rid, partial);
+    else hipLaunchKernelGGL((k_vec_chain<T, RED, R, NIN, 1>), dim3((unsigned)g), dim3(256), 0, stream(), a, rid, partial);
+  }
   if constexpr (RED != 0) {
     // the per-workgroup partials (<= 16 384 x 8 B) travel to page-locked memory and the host folds them in index order — a fixed
     // tree like the one-workgroup k_chain_final it replaces in the common case (one kernel and one launch gap less per PageRank iteration)

@@ -368,8 +368,16 @@ static __global__ __launch_bounds__(256) void k_xc_verify(const uint32_t* __rest
 }
 // xhot[k*H + h] = u[hot column h of panel k]: the eight LDS tables' contents, gathered once per call (every workgroup of a
 // panel then loads its table with coalesced reads; gathering in each of the 32 workgroups cost 7-16 us of L2 traffic)
-template <class T> __global__ void k_xp_hot_gather(const T* __restrict__ u, const uint32_t* __restrict__ hot_cols, uint32_t total, T* __restrict__ xhot) {
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) xhot[i] = u[hot_cols[i]];
+// (four slots per lane, the four gathers in flight together: one slot per lane — a chain of two dependent loads and nothing else — took 28.7 us for
+//  the 2.5e6 slots of a 64-table plan)
+template <class T> __global__ __launch_bounds__(256) void k_xp_hot_gather(const T* __restrict__ u, const uint32_t* __restrict__ hot_cols, uint32_t total, T* __restrict__ xhot) {
+  for (uint32_t i = (blockIdx.x * 256 + threadIdx.x) * 4u; i < total; i += gridDim.x * 1024u) {
+    if (i + 4u <= total) {
+      const uint4 c = *(const uint4*)(hot_cols + i);
+      const T x0 = u[c.x], x1 = u[c.y], x2 = u[c.z], x3 = u[c.w];
+      xhot[i] = x0; xhot[i + 1] = x1; xhot[i + 2] = x2; xhot[i + 3] = x3;
+    } else for (uint32_t j = i; j < total; j++) xhot[j] = u[hot_cols[j]];
+  }
 }
 // y(i) = sum of the partials of row i's sub-rows, in panel order.  A workgroup owns XP_RB consecutive rows: their
 // sub-rows are one contiguous run in each panel (sub-rows are in row order inside a panel), so the eight runs are read
@@ -1007,7 +1015,7 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
   const bool uses_u = d.flip ? binop_uses_x(d.mulop) : binop_uses_y(d.mulop);
   constexpr uint32_t H = xt_hot<T>::H;
   XtCall<T> call{(const T*)c.uval, M.ncols, (uint32_t)(P->NS / XP), P->partial.as<T>()};
-  if (uses_u) hipLaunchKernelGGL((k_xp_hot_gather<T>), dim3(((uint32_t)P->NS * H + 255) / 256), dim3(256), 0, stream(), (const T*)c.uval, P->hot_cols.as<uint32_t>(), (uint32_t)P->NS * H, P->xhot.as<T>());
+  if (uses_u) hipLaunchKernelGGL((k_xp_hot_gather<T>), dim3(((uint32_t)P->NS * H + 1023) / 1024), dim3(256), 0, stream(), (const T*)c.uval, P->hot_cols.as<uint32_t>(), (uint32_t)P->NS * H, P->xhot.as<T>());
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;
     bool launched = false;

@@ -65,8 +65,8 @@ static GrB_Info vec_reduce(void* c, int ccode, GrB_BinaryOp accum, GrB_Monoid mo
       // u is the result of queued element-wise operations: their one kernel reduces it on the way (`t -= r; abs(t); reduce_float()`)
       const int mc = monoid->op->ztype->code; uint8_t r[16] = {0}, id[16]; memcpy(id, monoid->identity, 16);
       const bool nan_id = fp_minmax_identity(mc, monoid->op->opcode, id);
-      if (lazy_reduce(u, monoid->op->opcode, mc, id, r)) {
-        if (nan_id) nan_or_empty(r, mc, monoid, u->dpres.as<uint8_t>(), u->n);      // (u is materialised now)
+      if (lazy_reduce(u, monoid->op->opcode, mc, id, r, !nan_id)) {
+        if (nan_id) nan_or_empty(r, mc, monoid, u->dpres.as<uint8_t>(), u->n);      // (u is materialised now: may_keep was false)
         scalar_accum(c, ccode, r, mc, accum); return;
       }
     }

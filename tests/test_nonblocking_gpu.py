@@ -234,3 +234,62 @@ def test_traps(gb, gpu):
     k32 = j32 * i32
     assert k32.reduce_int() == int((2 * np.arange(n, dtype=np.int64) ** 2).sum())
     assert e.reduce_float() == float(2 * (7.0 * (n - 1) - 1.0))
+
+
+def test_a_reduced_chain_is_not_stored_until_somebody_looks(gb, gpu):
+    """`t -= r; t = abs(t); t.reduce_float()` (gap/prmark.py:24-26): the reduction runs the queue without storing t and keeps it queued
+    (grb_lazy.cpp run_queue `keep`); a later whole-vector assignment of t drops the steps unrun, any look at t runs them — and an
+    operand overwritten in between is still read first."""
+    n = 70000
+    F = gb.FP32
+    idx = np.arange(n, dtype=np.uint64)
+    tv = (np.arange(n) % 17).astype(np.float32); rv = (np.arange(n) % 5).astype(np.float32)
+    want = np.abs(tv - rv)
+
+    def fresh():
+        return gb.Vector.from_arrays(idx, tv, n, F), gb.Vector.from_arrays(idx[::3], rv[::3], n, F)
+    want_u = np.where(np.arange(n) % 3 == 0, want, tv)                # eWiseAdd: where r has no entry t keeps its value (abs of a non-negative)
+    # 1. reduce, reduce again, then look
+    t, r = fresh()
+    t -= r; t.apply(F.ABS, out=t)
+    s0 = stats(gb)
+    assert t.reduce_float() == float(want_u.astype(np.float64).sum())
+    s1 = stats(gb)
+    assert s1["chains"] == s0["chains"] + 1 and s1["reduces_fused"] == s0["reduces_fused"] + 1
+    assert t.reduce_float() == float(want_u.astype(np.float64).sum())
+    x, p = t.to_dense_arrays()
+    assert p.all() and np.array_equal(x, want_u)
+    # 2. reduce, then the vector is assigned as a whole: the two steps never run again, and never stored
+    t, r = fresh()
+    t -= r; t.apply(F.ABS, out=t)
+    assert t.reduce_float() == float(want_u.astype(np.float64).sum())
+    s2 = stats(gb)
+    t[:] = 4.0
+    w = r * r                                                        # (a new step behind the dropped ones: only it runs)
+    x, p = w.to_dense_arrays()
+    s3 = stats(gb)
+    assert s3["chains"] == s2["chains"] + 1 and s3["nodes"] == s2["nodes"] + 1
+    assert np.array_equal(np.flatnonzero(p), np.arange(0, n, 3)) and np.array_equal(x[::3], rv[::3] ** 2)
+    assert t.reduce_float() == 4.0 * n and r.nvals == len(idx[::3])
+    # 3. reduce, then an operand of the kept steps is overwritten: they run (and store) first
+    t, r = fresh()
+    t -= r; t.apply(F.ABS, out=t)
+    assert t.reduce_float() == float(want_u.astype(np.float64).sum())
+    r[:] = 100.0
+    x, p = t.to_dense_arrays()
+    assert p.all() and np.array_equal(x, want_u)
+    assert r.reduce_float() == 100.0 * n
+    # 4. reduce, then a step that reads the kept result through the queue, then the kept vector dies
+    t, r = fresh()
+    t -= r; t.apply(F.ABS, out=t)
+    assert t.reduce_float() == float(want_u.astype(np.float64).sum())
+    u = t * t
+    del t
+    x, p = u.to_dense_arrays()
+    assert p.all() and np.array_equal(x, want_u * want_u)
+    # 5. a MIN reduction (its identity needs the presence bytes when nothing is present: stored at once, as before)
+    t, r = fresh()
+    t -= r; t.apply(F.ABS, out=t)
+    assert t.reduce_float(F.MIN_MONOID) == float(want_u.min())
+    x, p = t.to_dense_arrays()
+    assert np.array_equal(x, want_u)
