@@ -40,16 +40,21 @@ namespace grb {
 // The 16-bit plane is used for 8-byte types only: with 4-byte values the table would shrink from 39932 to 24576 slots, and the
 // pattern-only FP32 product (PageRank's PLUS_SECOND) measured 130 us with it against 105 us with 32-bit words.
 template <class T> struct xt_fmt { static constexpr bool C16 = XT_C16 != 0 && sizeof(T) >= 8; };
-// 32-bit entry words (round 4): bit 31 first entry of a sub-row, bit 30 (XT_COLD) the column is not in the table, bits 29..0 the slot in the LDS
-// table or the column itself.  `word << 2` (4-byte values) then IS the byte offset — into the table for a hot entry, into u for a cold one —
-// with both flags shifted out.  The table's LAST slot holds zero bits and is never given to a column (HOT = H - 1): a cold lane reads it, a hot
-// lane's gather is suppressed and returns zero bits, and the operand's value is the OR of the two — no test, no select at consume time.
-constexpr uint32_t XT_COLD = 0x40000000u, XT_IDXMASK = 0x3FFFFFFFu;
+// 32-bit entry words (round 4): bit 31 first entry of a sub-row, bit 29 (XT_COLD) the column is not in the table, bits 28..0 the slot in the LDS
+// table or the column itself.  `off = (word & 0x3FFFFFFF) * sizeof(T)` — `word << 2` for 4-byte values — is the byte offset with the row-start
+// flag gone and the cold flag on top of it (bit 31 for 4-byte values).  Two instructions turn it into both addresses, no compare, no select:
+//   gather from u   off ^ cold-bit   a cold entry's offset into u; a hot entry's lands beyond the descriptor's range (u has < 2^29 elements): the
+//                                    load returns zero bits and makes no memory request
+//   LDS table       min(off, last)   a hot entry's slot; a cold one reads the table's LAST slot, which holds zero bits and is never given to a
+//                                    column (HOT = H - 1)
+// and the operand's value is the OR of the two — no test at consume time either.
+constexpr int XT_COLD_BIT = 29;
+constexpr uint32_t XT_COLD = 1u << XT_COLD_BIT, XT_IDXMASK = XT_COLD - 1u;
 template <class T> struct xt_hot {
   static constexpr int HLDS = (WP_LDS_BYTES - 16 - WP_WAVES * 64 * (int)sizeof(T)) / (int)sizeof(T);
   static constexpr int H = xt_fmt<T>::C16 ? (HLDS < 24576 ? HLDS : 24576) : HLDS;
   static constexpr int HOT = xt_fmt<T>::C16 ? H : H - 1;          // columns a table serves
-  static constexpr uint64_t MAXCOLS = xt_fmt<T>::C16 ? ((uint64_t)(32768 - H) << 16) : (uint64_t)XT_IDXMASK;
+  static constexpr uint64_t C16COLS = (uint64_t)(32768 - H) << 16, MAXCOLS = xt_fmt<T>::C16 && C16COLS < (uint64_t)XT_IDXMASK ? C16COLS : (uint64_t)XT_IDXMASK;      // (the plan is built from 32-bit words in either format)
 };
 template <class E> __device__ __forceinline__ E xt_or_bits(E a, E b) {
   if constexpr (sizeof(E) == 8) { union { E e; unsigned long long u; } x, y; x.e = a; y.e = b; x.u |= y.u; return x.e; }
@@ -94,6 +99,14 @@ template <class E> __device__ __forceinline__ E xt_select_mask(E if_clear, E if_
     return r.e;
   }
 }
+template <class T, int CTRL, int ROW_MASK> __device__ __forceinline__ T xt_dpp_move0(T v) {      // lanes without a source (or outside ROW_MASK) get zero bits
+  if constexpr (sizeof(T) == 8) {
+    union { T t; int u[2]; } a, r; a.t = v;
+    r.u[0] = __builtin_amdgcn_update_dpp(0, a.u[0], CTRL, ROW_MASK, 0xf, true); r.u[1] = __builtin_amdgcn_update_dpp(0, a.u[1], CTRL, ROW_MASK, 0xf, true); return r.t;
+  } else {
+    union { T t; int u; } a, r; a.u = 0; a.t = v; r.u = __builtin_amdgcn_update_dpp(0, a.u, CTRL, ROW_MASK, 0xf, true); return r.t;
+  }
+}
 template <class T, class SR> __device__ __forceinline__ void xt_seg_scan_masked(T& v, unsigned long long F, const SR& sr) {
   static_assert(sizeof(T) == 4 || sizeof(T) == 8, "DPP scan handles 4- and 8-byte types");
   constexpr unsigned long long LT1 = 0x0001000100010001ull, LT2 = 0x0003000300030003ull, LT4 = 0x000F000F000F000Full, LT8 = 0x00FF00FF00FF00FFull;
@@ -104,7 +117,9 @@ template <class T, class SR> __device__ __forceinline__ void xt_seg_scan_masked(
   const unsigned long long G4 = G2 | ((G2 << 2) & ~LT2);
   const unsigned long long G8 = G4 | ((G4 << 4) & ~LT4);
   const unsigned long long G16 = G8 | ((G8 << 8) & ~LT8);                 // a flag between the start of the row and lane i
-#define XT_MS_STEP(CTRL, MASK, ACCEPT) { const T vu = dpp_move_t<T, CTRL, MASK>(v); const T sum = sr.add(vu, v); v = xt_select_mask<T>(v, sum, (ACCEPT)); }
+  // (the value from below arrives with zeros in the lanes that have no source — those lanes never accept — so that the compiler can fold the move into
+  //  the add where the type has a DPP add: 2 instructions per step and 32-bit half instead of 4)
+#define XT_MS_STEP(CTRL, MASK, ACCEPT) { const T vu = xt_dpp_move0<T, CTRL, MASK>(v); const T sum = sr.add(vu, v); v = xt_select_mask<T>(v, sum, (ACCEPT)); }
   XT_MS_STEP(0x111, 0xf, ~G1 & ~LT1) XT_MS_STEP(0x112, 0xf, ~G2 & ~LT2) XT_MS_STEP(0x114, 0xf, ~G4 & ~LT4) XT_MS_STEP(0x118, 0xf, ~G8 & ~LT8)
   XT_MS_STEP(0x142, 0xa, ~G16 & ROWS13)                                   // lane 15 / 47 into the next row
   // rows 2 and 3 take lane 31: nothing may start between lane 32 and lane i — for row 3 that includes all of row 2 (its lane 47 in G16)
@@ -316,11 +331,16 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
 #pragma unroll
       for (int u = 0; u < WP_PER; u++) {
         const uint32_t w = s.c[u];
-        const bool cold = (w & XT_COLD) != 0;
-        const uint32_t off = (w & XT_IDXMASK) * (uint32_t)sizeof(T);                              // (4-byte values: w << 2)
-        s.g[u] = (use_u && EXP != 1) ? xt_buf_load<T>(u_rsrc, cold ? off : 0xFFFFFFFFu) : T();      // only the columns the table does not hold are fetched (the others return zero bits)
-        if constexpr (ZSLOT) s.hl[u] = use_u ? *(const T*)((const char*)s_hot + (cold ? (uint32_t)(H - 1) * (uint32_t)sizeof(T) : off)) : T();
-        else s.hl[u] = T();
+        const uint32_t off = (w & (XT_COLD | XT_IDXMASK)) * (uint32_t)sizeof(T);                  // (4-byte values: w << 2)
+        if constexpr (ZSLOT) {
+          s.g[u] = (use_u && EXP != 1) ? xt_buf_load<T>(u_rsrc, off ^ (XT_COLD * (uint32_t)sizeof(T))) : T();      // only the columns the table does not hold are fetched (the others are out of range: zero bits)
+          const uint32_t last = (uint32_t)(H - 1) * (uint32_t)sizeof(T);
+          s.hl[u] = use_u ? *(const T*)((const char*)s_hot + (off < last ? off : last)) : T();
+        } else {
+          const bool cold = (w & XT_COLD) != 0;
+          s.g[u] = (use_u && EXP != 1) ? xt_buf_load<T>(u_rsrc, cold ? (w & XT_IDXMASK) * (uint32_t)sizeof(T) : 0xFFFFFFFFu) : T();
+          s.hl[u] = T();
+        }
       }
     }
   };
@@ -421,11 +441,17 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
     // ---- an entry ends its sub-row when the next entry starts one
     const int nxt0 = (int)__builtin_amdgcn_update_dpp(0, (int)rs[0], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);   // first flag of the next lane (lane 63: 0, never used — pos + 1 == cnt there)
     bool end[WP_PER];
+    if (cnt == (uint32_t)WP_ENT) {                             // a full tile (wave-uniform; all but a panel's last): only its last entry looks beyond it
 #pragma unroll
-    for (int u = 0; u < WP_PER; u++) {
-      const uint32_t pos = (uint32_t)(lane * WP_PER + u);
-      const bool nx = u + 1 < WP_PER ? rs[u + 1 < WP_PER ? u + 1 : u] : nxt0 != 0;
-      end[u] = pos + 1 < cnt ? nx : (pos + 1 == cnt ? last_end : false);
+      for (int u = 0; u + 1 < WP_PER; u++) end[u] = rs[u + 1];
+      end[WP_PER - 1] = lane == 63 ? last_end : nxt0 != 0;
+    } else {
+#pragma unroll
+      for (int u = 0; u < WP_PER; u++) {
+        const uint32_t pos = (uint32_t)(lane * WP_PER + u);
+        const bool nx = u + 1 < WP_PER ? rs[u + 1 < WP_PER ? u + 1 : u] : nxt0 != 0;
+        end[u] = pos + 1 < cnt ? nx : (pos + 1 == cnt ? last_end : false);
+      }
     }
     // ---- the sums of the sub-rows that end in this tile leave through the wave's staging slots: the ends are ranked by
     // sub-row (rf, rf+1, ... — consecutive), so 64 of them at a time become one coalesced store.  (Storing from the

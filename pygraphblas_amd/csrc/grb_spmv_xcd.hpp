@@ -306,7 +306,7 @@ static __global__ __launch_bounds__(256) void k_xc_count(const uint32_t* __restr
   const uint32_t lane = threadIdx.x & 63;
   for (uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6); g < ntiles; g += gridDim.x * 4) {
     const uint4 wd = *(const uint4*)(pcol + (size_t)g * WP_ENT + lane * 4);
-    const uint32_t c = ((wd.x >> 30) & 1u) + ((wd.y >> 30) & 1u) + ((wd.z >> 30) & 1u) + ((wd.w >> 30) & 1u);      // XT_COLD
+    const uint32_t c = ((wd.x >> XT_COLD_BIT) & 1u) + ((wd.y >> XT_COLD_BIT) & 1u) + ((wd.z >> XT_COLD_BIT) & 1u) + ((wd.w >> XT_COLD_BIT) & 1u);
     const uint32_t tot = __builtin_amdgcn_wave_reduce_add_u32(c, 0);
     if (lane == 0) tcnt[g] = tot;
   }
