@@ -63,7 +63,16 @@ void release_reads() { for (auto& nd : g_q) for (int k = 0; k < 2; k++) if (nd.i
 void run_queue(const ChainReduce* red, void* red_result, bool keep = false) {
   if (g_q.empty()) return;
   g_flushing = true;
-  struct Restore { ~Restore() { g_flushing = false; } } restore;
+  // if anything below throws (an allocation, a launch): the queue is abandoned as a whole — every vector it would have written keeps its stored value
+  // (what lazy == 2 describes anyway), no node keeps a pointer that a later GrB_free could leave dangling, and the caller sees the error
+  struct Restore {
+    bool committed = false;
+    ~Restore() {
+      g_flushing = false;
+      if (!committed) { release_reads(); for (auto& nd : g_q) if (nd.out && nd.out->lazy == 2) { GrB_Vector w = nd.out; w->lazy = 0; if (!w->dev_valid) { w->hi.clear(); w->hx.clear(); w->pending.clear(); w->host_valid = true; } }      // (a result that never had buffers: empty, as after a failed call)
+        g_q.clear(); g_q_type = -1; g_q_n = 0; }
+    }
+  } restore;
   ChainLaunch L{};
   L.tcode = g_q_type; L.n = g_q_n; L.nsteps = (int)g_q.size();
   std::vector<GrB_Vector> ext;
@@ -111,6 +120,7 @@ void run_queue(const ChainReduce* red, void* red_result, bool keep = false) {
   if (red) L.red = *red;
   vec_chain_launch(L, red_result);
   g_stat_chains++; g_stat_nodes += g_q.size(); if (red) g_stat_reduces_fused++;
+  restore.committed = true;
   if (keep) return;
   release_reads();
   for (size_t o = 0; o < outs.size(); o++) {

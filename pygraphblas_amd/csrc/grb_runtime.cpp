@@ -18,7 +18,7 @@ extern "C" const uint64_t* GrB_ALL = &grb_all_sentinel;
 
 namespace grb {
 
-static std::mutex g_mu;
+static std::mutex& g_mu = *new std::mutex();      // (immortal, like the pool's registries below)
 static bool g_inited = false, g_device_ok = false;
 static std::string g_device_err = "GrB_init has not been called";
 static hipStream_t g_stream = 0;
@@ -31,8 +31,10 @@ std::string g_last_plan;
 thread_local std::string g_last_error;
 
 // ---- pooled allocator: power-of-two-ish size classes, blocks are never split -------------------
-static std::multimap<size_t, void*> g_free;           // size class -> block
-static std::unordered_map<void*, size_t> g_live;      // block -> size class
+// (never destroyed: the scratch buffers some kernels' launchers keep per thread — thread_local DevBufs — are released by destructors that run at thread or
+//  process exit, possibly after this translation unit's statics are gone and after GrB_finalize returned the cached blocks; they only re-enter the free list)
+static std::multimap<size_t, void*>& g_free = *new std::multimap<size_t, void*>();                  // size class -> block
+static std::unordered_map<void*, size_t>& g_live = *new std::unordered_map<void*, size_t>();        // block -> size class
 static size_t g_in_use = 0, g_cached = 0;
 
 static size_t size_class(size_t n) {
