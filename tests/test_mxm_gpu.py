@@ -250,8 +250,8 @@ def test_two_pass_hash_spgemm_every_bin_against_expand_sort_compress(gpu, typ, s
 
 @pytest.mark.parametrize("typ,sr", [("INT64", "PLUS_TIMES"), ("FP32", "MIN_PLUS"), ("FP64", "PLUS_TIMES")])
 def test_hash_spgemm_wide_rows_through_many_column_blocks(gpu, typ, sr, monkeypatch):
-    """Rows of the result with tens of thousands of entries over 70 000 columns: the LDS dense accumulator walks 9 (8-byte) / 5
-    (4-byte) column blocks per row with its cursors into the B rows; empty blocks, B rows that end inside a block, a last
+    """Rows of the result with tens of thousands of entries over 70 000 columns: the LDS dense accumulator walks 5 (8-byte: 16 384 columns each) / 3
+    (4-byte: 28 672) column blocks per row with its cursors into the B rows; empty blocks, B rows that end inside a block, a last
     partial block.  Against expand / sort / compress."""
     rng = np.random.default_rng(9)
     A, rp, col, vals = _rmat_matrix(12, typ, rng, 1, 3)
