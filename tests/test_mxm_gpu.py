@@ -349,3 +349,41 @@ def test_ewise_on_few_long_rows_matches_the_row_merge_kernels(gpu, monkeypatch):
         a, b = res
         assert np.array_equal(a.I, b.I) and np.array_equal(a.J, b.J), (typ, opn, kw)
         assert np.allclose(a.X.astype(np.float64), b.X.astype(np.float64), rtol=1e-6, atol=0.0, equal_nan=True), (typ, opn, kw)
+
+
+def test_unmasked_product_rmat18_by_its_row_sums_and_entry_count(gpu, monkeypatch):
+    """A @ A on the symmetric R-MAT-18 (9.5e9 products, 3.0e9 entries: the rows beyond the LDS tables carry nearly all of them — the
+    dense-accumulator path of grb_spgemm_hash.hpp at the size tools/workloads.py times it; lib.GrB_mxm without a mask,
+    pygraphblas/matrix.py:2572-2583).  No oracle holds 35 GB of result, so the size-independent properties: with integer-valued
+    entries (C 1) = A (A 1) exactly, row by row (every product lands in the right row, once); the sum of all entries is
+    sum_k colsum(k) rowsum(k); and the pattern's size is what the two-pass product of the PATTERNS gives through the other type's
+    kernels (BOOL LOR_LAND: 4-byte accumulators, other block width)."""
+    import torch
+    from pygraphblas_amd import rmat
+    dev = torch.device("cuda", 0)
+    S = 18; n = 1 << S
+    rowptr, col = rmat.csr_torch(S, dev, seed=42, symmetric=True, drop_self_loops=True)
+    nnz = int(col.numel())
+    g = torch.Generator(device="cpu"); g.manual_seed(3)
+    vals = torch.randint(1, 4, (nnz,), generator=g, dtype=torch.int64).to(torch.float64).to(dev)
+    A = gb.Matrix.from_csr(gb.FP64, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+    monkeypatch.setenv("GRB_MI355X_SPGEMM", "hash")
+    C = A.mxm(A, semiring=gb.FP64.PLUS_TIMES)
+    plan = gb.last_kernel_plan()
+    num = [int(x) for x in plan.split("numeric bins ")[1].split()[0].split("/")]
+    assert "spgemm_hash" in plan and num[3] > 100000, plan
+    ones = gb.Vector.from_dense_array(np.ones(n), gb.FP64)
+    a1 = A.mxv(ones, semiring=gb.FP64.PLUS_TIMES)
+    want = A.mxv(a1, semiring=gb.FP64.PLUS_TIMES)                    # A (A 1): two products of the north-star path, exact in integers
+    got = C.reduce_vector(gb.FP64.PLUS_MONOID)                      # (C 1)
+    wi, wx = want.to_arrays(); gi, gx = got.to_arrays()
+    assert np.array_equal(wi, gi) and np.array_equal(wx, gx)
+    rs, _ = a1.to_dense_arrays()                                     # A symmetric in pattern, not in values: column sums come from the transpose
+    cs = A.transpose().mxv(ones, semiring=gb.FP64.PLUS_TIMES).to_dense_arrays()[0]
+    assert C.reduce_float() == float(np.dot(cs, rs))                 # (< 2^53: exact whatever the order)
+    nv = C.nvals
+    del C
+    P = gb.Matrix.from_csr(gb.BOOL, n, n, rowptr.data_ptr(), col.data_ptr(), (torch.ones(nnz, dtype=torch.bool, device=dev).data_ptr(), nnz), device=True)
+    CP = P.mxm(P, semiring=gb.BOOL.LOR_LAND)
+    assert CP.nvals == nv and nv > 2 * 10**9
+    assert CP.reduce_bool(gb.BOOL.LAND_MONOID)
