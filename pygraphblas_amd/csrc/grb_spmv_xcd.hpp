@@ -602,6 +602,8 @@ __global__ __launch_bounds__(XM_CT) void k_xp_merge(uint32_t nrows, uint32_t nbl
 //     into a chunk from the chunks before it (a row that began earlier) is added to the last slot of the chunk's leading piece after a
 //     barrier, by walking back over the chunk totals.  Every order is fixed: reproducible.
 //   * persistent workgroups (a few per CU) over an XCD's contiguous eighth of the blocks, the next block's bounds fetched a block ahead.
+// (Also measured, no change: the run of a position from a ballot over lane-held prefixes + readlanes instead of the bisection's six dependent LDS
+//  reads — 406 against 402 us: the kernel is not bound by that chain either; blocks of 2048 / 8192 sub-rows: 503 / 422 us against 341-400.)
 // LDS: m_slots values + m_slots flag bytes.
 #ifndef XMW_TARGET_V
 #define XMW_TARGET_V 4096          // sub-rows per block of the wide merge (measurement builds: make XTFLAGS=-DXMW_TARGET_V=8192)
