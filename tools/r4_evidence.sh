@@ -9,6 +9,22 @@ PMC_PASSES=3 bash tools/pmc_spmv.sh $out/pmc_spmv --variants FP64.PLUS_TIMES --m
 timeout 300 python tools/bfs_probe.py > $out/bfs_per_call_timeline.txt 2>&1
 timeout 300 python tools/sssp_probe.py > $out/sssp_per_call_timeline.txt 2>&1
 timeout 900 python tools/workloads.py --what bfs,tc,pr,bc,bcfull,aa > $out/workloads_scale22.jsonl 2> $out/workloads.err; echo "workloads rc=$?"
+# the unmasked product (A @ A, R-MAT-18): kernel times of the hash path + where its waves' cycles go
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/aa_kt -o aa -- python tools/workloads.py --what aa --aa-methods hash > $out/aa_kt.log 2>&1
+bash tools/pmc_sq_aa.sh $out/aa_sq > $out/aa_sq.log 2>&1
+python - $out <<'PY' > $out/aa_kernel_stats.txt
+import csv, glob, sys
+out = sys.argv[1]
+print("A @ A (unmasked GrB_mxm), symmetric R-MAT-18 FP64 PLUS_TIMES, two-pass hash path: rocprofv3 --kernel-trace --stats of tools/workloads.py --what aa --aa-methods hash (3 products)")
+for l in open(f"{out}/aa_kt.log"):
+    if l.startswith("{"): print("  ", l.strip()[:700])
+for f in glob.glob(f"{out}/aa_kt/**/*kernel_stats.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "grb::" in r["Name"] and float(r["TotalDurationNs"]) > 3e5: print(f'   {r["Name"].split("(")[0][-90:]:90s} calls {r["Calls"]:>4s} avg {float(r["AverageNs"])/1e3:10.1f} us')
+print("SQ counters (rocprofv3 --pmc, their own passes: tools/pmc_sq_aa.sh):")
+try: print(open(f"{out}/aa_sq/sq_summary.txt").read())
+except Exception as e: print("   (missing)", e)
+PY
 for S in 1 a; do
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/pr25_kt_$S -o kt -- python tools/r4_subpanel_probe.py --skip-a --pr-subpanels $S > $out/pr25_kt_$S.log 2>&1
   timeout 200 rocprofv3 --pmc WRITE_SIZE TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $out/pr25_p1_$S -o pmc -- python tools/r4_subpanel_probe.py --skip-a --pr-subpanels $S > $out/pr25_p1_$S.log 2>&1
