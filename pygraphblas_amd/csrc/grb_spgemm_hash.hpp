@@ -227,6 +227,8 @@ constexpr uint32_t SPA_CHUNK = 992;             // entries of A(i,:) per walk of
 //  * reading the batch's bitmap words together before its atomics: 57 -> 61 (later rounds no longer see the bits the earlier ones set);
 //  * 512 threads per workgroup (half the fixed per-wave work of a step): 63 -> 75 + 30; two workgroups of 8192 columns per CU: 57 -> 78;
 //  * barriers that wait for the LDS only (s_waitcnt lgkmcnt(0); s_barrier — not for the stores on their way to the HBM): no change.
+//  * the emission a LANE per column (a wave walks its 1024 columns 64 at a time; ballot + v_mbcnt ranks: the lanes of a store write consecutive
+//    entries) instead of 16 columns per thread: 55 -> 59.5 (the scattered stores were not what the emission costs).
 #ifndef SPA_R_V
 #define SPA_R_V 8
 #endif
