@@ -163,6 +163,7 @@ struct GrB_Vector_opaque {
   // Every access goes through vec_gate() (vec_to_device / vec_to_host / vec_nvals / the entry points of grb_container.cpp).
   int lazy = 0; uint8_t lazy_fill[16] = {0}; int q_reads = 0;
   bool holes_zero = false;     // the device values of absent positions are all-zero bits (written so by the element-wise chain kernel)
+  bool holes_big = false; uint8_t holes_big_val[16] = {0};      // ... or all hold this value of the vector's type (the BIG fill of a MIN_PLUS / MAX_PLUS sweep, grb_mxv.cpp; round 4).  Reset wherever holes_zero is.
   // BOOL vectors: "is any stored value true", recorded by the product kernel that wrote the device buffers `lor_key`
   // (0 unknown, 1 in the device word of grb_container.cpp's any_true_*, 2 false, 3 true) — `while q.reduce_bool()` of a BFS loop
   uint8_t lor_state = 0; uint32_t lor_tag = 0; const void* lor_key = nullptr;

@@ -128,7 +128,7 @@ void run_queue(const ChainReduce* red, void* red_result, bool keep = false) {
     if (nval[o].p) { w->dval = std::move(nval[o]); w->dpres = std::move(npres[o]); }
     w->lazy = 0; w->dev_valid = true; w->host_valid = false; w->hi.clear(); w->hx.clear(); w->pending.clear();
     w->dnvals_known = out_full[o]; w->dnvals = out_full[o] ? w->n : 0;
-    w->holes_zero = true; w->fe_lb = 0; w->fe_lb_key = 0; w->lor_state = 0; w->abs_bound = -1; w->small_valid = false;
+    w->holes_zero = true; w->holes_big = false; w->fe_lb = 0; w->fe_lb_key = 0; w->lor_state = 0; w->abs_bound = -1; w->small_valid = false;
   }
   g_q.clear(); g_q_type = -1; g_q_n = 0;
 }
@@ -138,7 +138,7 @@ void materialise_fill(GrB_Vector w) {
   w->lazy = 0;
   w->dval.alloc(n * ts ? n * ts : 1); w->dpres.alloc(n ? n : 1);
   vec_assign_scalar(w->type->code, n, w->dval.p, w->dpres.as<uint8_t>(), nullptr, nullptr, w->lazy_fill, -1, false);
-  w->dev_valid = true; w->host_valid = false; w->dnvals = n; w->dnvals_known = true; w->holes_zero = false; w->lor_state = 0; w->abs_bound = -1; w->small_valid = false;
+  w->dev_valid = true; w->host_valid = false; w->dnvals = n; w->dnvals_known = true; w->holes_zero = false; w->holes_big = false; w->lor_state = 0; w->abs_bound = -1; w->small_valid = false;
 }
 
 }  // namespace
@@ -189,7 +189,7 @@ bool lazy_fill(GrB_Vector w, const void* s_in_w_type) {
   vec_overwritten(w);
   // the buffers go back to the pool: whoever consumes the fill allocates the result
   w->hi.clear(); w->hx.clear(); w->pending.clear(); w->host_valid = false; w->iso_full = false;
-  w->dev_valid = false; w->dval.reset(); w->dpres.reset(); w->dnvals = 0; w->dnvals_known = false; w->fe_lb = 0; w->fe_lb_key = 0; w->holes_zero = false;
+  w->dev_valid = false; w->dval.reset(); w->dpres.reset(); w->dnvals = 0; w->dnvals_known = false; w->fe_lb = 0; w->fe_lb_key = 0; w->holes_zero = false; w->holes_big = false;
   w->lazy = 1; memcpy(w->lazy_fill, s_in_w_type, 16); w->lor_state = 0; w->abs_bound = -1; w->small_valid = false;
   return true;
 }
@@ -231,7 +231,7 @@ static bool enqueue(Node nd, GrB_Vector w, int tcode) {
   else if (w->lazy == 2) { for (auto& q : g_q) if (q.out == w) q.out = nullptr; }
   // (while lazy == 2, dnvals / holes_zero keep describing the STORED value — the queue reads it; nobody else can without passing vec_gate)
   if (!w->q_reads) { w->hi.clear(); w->hx.clear(); w->pending.clear(); w->host_valid = false; w->iso_full = false; w->dev_valid = false; w->dval.reset(); w->dpres.reset();
-                     w->dnvals = 0; w->dnvals_known = false; w->holes_zero = false; }
+                     w->dnvals = 0; w->dnvals_known = false; w->holes_zero = false; w->holes_big = false; }
   else { w->host_valid = false; w->hi.clear(); w->hx.clear(); w->pending.clear(); }
   w->fe_lb = 0; w->fe_lb_key = 0; w->lor_state = 0; w->abs_bound = -1; w->small_valid = false;
   w->lazy = 2;
