@@ -471,8 +471,7 @@ GrB_Info GrB_Vector_dup(GrB_Vector* w, const GrB_Vector u) {
     else {
       const size_t ts = u->type->size;
       r->dval.alloc(u->n * ts ? u->n * ts : 1); r->dpres.alloc(u->n ? u->n : 1);
-      if (u->n) { GRB_HIP(hipMemcpyAsync(r->dval.p, u->dval.p, u->n * ts, hipMemcpyDeviceToDevice, stream()));
-                  GRB_HIP(hipMemcpyAsync(r->dpres.p, u->dpres.p, u->n, hipMemcpyDeviceToDevice, stream())); }
+      if (u->n) dev_copy2(r->dval.p, u->dval.p, u->n * ts, r->dpres.p, u->dpres.p, u->n);
       r->dnvals = u->dnvals; r->dnvals_known = u->dnvals_known; r->dev_valid = true; r->host_valid = false;
     }
   });

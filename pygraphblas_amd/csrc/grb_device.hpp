@@ -191,6 +191,7 @@ void sort_keys_u32(const uint32_t* kin, uint32_t* kout, uint64_t n, int end_bit)
 void sort_pairs_u64(const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n, int end_bit);
 
 // ---- kernels in grb_vecops.hip ---------------------------------------------------------------------------------
+void dev_copy2(void* d0, const void* s0, uint64_t n0, void* d1, const void* s1, uint64_t n1);      // two device-to-device copies (byte counts), one launch
 // min / max of the present finite values (in the type itself), how many present values are NaN or infinite, how many are present;
 // false for types other than INT32 / INT64 / FP32 / FP64
 bool value_range(int code, uint64_t n, const void* val, const uint8_t* pres, void* vmin, void* vmax, uint64_t* nonfinite, uint64_t* count);

@@ -143,22 +143,45 @@ __device__ __forceinline__ void block_add_u64(unsigned long long c, unsigned lon
 }
 static inline int grid_capped(uint64_t n, int per_thread, int cap = 512) { const int g = grid_for(n, per_thread); return g < cap ? g : cap; }
 
-__global__ void k_count(const uint8_t* __restrict__ pres, uint64_t n, unsigned long long* out) {
+// (round 4: 128 workgroups, four 16-byte loads in flight per lane — 512 workgroups of two loads each ended in 512 same-address atomics: 10 us for a 4 MB
+//  bitmap, and the shortest-path loop's `iseq` counts two of them per sweep)
+__global__ __launch_bounds__(256) void k_count(const uint8_t* __restrict__ pres, uint64_t n, unsigned long long* out) {
   unsigned long long c = 0;
-  // 16 bytes per lane per step
-  const uint64_t n16 = n / 16;
+  // 16 bytes per lane per load
+  const uint64_t n16 = n / 16, T = gridDim.x * 256ull;
   const uint4* p4 = (const uint4*)pres;
-  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += gridDim.x * 256ull) {
-    uint4 v = p4[i];
-    c += __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) + __popc(v.w & 0x01010101u);
-  }
-  for (uint64_t i = n16 * 16 + blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) c += pres[i] != 0;
+  auto ones = [](const uint4& v) { return (unsigned)(__popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) + __popc(v.w & 0x01010101u)); };
+  uint64_t i = blockIdx.x * 256ull + threadIdx.x;
+  for (; i + 3 * T < n16; i += 4 * T) { const uint4 a = p4[i], b = p4[i + T], d = p4[i + 2 * T], e = p4[i + 3 * T]; c += ones(a) + ones(b) + ones(d) + ones(e); }
+  for (; i < n16; i += T) c += ones(p4[i]);
+  for (uint64_t j = n16 * 16 + blockIdx.x * 256ull + threadIdx.x; j < n; j += T) c += pres[j] != 0;
   block_add_u64(c, out);
+}
+// two device-to-device copies in one launch (GrB_Vector_dup: values + presence bytes — `w = v.dup()` opens every sweep of the shortest-path loop;
+// two hipMemcpyAsync were two launches of the runtime's own copy kernel)
+__global__ __launch_bounds__(256) void k_copy2(uint4* __restrict__ d0, const uint4* __restrict__ s0, uint64_t n0 /* bytes */, uint4* __restrict__ d1, const uint4* __restrict__ s1, uint64_t n1) {
+  const uint64_t q0 = n0 / 16, q1 = n1 / 16, T = gridDim.x * 256ull;
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < q0 + q1; i += T) { if (i < q0) d0[i] = s0[i]; else d1[i - q0] = s1[i - q0]; }
+  if (blockIdx.x == 0) {
+    for (uint64_t b = q0 * 16 + threadIdx.x; b < n0; b += 256) ((uint8_t*)d0)[b] = ((const uint8_t*)s0)[b];
+    for (uint64_t b = q1 * 16 + threadIdx.x; b < n1; b += 256) ((uint8_t*)d1)[b] = ((const uint8_t*)s1)[b];
+  }
+}
+void dev_copy2(void* d0, const void* s0, uint64_t n0, void* d1, const void* s1, uint64_t n1) {
+  if (!(n0 + n1)) return;
+  if ((((uintptr_t)d0 | (uintptr_t)s0 | (uintptr_t)d1 | (uintptr_t)s1) & 15) != 0) {      // (never with the pool's blocks)
+    if (n0) GRB_HIP(hipMemcpyAsync(d0, s0, n0, hipMemcpyDeviceToDevice, stream()));
+    if (n1) GRB_HIP(hipMemcpyAsync(d1, s1, n1, hipMemcpyDeviceToDevice, stream()));
+    return;
+  }
+  const uint64_t q = (n0 + n1) / 16 + 1;
+  uint64_t g = (q + 256ull * 4 - 1) / (256ull * 4); const uint64_t gmax = (uint64_t)(device_cus() > 0 ? device_cus() : 256) * 8ull; if (g > gmax) g = gmax; if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_copy2, dim3((unsigned)g), dim3(256), 0, stream(), (uint4*)d0, (const uint4*)s0, n0, (uint4*)d1, (const uint4*)s1, n1);
 }
 uint64_t count_present(const uint8_t* pres, uint64_t n) {
   if (!n) return 0;
   ScalarSlot slot; slot.zero();
-  hipLaunchKernelGGL(k_count, dim3(grid_capped(n, 16)), dim3(256), 0, stream(), pres, n, (unsigned long long*)slot.dev());
+  hipLaunchKernelGGL(k_count, dim3(grid_capped(n, 16, 128)), dim3(256), 0, stream(), pres, n, (unsigned long long*)slot.dev());
   return slot.read_u64();
 }
 
