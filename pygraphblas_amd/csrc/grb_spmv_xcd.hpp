@@ -144,6 +144,24 @@ static __global__ void k_xp_column_codes(const uint32_t* __restrict__ key, const
     if (local < hot) hot_cols[(size_t)k * H + local] = c;
   }
 }
+// the hot columns of a stream take their slots in COLUMN order (round 4): the table gather of a call (k_xp_hot_gather: xhot[slot] = u[hot column]) then walks u
+// front to back inside every stream — with the slots in order of popularity its 2.5e6 gathers of a 64-table plan were 2.5e6 separate 128-byte lines.
+// Every stream contributes exactly H keys (its unused slots sort behind its columns), so sorted position i is slot i - k H of stream k.
+static __global__ void k_xp_hot_keys(const uint32_t* __restrict__ hot_cols, const uint32_t* __restrict__ start, uint32_t ns, uint32_t H, uint32_t hot, unsigned long long* __restrict__ key, uint32_t* __restrict__ val) {
+  const uint64_t tot = (uint64_t)ns * H;
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < tot; i += gridDim.x * 256ull) {
+    const uint32_t k = (uint32_t)(i / H), slot = (uint32_t)(i - (uint64_t)k * H), have = start[k + 1] - start[k];
+    const bool valid = slot < hot && slot < have;
+    key[i] = ((unsigned long long)k << 32) | (valid ? hot_cols[i] : 0xFFFFFFFFu); val[i] = 0;
+  }
+}
+static __global__ void k_xp_hot_reslot(const unsigned long long* __restrict__ key, uint32_t ns, uint32_t H, uint32_t* __restrict__ code, uint32_t* __restrict__ hot_cols) {
+  const uint64_t tot = (uint64_t)ns * H;
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < tot; i += gridDim.x * 256ull) {
+    const uint32_t k = (uint32_t)(key[i] >> 32), c = (uint32_t)key[i], slot = (uint32_t)(i - (uint64_t)k * H);
+    if (c != 0xFFFFFFFFu) { hot_cols[i] = c; code[c] = slot; } else hot_cols[i] = 0;
+  }
+}
 // row of every entry: the non-empty rows mark their first entry, an inclusive max-scan fills the rest
 static __global__ void k_xp_mark_rows(const uint32_t* __restrict__ rowptr, uint32_t nrows, uint32_t* __restrict__ rowidx) {
   for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < nrows; r += gridDim.x * 256) { const uint32_t s = rowptr[r]; if (rowptr[r + 1] > s) rowidx[s] = r; }
@@ -832,6 +850,13 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
     hipLaunchKernelGGL(k_xp_panel_starts, dim3(grid_n(n)), dim3(256), 0, stream(), k32o.as<uint32_t>(), n, cstart.as<uint32_t>());
     hipLaunchKernelGGL(k_xp_fix_starts, dim3(1), dim3(1), 0, stream(), cstart.as<uint32_t>(), n, NS);
     hipLaunchKernelGGL(k_xp_column_codes, dim3(grid_n(n)), dim3(256), 0, stream(), k32o.as<uint32_t>(), cout.as<uint32_t>(), n, H, (uint32_t)xt_hot<T>::HOT, cstart.as<uint32_t>(), code.as<uint32_t>(), P->hot_cols.as<uint32_t>());
+    if (wp_env("GRB_MI355X_XHOT_BY_COLUMN", 1) != 0) {
+      const uint64_t tot = (uint64_t)NS * H;
+      DevBuf k64(tot * 8 + 8), k64o(tot * 8 + 8), v32(tot * 4 + 4), v32o(tot * 4 + 4);
+      hipLaunchKernelGGL(k_xp_hot_keys, dim3(grid_n(tot)), dim3(256), 0, stream(), P->hot_cols.as<uint32_t>(), cstart.as<uint32_t>(), NS, (uint32_t)H, (uint32_t)xt_hot<T>::HOT, (unsigned long long*)k64.p, v32.as<uint32_t>());
+      sort_pairs_u64((const uint64_t*)k64.p, (uint64_t*)k64o.p, v32.as<uint32_t>(), v32o.as<uint32_t>(), tot, 32 + 7);
+      hipLaunchKernelGGL(k_xp_hot_reslot, dim3(grid_n(tot)), dim3(256), 0, stream(), (const unsigned long long*)k64o.p, NS, (uint32_t)H, code.as<uint32_t>(), P->hot_cols.as<uint32_t>());
+    }
   }   // (the temporaries return to the pool; reuse is stream-ordered)
   // 2. row of every entry
   DevBuf rowidx(nnz * 4 + 4);
