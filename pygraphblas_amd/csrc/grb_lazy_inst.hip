@@ -6,6 +6,7 @@
 // written once — zeros where a result has no entry, so that a later product may gather from the values without a fill pass.
 // `t -= r; t = abs(t); t.reduce_float()` (gap/prmark.py:24-26) moves 3 x 4 B per vertex instead of 8 x 4 + 6 x 1 in four kernels.
 // The operator codes are wave-uniform kernel arguments: one scalar branch per step, as in the runtime-opcode semirings.
+#include <atomic>
 #include <type_traits>
 #include "grb_api.hpp"
 #include "grb_device.hpp"
@@ -243,14 +244,14 @@ template <class T, int RED, class R, int NIN> static void launch_chain(const Cha
   // one round of workgroups: 4 per CU are resident whatever the variant's register count (with 2048 workgroups of a 69-register
   // variant — 7 per CU — the eighth waited for a slot and the kernel ran a second, nearly empty round: 27 us for 50 MB)
   // (as many workgroups as are resident at once for THIS variant: the occupancy API, asked once per instantiation)
-  static int occ4 = 0, occ1 = 0;
-  if (!occ4) { int b = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_vec_chain<T, RED, R, NIN, 4>, 256, 0) != hipSuccess || b < 1) { (void)hipGetLastError(); b = 4; } occ4 = b > 64 ? 64 : b; }
-  if (!occ1) { int b = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_vec_chain<T, RED, R, NIN, 1>, 256, 0) != hipSuccess || b < 1) { (void)hipGetLastError(); b = 4; } occ1 = b > 64 ? 64 : b; }
+  static std::atomic<int> occ4{0}, occ1{0};            // (asked once per instantiation; concurrent first callers compute the same numbers)
+  if (!occ4) { int b = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_vec_chain<T, RED, R, NIN, 4>, 256, 0) != hipSuccess || b < 1) { (void)hipGetLastError(); b = 4; } occ4.store(b > 64 ? 64 : b); }
+  if (!occ1) { int b = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_vec_chain<T, RED, R, NIN, 1>, 256, 0) != hipSuccess || b < 1) { (void)hipGetLastError(); b = 4; } occ1.store(b > 64 ? 64 : b); }
   static const int env_vec = getenv("GRB_MI355X_CHAIN_VEC") ? atoi(getenv("GRB_MI355X_CHAIN_VEC")) : 4;            // measurement hooks
   static const int env_bpc = getenv("GRB_MI355X_CHAIN_BPC") ? atoi(getenv("GRB_MI355X_CHAIN_BPC")) : 0;
   if (env_vec == 1) aligned = false;
-  if (env_bpc > 0) { occ4 = env_bpc; occ1 = env_bpc; }
-  const uint64_t gmax = (uint64_t)(device_cus() > 0 ? device_cus() : 256) * (uint64_t)(aligned ? occ4 : occ1);
+  const int use4 = env_bpc > 0 ? env_bpc : occ4.load(), use1 = env_bpc > 0 ? env_bpc : occ1.load();
+  const uint64_t gmax = (uint64_t)(device_cus() > 0 ? device_cus() : 256) * (uint64_t)(aligned ? use4 : use1);
   uint64_t g = (L.n + 256ull * 4 - 1) / (256ull * 4); if (g < 1) g = 1; if (g > gmax) g = gmax; if (g > 16384) g = 16384;
   R rid{}; R* result = nullptr; R* partial = nullptr;
   if constexpr (RED != 0) {
