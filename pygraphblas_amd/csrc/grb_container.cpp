@@ -204,8 +204,9 @@ void vec_to_device(GrB_Vector v) {
     // few entries (an empty output vector, the one-entry frontier of a BFS): zero the bitmap in HBM and scatter the entries —
     // staging n zero bytes on the host and copying them cost 2 x 15 ms per PageRank run at R-MAT-25 and half of a BFS at R-MAT-22
     const uint32_t k = (uint32_t)v->hi.size();
-    GRB_HIP(hipMemsetAsync(v->dval.p, 0, n * ts, stream())); GRB_HIP(hipMemsetAsync(v->dpres.p, 0, n, stream()));
-    if (k && k <= 16 && ts <= 8) scatter_entries_small(k, v->hi.data(), v->hx.data(), ts, v->dval.p, v->dpres.as<uint8_t>());
+    if (k <= 16 && ts <= 8) init_entries_small(k, v->hi.data(), v->hx.data(), ts, v->dval.p, v->dpres.as<uint8_t>(), n);      // zeros + the entries, one launch
+    else { GRB_HIP(hipMemsetAsync(v->dval.p, 0, n * ts, stream())); GRB_HIP(hipMemsetAsync(v->dpres.p, 0, n, stream())); }
+    if (k <= 16 && ts <= 8) {}
     else if (k) {
       std::vector<uint32_t> i32(k); for (uint32_t e = 0; e < k; e++) i32[e] = (uint32_t)v->hi[e];
       DevBuf di((size_t)k * 4), dx((size_t)k * ts);

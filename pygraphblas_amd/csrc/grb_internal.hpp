@@ -239,7 +239,7 @@ void vec_cast_fill_values(int dst_code, void* dst, int src_code, const void* src
 void build_allow(uint64_t n, int mcode, const void* mval, const uint8_t* mpres, bool structural,
                  bool complement, uint8_t* allow);
 uint64_t count_present(const uint8_t* pres, uint64_t n);
-void scatter_entries_small(uint32_t k, const uint64_t* idx_host, const uint8_t* vals_host, size_t ts, void* val, uint8_t* pres);   // k <= 16, ts <= 8: entries passed as kernel arguments (no staging, no synchronisation)
+void init_entries_small(uint32_t k, const uint64_t* idx_host, const uint8_t* vals_host, size_t ts, void* val, uint8_t* pres, uint64_t n);      // zero both arrays of an n-vector and write k <= 16 entries: one launch   // k <= 16, ts <= 8: entries passed as kernel arguments (no staging, no synchronisation)
 void write_small_list(uint32_t k, const uint32_t* idx_host, uint32_t* out_dev);   // k <= 64 indices passed as kernel arguments
 void scatter_entries(uint32_t k, const uint32_t* idx_dev, const void* vals_dev, size_t ts, void* val, uint8_t* pres);   // val[idx[e]] = vals[e], pres[idx[e]] = 1
 uint64_t frontier_edges(const uint8_t* pres, const uint32_t* rowptr, uint64_t n);
