@@ -25,6 +25,9 @@ Beside the step the JSON line carries, every one with its own `r
   pagerank          configs[4]'s loop (gap/prmark.py, FP32 PLUS_SECOND) on the step's partition                    [every N]
   pagerank_scale25  configs[4] at its stated size: R-MAT scale-25 on one GPU / over the N ranks                    [every N]
   sssp              the reference's MIN_PLUS shortest-path loop on R-MAT-22, INT64 weights, bit-exact              [N = 1]
+  aa                the unmasked A @ A (GrB_mxm, mask = NULL) on R-MAT-18 FP64: the two-pass LDS-hash Gustavson, sampled rows of
+                    the result against the oracle                                                                  [N = 1]
+  bc                gap/bcmark.py's batched betweenness centrality (ns = 4) on R-MAT-22, against the oracle        [N = 1]
 Rank 0 prints ONE JSON line; see DESIGN.md §6 for how `roofline` and `cpu_baseline` are measured.
 """
 import argparse
@@ -71,6 +74,7 @@ def main():
     ap.add_argument("--scale", type=int, default=22, help="R-MAT scale (22 = the BASELINE config): per GPU for weak scaling, of the whole graph for strong")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="what the headline step does for N > 1")
     ap.add_argument("--pr-scale", type=int, default=25, help="scale of the pagerank_scale25 sub-object (configs[4])")
+    ap.add_argument("--aa-scale", type=int, default=18, help="scale of the unmasked A @ A sub-object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed step (no sub-objects)")
     args = ap.parse_args()
@@ -236,6 +240,9 @@ def main():
             out["pagerank_scale25"] = bench_pagerank(cx, args.pr_scale, pr_bounds, min(args.steps, 10), "pagerank_scale25")
         if world == 1:
             out["sssp"] = bench_sssp(cx, args.scale)
+            torch.cuda.empty_cache()
+            out["aa"] = bench_aa(cx, args.aa_scale)
+            out["bc"] = bench_bc(cx, args.scale)
 
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -651,6 +658,130 @@ def bench_sssp(cx, scale):
         ok = bool(osweeps == sweeps and np.array_equal(gp != 0, pres != 0) and np.array_equal(gd[pres != 0], dist[pres != 0]))
         out["parity_vs_oracle"] = "bit-exact distances, same sweep count" if ok else f"MISMATCH (oracle sweeps {osweeps})"
         out["cpu_baseline"] = {"seconds": round(cpu_s, 3), "cores": O.num_threads(), "kind": "port", "sample": "one pass of oracle fast_sssp (includes its transpose)"}
+    return out
+
+
+def bench_aa(cx, scale=18):
+    """The north star's general SpGEMM: the UNMASKED A @ A (lib.GrB_mxm with mask = NULL, pygraphblas/matrix.py:2572-2583) on the symmetric
+    R-MAT-`scale`, FP64 PLUS_TIMES, through the two-pass (symbolic + numeric) LDS-hash Gustavson of grb_spgemm_hash.hpp.  Median of five runs;
+    sampled rows of the result (every numeric bin, the hub rows) against the oracle's Gustavson rows; the oracle's rows timed as the CPU baseline."""
+    gb, rmat, torch, dev, np, lib = cx.gb, cx.rmat, cx.torch, cx.dev, cx.np, cx.lib
+    n = 1 << scale
+    rowptr, col = rmat.csr_torch(scale, dev, seed=42, symmetric=True, drop_self_loops=True)
+    nnz = int(col.numel())
+    vals = rmat.values_torch(nnz, dev, seed=45).to(torch.float64) + 0.5
+    A = gb.Matrix.from_csr(gb.FP64, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+    dA = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+    products = int(dA[col.to(torch.int64) & 0xFFFFFFFF].sum())
+    Cm = A.mxm(A, semiring=gb.FP64.PLUS_TIMES)                                   # first run: the result's 35 GB come from hipMalloc, later ones from the pool
+    times = []
+    for _ in range(5):
+        Cm = None
+        torch.cuda.synchronize(); t = time.perf_counter()
+        Cm = A.mxm(A, semiring=gb.FP64.PLUS_TIMES)
+        torch.cuda.synchronize(); times.append(time.perf_counter() - t)
+    sec = sorted(times)[2]
+    plan = gb.last_kernel_plan()
+    nc = Cm.nvals
+    # SURVEY.md 8d, unmasked form: A once (12 B per entry + row pointers), one B-row entry (column + FP64 value) per product, C written
+    alg = nnz * 12 + (n + 1) * 4 + products * 12 + nc * 12 + (n + 1) * 4
+    out = {"workload": f"A @ A (unmasked GrB_mxm, two-pass LDS-hash Gustavson) R-MAT-{scale} symmetric FP64 PLUS_TIMES", "n": n, "nnz_A": nnz, "products": products, "nnz_C": nc,
+           "seconds": round(sec, 5), "seconds_runs": [round(x, 5) for x in times], "GFLOPS": round(2.0 * products / sec / 1e9, 1), "dtype": "f64", "kernel": plan,
+           "roofline": roof(alg, sec, note="nnz(A)*12 + products*12 (B-row entries, column + value, counted once per product) + nnz(C)*12 + 2*(n+1)*4")}
+    if not cx.args.no_cpu_baseline:
+        from oracle import oracle as O
+        crp = torch.empty(n + 1, dtype=torch.int32, device=dev); ccol = torch.empty(nc, dtype=torch.int32, device=dev); cval = torch.empty(nc, dtype=torch.float64, device=dev)
+        gb.base.check(lib.GrBX_Matrix_export_CSR(Cm._h, C.c_void_p(crp.data_ptr()), C.c_void_p(ccol.data_ptr()), C.c_void_p(cval.data_ptr()), C.c_int(1)))
+        Cm = None
+        rp64 = crp.to(torch.int64) & 0xFFFFFFFF
+        lens = (rp64[1:] - rp64[:-1]).cpu().numpy()
+        order = np.argsort(lens, kind="stable"); order = order[lens[order] > 0]
+        rows = np.unique(np.concatenate([order[np.linspace(0, len(order) - 1, 400).astype(np.int64)], order[-32:], np.random.default_rng(9).choice(n, 200, replace=False)])).astype(np.uint32)
+        r = torch.as_tensor(rows.astype(np.int64), device=dev)
+        b = rp64[r]; ln = rp64[r + 1] - b
+        off = torch.zeros(len(rows) + 1, dtype=torch.int64, device=dev); off[1:] = torch.cumsum(ln, 0)
+        idx = torch.arange(int(off[-1]), device=dev, dtype=torch.int64) - torch.repeat_interleave(off[:-1], ln) + torch.repeat_interleave(b, ln)
+        gc, gv = ccol[idx].cpu().numpy().view(np.uint32), cval[idx].cpu().numpy()
+        del crp, ccol, cval, idx
+        rp_h, col_h, val_h = rowptr.cpu().numpy().view(np.uint32), col.cpu().numpy().view(np.uint32), vals.cpu().numpy()
+        woff, wc, wv, wprod = O.fast_mxm_rows(rp_h, col_h, val_h, rows)
+        ok = bool(np.array_equal(off.cpu().numpy(), woff) and np.array_equal(gc, wc) and np.allclose(gv, wv, rtol=1e-6, atol=0.0))
+        out["parity_vs_oracle"] = (f"ok ({len(rows)} sampled rows of C — spread over the rows' lengths, the 32 longest, 200 random; {len(wc)} entries: pattern exact, values rtol 1e-6)"
+                                   if ok else "MISMATCH on the sampled rows")
+        # CPU baseline: the oracle's Gustavson rows (dense accumulator per thread) on random rows until ~8 s are spent
+        rng = np.random.default_rng(10); done_p, reps, t0 = 0, 0, time.perf_counter()
+        while reps < 40 and (reps < 1 or time.perf_counter() - t0 < 8.0):
+            rs = rng.choice(n, 4096, replace=False).astype(np.uint32)
+            done_p += int(O.fast_mxm_rows(rp_h, col_h, val_h, rs)[3].sum()) * 2          # (count pass + fill pass: every product is formed twice)
+            reps += 1
+        cpu_s = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(2.0 * done_p / cpu_s / 1e9, 3), "unit": "GFLOP/s", "cores": O.num_threads(), "kind": "port",
+                               "sample": f"{reps * 4096} random rows of the same product ({done_p} products) with oracle fast_mxm_rows_plus_times_fp64 (OpenMP, {O.num_threads()} threads, dense accumulator per thread)",
+                               "seconds_extrapolated_to_the_whole_product": round(products / (done_p / cpu_s), 2)}
+    Cm = None
+    return out
+
+
+def bench_bc(cx, scale):
+    """The batched betweenness centrality of gap/bcmark.py:16-67 (tools/bc_algorithm.py restates the driver statement for statement), ns = 4
+    sources of maximum degree on the directed R-MAT-`scale`, FP32: masked PLUS_FIRST GrB_mxm per level forwards and backwards.  The step the
+    north star's SpGEMM serves is the frontier product; the whole algorithm is timed, the forward sweep's products beside it."""
+    gb, rmat, torch, dev, np = cx.gb, cx.rmat, cx.torch, cx.dev, cx.np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bc_algorithm import bc as bc_full
+    from pygraphblas_amd import descriptor as D
+    n = 1 << scale; ns = 4
+    rowptr, col = rmat.csr_torch(scale, dev, seed=42, drop_self_loops=True)
+    nnz = int(col.numel()); vals = torch.ones(nnz, dtype=torch.float32, device=dev)
+    A = gb.Matrix.from_csr(gb.FP32, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+    AT = A.transpose()
+    deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+    sources = [int(x) for x in torch.argsort(deg, descending=True, stable=True)[:ns].cpu()]
+    bc_full(gb, sources, AT, A)                                                  # cached transposes, pool
+    times = []; sizes = []
+    for _ in range(5):
+        del sizes[:]
+        torch.cuda.synchronize(); t = time.perf_counter(); cent, depth = bc_full(gb, sources, AT, A, sizes=sizes); torch.cuda.synchronize(); times.append(time.perf_counter() - t)
+    sec = sorted(times)[2]
+    plan = gb.last_kernel_plan()
+    cv = cent.to_dense_arrays()[0]
+    # the forward sweep's products alone (frontier<!paths,replace> = frontier (+).first A per level), synchronised per level
+    paths = gb.Matrix.dense(gb.FP32, ns, n, 0); frontier = gb.Matrix.sparse(gb.FP32, ns, n)
+    for i, s in enumerate(sources):
+        paths[i, s] = 1; frontier[i, s] = 1
+    step_s = []
+    for _ in range(depth + 1):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        frontier.mxm(A, out=frontier, mask=paths, semiring=gb.FP32.PLUS_FIRST, desc=D.RC)
+        torch.cuda.synchronize(); step_s.append(time.perf_counter() - t)
+        if frontier.nvals == 0:
+            break
+        paths.assign_matrix(frontier, accum=gb.FP32.PLUS)
+    # algorithmic bytes, a lower bound for ANY implementation of the driver: every source's forward and backward sweep each read the edges
+    # leaving / entering its reached vertices once (4 B column per edge: FIRST ignores A's values), the reached vertices' path counts and
+    # dependencies (2 x 8 B each per sweep), and the centrality is written once
+    pv, pp = None, None
+    reached = np.zeros(ns, np.int64); edges = np.zeros(ns, np.int64)
+    degh = deg.cpu().numpy()
+    prp, pci, pvals = paths.to_csr()
+    for s in range(ns):
+        seg = slice(int(prp[s]), int(prp[s + 1])); hit = pci[seg][pvals[seg] != 0].astype(np.int64)
+        reached[s] = len(hit); edges[s] = int(degh[hit].sum())
+    alg = int(2 * edges.sum() * 4 + 2 * reached.sum() * 16 + n * 4)
+    out = {"workload": f"batched betweenness centrality, gap/bcmark.py:16-67, R-MAT-{scale} directed, ns = {ns} sources of maximum degree, FP32 (masked PLUS_FIRST GrB_mxm per level)",
+           "nnz": nnz, "depth": depth, "frontier_nvals": list(sizes), "seconds": round(sec, 5), "seconds_runs": [round(x, 5) for x in times], "dtype": "f32",
+           "forward_products_ms": [round(x * 1e3, 3) for x in step_s], "kernel": plan,
+           "roofline": roof(alg, sec, note="lower bound of any implementation: per source, forward and backward sweep each read the edges of the reached vertices once (4 B) and "
+                                           "their path counts / dependencies (2 x 8 B); centrality written once.  The driver's own formulation moves ns x n dense batches per level on top")}
+    if not cx.args.no_cpu_baseline:
+        from oracle import oracle as O
+        rpt, colt = AT.to_csr()[:2]
+        t = time.perf_counter()
+        want, odepth, olv = O.fast_bc(rowptr.cpu().numpy().view(np.uint32), col.cpu().numpy().view(np.uint32), rpt, colt, sources)
+        cpu_s = time.perf_counter() - t
+        ok = bool(depth == odepth and list(sizes) == list(olv) and np.allclose(cv.astype(np.float64), want, rtol=1e-4, atol=1e-3))
+        out["parity_vs_oracle"] = "ok (depth and every level's frontier size exact, centrality rtol 1e-4 vs the FP64 restatement)" if ok else f"MISMATCH (oracle depth {odepth}, levels {olv})"
+        out["cpu_baseline"] = {"seconds": round(cpu_s, 3), "cores": O.num_threads(), "kind": "port", "sample": "one pass of oracle fast_bc_batch (the same algorithm on dense ns x n batches of doubles, OpenMP)"}
     return out
 
 

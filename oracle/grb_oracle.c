@@ -508,6 +508,29 @@ int fast_bc_batch(uint32_t n, const uint32_t* rp, const uint32_t* col, const uin
   free(S); free(paths); free(f); free(g); free(fp); free(gp); free(bcu);
   return depth;
 }
+/* Rows `rows[0..ns)` of the UNMASKED product C = A (+).(x) A over PLUS_TIMES FP64 (lib.GrB_mxm with mask = NULL,
+ * pygraphblas/matrix.py:2572-2583; C API 1.3 / SURVEY.md Appendix A item 2: C(i,j) exists iff some k has A(i,k) and A(k,j) stored),
+ * Gustavson row by row with a dense accumulator, products added in ascending k.  Two calls: with out_col == NULL it fills
+ * counts[s] = entries of row rows[s] and products[s] = sum_k nnz(A(k,:)); with out_col / out_val it writes row s, columns ascending,
+ * at offsets[s].  Used by the tests and bench.py to check SAMPLED rows of a product too large for any host (A @ A on R-MAT-18:
+ * 3e9 entries), and timed as the CPU baseline of that product. */
+void fast_mxm_rows_plus_times_fp64(uint32_t n, const uint32_t* rp, const uint32_t* col, const double* val, uint32_t ns, const uint32_t* rows,
+                                   int64_t* counts, int64_t* products, const int64_t* offsets, uint32_t* out_col, double* out_val) {
+#pragma omp parallel
+  {
+    double* acc = (double*)calloc((size_t)n, 8); uint8_t* has = (uint8_t*)calloc((size_t)n, 1);
+#pragma omp for schedule(dynamic, 1)
+    for (int64_t s = 0; s < (int64_t)ns; s++) {
+      const uint32_t i = rows[s]; int64_t cnt = 0, prod = 0; uint32_t lo = n, hi = 0;
+      for (uint32_t p = rp[i]; p < rp[i + 1]; p++) { const uint32_t k = col[p]; const double a = val[p]; prod += rp[k + 1] - rp[k];
+        for (uint32_t q = rp[k]; q < rp[k + 1]; q++) { const uint32_t j = col[q]; acc[j] += a * val[q]; if (!has[j]) { has[j] = 1; cnt++; if (j < lo) lo = j; if (j > hi) hi = j; } } }
+      if (!out_col) { counts[s] = cnt; products[s] = prod; }
+      int64_t o = out_col ? offsets[s] : 0;
+      if (cnt) for (uint32_t j = lo; j <= hi; j++) if (has[j]) { if (out_col) { out_col[o] = j; out_val[o] = acc[j]; o++; } acc[j] = 0.0; has[j] = 0; }
+    }
+    free(acc); free(has);
+  }
+}
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

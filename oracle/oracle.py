@@ -195,6 +195,20 @@ def fast_masked_mxm(rowptr, col, val=None):
     return out, has
 
 
+def fast_mxm_rows(rowptr, col, val, rows):
+    """Rows `rows` of the unmasked C = A (+).(x) A (PLUS_TIMES FP64): (row pointers int64[len(rows)+1], columns uint32, values float64,
+    products per row) — columns ascending inside a row, products added in ascending k."""
+    rowptr, col, val, rows = _arr(rowptr, np.uint32), _arr(col, np.uint32), _arr(val, np.float64), _arr(rows, np.uint32)
+    n, ns = len(rowptr) - 1, len(rows)
+    counts = np.zeros(ns, np.int64); prods = np.zeros(ns, np.int64)
+    f = lib().fast_mxm_rows_plus_times_fp64
+    f(C.c_uint32(n), _p(rowptr), _p(col), _p(val), C.c_uint32(ns), _p(rows), _p(counts), _p(prods), None, None, None)
+    off = np.zeros(ns + 1, np.int64); np.cumsum(counts, out=off[1:])
+    oc = np.zeros(int(off[-1]), np.uint32); ov = np.zeros(int(off[-1]), np.float64)
+    f(C.c_uint32(n), _p(rowptr), _p(col), _p(val), C.c_uint32(ns), _p(rows), None, None, _p(off), _p(oc), _p(ov))
+    return off, oc, ov, prods
+
+
 def fast_bc(rowptr, col, rowptr_t, col_t, sources, max_levels=64):
     """gap/bcmark.py:16-67 on the directed graph A = (rowptr, col), AT = its transpose: (centrality float64[n], depth, frontier sizes)."""
     rowptr, col, rowptr_t, col_t = _arr(rowptr, np.uint32), _arr(col, np.uint32), _arr(rowptr_t, np.uint32), _arr(col_t, np.uint32)

@@ -89,8 +89,9 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
 
   bool fused_mask = false;
   if (mask_is_u) {
-    const DevCSR& R0 = useT ? mat_csc(A) : A->csr;
-    fused_mask = !push && !accum && dv.replace && type_size(u->type->code) == 1 && spmv_rowlane_applies(R0, sd, method);
+    // (the pull operand — for vxm the cached transpose, built on first need — is looked at only when the product pulls: a BFS that
+    //  stays in push for every level never pays for a transpose it does not use)
+    fused_mask = !push && !accum && dv.replace && type_size(u->type->code) == 1 && spmv_rowlane_applies(useT ? mat_csc(A) : A->csr, sd, method);
     if (!fused_mask) {
       allow_buf.alloc(mr); ubool.alloc(mr + 1);
       build_allow_and_bool(mr, u->type->code, u->dval.p, u->dpres.as<uint8_t>(), dv.mask_struct, dv.mask_comp, allow_buf.as<uint8_t>(), ubool.as<uint8_t>());
@@ -195,7 +196,16 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   // a BOOL result that replaces w: the kernel notes whether it wrote a true value, and the `q.reduce_bool()` that follows a BFS
   // level (tests/test_bfs.py loop: `while q.reduce_bool() and level <= n`) reads that word instead of scanning q
   bool any_done = false;
-  if (sd.zcode == T_BOOL && w->type->code == T_BOOL && !accum && method == SPMV_AUTO) { call.any_true = any_true_acquire(&call.any_true_tag); call.any_true_done = &any_done; }
+  bool fe_done = false; uint64_t fe_key = 0;
+  if (sd.zcode == T_BOOL && w->type->code == T_BOOL && !accum && method == SPMV_AUTO) {
+    call.any_true = any_true_acquire(&call.any_true_tag); call.any_true_done = &any_done;
+    // ... and, on a square matrix, the edges leaving the result's true entries in the row pointers the direction choice above counts in:
+    // the product after `v[q] = level` then knows its operand is too heavy for a push step without counting (SpmvCall::fe_slots)
+    if (mr == mc && (useT || A->csc.valid)) {
+      const DevCSR& P0 = useT ? A->csr : mat_csc(A);
+      if (P0.nrows == mr && P0.rowptr.serial) { call.fe_rowptr = P0.rowptr.as<uint32_t>(); fe_summary_buffers(&call.fe_slots, &call.fe_zero); call.fe_done = &fe_done; fe_key = P0.rowptr.serial; }
+    }
+  }
   const void* const tkey = tval.p;
   if (push) {
     // push walks rows of M^T:  M^T = useT ? A : A^T
@@ -253,7 +263,7 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   // next sweep measures the range again.
   const bool accum_selects = accum && check_obj(accum) && (accum->opcode == B_MIN || accum->opcode == B_MAX || accum->opcode == B_FIRST || accum->opcode == B_SECOND || accum->opcode == B_ANY);
   if (big_holes && w->type->code == sd.zcode && (!accum || w_was_empty || (w_is_u && accum_selects))) w->abs_bound = big_uabs + big_aabs;
-  if (any_done) any_true_written(w->lazy == 0 && w->dev_valid && w->dval.p == tkey ? w : nullptr, tkey, call.any_true_tag);       // (adopted as they are: w is exactly T)
+  if (any_done) any_true_written(w->lazy == 0 && w->dev_valid && w->dval.p == tkey ? w : nullptr, tkey, call.any_true_tag, fe_done ? fe_key : 0);       // (adopted as they are: w is exactly T)
 }
 
 extern "C" {

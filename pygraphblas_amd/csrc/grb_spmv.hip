@@ -101,16 +101,17 @@ void spmspv_push(const SpmvCall& c, const SemiringDesc& d, uint64_t u_nvals) {
   DevCSR& M = *c.M; const uint64_t nu = M.nrows, nout = M.ncols;
   auto grid_of = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 4096) b = 4096; return (unsigned)b; };
   DevBuf flags, pos, fidx((u_nvals + 1) * 4), longlist((u_nvals + 2) * 4);
-  GRB_HIP(hipMemsetAsync(longlist.p, 0, 4, stream()));
   if (c.small_idx && c.small_n == u_nvals && u_nvals <= 64) {
-    write_small_list((uint32_t)u_nvals, c.small_idx, fidx.as<uint32_t>());      // the frontier is known on the host: its list travels as kernel arguments
+    // the frontier is known on the host: its list travels as kernel arguments of run_push's first launch (k_push_init), which also clears
+    // the presence bytes and the hub-row counter
   } else {
+    GRB_HIP(hipMemsetAsync(longlist.p, 0, 4, stream()));
     flags.alloc(nu * 4 + 4); pos.alloc(nu * 4 + 4);
     hipLaunchKernelGGL(k_flag_to_u32, dim3(grid_of(nu)), dim3(256), 0, stream(), c.upres, nu, flags.as<uint32_t>());
     exclusive_scan_u32(flags.as<uint32_t>(), pos.as<uint32_t>(), nu);
     hipLaunchKernelGGL(k_compact_idx, dim3(grid_of(nu)), dim3(256), 0, stream(), c.upres, pos.as<uint32_t>(), nu, fidx.as<uint32_t>());
+    GRB_HIP(hipMemsetAsync(c.tpres, 0, nout ? nout : 1, stream()));
   }
-  GRB_HIP(hipMemsetAsync(c.tpres, 0, nout ? nout : 1, stream()));
   dispatch_type(d.zcode, [&]<class T>() { run_push<T>(c, d, fidx.as<uint32_t>(), u_nvals, longlist.as<uint32_t>()); });
   GRB_HIP(hipGetLastError());
 }

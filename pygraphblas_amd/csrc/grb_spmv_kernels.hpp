@@ -50,7 +50,16 @@ template <class T> struct SpmvKArgs {
   uint32_t nrows;
   uint32_t* any_true; uint32_t any_true_tag;      // BOOL results only (nullptr otherwise): set to the tag when an entry with value true is written
   const uint8_t* fm_val; uint32_t fm_flags;       // SpmvCall::fm_val / fm_flags (row-lane kernel, FUSED instantiation)
+  const uint32_t* fe_rowptr; unsigned long long* fe_slots; unsigned long long* fe_zero;      // SpmvCall::fe_* (row-lane kernel)
 };
+// a wave's share of the result's summary (SpmvCall::fe_slots): edge sum and entry count of the true entries it wrote
+__device__ __forceinline__ void fe_wave_add(unsigned long long* __restrict__ slots, unsigned long long fe, unsigned long long cnt, uint64_t wave) {
+  cnt = wave_reduce_add_u64(cnt);
+  if (cnt) {                                                   // (wave-uniform)
+    fe = wave_reduce_add_u64(fe);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&slots[2 * (wave & 63)], fe); atomicAdd(&slots[2 * (wave & 63) + 1], cnt); }
+  }
+}
 template <class T> __device__ __forceinline__ bool spmv_truthy(T v) { if constexpr (is_bool<T>::value) return v.v != 0; else return v != T(); }
 
 // ---- kernel A ---------------------------------------------------------------------------------------------------
@@ -241,63 +250,106 @@ __global__ __launch_bounds__(256) void k_spmv_rowgroup(const SpmvKArgs<T> a, con
 // entries; the rows that are neither finished nor at their monoid's terminal value by then (hub rows) are completed by the
 // whole wave, 64 entries per step, starting from the lane's partial result.
 constexpr uint32_t SPMV_LANE_E = 8;
+constexpr int SPMV_LANE_K = 4;
+// Round 5: a lane owns SPMV_LANE_K rows at once (rows r, r + 64, r + 128, r + 192 of the wave's 256).  A row is a chain of four dependent
+// loads — mask byte / row pointers, column, operand byte — and with one row per lane a wave had 64 chains in flight and nothing to do
+// while they were: the level-2 pull of the R-MAT-22 BFS took 54 us for 64 MB, the late levels 17 us each for a handful of vertices
+// (65 536 waves of one round trip after the other).  With K rows the K loads of every stage are issued together: all of them are
+// unconditional (an idle slot reads entry 0 of its array and drops it), so they stand in one basic block.
 template <class T, class SR, bool U_FULL, bool FUSED = false>
 __global__ __launch_bounds__(256) void k_spmv_rowlane(const SpmvKArgs<T> a, const SR sr) {
+  constexpr int K = SPMV_LANE_K;
   const int lane = threadIdx.x & 63;
   const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = (uint64_t)gridDim.x * 4;
   const bool use_a = sr.uses_a(), use_u = sr.uses_u();
-  const uint64_t nround = ((uint64_t)a.nrows + 63) / 64 * 64;
-  for (uint64_t base = wave * 64; base < nround; base += nwaves * 64) {
-    const uint64_t r = base + lane;
-    const bool valid = r < a.nrows;
-    bool allowed;
-    if constexpr (FUSED) allowed = valid && ((a.upres[r] != 0 && ((a.fm_flags & 1u) || a.fm_val[r] != 0)) != ((a.fm_flags & 2u) != 0));     // the mask vector itself
-    else allowed = valid && (!a.allow || a.allow[r]);
-    // operand value at column c: the vector's own byte as BOOL when fused
-    auto uat = [&](uint32_t c) __attribute__((always_inline)) -> T { if constexpr (FUSED) { T t; t = T(a.fm_val[c] != 0); return t; } else return a.uval[c]; };
-    // (the row pointers are fetched whether or not the row is allowed: one dependent round trip less per wave — the late levels of a BFS,
-    //  where half of the 4 M rows are empty and unvisited, are a chain of such trips and little else)
-    uint32_t pb = 0, pe = 0;
-    if (FUSED ? valid : allowed) { pb = a.rowptr[r]; pe = a.rowptr[r + 1]; }
-    T acc = sr.identity; bool has = false, done = !allowed;
-    if (allowed) {
-      const uint32_t e = pe - pb > SPMV_LANE_E ? pb + SPMV_LANE_E : pe;
-      for (uint32_t p = pb; p < e; p++) {
-        const uint32_t c = a.col[p];
-        bool pr = true;
-        if constexpr (!U_FULL) pr = a.upres[c] != 0;
-        if (pr) {
-          const T m = sr.mult(use_a ? a.aval[p] : T(), use_u ? uat(c) : T());
-          acc = has ? sr.add(acc, m) : m; has = true;
-          if (sr.has_terminal && memcmp_eq(acc, sr.terminal)) { done = true; break; }
-        }
-      }
-      if (pe - pb <= SPMV_LANE_E) done = true;
+  const uint64_t span = 64ull * K, nround = ((uint64_t)a.nrows + span - 1) / span * span;
+  unsigned long long fe = 0, fcnt = 0;
+  if (a.fe_zero && blockIdx.x == 0 && threadIdx.x < 128) a.fe_zero[threadIdx.x] = 0;          // the other buffer of the pair: ready for the product after this one
+  for (uint64_t base = wave * span; base < nround; base += nwaves * span) {
+    uint64_t r[K]; bool valid[K], allowed[K], has[K], done[K]; uint32_t pb[K], pe[K]; T acc[K];
+    uint8_t m0[K], m1[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      r[k] = base + 64ull * k + lane; valid[k] = r[k] < a.nrows;
+      const uint64_t rr = valid[k] ? r[k] : 0;
+      if constexpr (FUSED) { m0[k] = a.upres[rr]; m1[k] = a.fm_val[rr]; }                       // the mask vector itself
+      else { m0[k] = a.allow ? a.allow[rr] : (uint8_t)1; m1[k] = 1; }
+      // (the row pointers are fetched whether or not the row is allowed: one dependent round trip less — the late levels of a BFS,
+      //  where half of the 4 M rows are empty and unvisited, are a chain of such trips and little else)
+      pb[k] = a.rowptr[rr]; pe[k] = a.rowptr[rr + 1];
     }
-    // the unfinished rows, one after the other, by the whole wave
-    unsigned long long todo = __ballot(allowed && !done);
-    while (todo) {
-      const int L = __builtin_ctzll(todo); todo &= todo - 1;
-      const uint32_t qb = (uint32_t)__shfl((int)pb, L, 64) + SPMV_LANE_E, qe = (uint32_t)__shfl((int)pe, L, 64);
-      T part = sr.identity; bool phas = false;
-      for (uint32_t p0 = qb; p0 < qe; p0 += 64) {
-        const uint32_t p = p0 + lane;
-        if (p < qe) {
-          const uint32_t c = a.col[p];
-          bool pr = true;
-          if constexpr (!U_FULL) pr = a.upres[c] != 0;
-          if (pr) { const T m = sr.mult(use_a ? a.aval[p] : T(), use_u ? uat(c) : T()); part = phas ? sr.add(part, m) : m; phas = true; }
-        }
-        if (sr.has_terminal && __ballot(phas && memcmp_eq(part, sr.terminal))) break;      // some lane is at the terminal value: so is the row
-      }
-      const unsigned long long hb = __ballot(phas);
-      // (ANY keeps "a" value: the tree below would also consider the identity of the lanes that saw nothing — take a real one)
-      const T red = sr.add_op() == B_ANY ? shfl_t<T>(part, hb ? __builtin_ctzll(hb) : 0) : wave_reduce_op<T, false>(sr.add_op(), phas ? part : sr.identity);
-      if (lane == L && hb) { acc = has ? sr.add(acc, red) : red; has = true; }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      if constexpr (FUSED) allowed[k] = valid[k] && ((m0[k] != 0 && ((a.fm_flags & 1u) || m1[k] != 0)) != ((a.fm_flags & 2u) != 0));
+      else allowed[k] = valid[k] && m0[k] != 0;
+      acc[k] = sr.identity; has[k] = false; done[k] = !allowed[k] || pe[k] == pb[k];
     }
-    if (valid) { if (allowed && has) a.tval[r] = acc; a.tpres[r] = (allowed && has) ? 1 : 0; }
-    if (a.any_true) { if (__ballot(valid && allowed && has && spmv_truthy<T>(acc)) && lane == 0) *a.any_true = a.any_true_tag; }      // (same value from every wave: a benign race)
+    // the first SPMV_LANE_E entries of the K rows, entry by entry
+    for (uint32_t e = 0; e < SPMV_LANE_E; e++) {
+      bool act[K]; bool any = false;
+#pragma unroll
+      for (int k = 0; k < K; k++) { act[k] = !done[k] && pb[k] + e < pe[k]; any = any || act[k]; }
+      if (!__ballot(any)) break;
+      uint32_t c[K];
+#pragma unroll
+      for (int k = 0; k < K; k++) c[k] = a.col[act[k] ? pb[k] + e : 0u];                         // (some lane is active: the matrix has an entry 0)
+      uint8_t pr[K]; T uv[K], av[K];
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        if constexpr (U_FULL) pr[k] = 1; else pr[k] = a.upres[c[k]];
+        if constexpr (FUSED) { T t; t = T(a.fm_val[c[k]] != 0); uv[k] = t; }                       // the vector's own byte as BOOL
+        else uv[k] = use_u ? a.uval[c[k]] : T();
+        av[k] = use_a ? a.aval[act[k] ? pb[k] + e : 0u] : T();
+      }
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        if (act[k] && pr[k]) {
+          const T m = sr.mult(av[k], uv[k]);
+          acc[k] = has[k] ? sr.add(acc[k], m) : m; has[k] = true;
+          if (sr.has_terminal && memcmp_eq(acc[k], sr.terminal)) done[k] = true;
+        }
+        if (pb[k] + e + 1 >= pe[k]) done[k] = true;                                                // the row is exhausted
+      }
+    }
+    // the unfinished rows (hub rows), one after the other, by the whole wave
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      unsigned long long todo = __ballot(!done[k]);
+      while (todo) {
+        const int L = __builtin_ctzll(todo); todo &= todo - 1;
+        const uint32_t qb = (uint32_t)__shfl((int)pb[k], L, 64) + SPMV_LANE_E, qe = (uint32_t)__shfl((int)pe[k], L, 64);
+        T part = sr.identity; bool phas = false;
+        for (uint32_t p0 = qb; p0 < qe; p0 += 64) {
+          const uint32_t p = p0 + lane;
+          if (p < qe) {
+            const uint32_t c = a.col[p];
+            bool pr = true;
+            if constexpr (!U_FULL) pr = a.upres[c] != 0;
+            if (pr) {
+              T u1; if constexpr (FUSED) { u1 = T(a.fm_val[c] != 0); } else { u1 = use_u ? a.uval[c] : T(); }
+              const T m = sr.mult(use_a ? a.aval[p] : T(), u1); part = phas ? sr.add(part, m) : m; phas = true;
+            }
+          }
+          if (sr.has_terminal && __ballot(phas && memcmp_eq(part, sr.terminal))) break;      // some lane is at the terminal value: so is the row
+        }
+        const unsigned long long hb = __ballot(phas);
+        // (ANY keeps "a" value: the tree below would also consider the identity of the lanes that saw nothing — take a real one)
+        const T red = sr.add_op() == B_ANY ? shfl_t<T>(part, hb ? __builtin_ctzll(hb) : 0) : wave_reduce_op<T, false>(sr.add_op(), phas ? part : sr.identity);
+        if (lane == L && hb) { acc[k] = has[k] ? sr.add(acc[k], red) : red; has[k] = true; }
+      }
+    }
+    bool wrote_true = false;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const bool w = allowed[k] && has[k];
+      if (valid[k]) { if (w) a.tval[r[k]] = acc[k]; a.tpres[r[k]] = w ? 1 : 0; }
+      const bool tr = w && spmv_truthy<T>(acc[k]);
+      wrote_true = wrote_true || tr;
+      if (a.fe_slots && tr) { fe += a.fe_rowptr[r[k] + 1] - a.fe_rowptr[r[k]]; fcnt++; }
+    }
+    if (a.any_true) { if (__ballot(wrote_true) && lane == 0) *a.any_true = a.any_true_tag; }      // (same value from every wave: a benign race)
   }
+  if (a.fe_slots) fe_wave_add(a.fe_slots, fe, fcnt, wave);
 }
 
 // ---- kernel C: push.  t is pre-initialised (tpres = 0); entries are claimed with tpres CAS-free flags ---------------
@@ -336,12 +388,15 @@ template <class T, class SR>
 __global__ __launch_bounds__(256) void k_spmspv_push(const uint32_t* __restrict__ fidx, uint32_t nf, const uint32_t* __restrict__ rowptr,
                                                      const uint32_t* __restrict__ col, const T* __restrict__ aval, const T* __restrict__ uval,
                                                      const uint8_t* __restrict__ allow, T* __restrict__ tval, uint8_t* __restrict__ tpres,
-                                                     uint32_t* __restrict__ longlist, const SR sr, uint32_t* __restrict__ any_true = nullptr, const uint32_t any_tag = 0) {
+                                                     uint32_t* __restrict__ longlist, const SR sr, uint32_t* __restrict__ any_true = nullptr, const uint32_t any_tag = 0,
+                                                     unsigned long long* __restrict__ fe_slots = nullptr, unsigned long long* __restrict__ fe_zero = nullptr) {
   // one wave per frontier entry: its row of M^T (= CSR row of the stored matrix) is streamed coalesced
   const int lane = threadIdx.x & 63;
   const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6;
   const uint64_t nwaves = (uint64_t)gridDim.x * 4;
   const bool use_a = sr.uses_a(), use_u = sr.uses_u();
+  unsigned long long fe = 0, fcnt = 0;                                       // (fe_slots: nf == 1 — SpmvCall::fe_slots)
+  if (fe_zero && blockIdx.x == 0 && threadIdx.x < 128) fe_zero[threadIdx.x] = 0;
   for (uint64_t f = wave; f < nf; f += nwaves) {
     const uint32_t i = fidx[f];
     const T ui = use_u ? uval[i] : T();
@@ -357,8 +412,10 @@ __global__ __launch_bounds__(256) void k_spmspv_push(const uint32_t* __restrict_
       atomic_combine<T>(sr.add_op(), &tval[j], m);
       tpres[j] = 1;
       if (any_true && spmv_truthy<T>(m)) *any_true = any_tag;             // BOOL monoids of the push path only OR values in: a true product is a true entry
+      if (fe_slots && spmv_truthy<T>(m)) { fe += rowptr[j + 1] - rowptr[j]; fcnt++; }
     }
   }
+  if (fe_slots) fe_wave_add(fe_slots, fe, fcnt, wave);
 }
 
 // frontier rows longer than PUSH_LONG: every block of the grid takes a slice of each (the list is short: hubs only)
@@ -366,9 +423,10 @@ template <class T, class SR>
 __global__ __launch_bounds__(256) void k_spmspv_push_long(const uint32_t* __restrict__ longlist, const uint32_t* __restrict__ rowptr,
                                                           const uint32_t* __restrict__ col, const T* __restrict__ aval, const T* __restrict__ uval,
                                                           const uint8_t* __restrict__ allow, T* __restrict__ tval, uint8_t* __restrict__ tpres, const SR sr,
-                                                          uint32_t* __restrict__ any_true = nullptr, const uint32_t any_tag = 0) {
+                                                          uint32_t* __restrict__ any_true = nullptr, const uint32_t any_tag = 0, unsigned long long* __restrict__ fe_slots = nullptr) {
   const uint32_t nl = longlist[0];
   const bool use_a = sr.uses_a(), use_u = sr.uses_u();
+  unsigned long long fe = 0, fcnt = 0;
   // few long rows: every block takes a slice of each; many: one block per row
   const bool split = nl < gridDim.x / 8;
   for (uint32_t l = split ? 0 : blockIdx.x; l < nl; l += split ? 1 : gridDim.x) {
@@ -382,8 +440,10 @@ __global__ __launch_bounds__(256) void k_spmspv_push_long(const uint32_t* __rest
       atomic_combine<T>(sr.add_op(), &tval[j], m);
       tpres[j] = 1;
       if (any_true && spmv_truthy<T>(m)) *any_true = any_tag;
+      if (fe_slots && spmv_truthy<T>(m)) { fe += rowptr[j + 1] - rowptr[j]; fcnt++; }
     }
   }
+  if (fe_slots) fe_wave_add(fe_slots, fe, fcnt, (blockIdx.x * 256ull + threadIdx.x) >> 6);
 }
 
 // ---- host drivers ---------------------------------------------------------------------------------------------------------
@@ -415,6 +475,7 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
     SpmvKArgs<T> a{};
     a.rowptr = M.rowptr.as<uint32_t>(); a.col = M.col.as<uint32_t>(); a.aval = (const T*)c.aval;
     a.uval = (const T*)c.uval; a.upres = c.upres; a.allow = c.allow; a.tval = (T*)c.tval; a.tpres = c.tpres; a.nrows = M.nrows; a.any_true = nullptr;
+    a.fe_rowptr = nullptr; a.fe_slots = nullptr; a.fe_zero = nullptr;
     const bool full = c.upres == nullptr;
     // masked pull with a terminal monoid (BFS) -> row-group kernel with early exit; otherwise the row-block kernel
     const bool prefer_rowgroup = c.method == SPMV_ROWGROUP || (c.method == SPMV_AUTO && (c.allow || c.fm_val) && d.has_terminal);
@@ -429,8 +490,11 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
       else hipLaunchKernelGGL((k_spmv_rowgroup<T, SR, GG, false>), dim3((unsigned)nb), dim3(256), 0, stream(), a, sr);
       static const bool no_lane = wp_env("GRB_MI355X_NO_ROWLANE", 0) != 0;      // measurement hook
       if (G == 8 && !no_lane && c.method == SPMV_AUTO) {                          // short rows on average: a lane per row (kernel B')
-        uint64_t nbl = ((uint64_t)M.nrows + 255) / 256; if (nbl < 1) nbl = 1; if (nbl > 65536) nbl = 65536;
-        if (c.any_true && c.any_true_done && is_bool<T>::value) { a.any_true = c.any_true; a.any_true_tag = c.any_true_tag; *c.any_true_done = true; }
+        uint64_t nbl = ((uint64_t)M.nrows + 256 * SPMV_LANE_K - 1) / (256 * SPMV_LANE_K); if (nbl < 1) nbl = 1; if (nbl > 65536) nbl = 65536;
+        if (c.any_true && c.any_true_done && is_bool<T>::value) {
+          a.any_true = c.any_true; a.any_true_tag = c.any_true_tag; *c.any_true_done = true;
+          if (c.fe_slots && c.fe_done && c.fe_rowptr) { a.fe_rowptr = c.fe_rowptr; a.fe_slots = c.fe_slots; a.fe_zero = c.fe_zero; *c.fe_done = true; }
+        }
         if constexpr (is_bool<T>::value) {
           if (c.fm_val) {                                                       // the mask is the operand itself: no allow / BOOL-value arrays were made
             a.fm_val = c.fm_val; a.fm_flags = c.fm_flags;
@@ -516,19 +580,41 @@ template <class T> __global__ void k_fill(T* p, uint64_t n, T v) {
   for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) p[i] = v;
 }
 
+// zero fill of the presence bytes, identity fill of the values (16 positions per thread), the operand's list and the cleared hub-row counter: one launch
+struct SmallList64 { uint32_t n; uint32_t idx[64]; };
+template <class T> __global__ void k_push_init(T* __restrict__ tval, uint8_t* __restrict__ tpres, uint64_t n, T ident, const SmallList64 sl, uint32_t* __restrict__ fidx, uint32_t* __restrict__ longlist) {
+  if (blockIdx.x == 0) { if (threadIdx.x < sl.n) fidx[threadIdx.x] = sl.idx[threadIdx.x]; if (threadIdx.x == 64) longlist[0] = 0; }
+  const uint64_t n16 = n / 16;
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += gridDim.x * 256ull) {
+    ((uint4*)tpres)[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 16; q++) tval[i * 16 + q] = ident;
+  }
+  for (uint64_t i = n16 * 16 + blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) { tpres[i] = 0; tval[i] = ident; }
+}
 template <class T> void run_push(const SpmvCall& c, const SemiringDesc& d, const uint32_t* fidx, uint64_t u_nvals, uint32_t* longlist) {
   DevCSR& M = *c.M; const uint64_t nout = M.ncols;
+  uint32_t* const fidx_w = const_cast<uint32_t*>(fidx);
   auto grid_of = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 4096) b = 4096; return (unsigned)b; };
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;
-    if (nout) hipLaunchKernelGGL((k_fill<T>), dim3(grid_of(nout)), dim3(256), 0, stream(), (T*)c.tval, nout, sr.identity);
+    // the accumulator starts at the identity with no entry; with the operand's list known on the host (<= 64 entries, SpmvCall::small_idx) the
+    // same launch writes the list and clears the hub-row counter (round 5: six launches -> three for the first level of a BFS)
+    if (c.small_idx && c.small_n == u_nvals && u_nvals <= 64) {
+      SmallList64 sl; sl.n = (uint32_t)u_nvals; for (uint32_t q = 0; q < sl.n; q++) sl.idx[q] = c.small_idx[q];
+      hipLaunchKernelGGL((k_push_init<T>), dim3(grid_of(nout / 16 + 1)), dim3(256), 0, stream(), (T*)c.tval, c.tpres, nout, sr.identity, sl, (uint32_t*)fidx_w, longlist);
+    } else if (nout) hipLaunchKernelGGL((k_fill<T>), dim3(grid_of(nout)), dim3(256), 0, stream(), (T*)c.tval, nout, sr.identity);
     uint64_t nb = (u_nvals + 3) / 4; if (nb < 1) nb = 1; if (nb > 16384) nb = 16384;
-    uint32_t* any_true = nullptr;
-    if (c.any_true && c.any_true_done && is_bool<T>::value && (sr.add_op() == B_LOR || sr.add_op() == B_PLUS || sr.add_op() == B_MAX)) { any_true = c.any_true; *c.any_true_done = true; }
+    uint32_t* any_true = nullptr; unsigned long long* fe_slots = nullptr; unsigned long long* fe_zero = nullptr;
+    if (c.any_true && c.any_true_done && is_bool<T>::value && (sr.add_op() == B_LOR || sr.add_op() == B_PLUS || sr.add_op() == B_MAX)) {
+      any_true = c.any_true; *c.any_true_done = true;
+      // one operand entry: the columns of its row are distinct, so the true entries written and the edges leaving them are counted exactly
+      if (u_nvals == 1 && c.fe_slots && c.fe_done && c.fe_rowptr == M.rowptr.as<uint32_t>()) { fe_slots = c.fe_slots; fe_zero = c.fe_zero; *c.fe_done = true; }
+    }
     hipLaunchKernelGGL((k_spmspv_push<T, SR>), dim3((unsigned)nb), dim3(256), 0, stream(), fidx, (uint32_t)u_nvals,
-                       M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(), (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, longlist, sr, any_true, c.any_true_tag);
+                       M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(), (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, longlist, sr, any_true, c.any_true_tag, fe_slots, fe_zero);
     hipLaunchKernelGGL((k_spmspv_push_long<T, SR>), dim3(1024), dim3(256), 0, stream(), longlist, M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(),
-                       (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, sr, any_true, c.any_true_tag);
+                       (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, sr, any_true, c.any_true_tag, fe_slots);
     g_last_plan += std::string("k_spmspv_push<") + (sr.is_static ? "static> " : "dynamic> ");
   });
 }

@@ -5,6 +5,7 @@ rtol 1e-6 otherwise.  Covers what the reference's tests pin for this path (tests
 structural / complemented), replace, T0/T1, output aliasing an input, typecasts, empty operands,
 plus the triangle-count workload of BASELINE.json configs[3] at small scale.
 """
+import ctypes as C
 import itertools
 
 import numpy as np
@@ -387,3 +388,64 @@ def test_unmasked_product_rmat18_by_its_row_sums_and_entry_count(gpu, monkeypatc
     CP = P.mxm(P, semiring=gb.BOOL.LOR_LAND)
     assert CP.nvals == nv and nv > 2 * 10**9
     assert CP.reduce_bool(gb.BOOL.LAND_MONOID)
+
+
+def gather_rows_from_device(torch, crp, ccol, cval, rows):
+    """Rows `rows` of a CSR held in HBM as torch tensors (u32 bit patterns in int32 tensors) -> host (offsets int64, columns uint32, values)."""
+    r = torch.as_tensor(rows, dtype=torch.int64, device=crp.device)
+    rp = crp.to(torch.int64) & 0xFFFFFFFF
+    b, e = rp[r], rp[r + 1]
+    ln = e - b
+    off = torch.zeros(len(rows) + 1, dtype=torch.int64, device=crp.device); off[1:] = torch.cumsum(ln, 0)
+    tot = int(off[-1])
+    idx = torch.arange(tot, device=crp.device, dtype=torch.int64) - torch.repeat_interleave(off[:-1], ln) + torch.repeat_interleave(b, ln)
+    return off.cpu().numpy(), ccol[idx].cpu().numpy().view(np.uint32), cval[idx].cpu().numpy()
+
+
+def stratified_rows(lens, k_even, k_top, k_random, rng):
+    """Row sample across every numeric bin of the two-pass product: evenly spaced in the order of the result rows' lengths (short table
+    rows ... rows beyond the tables), the longest rows (hubs), and uniformly random ones."""
+    order = np.argsort(lens, kind="stable")
+    order = order[lens[order] > 0]
+    pick = set(order[np.linspace(0, len(order) - 1, k_even).astype(np.int64)].tolist())
+    pick.update(order[-k_top:].tolist())
+    pick.update(rng.choice(len(lens), k_random, replace=False).tolist())
+    return np.array(sorted(pick), dtype=np.uint32)
+
+
+def test_unmasked_product_rmat18_sampled_rows_against_the_oracle(gpu, monkeypatch):
+    """A @ A on the symmetric R-MAT-18 at the size it is timed (9.5e9 products, 3.0e9 entries; lib.GrB_mxm with mask = NULL,
+    pygraphblas/matrix.py:2572-2583), checked against the ORACLE on > 2 000 sampled rows: rows spread evenly over the order of the result
+    rows' lengths (every numeric bin of grb_spgemm_hash.hpp: the 256 / 2048 / 8192-slot tables and the dense-accumulator path that
+    carries nearly all products), the 64 longest rows (hubs) and random ones — pattern exact, values to 1e-6 relative (north_star)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    S = 18; n = 1 << S
+    rowptr, col = rmat.csr_torch(S, dev, seed=42, symmetric=True, drop_self_loops=True)
+    nnz = int(col.numel())
+    g = torch.Generator(device="cpu"); g.manual_seed(5)
+    vals = (torch.rand(nnz, generator=g, dtype=torch.float64) + 0.5).to(dev)
+    A = gb.Matrix.from_csr(gb.FP64, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+    monkeypatch.setenv("GRB_MI355X_SPGEMM", "hash")
+    Cm = A.mxm(A, semiring=gb.FP64.PLUS_TIMES)
+    plan = gb.last_kernel_plan()
+    num = [int(x) for x in plan.split("numeric bins ")[1].split()[0].split("/")]
+    assert "spgemm_hash" in plan and num[3] > 100000, plan
+    nv = Cm.nvals
+    assert 2 * 10**9 < nv < 2**32
+    crp = torch.empty(n + 1, dtype=torch.int32, device=dev); ccol = torch.empty(nv, dtype=torch.int32, device=dev); cval = torch.empty(nv, dtype=torch.float64, device=dev)
+    gb.base.check(gb.lib.GrBX_Matrix_export_CSR(Cm._h, C.c_void_p(crp.data_ptr()), C.c_void_p(ccol.data_ptr()), C.c_void_p(cval.data_ptr()), C.c_int(1)))
+    del Cm
+    lens = np.diff((crp.to(torch.int64) & 0xFFFFFFFF).cpu().numpy())
+    rows = stratified_rows(lens, 1500, 64, 600, np.random.default_rng(7))
+    assert len(rows) >= 2000
+    # every numeric bin is in the sample: table rows of <= 128 / <= 1024 / <= 4096 entries and rows beyond the tables
+    sl = lens[rows]
+    assert (sl <= 128).any() and ((sl > 128) & (sl <= 1024)).any() and ((sl > 1024) & (sl <= 4096)).any() and (sl > 4096).sum() > 500
+    off, gc, gv = gather_rows_from_device(torch, crp, ccol, cval, rows)
+    del crp, ccol, cval
+    rp_h, col_h, val_h = rowptr.cpu().numpy().view(np.uint32), col.cpu().numpy().view(np.uint32), vals.cpu().numpy()
+    woff, wc, wv, _ = O.fast_mxm_rows(rp_h, col_h, val_h, rows)
+    assert np.array_equal(off, woff), "row lengths differ"
+    assert np.array_equal(gc, wc), "pattern differs"
+    assert np.allclose(gv, wv, rtol=1e-6, atol=0.0), float(np.abs(gv / wv - 1).max())

@@ -229,3 +229,29 @@ def test_batched_bc_fast_path_matches_networkx():
     w = np.array([want[v] for v in others])
     assert depth >= 3 and len(sizes) == depth and all(x > 0 for x in sizes) and w.max() > 1.0
     assert np.allclose(cent[others], w, rtol=1e-9, atol=1e-9), np.abs(cent[others] - w).max()
+
+
+def test_sampled_rows_of_the_unmasked_product_fast_path_matches_generic_and_scipy():
+    """fast_mxm_rows (the checker of sampled rows of A @ A at R-MAT-18 and bench.py's `aa` CPU baseline) against the generic restatement
+    and scipy on a small R-MAT: same rows, same pattern (stored zeros included: values of +-1 cancel), values exact on integers."""
+    rp, col = rmat.csr_numpy(9, seed=3, symmetric=True, drop_self_loops=True)
+    n = len(rp) - 1
+    rng = np.random.default_rng(11)
+    val = rng.choice([-1.0, 1.0, 2.0], len(col))
+    rows = np.unique(rng.integers(0, n, 150)).astype(np.uint32)
+    off, oc, ov, prods = O.fast_mxm_rows(rp, col, val, rows)
+    I = np.repeat(np.arange(n), np.diff(rp.astype(np.int64)))
+    A = O.Tuples("FP64", n, n, I, col, val)
+    full = O.mxm(O.Tuples("FP64", n, n), A, A, "PLUS", "TIMES", "FP64").sorted()
+    crp = np.zeros(n + 1, np.int64); np.cumsum(np.bincount(full.I.astype(np.int64), minlength=n), out=crp[1:])
+    sa = sp.csr_matrix((val, col.astype(np.int64), rp.astype(np.int64)), shape=(n, n)); ss = (sa @ sa).toarray()
+    deg = np.diff(rp.astype(np.int64))
+    cancelled = 0
+    for s, i in enumerate(rows.tolist()):
+        b, e = crp[i], crp[i + 1]
+        assert np.array_equal(oc[off[s]:off[s + 1]], full.J[b:e].astype(np.uint32)), i
+        assert np.array_equal(ov[off[s]:off[s + 1]], full.X[b:e]), i
+        assert np.array_equal(ss[i, oc[off[s]:off[s + 1]].astype(np.int64)], ov[off[s]:off[s + 1]])
+        assert prods[s] == deg[col[rp[i]:rp[i + 1]].astype(np.int64)].sum()
+        cancelled += int((ov[off[s]:off[s + 1]] == 0).sum())
+    assert cancelled > 0            # an entry whose products cancel is still an entry (SURVEY.md Appendix A item 2)
