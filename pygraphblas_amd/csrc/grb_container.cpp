@@ -146,30 +146,30 @@ void vec_host_assemble(GrB_Vector v) {
 // One device word per thread.  Every product brings a fresh non-zero tag and its kernels store that tag, so the word never has
 // to be cleared: it answers "true" for the vector that holds the tag it currently shows, and only the latest product's vector
 // may ask (GrB_Vector_reduce_BOOL with LOR then reads four bytes instead of launching a kernel over the vector).
-// Round 5: behind the word, two buffers of 64 (edge sum, entry count) pairs — the summary of the result's true entries that the kernels of
-// SpmvCall::fe_slots add to.  A product that fills one clears the other for its successor, so neither is ever cleared by a launch of its own;
-// the parity flips only when a product really used its buffer.
+// Round 5: the summary of a BOOL result's true entries (SpmvCall::fe_host) — every workgroup of the product stores its (edge sum, entry count),
+// tagged, into its own pair of page-locked HOST words, and the lookup spins until all pairs carry the product's tag: no copy, no stream
+// synchronisation.
 namespace {
-constexpr size_t ANY_WORD_BYTES = 64, FE_BUF_BYTES = 64 * 2 * 8;
-struct AnyTrue { DevBuf word; GrB_Vector owner = nullptr; uint32_t tag = 0; int fe_par = 0; bool fe_has = false; int fe_read_par = 0; uint64_t fe_key = 0; };
+constexpr size_t FE_HOST_PAIRS = 2048;      // (grb_spmv_kernels.hpp: FE_MAX_BLOCKS)
+struct AnyTrue { DevBuf word; GrB_Vector owner = nullptr; uint32_t tag = 0; bool fe_has = false; uint64_t fe_key = 0; uint32_t fe_nblocks = 0; unsigned long long* host = nullptr; unsigned long long* host_dev = nullptr; };
 thread_local AnyTrue t_any;
 }
 uint32_t* any_true_acquire(uint32_t* tag) {
   AnyTrue& s = t_any;
-  if (!s.word.p) { s.word.alloc(ANY_WORD_BYTES + 2 * FE_BUF_BYTES); GRB_HIP(hipMemsetAsync(s.word.p, 0, ANY_WORD_BYTES + 2 * FE_BUF_BYTES, stream())); }
-  if (++s.tag == 0) s.tag = 1;            // (a wrap after 2^32 products could meet a stale equal tag only if the word was last written 2^32 products ago)
+  if (!s.word.p) {
+    s.word.alloc(64); GRB_HIP(hipMemsetAsync(s.word.p, 0, 64, stream()));
+    void* h = nullptr; GRB_HIP(hipHostMalloc(&h, FE_HOST_PAIRS * 8, hipHostMallocMapped | hipHostMallocCoherent)); memset(h, 0, FE_HOST_PAIRS * 8); s.host = (unsigned long long*)h;      // (lives as long as the thread's pinned scratch: never freed)
+    void* dp = nullptr; if (hipHostGetDevicePointer(&dp, h, 0) != hipSuccess) { (void)hipGetLastError(); dp = h; }
+    s.host_dev = (unsigned long long*)dp;
+  }
+  if ((++s.tag & 0xFFFFFFu) == 0) s.tag++;            // (the low 24 bits travel in the host words of the summary: never zero)
   s.owner = nullptr; s.fe_has = false; *tag = s.tag;
   return s.word.as<uint32_t>();
 }
-void fe_summary_buffers(unsigned long long** slots, unsigned long long** zero) {      // (after any_true_acquire)
+unsigned long long* fe_summary_host() { return t_any.host_dev; }      // (after any_true_acquire)
+void any_true_written(GrB_Vector w, const void* key, uint32_t tag, uint64_t fe_key, uint32_t fe_nblocks) {
   AnyTrue& s = t_any;
-  *slots = (unsigned long long*)(s.word.as<uint8_t>() + ANY_WORD_BYTES + (size_t)s.fe_par * FE_BUF_BYTES);
-  *zero = (unsigned long long*)(s.word.as<uint8_t>() + ANY_WORD_BYTES + (size_t)(s.fe_par ^ 1) * FE_BUF_BYTES);
-}
-void any_true_written(GrB_Vector w, const void* key, uint32_t tag, uint64_t fe_key) {
-  AnyTrue& s = t_any;
-  s.owner = w;
-  if (fe_key) { s.fe_has = w != nullptr; s.fe_read_par = s.fe_par; s.fe_key = fe_key; s.fe_par ^= 1; }      // (the buffer was used whether or not anybody owns the result)
+  s.owner = w; s.fe_has = fe_key != 0 && w != nullptr && fe_nblocks > 0 && fe_nblocks <= FE_HOST_PAIRS; s.fe_key = fe_key; s.fe_nblocks = fe_nblocks;
   if (w) { w->lor_state = 1; w->lor_key = key; w->lor_tag = tag; }
 }
 bool any_true_lookup(GrB_Vector u, bool* value) {
@@ -177,17 +177,27 @@ bool any_true_lookup(GrB_Vector u, bool* value) {
   if (u->lor_state == 1) {
     AnyTrue& s = t_any;
     if (s.owner != u || s.tag != u->lor_tag) { u->lor_state = 0; return false; }
-    uint8_t* pin = (uint8_t*)pinned_scratch();
-    const size_t bytes = s.fe_has ? ANY_WORD_BYTES + 2 * FE_BUF_BYTES : 4;
-    GRB_HIP(hipMemcpyAsync(pin, s.word.p, bytes, hipMemcpyDeviceToHost, stream()));
-    GRB_HIP(hipStreamSynchronize(stream()));
-    uint32_t w0; memcpy(&w0, pin, 4);
-    u->lor_state = w0 == u->lor_tag ? 3 : 2; s.owner = nullptr;
     if (s.fe_has) {
-      // the edges leaving u's true entries (exact when the kernel counted: a lower bound is all the direction choice asks for)
-      const unsigned long long* sl = (const unsigned long long*)(pin + ANY_WORD_BYTES + (size_t)s.fe_read_par * FE_BUF_BYTES);
-      unsigned long long fe = 0; for (int q = 0; q < 64; q++) fe += sl[2 * q];
-      u->fe_lb = fe; u->fe_lb_key = s.fe_key; s.fe_has = false;
+      // every workgroup stores  tag (24 bits) | true entries, saturating (8) | edge sum, saturating (32)  into its host word: wait for all of them,
+      // and clear what was read (a word is never mistaken for a later product's with the same 24-bit tag)
+      volatile unsigned long long* h = s.host; const unsigned long long want = (unsigned long long)(u->lor_tag & 0xFFFFFFu);
+      unsigned long long fe = 0, cnt = 0; uint32_t i = 0; const uint32_t nb = s.fe_nblocks;
+      for (int round = 0; round < 2 && i < nb; round++) {
+        for (uint64_t spin = 0; spin < (1ull << 22) && i < nb;) {
+          const unsigned long long a = h[i];
+          if ((a >> 40) == want && a != 0) { fe += a & 0xFFFFFFFFull; cnt += (a >> 32) & 0xFFull; h[i] = 0; i++; } else { spin++; __builtin_ia32_pause(); }
+        }
+        if (i < nb) GRB_HIP(hipStreamSynchronize(stream()));      // (far beyond any product's time: let a failed launch report itself, then look once more)
+      }
+      s.owner = nullptr; s.fe_has = false;
+      if (i < nb) { u->lor_state = 0; return false; }
+      u->lor_state = cnt ? 3 : 2;
+      u->fe_lb = fe; u->fe_lb_key = s.fe_key;      // the edges leaving u's true entries (exact when the kernel counted: a lower bound is all the direction choice asks for)
+    } else {
+      uint32_t* pin = (uint32_t*)pinned_scratch();
+      GRB_HIP(hipMemcpyAsync(pin, s.word.p, 4, hipMemcpyDeviceToHost, stream()));
+      GRB_HIP(hipStreamSynchronize(stream()));
+      u->lor_state = pin[0] == u->lor_tag ? 3 : 2; s.owner = nullptr;
     }
   }
   *value = u->lor_state == 3; return true;

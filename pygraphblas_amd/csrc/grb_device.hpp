@@ -155,10 +155,11 @@ __device__ __forceinline__ bool mask_truth_at(const void* mval, int mcode, uint6
 }
 
 // ---- a device word the host can read back (count results, flags) ------------------------------------------
-// 256 bytes of page-locked host memory per thread: the landing place of the small device-to-host readbacks (counts, reduced scalars)
+// 16 KiB of page-locked host memory per thread: the landing place of the small device-to-host readbacks (counts, reduced scalars, the
+// result summary of a BOOL product: 8.1 KiB)
 inline void* pinned_scratch() {
   static thread_local void* p = nullptr;
-  if (!p) GRB_HIP(hipHostMalloc(&p, 256, hipHostMallocDefault));
+  if (!p) GRB_HIP(hipHostMalloc(&p, 16384, hipHostMallocDefault));
   return p;
 }
 struct ScalarSlot {

@@ -196,14 +196,14 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   // a BOOL result that replaces w: the kernel notes whether it wrote a true value, and the `q.reduce_bool()` that follows a BFS
   // level (tests/test_bfs.py loop: `while q.reduce_bool() and level <= n`) reads that word instead of scanning q
   bool any_done = false;
-  bool fe_done = false; uint64_t fe_key = 0;
+  bool fe_done = false; uint64_t fe_key = 0; uint32_t fe_nblocks = 0;
   if (sd.zcode == T_BOOL && w->type->code == T_BOOL && !accum && method == SPMV_AUTO) {
     call.any_true = any_true_acquire(&call.any_true_tag); call.any_true_done = &any_done;
     // ... and, on a square matrix, the edges leaving the result's true entries in the row pointers the direction choice above counts in:
     // the product after `v[q] = level` then knows its operand is too heavy for a push step without counting (SpmvCall::fe_slots)
     if (mr == mc && (useT || A->csc.valid)) {
       const DevCSR& P0 = useT ? A->csr : mat_csc(A);
-      if (P0.nrows == mr && P0.rowptr.serial) { call.fe_rowptr = P0.rowptr.as<uint32_t>(); fe_summary_buffers(&call.fe_slots, &call.fe_zero); call.fe_done = &fe_done; fe_key = P0.rowptr.serial; }
+      if (P0.nrows == mr && P0.rowptr.serial) { call.fe_rowptr = P0.rowptr.as<uint32_t>(); call.fe_host = fe_summary_host(); call.fe_done = &fe_done; call.fe_nblocks = &fe_nblocks; fe_key = P0.rowptr.serial; }
     }
   }
   const void* const tkey = tval.p;
@@ -263,7 +263,7 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   // next sweep measures the range again.
   const bool accum_selects = accum && check_obj(accum) && (accum->opcode == B_MIN || accum->opcode == B_MAX || accum->opcode == B_FIRST || accum->opcode == B_SECOND || accum->opcode == B_ANY);
   if (big_holes && w->type->code == sd.zcode && (!accum || w_was_empty || (w_is_u && accum_selects))) w->abs_bound = big_uabs + big_aabs;
-  if (any_done) any_true_written(w->lazy == 0 && w->dev_valid && w->dval.p == tkey ? w : nullptr, tkey, call.any_true_tag, fe_done ? fe_key : 0);       // (adopted as they are: w is exactly T)
+  if (any_done) any_true_written(w->lazy == 0 && w->dev_valid && w->dval.p == tkey ? w : nullptr, tkey, call.any_true_tag, fe_done ? fe_key : 0, fe_nblocks);       // (adopted as they are: w is exactly T)
 }
 
 extern "C" {

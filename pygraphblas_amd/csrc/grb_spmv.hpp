@@ -38,13 +38,13 @@ struct SpmvCall {
   // cleared).  A kernel that honours it sets *any_true_done.
   uint32_t* any_true = nullptr; uint32_t any_true_tag = 0; bool* any_true_done = nullptr;
   // ... and, for a square matrix, the edges that leave the result's TRUE entries in the push orientation (round 5): `fe_rowptr` are the row
-  // pointers the direction choice of the NEXT product would count them in (grb_mxv.cpp), `fe_slots` 64 pairs (edge sum, entry count) of
-  // 64-bit words the kernel adds to (slot = wave number mod 64: no two thousand atomics on one address), `fe_zero` the other buffer of the
-  // pair, which the kernel clears for the product after it.  The masked pull counts exactly; the push kernels only when the operand has ONE
-  // entry (the columns of one row are distinct: no product lands twice).  A kernel that honours it sets *fe_done.  The BFS loop's
-  // `q.reduce_bool()` reads the slots with the any-true word, `v[q] = level` hands the sum on to v, and the level-2 product needs no
-  // counting kernel and no read-back of its own (62 us of 313 at R-MAT-22).
-  const uint32_t* fe_rowptr = nullptr; unsigned long long* fe_slots = nullptr; unsigned long long* fe_zero = nullptr; bool* fe_done = nullptr;
+  // pointers the direction choice of the NEXT product would count them in (grb_mxv.cpp); every workgroup of the kernel stores its (edge sum,
+  // entry count), tagged with `any_true_tag`, into its own pair of the page-locked host words `fe_host` (<= 2048 pairs).  The masked pull
+  // counts exactly; the push kernels only when the operand has ONE entry (the columns of one row are distinct: no product lands twice).
+  // A kernel that honours it sets *fe_done and *fe_nblocks (the pairs to expect).  The BFS loop's `q.reduce_bool()` spins on the host words —
+  // no device-to-host copy, no stream synchronisation — `v[q] = level` hands the edge sum on to v, and the level-2 product needs no counting
+  // kernel and no read-back of its own.
+  const uint32_t* fe_rowptr = nullptr; unsigned long long* fe_host = nullptr; bool* fe_done = nullptr; uint32_t* fe_nblocks = nullptr;
   // The mask IS the operand, of a one-byte type, under a Boolean semiring (`v.vxm(A, mask=v, out=q, desc=RC)` on the level vector of the
   // reference's BFS loop): the row-lane kernel can read the vector itself — allowed(r) = (pres[r] && (structural || val[r])) != complement,
   // operand value = (val[c] != 0) — where the caller would otherwise make allow bytes and BOOL values in a pass of its own (11 us per

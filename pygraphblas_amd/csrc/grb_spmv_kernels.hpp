@@ -50,16 +50,32 @@ template <class T> struct SpmvKArgs {
   uint32_t nrows;
   uint32_t* any_true; uint32_t any_true_tag;      // BOOL results only (nullptr otherwise): set to the tag when an entry with value true is written
   const uint8_t* fm_val; uint32_t fm_flags;       // SpmvCall::fm_val / fm_flags (row-lane kernel, FUSED instantiation)
-  const uint32_t* fe_rowptr; unsigned long long* fe_slots; unsigned long long* fe_zero;      // SpmvCall::fe_* (row-lane kernel)
+  const uint32_t* fe_rowptr; unsigned long long* fe_host;      // SpmvCall::fe_* (row-lane kernel)
 };
-// a wave's share of the result's summary (SpmvCall::fe_slots): edge sum and entry count of the true entries it wrote
-__device__ __forceinline__ void fe_wave_add(unsigned long long* __restrict__ slots, unsigned long long fe, unsigned long long cnt, uint64_t wave) {
-  cnt = wave_reduce_add_u64(cnt);
-  if (cnt) {                                                   // (wave-uniform)
-    fe = wave_reduce_add_u64(fe);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&slots[2 * (wave & 63)], fe); atomicAdd(&slots[2 * (wave & 63) + 1], cnt); }
+// a workgroup's share of the result's summary (SpmvCall::fe_host): edge sum and entry count of the true entries it wrote, stored — each in the
+// low half of a 64-bit word whose high half is the product's tag — into ITS OWN pair of page-locked HOST words.  The `q.reduce_bool()` that
+// follows spins until every pair carries the tag and adds them up: no device-to-host copy, no stream synchronisation (17 us on this box, six
+// times per BFS), and nothing for the workgroups to agree on.  What was tried on the device side first (R-MAT-22, the late levels' 13 us pull):
+// a pair of atomics per WAVE on packed pairs — 131 072 atomics on eight cache lines — 261 us; a pair per workgroup on 32 padded pairs + one
+// ticket for the last workgroup to report: +28 us for 1024 workgroups; tickets in two levels: +25 us — agent-scope atomics are performed at
+// the memory side, and those on one LINE complete one after the other, ~100 ns each.
+// One word per workgroup: tag (24 bits) | true entries, saturating at 255 (8 bits: only "any" is asked) | edge sum, saturating (32 bits: a lower bound is
+// all the direction choice asks for).  (Two words per workgroup from 1024 workgroups of 256 threads made the pull 7 us longer: 2048 small writes across
+// PCIe at the end of a 13 us kernel.  Hence one word, and workgroups of 1024 threads.)
+__device__ __forceinline__ void fe_block_report(unsigned long long* __restrict__ host_out, uint32_t slot, uint32_t tag, unsigned long long fe, unsigned long long cnt) {
+  __shared__ unsigned long long s_fe[2][16];
+  cnt = wave_reduce_add_u64(cnt); fe = wave_reduce_add_u64(fe);
+  const int wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) { s_fe[0][wv & 15] = fe; s_fe[1][wv & 15] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    fe = 0; cnt = 0; for (int q = 0; q < nw; q++) { fe += s_fe[0][q]; cnt += s_fe[1][q]; }
+    if (fe > 0xFFFFFFFFull) fe = 0xFFFFFFFFull;
+    if (cnt > 0xFFull) cnt = 0xFFull;
+    __hip_atomic_store(host_out + slot, ((unsigned long long)(tag & 0xFFFFFFu) << 40) | (cnt << 32) | fe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+
 template <class T> __device__ __forceinline__ bool spmv_truthy(T v) { if constexpr (is_bool<T>::value) return v.v != 0; else return v != T(); }
 
 // ---- kernel A ---------------------------------------------------------------------------------------------------
@@ -250,21 +266,84 @@ __global__ __launch_bounds__(256) void k_spmv_rowgroup(const SpmvKArgs<T> a, con
 // entries; the rows that are neither finished nor at their monoid's terminal value by then (hub rows) are completed by the
 // whole wave, 64 entries per step, starting from the lane's partial result.
 constexpr uint32_t SPMV_LANE_E = 8;
+template <class T, class SR, bool U_FULL, bool FUSED = false>
+__global__ __launch_bounds__(1024) void k_spmv_rowlane(const SpmvKArgs<T> a, const SR sr) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+  const bool use_a = sr.uses_a(), use_u = sr.uses_u();
+  const uint64_t nround = ((uint64_t)a.nrows + 63) / 64 * 64;
+  unsigned long long fe = 0, fcnt = 0;
+  for (uint64_t base = wave * 64; base < nround; base += nwaves * 64) {
+    const uint64_t r = base + lane;
+    const bool valid = r < a.nrows;
+    bool allowed;
+    if constexpr (FUSED) allowed = valid && ((a.upres[r] != 0 && ((a.fm_flags & 1u) || a.fm_val[r] != 0)) != ((a.fm_flags & 2u) != 0));     // the mask vector itself
+    else allowed = valid && (!a.allow || a.allow[r]);
+    // operand value at column c: the vector's own byte as BOOL when fused
+    auto uat = [&](uint32_t c) __attribute__((always_inline)) -> T { if constexpr (FUSED) { T t; t = T(a.fm_val[c] != 0); return t; } else return a.uval[c]; };
+    // (the row pointers are fetched whether or not the row is allowed: one dependent round trip less per wave — the late levels of a BFS,
+    //  where half of the 4 M rows are empty and unvisited, are a chain of such trips and little else)
+    uint32_t pb = 0, pe = 0;
+    if (FUSED ? valid : allowed) { pb = a.rowptr[r]; pe = a.rowptr[r + 1]; }
+    T acc = sr.identity; bool has = false, done = !allowed;
+    if (allowed) {
+      const uint32_t e = pe - pb > SPMV_LANE_E ? pb + SPMV_LANE_E : pe;
+      for (uint32_t p = pb; p < e; p++) {
+        const uint32_t c = a.col[p];
+        bool pr = true;
+        if constexpr (!U_FULL) pr = a.upres[c] != 0;
+        if (pr) {
+          const T m = sr.mult(use_a ? a.aval[p] : T(), use_u ? uat(c) : T());
+          acc = has ? sr.add(acc, m) : m; has = true;
+          if (sr.has_terminal && memcmp_eq(acc, sr.terminal)) { done = true; break; }
+        }
+      }
+      if (pe - pb <= SPMV_LANE_E) done = true;
+    }
+    // the unfinished rows, one after the other, by the whole wave
+    unsigned long long todo = __ballot(allowed && !done);
+    while (todo) {
+      const int L = __builtin_ctzll(todo); todo &= todo - 1;
+      const uint32_t qb = (uint32_t)__shfl((int)pb, L, 64) + SPMV_LANE_E, qe = (uint32_t)__shfl((int)pe, L, 64);
+      T part = sr.identity; bool phas = false;
+      for (uint32_t p0 = qb; p0 < qe; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        if (p < qe) {
+          const uint32_t c = a.col[p];
+          bool pr = true;
+          if constexpr (!U_FULL) pr = a.upres[c] != 0;
+          if (pr) { const T m = sr.mult(use_a ? a.aval[p] : T(), use_u ? uat(c) : T()); part = phas ? sr.add(part, m) : m; phas = true; }
+        }
+        if (sr.has_terminal && __ballot(phas && memcmp_eq(part, sr.terminal))) break;      // some lane is at the terminal value: so is the row
+      }
+      const unsigned long long hb = __ballot(phas);
+      // (ANY keeps "a" value: the tree below would also consider the identity of the lanes that saw nothing — take a real one)
+      const T red = sr.add_op() == B_ANY ? shfl_t<T>(part, hb ? __builtin_ctzll(hb) : 0) : wave_reduce_op<T, false>(sr.add_op(), phas ? part : sr.identity);
+      if (lane == L && hb) { acc = has ? sr.add(acc, red) : red; has = true; }
+    }
+    if (valid) { if (allowed && has) a.tval[r] = acc; a.tpres[r] = (allowed && has) ? 1 : 0; }
+    const bool tr = valid && allowed && has && spmv_truthy<T>(acc);
+    if (a.fe_host) { if (tr) { fe += a.fe_rowptr[r + 1] - a.fe_rowptr[r]; fcnt++; } }      // (the summary's count answers "any true" as well)
+    else if (a.any_true) { if (__ballot(tr) && lane == 0) *a.any_true = a.any_true_tag; }      // (same value from every wave: a benign race)
+  }
+  if (a.fe_host) fe_block_report(a.fe_host, blockIdx.x, a.any_true_tag, fe, fcnt);      // (argument-uniform branch: every thread of the workgroup gets here)
+}
+
+
 constexpr int SPMV_LANE_K = 4;
+constexpr uint32_t FE_MAX_BLOCKS = 2048;      // pairs of host words of the result summary (grb_container.cpp allocates them)
 // Round 5: a lane owns SPMV_LANE_K rows at once (rows r, r + 64, r + 128, r + 192 of the wave's 256).  A row is a chain of four dependent
 // loads — mask byte / row pointers, column, operand byte — and with one row per lane a wave had 64 chains in flight and nothing to do
 // while they were: the level-2 pull of the R-MAT-22 BFS took 54 us for 64 MB, the late levels 17 us each for a handful of vertices
 // (65 536 waves of one round trip after the other).  With K rows the K loads of every stage are issued together: all of them are
 // unconditional (an idle slot reads entry 0 of its array and drops it), so they stand in one basic block.
-template <class T, class SR, bool U_FULL, bool FUSED = false>
-__global__ __launch_bounds__(256) void k_spmv_rowlane(const SpmvKArgs<T> a, const SR sr) {
-  constexpr int K = SPMV_LANE_K;
+template <class T, class SR, bool U_FULL, bool FUSED, int K>
+__global__ __launch_bounds__(1024) void k_spmv_rowlane_k(const SpmvKArgs<T> a, const SR sr) {
   const int lane = threadIdx.x & 63;
-  const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = (uint64_t)gridDim.x * 4;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
   const bool use_a = sr.uses_a(), use_u = sr.uses_u();
   const uint64_t span = 64ull * K, nround = ((uint64_t)a.nrows + span - 1) / span * span;
   unsigned long long fe = 0, fcnt = 0;
-  if (a.fe_zero && blockIdx.x == 0 && threadIdx.x < 128) a.fe_zero[threadIdx.x] = 0;          // the other buffer of the pair: ready for the product after this one
   for (uint64_t base = wave * span; base < nround; base += nwaves * span) {
     uint64_t r[K]; bool valid[K], allowed[K], has[K], done[K]; uint32_t pb[K], pe[K]; T acc[K];
     uint8_t m0[K], m1[K];
@@ -345,11 +424,11 @@ __global__ __launch_bounds__(256) void k_spmv_rowlane(const SpmvKArgs<T> a, cons
       if (valid[k]) { if (w) a.tval[r[k]] = acc[k]; a.tpres[r[k]] = w ? 1 : 0; }
       const bool tr = w && spmv_truthy<T>(acc[k]);
       wrote_true = wrote_true || tr;
-      if (a.fe_slots && tr) { fe += a.fe_rowptr[r[k] + 1] - a.fe_rowptr[r[k]]; fcnt++; }
+      if (a.fe_host && tr) { fe += a.fe_rowptr[r[k] + 1] - a.fe_rowptr[r[k]]; fcnt++; }
     }
-    if (a.any_true) { if (__ballot(wrote_true) && lane == 0) *a.any_true = a.any_true_tag; }      // (same value from every wave: a benign race)
+    if (!a.fe_host && a.any_true) { if (__ballot(wrote_true) && lane == 0) *a.any_true = a.any_true_tag; }      // (same value from every wave: a benign race)
   }
-  if (a.fe_slots) fe_wave_add(a.fe_slots, fe, fcnt, wave);
+  if (a.fe_host) fe_block_report(a.fe_host, blockIdx.x, a.any_true_tag, fe, fcnt);
 }
 
 // ---- kernel C: push.  t is pre-initialised (tpres = 0); entries are claimed with tpres CAS-free flags ---------------
@@ -389,14 +468,13 @@ __global__ __launch_bounds__(256) void k_spmspv_push(const uint32_t* __restrict_
                                                      const uint32_t* __restrict__ col, const T* __restrict__ aval, const T* __restrict__ uval,
                                                      const uint8_t* __restrict__ allow, T* __restrict__ tval, uint8_t* __restrict__ tpres,
                                                      uint32_t* __restrict__ longlist, const SR sr, uint32_t* __restrict__ any_true = nullptr, const uint32_t any_tag = 0,
-                                                     unsigned long long* __restrict__ fe_slots = nullptr, unsigned long long* __restrict__ fe_zero = nullptr) {
+                                                     unsigned long long* __restrict__ fe_host = nullptr) {
   // one wave per frontier entry: its row of M^T (= CSR row of the stored matrix) is streamed coalesced
   const int lane = threadIdx.x & 63;
   const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6;
   const uint64_t nwaves = (uint64_t)gridDim.x * 4;
   const bool use_a = sr.uses_a(), use_u = sr.uses_u();
-  unsigned long long fe = 0, fcnt = 0;                                       // (fe_slots: nf == 1 — SpmvCall::fe_slots)
-  if (fe_zero && blockIdx.x == 0 && threadIdx.x < 128) fe_zero[threadIdx.x] = 0;
+  unsigned long long fe = 0, fcnt = 0;                                       // (fe_host: nf == 1 — SpmvCall::fe_host)
   for (uint64_t f = wave; f < nf; f += nwaves) {
     const uint32_t i = fidx[f];
     const T ui = use_u ? uval[i] : T();
@@ -412,10 +490,10 @@ __global__ __launch_bounds__(256) void k_spmspv_push(const uint32_t* __restrict_
       atomic_combine<T>(sr.add_op(), &tval[j], m);
       tpres[j] = 1;
       if (any_true && spmv_truthy<T>(m)) *any_true = any_tag;             // BOOL monoids of the push path only OR values in: a true product is a true entry
-      if (fe_slots && spmv_truthy<T>(m)) { fe += rowptr[j + 1] - rowptr[j]; fcnt++; }
+      if (fe_host && spmv_truthy<T>(m)) { fe += rowptr[j + 1] - rowptr[j]; fcnt++; }
     }
   }
-  if (fe_slots) fe_wave_add(fe_slots, fe, fcnt, wave);
+  if (fe_host) fe_block_report(fe_host, blockIdx.x, any_tag, fe, fcnt);                // (one operand entry: one workgroup)
 }
 
 // frontier rows longer than PUSH_LONG: every block of the grid takes a slice of each (the list is short: hubs only)
@@ -423,7 +501,7 @@ template <class T, class SR>
 __global__ __launch_bounds__(256) void k_spmspv_push_long(const uint32_t* __restrict__ longlist, const uint32_t* __restrict__ rowptr,
                                                           const uint32_t* __restrict__ col, const T* __restrict__ aval, const T* __restrict__ uval,
                                                           const uint8_t* __restrict__ allow, T* __restrict__ tval, uint8_t* __restrict__ tpres, const SR sr,
-                                                          uint32_t* __restrict__ any_true = nullptr, const uint32_t any_tag = 0, unsigned long long* __restrict__ fe_slots = nullptr) {
+                                                          uint32_t* __restrict__ any_true = nullptr, const uint32_t any_tag = 0, unsigned long long* __restrict__ fe_host = nullptr) {
   const uint32_t nl = longlist[0];
   const bool use_a = sr.uses_a(), use_u = sr.uses_u();
   unsigned long long fe = 0, fcnt = 0;
@@ -440,10 +518,10 @@ __global__ __launch_bounds__(256) void k_spmspv_push_long(const uint32_t* __rest
       atomic_combine<T>(sr.add_op(), &tval[j], m);
       tpres[j] = 1;
       if (any_true && spmv_truthy<T>(m)) *any_true = any_tag;
-      if (fe_slots && spmv_truthy<T>(m)) { fe += rowptr[j + 1] - rowptr[j]; fcnt++; }
+      if (fe_host && spmv_truthy<T>(m)) { fe += rowptr[j + 1] - rowptr[j]; fcnt++; }
     }
   }
-  if (fe_slots) fe_wave_add(fe_slots, fe, fcnt, (blockIdx.x * 256ull + threadIdx.x) >> 6);
+  if (fe_host) fe_block_report(fe_host, 1u + blockIdx.x, any_tag, fe, fcnt);             // (pair 0 is the short-row kernel's)
 }
 
 // ---- host drivers ---------------------------------------------------------------------------------------------------------
@@ -475,7 +553,7 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
     SpmvKArgs<T> a{};
     a.rowptr = M.rowptr.as<uint32_t>(); a.col = M.col.as<uint32_t>(); a.aval = (const T*)c.aval;
     a.uval = (const T*)c.uval; a.upres = c.upres; a.allow = c.allow; a.tval = (T*)c.tval; a.tpres = c.tpres; a.nrows = M.nrows; a.any_true = nullptr;
-    a.fe_rowptr = nullptr; a.fe_slots = nullptr; a.fe_zero = nullptr;
+    a.fe_rowptr = nullptr; a.fe_host = nullptr;
     const bool full = c.upres == nullptr;
     // masked pull with a terminal monoid (BFS) -> row-group kernel with early exit; otherwise the row-block kernel
     const bool prefer_rowgroup = c.method == SPMV_ROWGROUP || (c.method == SPMV_AUTO && (c.allow || c.fm_val) && d.has_terminal);
@@ -490,19 +568,29 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
       else hipLaunchKernelGGL((k_spmv_rowgroup<T, SR, GG, false>), dim3((unsigned)nb), dim3(256), 0, stream(), a, sr);
       static const bool no_lane = wp_env("GRB_MI355X_NO_ROWLANE", 0) != 0;      // measurement hook
       if (G == 8 && !no_lane && c.method == SPMV_AUTO) {                          // short rows on average: a lane per row (kernel B')
-        uint64_t nbl = ((uint64_t)M.nrows + 256 * SPMV_LANE_K - 1) / (256 * SPMV_LANE_K); if (nbl < 1) nbl = 1; if (nbl > 65536) nbl = 65536;
+        static const int lane_k = (int)wp_env("GRB_MI355X_LANE_K", SPMV_LANE_K);                    // measurement hook: rows per lane of the fused (BFS) instantiation
+        uint64_t nbl = ((uint64_t)M.nrows + 255) / 256; if (nbl < 1) nbl = 1; if (nbl > 65536) nbl = 65536;
         if (c.any_true && c.any_true_done && is_bool<T>::value) {
           a.any_true = c.any_true; a.any_true_tag = c.any_true_tag; *c.any_true_done = true;
-          if (c.fe_slots && c.fe_done && c.fe_rowptr) { a.fe_rowptr = c.fe_rowptr; a.fe_slots = c.fe_slots; a.fe_zero = c.fe_zero; *c.fe_done = true; }
+          if (c.fe_host && c.fe_done && c.fe_rowptr) { a.fe_rowptr = c.fe_rowptr; a.fe_host = c.fe_host; }      // (honoured by the fused launch below)
         }
         if constexpr (is_bool<T>::value) {
           if (c.fm_val) {                                                       // the mask is the operand itself: no allow / BOOL-value arrays were made
             a.fm_val = c.fm_val; a.fm_flags = c.fm_flags;
-            hipLaunchKernelGGL((k_spmv_rowlane<T, SR, false, true>), dim3((unsigned)nbl), dim3(256), 0, stream(), a, sr);
+            const int kk = lane_k >= 4 ? 4 : lane_k >= 2 ? 2 : 1;
+            static const uint32_t lane_cap = wp_env("GRB_MI355X_LANE_BLOCKS", 256);                    // measurement hooks: grid cap (the kernel strides), threads per workgroup
+            static const uint32_t lane_thr = wp_env("GRB_MI355X_LANE_THREADS", 1024);
+            const unsigned thr = lane_thr >= 1024 ? 1024u : lane_thr >= 512 ? 512u : 256u;
+            uint64_t nbk = ((uint64_t)M.nrows + (uint64_t)thr * kk - 1) / ((uint64_t)thr * kk); if (nbk < 1) nbk = 1; if (nbk > lane_cap) nbk = lane_cap;
+            if (a.fe_host) { if (nbk > FE_MAX_BLOCKS) nbk = FE_MAX_BLOCKS; *c.fe_done = true; *c.fe_nblocks = (uint32_t)nbk; }
+            if (kk == 4) hipLaunchKernelGGL((k_spmv_rowlane_k<T, SR, false, true, 4>), dim3((unsigned)nbk), dim3(thr), 0, stream(), a, sr);
+            else if (kk == 2) hipLaunchKernelGGL((k_spmv_rowlane_k<T, SR, false, true, 2>), dim3((unsigned)nbk), dim3(thr), 0, stream(), a, sr);
+            else hipLaunchKernelGGL((k_spmv_rowlane<T, SR, false, true>), dim3((unsigned)nbk), dim3(thr), 0, stream(), a, sr);
             g_last_plan += std::string("k_spmv_rowlane<") + (sr.is_static ? "static" : "dynamic") + ",mask=operand> ";
             return;
           }
         }
+        a.fe_host = nullptr;                                                     // (the summary rides with the fused instantiation only)
         if (full) hipLaunchKernelGGL((k_spmv_rowlane<T, SR, true>), dim3((unsigned)nbl), dim3(256), 0, stream(), a, sr);
         else hipLaunchKernelGGL((k_spmv_rowlane<T, SR, false>), dim3((unsigned)nbl), dim3(256), 0, stream(), a, sr);
         g_last_plan += std::string("k_spmv_rowlane<") + (sr.is_static ? "static>" : "dynamic>") + " ";
@@ -605,16 +693,16 @@ template <class T> void run_push(const SpmvCall& c, const SemiringDesc& d, const
       hipLaunchKernelGGL((k_push_init<T>), dim3(grid_of(nout / 16 + 1)), dim3(256), 0, stream(), (T*)c.tval, c.tpres, nout, sr.identity, sl, (uint32_t*)fidx_w, longlist);
     } else if (nout) hipLaunchKernelGGL((k_fill<T>), dim3(grid_of(nout)), dim3(256), 0, stream(), (T*)c.tval, nout, sr.identity);
     uint64_t nb = (u_nvals + 3) / 4; if (nb < 1) nb = 1; if (nb > 16384) nb = 16384;
-    uint32_t* any_true = nullptr; unsigned long long* fe_slots = nullptr; unsigned long long* fe_zero = nullptr;
+    uint32_t* any_true = nullptr; unsigned long long* fe_host = nullptr;
     if (c.any_true && c.any_true_done && is_bool<T>::value && (sr.add_op() == B_LOR || sr.add_op() == B_PLUS || sr.add_op() == B_MAX)) {
       any_true = c.any_true; *c.any_true_done = true;
       // one operand entry: the columns of its row are distinct, so the true entries written and the edges leaving them are counted exactly
-      if (u_nvals == 1 && c.fe_slots && c.fe_done && c.fe_rowptr == M.rowptr.as<uint32_t>()) { fe_slots = c.fe_slots; fe_zero = c.fe_zero; *c.fe_done = true; }
+      if (u_nvals == 1 && c.fe_host && c.fe_done && c.fe_rowptr == M.rowptr.as<uint32_t>()) { fe_host = c.fe_host; *c.fe_done = true; *c.fe_nblocks = 1u + 1024u; }
     }
     hipLaunchKernelGGL((k_spmspv_push<T, SR>), dim3((unsigned)nb), dim3(256), 0, stream(), fidx, (uint32_t)u_nvals,
-                       M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(), (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, longlist, sr, any_true, c.any_true_tag, fe_slots, fe_zero);
+                       M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(), (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, longlist, sr, any_true, c.any_true_tag, fe_host);
     hipLaunchKernelGGL((k_spmspv_push_long<T, SR>), dim3(1024), dim3(256), 0, stream(), longlist, M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(),
-                       (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, sr, any_true, c.any_true_tag, fe_slots);
+                       (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, sr, any_true, c.any_true_tag, fe_host);
     g_last_plan += std::string("k_spmspv_push<") + (sr.is_static ? "static> " : "dynamic> ");
   });
 }
