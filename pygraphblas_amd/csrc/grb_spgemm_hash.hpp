@@ -200,6 +200,7 @@ __global__ __launch_bounds__(1024) void k_spgemm_dense(const HashArgs a, const T
 // faster walk, two workgroups of 8192 columns per CU: numeric pass 57 -> 78 ms)
 template <class T> struct spa_cfg { static constexpr uint32_t WD = sizeof(typename acc_word<T>::type) >= 8 ? (uint32_t)SPA_WD8_V : (uint32_t)SPA_WD4_V; };
 constexpr uint32_t SPA_SYM_WORDS = 32768;      // 2^20 bits
+constexpr uint32_t SPA_RANK_MAXBLK = 32;     // ranked rows (k_spgemm_spa_numeric): at most this many blocks of columns
 constexpr uint32_t SPA_CHUNK = 992;             // entries of A(i,:) per walk of the numeric kernel (the last 32 threads carry none: their share of the walk's arrays is the room the flag bytes need)
 // The products of up to 1024 entries k of A(i,:) (one per thread: `len` entries of B starting at `st`), dealt evenly to the 16
 // waves of the workgroup whatever the lengths are — most are empty or a single entry, a hub's is tens of thousands: an exclusive
@@ -312,17 +313,29 @@ template <class L, class A> __device__ __forceinline__ uint32_t spa_flat_walk(ui
   SPA_PF(2)
   return total;                                             // (the same in every thread)
 }
+// the next row of a persistent workgroup of the dense paths, handed out by a counter (round 5).  A static deal — row b, b + grid, ... — left the slowest
+// workgroup of the numeric pass of A@A on R-MAT-18 at 1.48 x the mean (rows of 6 000 and of 3 000 000 products), and the launch ends with it.  The counter is
+// drawn at the START of a row and looked at behind its end, so its latency is never waited for.
+__device__ __forceinline__ uint32_t spa_next_row(uint32_t* s_next, uint32_t drawn) {
+  if (threadIdx.x == 0) *s_next = drawn;
+  __syncthreads();
+  const uint32_t r = *s_next;
+  __syncthreads();
+  return r;
+}
 template <class T, class SR>
-__global__ __launch_bounds__(1024) void k_spgemm_spa_symbolic(const HashArgs a, uint32_t ncols) {
+__global__ __launch_bounds__(1024) void k_spgemm_spa_symbolic(const HashArgs a, uint32_t ncols, uint32_t* __restrict__ rowctr, uint32_t* __restrict__ bitmaps = nullptr, uint32_t* __restrict__ bmslot = nullptr) {
   __shared__ uint32_t s_bits[SPA_SYM_WORDS];
   __shared__ uint32_t s_exc[1025], s_shift[1024], s_wtot[16];
-  __shared__ uint32_t s_cnt;
+  __shared__ uint32_t s_cnt, s_next;
   const uint32_t words = (ncols + 31) / 32;
   const uint32_t t = threadIdx.x;
   for (uint32_t w = t; w < words; w += 1024) s_bits[w] = 0;
   if (t == 0) s_cnt = 0;
   __syncthreads();
-  for (uint32_t ridx = blockIdx.x; ridx < a.nrows_bin; ridx += gridDim.x) {
+  uint32_t drawn = 0;
+  for (uint32_t ridx = blockIdx.x; ridx < a.nrows_bin; ridx = spa_next_row(&s_next, drawn)) {
+    if (t == 0) drawn = gridDim.x + atomicAdd(rowctr, 1u);
     const uint32_t i = a.rows[ridx];
     const uint32_t ab = a.arp[i], ae = a.arp[i + 1];
     for (uint32_t base = ab; base < ae; base += 1024) {
@@ -332,11 +345,13 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_symbolic(const HashArgs a, 
                     [&](uint32_t j) { const uint32_t bit = 1u << (j & 31); if (!(s_bits[j >> 5] & bit)) atomicOr(&s_bits[j >> 5], bit); });
     }
     uint32_t c = 0;
-    for (uint32_t w = t; w < words; w += 1024) { c += __popc(s_bits[w]); s_bits[w] = 0; }
+    // (round 5: the row's bitmap is kept for the numeric pass — 32 KiB per row at 2^18 columns — which ranks a column among the row's entries with it)
+    if (bitmaps) { uint32_t* const bm = bitmaps + (size_t)ridx * words; for (uint32_t w = t; w < words; w += 1024) { const uint32_t x = s_bits[w]; c += __popc(x); bm[w] = x; s_bits[w] = 0; } }
+    else for (uint32_t w = t; w < words; w += 1024) { c += __popc(s_bits[w]); s_bits[w] = 0; }
     for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((t & 63) == 0 && c) atomicAdd(&s_cnt, c);
     __syncthreads();
-    if (t == 0) { a.rownnz[i] = s_cnt; s_cnt = 0; }
+    if (t == 0) { a.rownnz[i] = s_cnt; s_cnt = 0; if (bmslot) bmslot[i] = ridx; }
     __syncthreads();
   }
 }
@@ -357,15 +372,22 @@ static __global__ void k_spa_split(uint32_t nrows, const uint32_t* __restrict__ 
 }
 template <class T, class SR>
 __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, const T* __restrict__ aval, const T* __restrict__ bval, uint32_t* __restrict__ ocol, T* __restrict__ oval,
-                                                             uint32_t ncols, const uint32_t* __restrict__ split, const SR sr) {
+                                                             uint32_t ncols, const uint32_t* __restrict__ split, const SR sr, uint32_t* __restrict__ rowctr,
+                                                             const uint32_t* __restrict__ bitmaps = nullptr, const uint32_t* __restrict__ bmslot = nullptr) {
   typedef typename acc_word<T>::type W;
   constexpr uint32_t WD = spa_cfg<T>::WD;
-  __shared__ W s_acc[WD];
-  __shared__ uint32_t s_flag[WD / 4];                  // one byte per column of the block: 1 = the accumulator holds a product.  (Round 4; a bitmap before: a read, a test and an
-                                                       //  atomic OR per product — an LDS latency in every combine, eight of them one after the other per batch.  A byte is a plain store.)
+  // One region, two uses (round 5).  DIRECT: WD accumulators + one flag byte per column of the block: 1 = the accumulator holds a product (round 4;
+  // a bitmap before: a read, a test and an atomic OR per product — an LDS latency in every combine, eight of them one after the other per batch.  A byte
+  // is a plain store).  RANKED: the row's bitmap of all ncols bits (kept by the symbolic pass), a 16-bit exclusive bit count per bitmap word (relative
+  // to the wave's chunk of words) and accumulators indexed by a column's RANK among the row's entries — a row of <= W2 entries is ONE step instead of
+  // one per block of columns (see "ranked rows" below).
+  constexpr uint32_t REGION = WD * (uint32_t)sizeof(W) + WD;
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[REGION];
+  W* const s_acc = (W*)s_raw;
+  uint32_t* const s_flag = (uint32_t*)(s_raw + (size_t)WD * sizeof(W));
   __shared__ T s_av[SPA_CHUNK];
   __shared__ uint32_t s_exc[1025], s_shift[SPA_CHUNK], s_wtot[16];
-  __shared__ uint32_t s_wsum[16];
+  __shared__ uint32_t s_wsum[16], s_woff[16], s_blk[SPA_RANK_MAXBLK + 2], s_next;
   const uint32_t t = threadIdx.x, lane = t & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
   const bool use_a = sr.uses_a(), use_b = sr.uses_u();
   const W idw = to_word<T>(sr.identity);
@@ -374,14 +396,118 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
 #else
   unsigned long long* const pf = nullptr;
 #endif
-  for (uint32_t e = t; e < WD; e += 1024) s_acc[e] = idw;
-  for (uint32_t w = t; w < WD / 4; w += 1024) s_flag[w] = 0;
-  __syncthreads();
   const uint32_t nblk = (uint32_t)(((uint64_t)ncols + WD - 1) / WD);
-  for (uint32_t ridx = blockIdx.x; ridx < a.nrows_bin; ridx += gridDim.x) {
+  // ---- ranked rows (round 5) ----------------------------------------------------------------------------------------------------------
+  // A (row, block) step costs ~18 000 clocks whatever it carries (four barriers, a memory latency, the emission), and 73 % of the rows beyond the
+  // tables of A@A on R-MAT-18 have <= 32 768 entries spread over all 16 blocks: ~1 000 products per step.  With the row's bitmap in LDS a column's
+  // place among the row's entries is  rank(j) = bits set below j  = chunk offset + 16-bit word prefix + popcount of the word's low bits — three LDS
+  // reads — and accumulators indexed by rank need as many slots as the step has ENTRIES, not columns: consecutive blocks are grouped while
+  // their entries fit the W2 accumulators the bitmap leaves room for (12 288 eight-byte ones at 2^18 columns), a row of <= W2 entries is one step,
+  // and the emission needs no scan (the ranks ARE the output positions).  A row one of whose blocks alone holds more than W2 entries (the hub
+  // rows: dense, many products per step already) takes the direct path.  The B-row boundaries are those of k_spa_split: a product is visited once.
+  const bool rank_call = bitmaps != nullptr;
+  const uint32_t words = (ncols + 31u) >> 5;
+  uint32_t wpt = 1, csh = 6; while (wpt * 1024u < words) { wpt <<= 1; csh++; }         // bitmap words per thread (<= 8), log2 of the words per wave
+  const uint32_t rk_off = (words * 6u + 15u) & ~15u;
+  uint32_t* const s_bits = (uint32_t*)s_raw; uint16_t* const s_pre = (uint16_t*)(s_raw + (size_t)words * 4);
+  W* const s_racc = (W*)(s_raw + rk_off); const uint32_t W2 = rank_call ? (REGION - rk_off) / (uint32_t)sizeof(W) : 0u;
+  constexpr uint32_t WB = WD / 32u; static_assert(WD % 32u == 0, "a block of columns is whole bitmap words");
+  bool racc_clean = false;
+  if (!rank_call) {
+    for (uint32_t e = t; e < WD; e += 1024) s_acc[e] = idw;
+    for (uint32_t w = t; w < WD / 4; w += 1024) s_flag[w] = 0;
+    __syncthreads();
+  }
+  uint32_t drawn = 0;
+  for (uint32_t ridx = blockIdx.x; ridx < a.nrows_bin; ridx = spa_next_row(&s_next, drawn)) {
+    if (t == 0) drawn = gridDim.x + atomicAdd(rowctr, 1u);
     const uint32_t i = a.rows[ridx];
     const uint32_t ab = a.arp[i], ae = a.arp[i + 1];
     uint32_t obase = a.crp[i];
+    if (rank_call) {
+      __syncthreads();                                                           // (the row before this one has read its bitmap to the end)
+      const uint32_t* const bm = bitmaps + (size_t)bmslot[i] * words;
+      uint32_t xs[8], run = 0;
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q++) { const uint32_t w = t * wpt + q; xs[q] = (q < wpt && w < words) ? bm[w] : 0u; }
+      uint32_t pl[8];
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q++) { pl[q] = run; run += (uint32_t)__popc(xs[q]); }
+      const uint32_t inc = spa_wave_incl_add(run), wexc = inc - run;
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q++) { const uint32_t w = t * wpt + q; if (q < wpt && w < words) { s_bits[w] = xs[q]; s_pre[w] = (uint16_t)(wexc + pl[q]); } }
+      if (lane == 63) s_wsum[wave] = inc;
+      __syncthreads();
+      uint32_t woff, rtotal, cpre;
+      spa_wave_offsets(s_wsum, lane, wave, woff, rtotal, cpre);
+      if (t < 16) s_woff[t] = cpre;                                              // entries of the row before wave t's words
+      __syncthreads();
+      if (t <= nblk) { const uint32_t w0 = t * WB; s_blk[t] = w0 < words ? s_woff[w0 >> csh] + s_pre[w0] : rtotal; }      // entries before block t
+      __syncthreads();
+      bool ranked = true;
+      for (uint32_t c = 0; c < nblk; c++) ranked = ranked && s_blk[c + 1] - s_blk[c] <= W2;
+      if (ranked) {
+        if (!racc_clean) { for (uint32_t e = t; e < W2; e += 1024) s_racc[e] = idw; racc_clean = true; }      // (the walk's barriers stand between this and the first atomic)
+        struct RProd { uint32_t col; T x; };
+        uint32_t rbase = 0;
+        auto rwalk = [&](uint32_t st, uint32_t len) __attribute__((always_inline)) -> uint32_t {
+          return spa_flat_walk(st, len, s_exc, s_shift, s_wtot,
+            [&](uint32_t v, uint32_t pb) { RProd p; p.col = a.bcol[pb]; p.x = sr.mult(use_a ? s_av[v] : T(), use_b ? bval[pb] : T()); return p; },
+            [&](const RProd& p) { const uint32_t w = p.col >> 5; const uint32_t bits = s_bits[w];
+                                  const uint32_t rk = s_woff[w >> csh] + s_pre[w] + (uint32_t)__popc(bits & ((1u << (p.col & 31u)) - 1u)) - rbase;
+                                  word_combine<T>(sr.add_op(), &s_racc[rk], p.x); });
+        };
+        // the entries of blocks [c0, c1): the threads walk their own bitmap words, the rank of a word's first bit is known — no scan, no barrier
+        auto remit = [&](uint32_t c0, uint32_t c1) __attribute__((always_inline)) {
+          const uint32_t wlo = c0 * WB, whi = c1 * WB < words ? c1 * WB : words;
+          for (uint32_t q = 0; q < wpt; q++) {
+            const uint32_t w = t * wpt + q;
+            if (w < wlo || w >= whi) continue;
+            uint32_t bits = s_bits[w];
+            uint32_t rk = s_woff[w >> csh] + s_pre[w];
+            while (bits) {
+              uint32_t bb[4]; bool hs4[4];
+#pragma unroll
+              for (int j = 0; j < 4; j++) { hs4[j] = bits != 0; bb[j] = hs4[j] ? (uint32_t)__builtin_ctz(bits) : 0u; bits &= bits - 1u; }
+              W acc4[4];
+#pragma unroll
+              for (int j = 0; j < 4; j++) acc4[j] = s_racc[(hs4[j] ? rk + j : rk) - rbase];
+#pragma unroll
+              for (int j = 0; j < 4; j++) if (hs4[j]) { ocol[obase + rk] = w * 32u + bb[j]; oval[obase + rk] = from_word<T>(acc4[j]); s_racc[rk - rbase] = idw; rk++; }
+            }
+          }
+        };
+        const bool one_chunk = ae - ab <= SPA_CHUNK;
+        const bool has = one_chunk && t < SPA_CHUNK && ab + t < ae;
+        const uint32_t* const sp0 = has ? split + (size_t)a.acol[ab + t] * (nblk + 1) : split;
+        if (has && use_a) s_av[t] = aval[ab + t];                                // (read by other threads only behind the walk's first barrier)
+        uint32_t c0 = 0, c1 = 1;
+        while (c1 < nblk && s_blk[c1 + 1] - s_blk[c0] <= W2) c1++;
+        uint32_t cur_st = sp0[0], cur_en = sp0[c1];
+        while (c0 < nblk) {
+          uint32_t n1 = c1 < nblk ? c1 + 1 : c1;                                 // the group after this one, its boundary loaded a step ahead
+          while (n1 < nblk && s_blk[n1 + 1] - s_blk[c1 < nblk ? c1 : c0] <= W2) n1++;
+          const uint32_t nxt_en = sp0[n1];
+          rbase = s_blk[c0];
+          if (s_blk[c1] - rbase) {                                               // (no entry in these blocks: no product either)
+            if (one_chunk) rwalk(cur_st, has ? cur_en - cur_st : 0u);
+            else for (uint32_t base = ab; base < ae; base += SPA_CHUNK) {
+              const uint32_t pa = base + t; uint32_t st = 0, len = 0;
+              if (t < SPA_CHUNK && pa < ae) { const uint32_t* sp = split + (size_t)a.acol[pa] * (nblk + 1); st = sp[c0]; len = sp[c1] - st; if (use_a) s_av[t] = aval[pa]; }
+              rwalk(st, len);
+            }
+            remit(c0, c1);
+          }
+          cur_st = cur_en; cur_en = nxt_en; c0 = c1; c1 = n1;
+        }
+        continue;
+      }
+      // a direct row between ranked ones: the region held a bitmap
+      for (uint32_t e = t; e < WD; e += 1024) s_acc[e] = idw;
+      for (uint32_t w = t; w < WD / 4; w += 1024) s_flag[w] = 0;
+      racc_clean = false;
+      __syncthreads();
+    }
     // one chunk of the row's entries (their A values in s_av) against block c (columns lo ...): returns the number of products
     struct Prod { uint32_t rel; T x; };
     auto walk = [&](uint32_t lo, uint32_t st, uint32_t len) __attribute__((always_inline)) -> uint32_t {
@@ -515,13 +641,26 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
   const bool no_spa = getenv("GRB_MI355X_SPGEMM_NO_SPA") != nullptr;             // measurement / test hook: the HBM accumulators of round 2
   const bool spa = !no_spa && (uint64_t)ncols <= 64ull * spa_cfg<T>::WD && (uint64_t)ncols <= 32ull * SPA_SYM_WORDS;
   // (with the LDS bitmap at hand it also counts the rows of 4097 ... 16 384 products: marking bits beats clearing and counting a 32 768-slot table per row)
-  hipLaunchKernelGGL(k_hash_bin5, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, ub.as<unsigned long long>(), 128ull, 1024ull, 4096ull, spa ? 4096ull : 16384ull, counts.as<uint32_t>(), lists.as<uint32_t>());
+  // ranked rows (k_spgemm_spa_numeric, round 5): possible when the row bitmap leaves room for accumulators beside it (<= 2/5 of the region: 2^18 columns)
+  // and the column range is <= 32 blocks.  A ranked row of <= W2 entries is ONE step of ~10 us, where the 8192-slot table took 60 us per row of 1025 ... 4096
+  // entries (6.6 ms of A@A on R-MAT-18, and its rows went through the staging arrays and the sort): with ranking the dense path takes every row beyond 1024
+  // products / entries.  GRB_MI355X_SPA_RANK=0: round 4's bins and kernel.
+  constexpr uint32_t WDc = spa_cfg<T>::WD; constexpr uint64_t REGIONc = (uint64_t)WDc * sizeof(W) + WDc;
+  const bool rank_env = !(getenv("GRB_MI355X_SPA_RANK") && atoi(getenv("GRB_MI355X_SPA_RANK")) == 0);      // (read per call: a test hook)
+  const bool rank_static = spa && rank_env && (uint64_t)((ncols + 31) / 32) * 6 <= REGIONc * 2 / 5 && ((uint64_t)ncols + WDc - 1) / WDc <= SPA_RANK_MAXBLK;
+  const unsigned long long big_from = rank_static ? 1024ull : 4096ull;
+  hipLaunchKernelGGL(k_hash_bin5, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, ub.as<unsigned long long>(), 128ull, 1024ull, big_from, spa ? big_from : 16384ull, counts.as<uint32_t>(), lists.as<uint32_t>());
   uint32_t hs[5];
   GRB_HIP(hipMemcpyAsync(hs, counts.p, 20, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
   const uint32_t words = (ncols + 31) / 32;
   // persistent workgroups of the dense paths: bounded by memory (bitmaps: ncols/8 bytes each; accumulators: ncols words each, <= 4 GiB in all)
   auto dense_blocks = [&](uint32_t rows, size_t per_block) { uint64_t fit = (4ull << 30) / (per_block ? per_block : 1); if (fit < 1) fit = 1; return (unsigned)std::min<uint64_t>(std::min<uint64_t>(rows, (uint64_t)ncu * 2), fit); };
   uint32_t hn[4] = {0, 0, 0, 0};
+  DevBuf bitmaps, bmslot, rowctr(64); bool ranked = false;
+  GRB_HIP(hipMemsetAsync(rowctr.p, 0, 64, stream()));
+  if (rank_static && hs[4] && (uint64_t)hs[4] * words * 4 <= (12ull << 30)) {      // (the bitmaps of every row beyond the tables: ncols / 8 bytes each, 3.8 GB for A@A on R-MAT-18)
+    bitmaps.alloc((size_t)hs[4] * words * 4 + 16); bmslot.alloc((size_t)nrows * 4 + 16); ranked = true;
+  }
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;
     HashArgs a{A.rowptr.as<uint32_t>(), A.col.as<uint32_t>(), B.rowptr.as<uint32_t>(), B.col.as<uint32_t>(), nullptr, 0, rownnz.as<uint32_t>(), nullptr, nullptr};
@@ -529,7 +668,8 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
     {
       DevBuf bm;
       if (hs[4] && spa) { a.rows = L + (size_t)4 * nrows; a.nrows_bin = hs[4];
-                          hipLaunchKernelGGL((k_spgemm_spa_symbolic<T, SR>), dim3(std::min<unsigned>(hs[4], (unsigned)ncu)), dim3(1024), 0, stream(), a, ncols); }
+                          hipLaunchKernelGGL((k_spgemm_spa_symbolic<T, SR>), dim3(std::min<unsigned>(hs[4], (unsigned)ncu)), dim3(1024), 0, stream(), a, ncols, rowctr.as<uint32_t>(),
+                                             ranked ? bitmaps.as<uint32_t>() : (uint32_t*)nullptr, ranked ? bmslot.as<uint32_t>() : (uint32_t*)nullptr); }
       else if (hs[4]) { const unsigned nb = dense_blocks(hs[4], (size_t)words * 4); bm.alloc((size_t)nb * words * 4); GRB_HIP(hipMemsetAsync(bm.p, 0, (size_t)nb * words * 4, stream()));
                    a.rows = L + (size_t)4 * nrows; a.nrows_bin = hs[4];
                    hipLaunchKernelGGL((k_spgemm_dense<T, SR, false>), dim3(nb), dim3(1024), 0, stream(), a, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, ncols, bm.as<uint32_t>(), (W*)nullptr, sr); }
@@ -541,7 +681,7 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
       // ---- row pointers, the size of T, numeric bins ---------------------------------------------------------------------------
       exclusive_scan_u32(rownnz.as<uint32_t>(), out.rowptr.as<uint32_t>(), (uint64_t)nrows + 1);
       GRB_HIP(hipMemsetAsync(counts.p, 0, 64, stream()));
-      hipLaunchKernelGGL(k_hash_bin, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, (const unsigned long long*)nullptr, rownnz.as<uint32_t>(), 128ull, 1024ull, 4096ull, counts.as<uint32_t>(), lists.as<uint32_t>());
+      hipLaunchKernelGGL(k_hash_bin, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, (const unsigned long long*)nullptr, rownnz.as<uint32_t>(), 128ull, 1024ull, big_from, counts.as<uint32_t>(), lists.as<uint32_t>());
       hipLaunchKernelGGL(k_hash_total, dim3(grid_n(nrows)), dim3(256), 0, stream(), rownnz.as<uint32_t>(), nrows, (unsigned long long*)(counts.as<uint8_t>() + 32));
       uint64_t hc[5] = {0, 0, 0, 0, 0};                                // four bin counts (u32 x 4) | - | the 64-bit total at byte 32
       GRB_HIP(hipMemcpyAsync(hc, counts.p, 40, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));   // (also: the bitmaps of the symbolic pass are idle now)
@@ -560,7 +700,7 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
         // rows (<= 4096 entries each) need the unordered staging arrays, the sort and the move: their own compact row pointers
         // (16 B of temporaries per entry of THOSE rows — the 47 GB of the R-MAT-18 A@A were 94 GB of allocations per call).
         DevBuf tcnt(((size_t)nrows + 1) * 4), trp(((size_t)nrows + 1) * 4);
-        hipLaunchKernelGGL(k_table_counts, dim3(grid_n(nrows + 1)), dim3(256), 0, stream(), nrows, rownnz.as<uint32_t>(), 4096u, tcnt.as<uint32_t>());
+        hipLaunchKernelGGL(k_table_counts, dim3(grid_n(nrows + 1)), dim3(256), 0, stream(), nrows, rownnz.as<uint32_t>(), (uint32_t)big_from, tcnt.as<uint32_t>());
         exclusive_scan_u32(tcnt.as<uint32_t>(), trp.as<uint32_t>(), (uint64_t)nrows + 1);
         uint32_t ttotal = 0;
         GRB_HIP(hipMemcpyAsync(&ttotal, trp.as<uint32_t>() + nrows, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
@@ -571,8 +711,8 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
           hipLaunchKernelGGL(k_spa_split, dim3(std::min<unsigned>((B.nrows + 3) / 4, 65535u)), dim3(256), 0, stream(), B.nrows, B.rowptr.as<uint32_t>(), B.col.as<uint32_t>(),
                              WD, nblk, split.as<uint32_t>());
           a.crp = out.rowptr.as<uint32_t>(); a.ccol = nullptr; a.rows = L + (size_t)3 * nrows; a.nrows_bin = hn[3];
-          hipLaunchKernelGGL((k_spgemm_spa_numeric<T, SR>), dim3(std::min<unsigned>(hn[3], (unsigned)ncu * 2)), dim3(1024), 0, stream(), a, av, bv, out.col.as<uint32_t>(), out.val.as<T>(), ncols,
-                             split.as<uint32_t>(), sr);
+          hipLaunchKernelGGL((k_spgemm_spa_numeric<T, SR>), dim3(std::min<unsigned>(hn[3], (unsigned)ncu)), dim3(1024), 0, stream(), a, av, bv, out.col.as<uint32_t>(), out.val.as<T>(), ncols,
+                             split.as<uint32_t>(), sr, rowctr.as<uint32_t>() + 1, ranked ? bitmaps.as<uint32_t>() : (const uint32_t*)nullptr, ranked ? bmslot.as<uint32_t>() : (const uint32_t*)nullptr);
         }
         if (ttotal) {
           DevBuf ucol((size_t)ttotal * 4 + 8), uval((size_t)ttotal * sizeof(T) + 8), scol((size_t)ttotal * 4 + 8), perm0((size_t)ttotal * 4 + 8), perm((size_t)ttotal * 4 + 8);
@@ -615,7 +755,7 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
       }
     }
     g_last_plan += std::string("spgemm_hash<") + (sr.is_static ? "static" : "dynamic") + "> symbolic bins " + std::to_string(hs[0]) + "/" + std::to_string(hs[1]) + "/" + std::to_string(hs[2]) + "/" +
-                   std::to_string(hs[3]) + "/" + std::to_string(hs[4]) + " numeric bins " + std::to_string(hn[0]) + "/" + std::to_string(hn[1]) + "/" + std::to_string(hn[2]) + "/" + std::to_string(hn[3]) + " ";
+                   std::to_string(hs[3]) + "/" + std::to_string(hs[4]) + " numeric bins " + std::to_string(hn[0]) + "/" + std::to_string(hn[1]) + "/" + std::to_string(hn[2]) + "/" + std::to_string(hn[3]) + (ranked ? " ranked " : " ");
   });
   out.valid = true;
 }

@@ -230,7 +230,12 @@ def test_two_pass_hash_spgemm_every_bin_against_expand_sort_compress(gpu, typ, s
     assert "spgemm_esc" in gb.last_kernel_plan()
     monkeypatch.setenv("GRB_MI355X_SPGEMM", "hash")
     ei, ej, ex = E.to_arrays()
-    for no_spa in (False, True):             # rows beyond the tables: the dense accumulator in LDS (column blocks, in-order emission) / in HBM (round 2)
+    # rows beyond the tables: the dense accumulator in LDS with ranked rows (round 5: accumulators indexed by a column's rank in the row's bitmap; the dense
+    # path then takes every row beyond 1024 entries) / in LDS by column blocks only (round 4) / in HBM (round 2)
+    for mode in ("ranked", "blocks", "hbm"):
+        no_spa = mode == "hbm"
+        if mode == "blocks":
+            monkeypatch.setenv("GRB_MI355X_SPA_RANK", "0")
         if no_spa:
             monkeypatch.setenv("GRB_MI355X_SPGEMM_NO_SPA", "1")
         H = A.mxm(A, semiring=getattr(TYPE[typ], sr))
@@ -238,9 +243,12 @@ def test_two_pass_hash_spgemm_every_bin_against_expand_sort_compress(gpu, typ, s
         assert "spgemm_hash" in plan
         sym = [int(x) for x in plan.split("symbolic bins ")[1].split()[0].split("/")]
         num = [int(x) for x in plan.split("numeric bins ")[1].split()[0].split("/")]
-        # (with the LDS dense path its bitmap also counts the rows of 4097 ... 16 384 products: the 32 768-slot table stays empty)
-        assert all(x > 0 for k, x in enumerate(sym) if no_spa or k != 3) and all(x > 0 for x in num), plan
-        assert (sym[3] > 0) == no_spa, plan
+        if mode == "ranked":
+            assert " ranked" in plan and sym[0] > 0 and sym[1] > 0 and sym[2] == 0 and sym[3] == 0 and sym[4] > 0 and num[0] > 0 and num[1] > 0 and num[2] == 0 and num[3] > 0, plan
+        else:
+            # (with the LDS dense path its bitmap also counts the rows of 4097 ... 16 384 products: the 32 768-slot table stays empty)
+            assert " ranked" not in plan and all(x > 0 for k, x in enumerate(sym) if no_spa or k != 3) and all(x > 0 for x in num), plan
+            assert (sym[3] > 0) == no_spa, plan
         hi_, hj, hx = H.to_arrays()
         assert np.array_equal(ei, hi_) and np.array_equal(ej, hj), (plan, no_spa)
         if typ.startswith("FP"):
@@ -249,8 +257,9 @@ def test_two_pass_hash_spgemm_every_bin_against_expand_sort_compress(gpu, typ, s
             assert np.array_equal(hx, ex), (plan, no_spa)
 
 
+@pytest.mark.parametrize("ranked", ["1", "0"])
 @pytest.mark.parametrize("typ,sr", [("INT64", "PLUS_TIMES"), ("FP32", "MIN_PLUS"), ("FP64", "PLUS_TIMES")])
-def test_hash_spgemm_wide_rows_through_many_column_blocks(gpu, typ, sr, monkeypatch):
+def test_hash_spgemm_wide_rows_through_many_column_blocks(gpu, typ, sr, ranked, monkeypatch):
     """Rows of the result with tens of thousands of entries over 70 000 columns: the LDS dense accumulator walks 5 (8-byte: 16 384 columns each) / 3
     (4-byte: 28 672) column blocks per row with its cursors into the B rows; empty blocks, B rows that end inside a block, a last
     partial block.  Against expand / sort / compress."""
@@ -266,10 +275,11 @@ def test_hash_spgemm_wide_rows_through_many_column_blocks(gpu, typ, sr, monkeypa
     monkeypatch.setenv("GRB_MI355X_SPGEMM", "esc")
     E = A.mxm(B, semiring=getattr(TYPE[typ], sr))
     monkeypatch.setenv("GRB_MI355X_SPGEMM", "hash")
+    monkeypatch.setenv("GRB_MI355X_SPA_RANK", ranked)                                # ranked rows (blocks grouped while their entries fit the accumulators) / one step per block
     H = A.mxm(B, semiring=getattr(TYPE[typ], sr))
     plan = gb.last_kernel_plan()
     num = [int(x) for x in plan.split("numeric bins ")[1].split()[0].split("/")]
-    assert num[3] > 100, plan
+    assert num[3] > 100 and (" ranked" in plan) == (ranked == "1"), plan
     ei, ej, ex = E.to_arrays(); hi_, hj, hx = H.to_arrays()
     assert np.array_equal(ei, hi_) and np.array_equal(ej, hj), plan
     if typ.startswith("FP"):

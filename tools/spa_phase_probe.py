@@ -18,6 +18,8 @@ rc = lib.GrBX_spa_prof_read_double(buf.ctypes.data_as(C.c_void_p))
 p = buf.reshape(1024, 16)[:512].astype(np.float64); p = p[p[:, 7] > 0]
 names = ["scan+2 barriers", "rounds (thread 0's wave)", "wait for the other waves", "bitmap scan + 2 barriers", "emission", "last barrier"]
 tot = p[:, 7].mean()
-print(json.dumps({"seconds": round(sec, 4), "workgroups": len(p), "kernel_clocks_mean": tot, "steps_with_products": p[:, 6].mean(), "steps_without": p[:, 8].mean(),
+phases = p[:, :6].sum(axis=1)
+print(json.dumps({"seconds": round(sec, 4), "workgroups": len(p), "kernel_clocks_mean": tot, "kernel_clocks_min": p[:, 7].min(), "kernel_clocks_max": p[:, 7].max(),
+                  "direct_phase_clocks_mean (the rest of a workgroup's time is its ranked rows and row set-up)": phases.mean(), "steps_with_products": p[:, 6].mean(), "steps_without": p[:, 8].mean(),
                   "share": {n: round(p[:, k].mean() / tot, 4) for k, n in enumerate(names)},
                   "clocks_per_step": {n: round(p[:, k].sum() / p[:, 6].sum(), 1) for k, n in enumerate(names)}, "plan": gb.last_kernel_plan()}))
