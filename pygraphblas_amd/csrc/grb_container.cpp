@@ -252,7 +252,12 @@ void vec_to_device(GrB_Vector v) {
       v->small_idx.assign(k, 0); bool truthy = true;
       for (uint32_t e = 0; e < k; e++) {
         v->small_idx[e] = (uint32_t)v->hi[e];
-        bool nz = false; for (size_t b = 0; b < ts; b++) nz = nz || v->hx[(size_t)e * ts + b] != 0;
+        // truth as the mask kernels test it — value != 0 in the vector's type: the bytes of an FP -0.0 are not all zero, the value is false
+        bool nz = false;
+        const uint8_t* px = &v->hx[(size_t)e * ts];
+        if (v->type->code == T_FP32) { float f; memcpy(&f, px, 4); nz = f != 0.0f; }
+        else if (v->type->code == T_FP64) { double f; memcpy(&f, px, 8); nz = f != 0.0; }
+        else for (size_t b = 0; b < ts; b++) nz = nz || px[b] != 0;
         truthy = truthy && nz;
       }
       v->small_valid = true; v->small_truthy = truthy;

@@ -109,6 +109,7 @@ bool nccl_type(int code, ncclDataType_t* t) {
   }
 }
 }  // namespace
+namespace grb { bool dist_exchange_pending() { return g_pending; } }      // an exchange is writing into a vector's buffers on the second stream (grb_mxv.cpp: no in-place writes into operands meanwhile)
 
 extern "C" {
 

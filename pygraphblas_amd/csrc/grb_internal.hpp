@@ -213,6 +213,7 @@ inline void vec_gate(GrB_Vector v) { if (v->lazy | v->q_reads) vec_resolve(v); }
 void vec_overwritten(GrB_Vector v);       // v's value is about to be replaced as a whole: deferred work that only produced it is dropped
 uint32_t* any_true_acquire(uint32_t* tag);        // a device word a BOOL product kernel sets to the (fresh, non-zero) tag when it writes a true value (see lor_state)
 void any_true_written(GrB_Vector w_or_null, const void* key, uint32_t tag, uint64_t fe_key = 0, uint32_t fe_nblocks = 0);    // a kernel honoured it; w's device buffers `key` are the result it describes (nullptr: nobody's); fe_key != 0: the kernel also filled the edge summary (counted in the row pointers with that serial)
+bool dist_exchange_pending();                   // grb_dist.cpp: GrBX_Vector_allgatherv_start without its GrBX_dist_wait yet
 unsigned long long* fe_summary_host();      // SpmvCall::fe_host: the page-locked pairs of the result summary (device address), for the product that just called any_true_acquire
 bool any_true_lookup(GrB_Vector u, bool* value);
 bool nonblocking();                       // GrB_init(GrB_NONBLOCKING) and not GRB_MI355X_BLOCKING=1

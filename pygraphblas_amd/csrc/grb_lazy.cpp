@@ -49,6 +49,7 @@ struct Node {
 std::vector<Node> g_q;
 int g_q_type = -1; uint64_t g_q_n = 0;
 bool g_flushing = false;
+bool g_q_kept = false;          // the queue as it stands was already run once for a reduction only (run_queue(keep)): a second reduction of it stores
 std::recursive_mutex g_mu;
 uint64_t g_stat_chains = 0, g_stat_nodes = 0, g_stat_fills_folded = 0, g_stat_reduces_fused = 0;
 
@@ -70,7 +71,7 @@ void run_queue(const ChainReduce* red, void* red_result, bool keep = false) {
     ~Restore() {
       g_flushing = false;
       if (!committed) { release_reads(); for (auto& nd : g_q) if (nd.out && nd.out->lazy == 2) { GrB_Vector w = nd.out; w->lazy = 0; if (!w->dev_valid) { w->hi.clear(); w->hx.clear(); w->pending.clear(); w->host_valid = true; } }      // (a result that never had buffers: empty, as after a failed call)
-        g_q.clear(); g_q_type = -1; g_q_n = 0; }
+        g_q.clear(); g_q_type = -1; g_q_n = 0; g_q_kept = false; }
     }
   } restore;
   ChainLaunch L{};
@@ -119,9 +120,11 @@ void run_queue(const ChainReduce* red, void* red_result, bool keep = false) {
   L.nout = (int)outs.size();
   if (red) L.red = *red;
   vec_chain_launch(L, red_result);
-  g_stat_chains++; g_stat_nodes += g_q.size(); if (red) g_stat_reduces_fused++;
+  g_stat_chains++; if (red) g_stat_reduces_fused++;
+  if (!g_q_kept) g_stat_nodes += g_q.size();                     // (the operations of a kept queue are counted once, whichever run stores them)
   restore.committed = true;
-  if (keep) return;
+  if (keep) { g_q_kept = true; return; }
+  g_q_kept = false;
   release_reads();
   for (size_t o = 0; o < outs.size(); o++) {
     GrB_Vector w = outs[o];
@@ -166,6 +169,7 @@ static void prune_queue() {
     else for (int k = 0; k < 2; k++) if (g_q[i].in[k] && g_q[i].in[k]->q_reads) g_q[i].in[k]->q_reads--;
   }
   g_q.resize(w);
+  if (g_q.size() != need.size()) g_q_kept = false;                 // (a pruned queue is another queue)
   if (g_q.empty()) { g_q_type = -1; g_q_n = 0; }
 }
 
@@ -236,7 +240,7 @@ static bool enqueue(Node nd, GrB_Vector w, int tcode) {
   w->fe_lb = 0; w->fe_lb_key = 0; w->lor_state = 0; w->abs_bound = -1; w->small_valid = false;
   w->lazy = 2;
   nd.out = w;
-  g_q.push_back(nd); g_q_type = tcode; g_q_n = n;
+  g_q.push_back(nd); g_q_type = tcode; g_q_n = n; g_q_kept = false;
   return true;
 }
 
@@ -278,7 +282,8 @@ bool lazy_reduce(GrB_Vector u, int mop, int mcode, const void* identity, void* r
   if (!(mop == B_PLUS || mop == B_MIN || mop == B_MAX || mop == B_TIMES || mop == B_LOR || mop == B_LAND || mop == B_LXOR || mop == B_ANY)) return false;
   if (tc == T_BOOL && !(mop == B_LOR || mop == B_LAND || mop == B_LXOR)) return false;
   ChainReduce r{}; r.on = 1; r.op = mop; r.widen = widen ? 1 : 0; memcpy(r.identity, identity, 16);
-  run_queue(&r, result_in_mcode, may_keep && !g_env_store_reduced());
+  // (a queue that was already run for a reduction and is reduced AGAIN — a norm, then another look — stores this time: a third pass is the most it costs)
+  run_queue(&r, result_in_mcode, may_keep && !g_env_store_reduced() && !g_q_kept);
   return true;
 }
 

@@ -209,7 +209,9 @@ void do_reduce_vector(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Mon
     //  bits depending on whether an earlier operation happened to build the transpose)
     const int rop = monoid->op->opcode;
     const bool order_free = !(mc == T_FP32 || mc == T_FP64) || rop == B_MIN || rop == B_MAX || rop == B_ANY;
-    if (!A->csc.valid && A->csr.nnz >= (1u << 20) && !order_free && A->csr.nrows <= 64) {      // a few long rows (a batch of the BC sweeps): row after row, no atomics, fixed order
+    // (taken WHETHER OR NOT a cached transpose exists: its row reduction adds in another order, and the same call must not return other bits because an
+    //  earlier product happened to build the transpose)
+    if (A->csr.nnz >= (1u << 20) && !order_free && A->csr.nrows <= 64) {      // a few long rows (a batch of the BC sweeps): row after row, no atomics, fixed order
       const void* av = cast_values(mc, A->type->code, A->csr.val.p, A->csr.nnz, ac);
       done = csr_reduce_cols_few_rows(mc, A->csr, av, rop, tval.p, tpres.as<uint8_t>());
     }

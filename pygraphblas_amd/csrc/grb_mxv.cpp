@@ -179,11 +179,18 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
     // the fill goes into u's OWN buffer (the values of absent positions are nobody's business: holes_zero is dropped) and is remembered: the
     // sweeps of the shortest-path loop only add entries — real values, written by the merge's store — so from the second sweep on the operand
     // is ready as it stands (a cast-and-fill pass over the vector per sweep before: 18 us of 357 at R-MAT-22)
-    if (!(u->holes_big && memcmp(u->holes_big_val, big_fill, zs) == 0)) {
+    // (the operand is an INPUT: its stored entries never change, only the bytes behind its holes do — a write all the same.  Not while queued work
+    //  still reads the vector, nor while an exchange writes into vector buffers on the second stream: then the fill goes into a copy, as before round 4)
+    if (u->holes_big && memcmp(u->holes_big_val, big_fill, zs) == 0) uval = u->dval.p;
+    else if (u->q_reads || dist_exchange_pending()) {
+      ucast.alloc(u->n * zs + 1);
+      vec_cast_fill_values(sd.zcode, ucast.p, u->type->code, u->dval.p, u->dpres.as<uint8_t>(), u->n, big_fill);
+      uval = ucast.p;
+    } else {
       vec_cast_fill_values(sd.zcode, u->dval.p, u->type->code, u->dval.p, u->dpres.as<uint8_t>(), u->n, big_fill);      // (same type: big_holes requires it; element-wise, in place)
       u->holes_zero = false; u->holes_big = true; memcpy(u->holes_big_val, big_fill, 16);
+      uval = u->dval.p;
     }
-    uval = u->dval.p;
   } else if (uses_u && fill_holes) {
     ucast.alloc(u->n * zs + 1);
     vec_cast_fill_values(sd.zcode, ucast.p, u->type->code, u->dval.p, u->dpres.as<uint8_t>(), u->n, sd.identity);   // (identity of PLUS / LOR is the 0 / false the two other cases need)

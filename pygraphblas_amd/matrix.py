@@ -644,6 +644,40 @@ class Matrix:
         check(lib.GrB_Matrix_apply(out._h, mh, ah, C.c_void_p(op.get_op()), self._h, dh), out)
         return out
 
+    def apply_first(self, first, op, out=None, mask=None, accum=None, desc=None):
+        """`op(first, A(i,j))` with a bound scalar (reference: pygraphblas/matrix.py:1965-2005)."""
+        if out is None:
+            out = Matrix.sparse(self.type, self.nrows, self.ncols)
+        mh, ah, dh = get_args(mask, accum, desc)
+        fn = getattr(lib, "GxB_Matrix_apply_BinaryOp1st_" + self.type.__name__)
+        check(fn(out._h, mh, ah, C.c_void_p(op.get_op()), self.type._c(first), self._h, dh), out)
+        return out
+
+    def apply_second(self, op, second, out=None, mask=None, accum=None, desc=None):
+        """`op(A(i,j), second)` with a bound scalar (reference: pygraphblas/matrix.py:2007-2040)."""
+        if out is None:
+            out = Matrix.sparse(self.type, self.nrows, self.ncols)
+        mh, ah, dh = get_args(mask, accum, desc)
+        fn = getattr(lib, "GxB_Matrix_apply_BinaryOp2nd_" + self.type.__name__)
+        check(fn(out._h, mh, ah, C.c_void_p(op.get_op()), self._h, self.type._c(second), dh), out)
+        return out
+
+    def cast(self, cast, out=None):
+        """The same entries in another type (reference: pygraphblas/matrix.py:1063-1086)."""
+        if out is None:
+            out = Matrix.sparse(cast, self.nrows, self.ncols)
+        check(lib.GrB_Matrix_apply(out._h, None, None, C.c_void_p(cast.IDENTITY.get_op()), self._h, None), out)
+        return out
+
+    def __neg__(self):
+        return self.apply(self.type.AINV)
+
+    def __abs__(self):
+        return self.apply(self.type.ABS)
+
+    def __invert__(self):
+        return self.apply(self.type.MINV)
+
     def assign_matrix(self, value, rindex=None, cindex=None, mask=None, accum=None, desc=None):
         """`C(I,J)<mask> = accum(C(I,J), value)` (reference: pygraphblas/matrix.py:3057-3130); index lists or None for all."""
         mh, ah, dh = get_args(mask, accum, desc)

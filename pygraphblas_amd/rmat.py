@@ -191,3 +191,26 @@ def values_torch(nnz, device, seed=43, dtype=None):
     h = z ^ _lsr(z, 31)
     v = _lsr(h, 11).to(torch.float64) * (1.0 / (1 << 53))
     return v if dtype is None else v.to(dtype)
+
+
+def csr_numpy_pcg64(scale, seed=42, edgefactor=16, symmetric=False, drop_self_loops=False, lower=False):
+    """The graph of SURVEY.md §8d, to the letter: `numpy.random.Generator(PCG64(seed))`, one `random(m)` draw of doubles per bit level
+    (levels outer, edges vectorised inner), u in [0, 1): i_bit = u >= a + b;  j_bit = (a <= u < a + b) or (u >= a + b + c);  bit level l sets bit l;
+    no relabelling; duplicates collapse to one entry.  Same distribution as the counter-based stream above, a different graph (that one can be
+    generated slice by slice in HBM, which the row-partitioned runs need; this one is a sequential stream) — kept so that the headline can be shown
+    not to depend on the generator (tests/test_baseline_configs_gpu.py).  Returns (rowptr uint32[n + 1], col uint32[nnz])."""
+    n = 1 << scale; m = edgefactor << scale
+    a, b, c = 0.57, 0.19, 0.19
+    rng = np.random.Generator(np.random.PCG64(seed))
+    src = np.zeros(m, np.uint64); dst = np.zeros(m, np.uint64)
+    for lvl in range(scale):
+        u = rng.random(m)
+        src |= (u >= a + b).astype(np.uint64) << np.uint64(lvl)
+        dst |= (((u >= a) & (u < a + b)) | (u >= a + b + c)).astype(np.uint64) << np.uint64(lvl)
+        del u
+    return _finish_numpy(src, dst, n, symmetric, drop_self_loops, lower, None)
+
+
+def values_numpy_pcg64(nnz, seed=43):
+    """`Generator(PCG64(43)).random(nnz)` for the matrix values, seed 44 for the operand."""
+    return np.random.Generator(np.random.PCG64(seed)).random(nnz)

@@ -305,6 +305,43 @@ class Vector:
         check(fn(out._h, mh, ah, C.c_void_p(op.get_op()), self.type._c(first), self._h, dh), out)
         return out
 
+    def select(self, op, thunk=None, out=None, mask=None, accum=None, desc=None):
+        """`GxB_Vector_select` with a built-in select operator name ("NONZERO", ">", ...) (reference: pygraphblas/vector.py:1354-1404)."""
+        opname = {"nonzero": "NONZERO", "!=0": "NONZERO", "==0": "EQ_ZERO", ">0": "GT_ZERO", ">=0": "GE_ZERO", "<0": "LT_ZERO", "<=0": "LE_ZERO",
+                  "!=": "NE_THUNK", "==": "EQ_THUNK", ">": "GT_THUNK", ">=": "GE_THUNK", "<": "LT_THUNK", "<=": "LE_THUNK"}.get(op, op)
+        if out is None:
+            out = Vector.sparse(self.type, self.size)
+        th = None
+        if thunk is not None:
+            th = C.c_void_p()
+            check(lib.GxB_Scalar_new(C.byref(th), C.c_void_p(self.type._h)))
+            check(getattr(lib, "GxB_Scalar_setElement_" + self.type.__name__)(th, self.type._c(thunk)))
+        mh, ah, dh = get_args(mask, accum, desc)
+        try:
+            check(lib.GxB_Vector_select(out._h, mh, ah, C.c_void_p(_capi.handle("GxB_" + opname)), self._h, th, dh), out)
+        finally:
+            if th is not None:
+                lib.GxB_Scalar_free(C.byref(th))
+        return out
+
+    def nonzero(self):
+        return self.select("NONZERO")
+
+    def pattern(self, typ=types.BOOL):
+        """The structure of the vector as a vector of ones (reference: pygraphblas/vector.py:1406-1425)."""
+        out = Vector.sparse(typ, self.size)
+        check(lib.GrB_Vector_apply(out._h, None, None, C.c_void_p(typ.ONE.get_op()), self._h, None), out)
+        return out
+
+    def cast(self, cast, out=None):
+        if out is None:
+            out = Vector.sparse(cast, self.size)
+        check(lib.GrB_Vector_apply(out._h, None, None, C.c_void_p(cast.IDENTITY.get_op()), self._h, None), out)
+        return out
+
+    def __invert__(self):
+        return self.apply(self.type.MINV)
+
     # ---- operators (reference: pygraphblas/vector.py:982-1076): vector operands -> eadd / emult, scalars -> bound apply
     def _binop(self, other, opname, union, out=None, reverse=False):
         op = getattr(self.type, opname)

@@ -317,3 +317,22 @@ def test_column_reduce_and_element_access_of_a_large_device_matrix(gpu):
     free = next(c for c in range(n) if not ((I == 0) & (J == c)).any())
     S2[0, free] = 9                                             # a new entry: the host mirror takes over
     assert S2[0, free] == 9 and S2.nvals == len(key) + 1 and S2[i0, j0] == 5
+
+
+def test_column_reduce_of_a_few_long_fp_rows_does_not_depend_on_a_cached_transpose(gpu):
+    """`reduce_vector(desc=T0)` with an FP PLUS monoid over a batch of <= 64 long rows (the last statement of gap/bcmark.py:66): one fixed-order algorithm
+    whatever the matrix has cached — the same call returned other bits after an earlier product had built the transpose (round-4 advice)."""
+    rng = np.random.default_rng(31)
+    nr, nc = 4, 1 << 19
+    keep = rng.random((nr, nc)) < 0.6
+    I, J = np.nonzero(keep)
+    X = rng.random(len(I)).astype(np.float32)
+    assert len(I) >= 1 << 20
+    A = gb.Matrix.from_arrays(I.astype(np.uint64), J.astype(np.uint64), X, nr, nc, gb.FP32)
+    r1 = A.reduce_vector(gb.FP32.PLUS_MONOID, desc=D.T0).to_arrays()
+    u = gb.Vector.from_dense_array(np.ones(nr, np.float32), gb.FP32)
+    A.mxv(u, semiring=gb.FP32.PLUS_TIMES, desc=D.T0)                       # builds and caches the transpose
+    r2 = A.reduce_vector(gb.FP32.PLUS_MONOID, desc=D.T0).to_arrays()
+    assert np.array_equal(r1[0], r2[0]) and np.array_equal(r1[1].view(np.uint32), r2[1].view(np.uint32))
+    want = np.zeros(nc, np.float64); np.add.at(want, J, X.astype(np.float64))
+    assert np.allclose(r1[1], want[r1[0].astype(np.int64)], rtol=1e-5)
