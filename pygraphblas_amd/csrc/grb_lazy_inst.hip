@@ -197,7 +197,10 @@ __global__ __launch_bounds__(256) void k_vec_chain(const ChainK<T> a, const R ri
   if constexpr (RED != 0) {
     // lanes -> wave -> workgroup -> one partial per workgroup; a one-workgroup k_chain_final folds the partials in index order (a fixed
     // tree: the result does not depend on the order the workgroups ran in).  (Folding them in the last workgroup to finish, behind
-    // an agent-scope fence and a ticket, made every workgroup write back its XCD's L2 in the middle of the stores: 102 us.)
+    // an agent-scope fence and a ticket, made every workgroup write back its XCD's L2 in the middle of the stores: 102 us.  Round 5: the
+    // workgroups storing their partials as tagged words straight into page-locked host memory, on which the caller spins — what the BFS's
+    // `reduce_bool` does with 256 words, grb_container.cpp — made a PageRank iteration at R-MAT-22 0.171 -> 0.186 ms: 2 x 1024 small
+    // writes across PCIe at the end of a 13 us kernel cost more than the copy + synchronise they replace.)
     __shared__ R sh[4];
     racc = wave_reduce_op<R, false>(a.red_op, racc);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = racc;

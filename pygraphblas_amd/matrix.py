@@ -601,8 +601,11 @@ class Matrix:
 
     # ---- companions of the hot path -------------------------------------------------------------------------
     def transpose(self, cast=None, out=None, mask=None, accum=None, desc=None):
+        """`GrB_transpose`; with desc T0 the input is transposed first, so the result has the matrix's own shape (reference: pygraphblas/matrix.py:1003-1061,
+        pinned by tests/test_matrix.py:324-325)."""
         if out is None:
-            out = Matrix.sparse(cast or self.type, self.ncols, self.nrows)
+            t0 = desc is not None and _d.T0 in desc
+            out = Matrix.sparse(cast or self.type, *((self.nrows, self.ncols) if t0 else (self.ncols, self.nrows)))
         mh, ah, dh = get_args(mask, accum, desc)
         check(lib.GrB_transpose(out._h, mh, ah, self._h, dh), out)
         return out

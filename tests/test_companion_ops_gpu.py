@@ -329,10 +329,10 @@ def test_column_reduce_of_a_few_long_fp_rows_does_not_depend_on_a_cached_transpo
     X = rng.random(len(I)).astype(np.float32)
     assert len(I) >= 1 << 20
     A = gb.Matrix.from_arrays(I.astype(np.uint64), J.astype(np.uint64), X, nr, nc, gb.FP32)
-    r1 = A.reduce_vector(gb.FP32.PLUS_MONOID, desc=D.T0).to_arrays()
+    r1 = A.reduce_vector(gb.FP32.PLUS_MONOID, out=gb.Vector.sparse(gb.FP32, nc), desc=D.T0).to_arrays()
     u = gb.Vector.from_dense_array(np.ones(nr, np.float32), gb.FP32)
     A.mxv(u, semiring=gb.FP32.PLUS_TIMES, desc=D.T0)                       # builds and caches the transpose
-    r2 = A.reduce_vector(gb.FP32.PLUS_MONOID, desc=D.T0).to_arrays()
+    r2 = A.reduce_vector(gb.FP32.PLUS_MONOID, out=gb.Vector.sparse(gb.FP32, nc), desc=D.T0).to_arrays()
     assert np.array_equal(r1[0], r2[0]) and np.array_equal(r1[1].view(np.uint32), r2[1].view(np.uint32))
     want = np.zeros(nc, np.float64); np.add.at(want, J, X.astype(np.float64))
     assert np.allclose(r1[1], want[r1[0].astype(np.int64)], rtol=1e-5)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, GPU session 1: full GPU suite, BFS timeline, bench line
 set -u
-out=gpurun_out/r5a; mkdir -p "$out"
+out=gpurun_out/${1:-r5a}; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 timeout 900 python -m pytest tests -m gpu -x -q --timeout 600 --durations=6 > "$out/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$out/pytest_gpu.log"
 tail -12 "$out/pytest_gpu.log"
