@@ -25,6 +25,7 @@ struct SpgemmCall {
   const DevCSR* A; const void* aval;     // values already in the semiring type (nullptr: multiply ignores them)
   const DevCSR* B; const void* bval;
   const DevCSR* M; int mcode; bool mstruct;   // non-complemented mask for the masked kernel (nullptr otherwise)
+  bool ordered = false;                       // spgemm_hash: floating-point sums in a fixed order (GRB_MI355X_DETERMINISTIC=1 / GxB_AxB_GUSTAVSON)
 };
 // T<M> = A (+).(x) B restricted to the entries the mask allows; T's pattern is a subset of M's
 void spgemm_masked(const SpgemmCall& c, const SemiringDesc& d, DevCSR& out);

@@ -265,7 +265,11 @@ __device__ __forceinline__ void spa_wave_offsets(const uint32_t* s_w, uint32_t l
   total = (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
   woff = (uint32_t)__builtin_amdgcn_readlane((int)pre, (int)wave);
 }
-template <class L, class A> __device__ __forceinline__ uint32_t spa_flat_walk(uint32_t st, uint32_t len, uint32_t* s_exc /* [1025] */, uint32_t* s_shift /* [1024] */, uint32_t* s_wtot /* [16] */, L&& load, A&& apply, unsigned long long* pf = nullptr) {
+// `ordered` (round 5, the library's deterministic mode — GRB_MI355X_DETERMINISTIC=1 or the descriptor's GxB_AxB_GUSTAVSON): the sixteen waves combine their
+// batches ONE AFTER THE OTHER, in wave order, behind a barrier each — the products of a batch are dealt to lanes and rounds statically and a wave's LDS
+// atomics execute in program order, so every accumulator receives its terms in the same order in every run and a floating-point sum is reproducible bit
+// for bit; what it costs is the sixteen barriers per 8 192 products (A@A on R-MAT-18: see DESIGN.md).  Without it the waves' atomics land as they come.
+template <bool ordered = false, class L, class A> __device__ __forceinline__ uint32_t spa_flat_walk(uint32_t st, uint32_t len, uint32_t* s_exc /* [1025] */, uint32_t* s_shift /* [1024] */, uint32_t* s_wtot /* [16] */, L&& load, A&& apply, unsigned long long* pf = nullptr) {
   const uint32_t t = threadIdx.x, lane = t & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
   const uint32_t inc = spa_wave_incl_add(len);
   if (lane == 63) s_wtot[wave] = inc;
@@ -285,7 +289,12 @@ template <class L, class A> __device__ __forceinline__ uint32_t spa_flat_walk(ui
   };
   uint32_t rpb = (total + 1023u) >> 10; rpb = rpb < 1u ? 1u : (rpb > (uint32_t)SPA_R ? (uint32_t)SPA_R : rpb);      // rounds per batch: one batch per wave while that fits
   const uint32_t bsz = 64u * rpb, nb = (total + bsz - 1u) / bsz;
-  for (uint32_t b = wave; b < nb; b += 16u) {
+  for (uint32_t b0 = 0; b0 < nb; b0 += 16u) {
+    const uint32_t b = b0 + wave;
+    if (b >= nb) {                                           // (its batches are b = wave, wave + 16, ...: none left)
+      if constexpr (ordered) { for (uint32_t w = 0; w < 16u; w++) __syncthreads(); continue; }      // ordered: this wave keeps the others company at their barriers
+      else break;
+    }
     const uint32_t qb = b * bsz, qe = qb + bsz < total ? qb + bsz : total;
     const uint32_t vbase = entry_of(qb), vlast = entry_of(qe - 1u);
     uint32_t q[SPA_R], vlo[SPA_R], vhi[SPA_R];
@@ -305,8 +314,18 @@ template <class L, class A> __device__ __forceinline__ uint32_t spa_flat_walk(ui
     for (int r = 0; r < SPA_R; r++) item[r] = load(vlo[r], pb[r]);
     // (the bitmap words are read round by round, not together before the batch's atomics: a hub's part sets the bits of its 32-column
     //  words in its first round and the later rounds see them — reading all of them first meant more same-word atomics: 56.9 -> 61.1 ms)
+    if constexpr (!ordered) {
 #pragma unroll
-    for (int r = 0; r < SPA_R; r++) if (q[r] < qe) apply(item[r]);
+      for (int r = 0; r < SPA_R; r++) if (q[r] < qe) apply(item[r]);
+    } else {
+      for (uint32_t w = 0; w < 16u; w++) {
+        if (w == wave) {
+#pragma unroll
+          for (int r = 0; r < SPA_R; r++) if (q[r] < qe) apply(item[r]);
+        }
+        __syncthreads();
+      }
+    }
   }
   SPA_PF(1)
   __syncthreads();
@@ -370,7 +389,7 @@ static __global__ void k_spa_split(uint32_t nrows, const uint32_t* __restrict__ 
     for (uint32_t c = last + lane; c <= nblk; c += 64) sp[c] = be;
   }
 }
-template <class T, class SR>
+template <class T, class SR, bool ORDERED = false>
 __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, const T* __restrict__ aval, const T* __restrict__ bval, uint32_t* __restrict__ ocol, T* __restrict__ oval,
                                                              uint32_t ncols, const uint32_t* __restrict__ split, const SR sr, uint32_t* __restrict__ rowctr,
                                                              const uint32_t* __restrict__ bitmaps = nullptr, const uint32_t* __restrict__ bmslot = nullptr) {
@@ -451,11 +470,11 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
         struct RProd { uint32_t col; T x; };
         uint32_t rbase = 0;
         auto rwalk = [&](uint32_t st, uint32_t len) __attribute__((always_inline)) -> uint32_t {
-          return spa_flat_walk(st, len, s_exc, s_shift, s_wtot,
+          return spa_flat_walk<ORDERED>(st, len, s_exc, s_shift, s_wtot,
             [&](uint32_t v, uint32_t pb) { RProd p; p.col = a.bcol[pb]; p.x = sr.mult(use_a ? s_av[v] : T(), use_b ? bval[pb] : T()); return p; },
             [&](const RProd& p) { const uint32_t w = p.col >> 5; const uint32_t bits = s_bits[w];
                                   const uint32_t rk = s_woff[w >> csh] + s_pre[w] + (uint32_t)__popc(bits & ((1u << (p.col & 31u)) - 1u)) - rbase;
-                                  word_combine<T>(sr.add_op(), &s_racc[rk], p.x); });
+                                  word_combine<T>(sr.add_op(), &s_racc[rk], p.x); }, nullptr);
         };
         // the entries of blocks [c0, c1): the threads walk their own bitmap words, the rank of a word's first bit is known — no scan, no barrier
         auto remit = [&](uint32_t c0, uint32_t c1) __attribute__((always_inline)) {
@@ -511,7 +530,7 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
     // one chunk of the row's entries (their A values in s_av) against block c (columns lo ...): returns the number of products
     struct Prod { uint32_t rel; T x; };
     auto walk = [&](uint32_t lo, uint32_t st, uint32_t len) __attribute__((always_inline)) -> uint32_t {
-      return spa_flat_walk(st, len, s_exc, s_shift, s_wtot,
+      return spa_flat_walk<ORDERED>(st, len, s_exc, s_shift, s_wtot,
         [&](uint32_t v, uint32_t pb) { Prod p; p.rel = a.bcol[pb] - lo; p.x = sr.mult(use_a ? s_av[v] : T(), use_b ? bval[pb] : T()); return p; },
         [&](const Prod& p) { ((unsigned char*)s_flag)[p.rel] = 1; word_combine<T>(sr.add_op(), &s_acc[p.rel], p.x); }, pf);
     };
@@ -648,8 +667,11 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
   constexpr uint32_t WDc = spa_cfg<T>::WD; constexpr uint64_t REGIONc = (uint64_t)WDc * sizeof(W) + WDc;
   const bool rank_env = !(getenv("GRB_MI355X_SPA_RANK") && atoi(getenv("GRB_MI355X_SPA_RANK")) == 0);      // (read per call: a test hook)
   const bool rank_static = spa && rank_env && (uint64_t)((ncols + 31) / 32) * 6 <= REGIONc * 2 / 5 && ((uint64_t)ncols + WDc - 1) / WDc <= SPA_RANK_MAXBLK;
-  const unsigned long long big_from = rank_static ? 1024ull : 4096ull;
-  hipLaunchKernelGGL(k_hash_bin5, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, ub.as<unsigned long long>(), 128ull, 1024ull, big_from, spa ? big_from : 16384ull, counts.as<uint32_t>(), lists.as<uint32_t>());
+  // deterministic mode (SpgemmCall::ordered) for a floating-point monoid: only the one-wave table kernel (<= 128 products: a wave's LDS atomics execute in
+  // program order) and the dense path with its ordered walk add in a fixed order — every other row goes to the dense path
+  const bool ordered = c.ordered && spa && (d.zcode == T_FP32 || d.zcode == T_FP64);
+  const unsigned long long big_from = ordered ? 128ull : rank_static ? 1024ull : 4096ull, mid_from = ordered ? 128ull : 1024ull;
+  hipLaunchKernelGGL(k_hash_bin5, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, ub.as<unsigned long long>(), 128ull, mid_from, big_from, spa ? big_from : 16384ull, counts.as<uint32_t>(), lists.as<uint32_t>());
   uint32_t hs[5];
   GRB_HIP(hipMemcpyAsync(hs, counts.p, 20, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
   const uint32_t words = (ncols + 31) / 32;
@@ -681,7 +703,7 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
       // ---- row pointers, the size of T, numeric bins ---------------------------------------------------------------------------
       exclusive_scan_u32(rownnz.as<uint32_t>(), out.rowptr.as<uint32_t>(), (uint64_t)nrows + 1);
       GRB_HIP(hipMemsetAsync(counts.p, 0, 64, stream()));
-      hipLaunchKernelGGL(k_hash_bin, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, (const unsigned long long*)nullptr, rownnz.as<uint32_t>(), 128ull, 1024ull, big_from, counts.as<uint32_t>(), lists.as<uint32_t>());
+      hipLaunchKernelGGL(k_hash_bin, dim3(grid_n(nrows)), dim3(256), 0, stream(), nrows, (const unsigned long long*)nullptr, rownnz.as<uint32_t>(), 128ull, mid_from, big_from, counts.as<uint32_t>(), lists.as<uint32_t>());
       hipLaunchKernelGGL(k_hash_total, dim3(grid_n(nrows)), dim3(256), 0, stream(), rownnz.as<uint32_t>(), nrows, (unsigned long long*)(counts.as<uint8_t>() + 32));
       uint64_t hc[5] = {0, 0, 0, 0, 0};                                // four bin counts (u32 x 4) | - | the 64-bit total at byte 32
       GRB_HIP(hipMemcpyAsync(hc, counts.p, 40, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));   // (also: the bitmaps of the symbolic pass are idle now)
@@ -711,8 +733,14 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
           hipLaunchKernelGGL(k_spa_split, dim3(std::min<unsigned>((B.nrows + 3) / 4, 65535u)), dim3(256), 0, stream(), B.nrows, B.rowptr.as<uint32_t>(), B.col.as<uint32_t>(),
                              WD, nblk, split.as<uint32_t>());
           a.crp = out.rowptr.as<uint32_t>(); a.ccol = nullptr; a.rows = L + (size_t)3 * nrows; a.nrows_bin = hn[3];
-          hipLaunchKernelGGL((k_spgemm_spa_numeric<T, SR>), dim3(std::min<unsigned>(hn[3], (unsigned)ncu)), dim3(1024), 0, stream(), a, av, bv, out.col.as<uint32_t>(), out.val.as<T>(), ncols,
-                             split.as<uint32_t>(), sr, rowctr.as<uint32_t>() + 1, ranked ? bitmaps.as<uint32_t>() : (const uint32_t*)nullptr, ranked ? bmslot.as<uint32_t>() : (const uint32_t*)nullptr);
+          const uint32_t* const bmp = ranked ? bitmaps.as<uint32_t>() : (const uint32_t*)nullptr; const uint32_t* const bms = ranked ? bmslot.as<uint32_t>() : (const uint32_t*)nullptr;
+          const dim3 ngrid(std::min<unsigned>(hn[3], (unsigned)ncu));
+          bool launched = false;
+          if constexpr (std::is_floating_point<T>::value) if (ordered) {
+            hipLaunchKernelGGL((k_spgemm_spa_numeric<T, SR, true>), ngrid, dim3(1024), 0, stream(), a, av, bv, out.col.as<uint32_t>(), out.val.as<T>(), ncols, split.as<uint32_t>(), sr, rowctr.as<uint32_t>() + 1, bmp, bms);
+            launched = true;
+          }
+          if (!launched) hipLaunchKernelGGL((k_spgemm_spa_numeric<T, SR, false>), ngrid, dim3(1024), 0, stream(), a, av, bv, out.col.as<uint32_t>(), out.val.as<T>(), ncols, split.as<uint32_t>(), sr, rowctr.as<uint32_t>() + 1, bmp, bms);
         }
         if (ttotal) {
           DevBuf ucol((size_t)ttotal * 4 + 8), uval((size_t)ttotal * sizeof(T) + 8), scol((size_t)ttotal * 4 + 8), perm0((size_t)ttotal * 4 + 8), perm((size_t)ttotal * 4 + 8);
@@ -755,7 +783,7 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
       }
     }
     g_last_plan += std::string("spgemm_hash<") + (sr.is_static ? "static" : "dynamic") + "> symbolic bins " + std::to_string(hs[0]) + "/" + std::to_string(hs[1]) + "/" + std::to_string(hs[2]) + "/" +
-                   std::to_string(hs[3]) + "/" + std::to_string(hs[4]) + " numeric bins " + std::to_string(hn[0]) + "/" + std::to_string(hn[1]) + "/" + std::to_string(hn[2]) + "/" + std::to_string(hn[3]) + (ranked ? " ranked " : " ");
+                   std::to_string(hs[3]) + "/" + std::to_string(hs[4]) + " numeric bins " + std::to_string(hn[0]) + "/" + std::to_string(hn[1]) + "/" + std::to_string(hn[2]) + "/" + std::to_string(hn[3]) + (ranked ? " ranked" : "") + (ordered ? " ordered " : " ");
   });
   out.valid = true;
 }

@@ -459,3 +459,57 @@ def test_unmasked_product_rmat18_sampled_rows_against_the_oracle(gpu, monkeypatc
     assert np.array_equal(off, woff), "row lengths differ"
     assert np.array_equal(gc, wc), "pattern differs"
     assert np.allclose(gv, wv, rtol=1e-6, atol=0.0), float(np.abs(gv / wv - 1).max())
+
+
+def test_deterministic_mode_of_the_unmasked_product_small_against_the_oracle(gpu, monkeypatch):
+    """GRB_MI355X_DETERMINISTIC=1 (or the descriptor's GxB_AxB_GUSTAVSON): every row beyond 128 products goes through the dense path's ordered walk.  Same
+    pattern and values (1e-12: another order of the same terms) as the oracle's ascending-k Gustavson, on a graph small enough for the generic restatement."""
+    monkeypatch.setenv("GRB_MI355X_SPGEMM", "hash")
+    monkeypatch.setenv("GRB_MI355X_DETERMINISTIC", "1")
+    rng = np.random.default_rng(12)
+    scale = 11; n = 1 << scale
+    rp, col = rmat.csr_numpy(scale, symmetric=True, drop_self_loops=True)
+    vals = rng.random(len(col)) + 0.5
+    A = gb.Matrix.from_csr(gb.FP64, n, n, rp, col, vals)
+    Cm = A.mxm(A, semiring=gb.FP64.PLUS_TIMES)
+    plan = gb.last_kernel_plan()
+    num = [int(x) for x in plan.split("numeric bins ")[1].split()[0].split("/")]
+    assert " ordered" in plan and num[1] == 0 and num[2] == 0 and num[3] > 0, plan
+    rows = np.arange(n, dtype=np.uint32)
+    off, oc, ov, _ = O.fast_mxm_rows(rp, col, vals, rows)
+    crp, ccol, cval = Cm.to_csr()
+    assert np.array_equal(crp.astype(np.int64), off) and np.array_equal(ccol, oc)
+    assert np.allclose(cval, ov, rtol=1e-12, atol=0.0)
+    again = A.mxm(A, semiring=gb.FP64.PLUS_TIMES).to_csr()[2]
+    assert np.array_equal(again.view(np.uint64), cval.view(np.uint64))
+
+
+def test_deterministic_mode_of_the_unmasked_product_rmat18_is_bitwise_repeatable(gpu, monkeypatch):
+    """A @ A on the symmetric R-MAT-18 with random FP64 values (9.5e9 products) in deterministic mode, three times: the 3.0e9 values are the same BITS every
+    time (the default mode's atomics land as they come and differ in the last places), and they agree with the default mode's to 1e-10."""
+    import torch
+    dev = torch.device("cuda", 0)
+    S = 18; n = 1 << S
+    rowptr, col = rmat.csr_torch(S, dev, seed=42, symmetric=True, drop_self_loops=True)
+    nnz = int(col.numel())
+    vals = rmat.values_torch(nnz, dev, seed=46) + 0.5
+    A = gb.Matrix.from_csr(gb.FP64, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+    monkeypatch.setenv("GRB_MI355X_SPGEMM", "hash")
+
+    def product_values():
+        Cm = A.mxm(A, semiring=gb.FP64.PLUS_TIMES)
+        nv = Cm.nvals
+        cval = torch.empty(nv, dtype=torch.float64, device=dev)
+        gb.base.check(gb.lib.GrBX_Matrix_export_CSR(Cm._h, None, None, C.c_void_p(cval.data_ptr()), C.c_int(1)))
+        return cval, gb.last_kernel_plan()
+    base, plan0 = product_values()
+    assert " ordered" not in plan0
+    monkeypatch.setenv("GRB_MI355X_DETERMINISTIC", "1")
+    first, plan = product_values()
+    assert " ordered" in plan, plan
+    assert first.numel() == base.numel() and torch.allclose(first, base, rtol=1e-10, atol=0.0)
+    del base
+    for _ in range(2):
+        again, _ = product_values()
+        assert torch.equal(again.view(torch.int64), first.view(torch.int64))
+        del again
