@@ -484,9 +484,11 @@ def bench_bfs(cx, scale):
 
     loops = cx.loops
 
-    def single():
-        del plans[:]
-        return loops.bfs(A, src, plans=plans)
+    def single(record=False):
+        # (the kernel names are collected in a run of their own: a `last_kernel_plan()` call and a string split per level are the harness's, not the loop's)
+        if record:
+            del plans[:]
+        return loops.bfs(A, src, plans=plans if record else None)
     if world == 1:
         run = single
     else:
@@ -504,7 +506,7 @@ def bench_bfs(cx, scale):
     out = {"workload": f"BFS R-MAT-{scale} BOOL LOR_LAND, the reference's vxm loop (BASELINE.json configs[2])" + (f", {world} entry-balanced row blocks, bit frontier" if world > 1 else ""),
            "nnz": nnz, "source": src, "depth": depth, "seconds": round(best, 5), "dtype": "bool"}
     # parity and the rate need the whole level vector: every rank holds the graph, so the single-GPU loop gives it
-    v1, d1 = single(); lev, _ = v1.to_dense_arrays()
+    v1, d1 = single(record=True); lev, _ = v1.to_dense_arrays()
     if world > 1:
         ok = bool(d1 == depth and np.array_equal(lev[bounds[rank]:bounds[rank + 1]], lev_mine))
         flag = torch.tensor([int(ok)], dtype=torch.int64); cx.tdist.all_reduce(flag, op=cx.tdist.ReduceOp.MIN)

@@ -273,12 +273,18 @@ template <class T, int RED, class R, int NIN> static void launch_chain(const Cha
     if (!no_spec && RED == 0 && L.nsteps == 1 && L.next == 2 && s0.kind == 0 && s0.op == B_DIV && !s0.is_union && s0.src[0] == 0 && s0.src[1] == 1 && L.nout == 1 && s0.out == 0 && L.op[0] != nullptr) spec = 2;
   }
   bool launched = false;
-  if constexpr (std::is_floating_point<T>::value && NIN == 2 && RED != 0) {
+  // a floating-point chain that was seen before runs through the kernel hipRTC compiled for exactly its steps (grb_chain_jit.cpp); the two shapes
+  // below stay compiled ahead of time (no first-use compilation inside somebody's PageRank loop) unless GRB_MI355X_CHAIN_JIT=2 asks for the comparison
+  if constexpr (std::is_floating_point<T>::value) {
+    if (aligned) launched = chain_jit_launch(L, std::is_same<T, float>::value, RED, RED != 0 ? (const void*)&rid : nullptr, (void*)partial, (unsigned)g, spec != 0);
+  }
+  if (launched) {}
+  else if constexpr (std::is_floating_point<T>::value && NIN == 2 && RED != 0) {
     if (spec == 1) { if (aligned) hipLaunchKernelGGL((k_vec_chain<T, RED, R, NIN, 4, 1>), dim3((unsigned)g), dim3(256), 0, stream(), a, rid, partial);
                      else hipLaunchKernelGGL((k_vec_chain<T, RED, R, NIN, 1, 1>), dim3((unsigned)g), dim3(256), 0, stream(), a, rid, partial); launched = true; }
   }
   if constexpr (std::is_floating_point<T>::value && NIN == 2 && RED == 0) {
-    if (spec == 2) { if (aligned) hipLaunchKernelGGL((k_vec_chain<T, RED, R, NIN, 4, 2>), dim3((unsigned)g), dim3(256), 0, stream(), a, rid, partial);
+    if (!launched && spec == 2) { if (aligned) hipLaunchKernelGGL((k_vec_chain<T, RED, R, NIN, 4, 2>), dim3((unsigned)g), dim3(256), 0, stream(), a, rid, partial);
                      else hipLaunchKernelGGL((k_vec_chain<T, RED, R, NIN, 1, 2>), dim3((unsigned)g), dim3(256), 0, stream(), a, rid, partial); launched = true; }
   }
   if (!launched) {

@@ -7,13 +7,13 @@ same stopping rule); nothing here is part of the GraphBLAS API surface.
   sssp(A, start)           demo/Intro-Prez.ipynb:1034-1045; pygraphblas/vector.py:883-885  MIN_PLUS, accum MIN
   triangle_count(L)        demo/TriangleCentrality.ipynb:1446-1449  PLUS_PAIR, mask L                 (configs[3])
 """
+from . import Vector, UINT8, BOOL, FP32, INT64, descriptor as D, last_kernel_plan      # (the package is initialised by the time this submodule is asked for)
 
 
 def pagerank(A, d, damping=0.85, itermax=100, tol=1e-4, fixed_iterations=None, trace=None):
     """gap/prmark.py:8-30.  A: adjacency matrix (any type; the semiring ignores its values), d: FP32 out-degrees with no entry
     for dangling vertices (`A.reduce_vector()`); the product runs on A' through the descriptor, as the reference's does.
     `fixed_iterations` (bench.py) runs exactly that many iterations.  Returns (r, iterations, rdiff)."""
-    from . import Vector, FP32, descriptor as D
     n = A.nrows
     r = Vector.sparse(FP32, n)
     t = Vector.sparse(FP32, n)
@@ -39,7 +39,6 @@ def pagerank(A, d, damping=0.85, itermax=100, tol=1e-4, fixed_iterations=None, t
 
 def bfs(A, start, plans=None):
     """Level BFS: levels start at 1, unreached vertices have no entry.  Returns (v, depth)."""
-    from . import Vector, UINT8, BOOL, descriptor as D, last_kernel_plan
     v = Vector.sparse(UINT8, A.nrows)
     q = Vector.sparse(BOOL, A.nrows)
     q[start] = True
@@ -56,7 +55,6 @@ def bfs(A, start, plans=None):
 def sssp(A, start, plans=None, max_sweeps=None, before_sweep=None):
     """Shortest path lengths from `start` by repeated `v<accum MIN> = v MIN_PLUS A` until a sweep changes nothing.
     `before_sweep(v)` (bench.py's byte accounting) sees the operand of every product.  Returns (v, sweeps)."""
-    from . import Vector, last_kernel_plan
     typ = A.type
     v = Vector.sparse(typ, A.nrows)
     v[start] = 0
@@ -75,5 +73,4 @@ def sssp(A, start, plans=None, max_sweeps=None, before_sweep=None):
 
 
 def triangle_count(L):
-    from . import INT64
     return L.mxm(L, semiring=INT64.PLUS_PAIR, mask=L).reduce_int()

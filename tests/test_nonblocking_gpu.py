@@ -293,3 +293,65 @@ def test_a_reduced_chain_is_not_stored_until_somebody_looks(gb, gpu):
     assert t.reduce_float(F.MIN_MONOID) == float(want_u.min())
     x, p = t.to_dense_arrays()
     assert np.array_equal(x, want_u)
+
+
+def jit_stats(gb):
+    a = [C.c_uint64(0), C.c_uint64(0)]
+    assert gb.lib.GrBX_chain_jit_stats(C.byref(a[0]), C.byref(a[1])) == 0
+    return a[0].value, a[1].value
+
+
+@pytest.mark.parametrize("tname", ["FP32", "FP64"])
+def test_random_programs_through_the_compiled_chains(gb, gpu, tname, monkeypatch):
+    """The random programs of test_random_programs_against_a_model with every floating-point chain compiled by hipRTC at first sight
+    (GRB_MI355X_CHAIN_JIT=2, grb_chain_jit.cpp) instead of run by the interpreter kernel: same numpy model, exact values."""
+    monkeypatch.setenv("GRB_MI355X_CHAIN_JIT", "2")
+    c0, l0 = jit_stats(gb)
+    test_random_programs_against_a_model(gb, gpu, tname)
+    c1, l1 = jit_stats(gb)
+    assert c1 > c0 and l1 - l0 >= 20, (c0, c1, l0, l1)
+
+
+def test_a_chain_outside_the_pagerank_loop_runs_as_fast_as_the_compiled_shapes(gb, gpu, monkeypatch, capsys):
+    """`reduce(+, abs(x * y - z))` over 2^25 FP32 positions — a chain gap/prmark.py does not contain: four streams of 4 bytes.  The second time the library sees
+    it, hipRTC compiles its steps (default mode: GRB_MI355X_CHAIN_JIT=1), and from then on it moves its bytes within 1.3 x of the rate of the ahead-of-time
+    shape `reduce(+, abs(x - y))` (k_vec_chain<..., SPEC = 1>: two streams), where the interpreter kernel is bound by instruction issue.  Values against numpy."""
+    monkeypatch.delenv("GRB_MI355X_CHAIN_JIT", raising=False)
+    n = 1 << 25
+    rng = np.random.default_rng(4)
+    xs, ys, zs = (rng.random(n, dtype=np.float32) for _ in range(3))
+    x, y, z = (gb.Vector.from_dense_array(a, gb.FP32) for a in (xs, ys, zs))
+
+    def generic():
+        t = x.emult(y, gb.FP32.TIMES); t = t.eadd(z, gb.FP32.MINUS); t = t.apply(gb.FP32.ABS)
+        return t.reduce_float()
+
+    def spec():
+        t = x.eadd(y, gb.FP32.MINUS); t = t.apply(gb.FP32.ABS)
+        return t.reduce_float()
+
+    def timed(fn, reps=20):
+        fn(); fn()
+        best = 1e9
+        for _ in range(3):
+            gb.lib.GrBX_timer_start()
+            for _ in range(reps):
+                r = fn()
+            ms = C.c_float(0); gb.lib.GrBX_timer_stop(C.byref(ms)); best = min(best, ms.value / reps)
+        return r, best
+    c0, _ = jit_stats(gb)
+    got, ms_gen = timed(generic)
+    c1, l1 = jit_stats(gb)
+    assert c1 == c0 + 1 and l1 > 0                                       # compiled once, at its second appearance
+    want = float(np.abs(xs.astype(np.float64) * ys - zs).sum())
+    assert abs(got - want) <= 1e-5 * want, (got, want)
+    _, ms_spec = timed(spec)
+    monkeypatch.setenv("GRB_MI355X_CHAIN_JIT", "0")
+    got_i, ms_int = timed(generic)
+    assert abs(got_i - want) <= 1e-5 * want
+    rate_gen, rate_spec, rate_int = 3 * 4 * n / ms_gen, 2 * 4 * n / ms_spec, 3 * 4 * n / ms_int           # bytes per ms
+    with capsys.disabled():
+        print(f"\n[chain abs(x*y - z) reduced, 2^25 FP32: compiled {ms_gen * 1e3:.1f} us = {rate_gen / 1e9:.2f} TB/s; interpreter {ms_int * 1e3:.1f} us = {rate_int / 1e9:.2f} TB/s; "
+              f"ahead-of-time shape abs(x - y) reduced {ms_spec * 1e3:.1f} us = {rate_spec / 1e9:.2f} TB/s]")
+    assert rate_gen * 1.3 >= rate_spec, (rate_gen, rate_spec)
+    assert ms_gen < ms_int
