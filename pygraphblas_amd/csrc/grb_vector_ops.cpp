@@ -114,6 +114,9 @@ static void vec_assign(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const 
         bool snz = false; for (size_t b = 0; b < type_size(wcode0); b++) snz = snz || s0[b] != 0;
         keep_list = merged.size() <= 64; truthy = snz && (w->small_truthy || w->small_idx.empty());
       }
+      // (Round 5, measured and dropped: recording this assign and letting the masked pull that follows apply it on its way over the rows — one launch and
+      //  one dependent kernel less per BFS level.  The pull then looks at q beside v wherever it gathers an operand entry: +2 byte gathers per entry
+      //  made the level-2 pull of the R-MAT-22 BFS 65 -> 106 us and the whole loop 283 -> 341 us.)
       vec_assign_scalar_masked(wcode0, n, w->dval.p, w->dpres.as<uint8_t>(), mask->type->code, mask->dval.p, mask->dpres.as<uint8_t>(), dv.mask_struct, dv.mask_comp, s0,
                                accum ? accum->opcode : -1, dv.replace);
       vec_invalidate_host(w);
