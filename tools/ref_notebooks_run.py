@@ -9,6 +9,7 @@ import glob, json, os, signal, sys, traceback, io, contextlib
 
 nbdir = sys.argv[1]
 only = set(sys.argv[2:])
+show = set(os.environ.get("REF_NOTEBOOKS_SHOW", "Triangle-Counting").split(","))
 os.chdir(nbdir)
 
 
@@ -31,18 +32,28 @@ for f in sorted(glob.glob("*.ipynb")):
     ns = {"__name__": "__main__", "display": lambda *a, **k: None}      # IPython puts display() into a notebook's namespace
     ok = 0
     errs = []
+    shown = []
     for i, src in enumerate(cells):
         src = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith(("%", "!")))
         if not src.strip():
             ok += 1
             continue
         try:
-            code = compile(src, f"{name}[{i}]", "exec")
+            # like a notebook: the value of a cell's last expression is its output (shown for the notebooks named in REF_NOTEBOOKS_SHOW, with what it printed)
+            import ast
+            tree = ast.parse(src, f"{name}[{i}]", "exec")
+            last = tree.body.pop() if tree.body and isinstance(tree.body[-1], ast.Expr) else None
+            code = compile(tree, f"{name}[{i}]", "exec")
+            buf = io.StringIO(); val = None
             signal.alarm(60)
-            with contextlib.redirect_stdout(io.StringIO()):
+            with contextlib.redirect_stdout(buf):
                 exec(code, ns)
+                if last is not None:
+                    val = eval(compile(ast.Expression(last.value), f"{name}[{i}]", "eval"), ns)
             signal.alarm(0)
             ok += 1
+            if name in show:
+                shown.append((i, buf.getvalue().strip()[:200], None if val is None else repr(val)[:200]))
         except BaseException as e:  # noqa: BLE001 - a harness: every failure is data
             signal.alarm(0)
             if isinstance(e, KeyboardInterrupt):
@@ -53,5 +64,8 @@ for f in sorted(glob.glob("*.ipynb")):
     print(f"== {name}: {ok} of {len(cells)} code cells run")
     for i, t, m in errs:
         print(f"     cell {i}: {t}: {m}")
+    for i, out, val in shown:
+        if out or val is not None:
+            print(f"     cell {i} shows: " + " | ".join(x for x in (out.replace(chr(10), " / "), ("Out: " + val) if val is not None else "") if x))
     sys.stdout.flush()
 print(f"TOTAL: {tot_ok} of {tot_cells} code cells run")
