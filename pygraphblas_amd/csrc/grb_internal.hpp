@@ -106,10 +106,15 @@ struct DevCSR {
   // kernel-W plan (grb_spmv_wavepipe.hpp): per-task first row, hot-column list, remapped column array, per-wave carries
   DevBuf wp_rs, wp_hot, wp_pcol, wp_carry; uint32_t wp_nhot = 0, wp_ntasks = 0, wp_nwarm = 0; int wp_tsize = 0;
   std::shared_ptr<void> xcd;    // kernel-X plan (grb_spmv_xcd.hpp: XcdPlan), panel-major copy of the matrix
+  // row heads (grb_spmv_kernels.hpp, round 5): for the masked pull of a BFS level — per row its first four entries as one 16-byte word (per entry:
+  // bits 29..0 the column, bit 31 its BOOL value, in the fourth bit 30 = the row has more entries; absent = 0xFFFFFFFF) and one bit per row "has an
+  // entry": a level then costs what its unvisited NON-EMPTY rows cost, and a row decided by its first entries never touches the column array.
+  // Built at the first masked pull of a matrix with < 2^30 - 1 columns; heads_vals: the value bits come from one-byte BOOL values (else they are 1).
+  DevBuf heads, nonempty; bool heads_valid = false, heads_vals = false;
   uint32_t pipe_uses = 0;       // full-operand pull products this matrix has served: the first runs kernel W (cheap plan), kernel X's plan is built for the second
   bool valid = false;
   void clear() { rowptr.reset(); col.reset(); val.reset(); plan_blocks.reset(); plan_aux.reset();
-                 wp_rs.reset(); wp_hot.reset(); wp_pcol.reset(); wp_carry.reset(); wp_nhot = wp_ntasks = 0; wp_tsize = 0; xcd.reset(); pipe_uses = 0;
+                 wp_rs.reset(); wp_hot.reset(); wp_pcol.reset(); wp_carry.reset(); wp_nhot = wp_ntasks = 0; wp_tsize = 0; xcd.reset(); pipe_uses = 0; heads.reset(); nonempty.reset(); heads_valid = false;
                  nnz = 0; has_plan = false; locality_pct = -1; range_state = 0; valid = false; plan_nblocks = plan_nlong = 0; }
 };
 

@@ -51,6 +51,7 @@ template <class T> struct SpmvKArgs {
   uint32_t* any_true; uint32_t any_true_tag;      // BOOL results only (nullptr otherwise): set to the tag when an entry with value true is written
   const uint8_t* fm_val; uint32_t fm_flags;       // SpmvCall::fm_val / fm_flags (row-lane kernel, FUSED instantiation)
   const uint32_t* fe_rowptr; unsigned long long* fe_host;      // SpmvCall::fe_* (row-lane kernel)
+  const uint4* heads; const uint32_t* nonempty;                // DevCSR::heads / nonempty (row-lane kernel, FUSED, K rows per lane)
 };
 // a workgroup's share of the result's summary (SpmvCall::fe_host): edge sum and entry count of the true entries it wrote, stored — each in the
 // low half of a 64-bit word whose high half is the product's tag — into ITS OWN pair of page-locked HOST words.  The `q.reduce_bool()` that
@@ -347,24 +348,79 @@ __global__ __launch_bounds__(1024) void k_spmv_rowlane_k(const SpmvKArgs<T> a, c
   for (uint64_t base = wave * span; base < nround; base += nwaves * span) {
     uint64_t r[K]; bool valid[K], allowed[K], has[K], done[K]; uint32_t pb[K], pe[K]; T acc[K];
     uint8_t m0[K], m1[K];
+    uint32_t e0 = 0;                                                                               // first entry the generic loop below looks at
+    bool use_heads = false;
+    if constexpr (FUSED) use_heads = a.heads != nullptr;                                           // (argument-uniform)
 #pragma unroll
     for (int k = 0; k < K; k++) {
       r[k] = base + 64ull * k + lane; valid[k] = r[k] < a.nrows;
       const uint64_t rr = valid[k] ? r[k] : 0;
       if constexpr (FUSED) { m0[k] = a.upres[rr]; m1[k] = a.fm_val[rr]; }                       // the mask vector itself
       else { m0[k] = a.allow ? a.allow[rr] : (uint8_t)1; m1[k] = 1; }
-      // (the row pointers are fetched whether or not the row is allowed: one dependent round trip less — the late levels of a BFS,
-      //  where half of the 4 M rows are empty and unvisited, are a chain of such trips and little else)
-      pb[k] = a.rowptr[rr]; pe[k] = a.rowptr[rr + 1];
+      // (without row heads the row pointers are fetched whether or not the row is allowed: one dependent round trip less — the late levels of a
+      //  BFS, where half of the 4 M rows are empty and unvisited, are a chain of such trips and little else)
+      if (!use_heads) { pb[k] = a.rowptr[rr]; pe[k] = a.rowptr[rr + 1]; } else { pb[k] = 0; pe[k] = 0; }
     }
 #pragma unroll
     for (int k = 0; k < K; k++) {
       if constexpr (FUSED) allowed[k] = valid[k] && ((m0[k] != 0 && ((a.fm_flags & 1u) || m1[k] != 0)) != ((a.fm_flags & 2u) != 0));
       else allowed[k] = valid[k] && m0[k] != 0;
-      acc[k] = sr.identity; has[k] = false; done[k] = !allowed[k] || pe[k] == pb[k];
+      acc[k] = sr.identity; has[k] = false; done[k] = !allowed[k] || (!use_heads && pe[k] == pb[k]);
+    }
+    if constexpr (FUSED) if (use_heads) {
+      // Row heads (DevCSR::heads, round 5): one bit says whether an allowed row has an entry at all — half of R-MAT-22's rows have none, and they stay
+      // "unvisited" for the whole search — and one 16-byte word carries the row's first four columns.  The level-2 pull of the BFS, which touched a
+      // 128-byte line of the column array for the first entries of each of 2 M rows (65 us: bandwidth), reads 16 bytes per live row; a late level
+      // reads the vector, the bits, and the heads of the handful of rows that are still live.
+      uint32_t nw[K];
+#pragma unroll
+      for (int k = 0; k < K; k++) nw[k] = a.nonempty[(valid[k] ? r[k] : 0) >> 5];
+      uint4 hd[K];
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const bool live = allowed[k] && ((nw[k] >> (r[k] & 31)) & 1u);
+        done[k] = !live;
+        hd[k] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (live) hd[k] = a.heads[r[k]];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        uint32_t c[K]; bool act[K], hv[K]; bool any = false;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+          const uint32_t raw = e == 0 ? hd[k].x : e == 1 ? hd[k].y : e == 2 ? hd[k].z : hd[k].w;
+          act[k] = !done[k] && raw != 0xFFFFFFFFu;
+          if (!done[k] && raw == 0xFFFFFFFFu) done[k] = true;                                      // fewer than e + 1 entries: the row is exhausted
+          c[k] = act[k] ? (raw & 0x3FFFFFFFu) : 0u;
+          hv[k] = (raw >> 31) != 0;
+          any = any || act[k];
+        }
+        if (!__ballot(any)) break;                                                                 // (a late level: most waves have no live row at all)
+        uint8_t pr[K], vb[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) { pr[k] = a.upres[c[k]]; vb[k] = a.fm_val[c[k]]; }                // (an idle slot reads position 0 and drops it)
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+          if (act[k] && pr[k]) {
+            T uvv; uvv = T(vb[k] != 0);
+            T avv; avv = T(hv[k]);                                                                    // (the entry's BOOL value rides in bit 31 of its head word)
+            const T m = sr.mult(use_a ? avv : T(), uvv);
+            acc[k] = has[k] ? sr.add(acc[k], m) : m; has[k] = true;
+            if (sr.has_terminal && memcmp_eq(acc[k], sr.terminal)) done[k] = true;
+          }
+        }
+      }
+      // rows with more than four entries that are still undecided go on in the column array (their row pointers are fetched now)
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const bool more = !done[k] && hd[k].w != 0xFFFFFFFFu && ((hd[k].w >> 30) & 1u);
+        if (!more) done[k] = true;
+        if (more) { pb[k] = a.rowptr[r[k]]; pe[k] = a.rowptr[r[k] + 1]; }
+      }
+      e0 = 4;
     }
     // the first SPMV_LANE_E entries of the K rows, entry by entry
-    for (uint32_t e = 0; e < SPMV_LANE_E; e++) {
+    for (uint32_t e = e0; e < SPMV_LANE_E; e++) {
       bool act[K]; bool any = false;
 #pragma unroll
       for (int k = 0; k < K; k++) { act[k] = !done[k] && pb[k] + e < pe[k]; any = any || act[k]; }
@@ -546,6 +602,33 @@ static inline int spmv_locality_pct(DevCSR& M) {
   return M.locality_pct;
 }
 
+// ---- row heads (DevCSR::heads / nonempty) --------------------------------------------------------------------------------------------------
+static __global__ void k_row_heads(uint32_t nrows, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const uint8_t* __restrict__ bval, uint4* __restrict__ heads, uint32_t* __restrict__ nonempty) {
+  const uint64_t r = blockIdx.x * 256ull + threadIdx.x;
+  uint32_t b = 0, e = 0;
+  if (r < nrows) { b = rowptr[r]; e = rowptr[r + 1]; }
+  const unsigned long long m = __ballot(e > b);
+  if (r < nrows) {
+    auto word = [&](uint32_t p) { return col[p] | ((!bval || bval[p]) ? 0x80000000u : 0u); };
+    uint4 h = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (e > b) h.x = word(b);
+    if (e > b + 1) h.y = word(b + 1);
+    if (e > b + 2) h.z = word(b + 2);
+    if (e > b + 3) h.w = word(b + 3) | (e > b + 4 ? 0x40000000u : 0u);
+    heads[r] = h;
+    if ((threadIdx.x & 31) == 0) nonempty[r >> 5] = (uint32_t)(m >> (threadIdx.x & 32));      // (the allocation holds whole words)
+  }
+}
+// bool8_vals: the matrix values as one-byte BOOLs in place (nullptr: the caller's multiplier ignores them)
+static inline bool spmv_row_heads(DevCSR& M, const uint8_t* bool8_vals) {
+  if (M.heads_valid && (M.heads_vals || !bool8_vals)) return true;
+  if (M.ncols >= 0x3FFFFFFFu || !M.nrows) return false;
+  if (!M.heads_valid) { M.heads.alloc((size_t)M.nrows * 16 + 16); M.nonempty.alloc(((size_t)M.nrows + 31) / 32 * 4 + 64); }
+  hipLaunchKernelGGL(k_row_heads, dim3((unsigned)(((uint64_t)M.nrows + 255) / 256)), dim3(256), 0, stream(), M.nrows, M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(), bool8_vals, (uint4*)M.heads.p, M.nonempty.as<uint32_t>());
+  M.heads_valid = true; M.heads_vals = bool8_vals != nullptr;
+  return true;
+}
+
 template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
   DevCSR& M = *c.M;
   with_semiring<T>(d, [&](auto sr) {
@@ -553,7 +636,7 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
     SpmvKArgs<T> a{};
     a.rowptr = M.rowptr.as<uint32_t>(); a.col = M.col.as<uint32_t>(); a.aval = (const T*)c.aval;
     a.uval = (const T*)c.uval; a.upres = c.upres; a.allow = c.allow; a.tval = (T*)c.tval; a.tpres = c.tpres; a.nrows = M.nrows; a.any_true = nullptr;
-    a.fe_rowptr = nullptr; a.fe_host = nullptr;
+    a.fe_rowptr = nullptr; a.fe_host = nullptr; a.heads = nullptr; a.nonempty = nullptr;
     const bool full = c.upres == nullptr;
     // masked pull with a terminal monoid (BFS) -> row-group kernel with early exit; otherwise the row-block kernel
     const bool prefer_rowgroup = c.method == SPMV_ROWGROUP || (c.method == SPMV_AUTO && (c.allow || c.fm_val) && d.has_terminal);
@@ -583,6 +666,10 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
             const unsigned thr = lane_thr >= 1024 ? 1024u : lane_thr >= 512 ? 512u : 256u;
             uint64_t nbk = ((uint64_t)M.nrows + (uint64_t)thr * kk - 1) / ((uint64_t)thr * kk); if (nbk < 1) nbk = 1; if (nbk > lane_cap) nbk = lane_cap;
             if (a.fe_host) { if (nbk > FE_MAX_BLOCKS) nbk = FE_MAX_BLOCKS; *c.fe_done = true; *c.fe_nblocks = (uint32_t)nbk; }
+            static const bool no_heads = wp_env("GRB_MI355X_NO_ROW_HEADS", 0) != 0;                    // measurement hook: round 5's first half (row pointers + column array)
+            // (the value bits need the matrix values as one-byte BOOLs where they lie: a BOOL matrix under a Boolean semiring — the adjacency matrix of the BFS)
+            const bool vals_in_place = c.aval == M.val.p;
+            if (kk > 1 && !no_heads && (!sr.uses_a() || vals_in_place) && spmv_row_heads(M, sr.uses_a() ? (const uint8_t*)M.val.p : nullptr)) { a.heads = (const uint4*)M.heads.p; a.nonempty = M.nonempty.as<uint32_t>(); }
             if (kk == 4) hipLaunchKernelGGL((k_spmv_rowlane_k<T, SR, false, true, 4>), dim3((unsigned)nbk), dim3(thr), 0, stream(), a, sr);
             else if (kk == 2) hipLaunchKernelGGL((k_spmv_rowlane_k<T, SR, false, true, 2>), dim3((unsigned)nbk), dim3(thr), 0, stream(), a, sr);
             else hipLaunchKernelGGL((k_spmv_rowlane<T, SR, false, true>), dim3((unsigned)nbk), dim3(thr), 0, stream(), a, sr);
