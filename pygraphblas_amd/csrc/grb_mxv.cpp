@@ -87,12 +87,15 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
     }
   }
 
-  bool fused_mask = false;
+  bool fused_mask = false, excl_small = false;
   if (mask_is_u) {
     // (the pull operand — for vxm the cached transpose, built on first need — is looked at only when the product pulls: a BFS that
     //  stays in push for every level never pays for a transpose it does not use)
     fused_mask = !push && !accum && dv.replace && type_size(u->type->code) == 1 && spmv_rowlane_applies(useT ? mat_csc(A) : A->csr, sd, method);
-    if (!fused_mask) {
+    // the first level of a BFS: the operand is a short list known on the host, it is also the (complemented) mask and every listed value is true — the
+    // push kernels skip the listed positions themselves and multiply by `true`: no allow bytes, no BOOL copy of the operand (a pass over all positions)
+    excl_small = !fused_mask && push && tiny && dv.mask_comp && (dv.mask_struct || u->small_truthy) && u->small_truthy;
+    if (!fused_mask && !excl_small) {
       allow_buf.alloc(mr); ubool.alloc(mr + 1);
       build_allow_and_bool(mr, u->type->code, u->dval.p, u->dpres.as<uint8_t>(), dv.mask_struct, dv.mask_comp, allow_buf.as<uint8_t>(), ubool.as<uint8_t>());
       allow = allow_buf.as<uint8_t>();
@@ -195,7 +198,7 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
     ucast.alloc(u->n * zs + 1);
     vec_cast_fill_values(sd.zcode, ucast.p, u->type->code, u->dval.p, u->dpres.as<uint8_t>(), u->n, sd.identity);   // (identity of PLUS / LOR is the 0 / false the two other cases need)
     uval = ucast.p;
-  } else if (uses_u && fused_mask) uval = nullptr;                 // (the kernel reads the vector's own bytes)
+  } else if (uses_u && (fused_mask || excl_small)) uval = nullptr;  // (the kernel reads the vector's own bytes / takes every operand value as true)
   else if (uses_u) uval = ubool.p ? ubool.p : cast_values(sd.zcode, u->type->code, u->dval.p, u->n, ucast);
 
   SpmvCall call{};
@@ -218,7 +221,7 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
     // push walks rows of M^T:  M^T = useT ? A : A^T
     DevCSR& P = useT ? A->csr : const_cast<DevCSR&>(mat_csc(A));
     call.M = &P; call.upres = u->dpres.as<uint8_t>();
-    if (u->small_valid && u->small_idx.size() == u_nvals) { call.small_idx = u->small_idx.data(); call.small_n = (uint32_t)u_nvals; }
+    if (u->small_valid && u->small_idx.size() == u_nvals) { call.small_idx = u->small_idx.data(); call.small_n = (uint32_t)u_nvals; call.excl_small = excl_small; }
     call.aval = uses_a ? cast_values(sd.zcode, A->type->code, P.val.p, P.nnz, acast) : nullptr;
     spmspv_push(call, sd, u_nvals);
   } else {

@@ -52,6 +52,10 @@ struct SpmvCall {
   const uint8_t* fm_val = nullptr; uint8_t fm_flags = 0;
   // push: the operand's entries as a host list of <= 64 ascending indices (GrB_Vector_opaque::small_idx) — no frontier compaction
   const uint32_t* small_idx = nullptr; uint32_t small_n = 0;
+  // push, round 5: the mask is that same short list, complemented, every listed value true (the first level of a BFS: `v.vxm(A, mask=v, desc=RC)` with v =
+  // {start}): the kernels skip the listed positions themselves and take the operand's values as `true` — no allow bytes, no BOOL copy of the operand
+  // (a pass over all n positions and its launch)
+  bool excl_small = false;
 };
 bool spmv_rowlane_applies(const DevCSR& M, const SemiringDesc& d, int method);      // would a masked pull of this matrix run the row-lane kernel?
 

@@ -519,12 +519,14 @@ template <class T> __device__ __forceinline__ void atomic_combine(int op, T* add
 }
 
 constexpr int PUSH_LONG = 4096;
+struct SmallList64 { uint32_t n; uint32_t idx[64]; };      // a short list handed over as a kernel argument
+__device__ __forceinline__ bool small_list_has(const SmallList64& l, uint32_t j) { bool x = false; for (uint32_t q = 0; q < l.n; q++) x = x || l.idx[q] == j; return x; }
 template <class T, class SR>
 __global__ __launch_bounds__(256) void k_spmspv_push(const uint32_t* __restrict__ fidx, uint32_t nf, const uint32_t* __restrict__ rowptr,
                                                      const uint32_t* __restrict__ col, const T* __restrict__ aval, const T* __restrict__ uval,
                                                      const uint8_t* __restrict__ allow, T* __restrict__ tval, uint8_t* __restrict__ tpres,
                                                      uint32_t* __restrict__ longlist, const SR sr, uint32_t* __restrict__ any_true = nullptr, const uint32_t any_tag = 0,
-                                                     unsigned long long* __restrict__ fe_host = nullptr) {
+                                                     unsigned long long* __restrict__ fe_host = nullptr, const SmallList64 excl = SmallList64{0, {0}}) {
   // one wave per frontier entry: its row of M^T (= CSR row of the stored matrix) is streamed coalesced
   const int lane = threadIdx.x & 63;
   const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6;
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(256) void k_spmspv_push(const uint32_t* __restrict_
   unsigned long long fe = 0, fcnt = 0;                                       // (fe_host: nf == 1 — SpmvCall::fe_host)
   for (uint64_t f = wave; f < nf; f += nwaves) {
     const uint32_t i = fidx[f];
-    const T ui = use_u ? uval[i] : T();
+    T ui = T(); if (use_u) { if (uval) ui = uval[i]; else ui = T(true); }          // (uval == nullptr: every operand value is true — SpmvCall::excl_small)
     const uint32_t pb = rowptr[i], pe = rowptr[i + 1];
     if (pe - pb > (uint32_t)PUSH_LONG) {          // hub row: handed to the all-blocks kernel below (one wave would take ms)
       if (lane == 0) longlist[1 + atomicAdd(&longlist[0], 1u)] = i;
@@ -542,6 +544,7 @@ __global__ __launch_bounds__(256) void k_spmspv_push(const uint32_t* __restrict_
     for (uint32_t p = pb + lane; p < pe; p += 64) {
       const uint32_t j = col[p];
       if (allow && !allow[j]) continue;
+      if (excl.n && small_list_has(excl, j)) continue;
       const T m = sr.mult(use_a ? aval[p] : T(), ui);
       atomic_combine<T>(sr.add_op(), &tval[j], m);
       tpres[j] = 1;
@@ -557,7 +560,8 @@ template <class T, class SR>
 __global__ __launch_bounds__(256) void k_spmspv_push_long(const uint32_t* __restrict__ longlist, const uint32_t* __restrict__ rowptr,
                                                           const uint32_t* __restrict__ col, const T* __restrict__ aval, const T* __restrict__ uval,
                                                           const uint8_t* __restrict__ allow, T* __restrict__ tval, uint8_t* __restrict__ tpres, const SR sr,
-                                                          uint32_t* __restrict__ any_true = nullptr, const uint32_t any_tag = 0, unsigned long long* __restrict__ fe_host = nullptr) {
+                                                          uint32_t* __restrict__ any_true = nullptr, const uint32_t any_tag = 0, unsigned long long* __restrict__ fe_host = nullptr,
+                                                          const SmallList64 excl = SmallList64{0, {0}}) {
   const uint32_t nl = longlist[0];
   const bool use_a = sr.uses_a(), use_u = sr.uses_u();
   unsigned long long fe = 0, fcnt = 0;
@@ -565,11 +569,12 @@ __global__ __launch_bounds__(256) void k_spmspv_push_long(const uint32_t* __rest
   const bool split = nl < gridDim.x / 8;
   for (uint32_t l = split ? 0 : blockIdx.x; l < nl; l += split ? 1 : gridDim.x) {
     const uint32_t i = longlist[1 + l];
-    const T ui = use_u ? uval[i] : T();
+    T ui = T(); if (use_u) { if (uval) ui = uval[i]; else ui = T(true); }
     const uint32_t pb = rowptr[i], pe = rowptr[i + 1];
     for (uint64_t p = (uint64_t)pb + (split ? blockIdx.x * 256ull : 0ull) + threadIdx.x; p < pe; p += split ? (uint64_t)gridDim.x * 256ull : 256ull) {
       const uint32_t j = col[p];
       if (allow && !allow[j]) continue;
+      if (excl.n && small_list_has(excl, j)) continue;
       const T m = sr.mult(use_a ? aval[p] : T(), ui);
       atomic_combine<T>(sr.add_op(), &tval[j], m);
       tpres[j] = 1;
@@ -756,7 +761,6 @@ template <class T> __global__ void k_fill(T* p, uint64_t n, T v) {
 }
 
 // zero fill of the presence bytes, identity fill of the values (16 positions per thread), the operand's list and the cleared hub-row counter: one launch
-struct SmallList64 { uint32_t n; uint32_t idx[64]; };
 template <class T> __global__ void k_push_init(T* __restrict__ tval, uint8_t* __restrict__ tpres, uint64_t n, T ident, const SmallList64 sl, uint32_t* __restrict__ fidx, uint32_t* __restrict__ longlist) {
   if (blockIdx.x == 0) { if (threadIdx.x < sl.n) fidx[threadIdx.x] = sl.idx[threadIdx.x]; if (threadIdx.x == 64) longlist[0] = 0; }
   const uint64_t n16 = n / 16;
@@ -780,6 +784,8 @@ template <class T> void run_push(const SpmvCall& c, const SemiringDesc& d, const
       hipLaunchKernelGGL((k_push_init<T>), dim3(grid_of(nout / 16 + 1)), dim3(256), 0, stream(), (T*)c.tval, c.tpres, nout, sr.identity, sl, (uint32_t*)fidx_w, longlist);
     } else if (nout) hipLaunchKernelGGL((k_fill<T>), dim3(grid_of(nout)), dim3(256), 0, stream(), (T*)c.tval, nout, sr.identity);
     uint64_t nb = (u_nvals + 3) / 4; if (nb < 1) nb = 1; if (nb > 16384) nb = 16384;
+    SmallList64 excl; excl.n = 0;
+    if (c.excl_small && c.small_idx && c.small_n == u_nvals && u_nvals <= 64) { excl.n = (uint32_t)u_nvals; for (uint32_t q = 0; q < excl.n; q++) excl.idx[q] = c.small_idx[q]; }
     uint32_t* any_true = nullptr; unsigned long long* fe_host = nullptr;
     if (c.any_true && c.any_true_done && is_bool<T>::value && (sr.add_op() == B_LOR || sr.add_op() == B_PLUS || sr.add_op() == B_MAX)) {
       any_true = c.any_true; *c.any_true_done = true;
@@ -787,9 +793,9 @@ template <class T> void run_push(const SpmvCall& c, const SemiringDesc& d, const
       if (u_nvals == 1 && c.fe_host && c.fe_done && c.fe_rowptr == M.rowptr.as<uint32_t>()) { fe_host = c.fe_host; *c.fe_done = true; *c.fe_nblocks = 1u + 1024u; }
     }
     hipLaunchKernelGGL((k_spmspv_push<T, SR>), dim3((unsigned)nb), dim3(256), 0, stream(), fidx, (uint32_t)u_nvals,
-                       M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(), (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, longlist, sr, any_true, c.any_true_tag, fe_host);
+                       M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(), (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, longlist, sr, any_true, c.any_true_tag, fe_host, excl);
     hipLaunchKernelGGL((k_spmspv_push_long<T, SR>), dim3(1024), dim3(256), 0, stream(), longlist, M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(),
-                       (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, sr, any_true, c.any_true_tag, fe_host);
+                       (const T*)c.aval, (const T*)c.uval, c.allow, (T*)c.tval, c.tpres, sr, any_true, c.any_true_tag, fe_host, excl);
     g_last_plan += std::string("k_spmspv_push<") + (sr.is_static ? "static> " : "dynamic> ");
   });
 }
