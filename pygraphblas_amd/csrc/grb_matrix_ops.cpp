@@ -94,6 +94,11 @@ void do_mxm(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, GrB_Semiring semirin
   call.aval = uses_a ? cast_values(sd.zcode, A->type->code, Ad.val.p, Ad.nnz, acast) : nullptr;
   call.bval = uses_b ? cast_values(sd.zcode, B->type->code, Bd.val.p, Bd.nnz, bcast) : nullptr;
   DevCSR T; bool t_masked = false;
+  {
+    const char* de = getenv("GRB_MI355X_DETERMINISTIC");
+    const bool fp = sd.zcode == T_FP32 || sd.zcode == T_FP64;
+    call.ordered = fp && ((de && atoi(de) != 0) || dv.axb == GxB_AxB_GUSTAVSON);
+  }
   if (mxm_few_rows_wanted(Ad, Bd)) {            // a handful of output rows (batched BC frontiers): one vxm per row, see grb_mxm_rows.cpp
     mxm_few_rows(Ad, A->type, M, dv, semiring, B, sd.zcode, T); t_masked = true;
   } else if (M && !dv.mask_comp) {
@@ -107,9 +112,6 @@ void do_mxm(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, GrB_Semiring semirin
     // walk (floating-point sums bit-reproducible from run to run at ~1.3 x the time, grb_spgemm_hash.hpp); results too wide for that path (> 2^20 columns)
     // take expand / sort / compress.  Integer / Boolean monoids are exact in any order: nothing changes for them.
     const char* e = getenv("GRB_MI355X_SPGEMM");
-    const char* de = getenv("GRB_MI355X_DETERMINISTIC");
-    const bool fp = sd.zcode == T_FP32 || sd.zcode == T_FP64;
-    call.ordered = fp && ((de && atoi(de) != 0) || dv.axb == GxB_AxB_GUSTAVSON);
     if ((e && !strcmp(e, "esc")) || dv.axb == GxB_AxB_DOT || (call.ordered && Bd.ncols > (1u << 20))) spgemm_esc(call, sd, T); else spgemm_hash(call, sd, T);
   }
   matrix_write_back(C, T, sd.zcode, M, dv, accum, t_masked);

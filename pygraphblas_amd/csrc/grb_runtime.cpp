@@ -355,3 +355,22 @@ GrB_Info GrBX_memory_in_use(size_t* b) { if (b) *b = g_in_use; return GrB_SUCCES
 GrB_Info GrBX_last_kernel_plan(char* buf, int len) { if (buf && len > 0) snprintf(buf, len, "%s", g_last_plan.c_str()); return GrB_SUCCESS; }
 
 }  // extern "C"
+
+// ---- the exact accumulators of the masked product's deterministic mode on the host (grb_exact.hpp): what the CPU suite checks against math.fsum ----------
+#include "grb_exact.hpp"
+extern "C" GrB_Info GrBX_exact_sum_host(const double* terms, uint64_t n, int significand_bits, double* sum, int* unit_exp_out) {
+  if (!terms || !sum || (significand_bits != 53 && significand_bits != 24)) return GrB_NULL_POINTER;
+  double bound = 0.0;
+  for (uint64_t q = 0; q < n; q++) { const double a = fabs(terms[q]); if (!(a <= bound)) bound = a; }       // NaN sticks
+  if (!(bound <= std::numeric_limits<double>::max())) return GrB_INVALID_VALUE;
+  int H = 0; while ((1ull << H) <= n) H++;
+  const int u = (bound > 0.0 ? ilogb(bound) + 2 : -1074) + H - 126;
+  unsigned long long lo = 0, hi = 0;
+  for (uint64_t q = 0; q < n; q++) {
+    unsigned long long xl, xh; grb::fx_from_double(terms[q], u, xl, xh);
+    const unsigned long long old = lo; lo += xl; hi += xh + (lo < old ? 1ull : 0ull);
+  }
+  *sum = significand_bits == 53 ? grb::fx_to_fp<53>(lo, hi, u) : grb::fx_to_fp<24>(lo, hi, u);
+  if (unit_exp_out) *unit_exp_out = u;
+  return GrB_SUCCESS;
+}

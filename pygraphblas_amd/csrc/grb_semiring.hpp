@@ -16,6 +16,7 @@ namespace grb {
 template <class T, int ADD, int MUL> struct StaticSR {
   static constexpr bool is_static = true;
   static constexpr bool pair_only = MUL == B_PAIR;      // the product is the constant 1 whatever the operands hold
+  static constexpr int add_code = ADD;
   T identity, terminal; bool has_terminal;
   GRB_HD T mult(T a, T u) const { return apply_binop<T>(MUL, a, u); }
   GRB_HD T add(T x, T y) const { return apply_binop<T>(ADD, x, y); }
@@ -28,6 +29,7 @@ template <class T, int ADD, int MUL> struct StaticSR {
 template <class T> struct DynSR {
   static constexpr bool is_static = false;
   static constexpr bool pair_only = false;
+  static constexpr int add_code = -1;                   // known at run time only
   T identity, terminal; bool has_terminal;
   int addop, mulop; bool flip;
   GRB_HD T mult(T a, T u) const { return flip ? apply_binop<T, false>(mulop, u, a) : apply_binop<T, false>(mulop, a, u); }

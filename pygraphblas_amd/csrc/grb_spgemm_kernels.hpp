@@ -19,6 +19,7 @@
 #include "grb_device.hpp"
 #include "grb_semiring.hpp"
 #include "grb_atomics.hpp"
+#include "grb_exact.hpp"
 #include "grb_matops.hpp"
 #include "grb_spgemm_kernels_fwd.hpp"
 #include <algorithm>
@@ -33,6 +34,8 @@ template <class T> struct SpgemmKArgs {
   const uint32_t* brp; const uint32_t* bcol; const T* bval;
   const uint32_t* mrp; const uint32_t* mcol; const void* mval; int mcode; bool mstruct;
   typename acc_word<T>::type* cacc; uint8_t* cflag;      // one slot per mask entry
+  // deterministic mode, exact accumulators (grb_exact.hpp): the unit exponent of every output row, and the 128-bit integers of the rows that accumulate in HBM
+  const int32_t* rowexp; unsigned long long* xlo; unsigned long long* xhi;
 };
 
 __device__ __forceinline__ bool spgemm_mask_truth(const void* mval, int mcode, uint32_t p, bool structural) {
@@ -100,9 +103,12 @@ constexpr uint32_t SPG_FILTER_MUL = 0x9E3779u;   // 24-bit multiplier: v_mul_u32
 // mbcnt), and whenever the queue holds 64 columns the wave looks all of them up in the exact table with every lane busy.
 // When the multiply reads no value (PLUS_PAIR: the triangle count) the queue is carried from B row to B row; otherwise it is
 // flushed at the end of every B row (the A value changes), and B rows shorter than 256 entries keep the direct lookup.
-template <class T, class SR, int SLOTS, int TEAM, int BLOCK>
+// EXACT (deterministic mode, PLUS monoid on FP32 / FP64): the accumulators are 128-bit integers in the row's unit (grb_exact.hpp) — the order the atomics
+// land in no longer matters, everything else in the kernel is the same.
+template <class T, class SR, int SLOTS, int TEAM, int BLOCK, bool EXACT = false>
 __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T> a, const uint32_t* __restrict__ rows, uint32_t nrows_bin, const SR sr) {
   typedef typename acc_word<T>::type W;
+  typedef typename std::conditional<EXACT, unsigned long long, W>::type AW;
   constexpr int TEAMS = BLOCK / TEAM;
   constexpr int LCAP = TEAM >= 1024 ? SPG_LIST_BIG_V : (TEAM >= 256 ? SPG_LIST : 64);
   constexpr bool NOVAL = SR::pair_only;                 // the product is a constant: a queued survivor is its column alone
@@ -115,7 +121,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
   constexpr int WAVES = BLOCK / 64;
   __shared__ uint32_t s_key[TEAMS][KS];
   __shared__ uint16_t s_pos[TEAMS][KS];
-  __shared__ W s_acc[TEAMS][ML];
+  __shared__ AW s_acc[TEAMS][ML];
+  __shared__ unsigned long long s_hi[TEAMS][EXACT ? ML : 1];
   __shared__ uint8_t s_flag[TEAMS][ML];
   __shared__ uint32_t s_filt[TEAMS][FW];
   __shared__ uint32_t s_qj[WAVES][SPG_QCAP];
@@ -129,7 +136,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
   constexpr int NG = TEAM / 16, NW = TEAM / 64;
   const bool use_a = sr.uses_a(), use_b = sr.uses_u();
   const W idw = to_word<T>(sr.identity);
-  uint32_t* key = s_key[team]; W* acc = s_acc[team]; uint16_t* pos = s_pos[team]; uint8_t* flag = s_flag[team]; uint32_t* filt = s_filt[team];
+  int uexp = 0;                                          // EXACT: the unit exponent of the row being formed
+  uint32_t* key = s_key[team]; AW* acc = s_acc[team]; unsigned long long* const hiw = s_hi[team]; uint16_t* pos = s_pos[team]; uint8_t* flag = s_flag[team]; uint32_t* filt = s_filt[team];
   uint32_t* lpa = s_lpa[team]; uint32_t* lbb = s_lbb[team]; uint32_t* lbe = s_lbe[team]; uint32_t* cnt = s_cnt[team];
   const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint32_t* qj = s_qj[wave_in_block]; uint32_t* qp = s_qp[NOVAL ? 0 : wave_in_block];
@@ -146,7 +154,12 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
     uint32_t h = hash_col(j, KS - 1);
     uint32_t kk = key[h];
     while (kk != j && kk != HASH_EMPTY) { h = (h + 1) & (KS - 1); kk = key[h]; }
-    if (kk == j) { const uint32_t mp = pos[h]; word_combine<T>(sr.add_op(), &acc[mp], sr.mult(av, use_b ? a.bval[pb] : T())); flag[mp] = 1; }
+    if (kk == j) {
+      const uint32_t mp = pos[h];
+      if constexpr (EXACT) fx_add(&acc[mp], &hiw[mp], (double)sr.mult(av, use_b ? a.bval[pb] : T()), uexp);
+      else word_combine<T>(sr.add_op(), &acc[mp], sr.mult(av, use_b ? a.bval[pb] : T()));
+      flag[mp] = 1;
+    }
   };
   // bit FSH.. of the 24-bit product picks the filter bit: the top LW bits the word, the five below them the bit in the word
   constexpr int LW = __builtin_ctz(FW);
@@ -194,7 +207,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
     const bool live = ridx < nrows_bin;
     const uint32_t i = live ? rows[ridx] : 0;
     for (int s2 = t; s2 < KS; s2 += TEAM) key[s2] = HASH_EMPTY;
-    for (int s2 = t; s2 < ML; s2 += TEAM) { acc[s2] = idw; flag[s2] = 0; }
+    if constexpr (EXACT) { uexp = __builtin_amdgcn_readfirstlane(live ? a.rowexp[i] : 0); for (int s2 = t; s2 < ML; s2 += TEAM) { acc[s2] = 0; hiw[s2] = 0; flag[s2] = 0; } }
+    else for (int s2 = t; s2 < ML; s2 += TEAM) { acc[s2] = idw; flag[s2] = 0; }
     for (int s2 = t; s2 < FW; s2 += TEAM) filt[s2] = 0;
     team_sync();
     const uint32_t mb = live ? a.mrp[i] : 0, me = live ? a.mrp[i + 1] : 0;
@@ -341,7 +355,10 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
       if (qn) { flush(qn, T()); qn = 0; }
       team_sync();
     }
-    for (uint32_t mp = t; mp < me - mb; mp += TEAM) if (flag[mp]) { a.cacc[mb + mp] = acc[mp]; a.cflag[mb + mp] = 1; }     // by mask position: coalesced
+    for (uint32_t mp = t; mp < me - mb; mp += TEAM) if (flag[mp]) {                                                         // by mask position: coalesced
+      if constexpr (EXACT) a.cacc[mb + mp] = to_word<T>((T)fx_to_fp<fx_bits<T>::P>(acc[mp], hiw[mp], uexp)); else a.cacc[mb + mp] = acc[mp];
+      a.cflag[mb + mp] = 1;
+    }
     team_sync();
   }
 }
@@ -358,20 +375,26 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
 constexpr uint32_t SPG_FILTER_WORDS = 8192;         // 2^18 bits = 32 KiB of LDS
 constexpr uint32_t SPG_MAP_LDS_BYTES = 96 * 1024;   // accumulators of the first positions of the mask row
 constexpr uint32_t SPG_MAP_SLICE = SPG_SLICE_V;            // entries of A(i,:) per task (1024: 44.2 ms, 2048: 43.4, 4096: 43.4, 8192: 43.1 for the R-MAT-22 triangle count)
-template <class T, class SR, bool CNT32>
+// EXACT (deterministic mode): every accumulator is a 128-bit integer (grb_exact.hpp) — low words, high words and flags of the first LCF positions in the
+// same LDS budget, the positions behind them and the hand-over of every task in a.xlo / a.xhi (integer atomics: the slices of a row and the workgroups may
+// finish in any order); k_exact_finish rounds the integers into cacc afterwards.
+template <class T, class SR, bool CNT32, bool EXACT = false>
 __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T> a, const uint32_t* __restrict__ rows, uint32_t nrows_bin, uint32_t nslices,
                                                             uint32_t* __restrict__ maps, uint32_t ncols, const SR sr) {
+  static_assert(!(CNT32 && EXACT), "counting products are integers");
   typedef typename acc_word<T>::type W;
-  typedef typename std::conditional<CNT32, uint32_t, W>::type LW;        // what an LDS accumulator holds
+  typedef typename std::conditional<CNT32, uint32_t, typename std::conditional<EXACT, unsigned long long, W>::type>::type LW;        // what an LDS accumulator holds
   constexpr uint32_t LC = SPG_MAP_LDS_BYTES / sizeof(LW);
   // counters: 0 = no hit yet.  Generic accumulators start at the identity and carry a flag byte each (LCF words + LCF bytes in the same budget)
-  constexpr uint32_t LCF = CNT32 ? LC : (uint32_t)(SPG_MAP_LDS_BYTES / (sizeof(LW) + 1));
+  constexpr uint32_t LCF = CNT32 ? LC : (uint32_t)(SPG_MAP_LDS_BYTES / ((EXACT ? 16 : sizeof(LW)) + 1));
   __shared__ uint32_t s_filter[SPG_FILTER_WORDS];
   // bit of column j: a multiplicative hash (R-MAT labels are skewed bit by bit: `j mod 2^18` crowds the filter's low words)
   constexpr int FSH = 32 - (__builtin_ctz(SPG_FILTER_WORDS) + 5);
   auto fbit = [](const uint32_t j) -> uint32_t { return (uint32_t)__umul24(j, SPG_FILTER_MUL) >> FSH; };
   __shared__ LW s_acc[LC];
-  uint8_t* const s_flag = (uint8_t*)(s_acc + LCF);
+  unsigned long long* const s_hiw = (unsigned long long*)(s_acc + LCF);          // (EXACT only)
+  uint8_t* const s_flag = (uint8_t*)(s_acc + (EXACT ? 2 * LCF : LCF));
+  int uexp = 0;
   constexpr uint32_t HL = 4096;                            // A-entries whose B row is huge: set aside by the waves, then walked by the whole block
   __shared__ uint32_t s_hl[HL];
   __shared__ uint32_t s_nh;
@@ -384,9 +407,11 @@ __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T>
     const uint32_t mp = slot1 - 1;
     if (mp < LCF) {
       if constexpr (CNT32) atomicAdd(&s_acc[mp], 1u);             // PLUS_PAIR: the product is 1
+      else if constexpr (EXACT) { fx_add((unsigned long long*)&s_acc[mp], &s_hiw[mp], (double)sr.mult(av, use_b ? a.bval[pb] : T()), uexp); s_flag[mp] = 1; }
       else { word_combine<T>(sr.add_op(), (W*)&s_acc[mp], sr.mult(av, use_b ? a.bval[pb] : T())); s_flag[mp] = 1; }
     } else {
-      word_combine<T>(sr.add_op(), &a.cacc[mb + mp], sr.mult(av, use_b ? a.bval[pb] : T()));
+      if constexpr (EXACT) fx_add(&a.xlo[mb + mp], &a.xhi[mb + mp], (double)sr.mult(av, use_b ? a.bval[pb] : T()), uexp);
+      else word_combine<T>(sr.add_op(), &a.cacc[mb + mp], sr.mult(av, use_b ? a.bval[pb] : T()));
       a.cflag[mb + mp] = 1;
     }
   };
@@ -430,16 +455,7 @@ __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T>
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const uint32_t pb = pb0 + step * u;
-        if (ss[u]) {
-          const uint32_t mp = ss[u] - 1;
-          if (mp < LCF) {
-            if constexpr (CNT32) atomicAdd(&s_acc[mp], 1u);             // PLUS_PAIR: the product is 1
-            else { word_combine<T>(sr.add_op(), (W*)&s_acc[mp], sr.mult(av, use_b ? a.bval[pb] : T())); s_flag[mp] = 1; }
-          } else {
-            word_combine<T>(sr.add_op(), &a.cacc[mb + mp], sr.mult(av, use_b ? a.bval[pb] : T()));
-            a.cflag[mb + mp] = 1;
-          }
-        }
+        if (ss[u]) hit(ss[u], pb, av, mb);
       }
     }
   };
@@ -456,7 +472,8 @@ __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T>
     const uint32_t mb = a.mrp[i], me = a.mrp[i + 1];
     for (uint32_t w = t; w < SPG_FILTER_WORDS; w += 1024) s_filter[w] = 0;
     const uint32_t nl = (me - mb) < LCF ? (me - mb) : LCF;
-    for (uint32_t w = t; w < nl; w += 1024) { if constexpr (CNT32) s_acc[w] = 0; else { s_acc[w] = (LW)idw; s_flag[w] = 0; } }
+    if constexpr (EXACT) uexp = __builtin_amdgcn_readfirstlane(a.rowexp[i]);
+    for (uint32_t w = t; w < nl; w += 1024) { if constexpr (CNT32) s_acc[w] = 0; else if constexpr (EXACT) { s_acc[w] = 0; s_hiw[w] = 0; s_flag[w] = 0; } else { s_acc[w] = (LW)idw; s_flag[w] = 0; } }
     if (t == 0) s_nh = 0;
     __syncthreads();
     for (uint32_t p = mb + t; p < me; p += 1024) if (spgemm_mask_truth(a.mval, a.mcode, p, a.mstruct)) {
@@ -489,6 +506,8 @@ __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T>
       if constexpr (CNT32) {
         const uint32_t c = s_acc[w];
         if (c) { if (shared_row) word_combine<T>(B_PLUS, &a.cacc[mb + w], (T)c); else a.cacc[mb + w] = to_word<T>((T)c); a.cflag[mb + w] = 1; }
+      } else if constexpr (EXACT) {
+        if (s_flag[w]) { fx_add_words(&a.xlo[mb + w], &a.xhi[mb + w], (unsigned long long)s_acc[w], s_hiw[w]); a.cflag[mb + w] = 1; }
       } else if (s_flag[w]) {
         if (shared_row) word_combine<T>(sr.add_op(), &a.cacc[mb + w], from_word<T>((W)s_acc[w])); else a.cacc[mb + w] = (W)s_acc[w];
         a.cflag[mb + w] = 1;
@@ -517,9 +536,132 @@ template <class T> __global__ void k_compact_acc(uint32_t nrows, const uint32_t*
 // and bin), reserves its part of every list with ONE global atomic per bin, and writes its rows behind that base — 1 280 global atomics
 // for any number of rows (one per wave and bin, on five addresses, was 1.2 ms of the R-MAT-22 triangle count: same-address
 // atomics complete one at a time).
+// ---- (1c) deterministic mode of the masked product (round 5; GRB_MI355X_DETERMINISTIC=1 / GxB_AxB_GUSTAVSON, floating point only) ----------------
+// The teams above let every 16-lane group and every wave of a row add into the row's accumulators as their atomics land.  Here ONE group of G lanes owns a
+// work item = (row i, slice of at most CAP entries of M(i,:)): the slice's columns (sorted, as every CSR row is) and its accumulators sit in the group's
+// own LDS; the group walks the entries k of A(i,:) one after the other, its lanes the entries of B(k,:) — columns of one B row are distinct, so the lanes
+// of a step touch distinct accumulators with plain read-add-write, and an accumulator receives its terms in k order in every run, whatever the
+// schedule.  A product finds its position by a range check and a binary search of the slice (no hash, no filter).  Mask rows longer than CAP are cut into
+// slices that different waves take (each walks all of the row's products and keeps those of its columns): the price of never sharing an accumulator.
+// G = 16 for mask rows of <= 32 entries (four rows per wave), G = 64 with slices of 512 for the rest.
+constexpr int SPG_ORD_CAP16 = 32, SPG_ORD_CAP64 = 512;
+static __global__ void k_ordered_items(const uint32_t* __restrict__ rows, uint32_t nrows_bin, const uint32_t* __restrict__ mrp, uint32_t* __restrict__ item_row,
+                                       uint32_t* __restrict__ item_slice, uint32_t* __restrict__ count) {
+  for (uint64_t q = blockIdx.x * 256ull + threadIdx.x; q < nrows_bin; q += gridDim.x * 256ull) {
+    const uint32_t i = rows[q], ns = (mrp[i + 1] - mrp[i] + SPG_ORD_CAP64 - 1) / SPG_ORD_CAP64;
+    const uint32_t base = atomicAdd(count, ns);
+    for (uint32_t z = 0; z < ns; z++) { item_row[base + z] = i; item_slice[base + z] = z; }
+  }
+}
+template <class T, class SR, int G>
+__global__ __launch_bounds__(256) void k_spgemm_masked_ordered(const SpgemmKArgs<T> a, const uint32_t* __restrict__ item_row, const uint32_t* __restrict__ item_slice,
+                                                               uint32_t nitems, const uint32_t* __restrict__ nitems_p, const SR sr) {
+  constexpr int GROUPS = 256 / G, CAP = G == 16 ? SPG_ORD_CAP16 : SPG_ORD_CAP64;
+  __shared__ uint32_t s_col[GROUPS][CAP];
+  __shared__ T s_acc[GROUPS][CAP];
+  __shared__ uint8_t s_flag[GROUPS][CAP];          // bit 1: the mask entry is true, bit 0: a product landed
+  const int g = threadIdx.x / G, t = threadIdx.x % G;
+  uint32_t* col = s_col[g]; T* acc = s_acc[g]; uint8_t* flag = s_flag[g];
+  const bool use_a = sr.uses_a(), use_b = sr.uses_u();
+  auto group_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };      // a group never spans waves: LDS operations of a wave execute in order
+  const uint32_t n = nitems_p ? *nitems_p : nitems;
+  for (uint64_t it = (uint64_t)blockIdx.x * GROUPS + g; it < n; it += (uint64_t)gridDim.x * GROUPS) {
+    const uint32_t i = item_row[it], sl = item_slice ? item_slice[it] : 0u;
+    const uint32_t mb = a.mrp[i] + sl * CAP, mend = a.mrp[i + 1], me = mb + CAP < mend ? mb + CAP : mend, len = me - mb;
+    group_sync();
+    for (uint32_t q = t; q < len; q += G) {
+      col[q] = a.mcol[mb + q]; acc[q] = sr.identity;
+      flag[q] = spgemm_mask_truth(a.mval, a.mcode, mb + q, a.mstruct) ? 2 : 0;
+    }
+    group_sync();
+    const uint32_t lo = col[0], hi = col[len - 1];
+    const uint32_t ab = a.arp[i], ae = a.arp[i + 1];
+    uint32_t bb = 0, be = 0; T av = T();
+    if (ab < ae) { const uint32_t k = a.acol[ab]; bb = a.brp[k]; be = a.brp[k + 1]; if (use_a) av = a.aval[ab]; }
+    for (uint32_t pa = ab; pa < ae; pa++) {
+      uint32_t nbb = 0, nbe = 0; T nav = T();                  // the next entry's B row is looked up while this one is walked
+      if (pa + 1 < ae) { const uint32_t k = a.acol[pa + 1]; nbb = a.brp[k]; nbe = a.brp[k + 1]; if (use_a) nav = a.aval[pa + 1]; }
+      for (uint32_t pb = bb + t; pb < be; pb += G) {
+        const uint32_t j = a.bcol[pb];
+        if (j < lo || j > hi) continue;
+        uint32_t l = 0, h = len;
+        while (h - l > 1) { const uint32_t mid = (l + h) >> 1; if (col[mid] <= j) l = mid; else h = mid; }
+        if (col[l] == j && (flag[l] & 2)) { acc[l] = sr.add(acc[l], sr.mult(av, use_b ? a.bval[pb] : T())); flag[l] = 3; }
+      }
+      asm volatile("" ::: "memory");
+      bb = nbb; be = nbe; av = nav;
+    }
+    group_sync();
+    for (uint32_t q = t; q < len; q += G) if (flag[q] & 1) { a.cacc[mb + q] = to_word<T>(acc[q]); a.cflag[mb + q] = 1; }
+  }
+}
+
+// ---- (1d) the exact accumulators' row units (grb_exact.hpp) ---------------------------------------------------------------------------------------
+// |x| as an ordered integer: NaN above Inf above every finite value, so an integer max carries "not finite" along
+__device__ __forceinline__ unsigned long long fx_abs_bits(const double v) { return (unsigned long long)__double_as_longlong(v) & 0x7FFFFFFFFFFFFFFFull; }
+template <class T> __global__ void k_row_absmax(uint32_t nrows, const uint32_t* __restrict__ rp, const T* __restrict__ val, double* __restrict__ out) {
+  const uint32_t g = (blockIdx.x * 256u + threadIdx.x) >> 4, l = threadIdx.x & 15u, ng = gridDim.x * 16u;
+  for (uint32_t r = g; r < nrows; r += ng) {
+    unsigned long long m = 0;
+    for (uint32_t p = rp[r] + l; p < rp[r + 1]; p += 16) { const unsigned long long b = fx_abs_bits((double)val[p]); m = b > m ? b : m; }
+    for (int o = 8; o; o >>= 1) { const unsigned long long x = __shfl_xor(m, o, 16); m = x > m ? x : m; }
+    if (l == 0) out[r] = __longlong_as_double((long long)m);
+  }
+}
+inline bool exact_mult_supported(int mulop) {
+  switch (mulop) { case B_TIMES: case B_FIRST: case B_SECOND: case B_PAIR: case B_PLUS: case B_MINUS: case B_RMINUS: case B_MIN: case B_MAX: case B_ANY: return true; default: return false; }
+}
+// unit exponent of row i: 2^E above the largest |product| the row can form (the multiply applied to |A(i,k)| and max |B(k,:)|, in T, rounded as the product
+// is — rounding is monotonic), 2^H above the number of products an entry can receive; FX_NO_EXP when that bound is Inf or NaN
+template <class T> __global__ void k_row_unit_exp(uint32_t nrows, const uint32_t* __restrict__ arp, const uint32_t* __restrict__ acol, const T* __restrict__ aval,
+                                                  const double* __restrict__ bmax, int mulop, int32_t* __restrict__ out) {
+  const uint32_t g = (blockIdx.x * 256u + threadIdx.x) >> 4, l = threadIdx.x & 15u, ng = gridDim.x * 16u;
+  for (uint32_t r = g; r < nrows; r += ng) {
+    unsigned long long m = 0;
+    const uint32_t ab = arp[r], ae = arp[r + 1];
+    for (uint32_t p = ab + l; p < ae; p += 16) {
+      const T aa = aval ? (T)fabs((double)aval[p]) : T(1), bb = bmax ? (T)bmax[acol[p]] : T(1);
+      unsigned long long b;
+      switch (mulop) {
+        case B_TIMES: b = fx_abs_bits((double)(T)(aa * bb)); break;
+        case B_FIRST: b = fx_abs_bits((double)aa); break;
+        case B_SECOND: b = fx_abs_bits((double)bb); break;
+        case B_PAIR: b = fx_abs_bits(1.0); break;
+        case B_PLUS: case B_MINUS: case B_RMINUS: b = fx_abs_bits((double)(T)(aa + bb)); break;
+        default: { const unsigned long long x = fx_abs_bits((double)aa), y = fx_abs_bits((double)bb); b = x > y ? x : y; } break;      // MIN, MAX, ANY
+      }
+      m = b > m ? b : m;
+    }
+    for (int o = 8; o; o >>= 1) { const unsigned long long x = __shfl_xor(m, o, 16); m = x > m ? x : m; }
+    if (l == 0) {
+      int32_t u = 0;
+      if (ae > ab) {
+        if (m > 0x7FEFFFFFFFFFFFFFull) u = FX_NO_EXP;
+        else { const double bound = __longlong_as_double((long long)m); u = (m ? ilogb(bound) + 2 : -1074) + (32 - __clz((int)(ae - ab))) - 126; }
+      }
+      out[r] = u;
+    }
+  }
+}
+static __global__ void k_rows_without_unit(uint32_t nrows, const int32_t* __restrict__ rowexp, const uint32_t* __restrict__ mrp, const uint32_t* __restrict__ arp,
+                                           uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+  for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < nrows; r += gridDim.x * 256ull)
+    if (rowexp[r] == FX_NO_EXP && mrp[r + 1] > mrp[r] && arp[r + 1] > arp[r]) list[atomicAdd(count, 1u)] = (uint32_t)r;
+}
+// the rows that accumulated in a.xlo / a.xhi (the HBM-map bin): the integers rounded once into the accumulator words the compaction reads
+template <class T> __global__ void k_exact_finish(const uint32_t* __restrict__ rows, uint32_t nrows_bin, const uint32_t* __restrict__ mrp, const int32_t* __restrict__ rowexp,
+                                                  const unsigned long long* __restrict__ xlo, const unsigned long long* __restrict__ xhi, const uint8_t* __restrict__ cflag,
+                                                  typename acc_word<T>::type* __restrict__ cacc) {
+  for (uint32_t q = blockIdx.x; q < nrows_bin; q += gridDim.x) {
+    const uint32_t i = rows[q]; const int u = rowexp[i];
+    for (uint32_t p = mrp[i] + threadIdx.x; p < mrp[i + 1]; p += blockDim.x) if (cflag[p]) cacc[p] = to_word<T>((T)fx_to_fp<fx_bits<T>::P>(xlo[p], xhi[p], u));
+  }
+}
+
 constexpr int SPG_BIN_ROWS = 16;      // rows per thread
 static __global__ __launch_bounds__(1024) void k_bin_rows(uint32_t nrows, const uint32_t* __restrict__ mrp, const uint32_t* __restrict__ arp, uint32_t* __restrict__ counts,
-                                  uint32_t* __restrict__ lists /* 5 x nrows */) {
+                                  uint32_t* __restrict__ lists /* 5 x nrows */, uint32_t lim3 /* longest mask row of the last LDS bin */,
+                                  const int32_t* __restrict__ rowexp /* exact mode: rows marked FX_NO_EXP are left out */) {
   __shared__ uint32_t s_cnt[5], s_base[5], s_max;
   const int lane = threadIdx.x & 63;
   if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
@@ -534,7 +676,7 @@ static __global__ __launch_bounds__(1024) void k_bin_rows(uint32_t nrows, const 
     int b = -1;
     if (r < nrows) {
       const uint32_t ml = mrp[r + 1] - mrp[r], al = arp[r + 1] - arp[r];
-      if (ml && al) b = ml <= 32 ? 0 : (ml <= 256 ? 1 : (ml <= 1024 ? 2 : (ml <= 4096 ? 3 : 4)));
+      if (ml && al && !(rowexp && rowexp[r] == FX_NO_EXP)) b = ml <= 32 ? 0 : (ml <= 256 ? 1 : (ml <= 1024 ? 2 : (ml <= lim3 ? 3 : 4)));
       if (b == 4 && al > al4) al4 = al;
     }
     bin[it] = (int8_t)b; rank[it] = 0;
@@ -585,14 +727,57 @@ template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDes
   DevBuf cacc(mnz * sizeof(W)), cflag(mnz), counts(32), lists((size_t)5 * nrows * 4 + 4);
   GRB_HIP(hipMemsetAsync(cflag.p, 0, mnz, stream()));
   GRB_HIP(hipMemsetAsync(counts.p, 0, 32, stream()));
-  hipLaunchKernelGGL(k_bin_rows, dim3((unsigned)(((uint64_t)nrows + 1024ull * SPG_BIN_ROWS - 1) / (1024ull * SPG_BIN_ROWS))), dim3(1024), 0, stream(), nrows, M.rowptr.as<uint32_t>(), A.rowptr.as<uint32_t>(), counts.as<uint32_t>(), lists.as<uint32_t>());
+  // Deterministic mode (c.ordered, floating point).  PLUS monoid over a multiply whose size can be bounded from the operands: the usual kernels with EXACT
+  // accumulators — 128-bit integers in a per-row unit, order-independent (grb_exact.hpp); rows whose bound is not finite, and every other semiring:
+  // k_spgemm_masked_ordered, one group per slice of a mask row with the entries of A(i,:) one after the other.
+  constexpr bool is_fp = std::is_floating_point<T>::value;
+  const bool exact = is_fp && c.ordered && d.addop == B_PLUS && !d.flip && exact_mult_supported(d.mulop) && !getenv("GRB_MI355X_NO_EXACT");
+  DevBuf rowexp, noexp_rows, xlo, xhi;
+  if constexpr (is_fp) if (exact) {
+    auto grid16 = [](uint64_t rows) { uint64_t b = (rows + 15) / 16; if (b < 1) b = 1; if (b > 16384) b = 16384; return (unsigned)b; };
+    DevBuf bmax;
+    if (c.bval) { bmax.alloc((size_t)B.nrows * 8 + 8);
+      hipLaunchKernelGGL((k_row_absmax<T>), dim3(grid16(B.nrows)), dim3(256), 0, stream(), B.nrows, B.rowptr.as<uint32_t>(), (const T*)c.bval, bmax.as<double>()); }
+    rowexp.alloc((size_t)nrows * 4 + 4); noexp_rows.alloc((size_t)nrows * 4 + 4);
+    hipLaunchKernelGGL((k_row_unit_exp<T>), dim3(grid16(nrows)), dim3(256), 0, stream(), nrows, A.rowptr.as<uint32_t>(), A.col.as<uint32_t>(), (const T*)c.aval,
+                       c.bval ? bmax.as<double>() : (const double*)nullptr, d.mulop, rowexp.as<int32_t>());
+    hipLaunchKernelGGL(k_rows_without_unit, dim3((unsigned)std::min<uint64_t>(((uint64_t)nrows + 255) / 256, 4096)), dim3(256), 0, stream(), nrows, rowexp.as<int32_t>(),
+                       M.rowptr.as<uint32_t>(), A.rowptr.as<uint32_t>(), noexp_rows.as<uint32_t>(), counts.as<uint32_t>() + 6);
+    GRB_HIP(hipStreamSynchronize(stream()));          // (bmax goes back to the pool)
+  }
+  hipLaunchKernelGGL(k_bin_rows, dim3((unsigned)(((uint64_t)nrows + 1024ull * SPG_BIN_ROWS - 1) / (1024ull * SPG_BIN_ROWS))), dim3(1024), 0, stream(), nrows, M.rowptr.as<uint32_t>(), A.rowptr.as<uint32_t>(), counts.as<uint32_t>(), lists.as<uint32_t>(),
+                     exact ? 2048u : 4096u, exact ? rowexp.as<int32_t>() : (const int32_t*)nullptr);
   uint32_t hc[8];
   GRB_HIP(hipMemcpyAsync(hc, counts.p, 32, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+  if (exact && hc[4]) { xlo.alloc(mnz * 8 + 8); xhi.alloc(mnz * 8 + 8); GRB_HIP(hipMemsetAsync(xlo.p, 0, mnz * 8, stream())); GRB_HIP(hipMemsetAsync(xhi.p, 0, mnz * 8, stream())); }
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;
     SpgemmKArgs<T> a{A.rowptr.as<uint32_t>(), A.col.as<uint32_t>(), (const T*)c.aval, B.rowptr.as<uint32_t>(), B.col.as<uint32_t>(), (const T*)c.bval,
-                     M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(), M.val.p, c.mcode, c.mstruct, cacc.as<W>(), cflag.as<uint8_t>()};
+                     M.rowptr.as<uint32_t>(), M.col.as<uint32_t>(), M.val.p, c.mcode, c.mstruct, cacc.as<W>(), cflag.as<uint8_t>(),
+                     exact ? rowexp.as<int32_t>() : (const int32_t*)nullptr, xlo.as<unsigned long long>(), xhi.as<unsigned long long>()};
     const uint32_t* L = lists.as<uint32_t>();
+    // the ordered kernel over (row, slice) work items: `lists_in` = up to four row lists, longest mask rows first; rows of <= 32 mask entries as 16-lane groups
+    [[maybe_unused]] auto run_ordered = [&](const uint32_t* const* lists_in, const uint32_t* counts_in, int nlists, const uint32_t* small, uint32_t nsmall) {
+      if constexpr (is_fp) {
+        uint64_t nbig = 0; for (int q = 0; q < nlists; q++) nbig += counts_in[q];
+        const uint64_t cap = nbig + mnz / SPG_ORD_CAP64 + 1;
+        DevBuf irow(cap * 4 + 4), islice(cap * 4 + 4), icount(4);
+        GRB_HIP(hipMemsetAsync(icount.p, 0, 4, stream()));
+        for (int q = 0; q < nlists; q++) if (counts_in[q])
+          hipLaunchKernelGGL(k_ordered_items, dim3((unsigned)std::min<uint64_t>(((uint64_t)counts_in[q] + 255) / 256, 4096)), dim3(256), 0, stream(), lists_in[q], counts_in[q],
+                             M.rowptr.as<uint32_t>(), irow.as<uint32_t>(), islice.as<uint32_t>(), icount.as<uint32_t>());
+        if (nbig) hipLaunchKernelGGL((k_spgemm_masked_ordered<T, SR, 64>), dim3(256 * 6), dim3(256), 0, stream(), a, irow.as<uint32_t>(), islice.as<uint32_t>(), 0u, icount.as<uint32_t>(), sr);
+        if (nsmall) hipLaunchKernelGGL((k_spgemm_masked_ordered<T, SR, 16>), dim3((unsigned)std::min<uint64_t>(((uint64_t)nsmall + 15) / 16, 2048)), dim3(256), 0, stream(), a, small,
+                                       (const uint32_t*)nullptr, nsmall, (const uint32_t*)nullptr, sr);
+        GRB_HIP(hipStreamSynchronize(stream()));          // the item lists go back to the pool when this scope ends
+        g_last_plan += std::string("k_spgemm_masked_ordered<") + (sr.is_static ? "static" : "dynamic") + "> rows " + std::to_string(nsmall) + " + " + std::to_string(nbig) + " ";
+      }
+    };
+    if constexpr (is_fp) if (c.ordered && !exact) {
+      const uint32_t* ls[4] = {L + (size_t)4 * nrows, L + (size_t)3 * nrows, L + (size_t)2 * nrows, L + (size_t)nrows}; const uint32_t cs[4] = {hc[4], hc[3], hc[2], hc[1]};
+      run_ordered(ls, cs, 4, L, hc[0]);
+      return;
+    }
     auto nblocks = [](uint32_t rows, int teams) { uint64_t b = ((uint64_t)rows + teams - 1) / teams; if (b > 256u * 64) b = 256u * 64; if (b < 1) b = 1; return (unsigned)b; };
     // the HBM-map kernel accumulates straight into cacc: start those slots at the identity (before any kernel writes results)
     if (hc[4]) hipLaunchKernelGGL((k_fill_words<W>), dim3(4096), dim3(256), 0, stream(), cacc.as<W>(), mnz, to_word<T>(sr.identity));
@@ -615,11 +800,27 @@ template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDes
     ax.fork(stream());
     const bool serial = getenv("GRB_MI355X_SPGEMM_SERIAL") != nullptr;      // experiment hook: run the bins one after the other
     hipStream_t bs[4]; for (int q = 0; q < 4; q++) bs[q] = serial ? stream() : ax.s[q];
+    constexpr bool can_exact = is_fp && (!SR::is_static || SR::add_code == B_PLUS);
+    bool launched_exact = false;
+    if constexpr (can_exact) if (exact) {
+      launched_exact = true;
+      if (hc[0]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 64, 64, 256, true>), dim3(nblocks(hc[0], 4)), dim3(256), 0, bs[0], a, L, hc[0], sr);
+      if (hc[1]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 512, 256, 256, true>), dim3(nblocks(hc[1], 1)), dim3(256), 0, bs[1], a, L + (size_t)nrows, hc[1], sr);
+      if (hc[2]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 2048, 512, 512, true>), dim3(nblocks(hc[2], 1)), dim3(512), 0, bs[2], a, L + (size_t)2 * nrows, hc[2], sr);
+      if (hc[3]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 4096, 1024, 1024, true>), dim3(nblocks(hc[3], 1)), dim3(1024), 0, bs[3], a, L + (size_t)3 * nrows, hc[3], sr);     // (mask rows of <= 2 048 entries: 16-byte accumulators)
+      if (hc[4]) {
+        hipLaunchKernelGGL((k_spgemm_masked_map<T, SR, false, true>), dim3(nb_map), dim3(1024), 0, stream(), a, L + (size_t)4 * nrows, hc[4], nslices, maps.as<uint32_t>(), B.ncols, sr);
+        hipLaunchKernelGGL((k_exact_finish<T>), dim3((unsigned)std::min<uint32_t>(hc[4], 4096u)), dim3(256), 0, stream(), L + (size_t)4 * nrows, hc[4], M.rowptr.as<uint32_t>(), rowexp.as<int32_t>(),
+                           xlo.as<unsigned long long>(), xhi.as<unsigned long long>(), cflag.as<uint8_t>(), cacc.as<W>());
+      }
+    }
+    if (!launched_exact) {
     if (hc[0]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 64, 64, 256>), dim3(nblocks(hc[0], 4)), dim3(256), 0, bs[0], a, L, hc[0], sr);
     if (hc[1]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 512, 256, 256>), dim3(nblocks(hc[1], 1)), dim3(256), 0, bs[1], a, L + (size_t)nrows, hc[1], sr);
     if (hc[2]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 2048, 512, 512>), dim3(nblocks(hc[2], 1)), dim3(512), 0, bs[2], a, L + (size_t)2 * nrows, hc[2], sr);
     if (hc[3]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 8192, 1024, 1024>), dim3(nblocks(hc[3], 1)), dim3(1024), 0, bs[3], a, L + (size_t)3 * nrows, hc[3], sr);
-    if (hc[4]) {
+    }
+    if (hc[4] && !launched_exact) {
       // a product that only counts (PLUS over PAIR on an integer type): 32-bit LDS counters, 24 576 positions per mask row
       constexpr bool can_count = SR::is_static && std::is_integral<T>::value && sizeof(T) >= 4;
       bool counted = false;
@@ -630,7 +831,11 @@ template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDes
     ax.join(stream()); guard.joined = true;
     if (hc[4]) GRB_HIP(hipStreamSynchronize(stream()));       // the maps go back to the pool when this scope ends
     g_last_plan += std::string("k_spgemm_masked<") + (sr.is_static ? "static" : "dynamic") + "> bins " + std::to_string(hc[0]) + "/" + std::to_string(hc[1]) + "/" +
-                   std::to_string(hc[2]) + "/" + std::to_string(hc[3]) + "/" + std::to_string(hc[4]) + " ";
+                   std::to_string(hc[2]) + "/" + std::to_string(hc[3]) + "/" + std::to_string(hc[4]) + (launched_exact ? " exact " : " ");
+    if (launched_exact && hc[6]) {                       // rows with an Inf / NaN bound
+      const uint32_t* ls[1] = {noexp_rows.as<uint32_t>()}; const uint32_t cs[1] = {hc[6]};
+      run_ordered(ls, cs, 1, nullptr, 0u);
+    }
   });
   GRB_HIP(hipGetLastError());
   // compaction (entry-parallel): position of every kept mask entry = exclusive scan of the flags

@@ -513,3 +513,142 @@ def test_deterministic_mode_of_the_unmasked_product_rmat18_is_bitwise_repeatable
         again, _ = product_values()
         assert torch.equal(again.view(torch.int64), first.view(torch.int64))
         del again
+
+
+def _mask_rows(rng, n, lens):
+    rows = np.concatenate([np.full(c, r) for r, c in enumerate(lens)]).astype(np.uint64)
+    cols = np.concatenate([np.sort(rng.choice(n, size=c, replace=False)) for c in lens]).astype(np.uint64)
+    return rows, cols
+
+
+def _bits(x):
+    return x.view(np.uint64 if x.dtype == np.float64 else np.uint32)
+
+
+def test_deterministic_mode_of_the_masked_product_every_mask_length_against_the_oracle(gpu, monkeypatch):
+    """GRB_MI355X_DETERMINISTIC=1 with a mask.  PLUS monoid: the usual kernels with exact accumulators (128-bit integers, grb_exact.hpp; plan "exact");
+    any other monoid: k_spgemm_masked_ordered (one group per slice of a mask row, the entries of A(i,:) in order).  Mask rows of 1 ... 30 000 entries (every
+    LDS bin, the HBM-map bin, up to 59 slices), valued masks with false entries and structural ones, FP64 and FP32, against the oracle, and the same bits twice."""
+    monkeypatch.setenv("GRB_MI355X_DETERMINISTIC", "1")
+    rng = np.random.default_rng(23)
+    n = 31000
+    lens = [1, 20, 32, 33, 200, 512, 513, 900, 1500, 2048, 2049, 3000, 5000, 9000, 30000]
+    rows, cols = _mask_rows(rng, n, lens)
+    for typ, rtol in (("FP64", 1e-13), ("FP32", 1e-5)):
+        for struct in (True, False):
+            mv = np.ones(len(rows), bool) if struct else rng.random(len(rows)) < 0.7
+            M = O.Tuples("BOOL", len(lens), n, rows, cols, mv)
+            for ka, da, db in ((300, 0.5, 0.05), (2500, 0.9, 0.01), (120, 0.6, 0.2)):
+                A = rand_matrix(rng, typ, len(lens), ka, da, small=False)
+                B = rand_matrix(rng, typ, ka, n, db, small=False)
+                for sr in ("PLUS_TIMES", "PLUS_SECOND", "PLUS_MIN", "MIN_PLUS"):
+                    add, mul = sr.split("_")
+                    desc = D.S if struct else None
+                    got = to_matrix(A).mxm(to_matrix(B), semiring=getattr(TYPE[typ], sr), mask=to_matrix(M), desc=desc)
+                    plan = gb.last_kernel_plan()
+                    assert (" exact" in plan) if add == "PLUS" else ("k_spgemm_masked_ordered" in plan), plan
+                    exp = O.mxm(O.Tuples(typ, len(lens), n), A, B, add, mul, typ, mask=M, mask_struct=struct)
+                    check(got, exp, typ, rtol=rtol, what=f"{typ}.{sr} struct={struct} ka={ka}")
+                    again = to_matrix(A).mxm(to_matrix(B), semiring=getattr(TYPE[typ], sr), mask=to_matrix(M), desc=desc)
+                    assert np.array_equal(_bits(matrix_tuples(got).X), _bits(matrix_tuples(again).X))
+    # integer types are exact in any order: the mode changes nothing for them
+    Ai, Bi = rand_matrix(rng, "INT64", len(lens), 300, 0.5), rand_matrix(rng, "INT64", 300, n, 0.05)
+    to_matrix(Ai).mxm(to_matrix(Bi), semiring=gb.INT64.PLUS_TIMES, mask=to_matrix(O.Tuples("BOOL", len(lens), n, rows, cols, np.ones(len(rows), bool))))
+    assert "ordered" not in gb.last_kernel_plan() and "exact" not in gb.last_kernel_plan()
+
+
+def test_exact_accumulators_of_the_masked_product_return_the_exactly_rounded_sums(gpu, monkeypatch):
+    """What "exact" means: every entry of C<M> = A (+.x) B is math.fsum of its products (each product rounded once by the multiply, the sum rounded once at
+    the end) — bit for bit, for FP64 and (products and result in FP32) for FP32, in every bin of the kernel including the rows that accumulate in HBM; values
+    spread over 2^40 so that an ordinary running sum differs from it in the last places.  A row holding an Inf is formed by the ordered kernel instead."""
+    import math
+    monkeypatch.setenv("GRB_MI355X_DETERMINISTIC", "1")
+    rng = np.random.default_rng(29)
+    n, ka = 9000, 200
+    lens = [3, 30, 200, 900, 2000, 3000, 8000]
+    rows, cols = _mask_rows(rng, n, lens)
+    M = O.Tuples("BOOL", len(lens), n, rows, cols, np.ones(len(rows), bool))
+    for typ, np_t in (("FP64", np.float64), ("FP32", np.float32)):
+        A = rand_matrix(rng, typ, len(lens), ka, 0.7, small=False)
+        B = rand_matrix(rng, typ, ka, n, 0.15, small=False)
+        A.X[:] = (A.X * np.exp2(rng.integers(-20, 20, len(A.X))) * rng.choice([-1.0, 1.0], len(A.X))).astype(np_t)
+        B.X[:] = (B.X * np.exp2(rng.integers(-20, 20, len(B.X))) * rng.choice([-1.0, 1.0], len(B.X))).astype(np_t)
+        got = to_matrix(A).mxm(to_matrix(B), semiring=getattr(TYPE[typ], "PLUS_TIMES"), mask=to_matrix(M), desc=D.S)
+        assert " exact" in gb.last_kernel_plan() and "ordered" not in gb.last_kernel_plan(), gb.last_kernel_plan()
+        Ad = np.zeros((len(lens), ka), np_t); Ap = np.zeros((len(lens), ka), bool)
+        Ad[A.I.astype(int), A.J.astype(int)] = A.X; Ap[A.I.astype(int), A.J.astype(int)] = True
+        Bd = np.zeros((ka, n), np_t); Bp = np.zeros((ka, n), bool)
+        Bd[B.I.astype(int), B.J.astype(int)] = B.X; Bp[B.I.astype(int), B.J.astype(int)] = True
+        g = matrix_tuples(got)
+        assert len(g.X) > 10000
+        differs_from_running_sum = 0
+        for i, j, x in zip(g.I.astype(int), g.J.astype(int), g.X):
+            ks = np.nonzero(Ap[i] & Bp[:, j])[0]
+            prods = (Ad[i, ks] * Bd[ks, j]).astype(np_t)                  # the multiply rounds once, in the value type
+            want = np_t(math.fsum(float(p) for p in prods)) if typ == "FP64" else None
+            if typ == "FP32":
+                from fractions import Fraction
+                ex = sum(Fraction(float(p)) for p in prods)
+                near = np.float32(float(ex))
+                cands = [np.nextafter(near, np.float32(-np.inf)), near, np.nextafter(near, np.float32(np.inf))]
+                want = min(cands, key=lambda c: (abs(Fraction(float(c)) - ex), int(np.float32(c).view(np.uint32)) & 1))
+            assert _bits(np.array([x], np_t))[0] == _bits(np.array([want], np_t))[0], (typ, i, j, x, want, len(ks))
+            run = np_t(0)
+            for p in prods: run = np_t(run + p)
+            differs_from_running_sum += int(run != x)
+        assert differs_from_running_sum > 0
+        # pattern: an entry exists wherever a product exists
+        exp = O.mxm(O.Tuples(typ, len(lens), n), A, B, "PLUS", "TIMES", typ, mask=M, mask_struct=True)
+        assert np.array_equal(g.I, exp.I) and np.array_equal(g.J, exp.J)
+    A.X[np.nonzero(A.I == 3)[0][0]] = np.inf
+    got = to_matrix(A).mxm(to_matrix(B), semiring=gb.FP32.PLUS_TIMES, mask=to_matrix(M), desc=D.S)
+    plan = gb.last_kernel_plan()
+    assert " exact" in plan and "k_spgemm_masked_ordered<static> rows 0 + 1" in plan, plan
+    g2 = matrix_tuples(got)
+    exp = O.mxm(O.Tuples("FP32", len(lens), n), A, B, "PLUS", "TIMES", "FP32", mask=M, mask_struct=True)
+    assert np.array_equal(g2.I, exp.I) and np.array_equal(g2.J, exp.J)
+    other = g2.I != 3
+    assert np.array_equal(_bits(g2.X[other]), _bits(g.X[g.I != 3]))              # the other rows: the exact sums as before
+    r3 = ~other
+    assert np.array_equal(np.isnan(g2.X[r3]), np.isnan(exp.X[r3])) and np.array_equal(np.isposinf(g2.X[r3]), np.isposinf(exp.X[r3]))
+    assert np.array_equal(np.isneginf(g2.X[r3]), np.isneginf(exp.X[r3])) and (~np.isfinite(g2.X[r3])).sum() > 100
+
+
+def test_deterministic_mode_of_the_masked_product_rmat18_is_bitwise_repeatable(gpu, monkeypatch):
+    """C<A> = A (+.x) A on the symmetric R-MAT-18 with random FP64 values (9.5e9 products against 7.6e6 mask entries): the deterministic mode's values are the
+    same bits three times, agree with the default mode's (atomics as they land) to 1e-10, and the pattern is the default mode's."""
+    import time
+    import torch
+    dev = torch.device("cuda", 0)
+    S = 18; n = 1 << S
+    rowptr, col = rmat.csr_torch(S, dev, seed=42, symmetric=True, drop_self_loops=True)
+    nnz = int(col.numel())
+    vals = rmat.values_torch(nnz, dev, seed=46) + 0.5
+    A = gb.Matrix.from_csr(gb.FP64, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+
+    def product():
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        Cm = A.mxm(A, semiring=gb.FP64.PLUS_TIMES, mask=A, desc=D.S)
+        nv = Cm.nvals
+        dt = time.perf_counter() - t0
+        crp = torch.empty(n + 1, dtype=torch.int32, device=dev); ccol = torch.empty(nv, dtype=torch.int32, device=dev)
+        cval = torch.empty(nv, dtype=torch.float64, device=dev)
+        gb.base.check(gb.lib.GrBX_Matrix_export_CSR(Cm._h, C.c_void_p(crp.data_ptr()), C.c_void_p(ccol.data_ptr()), C.c_void_p(cval.data_ptr()), C.c_int(1)))
+        return crp, ccol, cval, gb.last_kernel_plan(), dt
+    product()
+    rp0, c0, v0, plan0, t_default = product()
+    assert "ordered" not in plan0
+    monkeypatch.setenv("GRB_MI355X_DETERMINISTIC", "1")
+    product()
+    rp1, c1, v1, plan1, t_ordered = product()
+    assert " exact" in plan1, plan1
+    assert torch.equal(rp0, rp1) and torch.equal(c0, c1) and torch.allclose(v0, v1, rtol=1e-10, atol=0.0)
+    for _ in range(2):
+        v2 = product()[2]
+        assert torch.equal(v2.view(torch.int64), v1.view(torch.int64))
+    monkeypatch.setenv("GRB_MI355X_NO_EXACT", "1")
+    product()
+    v3, plan3, t_slow = product()[2:]
+    assert "k_spgemm_masked_ordered" in plan3 and torch.allclose(v3, v0, rtol=1e-10, atol=0.0)
+    print(f"\nmasked product R-MAT-18 FP64: default {t_default * 1e3:.2f} ms, deterministic (exact accumulators) {t_ordered * 1e3:.2f} ms ({t_ordered / t_default:.2f} x), "
+          f"ordered kernel {t_slow * 1e3:.2f} ms [{plan1.strip()}]")
