@@ -40,6 +40,16 @@ __device__ __forceinline__ void fx_add(unsigned long long* lo, unsigned long lon
   unsigned long long xl, xh; fx_from_double(p, unit_exp, xl, xh);
   fx_add_words(lo, hi, xl, xh);
 }
+// the same on an LDS accumulator as ONE out-of-line function (the kernels' hit path is inlined at some forty places: ~100 instructions each doubled their
+// code, and four of them share the CUs' instruction caches); the LDS addresses travel as 32-bit offsets so the atomics stay ds_add_*
+typedef __attribute__((address_space(3))) unsigned long long* fx_lds_ptr;
+__device__ __attribute__((noinline)) inline void fx_add_lds(const uint32_t lo_addr, const uint32_t hi_addr, const double p, const int unit_exp) {
+  unsigned long long xl, xh; fx_from_double(p, unit_exp, xl, xh);
+  fx_lds_ptr lo = (fx_lds_ptr)(uintptr_t)lo_addr; fx_lds_ptr hi = (fx_lds_ptr)(uintptr_t)hi_addr;
+  if (xl) { const unsigned long long old = __hip_atomic_fetch_add(lo, xl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); if (old + xl < xl) xh++; }
+  if (xh) __hip_atomic_fetch_add(hi, xh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t fx_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
 #endif
 // the integer rounded once to P significant bits (53: double, 24: float), nearest / ties to even; returned as a double (exactly representable)
 template <int P> GRB_HD double fx_to_fp(unsigned long long lo, unsigned long long hi, const int unit_exp) {

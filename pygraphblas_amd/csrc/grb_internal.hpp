@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <stdlib.h>
 #include <memory>
 #include "grb_ops.hpp"
 
@@ -219,6 +220,8 @@ void vec_overwritten(GrB_Vector v);       // v's value is about to be replaced a
 uint32_t* any_true_acquire(uint32_t* tag);        // a device word a BOOL product kernel sets to the (fresh, non-zero) tag when it writes a true value (see lor_state)
 void any_true_written(GrB_Vector w_or_null, const void* key, uint32_t tag, uint64_t fe_key = 0, uint32_t fe_nblocks = 0);    // a kernel honoured it; w's device buffers `key` are the result it describes (nullptr: nobody's); fe_key != 0: the kernel also filled the edge summary (counted in the row pointers with that serial)
 bool dist_exchange_pending();                   // grb_dist.cpp: GrBX_Vector_allgatherv_start without its GrBX_dist_wait yet
+// GRB_MI355X_DETERMINISTIC=1: floating-point PLUS results are the same bits in every run (mxm: grb_matrix_ops.cpp; vxm / mxv: no push step, whose atomics land in any order)
+inline bool deterministic_env() { const char* e = getenv("GRB_MI355X_DETERMINISTIC"); return e && atoi(e) != 0; }
 unsigned long long* fe_summary_host();      // SpmvCall::fe_host: the page-locked pairs of the result summary (device address), for the product that just called any_true_acquire
 bool any_true_lookup(GrB_Vector u, bool* value);
 bool nonblocking();                       // GrB_init(GrB_NONBLOCKING) and not GRB_MI355X_BLOCKING=1

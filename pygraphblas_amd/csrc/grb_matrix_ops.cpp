@@ -95,9 +95,8 @@ void do_mxm(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, GrB_Semiring semirin
   call.bval = uses_b ? cast_values(sd.zcode, B->type->code, Bd.val.p, Bd.nnz, bcast) : nullptr;
   DevCSR T; bool t_masked = false;
   {
-    const char* de = getenv("GRB_MI355X_DETERMINISTIC");
     const bool fp = sd.zcode == T_FP32 || sd.zcode == T_FP64;
-    call.ordered = fp && ((de && atoi(de) != 0) || dv.axb == GxB_AxB_GUSTAVSON);
+    call.ordered = fp && (deterministic_env() || dv.axb == GxB_AxB_GUSTAVSON);
   }
   if (mxm_few_rows_wanted(Ad, Bd)) {            // a handful of output rows (batched BC frontiers): one vxm per row, see grb_mxm_rows.cpp
     mxm_few_rows(Ad, A->type, M, dv, semiring, B, sd.zcode, T); t_masked = true;

@@ -104,7 +104,12 @@ constexpr uint32_t SPG_FILTER_MUL = 0x9E3779u;   // 24-bit multiplier: v_mul_u32
 // When the multiply reads no value (PLUS_PAIR: the triangle count) the queue is carried from B row to B row; otherwise it is
 // flushed at the end of every B row (the A value changes), and B rows shorter than 256 entries keep the direct lookup.
 // EXACT (deterministic mode, PLUS monoid on FP32 / FP64): the accumulators are 128-bit integers in the row's unit (grb_exact.hpp) — the order the atomics
-// land in no longer matters, everything else in the kernel is the same.
+// land in no longer matters, everything else in the kernel is the same.  A hit then costs ~95 instructions and a returning LDS atomic instead of a multiply
+// and ds_add_f64, and a wave pays them whenever ANY of its lanes hits (93 % of the lookups at 4 % hits per lane) in a kernel the VALU bounds: the LDS bins run
+// 1.55-1.8 x their default time (R-MAT-22, FP64 PLUS_TIMES: 72.6 / 56.0 / 43.8 ms against 47.4 / 31.4 / 27.3), the whole product 1.46 x.  Measured and
+// dropped: the add inlined at its ~35 sites (twice the code, same time: 73.9 ms); every product through the filter with the survivors queued as
+// (column, product) across B rows like the counting products (111 ms: the value load stalls every push) or as (column, position in B, position in A) with
+// the loads at the flush (81.6 ms; the third queue array takes the 512-slot bin from three workgroups per CU to two).
 template <class T, class SR, int SLOTS, int TEAM, int BLOCK, bool EXACT = false>
 __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T> a, const uint32_t* __restrict__ rows, uint32_t nrows_bin, const SR sr) {
   typedef typename acc_word<T>::type W;
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
     while (kk != j && kk != HASH_EMPTY) { h = (h + 1) & (KS - 1); kk = key[h]; }
     if (kk == j) {
       const uint32_t mp = pos[h];
-      if constexpr (EXACT) fx_add(&acc[mp], &hiw[mp], (double)sr.mult(av, use_b ? a.bval[pb] : T()), uexp);
+      if constexpr (EXACT) fx_add_lds(fx_lds_addr(&acc[mp]), fx_lds_addr(&hiw[mp]), (double)sr.mult(av, use_b ? a.bval[pb] : T()), uexp);
       else word_combine<T>(sr.add_op(), &acc[mp], sr.mult(av, use_b ? a.bval[pb] : T()));
       flag[mp] = 1;
     }
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(1024) void k_spgemm_masked_map(const SpgemmKArgs<T>
     const uint32_t mp = slot1 - 1;
     if (mp < LCF) {
       if constexpr (CNT32) atomicAdd(&s_acc[mp], 1u);             // PLUS_PAIR: the product is 1
-      else if constexpr (EXACT) { fx_add((unsigned long long*)&s_acc[mp], &s_hiw[mp], (double)sr.mult(av, use_b ? a.bval[pb] : T()), uexp); s_flag[mp] = 1; }
+      else if constexpr (EXACT) { fx_add_lds(fx_lds_addr(&s_acc[mp]), fx_lds_addr(&s_hiw[mp]), (double)sr.mult(av, use_b ? a.bval[pb] : T()), uexp); s_flag[mp] = 1; }
       else { word_combine<T>(sr.add_op(), (W*)&s_acc[mp], sr.mult(av, use_b ? a.bval[pb] : T())); s_flag[mp] = 1; }
     } else {
       if constexpr (EXACT) fx_add(&a.xlo[mb + mp], &a.xhi[mb + mp], (double)sr.mult(av, use_b ? a.bval[pb] : T()), uexp);
@@ -599,48 +604,55 @@ __global__ __launch_bounds__(256) void k_spgemm_masked_ordered(const SpgemmKArgs
 // ---- (1d) the exact accumulators' row units (grb_exact.hpp) ---------------------------------------------------------------------------------------
 // |x| as an ordered integer: NaN above Inf above every finite value, so an integer max carries "not finite" along
 __device__ __forceinline__ unsigned long long fx_abs_bits(const double v) { return (unsigned long long)__double_as_longlong(v) & 0x7FFFFFFFFFFFFFFFull; }
-template <class T> __global__ void k_row_absmax(uint32_t nrows, const uint32_t* __restrict__ rp, const T* __restrict__ val, double* __restrict__ out) {
-  const uint32_t g = (blockIdx.x * 256u + threadIdx.x) >> 4, l = threadIdx.x & 15u, ng = gridDim.x * 16u;
-  for (uint32_t r = g; r < nrows; r += ng) {
-    unsigned long long m = 0;
-    for (uint32_t p = rp[r] + l; p < rp[r + 1]; p += 16) { const unsigned long long b = fx_abs_bits((double)val[p]); m = b > m ? b : m; }
-    for (int o = 8; o; o >>= 1) { const unsigned long long x = __shfl_xor(m, o, 16); m = x > m ? x : m; }
-    if (l == 0) out[r] = __longlong_as_double((long long)m);
+// 256 consecutive rows per workgroup, their entries dealt to the threads 256 apart (a hub row of 10^5 entries is 400 steps of the workgroup, not 6 000 of a
+// 16-lane group); an entry finds its row in the workgroup's 257 row pointers (LDS) and raises the row's maximum there
+template <class F> __device__ __forceinline__ void block_rows_max(const uint32_t* __restrict__ rp, uint32_t nrows, uint32_t* s_rp, unsigned long long* s_max, F&& bits_of) {
+  const uint32_t r0 = blockIdx.x * 256u, nr = nrows - r0 < 256u ? nrows - r0 : 256u;
+  for (uint32_t q = threadIdx.x; q <= nr; q += 256) s_rp[q] = rp[r0 + q];
+  s_max[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t e1 = s_rp[nr];
+  for (uint32_t p = s_rp[0] + threadIdx.x; p < e1; p += 256) {
+    uint32_t lo = 0, hi = nr;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_rp[mid] <= p) lo = mid; else hi = mid; }
+    atomicMax(&s_max[lo], bits_of(p));
   }
+  __syncthreads();
+}
+template <class T> __global__ __launch_bounds__(256) void k_row_absmax(uint32_t nrows, const uint32_t* __restrict__ rp, const T* __restrict__ val, double* __restrict__ out) {
+  __shared__ uint32_t s_rp[257]; __shared__ unsigned long long s_max[256];
+  block_rows_max(rp, nrows, s_rp, s_max, [&](const uint32_t p) { return fx_abs_bits((double)val[p]); });
+  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+  if (r < nrows) out[r] = __longlong_as_double((long long)s_max[threadIdx.x]);
 }
 inline bool exact_mult_supported(int mulop) {
   switch (mulop) { case B_TIMES: case B_FIRST: case B_SECOND: case B_PAIR: case B_PLUS: case B_MINUS: case B_RMINUS: case B_MIN: case B_MAX: case B_ANY: return true; default: return false; }
 }
 // unit exponent of row i: 2^E above the largest |product| the row can form (the multiply applied to |A(i,k)| and max |B(k,:)|, in T, rounded as the product
 // is — rounding is monotonic), 2^H above the number of products an entry can receive; FX_NO_EXP when that bound is Inf or NaN
-template <class T> __global__ void k_row_unit_exp(uint32_t nrows, const uint32_t* __restrict__ arp, const uint32_t* __restrict__ acol, const T* __restrict__ aval,
-                                                  const double* __restrict__ bmax, int mulop, int32_t* __restrict__ out) {
-  const uint32_t g = (blockIdx.x * 256u + threadIdx.x) >> 4, l = threadIdx.x & 15u, ng = gridDim.x * 16u;
-  for (uint32_t r = g; r < nrows; r += ng) {
-    unsigned long long m = 0;
-    const uint32_t ab = arp[r], ae = arp[r + 1];
-    for (uint32_t p = ab + l; p < ae; p += 16) {
-      const T aa = aval ? (T)fabs((double)aval[p]) : T(1), bb = bmax ? (T)bmax[acol[p]] : T(1);
-      unsigned long long b;
-      switch (mulop) {
-        case B_TIMES: b = fx_abs_bits((double)(T)(aa * bb)); break;
-        case B_FIRST: b = fx_abs_bits((double)aa); break;
-        case B_SECOND: b = fx_abs_bits((double)bb); break;
-        case B_PAIR: b = fx_abs_bits(1.0); break;
-        case B_PLUS: case B_MINUS: case B_RMINUS: b = fx_abs_bits((double)(T)(aa + bb)); break;
-        default: { const unsigned long long x = fx_abs_bits((double)aa), y = fx_abs_bits((double)bb); b = x > y ? x : y; } break;      // MIN, MAX, ANY
-      }
-      m = b > m ? b : m;
+template <class T> __global__ __launch_bounds__(256) void k_row_unit_exp(uint32_t nrows, const uint32_t* __restrict__ arp, const uint32_t* __restrict__ acol, const T* __restrict__ aval,
+                                                                         const double* __restrict__ bmax, int mulop, int32_t* __restrict__ out) {
+  __shared__ uint32_t s_rp[257]; __shared__ unsigned long long s_max[256];
+  block_rows_max(arp, nrows, s_rp, s_max, [&](const uint32_t p) {
+    const T aa = aval ? (T)fabs((double)aval[p]) : T(1), bb = bmax ? (T)bmax[acol[p]] : T(1);
+    switch (mulop) {
+      case B_TIMES: return fx_abs_bits((double)(T)(aa * bb));
+      case B_FIRST: return fx_abs_bits((double)aa);
+      case B_SECOND: return fx_abs_bits((double)bb);
+      case B_PAIR: return fx_abs_bits(1.0);
+      case B_PLUS: case B_MINUS: case B_RMINUS: return fx_abs_bits((double)(T)(aa + bb));
+      default: { const unsigned long long x = fx_abs_bits((double)aa), y = fx_abs_bits((double)bb); return x > y ? x : y; }      // MIN, MAX, ANY
     }
-    for (int o = 8; o; o >>= 1) { const unsigned long long x = __shfl_xor(m, o, 16); m = x > m ? x : m; }
-    if (l == 0) {
-      int32_t u = 0;
-      if (ae > ab) {
-        if (m > 0x7FEFFFFFFFFFFFFFull) u = FX_NO_EXP;
-        else { const double bound = __longlong_as_double((long long)m); u = (m ? ilogb(bound) + 2 : -1074) + (32 - __clz((int)(ae - ab))) - 126; }
-      }
-      out[r] = u;
+  });
+  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+  if (r < nrows) {
+    const unsigned long long m = s_max[threadIdx.x]; const uint32_t al = s_rp[threadIdx.x + 1] - s_rp[threadIdx.x];
+    int32_t u = 0;
+    if (al) {
+      if (m > 0x7FEFFFFFFFFFFFFFull) u = FX_NO_EXP;
+      else { const double bound = __longlong_as_double((long long)m); u = (m ? ilogb(bound) + 2 : -1074) + (32 - __clz((int)al)) - 126; }
     }
+    out[r] = u;
   }
 }
 static __global__ void k_rows_without_unit(uint32_t nrows, const int32_t* __restrict__ rowexp, const uint32_t* __restrict__ mrp, const uint32_t* __restrict__ arp,
@@ -732,10 +744,9 @@ template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDes
   // k_spgemm_masked_ordered, one group per slice of a mask row with the entries of A(i,:) one after the other.
   constexpr bool is_fp = std::is_floating_point<T>::value;
   const bool exact = is_fp && c.ordered && d.addop == B_PLUS && !d.flip && exact_mult_supported(d.mulop) && !getenv("GRB_MI355X_NO_EXACT");
-  DevBuf rowexp, noexp_rows, xlo, xhi;
+  DevBuf rowexp, noexp_rows, xlo, xhi, bmax;
   if constexpr (is_fp) if (exact) {
-    auto grid16 = [](uint64_t rows) { uint64_t b = (rows + 15) / 16; if (b < 1) b = 1; if (b > 16384) b = 16384; return (unsigned)b; };
-    DevBuf bmax;
+    auto grid16 = [](uint64_t rows) { return (unsigned)((rows + 255) / 256 > 0 ? (rows + 255) / 256 : 1); };        // 256 rows per workgroup
     if (c.bval) { bmax.alloc((size_t)B.nrows * 8 + 8);
       hipLaunchKernelGGL((k_row_absmax<T>), dim3(grid16(B.nrows)), dim3(256), 0, stream(), B.nrows, B.rowptr.as<uint32_t>(), (const T*)c.bval, bmax.as<double>()); }
     rowexp.alloc((size_t)nrows * 4 + 4); noexp_rows.alloc((size_t)nrows * 4 + 4);
@@ -743,7 +754,6 @@ template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDes
                        c.bval ? bmax.as<double>() : (const double*)nullptr, d.mulop, rowexp.as<int32_t>());
     hipLaunchKernelGGL(k_rows_without_unit, dim3((unsigned)std::min<uint64_t>(((uint64_t)nrows + 255) / 256, 4096)), dim3(256), 0, stream(), nrows, rowexp.as<int32_t>(),
                        M.rowptr.as<uint32_t>(), A.rowptr.as<uint32_t>(), noexp_rows.as<uint32_t>(), counts.as<uint32_t>() + 6);
-    GRB_HIP(hipStreamSynchronize(stream()));          // (bmax goes back to the pool)
   }
   hipLaunchKernelGGL(k_bin_rows, dim3((unsigned)(((uint64_t)nrows + 1024ull * SPG_BIN_ROWS - 1) / (1024ull * SPG_BIN_ROWS))), dim3(1024), 0, stream(), nrows, M.rowptr.as<uint32_t>(), A.rowptr.as<uint32_t>(), counts.as<uint32_t>(), lists.as<uint32_t>(),
                      exact ? 2048u : 4096u, exact ? rowexp.as<int32_t>() : (const int32_t*)nullptr);

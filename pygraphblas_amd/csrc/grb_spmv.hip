@@ -85,6 +85,7 @@ bool spmspv_push_supported(const SemiringDesc& d) {
   const int ts = type_size(d.zcode);
   if (d.zcode == T_BOOL) return d.addop == B_LOR || d.addop == B_ANY || d.addop == B_PLUS || d.addop == B_MAX;
   if (ts < 4) return false;
+  if (d.addop == B_PLUS && (d.zcode == T_FP32 || d.zcode == T_FP64) && deterministic_env()) return false;      // floating-point sums by atomics: the pull kernels add in a fixed order
   return d.addop == B_PLUS || d.addop == B_MIN || d.addop == B_MAX;
 }
 

@@ -652,3 +652,35 @@ def test_deterministic_mode_of_the_masked_product_rmat18_is_bitwise_repeatable(g
     assert "k_spgemm_masked_ordered" in plan3 and torch.allclose(v3, v0, rtol=1e-10, atol=0.0)
     print(f"\nmasked product R-MAT-18 FP64: default {t_default * 1e3:.2f} ms, deterministic (exact accumulators) {t_ordered * 1e3:.2f} ms ({t_ordered / t_default:.2f} x), "
           f"ordered kernel {t_slow * 1e3:.2f} ms [{plan1.strip()}]")
+
+
+def test_deterministic_mode_of_the_masked_product_rmat22_is_bitwise_repeatable(gpu, monkeypatch):
+    """BASELINE configs[3]'s shape on floating-point values: C<L> = L (+.x) L, FP64 PLUS_TIMES, L = the lower triangle of the symmetric R-MAT-22 (6.4e7 entries,
+    5.8e10 products, mask rows up to the HBM-map bin) in deterministic mode: the same bits three times, the default mode's pattern, its values to 1e-10."""
+    import torch
+    dev = torch.device("cuda", 0)
+    S = 22; n = 1 << S
+    rowptr, col = rmat.csr_torch(S, dev, seed=42, symmetric=True, drop_self_loops=True, lower=True)
+    nnz = int(col.numel())
+    vals = rmat.values_torch(nnz, dev, seed=46) + 0.5
+    L = gb.Matrix.from_csr(gb.FP64, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+
+    def product():
+        Cm = L.mxm(L, semiring=gb.FP64.PLUS_TIMES, mask=L, desc=D.S)
+        nv = Cm.nvals
+        crp = torch.empty(n + 1, dtype=torch.int32, device=dev); ccol = torch.empty(nv, dtype=torch.int32, device=dev)
+        cval = torch.empty(nv, dtype=torch.float64, device=dev)
+        gb.base.check(gb.lib.GrBX_Matrix_export_CSR(Cm._h, C.c_void_p(crp.data_ptr()), C.c_void_p(ccol.data_ptr()), C.c_void_p(cval.data_ptr()), C.c_int(1)))
+        return crp, ccol, cval, gb.last_kernel_plan()
+    rp0, c0, v0, plan0 = product()
+    assert "exact" not in plan0
+    monkeypatch.setenv("GRB_MI355X_DETERMINISTIC", "1")
+    rp1, c1, v1, plan1 = product()
+    bins = [int(x) for x in plan1.split("bins ")[1].split()[0].split("/")]
+    assert " exact" in plan1 and bins[4] > 0, plan1
+    assert torch.equal(rp0, rp1) and torch.equal(c0, c1) and torch.allclose(v0, v1, rtol=1e-10, atol=0.0)
+    del rp0, c0, v0, rp1, c1
+    for _ in range(2):
+        v2 = product()[2]
+        assert torch.equal(v2.view(torch.int64), v1.view(torch.int64))
+        del v2

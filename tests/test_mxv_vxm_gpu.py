@@ -438,3 +438,34 @@ def test_min_plus_over_an_operand_with_holes_runs_the_full_operand_kernels(gpu):
                         assert "k_spmv_wavepipe" in plan or "k_spmv_xcd" in plan, plan
                     else:
                         assert "k_spmv_wavepipe" not in plan and "k_spmv_xcd" not in plan, plan
+
+
+def test_deterministic_mode_keeps_fp_sums_out_of_the_push_kernels(gpu, monkeypatch):
+    """A sparse FP64 operand normally takes the push step (SpMSpV: one atomic per product, landing in any order).  With GRB_MI355X_DETERMINISTIC=1 a
+    floating-point PLUS product pulls instead (fixed lane partition, fixed combination order): the same bits every time, the oracle's values to 1e-12;
+    MIN / MAX monoids (any order gives the same bits) and integers keep the push step."""
+    rng = np.random.default_rng(31)
+    n = 60000
+    A = rand_matrix(rng, "FP64", n, n, 0.0005, small=False)
+    ui, ux = rand_vector(rng, "FP64", n, 0.002, small=False)
+    M = to_matrix(A); u = to_vector("FP64", n, ui, ux)
+    w = u.vxm(M, semiring=gb.FP64.PLUS_TIMES)
+    assert "push" in gb.last_kernel_plan(), gb.last_kernel_plan()
+    monkeypatch.setenv("GRB_MI355X_DETERMINISTIC", "1")
+    ref = None
+    for _ in range(4):
+        w = u.vxm(M, semiring=gb.FP64.PLUS_TIMES)
+        assert "push" not in gb.last_kernel_plan(), gb.last_kernel_plan()
+        gi, gx = vector_pairs(w)
+        cur = (np.asarray(gi).tobytes(), np.asarray(gx, np.float64).tobytes())
+        if ref is None: ref = cur
+        assert cur == ref
+    gi, gx = vector_pairs(w)
+    want = np.zeros(n)
+    uval = np.zeros(n); uval[ui.astype(np.int64)] = ux; upres = np.zeros(n, bool); upres[ui.astype(np.int64)] = True
+    sel = upres[A.I.astype(np.int64)]
+    np.add.at(want, A.J.astype(np.int64)[sel], A.X[sel] * uval[A.I.astype(np.int64)[sel]])
+    pres = np.zeros(n, bool); pres[A.J.astype(np.int64)[sel]] = True
+    assert np.array_equal(np.asarray(gi, np.int64), np.nonzero(pres)[0]) and np.allclose(np.asarray(gx), want[pres], rtol=1e-12, atol=0)
+    u.vxm(M, semiring=gb.FP64.MIN_PLUS)
+    assert "push" in gb.last_kernel_plan(), gb.last_kernel_plan()

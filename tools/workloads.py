@@ -92,6 +92,41 @@ if "tc" in args.what:
     print(json.dumps(out), flush=True)
 
 
+if "tcfp" in args.what:
+    # the masked product on floating-point values: C<L> = L (+.x) L, FP64 — default mode (atomics as they land) against the deterministic mode
+    # (GRB_MI355X_DETERMINISTIC=1: exact 128-bit integer accumulators, grb_exact.hpp), same bits from run to run
+    rowptr, col = rmat.csr_torch(args.scale, dev, seed=42, symmetric=True, drop_self_loops=True, lower=True)
+    nnz = col.numel()
+    vals = rmat.values_torch(nnz, dev, seed=46) + 0.5
+    L = gb.Matrix.from_csr(gb.FP64, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+    dL = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+    products = int(dL[col.to(torch.int64) & 0xFFFFFFFF].sum())
+    def values_of(Cm):
+        nv = Cm.nvals
+        cval = torch.empty(nv, dtype=torch.float64, device=dev)
+        gb.base.check(lib.GrBX_Matrix_export_CSR(Cm._h, None, None, C.c_void_p(cval.data_ptr()), C.c_int(1)))
+        return cval
+    def run():
+        Cm = L.mxm(L, semiring=gb.FP64.PLUS_TIMES, mask=L, desc=D.S); Cm.nvals; return Cm
+    res = {}
+    for mode in ("default", "deterministic"):
+        if mode == "deterministic": os.environ["GRB_MI355X_DETERMINISTIC"] = "1"
+        Cm, _ = timed(run); best = 1e9
+        for _ in range(args.reps):
+            Cm, t = timed(run); best = min(best, t)
+        v = values_of(Cm)
+        again = values_of(run())
+        res[mode] = {"seconds": round(best, 5), "plan": gb.last_kernel_plan().strip(), "same_bits_twice": bool(torch.equal(v.view(torch.int64), again.view(torch.int64)))}
+        if mode == "default": v0 = v
+        else: res[mode]["agrees_with_default_rtol_1e-10"] = bool(torch.allclose(v, v0, rtol=1e-10, atol=0.0)); res[mode]["entries"] = int(v.numel())
+    os.environ.pop("GRB_MI355X_DETERMINISTIC", None)
+    alg_bytes = 2 * (nnz * 12 + (n + 1) * 4) + products * 12
+    print(json.dumps({"workload": f"masked product on FP64 values R-MAT-{args.scale}: L.mxm(L, PLUS_TIMES, mask=L)", "n": n, "nnz_L": nnz, "products": products,
+                      "default": res["default"], "deterministic": res["deterministic"],
+                      "deterministic_over_default": round(res["deterministic"]["seconds"] / res["default"]["seconds"], 3),
+                      "GBps_algorithmic_deterministic": round(alg_bytes / res["deterministic"]["seconds"] / 1e9, 1)}), flush=True)
+
+
 def pagerank(A, d, damping, itermax):
     """gap/prmark.py:8-30 with the modern descriptor name (descriptor.T0 for the stale `TransposeA`)."""
     from pygraphblas_amd import Vector, FP32
