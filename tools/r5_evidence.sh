@@ -24,7 +24,7 @@ for tag, title in (("aa_kt", "default mode"), ("aa_kt_det", "deterministic mode 
             if "grb::" in r["Name"] and float(r["TotalDurationNs"]) > 3e5: print(f'   {r["Name"].split("(")[0][-90:]:90s} calls {r["Calls"]:>4s} avg {float(r["AverageNs"])/1e3:10.1f} us')
 PY
 cat $out/aa_kernel_stats.txt | cut -c1-180
-timeout 600 python tools/workloads.py --what bfs,tc,pr,bc,bcfull > $out/workloads_scale22.jsonl 2> $out/workloads.err; echo "workloads rc=$?"
+timeout 600 python tools/workloads.py --what bfs,tc,pr,bc,bcfull,tcfp > $out/workloads_scale22.jsonl 2> $out/workloads.err; echo "workloads rc=$?"
 if [ -d .refscratch ]; then
   bash tools/ref_tests_gpu.sh $out/reftests > $out/reftests.log 2>&1; tail -3 $out/reftests/pytest_reference.log
   bash tools/ref_doctests_gpu.sh $out/refdoctests > $out/refdoctests.log 2>&1; tail -3 $out/refdoctests.log
