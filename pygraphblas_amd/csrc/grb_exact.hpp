@@ -2,12 +2,12 @@
 //
 // A sum of doubles is the same bits in every run if it is formed in integers.  Every output row i gets a unit 2^u(i) such that no sum of the row's products can
 // leave a signed 128-bit count of units: u(i) = E + H - 126 with 2^E above the row's largest possible |product| (k_row_unit_exp: the multiply applied to
-// |A(i,k)| and the largest |B(k,:)|, rounded as the product itself is) and 2^H above the number of products one entry can receive (the entries of A(i,:)).
+// the largest |A(i,k)| and the largest |B|, rounded as the product itself is) and 2^H above the number of products one entry can receive (the entries of A(i,:)).
 // A product p = m 2^e (m: its 53-bit significand) adds m shifted by e - u(i) <= 73 - H bits: two 64-bit integer atomics, the second only when the high
-// word changes (a negative term, a carry).  Whatever order the atomics land in, the accumulator ends as the EXACT sum of the products (each rounded once, by
-// the multiply, as always) wherever every product lies within 2^(74-H) of the row's bound — beyond that a product's bits below 2^u(i) are cut — and the
-// result is that integer rounded ONCE to the value type (nearest, ties to even): what math.fsum of the products returns, which the tests compare bit by bit.
-// Rows whose bound is not finite (an Inf or NaN operand) are left to k_spgemm_masked_ordered.
+// word changes (a negative term, a carry).  k_row_unit_exp admits a row only if no product of it can have a bit below 2^u(i) (its operands are spread over
+// less than ~2^(74-H)), so whatever order the atomics land in, the accumulator ends as the EXACT sum of the products (each rounded once, by the multiply, as
+// always), and the result is that integer rounded ONCE to the value type (nearest, ties to even): what math.fsum of the products returns, which the tests
+// compare bit by bit.  Rows that are not admitted (operands spread too far, an Inf or NaN operand) are left to k_spgemm_masked_ordered.
 #pragma once
 #include "grb_ops.hpp"
 #include <string.h>

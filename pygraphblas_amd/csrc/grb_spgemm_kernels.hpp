@@ -86,6 +86,12 @@ __device__ __forceinline__ spg_u4 spg_ld4(const uint32_t* __restrict__ p, uint32
 #ifndef SPG_LIST_V
 #define SPG_LIST_V 512
 #endif
+#ifndef SPG_EXACT_EXP
+#define SPG_EXACT_EXP 0
+#endif
+#ifndef SPG_PROBE4_V
+#define SPG_PROBE4_V 1          // products that read values: four lookups, then their hits in passes (0: lookup and hit one product at a time)
+#endif
 #ifndef SPG_HUGE_V
 #define SPG_HUGE_V 8192
 #endif
@@ -115,13 +121,15 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
   typedef typename acc_word<T>::type W;
   typedef typename std::conditional<EXACT, unsigned long long, W>::type AW;
   constexpr int TEAMS = BLOCK / TEAM;
-  constexpr int LCAP = TEAM >= 1024 ? SPG_LIST_BIG_V : (TEAM >= 256 ? SPG_LIST : 64);
+  // (EXACT, last bin: 16-byte accumulators for 4 096 mask entries — the work lists and the filter give up LDS for them: 512 k's per round, 8 filter bits per slot)
+  constexpr bool EXBIG = EXACT && SLOTS >= 8192;
+  constexpr int LCAP = EXBIG ? 512 : (TEAM >= 1024 ? SPG_LIST_BIG_V : (TEAM >= 256 ? SPG_LIST : 64));
   constexpr bool NOVAL = SR::pair_only;                 // the product is a constant: a queued survivor is its column alone
   // the exact table: open addressing, at most SLOTS / 2 mask entries in KS keys (load <= 1/4 in the two small bins, <= 1/2 in the
   // large ones, where the LDS goes to the filter and the queues instead — only survivors of the filter walk its chains now);
   // the accumulators are indexed by the mask position the slot carries and take only SLOTS / 2 words
   constexpr int KS = SLOTS <= 512 ? 2 * SLOTS : SLOTS, ML = SLOTS / 2;
-  constexpr int FBITS = (SPG_FBITS_SMALL_V && SLOTS <= 512 ? SPG_FBITS_SMALL_V : SPG_FBITS_V) * SLOTS, FW = FBITS / 32;    // the filter: >= 64 bits per mask entry (R-MAT-22 triangle count: 8 x SLOTS bits 47.2 ms, 16 x 45.0, 32 x 44.2; 64 / 128 x in the two small bins only: 44.9 / 45.8)
+  constexpr int FBITS = (EXBIG ? 8 : (SPG_FBITS_SMALL_V && SLOTS <= 512 ? SPG_FBITS_SMALL_V : SPG_FBITS_V)) * SLOTS, FW = FBITS / 32;    // the filter: >= 64 bits per mask entry (R-MAT-22 triangle count: 8 x SLOTS bits 47.2 ms, 16 x 45.0, 32 x 44.2; 64 / 128 x in the two small bins only: 44.9 / 45.8)
   constexpr int FSH = 32 - __builtin_ctz(FBITS);
   constexpr int WAVES = BLOCK / 64;
   __shared__ uint32_t s_key[TEAMS][KS];
@@ -154,16 +162,37 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
     else __syncthreads();
   };
   // one product against the table: column j of B(k,:) at position pb
-  auto probe = [&](const uint32_t j, const uint32_t pb, const T av) {
-    if constexpr (SPG_EXP == 2) { if (j == 0xFFFFFFF1u) flag[0] = 1; return; }
+  auto lookup = [&](const uint32_t j) -> uint32_t {          // the mask position of column j, or ~0
     uint32_t h = hash_col(j, KS - 1);
     uint32_t kk = key[h];
     while (kk != j && kk != HASH_EMPTY) { h = (h + 1) & (KS - 1); kk = key[h]; }
-    if (kk == j) {
-      const uint32_t mp = pos[h];
-      if constexpr (EXACT) fx_add_lds(fx_lds_addr(&acc[mp]), fx_lds_addr(&hiw[mp]), (double)sr.mult(av, use_b ? a.bval[pb] : T()), uexp);
-      else word_combine<T>(sr.add_op(), &acc[mp], sr.mult(av, use_b ? a.bval[pb] : T()));
-      flag[mp] = 1;
+    return kk == j ? (uint32_t)pos[h] : 0xFFFFFFFFu;
+  };
+  auto hit_at = [&](const uint32_t mp, const uint32_t pb, const T av) {
+    if constexpr (EXACT && SPG_EXACT_EXP == 1) atomicAdd((double*)&acc[mp], (double)sr.mult(av, use_b ? a.bval[pb] : T()));          // measurement build: everything of EXACT but the integer add
+    else if constexpr (EXACT && SPG_EXACT_EXP == 2) { unsigned long long xl, xh; fx_from_double((double)sr.mult(av, use_b ? a.bval[pb] : T()), uexp, xl, xh); atomicAdd(&acc[mp], xl); atomicAdd(&hiw[mp], xh); }   // measurement build: no returning atomic (carries lost)
+    else if constexpr (EXACT) fx_add_lds(fx_lds_addr(&acc[mp]), fx_lds_addr(&hiw[mp]), (double)sr.mult(av, use_b ? a.bval[pb] : T()), uexp);
+    else word_combine<T>(sr.add_op(), &acc[mp], sr.mult(av, use_b ? a.bval[pb] : T()));
+    flag[mp] = 1;
+  };
+  auto probe = [&](const uint32_t j, const uint32_t pb, const T av) {
+    if constexpr (SPG_EXP == 2) { if (j == 0xFFFFFFF1u) flag[0] = 1; return; }
+    const uint32_t mp = lookup(j);
+    if (mp != 0xFFFFFFFFu) hit_at(mp, pb, av);
+  };
+  // Four products of a lane against the table: the four lookups first, then the hits — one per lane and pass.  A hit that reads a value waits for B's value (and,
+  // EXACT, runs ~95 instructions) with the whole wave, and at 4 % hits per lane 93 % of the single lookups have one somewhere in the wave: four lookups
+  // have their hits in ~1.5 passes instead of 3.7.  pb of product u = pb0 + stride * u.
+  [[maybe_unused]] auto probe4 = [&](const uint32_t (&jj)[4], const uint32_t pb0, const uint32_t stride, const uint32_t be, const T av) {
+    uint32_t mps[4]; uint32_t pend = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) { mps[u] = pb0 + stride * u < be ? lookup(jj[u]) : 0xFFFFFFFFu; pend |= mps[u] != 0xFFFFFFFFu ? 1u << u : 0u; }
+    while (__ballot(pend != 0)) {
+      if (pend) {
+        const uint32_t u = (uint32_t)__builtin_ctz(pend); pend &= pend - 1u;
+        const uint32_t mp = u == 0 ? mps[0] : (u == 1 ? mps[1] : (u == 2 ? mps[2] : mps[3]));
+        hit_at(mp, pb0 + stride * u, av);
+      }
     }
   };
   // bit FSH.. of the 24-bit product picks the filter bit: the top LW bits the word, the five below them the bit in the word
@@ -260,6 +289,14 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
       for (uint32_t q = grp; q < nshort; q += NG) {
         const T av = use_a ? a.aval[lpa[q]] : T();
         const uint32_t be = lbe[q];
+        if constexpr (!NOVAL && SPG_PROBE4_V) {              // (a short row has < 64 entries: four steps of the group, their loads in flight together)
+          static_assert(SPG_LONG_V <= 64, "a short B row is at most four steps of a 16-lane group");
+          const uint32_t pb0 = lbb[q] + lane16;
+          uint32_t jj[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) jj[u] = pb0 + 16u * u < be ? spg_ld(a.bcol, pb0 + 16u * u) : 0u;
+          probe4(jj, pb0, 16u, be, av);
+        } else
         for (uint32_t pb = lbb[q] + lane16; pb < be; pb += 16) {
           const uint32_t j = spg_ld(a.bcol, pb);
           probe(j, pb, av);
@@ -322,8 +359,11 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
             uint32_t jj[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) { const uint32_t pb = pb0 + 64 * u; jj[u] = spg_ld(a.bcol, pb < be ? pb : be - 1); }   // 4 loads in flight
+            if constexpr (!NOVAL && SPG_PROBE4_V) probe4(jj, pb0, 64u, be, av);
+            else {
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t pb = pb0 + 64 * u; if (pb < be) probe(jj[u], pb, av); }
+              for (int u = 0; u < 4; u++) { const uint32_t pb = pb0 + 64 * u; if (pb < be) probe(jj[u], pb, av); }
+            }
           }
         }
       }
@@ -604,56 +644,78 @@ __global__ __launch_bounds__(256) void k_spgemm_masked_ordered(const SpgemmKArgs
 // ---- (1d) the exact accumulators' row units (grb_exact.hpp) ---------------------------------------------------------------------------------------
 // |x| as an ordered integer: NaN above Inf above every finite value, so an integer max carries "not finite" along
 __device__ __forceinline__ unsigned long long fx_abs_bits(const double v) { return (unsigned long long)__double_as_longlong(v) & 0x7FFFFFFFFFFFFFFFull; }
-// 256 consecutive rows per workgroup, their entries dealt to the threads 256 apart (a hub row of 10^5 entries is 400 steps of the workgroup, not 6 000 of a
-// 16-lane group); an entry finds its row in the workgroup's 257 row pointers (LDS) and raises the row's maximum there
-template <class F> __device__ __forceinline__ void block_rows_max(const uint32_t* __restrict__ rp, uint32_t nrows, uint32_t* s_rp, unsigned long long* s_max, F&& bits_of) {
-  const uint32_t r0 = blockIdx.x * 256u, nr = nrows - r0 < 256u ? nrows - r0 : 256u;
-  for (uint32_t q = threadIdx.x; q <= nr; q += 256) s_rp[q] = rp[r0 + q];
-  s_max[threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t e1 = s_rp[nr];
-  for (uint32_t p = s_rp[0] + threadIdx.x; p < e1; p += 256) {
-    uint32_t lo = 0, hi = nr;
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_rp[mid] <= p) lo = mid; else hi = mid; }
-    atomicMax(&s_max[lo], bits_of(p));
+// largest and smallest non-zero |value| of B as ordered integers, out[0] = max (NaN above Inf above finite), out[1] = min over the non-zero finite values (~0: none)
+template <class T> __global__ __launch_bounds__(256) void k_abs_minmax(uint64_t n, const T* __restrict__ val, unsigned long long* __restrict__ out) {
+  unsigned long long mx = 0, mn = ~0ull;
+  for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < n; p += gridDim.x * 256ull) {
+    const unsigned long long b = fx_abs_bits((double)val[p]);
+    mx = b > mx ? b : mx; if (b && b <= 0x7FEFFFFFFFFFFFFFull) mn = b < mn ? b : mn;
   }
-  __syncthreads();
-}
-template <class T> __global__ __launch_bounds__(256) void k_row_absmax(uint32_t nrows, const uint32_t* __restrict__ rp, const T* __restrict__ val, double* __restrict__ out) {
-  __shared__ uint32_t s_rp[257]; __shared__ unsigned long long s_max[256];
-  block_rows_max(rp, nrows, s_rp, s_max, [&](const uint32_t p) { return fx_abs_bits((double)val[p]); });
-  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-  if (r < nrows) out[r] = __longlong_as_double((long long)s_max[threadIdx.x]);
+  for (int o = 32; o; o >>= 1) { const unsigned long long x = __shfl_xor(mx, o, 64), y = __shfl_xor(mn, o, 64); mx = x > mx ? x : mx; mn = y < mn ? y : mn; }
+  if ((threadIdx.x & 63) == 0) { atomicMax(&out[0], mx); atomicMin(&out[1], mn); }
 }
 inline bool exact_mult_supported(int mulop) {
   switch (mulop) { case B_TIMES: case B_FIRST: case B_SECOND: case B_PAIR: case B_PLUS: case B_MINUS: case B_RMINUS: case B_MIN: case B_MAX: case B_ANY: return true; default: return false; }
 }
-// unit exponent of row i: 2^E above the largest |product| the row can form (the multiply applied to |A(i,k)| and max |B(k,:)|, in T, rounded as the product
-// is — rounding is monotonic), 2^H above the number of products an entry can receive; FX_NO_EXP when that bound is Inf or NaN
-template <class T> __global__ __launch_bounds__(256) void k_row_unit_exp(uint32_t nrows, const uint32_t* __restrict__ arp, const uint32_t* __restrict__ acol, const T* __restrict__ aval,
-                                                                         const double* __restrict__ bmax, int mulop, int32_t* __restrict__ out) {
-  __shared__ uint32_t s_rp[257]; __shared__ unsigned long long s_max[256];
-  block_rows_max(arp, nrows, s_rp, s_max, [&](const uint32_t p) {
-    const T aa = aval ? (T)fabs((double)aval[p]) : T(1), bb = bmax ? (T)bmax[acol[p]] : T(1);
-    switch (mulop) {
-      case B_TIMES: return fx_abs_bits((double)(T)(aa * bb));
-      case B_FIRST: return fx_abs_bits((double)aa);
-      case B_SECOND: return fx_abs_bits((double)bb);
-      case B_PAIR: return fx_abs_bits(1.0);
-      case B_PLUS: case B_MINUS: case B_RMINUS: return fx_abs_bits((double)(T)(aa + bb));
-      default: { const unsigned long long x = fx_abs_bits((double)aa), y = fx_abs_bits((double)bb); return x > y ? x : y; }      // MIN, MAX, ANY
+// The unit exponent of every output row (grb_exact.hpp), from the largest and smallest non-zero |A(i,k)| of the row and of B as a whole:
+//   2^E above the largest |product| the row can form — the multiply applied to the two maxima, in T, rounded as a product is (rounding is monotonic);
+//   2^H above the number of products one entry can receive (the entries of A(i,:));   u = E + H - 126.
+// A row is EXACT only if no product can have a bit below 2^u: the lowest bit of a product lies at or above 2^(e - 52), e the exponent of the multiply applied
+// to the two minima (TIMES), of the smaller minimum (PLUS / MINUS / MIN / MAX / ANY: sums and differences of doubles are multiples of the smaller operand's
+// last place), of the one operand read (FIRST / SECOND).  Rows that fail — operands spread over more than ~2^(74-H) — and rows with an Inf / NaN bound
+// are marked FX_NO_EXP and formed by k_spgemm_masked_ordered.  256 consecutive rows per workgroup, their entries dealt to the threads 256 apart; a thread
+// keeps the extremes of the row it is in and hands them to the row's LDS slot when it moves on (a hub row: one atomic per thread, not one per entry).
+template <class T> __global__ __launch_bounds__(256) void k_row_unit_exp(uint32_t nrows, const uint32_t* __restrict__ arp, const T* __restrict__ aval,
+                                                                         const unsigned long long* __restrict__ bmm, int mulop, int32_t* __restrict__ out) {
+  __shared__ uint32_t s_rp[257]; __shared__ unsigned long long s_max[256], s_min[256];
+  const uint32_t r0 = blockIdx.x * 256u, nr = nrows - r0 < 256u ? nrows - r0 : 256u;
+  for (uint32_t q = threadIdx.x; q <= nr; q += 256) s_rp[q] = arp[r0 + q];
+  s_max[threadIdx.x] = 0; s_min[threadIdx.x] = ~0ull;
+  __syncthreads();
+  if (aval) {
+    const uint32_t e1 = s_rp[nr];
+    uint32_t cur = 0, cur_end = 0; unsigned long long mx = 0, mn = ~0ull; bool have = false;
+    for (uint32_t p = s_rp[0] + threadIdx.x; p < e1; p += 256) {
+      if (!have || p >= cur_end) {
+        if (have) { atomicMax(&s_max[cur], mx); atomicMin(&s_min[cur], mn); }
+        uint32_t lo = 0, hi = nr;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_rp[mid] <= p) lo = mid; else hi = mid; }
+        cur = lo; cur_end = s_rp[lo + 1]; mx = 0; mn = ~0ull; have = true;
+      }
+      const unsigned long long b = fx_abs_bits((double)aval[p]);
+      mx = b > mx ? b : mx; if (b && b <= 0x7FEFFFFFFFFFFFFFull) mn = b < mn ? b : mn;
     }
-  });
-  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-  if (r < nrows) {
-    const unsigned long long m = s_max[threadIdx.x]; const uint32_t al = s_rp[threadIdx.x + 1] - s_rp[threadIdx.x];
-    int32_t u = 0;
-    if (al) {
-      if (m > 0x7FEFFFFFFFFFFFFFull) u = FX_NO_EXP;
-      else { const double bound = __longlong_as_double((long long)m); u = (m ? ilogb(bound) + 2 : -1074) + (32 - __clz((int)al)) - 126; }
-    }
-    out[r] = u;
+    if (have) { atomicMax(&s_max[cur], mx); atomicMin(&s_min[cur], mn); }
+    __syncthreads();
   }
+  const uint32_t r = r0 + threadIdx.x;
+  if (r >= nrows) return;
+  const uint32_t al = s_rp[threadIdx.x + 1] - s_rp[threadIdx.x];
+  if (!al) { out[r] = 0; return; }
+  const unsigned long long one = fx_abs_bits(1.0);
+  const unsigned long long amx = aval ? s_max[threadIdx.x] : one, amn = aval ? s_min[threadIdx.x] : one, bmx = bmm ? bmm[0] : one, bmn = bmm ? bmm[1] : one;
+  auto val_of = [](const unsigned long long b) { return (T)__longlong_as_double((long long)b); };
+  auto bits_of = [](const T v) { return fx_abs_bits((double)v); };
+  unsigned long long top, low;            // the largest |product|; a value whose exponent bounds the lowest bit of every non-zero product from below
+  const bool a_none = amn == ~0ull, b_none = bmn == ~0ull;          // no non-zero finite value on that side
+  switch (mulop) {
+    case B_TIMES: top = bits_of(val_of(amx) * val_of(bmx)); low = (a_none || b_none) ? ~0ull : bits_of(val_of(amn) * val_of(bmn)); if (!a_none && !b_none && low == 0) low = 1; break;   // (underflow: the last place of the subnormals)
+    case B_FIRST: top = amx; low = amn; break;
+    case B_SECOND: top = bmx; low = bmn; break;
+    case B_PAIR: top = one; low = one; break;
+    case B_PLUS: case B_MINUS: case B_RMINUS: top = bits_of(val_of(amx) + val_of(bmx)); low = amn < bmn ? amn : bmn; break;
+    default: top = amx > bmx ? amx : bmx; low = amn < bmn ? amn : bmn; break;       // MIN, MAX, ANY
+  }
+  int32_t u = FX_NO_EXP;
+  if (top <= 0x7FEFFFFFFFFFFFFFull && amx <= 0x7FEFFFFFFFFFFFFFull && bmx <= 0x7FEFFFFFFFFFFFFFull) {
+    const int E = top ? ilogb(__longlong_as_double((long long)top)) + 2 : -1074;
+    u = E + (32 - __clz((int)al)) - 126;
+    if (low != ~0ull) {                    // (no non-zero product at all: every sum is 0)
+      int lowbit = ilogb(__longlong_as_double((long long)low)) - 52; if (lowbit < -1074) lowbit = -1074;
+      if (lowbit < u) u = FX_NO_EXP;
+    }
+  }
+  out[r] = u;
 }
 static __global__ void k_rows_without_unit(uint32_t nrows, const int32_t* __restrict__ rowexp, const uint32_t* __restrict__ mrp, const uint32_t* __restrict__ arp,
                                            uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
@@ -746,17 +808,19 @@ template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDes
   const bool exact = is_fp && c.ordered && d.addop == B_PLUS && !d.flip && exact_mult_supported(d.mulop) && !getenv("GRB_MI355X_NO_EXACT");
   DevBuf rowexp, noexp_rows, xlo, xhi, bmax;
   if constexpr (is_fp) if (exact) {
-    auto grid16 = [](uint64_t rows) { return (unsigned)((rows + 255) / 256 > 0 ? (rows + 255) / 256 : 1); };        // 256 rows per workgroup
-    if (c.bval) { bmax.alloc((size_t)B.nrows * 8 + 8);
-      hipLaunchKernelGGL((k_row_absmax<T>), dim3(grid16(B.nrows)), dim3(256), 0, stream(), B.nrows, B.rowptr.as<uint32_t>(), (const T*)c.bval, bmax.as<double>()); }
+    if (c.bval) {
+      const unsigned long long init[2] = {0ull, ~0ull};
+      bmax.alloc(16); GRB_HIP(hipMemcpyAsync(bmax.p, init, 16, hipMemcpyHostToDevice, stream()));
+      hipLaunchKernelGGL((k_abs_minmax<T>), dim3((unsigned)std::min<uint64_t>((B.nnz + 255) / 256, 2048)), dim3(256), 0, stream(), (uint64_t)B.nnz, (const T*)c.bval, bmax.as<unsigned long long>());
+    }
     rowexp.alloc((size_t)nrows * 4 + 4); noexp_rows.alloc((size_t)nrows * 4 + 4);
-    hipLaunchKernelGGL((k_row_unit_exp<T>), dim3(grid16(nrows)), dim3(256), 0, stream(), nrows, A.rowptr.as<uint32_t>(), A.col.as<uint32_t>(), (const T*)c.aval,
-                       c.bval ? bmax.as<double>() : (const double*)nullptr, d.mulop, rowexp.as<int32_t>());
+    hipLaunchKernelGGL((k_row_unit_exp<T>), dim3((nrows + 255) / 256), dim3(256), 0, stream(), nrows, A.rowptr.as<uint32_t>(), (const T*)c.aval,
+                       c.bval ? bmax.as<unsigned long long>() : (const unsigned long long*)nullptr, d.mulop, rowexp.as<int32_t>());
     hipLaunchKernelGGL(k_rows_without_unit, dim3((unsigned)std::min<uint64_t>(((uint64_t)nrows + 255) / 256, 4096)), dim3(256), 0, stream(), nrows, rowexp.as<int32_t>(),
                        M.rowptr.as<uint32_t>(), A.rowptr.as<uint32_t>(), noexp_rows.as<uint32_t>(), counts.as<uint32_t>() + 6);
   }
   hipLaunchKernelGGL(k_bin_rows, dim3((unsigned)(((uint64_t)nrows + 1024ull * SPG_BIN_ROWS - 1) / (1024ull * SPG_BIN_ROWS))), dim3(1024), 0, stream(), nrows, M.rowptr.as<uint32_t>(), A.rowptr.as<uint32_t>(), counts.as<uint32_t>(), lists.as<uint32_t>(),
-                     exact ? 2048u : 4096u, exact ? rowexp.as<int32_t>() : (const int32_t*)nullptr);
+                     4096u, exact ? rowexp.as<int32_t>() : (const int32_t*)nullptr);
   uint32_t hc[8];
   GRB_HIP(hipMemcpyAsync(hc, counts.p, 32, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
   if (exact && hc[4]) { xlo.alloc(mnz * 8 + 8); xhi.alloc(mnz * 8 + 8); GRB_HIP(hipMemsetAsync(xlo.p, 0, mnz * 8, stream())); GRB_HIP(hipMemsetAsync(xhi.p, 0, mnz * 8, stream())); }
@@ -817,7 +881,7 @@ template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDes
       if (hc[0]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 64, 64, 256, true>), dim3(nblocks(hc[0], 4)), dim3(256), 0, bs[0], a, L, hc[0], sr);
       if (hc[1]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 512, 256, 256, true>), dim3(nblocks(hc[1], 1)), dim3(256), 0, bs[1], a, L + (size_t)nrows, hc[1], sr);
       if (hc[2]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 2048, 512, 512, true>), dim3(nblocks(hc[2], 1)), dim3(512), 0, bs[2], a, L + (size_t)2 * nrows, hc[2], sr);
-      if (hc[3]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 4096, 1024, 1024, true>), dim3(nblocks(hc[3], 1)), dim3(1024), 0, bs[3], a, L + (size_t)3 * nrows, hc[3], sr);     // (mask rows of <= 2 048 entries: 16-byte accumulators)
+      if (hc[3]) hipLaunchKernelGGL((k_spgemm_masked_lds<T, SR, 8192, 1024, 1024, true>), dim3(nblocks(hc[3], 1)), dim3(1024), 0, bs[3], a, L + (size_t)3 * nrows, hc[3], sr);
       if (hc[4]) {
         hipLaunchKernelGGL((k_spgemm_masked_map<T, SR, false, true>), dim3(nb_map), dim3(1024), 0, stream(), a, L + (size_t)4 * nrows, hc[4], nslices, maps.as<uint32_t>(), B.ncols, sr);
         hipLaunchKernelGGL((k_exact_finish<T>), dim3((unsigned)std::min<uint32_t>(hc[4], 4096u)), dim3(256), 0, stream(), L + (size_t)4 * nrows, hc[4], M.rowptr.as<uint32_t>(), rowexp.as<int32_t>(),

@@ -560,7 +560,8 @@ def test_deterministic_mode_of_the_masked_product_every_mask_length_against_the_
 def test_exact_accumulators_of_the_masked_product_return_the_exactly_rounded_sums(gpu, monkeypatch):
     """What "exact" means: every entry of C<M> = A (+.x) B is math.fsum of its products (each product rounded once by the multiply, the sum rounded once at
     the end) — bit for bit, for FP64 and (products and result in FP32) for FP32, in every bin of the kernel including the rows that accumulate in HBM; values
-    spread over 2^40 so that an ordinary running sum differs from it in the last places.  A row holding an Inf is formed by the ordered kernel instead."""
+    spread over 2^50 so that an ordinary running sum differs from it in the last places.  A row holding an Inf, and a row whose values are spread too far for
+    its 128-bit unit to hold every bit of every product (one entry 2^-80 among values near 1), are formed by the ordered kernel instead: never a cut bit."""
     import math
     monkeypatch.setenv("GRB_MI355X_DETERMINISTIC", "1")
     rng = np.random.default_rng(29)
@@ -571,8 +572,8 @@ def test_exact_accumulators_of_the_masked_product_return_the_exactly_rounded_sum
     for typ, np_t in (("FP64", np.float64), ("FP32", np.float32)):
         A = rand_matrix(rng, typ, len(lens), ka, 0.7, small=False)
         B = rand_matrix(rng, typ, ka, n, 0.15, small=False)
-        A.X[:] = (A.X * np.exp2(rng.integers(-20, 20, len(A.X))) * rng.choice([-1.0, 1.0], len(A.X))).astype(np_t)
-        B.X[:] = (B.X * np.exp2(rng.integers(-20, 20, len(B.X))) * rng.choice([-1.0, 1.0], len(B.X))).astype(np_t)
+        A.X[:] = ((0.5 + 0.5 * A.X) * np.exp2(rng.integers(-12, 12, len(A.X))) * rng.choice([-1.0, 1.0], len(A.X))).astype(np_t)
+        B.X[:] = ((0.5 + 0.5 * B.X) * np.exp2(rng.integers(-12, 12, len(B.X))) * rng.choice([-1.0, 1.0], len(B.X))).astype(np_t)
         got = to_matrix(A).mxm(to_matrix(B), semiring=getattr(TYPE[typ], "PLUS_TIMES"), mask=to_matrix(M), desc=D.S)
         assert " exact" in gb.last_kernel_plan() and "ordered" not in gb.last_kernel_plan(), gb.last_kernel_plan()
         Ad = np.zeros((len(lens), ka), np_t); Ap = np.zeros((len(lens), ka), bool)
@@ -612,6 +613,18 @@ def test_exact_accumulators_of_the_masked_product_return_the_exactly_rounded_sum
     r3 = ~other
     assert np.array_equal(np.isnan(g2.X[r3]), np.isnan(exp.X[r3])) and np.array_equal(np.isposinf(g2.X[r3]), np.isposinf(exp.X[r3]))
     assert np.array_equal(np.isneginf(g2.X[r3]), np.isneginf(exp.X[r3])) and (~np.isfinite(g2.X[r3])).sum() > 100
+    A.X[np.nonzero(A.I == 3)[0][0]] = 1.0
+    A.X[np.nonzero(A.I == 5)[0][0]] = np.float32(2.0 ** -80)
+    got = to_matrix(A).mxm(to_matrix(B), semiring=gb.FP32.PLUS_TIMES, mask=to_matrix(M), desc=D.S)
+    plan = gb.last_kernel_plan()
+    assert " exact" in plan and "k_spgemm_masked_ordered<static> rows 0 + 1" in plan, plan
+    g3 = matrix_tuples(got)
+    exp = O.mxm(O.Tuples("FP32", len(lens), n), A, B, "PLUS", "TIMES", "FP32", mask=M, mask_struct=True)
+    assert np.array_equal(g3.I, exp.I) and np.array_equal(g3.J, exp.J)
+    r5 = g3.I == 5
+    scale = np.abs(exp.X[r5]).max()
+    assert np.allclose(g3.X[r5], exp.X[r5], rtol=0, atol=1e-5 * scale)           # (row 5: the ordered kernel's running sums, as the oracle's)
+    assert np.array_equal(_bits(g3.X[(g3.I != 5) & (g3.I != 3)]), _bits(g.X[(g.I != 5) & (g.I != 3)]))
 
 
 def test_deterministic_mode_of_the_masked_product_rmat18_is_bitwise_repeatable(gpu, monkeypatch):
