@@ -110,12 +110,11 @@ constexpr uint32_t SPG_FILTER_MUL = 0x9E3779u;   // 24-bit multiplier: v_mul_u32
 // When the multiply reads no value (PLUS_PAIR: the triangle count) the queue is carried from B row to B row; otherwise it is
 // flushed at the end of every B row (the A value changes), and B rows shorter than 256 entries keep the direct lookup.
 // EXACT (deterministic mode, PLUS monoid on FP32 / FP64): the accumulators are 128-bit integers in the row's unit (grb_exact.hpp) — the order the atomics
-// land in no longer matters, everything else in the kernel is the same.  A hit then costs ~95 instructions and a returning LDS atomic instead of a multiply
-// and ds_add_f64, and a wave pays them whenever ANY of its lanes hits (93 % of the lookups at 4 % hits per lane) in a kernel the VALU bounds: the LDS bins run
-// 1.55-1.8 x their default time (R-MAT-22, FP64 PLUS_TIMES: 72.6 / 56.0 / 43.8 ms against 47.4 / 31.4 / 27.3), the whole product 1.46 x.  Measured and
-// dropped: the add inlined at its ~35 sites (twice the code, same time: 73.9 ms); every product through the filter with the survivors queued as
-// (column, product) across B rows like the counting products (111 ms: the value load stalls every push) or as (column, position in B, position in A) with
-// the loads at the flush (81.6 ms; the third queue array takes the 512-slot bin from three workgroups per CU to two).
+// land in no longer matters, everything else in the kernel is the same.  A hit then costs ~95 instructions (out of line: fx_add_lds) and a returning LDS
+// atomic instead of a multiply and ds_add_f64, and a wave pays them whenever ANY of its lanes hits: the bins run 1.2-1.3 x their default time (R-MAT-22, FP64
+// PLUS_TIMES: 54.9 / 38.5 / 34.8 / 14.7 ms against 45.3 / 30.0 / 26.0 / 11.9).  The last bin keeps its 4 096 mask entries (EXBIG below): with 2 048 the HBM-map
+// kernel got five times the rows and, one 147 KB workgroup per CU, kept every other bin off the CUs three times as long.  Measurement builds: SPG_EXACT_EXP = 1
+// (plain ds_add_f64 in the EXACT kernels: the same time, i.e. the integer add is not what an EXACT kernel costs), 2 (no returning atomic).
 template <class T, class SR, int SLOTS, int TEAM, int BLOCK, bool EXACT = false>
 __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T> a, const uint32_t* __restrict__ rows, uint32_t nrows_bin, const SR sr) {
   typedef typename acc_word<T>::type W;
@@ -418,7 +417,10 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_masked_lds(const SpgemmKArgs<T
 // and reach cacc as ONE plain store each at the end of the row; positions behind LC keep the global atomic.  The LDS they take
 // comes out of the filter: 2^18 bits instead of 2^20 (a 30 000-entry mask row lets ~11 % of the misses through to the map).
 constexpr uint32_t SPG_FILTER_WORDS = 8192;         // 2^18 bits = 32 KiB of LDS
-constexpr uint32_t SPG_MAP_LDS_BYTES = 96 * 1024;   // accumulators of the first positions of the mask row
+#ifndef SPG_MAP_LDS_KB_V
+#define SPG_MAP_LDS_KB_V 96
+#endif
+constexpr uint32_t SPG_MAP_LDS_BYTES = SPG_MAP_LDS_KB_V * 1024;   // accumulators of the first positions of the mask row
 constexpr uint32_t SPG_MAP_SLICE = SPG_SLICE_V;            // entries of A(i,:) per task (1024: 44.2 ms, 2048: 43.4, 4096: 43.4, 8192: 43.1 for the R-MAT-22 triangle count)
 // EXACT (deterministic mode): every accumulator is a 128-bit integer (grb_exact.hpp) — low words, high words and flags of the first LCF positions in the
 // same LDS budget, the positions behind them and the hand-over of every task in a.xlo / a.xhi (integer atomics: the slices of a row and the workgroups may
