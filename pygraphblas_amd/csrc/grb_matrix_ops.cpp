@@ -96,7 +96,7 @@ void do_mxm(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, GrB_Semiring semirin
   DevCSR T; bool t_masked = false;
   {
     const bool fp = sd.zcode == T_FP32 || sd.zcode == T_FP64;
-    call.ordered = fp && (deterministic_env() || dv.axb == GxB_AxB_GUSTAVSON);
+    call.ordered = fp && sd.addop != B_MIN && sd.addop != B_MAX && (deterministic_env() || dv.axb == GxB_AxB_GUSTAVSON);      // (MIN / MAX: the same bits in any order)
   }
   if (mxm_few_rows_wanted(Ad, Bd)) {            // a handful of output rows (batched BC frontiers): one vxm per row, see grb_mxm_rows.cpp
     mxm_few_rows(Ad, A->type, M, dv, semiring, B, sd.zcode, T); t_masked = true;

@@ -849,7 +849,8 @@ template <class T> void run_spgemm_masked(const SpgemmCall& c, const SemiringDes
         g_last_plan += std::string("k_spgemm_masked_ordered<") + (sr.is_static ? "static" : "dynamic") + "> rows " + std::to_string(nsmall) + " + " + std::to_string(nbig) + " ";
       }
     };
-    if constexpr (is_fp) if (c.ordered && !exact) {
+    // (MIN / MAX monoids give the same bits in any order: the default kernels are their deterministic mode)
+    if constexpr (is_fp) if (c.ordered && !exact && d.addop != B_MIN && d.addop != B_MAX) {
       const uint32_t* ls[4] = {L + (size_t)4 * nrows, L + (size_t)3 * nrows, L + (size_t)2 * nrows, L + (size_t)nrows}; const uint32_t cs[4] = {hc[4], hc[3], hc[2], hc[1]};
       run_ordered(ls, cs, 4, L, hc[0]);
       return;

@@ -527,7 +527,8 @@ def _bits(x):
 
 def test_deterministic_mode_of_the_masked_product_every_mask_length_against_the_oracle(gpu, monkeypatch):
     """GRB_MI355X_DETERMINISTIC=1 with a mask.  PLUS monoid: the usual kernels with exact accumulators (128-bit integers, grb_exact.hpp; plan "exact");
-    any other monoid: k_spgemm_masked_ordered (one group per slice of a mask row, the entries of A(i,:) in order).  Mask rows of 1 ... 30 000 entries (every
+    MIN / MAX monoids: the default kernels (any order gives the same bits); any other monoid (TIMES): k_spgemm_masked_ordered (one group per slice of a mask
+    row, the entries of A(i,:) in order).  Mask rows of 1 ... 30 000 entries (every
     LDS bin, the HBM-map bin, up to 59 slices), valued masks with false entries and structural ones, FP64 and FP32, against the oracle, and the same bits twice."""
     monkeypatch.setenv("GRB_MI355X_DETERMINISTIC", "1")
     rng = np.random.default_rng(23)
@@ -541,12 +542,12 @@ def test_deterministic_mode_of_the_masked_product_every_mask_length_against_the_
             for ka, da, db in ((300, 0.5, 0.05), (2500, 0.9, 0.01), (120, 0.6, 0.2)):
                 A = rand_matrix(rng, typ, len(lens), ka, da, small=False)
                 B = rand_matrix(rng, typ, ka, n, db, small=False)
-                for sr in ("PLUS_TIMES", "PLUS_SECOND", "PLUS_MIN", "MIN_PLUS"):
+                for sr in ("PLUS_TIMES", "PLUS_SECOND", "PLUS_MIN", "MIN_PLUS", "TIMES_MAX"):
                     add, mul = sr.split("_")
                     desc = D.S if struct else None
                     got = to_matrix(A).mxm(to_matrix(B), semiring=getattr(TYPE[typ], sr), mask=to_matrix(M), desc=desc)
                     plan = gb.last_kernel_plan()
-                    assert (" exact" in plan) if add == "PLUS" else ("k_spgemm_masked_ordered" in plan), plan
+                    assert (" exact" in plan) if add == "PLUS" else ("ordered" not in plan and "exact" not in plan) if add == "MIN" else ("k_spgemm_masked_ordered" in plan), plan
                     exp = O.mxm(O.Tuples(typ, len(lens), n), A, B, add, mul, typ, mask=M, mask_struct=struct)
                     check(got, exp, typ, rtol=rtol, what=f"{typ}.{sr} struct={struct} ka={ka}")
                     again = to_matrix(A).mxm(to_matrix(B), semiring=getattr(TYPE[typ], sr), mask=to_matrix(M), desc=desc)
