@@ -243,6 +243,7 @@ def main():
             torch.cuda.empty_cache()
             out["aa"] = bench_aa(cx, args.aa_scale)
             out["bc"] = bench_bc(cx, args.scale)
+            out["mxm_fp64_deterministic"] = bench_masked_fp64_deterministic(cx, args.scale)
 
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -722,6 +723,52 @@ def bench_aa(cx, scale=18):
                                "seconds_extrapolated_to_the_whole_product": round(products / (done_p / cpu_s), 2)}
     Cm = None
     return out
+
+
+def bench_masked_fp64_deterministic(cx, scale):
+    """configs[3]'s shape on floating-point values: C<L> = L (+.x) L, FP64 PLUS_TIMES, in the default mode (LDS / HBM atomics as they land) and with
+    GRB_MI355X_DETERMINISTIC=1 (exact 128-bit integer accumulators: the same bits in every run, the exactly rounded sums)."""
+    import ctypes as C
+    gb, rmat, torch, dev = cx.gb, cx.rmat, cx.torch, cx.dev
+    n = 1 << scale
+    rowptr, col = rmat.csr_torch(scale, dev, seed=42, symmetric=True, drop_self_loops=True, lower=True)
+    nnz = int(col.numel())
+    vals = rmat.values_torch(nnz, dev, seed=46) + 0.5
+    L = gb.Matrix.from_csr(gb.FP64, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+    dL = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+    products = int(dL[col.to(torch.int64) & 0xFFFFFFFF].sum())
+
+    def run():
+        Cm = L.mxm(L, semiring=gb.FP64.PLUS_TIMES, mask=L, desc=cx.gb.descriptor.S)
+        Cm.nvals
+        return Cm
+
+    def values_of(Cm):
+        v = torch.empty(Cm.nvals, dtype=torch.float64, device=dev)
+        gb.base.check(gb.lib.GrBX_Matrix_export_CSR(Cm._h, None, None, C.c_void_p(v.data_ptr()), C.c_int(1)))
+        return v
+    res = {}
+    saved = os.environ.get("GRB_MI355X_DETERMINISTIC")
+    try:
+        for mode in ("default", "deterministic"):
+            if mode == "deterministic": os.environ["GRB_MI355X_DETERMINISTIC"] = "1"
+            else: os.environ.pop("GRB_MI355X_DETERMINISTIC", None)
+            run(); times = []
+            for _ in range(5):
+                torch.cuda.synchronize(); t = time.perf_counter(); Cm = run(); torch.cuda.synchronize(); times.append(time.perf_counter() - t)
+            v = values_of(Cm); again = values_of(run())
+            res[mode] = {"seconds": round(sorted(times)[2], 5), "plan": gb.last_kernel_plan().strip(), "same_bits_twice": bool(torch.equal(v.view(torch.int64), again.view(torch.int64)))}
+            if mode == "default": v0 = v
+            else: res[mode]["agrees_with_default_rtol_1e-10"] = bool(torch.allclose(v, v0, rtol=1e-10, atol=0.0))
+            del again
+    finally:
+        if saved is None: os.environ.pop("GRB_MI355X_DETERMINISTIC", None)
+        else: os.environ["GRB_MI355X_DETERMINISTIC"] = saved
+    alg = 2 * (nnz * 12 + (n + 1) * 4) + products * 4 + int(v0.numel()) * 12
+    return {"workload": f"masked product on FP64 values R-MAT-{scale}: L.mxm(L, PLUS_TIMES, mask=L), default mode against GRB_MI355X_DETERMINISTIC=1 (median of 5 each)",
+            "nnz_L": nnz, "products": products, "entries": int(v0.numel()), "dtype": "f64", "default": res["default"], "deterministic": res["deterministic"],
+            "deterministic_over_default": round(res["deterministic"]["seconds"] / res["default"]["seconds"], 3),
+            "roofline": roof(alg, res["deterministic"]["seconds"], note="the deterministic mode's time; the triangle count's convention (SURVEY.md 8d): nnz(L)*(4+8)*2 + row pointers + products*4 (the column of every B-row entry; a value is read only by a hit) + entries*12")}
 
 
 def bench_bc(cx, scale):
