@@ -161,8 +161,14 @@ uint32_t* any_true_acquire(uint32_t* tag) {
     void* h = nullptr; GRB_HIP(hipHostMalloc(&h, FE_HOST_PAIRS * 8, hipHostMallocMapped | hipHostMallocCoherent)); memset(h, 0, FE_HOST_PAIRS * 8); s.host = (unsigned long long*)h;      // (lives as long as the thread's pinned scratch: never freed)
     void* dp = nullptr; if (hipHostGetDevicePointer(&dp, h, 0) != hipSuccess) { (void)hipGetLastError(); dp = h; }
     s.host_dev = (unsigned long long*)dp;
+    if (const char* e = getenv("GRB_MI355X_SUMMARY_TAG0")) s.tag = (uint32_t)strtoul(e, nullptr, 0);      // test hook: start the tags just below the 24-bit wrap
   }
-  if ((++s.tag & 0xFFFFFFu) == 0) s.tag++;            // (the low 24 bits travel in the host words of the summary: never zero)
+  if ((++s.tag & 0xFFFFFFu) == 0) {                   // (the low 24 bits travel in the host words of the summary: never zero)
+    s.tag++;
+    // the 24-bit tags start over: a word that a product 2^24 calls ago left unread (its summary was never asked for, and no product since had as many
+    // workgroups) must not pass for the coming product's — once per 16.7 million products, wait for the stream and wipe the words
+    GRB_HIP(hipStreamSynchronize(stream())); memset(s.host, 0, FE_HOST_PAIRS * 8);
+  }
   s.owner = nullptr; s.fe_has = false; *tag = s.tag;
   return s.word.as<uint32_t>();
 }

@@ -469,3 +469,35 @@ def test_deterministic_mode_keeps_fp_sums_out_of_the_push_kernels(gpu, monkeypat
     assert np.array_equal(np.asarray(gi, np.int64), np.nonzero(pres)[0]) and np.allclose(np.asarray(gx), want[pres], rtol=1e-12, atol=0)
     u.vxm(M, semiring=gb.FP64.MIN_PLUS)
     assert "push" in gb.last_kernel_plan(), gb.last_kernel_plan()
+
+
+def test_summary_words_survive_the_wrap_of_their_24_bit_tags(gpu):
+    """The product's host words carry a 24-bit tag; every 2^24 products the tags start over and the words are wiped (a word left unread 2^24 calls ago
+    must not pass for the coming product's).  In a process of its own whose tags start eight below the wrap (GRB_MI355X_SUMMARY_TAG0): products of
+    different sizes whose summaries are not all asked for, across the wrap — every `reduce_bool` is what a scan of the result gives."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import numpy as np, sys
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import pygraphblas_amd as gb
+        from pygraphblas_amd import descriptor as D
+        rng = np.random.default_rng(5)
+        mats = []
+        for n in (300000, 2000):                       # many workgroups / few workgroups
+            nnz = n * 4; flat = np.unique(rng.integers(0, n * n, nnz, dtype=np.int64)); nnz = len(flat); I, J = [x.astype(np.uint64) for x in np.divmod(flat, n)]
+            mats.append((n, gb.Matrix.from_arrays(I, J, np.ones(nnz, np.bool_), n, n, gb.BOOL)))
+        for it in range(40):
+            n, A = mats[0] if it %% 7 == 0 else mats[1]
+            seen = gb.Vector.from_arrays(np.arange(0, n, 3, dtype=np.uint64), np.ones(len(range(0, n, 3)), np.uint8), n, gb.UINT8)
+            ui = np.sort(rng.choice(n, 5 if it %% 3 else n // 2, replace=False)).astype(np.uint64)
+            u = gb.Vector.from_arrays(ui, np.ones(len(ui), np.bool_), n, gb.BOOL)
+            q = gb.Vector.sparse(gb.BOOL, n)
+            u.vxm(A, out=q, mask=seen, desc=D.RC)
+            if it %% 2:                                 # every other summary is never read
+                got = q.reduce_bool()
+                assert got == (q.nvals > 0), (it, got, q.nvals)
+        print("ok")
+    ''') % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GRB_MI355X_SUMMARY_TAG0=str(0xFFFFF8))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
