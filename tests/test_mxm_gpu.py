@@ -698,3 +698,51 @@ def test_deterministic_mode_of_the_masked_product_rmat22_is_bitwise_repeatable(g
         v2 = product()[2]
         assert torch.equal(v2.view(torch.int64), v1.view(torch.int64))
         del v2
+
+
+def test_exact_mode_of_the_masked_product_rmat18_sampled_rows_equal_fsum(gpu, monkeypatch):
+    """The exactness claim at BASELINE scale: C<A> = A (+.x) A on the symmetric R-MAT-18 with random FP64 values in deterministic mode, and ~400 rows of it
+    — random ones from every bin of the kernel (mask rows of <= 32, 256, 1 024, 4 096 and more entries) — recomputed on the host: for every entry (i, j)
+    the products A(i,k) * A(k,j) over the common k (scipy slices; each product one IEEE multiply, as on the device) summed with math.fsum.  The pattern is
+    the same and every value is the same 64 bits."""
+    import math
+    import scipy.sparse as sp
+    monkeypatch.setenv("GRB_MI355X_DETERMINISTIC", "1")
+    rng = np.random.default_rng(41)
+    S = 18; n = 1 << S
+    rp, col = rmat.csr_numpy(S, symmetric=True, drop_self_loops=True)
+    vals = rng.random(len(col)) + 0.5
+    A = gb.Matrix.from_csr(gb.FP64, n, n, rp, col, vals)
+    Cm = A.mxm(A, semiring=gb.FP64.PLUS_TIMES, mask=A, desc=D.S)
+    plan = gb.last_kernel_plan()
+    bins = [int(x) for x in plan.split("bins ")[1].split()[0].split("/")]
+    assert " exact" in plan and "ordered" not in plan and all(b > 0 for b in bins), plan
+    crp, ccol, cval = Cm.to_csr()
+    crp = crp.astype(np.int64)
+    lens = np.diff(rp.astype(np.int64))
+    edges = [0, 32, 256, 1024, 4096, 1 << 30]                # the kernel's bins by mask-row length: three LDS team sizes, the last LDS bin, the HBM-map bin
+    rows = np.sort(np.concatenate([rng.choice(np.nonzero((lens > lo) & (lens <= hi))[0], min(k, int(((lens > lo) & (lens <= hi)).sum())), replace=False)
+                                   for lo, hi, k in zip(edges[:-1], edges[1:], (150, 100, 60, 40, 50))]))
+    per_bin = [0] * 5
+    Sm = sp.csr_matrix((vals, col.astype(np.int64), rp.astype(np.int64)), shape=(n, n))
+    checked = entries = 0
+    for i in rows.tolist():
+        ks = col[rp[i]:rp[i + 1]].astype(np.int64); a = vals[rp[i]:rp[i + 1]]
+        if not len(ks):
+            assert crp[i + 1] == crp[i]
+            continue
+        sub = Sm[ks, :][:, ks].tocsc()                       # sub[k, j] = A(k, j) for k, j in the row's columns (the mask row = the A row)
+        if sub.nnz > 4_000_000:
+            continue                                         # (a hub row's 10^7 hits in a Python loop: the other rows of its bin stand for it)
+        want_cols, want_vals = [], []
+        ip, ix, dx = sub.indptr, sub.indices, sub.data
+        for c in range(len(ks)):
+            seg = slice(ip[c], ip[c + 1])
+            if ip[c + 1] > ip[c]:
+                terms = a[ix[seg]] * dx[seg]
+                want_cols.append(ks[c]); want_vals.append(math.fsum(terms.tolist()))
+        got_c = ccol[crp[i]:crp[i + 1]].astype(np.int64); got_v = cval[crp[i]:crp[i + 1]]
+        assert np.array_equal(got_c, np.array(want_cols, np.int64)), (i, len(ks))
+        assert np.array_equal(got_v.view(np.uint64), np.array(want_vals, np.float64).view(np.uint64)), (i, len(ks))
+        checked += 1; entries += len(want_cols); per_bin[int(np.searchsorted(edges, len(ks), side="left")) - 1] += 1
+    assert checked >= 350 and entries > 200_000 and min(per_bin) >= 30, (checked, entries, per_bin)
