@@ -265,14 +265,15 @@ __device__ __forceinline__ void spa_wave_offsets(const uint32_t* s_w, uint32_t l
   total = (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
   woff = (uint32_t)__builtin_amdgcn_readlane((int)pre, (int)wave);
 }
-// `ordered` (round 5, the library's deterministic mode — GRB_MI355X_DETERMINISTIC=1 or the descriptor's GxB_AxB_GUSTAVSON): the sixteen waves combine their
-// batches ONE AFTER THE OTHER, in wave order, behind a barrier each — the products of a batch are dealt to lanes and rounds statically and a wave's LDS
+// `ordered` (round 5, the library's deterministic mode — GRB_MI355X_DETERMINISTIC=1 or the descriptor's GxB_AxB_GUSTAVSON): the batches combine ONE AFTER THE
+// OTHER, in batch order, each behind a ticket the batch before it hands on — the products of a batch are dealt to lanes and rounds statically and a wave's LDS
 // atomics execute in program order, so every accumulator receives its terms in the same order in every run and a floating-point sum is reproducible bit
-// for bit; what it costs is the sixteen barriers per 8 192 products (A@A on R-MAT-18: see DESIGN.md).  Without it the waves' atomics land as they come.
-template <bool ordered = false, class L, class A> __device__ __forceinline__ uint32_t spa_flat_walk(uint32_t st, uint32_t len, uint32_t* s_exc /* [1025] */, uint32_t* s_shift /* [1024] */, uint32_t* s_wtot /* [16] */, L&& load, A&& apply, unsigned long long* pf = nullptr) {
+// for bit (A@A on R-MAT-18: see DESIGN.md).  Without it the waves' atomics land as they come.
+template <bool ordered = false, class L, class A> __device__ __forceinline__ uint32_t spa_flat_walk(uint32_t st, uint32_t len, uint32_t* s_exc /* [1025] */, uint32_t* s_shift /* [1024] */, uint32_t* s_wtot /* [16] */, L&& load, A&& apply, unsigned long long* pf = nullptr, uint32_t* s_turn = nullptr) {
   const uint32_t t = threadIdx.x, lane = t & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
   const uint32_t inc = spa_wave_incl_add(len);
   if (lane == 63) s_wtot[wave] = inc;
+  if constexpr (ordered) { if (t == 0) *s_turn = 0; }      // the batch whose turn it is to combine
   __syncthreads();
   uint32_t woff, total, cpre;                                // cpre: first product of the 64-entry chunk (lane & 15)
   spa_wave_offsets(s_wtot, lane, wave, woff, total, cpre);
@@ -291,10 +292,7 @@ template <bool ordered = false, class L, class A> __device__ __forceinline__ uin
   const uint32_t bsz = 64u * rpb, nb = (total + bsz - 1u) / bsz;
   for (uint32_t b0 = 0; b0 < nb; b0 += 16u) {
     const uint32_t b = b0 + wave;
-    if (b >= nb) {                                           // (its batches are b = wave, wave + 16, ...: none left)
-      if constexpr (ordered) { for (uint32_t w = 0; w < 16u; w++) __syncthreads(); continue; }      // ordered: this wave keeps the others company at their barriers
-      else break;
-    }
+    if (b >= nb) break;                                      // (its batches are b = wave, wave + 16, ...: none left)
     const uint32_t qb = b * bsz, qe = qb + bsz < total ? qb + bsz : total;
     const uint32_t vbase = entry_of(qb), vlast = entry_of(qe - 1u);
     uint32_t q[SPA_R], vlo[SPA_R], vhi[SPA_R];
@@ -318,13 +316,12 @@ template <bool ordered = false, class L, class A> __device__ __forceinline__ uin
 #pragma unroll
       for (int r = 0; r < SPA_R; r++) if (q[r] < qe) apply(item[r]);
     } else {
-      for (uint32_t w = 0; w < 16u; w++) {
-        if (w == wave) {
+      // batch b combines when the batches before it have: a ticket in LDS instead of sixteen barriers per group of batches — a wave goes on to search and load
+      // its next batch while the others combine (the LDS executes a wave's operations in order: the ticket a wave hands on is behind its atomics)
+      while (__hip_atomic_load(s_turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != b) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-          for (int r = 0; r < SPA_R; r++) if (q[r] < qe) apply(item[r]);
-        }
-        __syncthreads();
-      }
+      for (int r = 0; r < SPA_R; r++) if (q[r] < qe) apply(item[r]);
+      if (lane == 0) __hip_atomic_store(s_turn, b + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
   SPA_PF(1)
@@ -406,7 +403,7 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
   uint32_t* const s_flag = (uint32_t*)(s_raw + (size_t)WD * sizeof(W));
   __shared__ T s_av[SPA_CHUNK];
   __shared__ uint32_t s_exc[1025], s_shift[SPA_CHUNK], s_wtot[16];
-  __shared__ uint32_t s_wsum[16], s_woff[16], s_blk[SPA_RANK_MAXBLK + 2], s_next;
+  __shared__ uint32_t s_wsum[16], s_woff[16], s_blk[SPA_RANK_MAXBLK + 2], s_next, s_turn;
   const uint32_t t = threadIdx.x, lane = t & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
   const bool use_a = sr.uses_a(), use_b = sr.uses_u();
   const W idw = to_word<T>(sr.identity);
@@ -474,7 +471,7 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
             [&](uint32_t v, uint32_t pb) { RProd p; p.col = a.bcol[pb]; p.x = sr.mult(use_a ? s_av[v] : T(), use_b ? bval[pb] : T()); return p; },
             [&](const RProd& p) { const uint32_t w = p.col >> 5; const uint32_t bits = s_bits[w];
                                   const uint32_t rk = s_woff[w >> csh] + s_pre[w] + (uint32_t)__popc(bits & ((1u << (p.col & 31u)) - 1u)) - rbase;
-                                  word_combine<T>(sr.add_op(), &s_racc[rk], p.x); }, nullptr);
+                                  word_combine<T>(sr.add_op(), &s_racc[rk], p.x); }, nullptr, &s_turn);
         };
         // the entries of blocks [c0, c1): the threads walk their own bitmap words, the rank of a word's first bit is known — no scan, no barrier
         auto remit = [&](uint32_t c0, uint32_t c1) __attribute__((always_inline)) {
@@ -532,7 +529,7 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
     auto walk = [&](uint32_t lo, uint32_t st, uint32_t len) __attribute__((always_inline)) -> uint32_t {
       return spa_flat_walk<ORDERED>(st, len, s_exc, s_shift, s_wtot,
         [&](uint32_t v, uint32_t pb) { Prod p; p.rel = a.bcol[pb] - lo; p.x = sr.mult(use_a ? s_av[v] : T(), use_b ? bval[pb] : T()); return p; },
-        [&](const Prod& p) { ((unsigned char*)s_flag)[p.rel] = 1; word_combine<T>(sr.add_op(), &s_acc[p.rel], p.x); }, pf);
+        [&](const Prod& p) { ((unsigned char*)s_flag)[p.rel] = 1; word_combine<T>(sr.add_op(), &s_acc[p.rel], p.x); }, pf, &s_turn);
     };
     // emit the block in column order: every thread owns WD / 1024 columns; exclusive prefix of their counts, then every thread writes its own run —
     // four accumulators in flight.  (Round 4: 32 columns on half the threads, thread 0 adding up the wave sums between two barriers and a
