@@ -108,7 +108,7 @@ void do_mxm(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, GrB_Semiring semirin
     // no mask, or a complemented one (applied by the write-back): the two-pass LDS-hash Gustavson; expand / sort / compress on
     // request (it forms floating-point sums in a fixed order): GRB_MI355X_SPGEMM=esc or the descriptor's AxB method GxB_AxB_DOT
     // Deterministic mode (round 5): GRB_MI355X_DETERMINISTIC=1 or the descriptor's GxB_AxB_GUSTAVSON — the two-pass product with its dense path's ordered
-    // walk (floating-point sums bit-reproducible from run to run at ~1.6 x the time, grb_spgemm_hash.hpp); results too wide for that path (> 2^20 columns)
+    // walk (floating-point sums bit-reproducible from run to run at ~1.15 x the time, grb_spgemm_hash.hpp); results too wide for that path (> 2^20 columns)
     // take expand / sort / compress.  Integer / Boolean monoids are exact in any order: nothing changes for them.
     const char* e = getenv("GRB_MI355X_SPGEMM");
     if ((e && !strcmp(e, "esc")) || dv.axb == GxB_AxB_DOT || (call.ordered && Bd.ncols > (1u << 20))) spgemm_esc(call, sd, T); else spgemm_hash(call, sd, T);

@@ -269,7 +269,9 @@ __device__ __forceinline__ void spa_wave_offsets(const uint32_t* s_w, uint32_t l
 // OTHER, in batch order, each behind a ticket the batch before it hands on — the products of a batch are dealt to lanes and rounds statically and a wave's LDS
 // atomics execute in program order, so every accumulator receives its terms in the same order in every run and a floating-point sum is reproducible bit
 // for bit (A@A on R-MAT-18: see DESIGN.md).  Without it the waves' atomics land as they come.
-template <bool ordered = false, class L, class A> __device__ __forceinline__ uint32_t spa_flat_walk(uint32_t st, uint32_t len, uint32_t* s_exc /* [1025] */, uint32_t* s_shift /* [1024] */, uint32_t* s_wtot /* [16] */, L&& load, A&& apply, unsigned long long* pf = nullptr, uint32_t* s_turn = nullptr) {
+// A product is combined in two steps: slot_of(item) finds its accumulator (for a ranked row three LDS reads and a bit count — nothing that depends on the other
+// products), commit(slot, item) is the atomic.  The ordered walk computes the slots of a batch BEFORE it waits for its turn: only the atomics are serialised.
+template <bool ordered = false, class L, class S, class A> __device__ __forceinline__ uint32_t spa_flat_walk2(uint32_t st, uint32_t len, uint32_t* s_exc /* [1025] */, uint32_t* s_shift /* [1024] */, uint32_t* s_wtot /* [16] */, L&& load, S&& slot_of, A&& commit, unsigned long long* pf = nullptr, uint32_t* s_turn = nullptr) {
   const uint32_t t = threadIdx.x, lane = t & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
   const uint32_t inc = spa_wave_incl_add(len);
   if (lane == 63) s_wtot[wave] = inc;
@@ -314,13 +316,16 @@ template <bool ordered = false, class L, class A> __device__ __forceinline__ uin
     //  words in its first round and the later rounds see them — reading all of them first meant more same-word atomics: 56.9 -> 61.1 ms)
     if constexpr (!ordered) {
 #pragma unroll
-      for (int r = 0; r < SPA_R; r++) if (q[r] < qe) apply(item[r]);
+      for (int r = 0; r < SPA_R; r++) if (q[r] < qe) commit(slot_of(item[r]), item[r]);
     } else {
+      uint32_t slot[SPA_R];
+#pragma unroll
+      for (int r = 0; r < SPA_R; r++) slot[r] = q[r] < qe ? slot_of(item[r]) : 0u;
       // batch b combines when the batches before it have: a ticket in LDS instead of sixteen barriers per group of batches — a wave goes on to search and load
       // its next batch while the others combine (the LDS executes a wave's operations in order: the ticket a wave hands on is behind its atomics)
       while (__hip_atomic_load(s_turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != b) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-      for (int r = 0; r < SPA_R; r++) if (q[r] < qe) apply(item[r]);
+      for (int r = 0; r < SPA_R; r++) if (q[r] < qe) commit(slot[r], item[r]);
       if (lane == 0) __hip_atomic_store(s_turn, b + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
@@ -328,6 +333,10 @@ template <bool ordered = false, class L, class A> __device__ __forceinline__ uin
   __syncthreads();
   SPA_PF(2)
   return total;                                             // (the same in every thread)
+}
+template <bool ordered = false, class L, class A> __device__ __forceinline__ uint32_t spa_flat_walk(uint32_t st, uint32_t len, uint32_t* s_exc, uint32_t* s_shift, uint32_t* s_wtot, L&& load, A&& apply, unsigned long long* pf = nullptr) {
+  static_assert(!ordered, "the ordered walk takes slot_of / commit (spa_flat_walk2)");
+  return spa_flat_walk2<false>(st, len, s_exc, s_shift, s_wtot, load, [](const auto&) { return 0u; }, [&](uint32_t, const auto& it) { apply(it); }, pf, nullptr);
 }
 // the next row of a persistent workgroup of the dense paths, handed out by a counter (round 5).  A static deal — row b, b + grid, ... — left the slowest
 // workgroup of the numeric pass of A@A on R-MAT-18 at 1.48 x the mean (rows of 6 000 and of 3 000 000 products), and the launch ends with it.  The counter is
@@ -467,11 +476,11 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
         struct RProd { uint32_t col; T x; };
         uint32_t rbase = 0;
         auto rwalk = [&](uint32_t st, uint32_t len) __attribute__((always_inline)) -> uint32_t {
-          return spa_flat_walk<ORDERED>(st, len, s_exc, s_shift, s_wtot,
+          return spa_flat_walk2<ORDERED>(st, len, s_exc, s_shift, s_wtot,
             [&](uint32_t v, uint32_t pb) { RProd p; p.col = a.bcol[pb]; p.x = sr.mult(use_a ? s_av[v] : T(), use_b ? bval[pb] : T()); return p; },
-            [&](const RProd& p) { const uint32_t w = p.col >> 5; const uint32_t bits = s_bits[w];
-                                  const uint32_t rk = s_woff[w >> csh] + s_pre[w] + (uint32_t)__popc(bits & ((1u << (p.col & 31u)) - 1u)) - rbase;
-                                  word_combine<T>(sr.add_op(), &s_racc[rk], p.x); }, nullptr, &s_turn);
+            [&](const RProd& p) -> uint32_t { const uint32_t w = p.col >> 5; const uint32_t bits = s_bits[w];
+                                  return s_woff[w >> csh] + s_pre[w] + (uint32_t)__popc(bits & ((1u << (p.col & 31u)) - 1u)) - rbase; },
+            [&](const uint32_t rk, const RProd& p) { word_combine<T>(sr.add_op(), &s_racc[rk], p.x); }, nullptr, &s_turn);
         };
         // the entries of blocks [c0, c1): the threads walk their own bitmap words, the rank of a word's first bit is known — no scan, no barrier
         auto remit = [&](uint32_t c0, uint32_t c1) __attribute__((always_inline)) {
@@ -527,9 +536,10 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
     // one chunk of the row's entries (their A values in s_av) against block c (columns lo ...): returns the number of products
     struct Prod { uint32_t rel; T x; };
     auto walk = [&](uint32_t lo, uint32_t st, uint32_t len) __attribute__((always_inline)) -> uint32_t {
-      return spa_flat_walk<ORDERED>(st, len, s_exc, s_shift, s_wtot,
+      return spa_flat_walk2<ORDERED>(st, len, s_exc, s_shift, s_wtot,
         [&](uint32_t v, uint32_t pb) { Prod p; p.rel = a.bcol[pb] - lo; p.x = sr.mult(use_a ? s_av[v] : T(), use_b ? bval[pb] : T()); return p; },
-        [&](const Prod& p) { ((unsigned char*)s_flag)[p.rel] = 1; word_combine<T>(sr.add_op(), &s_acc[p.rel], p.x); }, pf, &s_turn);
+        [&](const Prod& p) -> uint32_t { ((unsigned char*)s_flag)[p.rel] = 1; return p.rel; },
+        [&](const uint32_t rel, const Prod& p) { word_combine<T>(sr.add_op(), &s_acc[rel], p.x); }, pf, &s_turn);
     };
     // emit the block in column order: every thread owns WD / 1024 columns; exclusive prefix of their counts, then every thread writes its own run —
     // four accumulators in flight.  (Round 4: 32 columns on half the threads, thread 0 adding up the wave sums between two barriers and a
