@@ -12,8 +12,10 @@
 //
 // Floating-point types only (their operators are plain C expressions — the definitions of grb_ops.hpp: fmin / fmax, IEEE division, 0 / 1 for the
 // comparisons); integer chains keep the interpreter, whose integer division and wrap-around rules live in grb_ops.hpp.  No hipRTC on the
-// machine, or a compile error: the interpreter runs, as before.  GRB_MI355X_CHAIN_JIT=0 turns it off, =2 compiles at the first sight and also
-// replaces the two ahead-of-time shapes (tests/test_nonblocking_gpu.py compares the three).
+// machine, or a compile error: the interpreter (or, for the two shapes of gap/prmark.py, the ahead-of-time kernel) runs, as before.  The two ahead-of-time
+// shapes are compiled like any other chain at their second appearance — the PageRank loop runs through the general mechanism, the k_vec_chain<..., SPEC>
+// kernels are what runs before that and without hipRTC.  GRB_MI355X_CHAIN_JIT=0 turns the compiler off, =2 compiles at the first sight, =3 keeps the
+// ahead-of-time shapes (round 4's behaviour; tests/test_nonblocking_gpu.py compares them).
 #include "grb_opcommon.hpp"
 #include "grb_lazy.hpp"
 #include <dlfcn.h>
@@ -167,7 +169,7 @@ std::string signature(const ChainLaunch& L, bool f32, int red) {
 // interpreter.  `grid` workgroups of 256 threads; `partial` receives the per-workgroup partials of a reduction.
 bool chain_jit_launch(const ChainLaunch& L, bool f32, int red, const void* rid, void* partial, unsigned grid, bool replaces_spec) {
   const int mode = jit_mode();
-  if (mode == 0 || (replaces_spec && mode != 2) || !L.nsteps || L.math) return false;
+  if (mode == 0 || (replaces_spec && mode == 3) || !L.nsteps || L.math) return false;
   std::lock_guard<std::mutex> lk(g_mu);
   const std::string key = signature(L, f32, red);
   Entry& en = g_cache[key];
