@@ -64,6 +64,7 @@ void mat_invalidate_host(GrB_Matrix A) {
   A->hi.shrink_to_fit(); A->hj.shrink_to_fit(); A->hx.shrink_to_fit();
   A->csc.clear(); A->csr.has_plan = false; A->csr.plan_blocks.reset(); A->csr.plan_aux.reset();
   A->csr.wp_rs.reset(); A->csr.wp_hot.reset(); A->csr.wp_pcol.reset(); A->csr.wp_tsize = 0; A->csr.xcd.reset();
+  A->csr.heads_valid = false; A->csr.range_state = 0;      // (the device copy was rewritten: whatever was derived from its values goes with the plans)
 }
 
 void mat_to_host(GrB_Matrix A) {
@@ -198,7 +199,7 @@ bool any_true_lookup(GrB_Vector u, bool* value) {
       s.owner = nullptr; s.fe_has = false;
       if (i < nb) { u->lor_state = 0; return false; }
       u->lor_state = cnt ? 3 : 2;
-      u->fe_lb = fe; u->fe_lb_key = s.fe_key;      // the edges leaving u's true entries (exact when the kernel counted: a lower bound is all the direction choice asks for)
+      u->fe_lb = fe; u->fe_lb_key = s.fe_key; u->fe_lb_true = true;      // the edges leaving u's true entries (exact when the kernel counted: a lower bound is all the direction choice asks for)
     } else {
       uint32_t* pin = (uint32_t*)pinned_scratch();
       GRB_HIP(hipMemcpyAsync(pin, s.word.p, 4, hipMemcpyDeviceToHost, stream()));
@@ -445,6 +446,7 @@ static GrB_Info mat_set(GrB_Matrix C, const void* x, int xcode, GrB_Index i, GrB
         GRB_HIP(hipMemcpyAsync((uint8_t*)C->csr.val.p + pos * C->type->size, pin, C->type->size, hipMemcpyHostToDevice, stream()));
         GRB_HIP(hipStreamSynchronize(stream()));
         C->csc.clear(); C->csr.xcd.reset(); C->csr.range_state = 0;
+        C->csr.heads_valid = false;      // the row heads carry the BOOL value of a row's first four entries
         return;
       }
     }

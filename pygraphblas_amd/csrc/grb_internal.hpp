@@ -160,7 +160,7 @@ struct GrB_Vector_opaque {
   // a lower bound of the edges that leave the vector's entries in one matrix (keyed by its row-pointer buffer), valid while entries are
   // only added (scalar assign under a mask without replace — the `v[q] = level` of a BFS loop): a masked product whose operand was
   // already too heavy for a push step needs no recount to stay a pull step.  A stale value can only cost speed, never correctness.
-  uint64_t fe_lb = 0; uint64_t fe_lb_key = 0;      // (key: the serial of the matrix's row-pointer allocation, 0 = none)
+  uint64_t fe_lb = 0; uint64_t fe_lb_key = 0; bool fe_lb_true = false;   // fe_lb_true: the bound counts the edges of the TRUE entries only (the product's summary), not of every present one      // (key: the serial of the matrix's row-pointer allocation, 0 = none)
   // ---- non-blocking state (grb_lazy.cpp; the library is initialised GrB_NONBLOCKING by the reference, pygraphblas/__init__.py:251-256) ----
   // lazy == 1: `w(:) = lazy_fill` over every index was requested and nothing has been written yet (no buffers): a product that
   //            accumulates into w with its monoid's operator folds the fill into its own store; anything else materialises it.

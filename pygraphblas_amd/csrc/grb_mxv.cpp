@@ -59,7 +59,7 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
     else if (!u->dnvals_known) {
       uint64_t cnt = 0;
       fe_cached = frontier_edges_and_count(u->dpres.as<uint8_t>(), P0.rowptr.as<uint32_t>(), u->n, &cnt);
-      u->dnvals = cnt; u->dnvals_known = true; u->fe_lb = fe_cached; u->fe_lb_key = P0.rowptr.serial;
+      u->dnvals = cnt; u->dnvals_known = true; u->fe_lb = fe_cached; u->fe_lb_key = P0.rowptr.serial; u->fe_lb_true = false;
     }
   }
   const uint64_t u_nvals = stays_pull && !u->dnvals_known ? (u->n ? u->n - 1 : 0) : vec_dev_nvals(u);             // (not counted: treated as "has holes")
@@ -83,7 +83,7 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
       const DevCSR& P = useT ? A->csr : mat_csc(A);
       const uint64_t fe = fe_cached != ~0ull ? fe_cached : frontier_edges(u->dpres.as<uint8_t>(), P.rowptr.as<uint32_t>(), u->n);
       push = fe * 16 < P.nnz + 16;
-      u->fe_lb = fe; u->fe_lb_key = P.rowptr.serial;                       // (exact now, a lower bound while entries are only added)
+      u->fe_lb = fe; u->fe_lb_key = P.rowptr.serial; u->fe_lb_true = false;                       // (exact now, a lower bound while entries are only added)
     }
   }
 
@@ -94,7 +94,9 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
     fused_mask = !push && !accum && dv.replace && type_size(u->type->code) == 1 && spmv_rowlane_applies(useT ? mat_csc(A) : A->csr, sd, method);
     // the first level of a BFS: the operand is a short list known on the host, it is also the (complemented) mask and every listed value is true — the
     // push kernels skip the listed positions themselves and multiply by `true`: no allow bytes, no BOOL copy of the operand (a pass over all positions)
-    excl_small = !fused_mask && push && tiny && dv.mask_comp && (dv.mask_struct || u->small_truthy) && u->small_truthy;
+    // (only for `w<!u, replace> = ...` without an accumulator, like the fused pull: with `allow == nullptr` the write-back makes w exactly T, which is
+    //  right only when the listed positions are to be deleted anyway and nothing of w's old content survives — ADVICE round 5)
+    excl_small = !fused_mask && push && tiny && !accum && dv.replace && dv.mask_comp && u->small_truthy;
     if (!fused_mask && !excl_small) {
       allow_buf.alloc(mr); ubool.alloc(mr + 1);
       build_allow_and_bool(mr, u->type->code, u->dval.p, u->dpres.as<uint8_t>(), dv.mask_struct, dv.mask_comp, allow_buf.as<uint8_t>(), ubool.as<uint8_t>());

@@ -123,7 +123,8 @@ static void vec_assign(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const 
       if (dv.replace) { w->fe_lb = 0; w->fe_lb_key = 0; }
       // the positions the mask allows are entries of w now: when the mask carries a bound of the edges leaving its TRUE entries (left by the
       // product that made it, any_true_lookup), w's entries include them — `v[q] = level`: the next product's direction choice needs no count
-      if (!dv.mask_comp && !dv.replace && mask->fe_lb_key && mask->fe_lb && mask->lazy == 0 && (w->fe_lb_key != mask->fe_lb_key || w->fe_lb < mask->fe_lb)) { w->fe_lb = mask->fe_lb; w->fe_lb_key = mask->fe_lb_key; }
+      // (a bound that counts every PRESENT entry of the mask says nothing about the positions a valued mask allows: ADVICE round 5)
+      if (!dv.mask_comp && !dv.replace && (dv.mask_struct || mask->fe_lb_true) && mask->fe_lb_key && mask->fe_lb && mask->lazy == 0 && (w->fe_lb_key != mask->fe_lb_key || w->fe_lb < mask->fe_lb)) { w->fe_lb = mask->fe_lb; w->fe_lb_key = mask->fe_lb_key; w->fe_lb_true = false; }
       w->dnvals_known = false; w->dnvals = 0;
       if (keep_list) { w->small_idx.swap(merged); w->small_valid = true; w->small_truthy = truthy; w->dnvals = w->small_idx.size(); w->dnvals_known = true; }
       return;
