@@ -51,6 +51,16 @@ def roof(alg_bytes, seconds, **extra):
     return r
 
 
+def first_run(cx, fn):
+    """(result, seconds) of the FIRST call of a workload on its freshly built operands — what a caller who runs it once pays (SURVEY.md 8d:
+    "additionally report end-to-end call time through the C ABI"): the cached transpose, row heads, kernel plans, row-binning buffers and the
+    pool's first allocations are all inside.  Device work is complete when the clock stops."""
+    cx.torch.cuda.synchronize(); cx.barrier(); t = time.perf_counter()
+    res = fn()
+    cx.torch.cuda.synchronize(); cx.barrier()
+    return res, cx.max_over_ranks(time.perf_counter() - t)
+
+
 def static_traffic(name):
     """HBM-side bytes per launch from the PMC passes of an earlier, separate run of the same workload (profiles/*.json)."""
     f = os.path.join(ROOT, "profiles", name)
@@ -242,6 +252,9 @@ def main():
             out["sssp"] = bench_sssp(cx, args.scale)
             torch.cuda.empty_cache()
             out["aa"] = bench_aa(cx, args.aa_scale)
+            torch.cuda.empty_cache()
+            out["aa_wide"] = bench_aa(cx, 20, edgefactor=4)       # 2^20 columns: four times what a row's bitmap + accumulators fit the LDS for (missing #3)
+            torch.cuda.empty_cache()
             out["bc"] = bench_bc(cx, args.scale)
             out["mxm_fp64_deterministic"] = bench_masked_fp64_deterministic(cx, args.scale)
 
@@ -440,7 +453,7 @@ def bench_triangles(cx, scale):
 
         def run():
             return cx.gdist.triangle_count(cx.comm, Lrows, L)
-    tri = run()                                                                  # first run: row binning buffers, pool warm-up
+    tri, first_s = first_run(cx, run)                                            # first run: row binning buffers, pool warm-up
     times = []
     for _ in range(5):
         cx.barrier(); t = time.perf_counter()
@@ -452,7 +465,8 @@ def bench_triangles(cx, scale):
     alg_bytes = 2 * (nnz * 4 + (n + 1) * 4) + (flops // 2) * 4 + nnz * 12
     traffic, traffic_source = static_traffic("spgemm_pmc_traffic.json") if (world == 1 and scale == 22) else (None, None)
     out = {"workload": f"triangle count R-MAT-{scale}: L.mxm(L, PLUS_PAIR, mask=L).reduce_int() (BASELINE.json configs[3])" + (f", rows of L and of the mask in {world} flop-balanced blocks, L replicated" if world > 1 else ""),
-           "nnz_L": nnz, "triangles": int(tri), "flops": flops, "seconds": round(best, 5), "GFLOPS": round(flops / best / 1e9, 1), "dtype": "int64",
+           "nnz_L": nnz, "triangles": int(tri), "flops": flops, "seconds": round(best, 5), "first_run_seconds": round(first_s, 5), "first_run_builds": "row-binning buffers, the result's allocations (pool misses)",
+           "GFLOPS": round(flops / best / 1e9, 1), "dtype": "int64",
            "roofline": roof(alg_bytes, best, traffic=traffic, traffic_source=traffic_source,
                             note="B-row entries are counted once per product although part of them is served by L2 / Infinity Cache; whole job (all ranks)"),
            "kernel": plan}
@@ -498,14 +512,15 @@ def bench_bfs(cx, scale):
 
         def run():
             return cx.gdist.bfs_levels(cx.comm, Arows, n, bounds, src)
-    run()                                                                        # first run builds the cached transpose / plans
+    _, first_s = first_run(cx, run)                                              # first run builds the cached transpose / row heads
     times = []
     for _ in range(7):
         cx.barrier(); t = time.perf_counter(); v, depth = run(); cx.barrier(); times.append(cx.max_over_ranks(time.perf_counter() - t))
     best = sorted(times)[len(times) // 2]                                        # the median run (round 3 reported the minimum)
     lev_mine, _ = v.to_dense_arrays()
     out = {"workload": f"BFS R-MAT-{scale} BOOL LOR_LAND, the reference's vxm loop (BASELINE.json configs[2])" + (f", {world} entry-balanced row blocks, bit frontier" if world > 1 else ""),
-           "nnz": nnz, "source": src, "depth": depth, "seconds": round(best, 5), "dtype": "bool"}
+           "nnz": nnz, "source": src, "depth": depth, "seconds": round(best, 7), "seconds_runs": [round(x, 7) for x in times], "first_run_seconds": round(first_s, 5),
+           "first_run_builds": "the transpose the pull levels read (cached with the matrix), the row heads of the masked pull, the loop's vectors (pool misses)", "dtype": "bool"}
     # parity and the rate need the whole level vector: every rank holds the graph, so the single-GPU loop gives it
     v1, d1 = single(record=True); lev, _ = v1.to_dense_arrays()
     if world > 1:
@@ -571,7 +586,7 @@ def bench_pagerank(cx, scale, bounds, iters, name):
 
         def run(fixed):
             return gdist.pagerank(cx.comm, Dm, Om, degrees(), n, bounds, fixed_iterations=fixed)
-    r3, _, _ = run(3)                                                                                 # plans, pool warm-up; and the state after 3 iterations for the parity leg
+    (r3, _, _), first_s = first_run(cx, lambda: run(3))                                               # plans, pool warm-up; and the state after 3 iterations for the parity leg
     r3 = r3.to_dense_arrays()[0] if world == 1 else None
     times = []
     for _ in range(5):
@@ -616,7 +631,8 @@ def bench_pagerank(cx, scale, bounds, iters, name):
                                 "sample": f"{reps} iterations of the same loop on the host: oracle fast_spmv_plus_second_fp32 (OpenMP, {O.num_threads()} threads) + numpy vector steps"}
         del rp, ci
     return {**side, "workload": f"PageRank R-MAT-{scale} FP32, gap/prmark.py loop (PLUS_SECOND, accum PLUS, w = t/d, |t-r| reduced) on {world} row block(s) (BASELINE.json configs[4])",
-            "dtype": "f32", "iterations_timed": its, "ms_per_iteration": round(sec / its * 1e3, 4), "ms_per_iteration_runs": [round(x / its * 1e3, 4) for x in times], "GFLOPS": round(2.0 * nnz_total * its / sec / 1e9, 1), "nnz": nnz_total,
+            "dtype": "f32", "iterations_timed": its, "ms_per_iteration": round(sec / its * 1e3, 4), "first_run_seconds": round(first_s, 5),
+            "first_run_builds": "three iterations on a fresh matrix: the transpose (desc T0 pulls along A'), kernel X's panel plan, the chains' code objects (hipRTC, first process only)", "ms_per_iteration_runs": [round(x / its * 1e3, 4) for x in times], "GFLOPS": round(2.0 * nnz_total * its / sec / 1e9, 1), "nnz": nnz_total,
             "iterations_to_converge": conv[1], "rdiff": float(conv[2]), "kernel": plan,
             "roofline": roof(alg, sec / its, note="per iteration on this rank: product nnz*4+(nrows+1)*4+ncols*4+nrows*4, plus 6 vector streams of 4 B per owned vertex (w = t/d; t = |t-r|) — what a fully fused iteration must move")}
 
@@ -633,7 +649,7 @@ def bench_sssp(cx, scale):
     deg = (rowptr[1:] - rowptr[:-1])
     src = int(torch.argmax(deg))
     plans = []
-    cx.loops.sssp(A, src)                                                         # cached transpose, plans
+    _, first_s = first_run(cx, lambda: cx.loops.sssp(A, src))                     # cached transpose, plans
     times = []
     for _ in range(5):
         del plans[:]
@@ -651,7 +667,9 @@ def bench_sssp(cx, scale):
     cx.loops.sssp(A, src, before_sweep=account)                                   # (untimed pass)
     alg = acc[0]
     out = {"workload": f"SSSP R-MAT-{scale} INT64 MIN_PLUS: v<accum MIN> = v MIN_PLUS A until nothing changes (demo/Intro-Prez.ipynb:1034-1045)", "nnz": nnz, "source": src,
-           "sweeps": sweeps, "reached": int((gp != 0).sum()), "seconds": round(best, 5), "ms_per_sweep": round(best / sweeps * 1e3, 3), "dtype": "int64", "kernels_per_sweep": list(plans),
+           "sweeps": sweeps, "reached": int((gp != 0).sum()), "seconds": round(best, 5), "first_run_seconds": round(first_s, 5),
+           "first_run_builds": "the transpose (vxm pulls along A'), the value range of A, kernel W's then kernel X's plan of the transpose, the chains' code objects",
+           "ms_per_sweep": round(best / sweeps * 1e3, 3), "dtype": "int64", "kernels_per_sweep": list(plans),
            "roofline": roof(alg, best, note="sum over sweeps of E_s*12 + V_s*8 (edges leaving / entries of the operand) + 6 vector streams of 9 B per vertex (output read + write, dup, iseq)")}
     if not cx.args.no_cpu_baseline:
         from oracle import oracle as O
@@ -664,19 +682,19 @@ def bench_sssp(cx, scale):
     return out
 
 
-def bench_aa(cx, scale=18):
+def bench_aa(cx, scale=18, edgefactor=16):
     """The north star's general SpGEMM: the UNMASKED A @ A (lib.GrB_mxm with mask = NULL, pygraphblas/matrix.py:2572-2583) on the symmetric
     R-MAT-`scale`, FP64 PLUS_TIMES, through the two-pass (symbolic + numeric) LDS-hash Gustavson of grb_spgemm_hash.hpp.  Median of five runs;
     sampled rows of the result (every numeric bin, the hub rows) against the oracle's Gustavson rows; the oracle's rows timed as the CPU baseline."""
     gb, rmat, torch, dev, np, lib = cx.gb, cx.rmat, cx.torch, cx.dev, cx.np, cx.lib
     n = 1 << scale
-    rowptr, col = rmat.csr_torch(scale, dev, seed=42, symmetric=True, drop_self_loops=True)
+    rowptr, col = rmat.csr_torch(scale, dev, seed=42, edgefactor=edgefactor, symmetric=True, drop_self_loops=True)
     nnz = int(col.numel())
     vals = rmat.values_torch(nnz, dev, seed=45).to(torch.float64) + 0.5
     A = gb.Matrix.from_csr(gb.FP64, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
     dA = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
     products = int(dA[col.to(torch.int64) & 0xFFFFFFFF].sum())
-    Cm = A.mxm(A, semiring=gb.FP64.PLUS_TIMES)                                   # first run: the result's 35 GB come from hipMalloc, later ones from the pool
+    Cm, first_s = first_run(cx, lambda: A.mxm(A, semiring=gb.FP64.PLUS_TIMES))   # first run: the result's 35 GB come from hipMalloc, later ones from the pool
     times = []
     for _ in range(5):
         Cm = None
@@ -688,8 +706,10 @@ def bench_aa(cx, scale=18):
     nc = Cm.nvals
     # SURVEY.md 8d, unmasked form: A once (12 B per entry + row pointers), one B-row entry (column + FP64 value) per product, C written
     alg = nnz * 12 + (n + 1) * 4 + products * 12 + nc * 12 + (n + 1) * 4
-    out = {"workload": f"A @ A (unmasked GrB_mxm, two-pass LDS-hash Gustavson) R-MAT-{scale} symmetric FP64 PLUS_TIMES", "n": n, "nnz_A": nnz, "products": products, "nnz_C": nc,
-           "seconds": round(sec, 5), "seconds_runs": [round(x, 5) for x in times], "GFLOPS": round(2.0 * products / sec / 1e9, 1), "dtype": "f64", "kernel": plan,
+    out = {"workload": f"A @ A (unmasked GrB_mxm, two-pass LDS-hash Gustavson) R-MAT-{scale} (edge factor {edgefactor}) symmetric FP64 PLUS_TIMES", "n": n, "nnz_A": nnz, "products": products, "nnz_C": nc,
+           "seconds": round(sec, 5), "seconds_runs": [round(x, 5) for x in times], "first_run_seconds": round(first_s, 5),
+           "first_run_builds": "the result's arrays and the symbolic pass's temporaries straight from hipMalloc (later runs: the pool)",
+           "GFLOPS": round(2.0 * products / sec / 1e9, 1), "dtype": "f64", "kernel": plan,
            "roofline": roof(alg, sec, note="nnz(A)*12 + products*12 (B-row entries, column + value, counted once per product) + nnz(C)*12 + 2*(n+1)*4")}
     if not cx.args.no_cpu_baseline:
         from oracle import oracle as O
@@ -786,7 +806,7 @@ def bench_bc(cx, scale):
     AT = A.transpose()
     deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
     sources = [int(x) for x in torch.argsort(deg, descending=True, stable=True)[:ns].cpu()]
-    bc_full(gb, sources, AT, A)                                                  # cached transposes, pool
+    _, first_s = first_run(cx, lambda: bc_full(gb, sources, AT, A))               # cached transposes, pool
     times = []; sizes = []
     for _ in range(5):
         del sizes[:]
@@ -818,7 +838,9 @@ def bench_bc(cx, scale):
         reached[s] = len(hit); edges[s] = int(degh[hit].sum())
     alg = int(2 * edges.sum() * 4 + 2 * reached.sum() * 16 + n * 4)
     out = {"workload": f"batched betweenness centrality, gap/bcmark.py:16-67, R-MAT-{scale} directed, ns = {ns} sources of maximum degree, FP32 (masked PLUS_FIRST GrB_mxm per level)",
-           "nnz": nnz, "depth": depth, "frontier_nvals": list(sizes), "seconds": round(sec, 5), "seconds_runs": [round(x, 5) for x in times], "dtype": "f32",
+           "nnz": nnz, "depth": depth, "frontier_nvals": list(sizes), "seconds": round(sec, 5), "seconds_runs": [round(x, 5) for x in times], "first_run_seconds": round(first_s, 5),
+           "first_run_builds": "the transposes the pull levels read, row heads, the dense ns x n batches (pool misses)", "dtype": "f32",
+           "parity_tolerance_note": "centrality rtol 1e-4: FP32 sums of the driver against an FP64 restatement (north star's 1e-6 holds for FP64 / FP32 products against same-precision references; here the reference is wider)",
            "forward_products_ms": [round(x * 1e3, 3) for x in step_s], "kernel": plan,
            "roofline": roof(alg, sec, note="lower bound of any implementation: per source, forward and backward sweep each read the edges of the reached vertices once (4 B) and "
                                            "their path counts / dependencies (2 x 8 B); centrality written once.  The driver's own formulation moves ns x n dense batches per level on top")}

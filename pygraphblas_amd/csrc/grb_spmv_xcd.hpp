@@ -70,8 +70,16 @@ struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per 
   // (an entry the table serves is now bound to its column's sub-panel as well).
   int S = 1, NP = XP, NS = XP; bool own = false;
   DevBuf vfirst;          // u32[NP + 1] first sub-row of every virtual panel (sub-rows are numbered in stream order)
+  // round 6: the lane-per-piece layout of the same streams (grb_spmv_sell.hpp): steps of 64 column words / values, the partial id of every chunk lane,
+  // the work items, the streams' argument block
+  DevBuf s_col, s_val, s_perm, s_items, s_args; bool sell = false; uint64_t s_nsteps = 0; uint32_t s_nchunks = 0, s_nitems = 0;
 };
 extern float g_xcd_plan_build_ms;     // duration of the most recent plan build (grb_spmv.hip; read by GrBX_last_plan_build_ms)
+}  // namespace grb
+#include "grb_spmv_sell.hpp"
+namespace grb {
+// does the plan of a matrix of this value type carry the lane-per-piece layout?  (GRB_MI355X_SELL=0: the tile pipeline only)
+template <class T> inline bool xp_sell_wanted() { return (sizeof(T) == 4 || sizeof(T) == 8) && wp_env("GRB_MI355X_SELL", 0) != 0; }
 
 // ---- plan pieces ----------------------------------------------------------------------------------------------------------
 // column counts = run lengths of the sorted column array.  (Counting with atomics — LDS-aggregated per workgroup, the rest
@@ -801,6 +809,9 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
   auto* P = new XcdPlan(); M.xcd.reset(P);
   const uint32_t n = M.ncols; const uint64_t nnz = M.nnz;
   constexpr uint32_t H = xt_hot<T>::H;
+  const bool sell = xp_sell_wanted<T>();
+  // columns a table serves: the lane-per-piece kernel wants the table's last slot free (it holds zero bits: what a cold entry "reads" there)
+  const uint32_t HOT = sell && (uint32_t)xt_hot<T>::HOT == H ? H - 1 : (uint32_t)xt_hot<T>::HOT;
   bool forced = false;
   int S = force_S ? force_S : xp_subpanels<T>(n, &forced);
   // 1. column counts; the 128-byte lines of u dealt to the (virtual) panels (equal entry counts); every stream's columns ranked by frequency
@@ -849,11 +860,11 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
     GRB_HIP(hipMemsetAsync(cstart.p, 0xFF, (XPMAX + 1) * 4, stream()));
     hipLaunchKernelGGL(k_xp_panel_starts, dim3(grid_n(n)), dim3(256), 0, stream(), k32o.as<uint32_t>(), n, cstart.as<uint32_t>());
     hipLaunchKernelGGL(k_xp_fix_starts, dim3(1), dim3(1), 0, stream(), cstart.as<uint32_t>(), n, NS);
-    hipLaunchKernelGGL(k_xp_column_codes, dim3(grid_n(n)), dim3(256), 0, stream(), k32o.as<uint32_t>(), cout.as<uint32_t>(), n, H, (uint32_t)xt_hot<T>::HOT, cstart.as<uint32_t>(), code.as<uint32_t>(), P->hot_cols.as<uint32_t>());
+    hipLaunchKernelGGL(k_xp_column_codes, dim3(grid_n(n)), dim3(256), 0, stream(), k32o.as<uint32_t>(), cout.as<uint32_t>(), n, H, HOT, cstart.as<uint32_t>(), code.as<uint32_t>(), P->hot_cols.as<uint32_t>());
     if (wp_env("GRB_MI355X_XHOT_BY_COLUMN", 1) != 0) {
       const uint64_t tot = (uint64_t)NS * H;
       DevBuf k64(tot * 8 + 8), k64o(tot * 8 + 8), v32(tot * 4 + 4), v32o(tot * 4 + 4);
-      hipLaunchKernelGGL(k_xp_hot_keys, dim3(grid_n(tot)), dim3(256), 0, stream(), P->hot_cols.as<uint32_t>(), cstart.as<uint32_t>(), NS, (uint32_t)H, (uint32_t)xt_hot<T>::HOT, (unsigned long long*)k64.p, v32.as<uint32_t>());
+      hipLaunchKernelGGL(k_xp_hot_keys, dim3(grid_n(tot)), dim3(256), 0, stream(), P->hot_cols.as<uint32_t>(), cstart.as<uint32_t>(), NS, (uint32_t)H, HOT, (unsigned long long*)k64.p, v32.as<uint32_t>());
       sort_pairs_u64((const uint64_t*)k64.p, (uint64_t*)k64o.p, v32.as<uint32_t>(), v32o.as<uint32_t>(), tot, 32 + 7);
       hipLaunchKernelGGL(k_xp_hot_reslot, dim3(grid_n(tot)), dim3(256), 0, stream(), (const unsigned long long*)k64o.p, NS, (uint32_t)H, code.as<uint32_t>(), P->hot_cols.as<uint32_t>());
     }
@@ -894,7 +905,7 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
     P->ne[k] = hp[(k + 1) * vps] - hp[k * vps];                          // a stream = its virtual panels, one after the other
     P->ntiles[k] = (uint32_t)((P->ne[k] + WP_ENT - 1) / WP_ENT);
     P->tbase[k + 1] = P->tbase[k] + P->ntiles[k];
-    const uint32_t nk = hp[XPMAX + 1 + k + 1] - hp[XPMAX + 1 + k]; P->nhot[k] = nk < (uint32_t)xt_hot<T>::HOT ? nk : (uint32_t)xt_hot<T>::HOT;
+    const uint32_t nk = hp[XPMAX + 1 + k + 1] - hp[XPMAX + 1 + k]; P->nhot[k] = nk < HOT ? nk : HOT;
     kt[k] = wp_chunk_tasks(P->ntiles[k], wpp);
     nchunks_total += (P->ntiles[k] + kt[k] - 1) / kt[k];
     for (uint32_t sp = 0; sp < vps; sp++) {
@@ -913,6 +924,23 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
   GRB_HIP(hipMemsetAsync(P->pcol.p, 0, nstore * 4, stream()));
   sw.pcol = P->pcol.as<uint32_t>(); sw.pval = with_vals ? P->pval.as<T>() : nullptr; sw.rowtmp = rowtmp.as<uint32_t>();
   hipLaunchKernelGGL((k_xp_sweep<T, true>), dim3(nunits), dim3(XP_ST), 0, stream(), sw);
+  // 4b. (lane-per-piece layout) the sub-rows cut into pieces of <= SELL_CAP entries / wave slices: more row-start flags, before anything is numbered
+  SellStreams sst{}; sst.ns = NS;
+  for (uint32_t k = 0; k <= NS; k++) sst.tbase[k] = P->tbase[k];
+  for (uint32_t k = 0; k < NS; k++) sst.ne[k] = P->ne[k];
+  const unsigned tile_grid = [&] { unsigned nb = (ntiles + 3) / 4; if (nb < 1) nb = 1; if (nb > 16384) nb = 16384; return nb; }();
+  if (sell) {
+    DevBuf tf0(((size_t)ntiles + 1) * 4), E0(((size_t)ntiles + 1) * 4);
+    GRB_HIP(hipMemsetAsync(tf0.as<uint32_t>() + ntiles, 0, 4, stream()));
+    hipLaunchKernelGGL(k_xp_tile_flags, dim3(tile_grid), dim3(256), 0, stream(), P->pcol.as<uint32_t>(), ntiles, tf0.as<uint32_t>());
+    exclusive_scan_u32(tf0.as<uint32_t>(), E0.as<uint32_t>(), (uint64_t)ntiles + 1);
+    uint32_t F0 = 0;
+    GRB_HIP(hipMemcpyAsync(&F0, E0.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+    DevBuf ps0((size_t)F0 * 4 + 8), pl0((size_t)F0 * 4 + 8);
+    hipLaunchKernelGGL(k_sell_pstart, dim3(tile_grid), dim3(256), 0, stream(), P->pcol.as<uint32_t>(), E0.as<uint32_t>(), ntiles, ps0.as<uint32_t>());
+    hipLaunchKernelGGL(k_sell_plen, dim3(grid_n(F0)), dim3(256), 0, stream(), ps0.as<uint32_t>(), (uint64_t)F0, sst, pl0.as<uint32_t>());
+    hipLaunchKernelGGL(k_sell_cap, dim3(tile_grid), dim3(256), 0, stream(), P->pcol.as<uint32_t>(), rowtmp.as<uint32_t>(), E0.as<uint32_t>(), ps0.as<uint32_t>(), pl0.as<uint32_t>(), sst, ntiles);
+  }
   // 5. sub-rows: starts per tile, scan, the total (second host round trip), then their numbering
   DevBuf tflags(((size_t)ntiles + 1) * 4), E(((size_t)ntiles + 1) * 4);
   GRB_HIP(hipMemsetAsync(tflags.as<uint32_t>() + ntiles, 0, 4, stream()));
@@ -979,6 +1007,60 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
     build_xcd_plan<T>(M, ncu, with_vals, 1);
     return;
   }
+  // 6b'. the lane-per-piece layout (grb_spmv_sell.hpp): pieces sorted by length inside windows, dealt to chunks of 64 lanes, entries scattered to
+  //      (chunk, step, lane); two host round trips (the groups' sizes, the streams' step counts)
+  uint32_t sell_hs[XPMAX + 2] = {0}, sell_ib[XPMAX + 1] = {0};      // first step / first work item of every stream
+  if (sell && P->m_ok && P->F < 0xFFFFFF00ull && ntiles) {
+    const uint64_t F = P->F;
+    DevBuf pstart(F * 4 + 8), plen(F * 4 + 8), key(F * 8 + 8), keyo(F * 8 + 8), id0(F * 4 + 8), sorted(F * 4 + 8), inv(F * 4 + 8), gstart((2 * XPMAX + 2) * 4);
+    hipLaunchKernelGGL(k_sell_pstart, dim3(tile_grid), dim3(256), 0, stream(), P->pcol.as<uint32_t>(), E.as<uint32_t>(), ntiles, pstart.as<uint32_t>());
+    hipLaunchKernelGGL(k_sell_plen, dim3(grid_n(F)), dim3(256), 0, stream(), pstart.as<uint32_t>(), F, sst, plen.as<uint32_t>());
+    hipLaunchKernelGGL(k_sell_keys, dim3(grid_n(F)), dim3(256), 0, stream(), pstart.as<uint32_t>(), plen.as<uint32_t>(), F, sst, P->vfirst.as<uint32_t>(), vps, (unsigned long long*)key.p, id0.as<uint32_t>());
+    sort_pairs_u64((const uint64_t*)key.p, (uint64_t*)keyo.p, id0.as<uint32_t>(), sorted.as<uint32_t>(), F, 47);
+    GRB_HIP(hipMemsetAsync(gstart.p, 0xFF, (2 * XPMAX + 2) * 4, stream()));
+    hipLaunchKernelGGL(k_sell_groups, dim3(grid_n(F)), dim3(256), 0, stream(), (const unsigned long long*)keyo.p, F, gstart.as<uint32_t>());
+    hipLaunchKernelGGL(k_xp_fix_starts, dim3(1), dim3(1), 0, stream(), gstart.as<uint32_t>(), (uint32_t)F, 2 * NS);
+    uint32_t hg[2 * XPMAX + 2];
+    GRB_HIP(hipMemcpyAsync(hg, gstart.p, (2 * NS + 1) * 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+    SellGroups gr{}; gr.ns = NS; uint32_t nchunks = 0;
+    for (uint32_t k = 0; k < NS; k++) {
+      gr.g1[k] = hg[2 * k]; gr.g0[k] = hg[2 * k + 1]; gr.gend[k] = hg[2 * k + 2];
+      gr.nc1[k] = (gr.g0[k] - gr.g1[k] + 63u) / 64u; gr.cbase[k] = nchunks; nchunks += gr.nc1[k] + (gr.gend[k] - gr.g0[k]);
+    }
+    gr.cbase[NS] = nchunks;
+    DevBuf lc(((size_t)nchunks + 1) * 4), cstep(((size_t)nchunks + 1) * 4), pk((XPMAX + 2) * 4);
+    GRB_HIP(hipMemsetAsync(lc.as<uint32_t>() + nchunks, 0, 4, stream()));
+    { unsigned nb = (nchunks + 3) / 4; if (nb < 1) nb = 1; if (nb > 16384) nb = 16384;
+      hipLaunchKernelGGL(k_sell_lc, dim3(nb), dim3(256), 0, stream(), sorted.as<uint32_t>(), plen.as<uint32_t>(), gr, nchunks, lc.as<uint32_t>()); }
+    exclusive_scan_u32(lc.as<uint32_t>(), cstep.as<uint32_t>(), (uint64_t)nchunks + 1);
+    hipLaunchKernelGGL(k_sell_pick, dim3(1), dim3(128), 0, stream(), cstep.as<uint32_t>(), gr, pk.as<uint32_t>());
+    uint32_t hs[XPMAX + 2];
+    GRB_HIP(hipMemcpyAsync(hs, pk.p, (NS + 1) * 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+    const uint64_t nsteps = hs[NS];
+    if (nsteps && nsteps * 256ull < (1ull << 40)) {
+      P->s_nsteps = nsteps; P->s_nchunks = nchunks;
+      P->s_col.alloc(nsteps * 256 + 64); P->s_perm.alloc((size_t)nchunks * 256 + 64);
+      GRB_HIP(hipMemsetAsync(P->s_col.p, 0, nsteps * 256 + 64, stream())); GRB_HIP(hipMemsetAsync(P->s_perm.p, 0xFF, (size_t)nchunks * 256 + 64, stream()));
+      if (with_vals) { P->s_val.alloc(nsteps * 64 * sizeof(T) + 64); GRB_HIP(hipMemsetAsync(P->s_val.p, 0, nsteps * 64 * sizeof(T) + 64, stream())); }
+      hipLaunchKernelGGL(k_sell_inv, dim3(grid_n(F)), dim3(256), 0, stream(), sorted.as<uint32_t>(), F, inv.as<uint32_t>());
+      hipLaunchKernelGGL((k_sell_scatter<T>), dim3(tile_grid), dim3(256), 0, stream(), P->pcol.as<uint32_t>(), with_vals ? P->pval.as<T>() : (const T*)nullptr, E.as<uint32_t>(), pstart.as<uint32_t>(),
+                         inv.as<uint32_t>(), lc.as<uint32_t>(), cstep.as<uint32_t>(), sst, gr, ntiles, P->s_col.as<uint32_t>(), with_vals ? P->s_val.as<T>() : (T*)nullptr, P->s_perm.as<uint32_t>());
+      { unsigned nb = (nchunks + 3) / 4; if (nb < 1) nb = 1; if (nb > 16384) nb = 16384;
+        hipLaunchKernelGGL(k_sell_meta, dim3(nb), dim3(256), 0, stream(), P->s_col.as<uint32_t>(), lc.as<uint32_t>(), cstep.as<uint32_t>(), gr, nchunks); }
+      uint32_t ibase[XPMAX + 1], nitems = 0;
+      for (uint32_t k = 0; k < NS; k++) { ibase[k] = nitems; nitems += (hs[k + 1] - hs[k] + SELL_ITEM - 1) / SELL_ITEM; }
+      ibase[NS] = nitems; P->s_nitems = nitems;
+      DevBuf dib((XPMAX + 1) * 4);
+      GRB_HIP(hipMemcpyAsync(dib.p, ibase, (NS + 1) * 4, hipMemcpyHostToDevice, stream()));
+      P->s_items.alloc(((size_t)nitems + 2) * 4);
+      hipLaunchKernelGGL(k_sell_items, dim3(grid_n((uint64_t)nitems + 1)), dim3(256), 0, stream(), cstep.as<uint32_t>(), gr, dib.as<uint32_t>(), nitems, (uint32_t)nsteps, P->s_items.as<uint32_t>());
+      memcpy(sell_hs, hs, sizeof(uint32_t) * (NS + 1)); memcpy(sell_ib, ibase, sizeof(uint32_t) * (NS + 1));
+      GRB_HIP(hipStreamSynchronize(stream()));      // (ibase lives on this frame)
+      P->sell = true;
+      if (getenv("GRB_MI355X_VERBOSE")) fprintf(stderr, "[grb] lane-per-piece layout: %llu pieces in %u chunks, %llu steps = %.3f x the entries, %u work items\n", (unsigned long long)F, nchunks,
+                                                (unsigned long long)nsteps, (double)nsteps * 64.0 / (double)nnz, nitems);
+    }
+  }
   // 6c. the 16-bit column plane (fourth host round trip: the number of cold entries); the 32-bit words are dropped
   constexpr bool c16 = xt_fmt<T>::C16;
   const bool keep32 = !c16 || wp_env("GRB_MI355X_XT_KEEP32", 0) != 0;
@@ -1024,6 +1106,18 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
       fprintf(stderr, "[grb] xcd plan stream %u: entries %llu tiles %u chunk %u hot %u (sub-rows in all %llu, chunks %llu, sub-panels per XCD %d, %s)\n", k, (unsigned long long)P->ne[k], P->ntiles[k], kt[k],
               P->nhot[k], (unsigned long long)P->F, (unsigned long long)nchunks_total, S, own ? "a table per sub-panel" : "a table per XCD");
   GRB_HIP(hipMemcpyAsync(P->args.p, ha, sizeof(ha), hipMemcpyHostToDevice, stream()));
+  SellPanel<T> sa[XPMAX]; memset((void*)sa, 0, sizeof(sa));
+  if (P->sell) {
+    for (uint32_t k = 0; k < NS; k++) {
+      SellPanel<T>& a = sa[k];
+      a.scol = P->s_col.as<uint32_t>() + (size_t)sell_hs[k] * 64; a.sval = with_vals ? P->s_val.as<T>() + (size_t)sell_hs[k] * 64 : nullptr;
+      a.item_first = P->s_items.as<uint32_t>() + sell_ib[k]; a.step0 = sell_hs[k]; a.nsteps = sell_hs[k + 1] - sell_hs[k]; a.nitems = sell_ib[k + 1] - sell_ib[k];
+      a.xhot = P->xhot.as<T>() + (size_t)k * H; a.nhot = P->nhot[k];
+      a.static_pct = wp_env("GRB_MI355X_WP_STATIC", WP_STATIC_PCT); a.interleave = wp_env("GRB_MI355X_XT_INTERLEAVE", vps > 1 ? 1u : 0u);
+    }
+    P->s_args.alloc(sizeof(sa));
+    GRB_HIP(hipMemcpyAsync(P->s_args.p, sa, sizeof(sa), hipMemcpyHostToDevice, stream()));      // (the stream is synchronised below, before this frame goes)
+  }
   P->tsize = (int)sizeof(T); P->has_vals = with_vals;
   GRB_HIP(hipEventRecord(ev1, stream()));
   GRB_HIP(hipStreamSynchronize(stream()));
@@ -1057,6 +1151,13 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
 #undef XT_TRY
     }
 #endif
+    if constexpr (sizeof(T) == 4 || sizeof(T) == 8) {
+      const bool sell_off = wp_env("GRB_MI355X_SELL_RUN", 1) == 0;            // measurement hook: the tile pipeline on a plan that carries both layouts
+      if (!launched && P->sell && !sell_off) {
+        hipLaunchKernelGGL((k_spmv_sell<T, SR>), dim3(ncu), dim3(XT_WAVES * 64), 0, stream(), call, (const SellPanel<T>*)P->s_args.p, P->s_perm.as<uint32_t>(), P->s_nchunks, sr);
+        launched = true;
+      }
+    }
     if (!launched) hipLaunchKernelGGL((k_spmv_tiles<T, SR>), dim3(ncu), dim3(XT_WAVES * 64), 0, stream(), call, (const XtPanel<T>*)P->args.p, sr);
     const uint32_t nblocks = (uint32_t)(((uint64_t)M.nrows + XP_RB - 1) / XP_RB);
     static const bool old_merge = wp_env("GRB_MI355X_XP_OLD_MERGE", 0) != 0;       // measurement hook: the per-panel merge kernel
@@ -1086,7 +1187,7 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
     } else
       hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3(nblocks), dim3(XP_CT), 0, stream(), M.nrows, P->blockptr.as<uint32_t>(), P->lrow.as<uint16_t>(), P->partial.as<T>(),
                          (T*)c.tval, c.tpres, sr);
-    g_last_plan += std::string("k_spmv_xcd<") + (sr.is_static ? "static" : "dynamic") + ",subrows=" + std::to_string(P->F) + (P->S > 1 ? ",subpanels=" + std::to_string(P->S) + (P->own ? "/own-tables" : "") : std::string()) + "," + xcd_mapping() + "> ";
+    g_last_plan += std::string("k_spmv_xcd<") + (sr.is_static ? "static" : "dynamic") + (P->sell ? ",lane-per-piece" : "") + ",subrows=" + std::to_string(P->F) + (P->S > 1 ? ",subpanels=" + std::to_string(P->S) + (P->own ? "/own-tables" : "") : std::string()) + "," + xcd_mapping() + "> ";
   });
   return true;
 }

@@ -144,12 +144,21 @@ def test_four_ranks_on_one_gpu_through_the_library_exchange_path(gb, gpu):
         assert res[r]["transport"].endswith("libfake_rccl.so"), res[r]["transport"]
 
 
+def test_eight_ranks_on_one_gpu_through_the_library_exchange_path(gb, gpu):
+    """World size 8 — the first real multi-GPU run will be the driver's N = 8 — at small scale: seven peers per rank in one send / receive group, eight
+    slices of the bit frontier, an eight-way all-reduce, eight entry-balanced row blocks of a skewed graph (the first block holds a handful of hub rows)."""
+    _ensure_fake_rccl()
+    res = _two_ranks(gb, "rccl", world=8)
+    for r in range(8):
+        assert res[r]["transport"].endswith("libfake_rccl.so"), res[r]["transport"]
+
+
 def _two_ranks(gb, transport, world=2):
     import torch.multiprocessing as mp
     ref = _single_process_reference(gb)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 2000) + (11 if transport == "rccl" else 0) + (5 if world != 2 else 0)
+    port = 29600 + (os.getpid() % 2000) + (11 if transport == "rccl" else 0) + 3 * (world - 2)
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, transport)) for r in range(world)]
     for p in procs:
         p.start()

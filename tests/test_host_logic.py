@@ -226,6 +226,44 @@ def test_dist_partition_helpers_on_cpu():
     assert (M.T != Mt).nnz == 0
 
 
+def test_pagerank_partition_of_an_rmat25_shaped_run_on_eight_ranks():
+    """BASELINE.json configs[4] as the driver's N = 8 run cuts it (bench.py: `balanced_row_blocks(rmat_expected_row_prefix(25), 8)`), on the CPU and
+    without generating 5.3e8 edges: the bounds every rank derives are identical and monotone, the EXPECTED entries per rank are within 2 % of
+    one eighth (R-MAT's skew is in the row labels: equal row COUNTS would give the first rank 3.2 x the average), a rank's share fits its GPU many times
+    over, and at a scale small enough to build (R-MAT-16, the same generator) the actual entries follow the expected split and the diagonal /
+    off-diagonal split of every block adds up to the block."""
+    import torch
+    from pygraphblas_amd import rmat, dist as gdist
+    world = 8
+    prefix = gdist.rmat_expected_row_prefix(25)
+    bounds = gdist.balanced_row_blocks(prefix, world)
+    assert bounds == gdist.balanced_row_blocks(gdist.rmat_expected_row_prefix(25), world)           # every rank computes the same cut
+    assert bounds[0] == 0 and bounds[-1] == 1 << 25 and all(a < b for a, b in zip(bounds, bounds[1:]))
+    share = np.diff(prefix[bounds].astype(np.float64)) / float(prefix[-1])
+    assert np.all(np.abs(share * world - 1.0) < 0.02), share
+    rows = np.diff(np.array(bounds)); assert rows.max() > 2.5 * rows.min()                          # balanced by entries, not by rows
+    nnz_total = 5.3e8                                                                                # distinct entries of R-MAT-25 (measured: 5.29e8)
+    # bytes a rank holds: its rows of A' twice (diagonal + off-diagonal CSR, 4 B columns), kernel X's panel-major copy (4 B words), the operand and a few vectors
+    per_rank = share.max() * nnz_total * (4 + 4 + 4) + 4 * (1 << 25) * 6
+    assert per_rank < 0.05 * 288e9, per_rank
+    # the same cut on a graph that can be built here
+    scale = 16; n = 1 << scale
+    b16 = gdist.balanced_row_blocks(gdist.rmat_expected_row_prefix(scale), world)
+    rpt, ct = rmat.csr_numpy(scale, transpose=True)
+    actual = np.diff(rpt.astype(np.int64)[b16]) / float(len(ct))
+    assert np.all(np.abs(actual * world - 1.0) < 0.25), actual                                       # the transpose's rows (in-degrees) follow the same label skew
+    seen = 0
+    for r in range(world):
+        r0, r1 = b16[r], b16[r + 1]
+        rp, col = rmat.csr_numpy(scale, transpose=True, row_range=(r0, r1))
+        (rpd, cd, _), (rpo, co, _) = gdist.split_csr_columns(torch.from_numpy(rp.view(np.int32)), torch.from_numpy(col.view(np.int32)), r0, r1)
+        cdn, con = cd.numpy().view(np.uint32), co.numpy().view(np.uint32)
+        assert len(cdn) + len(con) == len(col) and ((cdn >= r0) & (cdn < r1)).all() and ((con < r0) | (con >= r1)).all()
+        assert int(rpd[-1]) == len(cdn) and int(rpo[-1]) == len(con)
+        seen += len(col)
+    assert seen == len(ct)
+
+
 def test_grb_binary_reader_against_the_references_fixture(tmp_path):
     """Matrix.binread on the reference's docs/test_binfile.grb (copied byte for byte to tests/golden/) gives the matrix of
     docs/test_mm.mm:1-15 (7x7 INT64, 12 entries with values 0..11, transcribed below 0-based); binwrite round-trips."""

@@ -423,15 +423,18 @@ def stratified_rows(lens, k_even, k_top, k_random, rng):
     return np.array(sorted(pick), dtype=np.uint32)
 
 
-def test_unmasked_product_rmat18_sampled_rows_against_the_oracle(gpu, monkeypatch):
+@pytest.mark.parametrize("S,edgefactor", [(18, 16), (20, 4)])
+def test_unmasked_product_rmat18_sampled_rows_against_the_oracle(gpu, monkeypatch, S, edgefactor):
     """A @ A on the symmetric R-MAT-18 at the size it is timed (9.5e9 products, 3.0e9 entries; lib.GrB_mxm with mask = NULL,
     pygraphblas/matrix.py:2572-2583), checked against the ORACLE on > 2 000 sampled rows: rows spread evenly over the order of the result
     rows' lengths (every numeric bin of grb_spgemm_hash.hpp: the 256 / 2048 / 8192-slot tables and the dense-accumulator path that
-    carries nearly all products), the 64 longest rows (hubs) and random ones — pattern exact, values to 1e-6 relative (north_star)."""
+    carries nearly all products), the 64 longest rows (hubs) and random ones — pattern exact, values to 1e-6 relative (north_star).
+    Round 6: also at 2^20 columns (R-MAT-20 with edge factor 4: 6.0e9 products, 3.4e9 entries) — beyond what one row's bitmap can share
+    the LDS with its accumulators, i.e. the size at which round 5's ranked rows were NOT taken (missing #3)."""
     import torch
     dev = torch.device("cuda", 0)
-    S = 18; n = 1 << S
-    rowptr, col = rmat.csr_torch(S, dev, seed=42, symmetric=True, drop_self_loops=True)
+    n = 1 << S
+    rowptr, col = rmat.csr_torch(S, dev, seed=42, edgefactor=edgefactor, symmetric=True, drop_self_loops=True)
     nnz = int(col.numel())
     g = torch.Generator(device="cpu"); g.manual_seed(5)
     vals = (torch.rand(nnz, generator=g, dtype=torch.float64) + 0.5).to(dev)

@@ -4,12 +4,18 @@ usage (python3.9 with cffi; PYTHONPATH=<repo>/shim:<scratch copy of the referenc
     python3.9 tools/ref_notebooks_run.py <dir with *.ipynb> [name ...]
 Every notebook runs in its own namespace, cell after cell; IPython magics are dropped; a cell that raises is recorded and the
 notebook goes on (later cells may then fail for want of its names — they are counted as 'follow-on').  One line per notebook and
-a total at the end; the first line of every exception is listed."""
+a total at the end; the first line of every exception is listed.
+
+Round 6: the notebooks are stale against the reference's own drawing module (`draw_graph(..., show_weight=...)`: pygraphblas/gviz.py:66 takes no
+such argument), and in rounds 2-5 that TypeError ended the cell before the names it defines existed, so the compute cells behind it — the
+`A.plus_second(w, ...)` of demo/PageRank.ipynb, the masked `mxm` loop of demo/BetweenessCentrality.ipynb — never ran.  The harness now rebinds the
+drawing entry points of `pygraphblas.gviz` (draw*, cy_matrix) to wrappers that run the original and turn an exception INSIDE THE DRAWING CALL into
+a logged no-op returning None.  Nothing of the reference is edited; only display code is affected; every skipped drawing is listed."""
 import glob, json, os, signal, sys, traceback, io, contextlib
 
 nbdir = sys.argv[1]
 only = set(sys.argv[2:])
-show = set(os.environ.get("REF_NOTEBOOKS_SHOW", "Triangle-Counting").split(","))
+show = set(os.environ.get("REF_NOTEBOOKS_SHOW", "Triangle-Counting,PageRank,BetweenessCentrality,TriangleCentrality").split(","))
 os.chdir(nbdir)
 
 
@@ -22,6 +28,27 @@ def on_alarm(sig, frm):
 
 
 signal.signal(signal.SIGALRM, on_alarm)
+draw_skips = []
+
+
+def _tolerant(fn, label):
+    def wrapper(*a, **k):
+        try:
+            return fn(*a, **k)
+        except Exception as e:  # noqa: BLE001 - display code only
+            draw_skips.append((label, type(e).__name__, str(e).splitlines()[0][:120] if str(e) else ""))
+            return None
+    wrapper.__name__ = getattr(fn, "__name__", label)
+    return wrapper
+
+
+try:
+    import pygraphblas.gviz as _gv
+    for _nm in dir(_gv):
+        if (_nm.startswith("draw") or _nm in ("cy_matrix",)) and callable(getattr(_gv, _nm)):
+            setattr(_gv, _nm, _tolerant(getattr(_gv, _nm), _nm))
+except Exception as e:  # noqa: BLE001
+    print("(pygraphblas.gviz not importable here: drawing cells fail as they are)", type(e).__name__, e)
 tot_ok = tot_cells = 0
 for f in sorted(glob.glob("*.ipynb")):
     name = f[:-6]
@@ -33,6 +60,7 @@ for f in sorted(glob.glob("*.ipynb")):
     ok = 0
     errs = []
     shown = []
+    del draw_skips[:]
     for i, src in enumerate(cells):
         src = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith(("%", "!")))
         if not src.strip():
@@ -61,7 +89,7 @@ for f in sorted(glob.glob("*.ipynb")):
             errs.append((i, type(e).__name__, str(e).splitlines()[0][:160] if str(e) else ""))
     tot_ok += ok
     tot_cells += len(cells)
-    print(f"== {name}: {ok} of {len(cells)} code cells run")
+    print(f"== {name}: {ok} of {len(cells)} code cells run" + (f"  ({len(draw_skips)} drawing call(s) skipped: " + "; ".join(sorted({f'{l}: {t}: {m}' for l, t, m in draw_skips}))[:300] + ")" if draw_skips else ""))
     for i, t, m in errs:
         print(f"     cell {i}: {t}: {m}")
     for i, out, val in shown:
