@@ -58,7 +58,7 @@ void mat_host_assemble(GrB_Matrix A) {
   A->hi.swap(ni); A->hj.swap(nj); A->hx.swap(nx); P.clear(); P.shrink_to_fit();
 }
 
-void mat_invalidate_device(GrB_Matrix A) { A->dev_valid = false; A->csr.clear(); A->csc.clear(); }
+void mat_invalidate_device(GrB_Matrix A) { A->dev_valid = false; A->csr.clear(); A->csc.clear(); A->bm.clear(); }
 void mat_invalidate_host(GrB_Matrix A) {
   A->host_valid = false; A->hi.clear(); A->hj.clear(); A->hx.clear(); A->pending.clear(); A->dev_elem_ops = 0;
   A->hi.shrink_to_fit(); A->hj.shrink_to_fit(); A->hx.shrink_to_fit();
@@ -70,6 +70,7 @@ void mat_invalidate_host(GrB_Matrix A) {
 void mat_to_host(GrB_Matrix A) {
   if (A->iso_full) fail(GrB_INSUFFICIENT_SPACE, ISO_MSG);
   if (A->host_valid) { mat_host_assemble(A); return; }
+  if (mat_bitmap_only(A)) mat_to_device(A);                  // a batch matrix that lives as a bitmap: its CSR first
   // download the device CSR and expand to sorted tuples
   const DevCSR& c = A->csr; const size_t ts = A->type->size;
   std::vector<uint32_t> rp(c.nrows + 1), col(c.nnz);
@@ -88,6 +89,7 @@ void mat_to_host(GrB_Matrix A) {
 
 void mat_to_device(GrB_Matrix A) {
   if (A->dev_valid) return;
+  if (mat_bitmap_only(A)) { mat_bitmap_to_csr(A); return; }
   if (A->type->code >= T_FC32) fail(GrB_DOMAIN_MISMATCH, "complex matrices are host-side containers here: no device arithmetic on them");
   need_device();
   mat_host_assemble(A);
@@ -113,6 +115,7 @@ void mat_to_device(GrB_Matrix A) {
 uint64_t mat_nvals(GrB_Matrix A) {
   if (A->iso_full) { const unsigned __int128 t = (unsigned __int128)A->nrows * A->ncols; return t > UINT64_MAX ? UINT64_MAX : (uint64_t)t; }
   if (A->host_valid) { mat_host_assemble(A); return A->hi.size(); }
+  if (mat_bitmap_only(A)) return mat_bitmap_nvals(A);
   return A->csr.nnz;
 }
 
@@ -352,7 +355,13 @@ GrB_Info GrB_Matrix_dup(GrB_Matrix* C, const GrB_Matrix A) {
     m->format = A->format; m->sparsity_control = A->sparsity_control; m->hyper_switch = A->hyper_switch;
     if (A->iso_full) { m->iso_full = true; memcpy(m->iso_val, A->iso_val, 16); }
     else if (A->host_valid) { mat_host_assemble(A); m->hi = A->hi; m->hj = A->hj; m->hx = A->hx; m->host_valid = true; }
-    else {
+    else if (mat_bitmap_only(A)) {                             // a batch matrix that lives as a bitmap: so does its copy
+      const size_t np = (size_t)A->nrows * A->ncols, ts = A->type->size;
+      m->bm.val.alloc(np * ts + 64); m->bm.pres.alloc(np + 64);
+      GRB_HIP(hipMemcpyAsync(m->bm.val.p, A->bm.val.p, np * ts, hipMemcpyDeviceToDevice, stream()));
+      GRB_HIP(hipMemcpyAsync(m->bm.pres.p, A->bm.pres.p, np, hipMemcpyDeviceToDevice, stream()));
+      m->bm.valid = true; m->bm.nvals = A->bm.nvals; m->bm.nvals_known = A->bm.nvals_known; m->host_valid = false; m->dev_valid = false;
+    } else {
       const DevCSR& s = A->csr; DevCSR& d = m->csr; const size_t ts = A->type->size;
       d.nrows = s.nrows; d.ncols = s.ncols; d.nnz = s.nnz;
       d.rowptr.alloc(((size_t)s.nrows + 1) * 4); d.col.alloc(s.nnz * 4); d.val.alloc(s.nnz * ts);
@@ -445,7 +454,7 @@ static GrB_Info mat_set(GrB_Matrix C, const void* x, int xcode, GrB_Index i, GrB
         uint8_t* pin = (uint8_t*)pinned_scratch() + 64; cast_scalar(C->type->code, pin, xcode, x);
         GRB_HIP(hipMemcpyAsync((uint8_t*)C->csr.val.p + pos * C->type->size, pin, C->type->size, hipMemcpyHostToDevice, stream()));
         GRB_HIP(hipStreamSynchronize(stream()));
-        C->csc.clear(); C->csr.xcd.reset(); C->csr.range_state = 0;
+ C->csc.clear(); C->csr.xcd.reset(); C->csr.range_state = 0; C->bm.clear();
         C->csr.heads_valid = false;      // the row heads carry the BOOL value of a row's first four entries
         return;
       }

@@ -82,14 +82,16 @@ uint64_t dev_alloc_serial();      // a number no other allocation of this proces
 struct DevBuf {
   void* p = nullptr; size_t bytes = 0;
   uint64_t serial = 0;              // identifies this allocation where a raw address could be a recycled one (Vector::fe_lb_key)
+  bool borrowed = false;            // a view of memory another DevBuf owns (a row of a batch matrix's bitmap handed to a vector kernel, grb_mxm_rows.cpp): never freed here
   DevBuf() {}
   explicit DevBuf(size_t n) { alloc(n); }
   DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), serial(o.serial) { o.p = nullptr; o.bytes = 0; o.serial = 0; }
-  DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { reset(); p = o.p; bytes = o.bytes; serial = o.serial; o.p = nullptr; o.bytes = 0; o.serial = 0; } return *this; }
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), serial(o.serial), borrowed(o.borrowed) { o.p = nullptr; o.bytes = 0; o.serial = 0; o.borrowed = false; }
+  DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { reset(); p = o.p; bytes = o.bytes; serial = o.serial; borrowed = o.borrowed; o.p = nullptr; o.bytes = 0; o.serial = 0; o.borrowed = false; } return *this; }
   ~DevBuf() { reset(); }
   void alloc(size_t n) { reset(); if (n) { p = dev_alloc(n); bytes = n; serial = dev_alloc_serial(); } }
-  void reset() { if (p) dev_free(p); p = nullptr; bytes = 0; serial = 0; }
+  void borrow(void* q, size_t n) { reset(); p = q; bytes = n; serial = dev_alloc_serial(); borrowed = true; }
+  void reset() { if (p && !borrowed) dev_free(p); p = nullptr; bytes = 0; serial = 0; borrowed = false; }
   template <class T> T* as() const { return (T*)p; }
 };
 
@@ -121,6 +123,12 @@ struct DevCSR {
 
 }  // namespace grb
 
+// A matrix of a few very long rows (the ns x n batches of the reference's betweenness centrality, gap/bcmark.py:16-67) as a BITMAP: val T[nrows x ncols]
+// | pres u8[nrows x ncols], row-major — i.e. ns bitmap vectors back to back, or one bitmap vector of nrows x ncols positions.  Round 6: such a matrix may
+// live in this form alone (dev_valid == host_valid == false, bm.valid == true): the batch operations (grb_mxm_rows.cpp) read and write it directly, and the
+// CSR is made from it only when something else asks (mat_to_device).
+namespace grb { struct DevBitmap { DevBuf val, pres; bool valid = false; uint64_t nvals = 0; bool nvals_known = false;
+                                  void clear() { val.reset(); pres.reset(); valid = false; nvals = 0; nvals_known = false; } }; }
 struct GrB_Matrix_opaque {
   uint64_t magic = GRB_MAGIC;
   GrB_Type type = nullptr;
@@ -139,6 +147,7 @@ struct GrB_Matrix_opaque {
   uint32_t dev_elem_ops = 0; // element reads / writes served on the device in a row (grb_container.cpp: after a few dozen the host mirror takes over)
   grb::DevCSR csr;          // by-row
   grb::DevCSR csc;          // CSR of the transpose (cached; invalidated with csr)
+  grb::DevBitmap bm;        // the bitmap form of a batch matrix (cached beside the CSR, or the only valid form)
   int format = 0;           // GxB_BY_ROW(0) / GxB_BY_COL(1): stored option only
   int sparsity_control = 15;
   double hyper_switch = 0.0625;
@@ -205,6 +214,12 @@ void mat_to_device(GrB_Matrix A);         // ensure device CSR valid (assembles 
 void mat_invalidate_host(GrB_Matrix A);   // device was written
 void mat_invalidate_device(GrB_Matrix A); // host was written
 uint64_t mat_nvals(GrB_Matrix A);
+// batch matrices (a few very long rows) in bitmap form — grb_mxm_rows.cpp
+bool mat_batch_shape(uint64_t nrows, uint64_t ncols, int type_code);   // <= 64 rows of >= 65536 (a multiple of 64) columns, a non-complex type, < 2^32 positions
+grb::DevBitmap& mat_bitmap(GrB_Matrix A);          // ensure the bitmap form is valid (made from the CSR when it is not)
+void mat_bitmap_to_csr(GrB_Matrix A);              // ... and the CSR from the bitmap (what mat_to_device does for a matrix that lives as a bitmap)
+uint64_t mat_bitmap_nvals(GrB_Matrix A);           // entries of the bitmap (counted once, then remembered)
+inline bool mat_bitmap_only(GrB_Matrix A) { return A->bm.valid && !A->dev_valid && !A->host_valid; }
 // hypersparse containers (a dimension beyond the device layouts): the products and eWise operations on the index sets that occur (grb_hyper.cpp)
 bool is_hyper(const GrB_Matrix_opaque* A); bool is_hyper(const GrB_Vector_opaque* v);
 void hyper_mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semiring semiring, GrB_Matrix A, GrB_Vector u, GrB_Descriptor desc, bool is_vxm);

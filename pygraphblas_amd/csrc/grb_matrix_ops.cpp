@@ -19,6 +19,11 @@ bool mxm_few_rows_wanted(const DevCSR& Ad, const DevCSR& Bd);
 void mxm_few_rows(const DevCSR& Ad, GrB_Type atype, GrB_Matrix Mmask, const DescView& dv, GrB_Semiring semiring, GrB_Matrix B, int zcode, DevCSR& T);
 bool few_long_rows(uint64_t nrows, uint64_t ncols, uint64_t nnz);
 void ewise_few_rows(GrB_Matrix C, GrB_Matrix Mmask, const DescView& dv, GrB_BinaryOp accum, GrB_BinaryOp op, const DevCSR& Ad, GrB_Type atype, const DevCSR& Bd, GrB_Type btype, bool is_union, DevCSR& T);
+// round 6: the same batches as bitmaps, all rows in one kernel (grb_mxm_rows.cpp)
+bool batch_wanted(GrB_Matrix C, uint64_t work);
+void ewise_batch(GrB_Matrix C, GrB_Matrix Mmask, const DescView& dv, GrB_BinaryOp accum, GrB_BinaryOp op, GrB_Matrix A, GrB_Matrix B, bool is_union);
+void apply_batch(GrB_Matrix C, int mode, int opcode, int xcode, const uint8_t* scalar16, GrB_Matrix A);
+bool mxm_batch(GrB_Matrix C, GrB_Matrix A, GrB_Matrix Mmask, const DescView& dv, GrB_BinaryOp accum, GrB_Semiring semiring, GrB_Matrix B, int zcode, DevCSR& T);
 }
 
 namespace {
@@ -31,7 +36,7 @@ const DevCSR& operand(GrB_Matrix A, bool transpose) { mat_to_device(A); return t
 void adopt(GrB_Matrix C, DevCSR& T, int tcode) {
   // C becomes exactly T (cast values if the types differ)
   if (tcode != C->type->code && T.nnz) { DevBuf c(T.nnz * C->type->size); vec_cast_values(C->type->code, c.p, tcode, T.val.p, T.nnz); T.val = std::move(c); }
-  mat_invalidate_host(C); C->csc.clear(); C->csr.clear();
+  mat_invalidate_host(C); C->csc.clear(); C->csr.clear(); C->bm.clear();
   C->csr.nrows = T.nrows; C->csr.ncols = T.ncols; C->csr.nnz = T.nnz;
   C->csr.rowptr = std::move(T.rowptr); C->csr.col = std::move(T.col); C->csr.val = std::move(T.val);
   if (!C->csr.val.p) C->csr.val.alloc(8);
@@ -86,6 +91,18 @@ void do_mxm(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, GrB_Semiring semirin
   SemiringDesc sd = make_semiring_desc(semiring, false);
   g_last_plan.clear();
   if (!M && dv.mask_comp) { if (dv.replace) GrB_Matrix_clear(C); return; }
+  // a batch of a few very long rows times a large matrix (the BC sweeps' frontier products): the rows of the batch's BITMAP through GrB_vxm, the result a bitmap
+  if (!dv.tran0 && mat_batch_shape(A->nrows, A->ncols, A->type->code) && mat_batch_shape(C->nrows, C->ncols, C->type->code) && (!M || mat_batch_shape(M->nrows, M->ncols, M->type->code)) &&
+      !is_hyper(B) && A != B && M != B) {
+    const DevCSR& Bd0 = operand(B, false);
+    const char* e = getenv("GRB_MI355X_BATCH");
+    if (e ? atoi(e) != 0 : (Bd0.nnz >= (1u << 20) && Bd0.ncols >= 65536u)) {
+      if (accum) check_binop(accum, "accum");
+      DevCSR T;
+      if (mxm_batch(C, A, M, dv, accum, semiring, B, sd.zcode, T)) return;
+      matrix_write_back(C, T, sd.zcode, M, dv, accum, true); return;
+    }
+  }
   const DevCSR& Ad = operand(A, dv.tran0); const DevCSR& Bd = operand(B, dv.tran1);
   const bool uses_a = binop_uses_x(sd.mulop), uses_b = binop_uses_y(sd.mulop);
   DevBuf acast, bcast;
@@ -142,8 +159,12 @@ void do_ewise(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, GrB_BinaryOp op, G
   const uint64_t ar = dv.tran0 ? A->ncols : A->nrows, ac = dv.tran0 ? A->nrows : A->ncols;
   const uint64_t br = dv.tran1 ? B->ncols : B->nrows, bc = dv.tran1 ? B->nrows : B->ncols;
   if (ar != br || ac != bc || C->nrows != ar || C->ncols != ac || (M && (M->nrows != ar || M->ncols != ac))) fail(GrB_DIMENSION_MISMATCH, "eWise: dimensions do not conform");
-  const DevCSR& Ad = operand(A, dv.tran0); const DevCSR& Bd = operand(B, dv.tran1);
   if (!M && dv.mask_comp) { if (dv.replace) GrB_Matrix_clear(C); return; }
+  if (!dv.tran0 && !dv.tran1 && batch_wanted(C, mat_nvals(A) + mat_nvals(B)) && A->type->code < T_FC32 && B->type->code < T_FC32 && (!M || M->type->code < T_FC32)) {
+    if (accum) check_binop(accum, "accum");
+    ewise_batch(C, M, dv, accum, op, A, B, is_union); return;      // a batch of a few very long rows (BC sweeps): its bitmap as ONE vector through the vector kernel
+  }
+  const DevCSR& Ad = operand(A, dv.tran0); const DevCSR& Bd = operand(B, dv.tran1);
   if (few_long_rows(C->nrows, C->ncols, Ad.nnz + Bd.nnz)) {          // a batch of a few very long rows (BC sweeps): row by row through the vector kernels
     DevCSR T; ewise_few_rows(C, M, dv, accum, op, Ad, A->type, Bd, B->type, is_union, T);
     adopt(C, T, C->type->code); return;
@@ -163,6 +184,10 @@ void do_apply(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, int mode, int opco
   const DescView dv(desc);
   const uint64_t r = dv.tran0 ? A->ncols : A->nrows, c = dv.tran0 ? A->nrows : A->ncols;
   if (C->nrows != r || C->ncols != c || (M && (M->nrows != r || M->ncols != c))) fail(GrB_DIMENSION_MISMATCH, "apply: dimensions do not conform");
+  if (!M && !accum && !dv.mask_comp && !dv.tran0 && A->bm.valid && !A->host_valid && batch_wanted(C, mat_nvals(A)) && A->type->code < T_FC32) {      // a batch that lives as a bitmap stays one
+    uint8_t s16[16] = {0}; if (scalar) cast_scalar(xcode, s16, scode, scalar);
+    apply_batch(C, mode, opcode, xcode, s16, A); return;
+  }
   const DevCSR& S = operand(A, dv.tran0);
   DevCSR T; T.nrows = S.nrows; T.ncols = S.ncols; T.nnz = S.nnz;
   T.rowptr.alloc(((size_t)S.nrows + 1) * 4); T.col.alloc(S.nnz * 4 + 4); T.val.alloc(S.nnz * type_size(xcode) + 8);

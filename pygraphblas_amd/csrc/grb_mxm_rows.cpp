@@ -173,4 +173,181 @@ void ewise_few_rows(GrB_Matrix C, GrB_Matrix Mmask, const DescView& dv, GrB_Bina
   g_last_plan = "ewise_rows<" + std::to_string(nr) + " x vector eWise> ";
 }
 
+
+// ---- batch matrices as bitmaps (round 6) ------------------------------------------------------------------------------------------
+// Rounds 3-5 ran every operation of the BC sweeps row by row: each of the ns rows of every operand was scattered from the CSR into a fresh
+// bitmap vector, the vector kernel ran, and the result was compacted back into CSR rows behind a host round trip — 15 of the driver's 23 ms
+// at R-MAT-22.  An ns x n batch IS a bitmap vector of ns * n positions: element-wise operations with mask,
+// accumulator and replace are ONE vector kernel over the flattened arrays, a row of a product is a slice of them, and nothing in the loop
+// ever needs the CSR of `paths` / `bc` / `W`.  So a batch result now stays a bitmap (GrB_Matrix_opaque::bm, the only valid form until
+// something else asks for the CSR: mat_to_device), inputs are read from their bitmaps (made once from the CSR when they arrive as one).
+namespace {
+template <int TS> __global__ void k_csr_to_bitmap(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const uint8_t* __restrict__ val, uint32_t nrows, uint64_t ncols, uint64_t nnz,
+                                                  uint8_t* __restrict__ dval, uint8_t* __restrict__ dpres) {
+  __shared__ uint32_t rp[66];
+  if (threadIdx.x <= nrows) rp[threadIdx.x] = rowptr[threadIdx.x];
+  __syncthreads();
+  for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < nnz; p += gridDim.x * 256ull) {
+    uint32_t r = 0; for (uint32_t j = 1; j < nrows; j++) r = p >= rp[j] ? j : r;        // (<= 64 rows)
+    const uint64_t i = (uint64_t)r * ncols + col[p];
+#pragma unroll
+    for (int b = 0; b < TS; b++) dval[i * TS + b] = val[p * TS + b];
+    dpres[i] = 1;
+  }
+}
+__global__ void k_bm_rowptr(const uint32_t* __restrict__ pos, uint32_t nrows, uint64_t ncols, uint32_t* __restrict__ rowptr) {
+  if (threadIdx.x <= nrows) rowptr[threadIdx.x] = pos[(uint64_t)threadIdx.x * ncols];
+}
+template <int TS> __global__ void k_bm_compact(const uint8_t* __restrict__ pres, const uint8_t* __restrict__ val, const uint32_t* __restrict__ pos, uint64_t np, uint64_t ncols,
+                                               uint32_t* __restrict__ ocol, uint8_t* __restrict__ oval) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < np; i += gridDim.x * 256ull) if (pres[i]) {
+    const size_t w = pos[i]; ocol[w] = (uint32_t)(i % ncols);
+#pragma unroll
+    for (int b = 0; b < TS; b++) oval[w * TS + b] = val[i * TS + b];
+  }
+}
+// a vector object over (a slice of) a bitmap: `own` moves the buffers in (the op may replace them; take them back with vec_release), else they are borrowed
+GrB_Vector view_vector(GrB_Type type, uint64_t n, void* val, void* pres, bool known, uint64_t nvals) {
+  GrB_Vector v = nullptr; if (GrB_Vector_new(&v, type, n) != GrB_SUCCESS) fail(GrB_OUT_OF_MEMORY, "batch: vector view");
+  v->dval.borrow(val, n * type->size); v->dpres.borrow(pres, n);
+  v->dev_valid = true; v->host_valid = false; v->dnvals = nvals; v->dnvals_known = known;
+  return v;
+}
+}  // namespace
+
+bool mat_batch_shape(uint64_t nrows, uint64_t ncols, int type_code) {
+  return nrows >= 1 && nrows <= 64 && ncols >= 65536u && (ncols & 63u) == 0 && nrows * ncols <= 0xFFFFFFF0ull && type_code < T_FC32 && device_ok();
+}
+DevBitmap& mat_bitmap(GrB_Matrix A) {
+  if (A->bm.valid) return A->bm;
+  mat_to_device(A);
+  const DevCSR& S = A->csr; const size_t ts = A->type->size; const uint64_t np = (uint64_t)A->nrows * A->ncols;
+  A->bm.val.alloc(np * ts + 64); A->bm.pres.alloc(np + 64);
+  GRB_HIP(hipMemsetAsync(A->bm.pres.p, 0, np + 64, stream()));
+  if (S.nnz) by_size(ts, [&](auto TS) {
+    hipLaunchKernelGGL((k_csr_to_bitmap<decltype(TS)::value>), dim3(grid_of(S.nnz)), dim3(256), 0, stream(), S.rowptr.as<uint32_t>(), S.col.as<uint32_t>(), (const uint8_t*)S.val.p, (uint32_t)A->nrows,
+                       (uint64_t)A->ncols, (uint64_t)S.nnz, (uint8_t*)A->bm.val.p, A->bm.pres.as<uint8_t>());
+  });
+  A->bm.valid = true; A->bm.nvals = S.nnz; A->bm.nvals_known = true;
+  return A->bm;
+}
+uint64_t mat_bitmap_nvals(GrB_Matrix A) {
+  if (!A->bm.nvals_known) { A->bm.nvals = count_present(A->bm.pres.as<uint8_t>(), (uint64_t)A->nrows * A->ncols); A->bm.nvals_known = true; }
+  return A->bm.nvals;
+}
+void mat_bitmap_to_csr(GrB_Matrix A) {
+  const uint64_t np = (uint64_t)A->nrows * A->ncols; const size_t ts = A->type->size;
+  DevBuf flags((np + 1) * 4 + 4), pos((np + 1) * 4 + 4);
+  hipLaunchKernelGGL(k_pres_to_u32, dim3(grid_of(np + 1)), dim3(256), 0, stream(), A->bm.pres.as<uint8_t>(), np, flags.as<uint32_t>());
+  exclusive_scan_u32(flags.as<uint32_t>(), pos.as<uint32_t>(), np + 1);
+  uint32_t nnz = 0;
+  GRB_HIP(hipMemcpyAsync(&nnz, pos.as<uint32_t>() + np, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+  DevCSR& c = A->csr; c.clear(); A->csc.clear();
+  c.nrows = (uint32_t)A->nrows; c.ncols = (uint32_t)A->ncols; c.nnz = nnz;
+  c.rowptr.alloc(((size_t)c.nrows + 1) * 4); c.col.alloc((size_t)nnz * 4 + 8); c.val.alloc((size_t)nnz * ts + 8);
+  hipLaunchKernelGGL(k_bm_rowptr, dim3(1), dim3(128), 0, stream(), pos.as<uint32_t>(), c.nrows, (uint64_t)A->ncols, c.rowptr.as<uint32_t>());
+  if (nnz) by_size(ts, [&](auto TS) {
+    hipLaunchKernelGGL((k_bm_compact<decltype(TS)::value>), dim3(grid_of(np)), dim3(256), 0, stream(), A->bm.pres.as<uint8_t>(), (const uint8_t*)A->bm.val.p, pos.as<uint32_t>(), np, (uint64_t)A->ncols,
+                       c.col.as<uint32_t>(), (uint8_t*)c.val.p);
+  });
+  GRB_HIP(hipGetLastError());
+  c.valid = true; A->dev_valid = true; A->bm.nvals = nnz; A->bm.nvals_known = true;
+}
+
+// C becomes the bitmap (val, pres): the batch operations' way of writing a result
+static void adopt_bitmap(GrB_Matrix C, DevBuf&& val, DevBuf&& pres, bool known, uint64_t nvals) {
+  mat_invalidate_host(C); C->csc.clear(); C->csr.clear(); C->dev_valid = false; C->iso_full = false;
+  C->bm.val = std::move(val); C->bm.pres = std::move(pres); C->bm.valid = true; C->bm.nvals = nvals; C->bm.nvals_known = known;
+}
+
+bool batch_wanted(GrB_Matrix C, uint64_t work) {
+  if (!mat_batch_shape(C->nrows, C->ncols, C->type->code)) return false;
+  if (getenv("GRB_MI355X_BATCH")) return atoi(getenv("GRB_MI355X_BATCH")) != 0;
+  return work >= (1u << 18);
+}
+
+// C<M, replace> = accum(C, A op B) on batch matrices, element-wise: ONE vector kernel over the nrows * ncols positions
+void ewise_batch(GrB_Matrix C, GrB_Matrix Mmask, const DescView& dv, GrB_BinaryOp accum, GrB_BinaryOp op, GrB_Matrix A, GrB_Matrix B, bool is_union) {
+  const uint64_t np = (uint64_t)C->nrows * C->ncols;
+  if (A != C) mat_bitmap(A); if (B != C) mat_bitmap(B); if (Mmask && Mmask != C) mat_bitmap(Mmask);
+  DevBitmap& cb = mat_bitmap(C);                                      // (an empty C: a cleared presence array)
+  VecGuard g;
+  // the output owns C's buffers for the call (the vector write-back may swap them for the result's); the inputs borrow theirs
+  GrB_Vector vc = nullptr; if (GrB_Vector_new(&vc, C->type, np) != GrB_SUCCESS) fail(GrB_OUT_OF_MEMORY, "batch: output view"); g.v.push_back(vc);
+  vc->dval = std::move(cb.val); vc->dpres = std::move(cb.pres); vc->dev_valid = true; vc->host_valid = false; vc->dnvals = cb.nvals; vc->dnvals_known = cb.nvals_known;
+  cb.valid = false;
+  auto view = [&](GrB_Matrix X) -> GrB_Vector {
+    if (X == C) return vc;
+    GrB_Vector v = view_vector(X->type, np, X->bm.val.p, X->bm.pres.p, X->bm.nvals_known, X->bm.nvals); g.v.push_back(v); return v;
+  };
+  GrB_Vector va = view(A), vb = B == A ? va : view(B), vm = !Mmask ? nullptr : (Mmask == A ? va : (Mmask == B ? vb : view(Mmask)));
+  GrB_Descriptor_opaque d{GRB_MAGIC, dv.replace ? GrB_REPLACE : 0, (dv.mask_comp ? GrB_COMP : 0) | (dv.mask_struct ? GrB_STRUCTURE : 0), 0, 0, 0, 0, 0, 0.0, false, "ewise_batch"};
+  const GrB_Info info = is_union ? GrB_Vector_eWiseAdd_BinaryOp(vc, vm, accum, op, va, vb, &d) : GrB_Vector_eWiseMult_BinaryOp(vc, vm, accum, op, va, vb, &d);
+  if (info != GrB_SUCCESS) { std::string e = vc->err; fail(info, "eWise (batch): " + e); }
+  vec_to_device(vc);                                                  // (completes whatever the non-blocking queue deferred; an empty result gets its cleared bitmap)
+  if (vc->dval.borrowed || vc->dpres.borrowed || vc->dval.bytes < np * C->type->size || vc->dpres.bytes < np) fail(GrB_PANIC, "eWise (batch): the result does not own its buffers");
+  adopt_bitmap(C, std::move(vc->dval), std::move(vc->dpres), vc->dnvals_known, vc->dnvals);
+  g_last_plan = "ewise_batch<" + std::to_string(C->nrows) + " x " + std::to_string(C->ncols) + " as one vector> ";
+}
+
+// C = f(A) on a batch matrix, no mask, no accumulator (`frontier.apply(BOOL.ONE, out=s)`, gap/bcmark.py:38-39): the values in one pass, the pattern copied
+void apply_batch(GrB_Matrix C, int mode, int opcode, int xcode, const uint8_t* scalar16, GrB_Matrix A) {
+  const uint64_t np = (uint64_t)A->nrows * A->ncols;
+  DevBitmap& ab = mat_bitmap(A);
+  DevBuf ac; const void* av = cast_values(xcode, A->type->code, ab.val.p, np, ac);
+  DevBuf out(np * type_size(xcode) + 64), pres(np + 64);
+  vec_apply(xcode, np, av, nullptr, mode, opcode, scalar16, out.p, nullptr);
+  GRB_HIP(hipMemcpyAsync(pres.p, ab.pres.p, np, hipMemcpyDeviceToDevice, stream()));
+  if (xcode != C->type->code) { DevBuf c(np * C->type->size + 64); vec_cast_values(C->type->code, c.p, xcode, out.p, np); out = std::move(c); }
+  const bool known = ab.nvals_known; const uint64_t nv = ab.nvals;
+  adopt_bitmap(C, std::move(out), std::move(pres), known, nv);
+  g_last_plan = "apply_batch ";
+}
+
+extern thread_local void* g_mxv_dest_val; extern thread_local uint8_t* g_mxv_dest_pres;      // grb_mxv.cpp
+// T = A (+).(x) op(B) under the mask for a batch A (and mask): one GrB_vxm per row on SLICES of the bitmaps, results into the rows of a new bitmap.
+// Writes C itself when the write-back is "C becomes T" (no accumulator; replace, no mask, or an empty C) and returns true; otherwise leaves T as a CSR for
+// the general write-back and returns false.
+bool mxm_batch(GrB_Matrix C, GrB_Matrix A, GrB_Matrix Mmask, const DescView& dv, GrB_BinaryOp accum, GrB_Semiring semiring, GrB_Matrix B, int zcode, DevCSR& T) {
+  const uint32_t nr = (uint32_t)A->nrows; const uint64_t nin = A->ncols, nout = dv.tran1 ? B->nrows : B->ncols;
+  const size_t zs = type_size(zcode); GrB_Type ztype = type_by_code(zcode);
+  DevBitmap& ab = mat_bitmap(A);
+  if (Mmask) mat_bitmap(Mmask);
+  GrB_Descriptor_opaque d{GRB_MAGIC, 0, (dv.mask_comp ? GrB_COMP : 0) | (dv.mask_struct ? GrB_STRUCTURE : 0), 0, dv.tran1 ? GrB_TRAN : 0, 0, 0, 0, 0.0, false, "mxm_batch"};
+  const uint64_t npo = (uint64_t)nr * nout;
+  DevBuf tval(npo * zs + 64), tpres(npo + 64);
+  std::string plans; uint64_t total = 0; bool known = true;
+  for (uint32_t s = 0; s < nr; s++) {
+    VecGuard tmp;
+    GrB_Vector u = view_vector(A->type, nin, (uint8_t*)ab.val.p + (size_t)s * nin * A->type->size, ab.pres.as<uint8_t>() + (size_t)s * nin, false, 0); tmp.v.push_back(u);
+    GrB_Vector mv = nullptr;
+    if (Mmask) { mv = view_vector(Mmask->type, nout, (uint8_t*)Mmask->bm.val.p + (size_t)s * nout * Mmask->type->size, Mmask->bm.pres.as<uint8_t>() + (size_t)s * nout, false, 0); tmp.v.push_back(mv); }
+    GrB_Vector w = nullptr; if (GrB_Vector_new(&w, ztype, nout) != GrB_SUCCESS) fail(GrB_OUT_OF_MEMORY, "mxm: row result"); tmp.v.push_back(w);
+    uint8_t* const row_val = (uint8_t*)tval.p + (size_t)s * nout * zs; uint8_t* const row_pres = tpres.as<uint8_t>() + (size_t)s * nout;
+    g_mxv_dest_val = row_val; g_mxv_dest_pres = row_pres;             // the product writes T's row in place (grb_mxv.cpp)
+    const GrB_Info info = GrB_vxm(w, mv, nullptr, semiring, u, B, &d);
+    g_mxv_dest_val = nullptr; g_mxv_dest_pres = nullptr;
+    if (info != GrB_SUCCESS) { std::string e = w->err; fail(info, "mxm (batch): " + e); }
+    if (plans.empty()) plans = g_last_plan;
+    vec_to_device(w);
+    if (w->dval.p != row_val) GRB_HIP(hipMemcpyAsync(row_val, w->dval.p, nout * zs, hipMemcpyDeviceToDevice, stream()));        // (the write-back did more than adopt T: e.g. an empty product)
+    if (w->dpres.p != row_pres) GRB_HIP(hipMemcpyAsync(row_pres, w->dpres.p, nout, hipMemcpyDeviceToDevice, stream()));
+    if (w->dnvals_known) total += w->dnvals; else known = false;
+  }
+  g_last_plan = "mxm_batch<" + std::to_string(nr) + " x vxm on bitmap rows> first row: " + plans;
+  const bool c_becomes_t = !accum && (!Mmask || dv.replace || mat_nvals(C) == 0) && mat_batch_shape(C->nrows, C->ncols, C->type->code);
+  if (c_becomes_t) {
+    if (zcode != C->type->code) { DevBuf c(npo * C->type->size + 64); vec_cast_values(C->type->code, c.p, zcode, tval.p, npo); tval = std::move(c); }
+    adopt_bitmap(C, std::move(tval), std::move(tpres), known, total);
+    return true;
+  }
+  // the general write-back wants a CSR: a temporary matrix object carries the bitmap through the conversion
+  GrB_Matrix_opaque tmpm; tmpm.type = ztype; tmpm.nrows = nr; tmpm.ncols = nout; tmpm.host_valid = false;
+  tmpm.bm.val = std::move(tval); tmpm.bm.pres = std::move(tpres); tmpm.bm.valid = true;
+  mat_bitmap_to_csr(&tmpm);
+  T.clear(); T.nrows = nr; T.ncols = (uint32_t)nout; T.nnz = tmpm.csr.nnz;
+  T.rowptr = std::move(tmpm.csr.rowptr); T.col = std::move(tmpm.csr.col); T.val = std::move(tmpm.csr.val); T.valid = true;
+  return false;
+}
+
 }  // namespace grb

@@ -16,6 +16,10 @@
 using namespace grb;
 
 static int g_force_method = SPMV_AUTO;   // test hook: GRB_MI355X_SPMV=adaptive|rowgroup|push
+// Where the next product on this thread writes T (round 6, grb_mxm_rows.cpp): a row of a batch matrix's bitmap.  The kernels write the row sums and presence
+// bytes there instead of into fresh buffers, and when the write-back makes w exactly T — the batch products' case — w ends up as a VIEW of that row: the
+// ns x (n values + n bytes) copies per product of the first bitmap version (3.8 of 14 ms of the BC driver at R-MAT-22) are gone.  One-shot: cleared by the call.
+namespace grb { thread_local void* g_mxv_dest_val = nullptr; thread_local uint8_t* g_mxv_dest_pres = nullptr; }
 
 static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semiring semiring, GrB_Matrix A, GrB_Vector u,
                      GrB_Descriptor desc, bool is_vxm) {
@@ -104,7 +108,9 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
     }
   }
   const size_t zs = type_size(sd.zcode);
-  DevBuf tval(mr * zs + 1), tpres(mr + 1), ucast, acast;
+  DevBuf tval, tpres, ucast, acast;
+  if (g_mxv_dest_val && g_mxv_dest_pres) { tval.borrow(g_mxv_dest_val, mr * zs); tpres.borrow(g_mxv_dest_pres, mr); } else { tval.alloc(mr * zs + 1); tpres.alloc(mr + 1); }
+  g_mxv_dest_val = nullptr; g_mxv_dest_pres = nullptr;
   // An operand with holes whose product is accumulated into a full vector with the monoid's own operator, no mask (PageRank:
   // r<accum PLUS> += A' (+).second w, w = t / d has no entry for dangling vertices — gap/prmark.py:21-23): where T has no
   // entry the output keeps its value, and where T's entries would come from absent operand entries only, accumulating the

@@ -305,7 +305,7 @@ def test_two_pass_hash_spgemm_against_the_oracle(gpu, monkeypatch):
     check(gC, O.mxm(Cm, At, At, "PLUS", "TIMES", "INT64", mask=Mm, accum="PLUS", mask_comp=True), "INT64", what="hash A*A <!M> accum")
 
 
-@pytest.mark.parametrize("scale,ns", [(8, 4), (10, 4)])
+@pytest.mark.parametrize("scale,ns", [(8, 4), (10, 4), (16, 4)])
 def test_whole_batched_betweenness_centrality_of_the_gap_driver(gpu, scale, ns, monkeypatch):
     """gap/bcmark.py:16-67 end to end over the mirror (forward sweep of masked frontier products, backward sweep of masked
     mxm / emult, reduce over the batch), against networkx's Brandes on the same directed graph: for every vertex that is not
@@ -315,6 +315,8 @@ def test_whole_batched_betweenness_centrality_of_the_gap_driver(gpu, scale, ns, 
     import networkx as nx
     from bc_algorithm import bc
     monkeypatch.setenv("GRB_MI355X_MXM_ROWS", "1")                    # the row-wise mxm the product picks by itself at scale
+    if scale >= 16:
+        monkeypatch.setenv("GRB_MI355X_BATCH", "1")                   # ... and, from 65 536 columns, the batches as bitmaps (round 6)
     n = 1 << scale
     rp, col = rmat.csr_numpy(scale, drop_self_loops=True)             # directed
     rows = np.repeat(np.arange(n), np.diff(rp.astype(np.int64)))
@@ -360,6 +362,82 @@ def test_ewise_on_few_long_rows_matches_the_row_merge_kernels(gpu, monkeypatch):
         a, b = res
         assert np.array_equal(a.I, b.I) and np.array_equal(a.J, b.J), (typ, opn, kw)
         assert np.allclose(a.X.astype(np.float64), b.X.astype(np.float64), rtol=1e-6, atol=0.0, equal_nan=True), (typ, opn, kw)
+
+
+def test_batch_matrices_as_bitmaps_match_the_generic_kernels(gpu, monkeypatch):
+    """Round 6: a batch of a few very long rows lives as a BITMAP (grb_mxm_rows.cpp: ewise_batch / apply_batch / mxm_batch) — element-wise operations are
+    one vector kernel over all rows, a product row is a slice, the CSR is made only when something else asks.  Every operation of the BC sweeps
+    (gap/bcmark.py:26-60) and the variations around them (valued / complemented / structural masks, accumulator, replace, output aliasing an input or the
+    mask, mixed types, chains of batch operations whose intermediate results never become a CSR) against the generic CSR kernels (GRB_MI355X_BATCH=0)."""
+    rng = np.random.default_rng(33)
+    nr, nc = 4, 1 << 16
+    def mk(typ, dens):
+        return rand_matrix(rng, typ, nr, nc, dens)
+    def run(forced, fn):
+        monkeypatch.setenv("GRB_MI355X_BATCH", forced); monkeypatch.setenv("GRB_MI355X_EWISE_ROWS", "0"); monkeypatch.setenv("GRB_MI355X_MXM_ROWS", "0")
+        return fn()
+    def same(a, b, what):
+        assert np.array_equal(a.I, b.I) and np.array_equal(a.J, b.J), what
+        assert np.allclose(a.X.astype(np.float64), b.X.astype(np.float64), rtol=1e-6, atol=0.0, equal_nan=True), what
+    cases = [("FP32", "DIV", False, dict(mask="BOOL", replace=True)), ("FP32", "TIMES", False, dict(accum="PLUS")), ("FP32", "PLUS", True, dict()),
+             ("INT64", "MIN", True, dict(mask="INT8", comp=True)), ("FP64", "PLUS", True, dict(accum="PLUS", alias=True)), ("INT32", "TIMES", False, dict(mask="BOOL", comp=True, replace=True, accum="MAX")),
+             ("FP32", "PLUS", True, dict(mask="FP32", struct=True, replace=True)), ("UINT8", "PLUS", True, dict(accum="PLUS", alias=True, mask="BOOL"))]
+    for typ, opn, union, kw in cases:
+        At, Bt, Ct = mk(typ, 0.4), mk(typ, 0.5), mk(typ, 0.3)
+        Mt = mk(kw["mask"], 0.5) if "mask" in kw else None
+        flags = ("R" if kw.get("replace") else "") + ("S" if kw.get("struct") else "") + ("C" if kw.get("comp") else "")
+        def one():
+            A, B, Cm = to_matrix(At), to_matrix(Bt), to_matrix(Ct)
+            out = A if kw.get("alias") else Cm
+            fn = A.eadd if union else A.emult
+            fn(B, getattr(TYPE[typ], opn), out=out, mask=to_matrix(Mt) if Mt is not None else None, accum=getattr(TYPE[typ], kw["accum"]) if "accum" in kw else None,
+               desc=getattr(D, flags) if flags else None)
+            plan = gb.last_kernel_plan()
+            return matrix_tuples(out), plan, out.nvals
+        (a, pa, na), (b, pb, nb) = run("0", one), run("1", one)
+        assert "ewise_batch" in pb, (pa, pb)
+        same(a, b, (typ, opn, kw)); assert na == nb == len(a.I)
+    # a chain that never leaves the bitmap form: the forward and backward steps of the driver on a random graph, then everything read back
+    n = nc
+    src = rng.integers(0, n, 400000); dst = rng.integers(0, n, 400000)
+    key = np.unique(src.astype(np.uint64) << np.uint64(32) | dst.astype(np.uint64))
+    gi, gj = (key >> np.uint64(32)), (key & np.uint64(0xFFFFFFFF))
+    G = gb.Matrix.from_arrays(gi, gj, np.ones(len(gi), np.float32), n, n, gb.FP32)
+    GT = G.transpose()
+    def chain():
+        paths = gb.Matrix.dense(gb.FP32, nr, n, 0); frontier = gb.Matrix.sparse(gb.FP32, nr, n)
+        for i in range(nr):
+            paths[i, 7 * i + 1] = 1; frontier[i, 7 * i + 1] = 1
+        S = []; plans = []
+        frontier.mxm(G, out=frontier, mask=paths, semiring=gb.FP32.PLUS_FIRST, desc=D.RC); plans.append(gb.last_kernel_plan())
+        for _ in range(3):
+            s = gb.Matrix.sparse(gb.BOOL, nr, n); frontier.apply(gb.BOOL.ONE, out=s); plans.append(gb.last_kernel_plan()); S.append(s)
+            paths.assign_matrix(frontier, accum=gb.FP32.PLUS); plans.append(gb.last_kernel_plan())
+            frontier.mxm(G, out=frontier, mask=paths, semiring=gb.FP32.PLUS_FIRST, desc=D.RC)
+        bcu = gb.Matrix.dense(gb.FP32, nr, n, 1); W = gb.Matrix.sparse(gb.FP32, nr, n)
+        for i in (2, 1):
+            bcu.emult(paths, gb.FP32.DIV, out=W, mask=S[i], desc=D.R)
+            W.mxm(GT, out=W, mask=S[i - 1], semiring=gb.FP32.PLUS_FIRST, desc=D.R)
+            W.emult(paths, gb.FP32.TIMES, out=bcu, accum=gb.FP32.PLUS)
+        cent = gb.Vector.dense(gb.FP32, n, -nr)
+        bcu.reduce_vector(accum=gb.FP32.PLUS, out=cent, desc=D.T0)
+        fn = frontier.nvals
+        # element reads and a duplicate of a matrix that lives as a bitmap
+        dup = W.dup(); e = paths[1, 8]
+        return [matrix_tuples(x) for x in (paths, frontier, W, bcu, S[0], S[2], dup)], cent.to_dense_arrays()[0], fn, e, plans
+    (ta, ca, fa, ea, pa), (tb, cb, fb, eb, pb) = run("0", chain), run("1", chain)
+    assert any("mxm_batch" in x for x in pb) and any("apply_batch" in x for x in pb) and any("ewise_batch" in x for x in pb), pb
+    for k, (x, y) in enumerate(zip(ta, tb)):
+        same(x, y, f"chain result {k}")
+    assert fa == fb and ea == eb and np.allclose(ca, cb, rtol=1e-5, atol=1e-6)
+    # another route out of the bitmap: a non-batch operation on a batch result (select -> the CSR is made on demand)
+    Pt, Qt = mk("FP32", 0.3), mk("FP32", 0.3)
+    def leave():
+        P = to_matrix(Pt); Q = to_matrix(Qt); R = gb.Matrix.sparse(gb.FP32, nr, nc)
+        P.eadd(Q, gb.FP32.PLUS, out=R)
+        return matrix_tuples(R.select(">", 1.0)), matrix_tuples(R.transpose()), R.reduce_float()
+    (sa, tra, ra), (sb, trb, rb) = run("0", leave), run("1", leave)
+    same(sa, sb, "select after a batch result"); same(tra, trb, "transpose after a batch result"); assert abs(ra - rb) <= 1e-5 * abs(ra)
 
 
 def test_unmasked_product_rmat18_by_its_row_sums_and_entry_count(gpu, monkeypatch):

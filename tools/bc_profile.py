@@ -1,5 +1,5 @@
 import sys, os, time, json
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch, numpy as np
 import pygraphblas_amd as gb
 from pygraphblas_amd import rmat, descriptor as D
