@@ -11,6 +11,8 @@
 // compacted into the CSR rows of T.  C<M,replace> = accum(C, T) then runs as for any other mxm.
 #include "grb_opcommon.hpp"
 #include "grb_matops.hpp"
+#include "grb_semiring.hpp"
+#include "grb_spmv.hpp"
 
 extern "C" GrB_Info GrB_vxm(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Semiring semiring, const GrB_Vector u, const GrB_Matrix A,
                             const GrB_Descriptor desc);
@@ -304,6 +306,218 @@ void apply_batch(GrB_Matrix C, int mode, int opcode, int xcode, const uint8_t* s
   g_last_plan = "apply_batch ";
 }
 
+
+// ---- the batch product as ONE pull pass over the matrix (round 6) ---------------------------------------------------------------
+// ns masked pulls of the same matrix read it ns times (the bitmap version of the BC driver at R-MAT-22: 20 launches of k_spmv_adaptive, 535 us each =
+// 10.7 of 13.5 ms).  All ns rows of the batch are multiplied in ONE pass: the operand rows are interleaved position-major — u(i, 0..NSP) side by side,
+// one 16- or 32-byte load per matrix entry, and one byte per position whose bit s says "row s has an entry at i" — the mask rows become one byte per
+// output position (bit s: row s may be written there; a position no row may write is skipped before a matrix byte is read: the late levels of a sweep cost
+// what their unvisited rows cost), a 16-lane group adds a row of the pull operand for all ns accumulators, rows beyond SPB_LONG entries go to a second
+// launch with one workgroup each.  Sums are formed in a fixed order => reproducible.
+constexpr uint32_t SPB_LONG = SPMV_NNZ;         // rows beyond a stream block of the row-block plan
+template <class T, int NSP> __global__ void k_spb_interleave(const T* __restrict__ uval, const uint8_t* __restrict__ upres, uint32_t ns, uint64_t n, T* __restrict__ ui, uint8_t* __restrict__ upm) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t sidx = 0; sidx < (uint32_t)NSP; sidx++) {
+      const bool in = sidx < ns; const bool pr = in && upres[(uint64_t)sidx * n + i] != 0;
+      T v; __builtin_memset(&v, 0, sizeof(T)); if (pr) v = uval[(uint64_t)sidx * n + i];
+      ui[i * NSP + sidx] = v; m |= pr ? (1u << sidx) : 0u;
+    }
+    upm[i] = (uint8_t)m;
+  }
+}
+// bit s of allowm[j]: row s may be written at j — (present && (structural || true-valued)) != complement; no mask: every row
+__global__ void k_spb_allow(const uint8_t* __restrict__ mbool, const uint8_t* __restrict__ mpres, uint32_t ns, uint64_t n, int structural, int comp, uint8_t* __restrict__ allowm) {
+  for (uint64_t j = blockIdx.x * 256ull + threadIdx.x; j < n; j += gridDim.x * 256ull) {
+    uint32_t m = 0;
+    for (uint32_t sidx = 0; sidx < ns; sidx++) {
+      bool a = true;
+      if (mpres) { const uint64_t q = (uint64_t)sidx * n + j; a = (mpres[q] != 0 && (structural || mbool[q] != 0)) != (comp != 0); }
+      m |= a ? (1u << sidx) : 0u;
+    }
+    allowm[j] = (uint8_t)m;
+  }
+}
+__global__ void k_spb_long_rows(const uint32_t* __restrict__ rowptr, const uint8_t* __restrict__ allowm, uint32_t nrows, uint32_t* __restrict__ cnt, uint32_t* __restrict__ list) {
+  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < nrows; j += gridDim.x * 256)
+    if (rowptr[j + 1] - rowptr[j] > SPB_LONG && allowm[j]) list[atomicAdd(cnt, 1u)] = j;
+}
+template <class T, class SR, int NSP> __device__ __forceinline__ void spb_entry(const SR& sr, T a, const T* __restrict__ ui, const uint8_t* __restrict__ upm, uint32_t c, uint32_t am, T (&acc)[NSP], uint32_t& has) {
+  const uint32_t pm = (uint32_t)upm[c] & am;
+  if (!pm) return;
+  T u[NSP];
+#pragma unroll
+  for (int sidx = 0; sidx < NSP; sidx++) u[sidx] = ui[(size_t)c * NSP + sidx];
+#pragma unroll
+  for (int sidx = 0; sidx < NSP; sidx++) if (pm & (1u << sidx)) { const T p = sr.mult(a, u[sidx]); acc[sidx] = (has & (1u << sidx)) ? sr.add(acc[sidx], p) : p; }
+  has |= pm;
+}
+// Stream blocks of the pull operand's row-block plan (grb_spmv.hip: consecutive rows holding <= SPMV_NNZ entries): phase 1 reads the block's entries fully
+// coalesced — 8 column loads, then 8 presence-byte gathers, then the interleaved operand vectors of the entries some row holds, all in flight before the first
+// use — and leaves the NSP products of every entry in LDS; phase 2 gives G lanes to a row (G = the largest power of two with rows * G <= 256), which add their
+// strided share per batch row under the output position's allow bits and combine in a fixed shuffle tree.  (The first version — a 16-lane group walking one
+// row after the other, four dependent round trips per row — took 1.3 ms per pass at R-MAT-22: as long as the four single-row pulls it replaced.)
+template <class T, class SR, int NSP>
+__global__ __launch_bounds__(SPMV_THREADS) void k_spb_blocks(const SpmvBlock* __restrict__ blocks, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const T* __restrict__ aval, uint64_t n,
+                                                            const T* __restrict__ ui, const uint8_t* __restrict__ upm, const uint8_t* __restrict__ allowm, T* __restrict__ tval, uint8_t* __restrict__ tpres,
+                                                            const SR sr) {
+  __shared__ T s_prod[NSP][SPMV_NNZ];
+  __shared__ uint8_t s_pm[SPMV_NNZ];
+  const int tid = threadIdx.x;
+  const SpmvBlock b = blocks[blockIdx.x];
+  if (b.nparts != 0) return;                                   // a part of a long row: k_spb_pull_long's
+  const uint32_t r0 = b.row, r1 = b.aux;
+  {
+    int any = 0;
+    for (uint32_t r = r0 + tid; r < r1; r += SPMV_THREADS) any |= allowm[r];
+    if (!__syncthreads_or(any)) return;                        // no row of the batch may write any of these positions: no matrix traffic (tpres was cleared)
+  }
+  const uint32_t p0 = rowptr[r0], p1 = rowptr[r1], cnt = p1 - p0;
+  if (cnt) {
+    uint32_t c[SPMV_UNROLL]; T av[SPMV_UNROLL]; uint8_t pm[SPMV_UNROLL]; T uv[SPMV_UNROLL][NSP];
+    const bool use_a = aval != nullptr;
+#pragma unroll
+    for (int u = 0; u < SPMV_UNROLL; u++) {
+      const uint32_t k = tid + u * SPMV_THREADS, p = p0 + (k < cnt ? k : cnt - 1);
+      c[u] = col[p]; av[u] = use_a ? aval[p] : T();
+    }
+#pragma unroll
+    for (int u = 0; u < SPMV_UNROLL; u++) pm[u] = upm[c[u]];
+#pragma unroll
+    for (int u = 0; u < SPMV_UNROLL; u++) {
+      if (pm[u]) {
+#pragma unroll
+        for (int sidx = 0; sidx < NSP; sidx++) uv[u][sidx] = ui[(size_t)c[u] * NSP + sidx];
+      } else {
+#pragma unroll
+        for (int sidx = 0; sidx < NSP; sidx++) uv[u][sidx] = T();
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < SPMV_UNROLL; u++) {
+      const uint32_t k = tid + u * SPMV_THREADS;
+      if (k < cnt) {
+        s_pm[k] = pm[u];
+#pragma unroll
+        for (int sidx = 0; sidx < NSP; sidx++) s_prod[sidx][k] = sr.mult(av[u], uv[u][sidx]);
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t nr = r1 - r0;
+  const uint32_t G = nr >= SPMV_THREADS / 2 ? 1u : (nr <= 4 ? 64u : (1u << (31 - __builtin_clz(SPMV_THREADS / nr))));
+  const uint32_t lane = tid & (G - 1), grp = tid / G, ngrp = SPMV_THREADS / G;
+  for (uint32_t rb = 0; rb < nr; rb += ngrp) {
+    const uint32_t r = r0 + rb + grp;
+    const bool live = rb + grp < nr;
+    const uint32_t am = live ? (uint32_t)allowm[r] : 0u;
+    uint32_t qb = 0, qe = 0;
+    if (am) { qb = rowptr[r] - p0; qe = rowptr[r + 1] - p0; }
+    T acc[NSP]; uint32_t has = 0;
+#pragma unroll
+    for (int sidx = 0; sidx < NSP; sidx++) acc[sidx] = sr.identity;
+    for (uint32_t q = qb + lane; q < qe; q += G) {
+      const uint32_t pm = (uint32_t)s_pm[q] & am;
+#pragma unroll
+      for (int sidx = 0; sidx < NSP; sidx++) if (pm & (1u << sidx)) acc[sidx] = (has & (1u << sidx)) ? sr.add(acc[sidx], s_prod[sidx][q]) : s_prod[sidx][q];
+      has |= pm;
+    }
+    if (G > 1) {
+      for (uint32_t d = G >> 1; d >= 1; d >>= 1) {
+        const uint32_t oh = (uint32_t)__shfl_down((int)has, (int)d, 64);
+#pragma unroll
+        for (int sidx = 0; sidx < NSP; sidx++) {
+          const T ov = shfl_down_t<T>(acc[sidx], (int)d);
+          if (oh & (1u << sidx)) acc[sidx] = (has & (1u << sidx)) ? sr.add(acc[sidx], ov) : ov;
+        }
+        has |= oh;
+      }
+    }
+    if (live && lane == 0) {
+#pragma unroll
+      for (int sidx = 0; sidx < NSP; sidx++) if (has & (1u << sidx)) { tval[(uint64_t)sidx * n + r] = acc[sidx]; tpres[(uint64_t)sidx * n + r] = 1; }
+    }
+  }
+}
+template <class T, class SR, int NSP>
+__global__ __launch_bounds__(256) void k_spb_pull_long(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const T* __restrict__ aval, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ list,
+                                                       uint64_t n, const T* __restrict__ ui, const uint8_t* __restrict__ upm, const uint8_t* __restrict__ allowm, T* __restrict__ tval, uint8_t* __restrict__ tpres,
+                                                       const SR sr) {
+  __shared__ T s_acc[4][NSP]; __shared__ uint32_t s_has[4];
+  const uint32_t nl = *cnt, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  for (uint32_t k = blockIdx.x; k < nl; k += gridDim.x) {
+    const uint32_t j = list[k], am = allowm[j], b = rowptr[j], e = rowptr[j + 1];
+    T acc[NSP]; uint32_t has = 0;
+#pragma unroll
+    for (int sidx = 0; sidx < NSP; sidx++) acc[sidx] = sr.identity;
+    for (uint32_t p = b + threadIdx.x; p < e; p += 256u) spb_entry<T, SR, NSP>(sr, aval ? aval[p] : T(), ui, upm, col[p], am, acc, has);
+#pragma unroll
+    for (int sidx = 0; sidx < NSP; sidx++) {
+      T v = (has & (1u << sidx)) ? acc[sidx] : sr.identity;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) v = sr.add(v, shfl_xor_t<T>(v, m));
+      acc[sidx] = v;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) has |= (uint32_t)__shfl_xor((int)has, m, 64);
+    __syncthreads();
+    if (lane == 0) { s_has[wv] = has; for (int sidx = 0; sidx < NSP; sidx++) s_acc[wv][sidx] = acc[sidx]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t hall = s_has[0] | s_has[1] | s_has[2] | s_has[3];
+      for (int sidx = 0; sidx < NSP; sidx++) if (hall & (1u << sidx)) {
+        T v = sr.identity; bool first = true;
+        for (int w = 0; w < 4; w++) if (s_has[w] & (1u << sidx)) { v = first ? s_acc[w][sidx] : sr.add(v, s_acc[w][sidx]); first = false; }
+        tval[(uint64_t)sidx * n + j] = v; tpres[(uint64_t)sidx * n + j] = 1;
+      }
+    }
+  }
+}
+// T (bitmap rows tval / tpres, nr x nout) = batch A (bitmap) (+).(x) op(B) under the mask's rows.  False when this product is not its case.
+static bool spmm_pull_batch(GrB_Matrix A, DevBitmap& ab, GrB_Matrix Mmask, const DescView& dv, GrB_Semiring semiring, GrB_Matrix B, int zcode, uint64_t nout, DevBuf& tval, DevBuf& tpres) {
+  const uint32_t nr = (uint32_t)A->nrows; const uint64_t nin = A->ncols;
+  const size_t zs = type_size(zcode);
+  if (nr > 8 || (zs != 4 && zs != 8) || A->type->code != zcode || zcode == T_BOOL || (nr > 4 ? 8u : 4u) * zs > 32) return false;      // (the products of a block in LDS: <= 64 KB)
+  const char* e = getenv("GRB_MI355X_SPMM"); if (e && atoi(e) == 0) return false;
+  const uint64_t tot = ab.nvals_known ? ab.nvals : count_present(ab.pres.as<uint8_t>(), (uint64_t)nr * nin);
+  ab.nvals = tot; ab.nvals_known = true;
+  // a thin batch (the first level: one entry per row; the last ones): the rows' own direction choice — a push over a handful of rows — beats a pass over the
+  // matrix.  (Measured at R-MAT-22, whole BC driver: one pass for every level 10.2 ms, only for batches of >= 1/256 of the positions 12-13.5 ms, never 13.9 ms: the
+  // per-row route pays two counting kernels and a host round trip per row, so the pass wins from a few thousand entries on.)
+  if (!(e && atoi(e) == 1) && tot * 4096 < (uint64_t)nr * nin) return false;
+  SemiringDesc sd = make_semiring_desc(semiring, /*swap_mult_args=*/true);       // vxm orientation: mult(u(i), B(i, j)); the kernels call mult(matrix value, operand value)
+  DevCSR& R = const_cast<DevCSR&>(dv.tran1 ? (mat_to_device(B), B->csr) : mat_csc(B));            // rows of R = output positions
+  if (R.nrows != nout || R.ncols != nin) return false;
+  spmv_build_plan(R);                                                              // its row blocks (cached with the matrix, shared with kernel A)
+  const bool uses_a = sd.flip ? binop_uses_y(sd.mulop) : binop_uses_x(sd.mulop);
+  DevBuf acast; const void* av = uses_a ? cast_values(zcode, B->type->code, R.val.p, R.nnz, acast) : nullptr;
+  const int NSP = nr <= 4 ? 4 : 8;
+  DevBuf ui((size_t)nin * NSP * zs + 64), upm(nin + 64), allowm(nout + 64), mb, lcnt(16), llist(((size_t)R.nrows / SPB_LONG + 16 + R.nnz / SPB_LONG) * 4 + 64);
+  const uint8_t* mbool = nullptr; const uint8_t* mpres = nullptr;
+  if (Mmask) { mpres = Mmask->bm.pres.as<uint8_t>(); mbool = (const uint8_t*)cast_values(T_BOOL, Mmask->type->code, Mmask->bm.val.p, (uint64_t)nr * nout, mb); }
+  hipLaunchKernelGGL(k_spb_allow, dim3(grid_of(nout)), dim3(256), 0, stream(), mbool, mpres, nr, nout, dv.mask_struct ? 1 : 0, dv.mask_comp ? 1 : 0, allowm.as<uint8_t>());
+  GRB_HIP(hipMemsetAsync(tpres.p, 0, (size_t)nr * nout, stream())); GRB_HIP(hipMemsetAsync(lcnt.p, 0, 16, stream()));
+  hipLaunchKernelGGL(k_spb_long_rows, dim3(grid_of(R.nrows)), dim3(256), 0, stream(), R.rowptr.as<uint32_t>(), allowm.as<uint8_t>(), R.nrows, lcnt.as<uint32_t>(), llist.as<uint32_t>());
+  bool ran = dispatch_type(zcode, [&]<class T>() {
+    if constexpr (sizeof(T) == 4 || sizeof(T) == 8) {
+      auto go = [&](auto NSPc) {
+        constexpr int N = decltype(NSPc)::value;
+        hipLaunchKernelGGL((k_spb_interleave<T, N>), dim3(grid_of(nin)), dim3(256), 0, stream(), (const T*)ab.val.p, ab.pres.as<uint8_t>(), nr, nin, (T*)ui.p, upm.as<uint8_t>());
+        with_semiring<T>(sd, [&](auto sr) {
+          typedef decltype(sr) SR;
+          if (R.plan_nblocks) hipLaunchKernelGGL((k_spb_blocks<T, SR, N>), dim3(R.plan_nblocks), dim3(SPMV_THREADS), 0, stream(), (const SpmvBlock*)R.plan_blocks.p, R.rowptr.as<uint32_t>(), R.col.as<uint32_t>(),
+                                                 (const T*)av, nout, (const T*)ui.p, upm.as<uint8_t>(), allowm.as<uint8_t>(), (T*)tval.p, tpres.as<uint8_t>(), sr);
+          hipLaunchKernelGGL((k_spb_pull_long<T, SR, N>), dim3(2048), dim3(256), 0, stream(), R.rowptr.as<uint32_t>(), R.col.as<uint32_t>(), (const T*)av, lcnt.as<uint32_t>(), llist.as<uint32_t>(), nout,
+                             (const T*)ui.p, upm.as<uint8_t>(), allowm.as<uint8_t>(), (T*)tval.p, tpres.as<uint8_t>(), sr);
+        });
+      };
+      if (NSP == 4) go(std::integral_constant<int, 4>{}); else go(std::integral_constant<int, 8>{});
+    }
+  });
+  GRB_HIP(hipGetLastError());
+  return ran;
+}
 extern thread_local void* g_mxv_dest_val; extern thread_local uint8_t* g_mxv_dest_pres;      // grb_mxv.cpp
 // T = A (+).(x) op(B) under the mask for a batch A (and mask): one GrB_vxm per row on SLICES of the bitmaps, results into the rows of a new bitmap.
 // Writes C itself when the write-back is "C becomes T" (no accumulator; replace, no mask, or an empty C) and returns true; otherwise leaves T as a CSR for
@@ -317,7 +531,9 @@ bool mxm_batch(GrB_Matrix C, GrB_Matrix A, GrB_Matrix Mmask, const DescView& dv,
   const uint64_t npo = (uint64_t)nr * nout;
   DevBuf tval(npo * zs + 64), tpres(npo + 64);
   std::string plans; uint64_t total = 0; bool known = true;
-  for (uint32_t s = 0; s < nr; s++) {
+  const bool one_pass = spmm_pull_batch(A, ab, Mmask, dv, semiring, B, zcode, nout, tval, tpres);
+  if (one_pass) { known = false; plans = "k_spb_blocks (all rows in one pull pass)"; }
+  for (uint32_t s = 0; s < nr && !one_pass; s++) {
     VecGuard tmp;
     GrB_Vector u = view_vector(A->type, nin, (uint8_t*)ab.val.p + (size_t)s * nin * A->type->size, ab.pres.as<uint8_t>() + (size_t)s * nin, false, 0); tmp.v.push_back(u);
     GrB_Vector mv = nullptr;

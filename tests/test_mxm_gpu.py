@@ -430,6 +430,15 @@ def test_batch_matrices_as_bitmaps_match_the_generic_kernels(gpu, monkeypatch):
     for k, (x, y) in enumerate(zip(ta, tb)):
         same(x, y, f"chain result {k}")
     assert fa == fb and ea == eb and np.allclose(ca, cb, rtol=1e-5, atol=1e-6)
+    # ... and with every product of the chain as ONE pull pass over the matrix for all rows of the batch (k_spb_pull), and with none
+    for forced in ("1", "0"):
+        monkeypatch.setenv("GRB_MI355X_SPMM", forced)
+        tc, cc, fc, ec, pc = run("1", chain)
+        assert any("k_spb_blocks" in x for x in pc) == (forced == "1"), pc
+        for k, (x, y) in enumerate(zip(ta, tc)):
+            same(x, y, f"chain result {k}, one-pass products forced {forced}")
+        assert fa == fc and ea == ec and np.allclose(ca, cc, rtol=1e-5, atol=1e-6)
+    monkeypatch.delenv("GRB_MI355X_SPMM")
     # another route out of the bitmap: a non-batch operation on a batch result (select -> the CSR is made on demand)
     Pt, Qt = mk("FP32", 0.3), mk("FP32", 0.3)
     def leave():
