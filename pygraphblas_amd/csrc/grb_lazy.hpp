@@ -29,7 +29,7 @@ void vec_chain_launch(const ChainLaunch& L, void* red_result);       // grb_lazy
 inline bool unop_needs_math_host(int op) { return op >= U_SQRT && op <= U_ISFINITE; }
 
 // grb_chain_jit.cpp: the chain through the kernel hipRTC compiled for its steps (FP32 / FP64); false = run the interpreter.  red: 0 none, 1 in T, 2 FP32 widened
-bool chain_jit_launch(const ChainLaunch& L, bool f32, int red, const void* rid, void* partial, unsigned grid, bool replaces_spec);
+bool chain_jit_launch(const ChainLaunch& L, int tcode, int red, const void* rid, void* partial, unsigned grid, bool replaces_spec);      // tcode: the chain's value type (FP32 / FP64 and the 4- and 8-byte integers)
 void set_nonblocking(bool on);
 void lazy_flush();
 // each returns false when the operation cannot be deferred (the caller then runs it the blocking way)

@@ -275,8 +275,10 @@ template <class T, int RED, class R, int NIN> static void launch_chain(const Cha
   bool launched = false;
   // a floating-point chain that was seen before runs through the kernel hipRTC compiled for exactly its steps (grb_chain_jit.cpp); the two shapes
   // below stay compiled ahead of time (no first-use compilation inside somebody's PageRank loop) unless GRB_MI355X_CHAIN_JIT=2 asks for the comparison
-  if constexpr (std::is_floating_point<T>::value) {
-    if (aligned) launched = chain_jit_launch(L, std::is_same<T, float>::value, RED, RED != 0 ? (const void*)&rid : nullptr, (void*)partial, (unsigned)g, spec != 0);
+  if constexpr (std::is_floating_point<T>::value || (std::is_integral<T>::value && (sizeof(T) == 4 || sizeof(T) == 8))) {
+    constexpr int tcode = std::is_same<T, float>::value ? T_FP32 : std::is_same<T, double>::value ? T_FP64 : std::is_same<T, int32_t>::value ? T_INT32 : std::is_same<T, uint32_t>::value ? T_UINT32
+                        : std::is_same<T, int64_t>::value ? T_INT64 : std::is_same<T, uint64_t>::value ? T_UINT64 : -1;
+    if (aligned && tcode >= 0) launched = chain_jit_launch(L, tcode, RED, RED != 0 ? (const void*)&rid : nullptr, (void*)partial, (unsigned)g, spec != 0);
   }
   if (launched) {}
   else if constexpr (std::is_floating_point<T>::value && NIN == 2 && RED != 0) {

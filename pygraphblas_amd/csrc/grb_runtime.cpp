@@ -80,6 +80,16 @@ void dev_free(void* p) {
   auto it = g_live.find(p);
   if (it == g_live.end()) return;
   size_t sc = it->second; g_live.erase(it); g_in_use -= sc;
+  // The pool keeps at most `cap` bytes of free blocks (round 6; default: half of the device's memory, GRB_MI355X_POOL_MAX_GB): a large block that would
+  // take it beyond goes back to the driver at once.  (Unbounded, a process that had once formed a 43 GB product kept 285 of the 288 GB for good, and a second
+  // process on the same GPU — a test's subprocess, another rank's — could not allocate at all.)  hipFree waits for the device: a block still read by
+  // queued kernels is safe, and only blocks of >= 256 MB ever take this path.
+  static const size_t cap = [] {
+    const char* e = getenv("GRB_MI355X_POOL_MAX_GB"); if (e && *e) return (size_t)atof(e) * (size_t)(1ull << 30);
+    size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); tot = 64ull << 30; }
+    return tot / 2;
+  }();
+  if (sc >= (256ull << 20) && g_cached + sc > cap) { (void)hipFree(p); return; }
   // stream-ordered reuse is safe: every kernel runs on the one library stream
   g_free.emplace(sc, p); g_cached += sc;
 }
@@ -92,6 +102,7 @@ void dev_pool_release() {
   g_free.clear(); g_cached = 0;
 }
 size_t dev_bytes_in_use() { return g_in_use; }
+size_t dev_bytes_cached() { return g_cached; }
 int device_cus() { return g_cus; }
 
 bool check_obj(const void* p) { return p && *(const uint64_t*)p == GRB_MAGIC; }

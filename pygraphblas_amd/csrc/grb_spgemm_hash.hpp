@@ -432,9 +432,15 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
   // rows: dense, many products per step already) takes the direct path.  The B-row boundaries are those of k_spa_split: a product is visited once.
   const bool rank_call = bitmaps != nullptr;
   const uint32_t words = (ncols + 31u) >> 5;
-  uint32_t wpt = 1, csh = 6; while (wpt * 1024u < words) { wpt <<= 1; csh++; }         // bitmap words per thread (<= 8), log2 of the words per wave
-  const uint32_t rk_off = (words * 6u + 15u) & ~15u;
-  uint32_t* const s_bits = (uint32_t*)s_raw; uint16_t* const s_pre = (uint16_t*)(s_raw + (size_t)words * 4);
+  // the slab of a ranked row: the whole row when its bitmap and word prefixes (6 bytes per word) fit 2/5 of the region — and 8 words per thread — else as
+  // many whole blocks as do
+  constexpr uint32_t WBc = WD / 32u;
+  constexpr uint32_t slab_fit = (uint32_t)(((uint64_t)REGION * 2 / 5) / 6) < 8192u ? (uint32_t)(((uint64_t)REGION * 2 / 5) / 6) : 8192u;
+  const uint32_t slabw = words <= slab_fit ? ((words + WBc - 1) / WBc) * WBc : (slab_fit / WBc) * WBc;      // (a multiple of a block's words; >= words when the row is one slab)
+  uint32_t wpt = 1, csh = 6; while (wpt * 1024u < (words < slabw ? words : slabw)) { wpt <<= 1; csh++; }         // bitmap words of a slab per thread (<= 8), log2 of the words per wave
+  const uint32_t swords = words < slabw ? words : slabw;
+  const uint32_t rk_off = (swords * 6u + 15u) & ~15u;
+  uint32_t* const s_bits = (uint32_t*)s_raw; uint16_t* const s_pre = (uint16_t*)(s_raw + (size_t)swords * 4);
   W* const s_racc = (W*)(s_raw + rk_off); const uint32_t W2 = rank_call ? (REGION - rk_off) / (uint32_t)sizeof(W) : 0u;
   constexpr uint32_t WB = WD / 32u; static_assert(WD % 32u == 0, "a block of columns is whole bitmap words");
   bool racc_clean = false;
@@ -449,90 +455,6 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
     const uint32_t i = a.rows[ridx];
     const uint32_t ab = a.arp[i], ae = a.arp[i + 1];
     uint32_t obase = a.crp[i];
-    if (rank_call) {
-      __syncthreads();                                                           // (the row before this one has read its bitmap to the end)
-      const uint32_t* const bm = bitmaps + (size_t)bmslot[i] * words;
-      uint32_t xs[8], run = 0;
-#pragma unroll
-      for (uint32_t q = 0; q < 8; q++) { const uint32_t w = t * wpt + q; xs[q] = (q < wpt && w < words) ? bm[w] : 0u; }
-      uint32_t pl[8];
-#pragma unroll
-      for (uint32_t q = 0; q < 8; q++) { pl[q] = run; run += (uint32_t)__popc(xs[q]); }
-      const uint32_t inc = spa_wave_incl_add(run), wexc = inc - run;
-#pragma unroll
-      for (uint32_t q = 0; q < 8; q++) { const uint32_t w = t * wpt + q; if (q < wpt && w < words) { s_bits[w] = xs[q]; s_pre[w] = (uint16_t)(wexc + pl[q]); } }
-      if (lane == 63) s_wsum[wave] = inc;
-      __syncthreads();
-      uint32_t woff, rtotal, cpre;
-      spa_wave_offsets(s_wsum, lane, wave, woff, rtotal, cpre);
-      if (t < 16) s_woff[t] = cpre;                                              // entries of the row before wave t's words
-      __syncthreads();
-      if (t <= nblk) { const uint32_t w0 = t * WB; s_blk[t] = w0 < words ? s_woff[w0 >> csh] + s_pre[w0] : rtotal; }      // entries before block t
-      __syncthreads();
-      bool ranked = true;
-      for (uint32_t c = 0; c < nblk; c++) ranked = ranked && s_blk[c + 1] - s_blk[c] <= W2;
-      if (ranked) {
-        if (!racc_clean) { for (uint32_t e = t; e < W2; e += 1024) s_racc[e] = idw; racc_clean = true; }      // (the walk's barriers stand between this and the first atomic)
-        struct RProd { uint32_t col; T x; };
-        uint32_t rbase = 0;
-        auto rwalk = [&](uint32_t st, uint32_t len) __attribute__((always_inline)) -> uint32_t {
-          return spa_flat_walk2<ORDERED>(st, len, s_exc, s_shift, s_wtot,
-            [&](uint32_t v, uint32_t pb) { RProd p; p.col = a.bcol[pb]; p.x = sr.mult(use_a ? s_av[v] : T(), use_b ? bval[pb] : T()); return p; },
-            [&](const RProd& p) -> uint32_t { const uint32_t w = p.col >> 5; const uint32_t bits = s_bits[w];
-                                  return s_woff[w >> csh] + s_pre[w] + (uint32_t)__popc(bits & ((1u << (p.col & 31u)) - 1u)) - rbase; },
-            [&](const uint32_t rk, const RProd& p) { word_combine<T>(sr.add_op(), &s_racc[rk], p.x); }, nullptr, &s_turn);
-        };
-        // the entries of blocks [c0, c1): the threads walk their own bitmap words, the rank of a word's first bit is known — no scan, no barrier
-        auto remit = [&](uint32_t c0, uint32_t c1) __attribute__((always_inline)) {
-          const uint32_t wlo = c0 * WB, whi = c1 * WB < words ? c1 * WB : words;
-          for (uint32_t q = 0; q < wpt; q++) {
-            const uint32_t w = t * wpt + q;
-            if (w < wlo || w >= whi) continue;
-            uint32_t bits = s_bits[w];
-            uint32_t rk = s_woff[w >> csh] + s_pre[w];
-            while (bits) {
-              uint32_t bb[4]; bool hs4[4];
-#pragma unroll
-              for (int j = 0; j < 4; j++) { hs4[j] = bits != 0; bb[j] = hs4[j] ? (uint32_t)__builtin_ctz(bits) : 0u; bits &= bits - 1u; }
-              W acc4[4];
-#pragma unroll
-              for (int j = 0; j < 4; j++) acc4[j] = s_racc[(hs4[j] ? rk + j : rk) - rbase];
-#pragma unroll
-              for (int j = 0; j < 4; j++) if (hs4[j]) { ocol[obase + rk] = w * 32u + bb[j]; oval[obase + rk] = from_word<T>(acc4[j]); s_racc[rk - rbase] = idw; rk++; }
-            }
-          }
-        };
-        const bool one_chunk = ae - ab <= SPA_CHUNK;
-        const bool has = one_chunk && t < SPA_CHUNK && ab + t < ae;
-        const uint32_t* const sp0 = has ? split + (size_t)a.acol[ab + t] * (nblk + 1) : split;
-        if (has && use_a) s_av[t] = aval[ab + t];                                // (read by other threads only behind the walk's first barrier)
-        uint32_t c0 = 0, c1 = 1;
-        while (c1 < nblk && s_blk[c1 + 1] - s_blk[c0] <= W2) c1++;
-        uint32_t cur_st = sp0[0], cur_en = sp0[c1];
-        while (c0 < nblk) {
-          uint32_t n1 = c1 < nblk ? c1 + 1 : c1;                                 // the group after this one, its boundary loaded a step ahead
-          while (n1 < nblk && s_blk[n1 + 1] - s_blk[c1 < nblk ? c1 : c0] <= W2) n1++;
-          const uint32_t nxt_en = sp0[n1];
-          rbase = s_blk[c0];
-          if (s_blk[c1] - rbase) {                                               // (no entry in these blocks: no product either)
-            if (one_chunk) rwalk(cur_st, has ? cur_en - cur_st : 0u);
-            else for (uint32_t base = ab; base < ae; base += SPA_CHUNK) {
-              const uint32_t pa = base + t; uint32_t st = 0, len = 0;
-              if (t < SPA_CHUNK && pa < ae) { const uint32_t* sp = split + (size_t)a.acol[pa] * (nblk + 1); st = sp[c0]; len = sp[c1] - st; if (use_a) s_av[t] = aval[pa]; }
-              rwalk(st, len);
-            }
-            remit(c0, c1);
-          }
-          cur_st = cur_en; cur_en = nxt_en; c0 = c1; c1 = n1;
-        }
-        continue;
-      }
-      // a direct row between ranked ones: the region held a bitmap
-      for (uint32_t e = t; e < WD; e += 1024) s_acc[e] = idw;
-      for (uint32_t w = t; w < WD / 4; w += 1024) s_flag[w] = 0;
-      racc_clean = false;
-      __syncthreads();
-    }
     // one chunk of the row's entries (their A values in s_av) against block c (columns lo ...): returns the number of products
     struct Prod { uint32_t rel; T x; };
     auto walk = [&](uint32_t lo, uint32_t st, uint32_t len) __attribute__((always_inline)) -> uint32_t {
@@ -580,6 +502,8 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
       obase += etotal;
       SPA_PF(4)
     };
+    // the blocks [cb0, cb1) of the row through the direct accumulators (the region holds WD accumulators + flag bytes)
+    auto direct_range = [&](uint32_t cb0, uint32_t cb1) __attribute__((always_inline)) {
     if (ae - ab <= SPA_CHUNK) {
       // a row of at most SPA_CHUNK entries — nearly all of them — is one chunk: its B rows and A values stay in place over the blocks, and the
       // boundary of the block after the next is loaded while this block is worked on (consecutive blocks share a boundary).  `nxt` is only
@@ -587,9 +511,9 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
       // long rows' path — the compiler copied it into place, and waited for it, on the spot: a memory latency per step.
       const bool has = t < SPA_CHUNK && ab + t < ae;
       const uint32_t* const sp0 = has ? split + (size_t)a.acol[ab + t] * (nblk + 1) : split;
-      uint32_t cur_st = sp0[0], cur_en = sp0[1], nxt = sp0[nblk > 1 ? 2 : 1];
+      uint32_t cur_st = sp0[cb0], cur_en = sp0[cb0 + 1], nxt = sp0[cb0 + 2 <= nblk ? cb0 + 2 : nblk];
       if (has && use_a) s_av[t] = aval[ab + t];                                  // (read by other threads only behind the walk's first barrier)
-      for (uint32_t c = 0; c < nblk; c++) {
+      for (uint32_t c = cb0; c < cb1; c++) {
         const uint32_t st = cur_st, len = has ? cur_en - cur_st : 0u;
         cur_st = cur_en; cur_en = nxt;
         nxt = sp0[c + 3 <= nblk ? c + 3 : nblk];
@@ -600,7 +524,7 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
         if (products) emit(c * WD);                         // (else nothing of this row falls into this block — the whole workgroup agrees: no emission, no barrier)
       }
     } else {
-      for (uint32_t c = 0; c < nblk; c++) {
+      for (uint32_t c = cb0; c < cb1; c++) {
         uint32_t products = 0;
         for (uint32_t base = ab; base < ae; base += SPA_CHUNK) {
           const uint32_t pa = base + t;
@@ -617,6 +541,106 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
         if (products) emit(c * WD);
       }
     }
+    };
+    if (rank_call) {
+      // Round 6: the row in SLABS of `slabw` bitmap words (<= 2^18 columns: what leaves room for accumulators beside it) — the whole row when it fits, as
+      // in round 5.  A slab's bitmap, word prefixes and block boundaries are loaded like the row's were; ranks are relative to the slab, its entries
+      // follow those of the slabs before it in the result.  A slab without an entry costs one load of its words and no step; a slab one of whose
+      // blocks alone holds more than W2 entries goes block by block (the region re-initialised around it).  So a result of 2^20 columns takes ~4 steps
+      // per row instead of 64 (A@A on R-MAT-20 with edge factor 4: 0.19 s — 7.6 % of the roofline — with the block-by-block path for every row).
+      const uint32_t* const bm = bitmaps + (size_t)bmslot[i] * words;
+      const bool one_chunk = ae - ab <= SPA_CHUNK;
+      const bool has = one_chunk && t < SPA_CHUNK && ab + t < ae;
+      const uint32_t* const sp0 = has ? split + (size_t)a.acol[ab + t] * (nblk + 1) : split;
+      for (uint32_t w_base = 0, cb0 = 0; w_base < words; w_base += slabw, cb0 += slabw / WB) {
+      const uint32_t words_s = words - w_base < slabw ? words - w_base : slabw;
+      const uint32_t nblk_s = nblk - cb0 < slabw / WB ? nblk - cb0 : slabw / WB;
+      __syncthreads();                                                           // (the slab / the row before this one has read its bitmap to the end)
+      uint32_t xs[8], run = 0;
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q++) { const uint32_t w = t * wpt + q; xs[q] = (q < wpt && w < words_s) ? bm[w_base + w] : 0u; }
+      uint32_t pl[8];
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q++) { pl[q] = run; run += (uint32_t)__popc(xs[q]); }
+      const uint32_t inc = spa_wave_incl_add(run), wexc = inc - run;
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q++) { const uint32_t w = t * wpt + q; if (q < wpt && w < words_s) { s_bits[w] = xs[q]; s_pre[w] = (uint16_t)(wexc + pl[q]); } }
+      if (lane == 63) s_wsum[wave] = inc;
+      __syncthreads();
+      uint32_t woff, rtotal, cpre;
+      spa_wave_offsets(s_wsum, lane, wave, woff, rtotal, cpre);
+      if (t < 16) s_woff[t] = cpre;                                              // entries of the slab before wave t's words
+      __syncthreads();
+      if (rtotal == 0) continue;                                                 // (the whole workgroup agrees: nothing of this row falls into the slab)
+      if (t <= nblk_s) { const uint32_t w0 = t * WB; s_blk[t] = w0 < words_s ? s_woff[w0 >> csh] + s_pre[w0] : rtotal; }      // entries before block t of the slab
+      __syncthreads();
+      bool ranked = true;
+      for (uint32_t c = 0; c < nblk_s; c++) ranked = ranked && s_blk[c + 1] - s_blk[c] <= W2;
+      if (ranked) {
+        if (!racc_clean) { for (uint32_t e = t; e < W2; e += 1024) s_racc[e] = idw; racc_clean = true; }      // (the walk's barriers stand between this and the first atomic)
+        struct RProd { uint32_t col; T x; };
+        uint32_t rbase = 0;
+        auto rwalk = [&](uint32_t st, uint32_t len) __attribute__((always_inline)) -> uint32_t {
+          return spa_flat_walk2<ORDERED>(st, len, s_exc, s_shift, s_wtot,
+            [&](uint32_t v, uint32_t pb) { RProd p; p.col = a.bcol[pb]; p.x = sr.mult(use_a ? s_av[v] : T(), use_b ? bval[pb] : T()); return p; },
+            [&](const RProd& p) -> uint32_t { const uint32_t w = (p.col >> 5) - w_base; const uint32_t bits = s_bits[w];
+                                  return s_woff[w >> csh] + s_pre[w] + (uint32_t)__popc(bits & ((1u << (p.col & 31u)) - 1u)) - rbase; },
+            [&](const uint32_t rk, const RProd& p) { word_combine<T>(sr.add_op(), &s_racc[rk], p.x); }, nullptr, &s_turn);
+        };
+        // the entries of the slab's blocks [c0, c1): the threads walk their own bitmap words, the rank of a word's first bit is known — no scan, no barrier
+        auto remit = [&](uint32_t c0, uint32_t c1) __attribute__((always_inline)) {
+          const uint32_t wlo = c0 * WB, whi = c1 * WB < words_s ? c1 * WB : words_s;
+          for (uint32_t q = 0; q < wpt; q++) {
+            const uint32_t w = t * wpt + q;
+            if (w < wlo || w >= whi) continue;
+            uint32_t bits = s_bits[w];
+            uint32_t rk = s_woff[w >> csh] + s_pre[w];
+            while (bits) {
+              uint32_t bb[4]; bool hs4[4];
+#pragma unroll
+              for (int j = 0; j < 4; j++) { hs4[j] = bits != 0; bb[j] = hs4[j] ? (uint32_t)__builtin_ctz(bits) : 0u; bits &= bits - 1u; }
+              W acc4[4];
+#pragma unroll
+              for (int j = 0; j < 4; j++) acc4[j] = s_racc[(hs4[j] ? rk + j : rk) - rbase];
+#pragma unroll
+              for (int j = 0; j < 4; j++) if (hs4[j]) { ocol[obase + rk] = (w_base + w) * 32u + bb[j]; oval[obase + rk] = from_word<T>(acc4[j]); s_racc[rk - rbase] = idw; rk++; }
+            }
+          }
+        };
+        if (has && use_a) s_av[t] = aval[ab + t];                                // (read by other threads only behind the walk's first barrier)
+        uint32_t c0 = 0, c1 = 1;
+        while (c1 < nblk_s && s_blk[c1 + 1] - s_blk[c0] <= W2) c1++;
+        uint32_t cur_st = sp0[cb0], cur_en = sp0[cb0 + c1];
+        while (c0 < nblk_s) {
+          uint32_t n1 = c1 < nblk_s ? c1 + 1 : c1;                               // the group after this one, its boundary loaded a step ahead
+          while (n1 < nblk_s && s_blk[n1 + 1] - s_blk[c1 < nblk_s ? c1 : c0] <= W2) n1++;
+          const uint32_t nxt_en = sp0[cb0 + n1];
+          rbase = s_blk[c0];
+          if (s_blk[c1] - rbase) {                                               // (no entry in these blocks: no product either)
+            if (one_chunk) rwalk(cur_st, has ? cur_en - cur_st : 0u);
+            else for (uint32_t base = ab; base < ae; base += SPA_CHUNK) {
+              const uint32_t pa = base + t; uint32_t st = 0, len = 0;
+              if (t < SPA_CHUNK && pa < ae) { const uint32_t* sp = split + (size_t)a.acol[pa] * (nblk + 1) + cb0; st = sp[c0]; len = sp[c1] - st; if (use_a) s_av[t] = aval[pa]; }
+              rwalk(st, len);
+            }
+            remit(c0, c1);
+          }
+          cur_st = cur_en; cur_en = nxt_en; c0 = c1; c1 = n1;
+        }
+        obase += rtotal;
+        continue;
+      }
+      // a slab that goes block by block between ranked ones: the region held a bitmap
+      __syncthreads();
+      for (uint32_t e = t; e < WD; e += 1024) s_acc[e] = idw;
+      for (uint32_t w = t; w < WD / 4; w += 1024) s_flag[w] = 0;
+      racc_clean = false;
+      __syncthreads();
+      direct_range(cb0, cb0 + nblk_s);
+      }     // slabs of the row
+      continue;
+    }
+    direct_range(0, nblk);
   }
 #ifdef SPA_PROFILE
   if (t == 0) { pf[7] = __builtin_amdgcn_s_memtime() - pf_start; for (int k = 0; k < 16; k++) g_spa_prof[(size_t)(blockIdx.x & 1023) * 16 + k] = pf[k]; }
@@ -673,7 +697,8 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
   // products / entries.  GRB_MI355X_SPA_RANK=0: round 4's bins and kernel.
   constexpr uint32_t WDc = spa_cfg<T>::WD; constexpr uint64_t REGIONc = (uint64_t)WDc * sizeof(W) + WDc;
   const bool rank_env = !(getenv("GRB_MI355X_SPA_RANK") && atoi(getenv("GRB_MI355X_SPA_RANK")) == 0);      // (read per call: a test hook)
-  const bool rank_static = spa && rank_env && (uint64_t)((ncols + 31) / 32) * 6 <= REGIONc * 2 / 5 && ((uint64_t)ncols + WDc - 1) / WDc <= SPA_RANK_MAXBLK;
+  // (round 6: any column range the dense path takes — a row wider than that is ranked slab by slab)
+  const bool rank_static = spa && rank_env && std::min<uint64_t>((REGIONc * 2 / 5) / 6, 8192) / (WDc / 32) >= 1 && std::min<uint64_t>((REGIONc * 2 / 5) / 6, 8192) / (WDc / 32) <= SPA_RANK_MAXBLK;
   // deterministic mode (SpgemmCall::ordered) for a floating-point monoid: only the one-wave table kernel (<= 128 products: a wave's LDS atomics execute in
   // program order) and the dense path with its ordered walk add in a fixed order — every other row goes to the dense path
   const bool ordered = c.ordered && spa && (d.zcode == T_FP32 || d.zcode == T_FP64);
@@ -687,8 +712,17 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
   uint32_t hn[4] = {0, 0, 0, 0};
   DevBuf bitmaps, bmslot, rowctr(64); bool ranked = false;
   GRB_HIP(hipMemsetAsync(rowctr.p, 0, 64, stream()));
-  if (rank_static && hs[4] && (uint64_t)hs[4] * words * 4 <= (12ull << 30)) {      // (the bitmaps of every row beyond the tables: ncols / 8 bytes each, 3.8 GB for A@A on R-MAT-18)
-    bitmaps.alloc((size_t)hs[4] * words * 4 + 16); bmslot.alloc((size_t)nrows * 4 + 16); ranked = true;
+  // the bitmaps of every row beyond the tables: ncols / 8 bytes each — 3.8 GB for A@A on R-MAT-18, 21 GB on R-MAT-20 with edge factor 4; at most a quarter of
+  // the device's memory (GRB_MI355X_SPA_BITMAP_GB), beyond that the rows go block by block as before round 5.  The figure is part of the plan string.
+  uint64_t bitmap_bytes = 0;
+  {
+    size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); tot = 64ull << 30; }
+    const char* eg = getenv("GRB_MI355X_SPA_BITMAP_GB");
+    const uint64_t cap = eg && *eg ? (uint64_t)(atof(eg) * (double)(1ull << 30)) : (uint64_t)tot / 4;
+    if (rank_static && hs[4] && (uint64_t)hs[4] * words * 4 <= cap) {
+      bitmap_bytes = (uint64_t)hs[4] * words * 4;
+      bitmaps.alloc((size_t)bitmap_bytes + 16); bmslot.alloc((size_t)nrows * 4 + 16); ranked = true;
+    }
   }
   with_semiring<T>(d, [&](auto sr) {
     typedef decltype(sr) SR;
@@ -790,7 +824,7 @@ template <class T> void run_spgemm_hash(const SpgemmCall& c, const SemiringDesc&
       }
     }
     g_last_plan += std::string("spgemm_hash<") + (sr.is_static ? "static" : "dynamic") + "> symbolic bins " + std::to_string(hs[0]) + "/" + std::to_string(hs[1]) + "/" + std::to_string(hs[2]) + "/" +
-                   std::to_string(hs[3]) + "/" + std::to_string(hs[4]) + " numeric bins " + std::to_string(hn[0]) + "/" + std::to_string(hn[1]) + "/" + std::to_string(hn[2]) + "/" + std::to_string(hn[3]) + (ranked ? " ranked" : "") + (ordered ? " ordered " : " ");
+                   std::to_string(hs[3]) + "/" + std::to_string(hs[4]) + " numeric bins " + std::to_string(hn[0]) + "/" + std::to_string(hn[1]) + "/" + std::to_string(hn[2]) + "/" + std::to_string(hn[3]) + (ranked ? " ranked (row bitmaps " + std::to_string((bitmap_bytes + (1ull << 29)) >> 30) + " GB)" : "") + (ordered ? " ordered " : " ");
   });
   out.valid = true;
 }

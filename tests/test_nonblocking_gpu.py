@@ -301,15 +301,89 @@ def jit_stats(gb):
     return a[0].value, a[1].value
 
 
-@pytest.mark.parametrize("tname", ["FP32", "FP64"])
-def test_random_programs_through_the_compiled_chains(gb, gpu, tname, monkeypatch):
-    """The random programs of test_random_programs_against_a_model with every floating-point chain compiled by hipRTC at first sight
-    (GRB_MI355X_CHAIN_JIT=2, grb_chain_jit.cpp) instead of run by the interpreter kernel: same numpy model, exact values."""
+@pytest.mark.parametrize("tname", ["FP32", "FP64", "INT32", "INT64", "UINT32", "UINT64"])
+def test_random_programs_through_the_compiled_chains(gb, gpu, tname, monkeypatch, tmp_path):
+    """The random programs of test_random_programs_against_a_model with every chain compiled by hipRTC at first sight
+    (GRB_MI355X_CHAIN_JIT=2, grb_chain_jit.cpp) instead of run by the interpreter kernel: same numpy model, exact values.  Round 6: the 4- and 8-byte
+    integer types too (wrap-around and SuiteSparse's integer division as helper functions of the generated text)."""
     monkeypatch.setenv("GRB_MI355X_CHAIN_JIT", "2")
+    monkeypatch.setenv("GRB_MI355X_CACHE_DIR", str(tmp_path))          # (every kernel really compiled here: an empty cache)
     c0, l0 = jit_stats(gb)
     test_random_programs_against_a_model(gb, gpu, tname)
     c1, l1 = jit_stats(gb)
     assert c1 > c0 and l1 - l0 >= 20, (c0, c1, l0, l1)
+
+
+def test_integer_division_and_wrap_around_rules_survive_the_compiler(gb, gpu, monkeypatch, tmp_path):
+    """The rules of grb_ops.hpp that are not plain C, through compiled integer chains against the interpreter (GRB_MI355X_CHAIN_JIT=0) and numpy: x / 0 saturates
+    by sign, 0 / 0 = 0, INT_MIN / -1 wraps instead of trapping, sums and products wrap modulo 2^bits, ABS(INT_MIN) = INT_MIN, AINV and MINV."""
+    monkeypatch.setenv("GRB_MI355X_CACHE_DIR", str(tmp_path))
+    n = 4096
+    for tname, dt in (("INT32", np.int32), ("INT64", np.int64), ("UINT32", np.uint32), ("UINT64", np.uint64)):
+        T = getattr(gb, tname); info = np.iinfo(dt)
+        rng = np.random.default_rng(11)
+        special = np.array([0, 1, info.max, info.min, info.max - 1, 2, 3] + ([-1, -2, info.min + 1] if info.min < 0 else [info.max // 2]), dtype=dt)
+        xs = rng.choice(special, n).astype(dt); ys = rng.choice(special, n).astype(dt)
+        res = {}
+        for mode in ("0", "2"):
+            monkeypatch.setenv("GRB_MI355X_CHAIN_JIT", mode)
+            x = gb.Vector.from_dense_array(xs.copy(), T); y = gb.Vector.from_dense_array(ys.copy(), T)
+            out = []
+            for opn in ("DIV", "PLUS", "TIMES", "MINUS", "MIN", "MAX", "RDIV"):
+                t = x.emult(y, getattr(T, opn)); t = t.eadd(x, T.PLUS); out.append(t.to_dense_arrays()[0].copy())      # two steps: a chain, not a single kernel
+            for opn in ("ABS", "AINV", "MINV"):
+                t = x.apply(getattr(T, opn)); t = t.emult(y, T.FIRST); out.append(t.to_dense_arrays()[0].copy())
+            t = x.emult(y, T.TIMES); out.append(np.array([t.reduce_int()]))
+            res[mode] = out
+        for k, (a0, a2) in enumerate(zip(res["0"], res["2"])):
+            assert np.array_equal(a0, a2), (tname, k)
+        with np.errstate(over="ignore"):
+            assert np.array_equal(res["2"][1], (xs + ys) + xs) and np.array_equal(res["2"][2], (xs * ys) + xs)                 # numpy integers wrap the same way
+        d0 = res["2"][0] - xs                                                                                                    # the DIV step alone (the PLUS x undone, modulo 2^bits)
+        zero = ys == 0
+        assert np.array_equal(d0[zero & (xs == 0)], np.zeros((zero & (xs == 0)).sum(), dt))
+        assert (d0[zero & (xs > 0)] == info.max).all()
+        if info.min < 0:
+            assert (d0[zero & (xs < 0)] == info.min).all() and (d0[(ys == -1) & (xs == info.min)] == info.min).all()
+
+
+def test_pagerank_loop_gives_the_same_bits_with_and_without_the_chain_compiler(gb, gpu, tmp_path):
+    """gap/prmark.py:17-29 on R-MAT-20 in three processes: GRB_MI355X_CHAIN_JIT=0 (interpreter and ahead-of-time shapes only), the default with an empty code-object
+    cache (its two chains are compiled by hipRTC at their second appearance), and the default again on the cache the second left behind: the rank vectors are the
+    same bits, the third process compiles NOTHING (its kernels come from GRB_MI355X_CACHE_DIR) and still launches through them."""
+    code = r"""
+import sys, json, ctypes as C
+sys.path.insert(0, %r)
+import numpy as np, torch
+import pygraphblas_amd as gb
+from pygraphblas_amd import rmat, loops
+S = 20; n = 1 << S; dev = torch.device("cuda", 0)
+rowptr, col = rmat.csr_torch(S, dev, seed=42); nnz = int(col.numel())
+ones = torch.ones(nnz, dtype=torch.float32, device=dev)
+A = gb.Matrix.from_csr(gb.FP32, n, n, rowptr.data_ptr(), col.data_ptr(), (ones.data_ptr(), nnz), device=True)
+deg = (rowptr[1:] - rowptr[:-1]).to(torch.float32); pres = (deg > 0).to(torch.uint8)
+d = gb.Vector.from_dense_array((deg.data_ptr(), n), gb.FP32, present=pres.data_ptr(), device=True)
+r, its, rdiff = loops.pagerank(A, d, fixed_iterations=12)
+a = [C.c_uint64(0) for _ in range(3)]
+gb.lib.GrBX_chain_jit_stats2(*[C.byref(x) for x in a])
+np.save(sys.argv[1], r.to_dense_arrays()[0])
+print(json.dumps({"rdiff": rdiff, "jit": [v.value for v in a]}))
+""" % ROOT
+    import json
+    cache = tmp_path / "cache"; cache.mkdir()
+    runs = []
+    for k, jit in enumerate(("0", "1", "1")):
+        f = str(tmp_path / f"r{k}.npy")
+        r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=400, env=dict(os.environ, GRB_MI355X_CHAIN_JIT=jit, GRB_MI355X_CACHE_DIR=str(cache)))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        runs.append((json.loads(r.stdout.strip().splitlines()[-1]), np.load(f)))
+    (j0, r0), (j1, r1), (j2, r2) = runs
+    assert np.array_equal(r0.view(np.uint32), r1.view(np.uint32)) and np.array_equal(r1.view(np.uint32), r2.view(np.uint32))
+    assert j0["rdiff"] == j1["rdiff"] == j2["rdiff"]
+    assert j0["jit"] == [0, 0, 0]
+    assert j1["jit"][0] == 2 and j1["jit"][2] == 0 and j1["jit"][1] >= 20, j1            # two chains compiled, none found on disk, the loop launched through them
+    assert j2["jit"][0] == 0 and j2["jit"][2] == 2 and j2["jit"][1] >= 20, j2            # the second start compiles nothing
+    assert len(list(cache.glob("chain-*.co"))) == 2
 
 
 def test_a_chain_outside_the_pagerank_loop_runs_as_fast_as_the_compiled_shapes(gb, gpu, monkeypatch, capsys):

@@ -1,4 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-timeout 900 python -m pytest tests/test_mxm_gpu.py -m gpu -x -q -k "batch or betweenness or few_long" 2>&1 | tail -3
-for i in 1 2; do timeout 300 python tools/workloads.py --scale 22 --what bcfull 2>&1 | tail -1 | cut -c1-220; done
-GRB_MI355X_SPMM=1 timeout 300 python tools/workloads.py --scale 22 --what bcfull 2>&1 | tail -1 | cut -c1-220
+out=gpurun_out/r6aa; mkdir -p $out
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -o aa -- python tools/workloads.py --what aa --aa-scale 20 --aa-edgefactor 4 --aa-methods hash > "$out/aa.json" 2> "$out/prof.err"
+python tools/kstats.py "$out/prof" 40 2>/dev/null | grep -v "at::\|rocclr" | head -14
+find "$out/prof" -name '*kernel_trace.csv' -delete

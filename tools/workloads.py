@@ -12,6 +12,7 @@ from pygraphblas_amd import rmat, descriptor as D
 ap = argparse.ArgumentParser()
 ap.add_argument("--scale", type=int, default=22)
 ap.add_argument("--what", default="bfs,tc,pr,bc")
+ap.add_argument("--aa-edgefactor", type=int, default=16)
 ap.add_argument("--aa-scale", type=int, default=18)
 ap.add_argument("--aa-methods", default="hash,esc")
 ap.add_argument("--reps", type=int, default=3)
@@ -225,7 +226,7 @@ if "bc" in args.what:
 if "aa" in args.what:
     # the unmasked product A @ A (lib.GrB_mxm without a mask, pygraphblas/matrix.py:2572-2583): two-pass LDS-hash Gustavson vs expand/sort/compress
     S = args.aa_scale; m = 1 << S
-    rowptr, col = rmat.csr_torch(S, dev, seed=42, symmetric=True, drop_self_loops=True)
+    rowptr, col = rmat.csr_torch(S, dev, seed=42, edgefactor=args.aa_edgefactor, symmetric=True, drop_self_loops=True)
     nnz = col.numel(); vals = torch.ones(nnz, dtype=torch.float64, device=dev)
     A = gb.Matrix.from_csr(gb.FP64, m, m, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
     dA = (rowptr[1:] - rowptr[:-1]).to(torch.int64); products = int(dA[col.to(torch.int64) & 0xFFFFFFFF].sum())
