@@ -1,5 +1,20 @@
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/r6aa; mkdir -p $out
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -o aa -- python tools/workloads.py --what aa --aa-scale 20 --aa-edgefactor 4 --aa-methods hash > "$out/aa.json" 2> "$out/prof.err"
-python tools/kstats.py "$out/prof" 40 2>/dev/null | grep -v "at::\|rocclr" | head -14
-find "$out/prof" -name '*kernel_trace.csv' -delete
+python /tmp/bfs_first.py 2>/dev/null || true
+cat > /tmp/bfs_first.py <<'PY'
+import os, sys, time
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+import torch
+import pygraphblas_amd as gb
+from pygraphblas_amd import rmat, loops
+S = 22; n = 1 << S; dev = torch.device("cuda", 0)
+rowptr, col = rmat.csr_torch(S, dev, seed=42, symmetric=True, drop_self_loops=True)
+nnz = int(col.numel()); vals = torch.ones(nnz, dtype=torch.bool, device=dev)
+src = int(torch.argmax(rowptr[1:] - rowptr[:-1]))
+for rep in range(3):
+    A = gb.Matrix.from_csr(gb.BOOL, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
+    torch.cuda.synchronize(); t = time.perf_counter(); loops.bfs(A, src); torch.cuda.synchronize(); print("first run on a fresh matrix", rep, round((time.perf_counter() - t) * 1e3, 2), "ms")
+    t = time.perf_counter(); loops.bfs(A, src); torch.cuda.synchronize(); print("   second", round((time.perf_counter() - t) * 1e3, 3), "ms")
+    del A
+PY
+python /tmp/bfs_first.py
+timeout 900 python -m pytest tests -m gpu -x -q -k "transpose or bfs or config2 or companion" 2>&1 | tail -4
