@@ -57,7 +57,12 @@ template <int P> GRB_HD double fx_to_fp(unsigned long long lo, unsigned long lon
   if (neg) { lo = ~lo + 1ull; hi = ~hi + (lo == 0 ? 1ull : 0ull); }
   if (!(lo | hi)) return 0.0;
   const int msb = hi ? 127 - __builtin_clzll(hi) : 63 - __builtin_clzll(lo);
-  const int s = msb + 1 - P;
+  //  a result that is SUBNORMAL in the target type keeps fewer than P bits: its last place is 2^-1074 (double) / 2^-149 (float) — rounding to P
+  // bits first and letting ldexp / the cast to float round again would round twice.  One rounding, at the place the target type really ends.
+  // (A sum whose terms are all -0.0 comes out as +0.0: the integer accumulator has one zero.  IEEE addition would give -0.0; the two compare equal.)
+  int s = msb + 1 - P;
+  { const int smin = (P == 53 ? -1074 : -149) - unit_exp; if (smin > s) s = smin; }
+  if (s > 127) return neg ? -0.0 : 0.0;                      // below half of the smallest subnormal
   unsigned long long mant = lo; int ex = unit_exp;
   if (s > 0) {
     unsigned long long q = s >= 64 ? hi >> (s - 64) : ((lo >> s) | (hi << (64 - s)));

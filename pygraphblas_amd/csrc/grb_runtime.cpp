@@ -375,7 +375,8 @@ extern "C" GrB_Info GrBX_exact_sum_host(const double* terms, uint64_t n, int sig
   for (uint64_t q = 0; q < n; q++) { const double a = fabs(terms[q]); if (!(a <= bound)) bound = a; }       // NaN sticks
   if (!(bound <= std::numeric_limits<double>::max())) return GrB_INVALID_VALUE;
   int H = 0; while ((1ull << H) <= n) H++;
-  const int u = (bound > 0.0 ? ilogb(bound) + 2 : -1074) + H - 126;
+  int u = (bound > 0.0 ? ilogb(bound) + 2 : -1074) + H - 126;
+  if (u < -1074) u = -1074;               // (as k_row_unit_exp: no double has a bit below 2^-1074)
   unsigned long long lo = 0, hi = 0;
   for (uint64_t q = 0; q < n; q++) {
     unsigned long long xl, xh; grb::fx_from_double(terms[q], u, xl, xh);

@@ -712,6 +712,7 @@ template <class T> __global__ __launch_bounds__(256) void k_row_unit_exp(uint32_
   if (top <= 0x7FEFFFFFFFFFFFFFull && amx <= 0x7FEFFFFFFFFFFFFFull && bmx <= 0x7FEFFFFFFFFFFFFFull) {
     const int E = top ? ilogb(__longlong_as_double((long long)top)) + 2 : -1074;
     u = E + (32 - __clz((int)al)) - 126;
+    if (u < -1074) u = -1074;             // (no double has a bit below 2^-1074: a smaller unit would only push subnormal terms beyond the 73-bit shift of fx_from_double)
     if (low != ~0ull) {                    // (no non-zero product at all: every sum is 0)
       int lowbit = ilogb(__longlong_as_double((long long)low)) - 52; if (lowbit < -1074) lowbit = -1074;
       if (lowbit < u) u = FX_NO_EXP;

@@ -78,3 +78,25 @@ def test_non_finite_terms_are_refused():
     arr = (C.c_double * 2)(1.0, float("inf"))
     out, u = C.c_double(), C.c_int()
     assert gb.lib.GrBX_exact_sum_host(arr, C.c_uint64(2), C.c_int(53), C.byref(out), C.byref(u)) != 0
+
+
+def test_subnormal_results_are_rounded_once():
+    """a sum that lands in the subnormal range of its target type is rounded ONCE, at the last place that type really has there (2^-1074 for a
+    double, 2^-149 for an FP32 result) — not to 53 / 24 bits first and then again by ldexp or the cast to float.  Doubles against math.fsum, the 24-bit results against
+    exact rationals rounded to the nearest float32 (ties to even) by numpy."""
+    rng = random.Random(9)
+    tiny = 5e-324
+    cases = [[3 * tiny, 2 * tiny, -tiny], [math.ldexp(1.0, -1060), math.ldexp(1.0, -1074), math.ldexp(1.0, -1073)], [math.ldexp(0.75, -1022), -math.ldexp(0.5, -1022), tiny]]
+    for _ in range(300):
+        cases.append([rng.choice([-1, 1]) * math.ldexp(rng.random() + 0.5, rng.randint(-1074, -1040)) for _ in range(rng.choice([2, 5, 33]))])
+    for terms in cases:
+        got, _ = exact_sum(terms)
+        assert struct.pack("<d", got) == struct.pack("<d", math.fsum(terms)) or (got == 0.0 and math.fsum(terms) == 0.0), terms
+    # FP32 results: products of floats summed exactly, the sum subnormal in float32
+    for _ in range(300):
+        terms = [float(np.float32(rng.choice([-1, 1]) * math.ldexp(rng.random() + 0.5, rng.randint(-149, -128)))) for _ in range(rng.choice([2, 7, 40]))]
+        got, _ = exact_sum(terms, bits=24)
+        exact = sum(Fraction(t) for t in terms)
+        want = float(np.float32(float(exact))) if exact.denominator.bit_length() <= 1000 else None      # the double of the exact sum is itself exact here (few bits, one binade range)
+        assert float(np.float32(got)) == got, terms                                                       # representable in float32
+        assert got == want, (terms, got, want)
