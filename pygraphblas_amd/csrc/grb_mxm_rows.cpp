@@ -284,10 +284,14 @@ void ewise_batch(GrB_Matrix C, GrB_Matrix Mmask, const DescView& dv, GrB_BinaryO
   };
   GrB_Vector va = view(A), vb = B == A ? va : view(B), vm = !Mmask ? nullptr : (Mmask == A ? va : (Mmask == B ? vb : view(Mmask)));
   GrB_Descriptor_opaque d{GRB_MAGIC, dv.replace ? GrB_REPLACE : 0, (dv.mask_comp ? GrB_COMP : 0) | (dv.mask_struct ? GrB_STRUCTURE : 0), 0, 0, 0, 0, 0, 0.0, false, "ewise_batch"};
-  const GrB_Info info = is_union ? GrB_Vector_eWiseAdd_BinaryOp(vc, vm, accum, op, va, vb, &d) : GrB_Vector_eWiseMult_BinaryOp(vc, vm, accum, op, va, vb, &d);
-  if (info != GrB_SUCCESS) { std::string e = vc->err; fail(info, "eWise (batch): " + e); }
-  vec_to_device(vc);                                                  // (completes whatever the non-blocking queue deferred; an empty result gets its cleared bitmap)
-  if (vc->dval.borrowed || vc->dpres.borrowed || vc->dval.bytes < np * C->type->size || vc->dpres.bytes < np) fail(GrB_PANIC, "eWise (batch): the result does not own its buffers");
+  // (C's buffers travel inside vc for the call: should the operation fail, C is left a valid, EMPTY matrix — the C API leaves an output's content undefined after an
+  //  error, not the object)
+  auto c_left_empty = [&] { C->hi.clear(); C->hj.clear(); C->hx.clear(); C->pending.clear(); C->host_valid = true; C->iso_full = false; mat_invalidate_device(C); };
+  GrB_Info info;
+  try { info = is_union ? GrB_Vector_eWiseAdd_BinaryOp(vc, vm, accum, op, va, vb, &d) : GrB_Vector_eWiseMult_BinaryOp(vc, vm, accum, op, va, vb, &d); if (info == GrB_SUCCESS) vec_to_device(vc); }
+  catch (...) { c_left_empty(); throw; }
+  if (info != GrB_SUCCESS) { std::string e = vc->err; c_left_empty(); fail(info, "eWise (batch): " + e); }
+  if (vc->dval.borrowed || vc->dpres.borrowed || vc->dval.bytes < np * C->type->size || vc->dpres.bytes < np) { c_left_empty(); fail(GrB_PANIC, "eWise (batch): the result does not own its buffers"); }
   adopt_bitmap(C, std::move(vc->dval), std::move(vc->dpres), vc->dnvals_known, vc->dnvals);
   g_last_plan = "ewise_batch<" + std::to_string(C->nrows) + " x " + std::to_string(C->ncols) + " as one vector> ";
 }

@@ -95,3 +95,46 @@ def test_min_plus_sweeps_on_sub_panel_plans(gb, graph, monkeypatch, S, own, typ)
         gi, gx = v.to_arrays()
         assert np.array_equal(gi, ov.J) and np.array_equal(gx, ov.X), (sweep, _plan(gb))
     assert seen                                                                              # kernel X on a sub-panel plan ran at least one of the sweeps
+
+
+@pytest.mark.parametrize("S", [1, 4])
+@pytest.mark.parametrize("typ,sr", [("FP64", "PLUS_TIMES"), ("FP32", "PLUS_SECOND"), ("INT64", "MIN_PLUS"), ("UINT32", "PLUS_TIMES")])
+def test_lane_per_piece_layout_matches_the_tile_pipeline(gb, graph, monkeypatch, S, typ, sr):
+    """Round 6's layout experiment (grb_spmv_sell.hpp, `GRB_MI355X_SELL=1`: a lane per piece of a sub-row, chunks of 64 pieces sorted by length inside
+    windows, the steps' records in two spare bits of the column words) against the oracle — integer-valued data: bit-exact in every type whatever order
+    the pieces add in — with one stream per XCD and with four sub-panels per XCD (a table per sub-panel: the kernel walks an XCD's streams one after the
+    other), on the plain store and on the accumulate-into-a-fill store of gap/prmark.py:21-23, twice for the same bits.  The experiment's verdict
+    (slower than the tile pipeline: profiles/r06_spmv_layout_experiment.txt) does not depend on this test; its correctness does."""
+    rp, col = graph
+    n = 1 << SCALE
+    monkeypatch.setenv("GRB_MI355X_SELL", "1"); monkeypatch.setenv("GRB_MI355X_XS", str(S)); monkeypatch.setenv("GRB_MI355X_XOWN", "1")
+    T = getattr(gb, typ); npt = T._np
+    rng = np.random.default_rng(77 + S)
+    vals = rng.integers(1, 8, len(col)).astype(npt)
+    xs = rng.integers(1, 5, n).astype(npt)
+    A = gb.Matrix.from_csr(T, n, n, rp, col, vals)
+    x = gb.Vector.from_dense_array(xs, T)
+    semiring = getattr(T, sr)
+    if sr == "MIN_PLUS":
+        rows = np.repeat(np.arange(n), np.diff(rp.astype(np.int64)))
+        y = np.full(n, np.iinfo(np.int64).max, np.int64); np.minimum.at(y, rows, vals.astype(np.int64) + xs[col.astype(np.int64)].astype(np.int64))
+        pres = (np.diff(rp.astype(np.int64)) > 0).astype(np.uint8)
+    else:
+        y, pres = O.fast_spmv(rp, col, vals.astype(np.float64) if sr == "PLUS_TIMES" else None, xs.astype(np.float64), **({} if sr == "PLUS_TIMES" else {"semiring": "PLUS_SECOND"}))
+    A.mxv(x, semiring=semiring)
+    w = A.mxv(x, semiring=semiring)
+    assert "lane-per-piece" in _plan(gb), _plan(gb)
+    gy, gp = w.to_dense_arrays()
+    assert np.array_equal(gp != 0, pres != 0) and np.array_equal(gy[pres != 0].astype(np.float64), np.asarray(y)[pres != 0].astype(np.float64))
+    again = A.mxv(x, semiring=semiring).to_dense_arrays()[0]
+    assert np.array_equal(again.view(np.uint8), gy.view(np.uint8))
+    if sr != "MIN_PLUS":
+        r2 = gb.Vector.sparse(T, n)
+        r2[:] = 3
+        A.mxv(x, out=r2, accum=T.PLUS, semiring=semiring)
+        g2, p2 = r2.to_dense_arrays()
+        assert p2.all() and np.array_equal(g2.astype(np.float64), 3.0 + np.where(pres != 0, y, 0.0))
+    # the same matrix object with the layout switched off at run time: the tile pipeline on the plan that carries both
+    monkeypatch.setenv("GRB_MI355X_SELL_RUN", "0")
+    t = A.mxv(x, semiring=semiring).to_dense_arrays()[0]
+    assert np.array_equal(t[pres != 0].astype(np.float64), np.asarray(y)[pres != 0].astype(np.float64))

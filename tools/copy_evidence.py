@@ -27,7 +27,7 @@ if os.path.exists(f):
         d = grab(key); r = int(d["TCC_EA0_RDREQ_sum"] * 128); w = int(d["WRITE_SIZE"] * 1024); per[name] = [r, w]; tot += r + w
     j = json.load(open(os.path.join(P, "spmv_pmc_traffic.json")))
     j["hbm_bytes_per_launch"] = tot; j["per_kernel_read_write_bytes"] = per
-    j["history"]["round 5: same kernels, counters re-collected with the round's final library"] = tot
+    j["history"][f"{pre}: same kernels, counters re-collected with the round's final library"] = tot
     j["ratio_to_algorithmic"] = round(tot / j["algorithmic_bytes"], 4)
     json.dump(j, open(os.path.join(P, "spmv_pmc_traffic.json"), "w"), indent=1)
     print("spmv traffic", tot, j["ratio_to_algorithmic"])
