@@ -443,6 +443,8 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
   uint32_t* const s_bits = (uint32_t*)s_raw; uint16_t* const s_pre = (uint16_t*)(s_raw + (size_t)swords * 4);
   W* const s_racc = (W*)(s_raw + rk_off); const uint32_t W2 = rank_call ? (REGION - rk_off) / (uint32_t)sizeof(W) : 0u;
   constexpr uint32_t WB = WD / 32u; static_assert(WD % 32u == 0, "a block of columns is whole bitmap words");
+  constexpr uint32_t CMAX = ((REGION - 5120u) / (8u + (uint32_t)sizeof(W))) & ~7u;      // entries of a row of few entries (the compact rank structure below): 8 B per non-empty word + an accumulator each
+  static_assert(CMAX < 65536u && 8u * CMAX + 5120u + CMAX * sizeof(W) <= REGION, "ranks and slots are 16-bit; the structure fits the region");
   bool racc_clean = false;
   if (!rank_call) {
     for (uint32_t e = t; e < WD; e += 1024) s_acc[e] = idw;
@@ -549,9 +551,66 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
       // blocks alone holds more than W2 entries goes block by block (the region re-initialised around it).  So a result of 2^20 columns takes ~4 steps
       // per row instead of 64 (A@A on R-MAT-20 with edge factor 4: 0.19 s — 7.6 % of the roofline — with the block-by-block path for every row).
       const uint32_t* const bm = bitmaps + (size_t)bmslot[i] * words;
+      const uint32_t rowent = a.crp[i + 1] - obase;
       const bool one_chunk = ae - ab <= SPA_CHUNK;
       const bool has = one_chunk && t < SPA_CHUNK && ab + t < ae;
       const uint32_t* const sp0 = has ? split + (size_t)a.acol[ab + t] * (nblk + 1) : split;
+      // ---- a row of FEW entries in a wide result (round 6): ONE step whatever the column range -----------------------------------------------------
+      // All 2^20-column rows of A@A on R-MAT-20 / edge factor 4 touch every slab, and 63 % of them hold <= 8 832 entries (11 % of the products): four slab
+      // steps of ~10 us for a handful of products each.  Their rank structure need not scale with the columns: only the NON-EMPTY bitmap words are kept —
+      // c_bits / c_pre (entries before the word) / c_widx (which word), in word order — behind an index per chunk of 64 words (a 64-bit mask of its non-empty
+      // words + the slot of its first): rank(j) = c_pre[slot] + popcount(c_bits[slot] below j) with slot = first[chunk] + popcount(mask below the word) —
+      // four LDS reads instead of three — and the accumulators, indexed by rank, need as many slots as the ROW has entries.
+      if (words > slabw && rowent <= CMAX && rowent) {
+        __syncthreads();                                                         // (whatever used the region before is done with it)
+        uint32_t* const c_bits = (uint32_t*)s_raw; uint16_t* const c_pre = (uint16_t*)(s_raw + 4u * CMAX); uint16_t* const c_widx = (uint16_t*)(s_raw + 6u * CMAX);
+        unsigned long long* const c_mask = (unsigned long long*)(s_raw + 8u * CMAX); uint16_t* const c_first = (uint16_t*)(s_raw + 8u * CMAX + 4096u);
+        W* const c_acc = (W*)(s_raw + 8u * CMAX + 5120u);
+        for (uint32_t e = t; e < rowent; e += 1024) c_acc[e] = idw;
+        uint32_t slot_base = 0, ent_base = 0;
+        for (uint32_t base = 0; base < words; base += 8192u) {
+          uint32_t xs[8], nzm = 0, nbits = 0;
+#pragma unroll
+          for (uint32_t q = 0; q < 8; q++) { const uint32_t w = base + t * 8u + q; xs[q] = w < words ? bm[w] : 0u; nzm |= xs[q] ? (1u << q) : 0u; nbits += (uint32_t)__popc(xs[q]); }
+          const uint32_t nzw = (uint32_t)__popc(nzm);
+          const uint32_t inc_w = spa_wave_incl_add(nzw), inc_b = spa_wave_incl_add(nbits);
+          if (lane == 63) { s_wsum[wave] = inc_w; s_woff[wave] = inc_b; }
+          __syncthreads();
+          uint32_t woff_w, tot_w, pre_w, woff_b, tot_b, pre_b;
+          spa_wave_offsets(s_wsum, lane, wave, woff_w, tot_w, pre_w);
+          spa_wave_offsets(s_woff, lane, wave, woff_b, tot_b, pre_b);
+          uint32_t slot = slot_base + woff_w + inc_w - nzw, ent = ent_base + woff_b + inc_b - nbits;
+          const uint32_t chunk = (base >> 6) + (t >> 3);
+          if (base + t * 8u < words) { ((unsigned char*)c_mask)[chunk * 8u + (t & 7u)] = (unsigned char)nzm; if ((t & 7u) == 0) c_first[chunk] = (uint16_t)slot; }
+#pragma unroll
+          for (uint32_t q = 0; q < 8; q++) if (xs[q]) { c_bits[slot] = xs[q]; c_pre[slot] = (uint16_t)ent; c_widx[slot] = (uint16_t)(base + t * 8u + q); slot++; ent += (uint32_t)__popc(xs[q]); }
+          slot_base += tot_w; ent_base += tot_b;
+          __syncthreads();                                                       // (the wave totals are read: the next round may overwrite them)
+        }
+        const uint32_t nzwords = slot_base;
+        struct CProd { uint32_t col; T x; };
+        auto cwalk = [&](uint32_t st, uint32_t len) __attribute__((always_inline)) -> uint32_t {
+          return spa_flat_walk2<ORDERED>(st, len, s_exc, s_shift, s_wtot,
+            [&](uint32_t v, uint32_t pb) { CProd p; p.col = a.bcol[pb]; p.x = sr.mult(use_a ? s_av[v] : T(), use_b ? bval[pb] : T()); return p; },
+            [&](const CProd& p) -> uint32_t { const uint32_t w = p.col >> 5, ch = w >> 6; const unsigned long long m = c_mask[ch];
+                                  const uint32_t sl = (uint32_t)c_first[ch] + (uint32_t)__popcll(m & ((1ull << (w & 63u)) - 1ull));
+                                  return (uint32_t)c_pre[sl] + (uint32_t)__popc(c_bits[sl] & ((1u << (p.col & 31u)) - 1u)); },
+            [&](const uint32_t rk, const CProd& p) { word_combine<T>(sr.add_op(), &c_acc[rk], p.x); }, nullptr, &s_turn);
+        };
+        if (one_chunk) { if (has && use_a) s_av[t] = aval[ab + t]; cwalk(has ? sp0[0] : 0u, has ? sp0[nblk] - sp0[0] : 0u); }
+        else for (uint32_t base = ab; base < ae; base += SPA_CHUNK) {
+          const uint32_t pa = base + t; uint32_t st = 0, len = 0;
+          if (t < SPA_CHUNK && pa < ae) { const uint32_t* sp = split + (size_t)a.acol[pa] * (nblk + 1); st = sp[0]; len = sp[nblk] - st; if (use_a) s_av[t] = aval[pa]; }
+          cwalk(st, len);
+        }
+        // the entries in column order: the non-empty words are in word order, a word's first entry has rank c_pre
+        for (uint32_t sl = t; sl < nzwords; sl += 1024) {
+          uint32_t bits = c_bits[sl], rk = c_pre[sl]; const uint32_t c0 = (uint32_t)c_widx[sl] * 32u;
+          while (bits) { const uint32_t bb = (uint32_t)__builtin_ctz(bits); bits &= bits - 1u; ocol[obase + rk] = c0 + bb; oval[obase + rk] = from_word<T>(c_acc[rk]); rk++; }
+        }
+        racc_clean = false;
+        continue;
+      }
       for (uint32_t w_base = 0, cb0 = 0; w_base < words; w_base += slabw, cb0 += slabw / WB) {
       const uint32_t words_s = words - w_base < slabw ? words - w_base : slabw;
       const uint32_t nblk_s = nblk - cb0 < slabw / WB ? nblk - cb0 : slabw / WB;
