@@ -13,7 +13,7 @@
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 
-template <int G, int DEPTH, bool GATHER, bool PID, bool VALS>
+template <int G, int DEPTH, bool GATHER, bool PID, bool VALS, int GAUX = 0>
 __global__ __launch_bounds__(1024, 1) void k_steps(const uint32_t* __restrict__ cols, const uint8_t* __restrict__ vals, const double* __restrict__ u, uint32_t ulen, uint32_t nmacro, uint32_t cold_thresh,
                                                    unsigned long long* sink) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -47,7 +47,27 @@ __global__ __launch_bounds__(1024, 1) void k_steps(const uint32_t* __restrict__ 
 #pragma unroll
     for (int j = 0; j < G; j++) {
       const uint32_t w = s.c[j];
-      if (GATHER) s.g[j] = __builtin_amdgcn_raw_buffer_load_b64(u_rs, (int)((w & 0xFFFFu) < cold_thresh ? (w >> 3) << 3 : 0xFFFFFFFFu), 0, 0);
+      if (GATHER && GAUX != 100) s.g[j] = __builtin_amdgcn_raw_buffer_load_b64(u_rs, (int)((w & 0xFFFFu) < cold_thresh ? (w >> 3) << 3 : 0xFFFFFFFFu), 0, GAUX);
+      if (GATHER && GAUX == 100) {
+        // the cold lanes one by one through the SCALAR data cache: readlane -> s_load_dwordx2 -> writelane, eight loads in flight
+        typedef __attribute__((address_space(4))) const unsigned long long* kptr;
+        const kptr uk = (kptr)(uintptr_t)u;
+        const bool cold = (w & 0xFFFFu) < cold_thresh;
+        const uint32_t off = (w >> 3);                  // index of the 8-byte value
+        unsigned long long m = __ballot(cold);
+        uint32_t glo = 0, ghi = 0;
+        while (m) {
+          int l[8]; bool ok[8]; unsigned long long x[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) { ok[q] = m != 0; l[q] = ok[q] ? __builtin_ctzll(m) : 0; m &= m - 1; }
+#pragma unroll
+          for (int q = 0; q < 8; q++) { const uint32_t o = ok[q] ? (uint32_t)__builtin_amdgcn_readlane((int)off, l[q]) : 0u; x[q] = uk[o]; }
+#pragma unroll
+          for (int q = 0; q < 8; q++) if (ok[q]) { const uint32_t xl = (uint32_t)x[q], xh = (uint32_t)(x[q] >> 32);
+            asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(glo), "+v"(ghi) : "s"(xl), "s"(xh), "s"(l[q]) : "m0"); }
+        }
+        s.g[j] = v2u{glo, ghi};
+      }
       if (PID) s.p[j] = __builtin_amdgcn_raw_buffer_load_b32(c_rs, (int)((w == 0x12345u) ? lane * 4u : 0xFFFFFFFFu), 0, 0);
     }
   };
@@ -72,14 +92,14 @@ __global__ __launch_bounds__(1024, 1) void k_steps(const uint32_t* __restrict__ 
   if (acc == 0x12345678u) sink[0] = acc;
 }
 
-template <int G, int DEPTH, bool GATHER, bool PID, bool VALS>
+template <int G, int DEPTH, bool GATHER, bool PID, bool VALS, int GAUX = 0>
 static void run(const char* name, const uint32_t* cols, const uint8_t* vals, const double* u, uint32_t ulen, uint32_t nsteps, uint32_t cold_pct, unsigned long long* sink) {
   const uint32_t nmacro = nsteps / G, thresh = 65536u * cold_pct / 100u;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 2; i++) hipLaunchKernelGGL((k_steps<G, DEPTH, GATHER, PID, VALS>), dim3(256), dim3(1024), 0, 0, cols, vals, u, ulen, nmacro, thresh, sink);
+  for (int i = 0; i < 2; i++) hipLaunchKernelGGL((k_steps<G, DEPTH, GATHER, PID, VALS, GAUX>), dim3(256), dim3(1024), 0, 0, cols, vals, u, ulen, nmacro, thresh, sink);
   hipEventRecord(e0, 0);
   const int reps = 10;
-  for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k_steps<G, DEPTH, GATHER, PID, VALS>), dim3(256), dim3(1024), 0, 0, cols, vals, u, ulen, nmacro, thresh, sink);
+  for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k_steps<G, DEPTH, GATHER, PID, VALS, GAUX>), dim3(256), dim3(1024), 0, 0, cols, vals, u, ulen, nmacro, thresh, sink);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms = 0; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
   const double bytes = (double)nmacro * G * (256.0 + (VALS ? 512.0 : 0.0));
@@ -116,6 +136,17 @@ int main(int argc, char** argv) {
   run<4, 4, true, false, true>("16B loads + 4 gathers per macro-step", cols, vals, u, ulen, nsteps, cp, sink);
   run<4, 8, true, false, true>("16B loads + 4 gathers per macro-step", cols, vals, u, ulen, nsteps, cp, sink);
   run<4, 8, true, true, true>("16B loads + 4 gathers + 4 oor per macro-step", cols, vals, u, ulen, nsteps, cp, sink);
+  // round 6, second look: the cache-policy bits of the GATHER instruction (aux: 1 = sc0, 2 = nt, 16 = sc1) — does any of them make a cold gather cheaper than a 128-byte L2->L1 line?
+  run<1, 16, true, false, true, 1>("+ gather per step, sc0", cols, vals, u, ulen, nsteps, cp, sink);
+  run<1, 16, true, false, true, 2>("+ gather per step, nt", cols, vals, u, ulen, nsteps, cp, sink);
+  run<1, 16, true, false, true, 3>("+ gather per step, sc0 nt", cols, vals, u, ulen, nsteps, cp, sink);
+  run<1, 16, true, false, true, 16>("+ gather per step, sc1", cols, vals, u, ulen, nsteps, cp, sink);
+  run<1, 16, true, false, true, 17>("+ gather per step, sc0 sc1", cols, vals, u, ulen, nsteps, cp, sink);
+  run<1, 16, true, false, true, 18>("+ gather per step, sc1 nt", cols, vals, u, ulen, nsteps, cp, sink);
+  run<1, 16, true, false, true, 19>("+ gather per step, sc0 sc1 nt", cols, vals, u, ulen, nsteps, cp, sink);
+  run<1, 16, true, false, true, 100>("+ cold lanes through the scalar cache", cols, vals, u, ulen, nsteps, cp, sink);
+  run<1, 8, true, false, true, 100>("+ cold lanes through the scalar cache", cols, vals, u, ulen, nsteps, cp, sink);
+  run<1, 16, true, false, false, 100>("column words + cold lanes through the scalar cache", cols, vals, u, ulen, nsteps, cp, sink);
   run<1, 16, false, false, false>("column words only, 4B per lane", cols, vals, u, ulen, nsteps, cp, sink);
   run<4, 8, false, false, false>("column words only, 16B per lane", cols, vals, u, ulen, nsteps, cp, sink);
   run<1, 16, true, false, false>("column words 4B + gather", cols, vals, u, ulen, nsteps, cp, sink);
