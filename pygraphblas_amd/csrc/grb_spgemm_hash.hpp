@@ -445,6 +445,7 @@ __global__ __launch_bounds__(1024) void k_spgemm_spa_numeric(const HashArgs a, c
   constexpr uint32_t WB = WD / 32u; static_assert(WD % 32u == 0, "a block of columns is whole bitmap words");
   constexpr uint32_t CMAX = ((REGION - 5120u) / (8u + (uint32_t)sizeof(W))) & ~7u;      // entries of a row of few entries (the compact rank structure below): 8 B per non-empty word + an accumulator each
   static_assert(CMAX < 65536u && 8u * CMAX + 5120u + CMAX * sizeof(W) <= REGION, "ranks and slots are 16-bit; the structure fits the region");
+  static_assert(SPA_SYM_WORDS / 64u * 8u <= 4096u && SPA_SYM_WORDS / 64u * 2u <= 1024u && SPA_SYM_WORDS <= 65536u, "the chunk index of the compact rank structure (4096 B of masks, 1024 B of first slots, 16-bit word numbers) covers every column range the dense path takes");
   bool racc_clean = false;
   if (!rank_call) {
     for (uint32_t e = t; e < WD; e += 1024) s_acc[e] = idw;

@@ -1,6 +1,12 @@
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/r6bfs; mkdir -p $out
-timeout 400 rocprofv3 --kernel-trace --output-format csv -d "$out/prof" -o bfs -- python tools/bfs_probe.py --only-async > "$out/bfs.txt" 2> "$out/prof.err"
-grep -v amdgpu.ids $out/bfs.txt | head -30
-python tools/ktimeline.py "$out/prof" 45
-find "$out/prof" -name '*kernel_trace.csv' -delete
+for rep in 1 2 3; do
+  for lib in .ab/libgrb_r5.so pygraphblas_amd/libgrb_mi355x.so; do
+    echo "== $lib"
+    GRB_MI355X_LIB=$GRAFT_REPO_ROOT/$lib timeout 200 python tools/bfs_probe.py --only-async 2>&1 | grep -E "total"
+    GRB_MI355X_LIB=$GRAFT_REPO_ROOT/$lib timeout 200 python tools/sssp_probe.py --only-async 2>&1 | grep -E "total"
+  done
+done
+for lib in .ab/libgrb_r5.so pygraphblas_amd/libgrb_mi355x.so; do
+  echo "== $lib"
+  GRB_MI355X_LIB=$GRAFT_REPO_ROOT/$lib timeout 300 python tools/workloads.py --what bfs,pr 2>/dev/null | cut -c1-330
+done
