@@ -551,6 +551,60 @@ def test_unmasked_product_rmat18_sampled_rows_against_the_oracle(gpu, monkeypatc
     assert np.allclose(gv, wv, rtol=1e-6, atol=0.0), float(np.abs(gv / wv - 1).max())
 
 
+@pytest.mark.parametrize("typ", ["FP64", "INT64", "FP32", "INT32"])
+def test_unmasked_wide_results_every_row_kind_at_the_boundaries_against_the_oracle(gpu, monkeypatch, typ):
+    """Round 6: the dense path of the unmasked product for results WIDER than one LDS slab (> 2^18 columns), every row kind at its boundaries, whole rows
+    against the oracle's generic mxm: rows of few entries (the compact rank structure: <= 8 896 entries with 8-byte accumulators, <= 11 520 with 4-byte
+    ones — counts at the limit, one below, one above), rows ranked slab by slab (around the ~12 300 / ~25 000 accumulators of a slab), rows beyond that
+    (block by block), a row of A with more entries than one walk takes (> 992), at 2^18 + 64 columns (the second slab holds two words), 2^19 and 2^20.
+    Values are small integers or eighths (every product and sum exact), so integer AND floating-point results are compared bit for bit; the
+    deterministic mode and the block-by-block kernel of rounds 3-5 (GRB_MI355X_SPA_RANK=0) run the same cases."""
+    rng = np.random.default_rng(77)
+    cmax = 8896 if typ in ("FP64", "INT64") else 11520
+    counts = [1100, 5000] + [cmax + d for d in (-8, -1, 0, 1, 8)] + [12000, 12280, 12296, 12400, 20000, 24500, 25100, 26000, 33000, 60000]
+    monkeypatch.setenv("GRB_MI355X_SPGEMM", "hash")
+    for N in ((1 << 18) + 64, 1 << 19, 1 << 20):
+        nb = 3 * len(counts) + 1500
+        bi, bj = [], []
+        ai, aj = [], []
+        for r, cnt in enumerate(counts):
+            e = cnt // 2; o = cnt - e
+            top = r % 3 == 1                                         # every third row keeps to the top of the column range: the slabs before the last hold nothing of it
+            def pick(k, parity):
+                span = min(N // 2, max(2 * cnt, N // 64)) if top else N // 2
+                sel = np.sort(rng.choice(span, k, replace=False)).astype(np.uint64)
+                half = (np.uint64(N // 2 - 1) - sel[::-1]) if top else sel
+                return half * np.uint64(2) + np.uint64(parity)
+            even, odd = pick(e, 0), pick(o, 1)
+            again = np.sort(rng.choice(odd, o // 2, replace=False))
+            for k, cols in enumerate((even, odd, again)):
+                bi.append(np.full(len(cols), 3 * r + k, np.uint64)); bj.append(cols)
+            ai.append(np.full(3, r, np.uint64)); aj.append(np.arange(3 * r, 3 * r + 3, dtype=np.uint64))
+        # ... and a row of A with 1 500 entries (two walks), its B rows of eight random columns each
+        base = 3 * len(counts)
+        for k in range(1500):
+            bi.append(np.full(8, base + k, np.uint64)); bj.append(np.sort(rng.choice(N, 8, replace=False)).astype(np.uint64))
+        ai.append(np.full(1500, len(counts), np.uint64)); aj.append(np.arange(base, base + 1500, dtype=np.uint64))
+        bi, bj, ai, aj = (np.concatenate(x) for x in (bi, bj, ai, aj))
+        vals = lambda k: (rng.integers(1, 50, k).astype(O.NP[typ]) if typ.startswith("INT") else (rng.integers(4, 36, k) / 8.0).astype(O.NP[typ]))      # (eighths: products and sums are exact in either precision, fused or not)
+        m = len(counts) + 1
+        At = O.Tuples(typ, m, nb, ai, aj, vals(len(ai))); Bt = O.Tuples(typ, nb, N, bi, bj, vals(len(bi)))
+        empty = O.Tuples(typ, m, N, np.zeros(0, np.uint64), np.zeros(0, np.uint64), np.zeros(0, O.NP[typ]))
+        exp = O.mxm(empty, At, Bt, "PLUS", "TIMES", typ)
+        lens = np.bincount(exp.I.astype(np.int64), minlength=m)
+        assert (lens[:len(counts)] > 0).all() and lens[2] == cmax - 8 and lens[4] == cmax and lens[5] == cmax + 1, lens[:8]
+        for env in ({}, {"GRB_MI355X_DETERMINISTIC": "1"}, {"GRB_MI355X_SPA_RANK": "0"}):
+            for k in ("GRB_MI355X_DETERMINISTIC", "GRB_MI355X_SPA_RANK"): monkeypatch.delenv(k, raising=False)
+            for k, v in env.items(): monkeypatch.setenv(k, v)
+            got = to_matrix(At).mxm(to_matrix(Bt), semiring=getattr(TYPE[typ], "PLUS_TIMES"))
+            plan = gb.last_kernel_plan()
+            assert "spgemm_hash" in plan and ("ranked" in plan) == ("GRB_MI355X_SPA_RANK" not in env), plan
+            g = matrix_tuples(got)
+            what = f"{typ} N={N} env={env} [{plan}]"
+            assert np.array_equal(g.I, exp.I) and np.array_equal(g.J, exp.J), "pattern differs " + what
+            assert np.array_equal(g.X, exp.X), "values differ (bit-exact) " + what
+
+
 def test_deterministic_mode_of_the_unmasked_product_small_against_the_oracle(gpu, monkeypatch):
     """GRB_MI355X_DETERMINISTIC=1 (or the descriptor's GxB_AxB_GUSTAVSON): every row beyond 128 products goes through the dense path's ordered walk.  Same
     pattern and values (1e-12: another order of the same terms) as the oracle's ascending-k Gustavson, on a graph small enough for the generic restatement."""

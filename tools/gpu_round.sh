@@ -4,7 +4,7 @@ set -u
 tag=${1:-r03}; shift || true
 out=gpurun_out/$tag; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-timeout 900 python -m pytest tests -m gpu -x -q --timeout 600 --durations=8 "$@" > "$out/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$out/pytest_gpu.log"
+timeout 2400 python -m pytest tests -m gpu -x -q --timeout 600 --durations=8 "$@" > "$out/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$out/pytest_gpu.log"
 tail -14 "$out/pytest_gpu.log"
 timeout 400 python bench.py > "$out/bench_line.json" 2> "$out/bench.err"; echo "bench rc=$?"; tail -3 "$out/bench.err"
 cat "$out/bench_line.json"

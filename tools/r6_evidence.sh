@@ -16,7 +16,7 @@ GRB_MI355X_SPA_RANK=0 timeout 300 python tools/workloads.py --what aa --aa-scale
 python - $out <<'PY' > $out/aa_kernel_stats.txt
 import csv, glob, sys
 out = sys.argv[1]
-for tag, title in (("aa_kt", "symmetric R-MAT-18 (edge factor 16)"), ("aa_kt_wide", "symmetric R-MAT-20 (edge factor 4): 2^20 columns, ranked rows slab by slab")):
+for tag, title in (("aa_kt", "symmetric R-MAT-18 (edge factor 16)"), ("aa_kt_wide", "symmetric R-MAT-20 (edge factor 4): 2^20 columns, ranked rows slab by slab, rows of few entries in one step")):
     print(f"A @ A (unmasked GrB_mxm), {title}, FP64 PLUS_TIMES, two-pass hash path: rocprofv3 --kernel-trace --stats of tools/workloads.py --what aa --aa-methods hash (3 products)")
     for l in open(f"{out}/{tag}.log"):
         if l.startswith("{"): print("  ", l.strip()[:700])
