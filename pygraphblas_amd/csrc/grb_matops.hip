@@ -330,4 +330,31 @@ void csr_dense_fill(uint32_t nrows, uint32_t ncols, const void* scalar, size_t t
   out.valid = true;
 }
 
+// ---- positional unary operators (GxB_POSITIONI / I1 / J / J1, round 6; pygraphblas/unaryop.py:55-63): an entry's value becomes its row or column index -----
+// which: 0 row, 1 row + 1, 2 column, 3 column + 1.  Z = int32_t / int64_t.
+template <class Z> static __global__ void k_u32_to_index(const uint32_t* __restrict__ src, uint64_t n, Z add, Z* __restrict__ dst) {
+  for (uint64_t e = blockIdx.x * 256ull + threadIdx.x; e < n; e += gridDim.x * 256ull) dst[e] = (Z)src[e] + add;
+}
+template <class Z> static __global__ void k_index_fill(uint64_t n, int which, Z* __restrict__ dst) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) dst[i] = which < 2 ? (Z)i + (Z)which : (Z)(which - 2);
+}
+void csr_position_values(int zcode, const DevCSR& A, int which, void* out) {
+  if (!A.nnz) return;
+  DevBuf rowidx; const uint32_t* src = A.col.as<uint32_t>();
+  if (which < 2) { rowidx.alloc(A.nnz * 4 + 4); csr_row_indices(A, rowidx.as<uint32_t>()); src = rowidx.as<uint32_t>(); }
+  const unsigned g = grid_n(A.nnz);
+  if (zcode == T_INT32) hipLaunchKernelGGL((k_u32_to_index<int32_t>), dim3(g), dim3(256), 0, stream(), src, A.nnz, (int32_t)(which & 1), (int32_t*)out);
+  else hipLaunchKernelGGL((k_u32_to_index<int64_t>), dim3(g), dim3(256), 0, stream(), src, A.nnz, (int64_t)(which & 1), (int64_t*)out);
+  GRB_HIP(hipGetLastError());
+}
+// the same for a vector (an n x 1 column): row = the index, column = 0
+void vec_position_values(int zcode, uint64_t n, int which, void* out) {
+  if (!n) return;
+  const unsigned g = grid_n(n);
+  if (zcode == T_INT32) hipLaunchKernelGGL((k_index_fill<int32_t>), dim3(g), dim3(256), 0, stream(), n, which, (int32_t*)out);
+  else hipLaunchKernelGGL((k_index_fill<int64_t>), dim3(g), dim3(256), 0, stream(), n, which, (int64_t*)out);
+  GRB_HIP(hipGetLastError());
+}
+
+
 }  // namespace grb

@@ -19,6 +19,9 @@ bool csr_reduce_cols_few_rows(int code, const DevCSR& A, const void* aval, int o
 uint64_t csr_find_entry(const DevCSR& A, uint32_t i, uint32_t j);        // position of (i, j) in col / val, ~0 when not stored (one host round trip)
 void csr_row_indices(const DevCSR& A, uint32_t* rowidx);
 void csr_dense_fill(uint32_t nrows, uint32_t ncols, const void* scalar, size_t ts, DevCSR& out);     // every position holds `scalar`: rowptr[i] = i ncols, col[e] = e mod ncols
+// positional unary operators (GxB_POSITIONI / I1 / J / J1): the row (which 0 / 1: + 1) or column (2 / 3) index of every entry of A as INT32 / INT64 values; the same for the n positions of a vector
+void csr_position_values(int zcode, const DevCSR& A, int which, void* out);
+void vec_position_values(int zcode, uint64_t n, int which, void* out);
 
 // ---- SpGEMM ----------------------------------------------------------------------------------------------
 struct SpgemmCall {

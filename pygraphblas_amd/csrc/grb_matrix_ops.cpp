@@ -184,6 +184,18 @@ void do_apply(GrB_Matrix C, GrB_Matrix M, GrB_BinaryOp accum, int mode, int opco
   const DescView dv(desc);
   const uint64_t r = dv.tran0 ? A->ncols : A->nrows, c = dv.tran0 ? A->nrows : A->ncols;
   if (C->nrows != r || C->ncols != c || (M && (M->nrows != r || M->ncols != c))) fail(GrB_DIMENSION_MISMATCH, "apply: dimensions do not conform");
+  if (mode == 0 && opcode >= U_POSITIONI && opcode <= U_POSITIONJ1) {      // positional: T has op(A)'s pattern, the values are the entries' row / column indices in the operator's type
+    if (!M && dv.mask_comp) { if (dv.replace) GrB_Matrix_clear(C); return; }
+    const DevCSR& S = operand(A, dv.tran0);
+    DevCSR T; T.nrows = S.nrows; T.ncols = S.ncols; T.nnz = S.nnz;
+    T.rowptr.alloc(((size_t)S.nrows + 1) * 4); T.col.alloc(S.nnz * 4 + 4); T.val.alloc(S.nnz * type_size(xcode) + 8);
+    GRB_HIP(hipMemcpyAsync(T.rowptr.p, S.rowptr.p, ((size_t)S.nrows + 1) * 4, hipMemcpyDeviceToDevice, stream()));
+    if (S.nnz) GRB_HIP(hipMemcpyAsync(T.col.p, S.col.p, S.nnz * 4, hipMemcpyDeviceToDevice, stream()));
+    csr_position_values(xcode, S, opcode - U_POSITIONI, T.val.p);
+    T.valid = true;
+    matrix_write_back(C, T, xcode, M, dv, accum, false);
+    return;
+  }
   if (!M && !accum && !dv.mask_comp && !dv.tran0 && A->bm.valid && !A->host_valid && batch_wanted(C, mat_nvals(A)) && A->type->code < T_FC32) {      // a batch that lives as a bitmap stays one
     uint8_t s16[16] = {0}; if (scalar) cast_scalar(xcode, s16, scode, scalar);
     apply_batch(C, mode, opcode, xcode, s16, A); return;
@@ -333,7 +345,7 @@ GrB_Info GrB_Matrix_eWiseMult_Semiring(GrB_Matrix C, const GrB_Matrix M, const G
   MAT_GUARD(C); if (!op || !A || !B) return GrB_NULL_POINTER; if (!check_obj(op)) return GrB_UNINITIALIZED_OBJECT; return guarded(C, [&] { do_ewise(C, M, accum, op->mul, A, B, desc, false); }); }
 GrB_Info GrB_Matrix_apply(GrB_Matrix C, const GrB_Matrix M, const GrB_BinaryOp accum, const GrB_UnaryOp op, const GrB_Matrix A, const GrB_Descriptor desc) {
   MAT_GUARD(C); if (!op || !A) return GrB_NULL_POINTER; if (!check_obj(op)) return GrB_UNINITIALIZED_OBJECT;
-  return guarded(C, [&] { if (op->opcode >= U_POSITIONI) not_implemented("positional / user-defined unary operator"); do_apply(C, M, accum, 0, op->opcode, op->xtype->code, nullptr, 0, A, desc); });
+  return guarded(C, [&] { if (op->opcode >= U_USER) not_implemented("user-defined unary operator"); do_apply(C, M, accum, 0, op->opcode, op->xtype->code, nullptr, 0, A, desc); });
 }
 GrB_Info GxB_Matrix_select(GrB_Matrix C, const GrB_Matrix M, const GrB_BinaryOp accum, const GxB_SelectOp op, const GrB_Matrix A, const GxB_Scalar thunk, const GrB_Descriptor desc) {
   MAT_GUARD(C); if (!op || !A) return GrB_NULL_POINTER; return guarded(C, [&] { do_select(C, M, accum, op, A, thunk, desc); });

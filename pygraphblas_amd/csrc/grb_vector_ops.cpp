@@ -8,6 +8,7 @@
 #include <algorithm>
 #include "grb_opcommon.hpp"
 #include "grb_lazy.hpp"
+#include "grb_matops.hpp"
 
 using namespace grb;
 
@@ -205,6 +206,22 @@ static void vec_apply_op(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, int 
   vector_write_back(w, opxcode, tval, tpres, allow, accum, dv.replace, false, u->dnvals_known ? u->dnvals : ~0ull);     // apply keeps the pattern
 }
 
+// positional unary operators on a vector (an n x 1 column): the pattern of u, the values are the index (which 0 / 1: + 1) or the column 0 (2 / 3: + 1)
+static void vec_position_op(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, int which, int zcode, GrB_Vector u, GrB_Descriptor desc) {
+  need_device();
+  if (!check_obj(u) || (mask && !check_obj(mask))) fail(GrB_UNINITIALIZED_OBJECT, "apply: uninitialised operand");
+  const DescView dv(desc); const uint64_t n = w->n;
+  if (u->n != n || (mask && mask->n != n)) fail(GrB_DIMENSION_MISMATCH, "apply: vector sizes differ");
+  DevBuf allow_buf; bool nothing = false;
+  const uint8_t* allow = vector_allow(mask, dv, n, allow_buf, &nothing);
+  if (nothing) { if (dv.replace) GrB_Vector_clear(w); return; }
+  vec_to_device(u);
+  DevBuf tval(n * type_size(zcode) + 1), tpres(n + 1);
+  vec_position_values(zcode, n, which, tval.p);
+  if (n) GRB_HIP(hipMemcpyAsync(tpres.p, u->dpres.p, n, hipMemcpyDeviceToDevice, stream()));
+  vector_write_back(w, zcode, tval, tpres, allow, accum, dv.replace, false, u->dnvals_known ? u->dnvals : ~0ull);
+}
+
 #define VEC_GUARD(w) if (!(w)) return GrB_NULL_POINTER; if (!check_obj(w)) return GrB_UNINITIALIZED_OBJECT
 
 extern "C" {
@@ -224,7 +241,8 @@ GrB_Info GrB_Vector_eWiseMult_Semiring(GrB_Vector w, const GrB_Vector mask, cons
 
 GrB_Info GrB_Vector_apply(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_UnaryOp op, const GrB_Vector u, const GrB_Descriptor desc) {
   VEC_GUARD(w); if (!op || !u) return GrB_NULL_POINTER; if (!check_obj(op)) return GrB_UNINITIALIZED_OBJECT;
-  return guarded(w, [&] { if (op->opcode >= U_POSITIONI) not_implemented("positional / user-defined unary operator");
+  return guarded(w, [&] { if (op->opcode >= U_USER) not_implemented("user-defined unary operator");
+    if (op->opcode >= U_POSITIONI) { vec_position_op(w, mask, accum, op->opcode - U_POSITIONI, op->ztype->code, u, desc); return; }
     vec_apply_op(w, mask, accum, 0, op->opcode, op->xtype->code, op->ztype->code, nullptr, 0, u, desc); });
 }
 

@@ -82,6 +82,44 @@ def test_select_transpose_pattern_reduce_vector(gpu):
     assert gb.Matrix.sparse(gb.INT64, 5, 5).reduce_int() == 0
 
 
+def test_positional_unary_operators(gpu):
+    """GxB_POSITIONI / POSITIONI1 / POSITIONJ / POSITIONJ1 (INT32, INT64; the reference lists them in pygraphblas/unaryop.py:55-63 and its notebooks use
+    `A.apply(INT64.POSITIONJ)`, `A.positioni1()`): the result has the operand's pattern, an entry's value is its row / column index (0- or 1-based) in
+    op(A) — whatever type the operand holds — and goes through the usual mask / accumulator / replace write-back.  A vector is an n x 1 column."""
+    rng = np.random.default_rng(41)
+    nr, nc = 70, 45
+    ii, jj = np.meshgrid(np.arange(nr), np.arange(nc), indexing="ij")
+    for styp in ("FP32", "INT64", "BOOL"):
+        A = rand_matrix(rng, styp, nr, nc, 0.2); d, p = dense_m(A); m = to_matrix(A)
+        for ztyp in ("INT64", "INT32"):
+            Z = getattr(gb, ztyp)
+            for name, exp in (("POSITIONI", ii), ("POSITIONI1", ii + 1), ("POSITIONJ", jj), ("POSITIONJ1", jj + 1)):
+                out = gb.Matrix.sparse(Z, nr, nc); m.apply(getattr(Z, name), out=out)
+                g, gp = got_m(out); assert np.array_equal(gp, p) and np.array_equal(g[gp], exp[gp]), (styp, ztyp, name)
+            # the transposed operand: positions in A'
+            out = gb.Matrix.sparse(Z, nc, nr); m.apply(Z.POSITIONI, out=out, desc=D.T0)
+            g, gp = got_m(out); assert np.array_equal(gp, p.T) and np.array_equal(g[gp], jj.T[gp])
+    # mask, accumulator, replace
+    A = rand_matrix(rng, "INT64", nr, nc, 0.3); d, p = dense_m(A); m = to_matrix(A)
+    Cm = rand_matrix(rng, "INT64", nr, nc, 0.3); cd, cp = dense_m(Cm)
+    Mk = rand_matrix(rng, "BOOL", nr, nc, 0.5); md, mp = dense_m(Mk); allow = mp & (md != 0)
+    out = to_matrix(Cm); m.apply(gb.INT64.POSITIONJ1, out=out, mask=to_matrix(Mk), accum=gb.INT64.PLUS)
+    g, gp = got_m(out)
+    ep = cp | (allow & p); e = np.where(allow & p, np.where(cp, cd, 0) + (jj + 1), cd)
+    assert np.array_equal(gp, ep) and np.array_equal(g[gp], e[gp])
+    out = to_matrix(Cm); m.apply(gb.INT64.POSITIONI, out=out, mask=to_matrix(Mk), desc=D.R)
+    g, gp = got_m(out); assert np.array_equal(gp, allow & p) and np.array_equal(g[gp], ii[gp])
+    # what the notebooks do with it: the column of every entry, reduced per row (demo/Louvain2.ipynb:52), one-based row labels (demo/Centrality.ipynb:653)
+    S = gb.Matrix.from_arrays(np.arange(6, dtype=np.uint64), np.array([2, 0, 2, 5, 5, 1], np.uint64), np.ones(6, bool), 6, 6, gb.BOOL)
+    lab, lp = got_v(S.cast(gb.INT64).apply(gb.INT64.POSITIONJ).reduce_vector())
+    assert lp.all() and np.array_equal(lab, [2, 0, 2, 5, 5, 1])
+    # vectors: the index, and column 0
+    n = 300; idx, vals = rand_vector(rng, "FP64", n, 0.3); u = to_vector("FP64", n, idx, vals)
+    for name, exp in (("POSITIONI", idx.astype(np.int64)), ("POSITIONI1", idx.astype(np.int64) + 1), ("POSITIONJ", np.zeros(len(idx), np.int64)), ("POSITIONJ1", np.ones(len(idx), np.int64))):
+        w = gb.Vector.sparse(gb.INT64, n); u.apply(getattr(gb.INT64, name), out=w)
+        g, gp = got_v(w); assert np.array_equal(np.flatnonzero(gp), idx.astype(np.int64)) and np.array_equal(g[gp != 0], exp), name
+
+
 def test_matrix_apply_and_bound_scalars(gpu):
     rng = np.random.default_rng(3)
     A = rand_matrix(rng, "FP64", 30, 20, 0.3); d, p = dense_m(A); m = to_matrix(A)

@@ -54,6 +54,10 @@ for t in FLOATS:
         unops.append((f"GxB_{op}_{t}", "U_" + op, t, t))
     for op in ["ISINF", "ISNAN", "ISFINITE"]:
         unops.append((f"GxB_{op}_{t}", "U_" + op, t, "BOOL"))
+# positional unary operators (round 6; pygraphblas/unaryop.py:55-63 lists them): the result is the entry's row / column index (0- or 1-based), whatever the input holds
+for t in ["INT32", "INT64"]:
+    for op in ["POSITIONI", "POSITIONI1", "POSITIONJ", "POSITIONJ1"]:
+        unops.append((f"GxB_{op}_{t}", "U_" + op, t, t))
 
 # ---- binary ops ----------------------------------------------------------------------------
 for t in REAL:
