@@ -3,10 +3,11 @@ pygraphblas_amd mirror.  The driver itself is written against descriptor names t
 `TransposeA`: stale API); they are RC, R and T0 in its current descriptor.py.  Shared by tests and tools."""
 
 
-def bc(gb, sources, AT, A, sizes=None):
-    """`sizes` (a list) receives the entry count of every level's frontier (the at-scale parity test compares them with the oracle's)."""
+def bc(gb, sources, AT, A, sizes=None, typ=None):
+    """`sizes` (a list) receives the entry count of every level's frontier (the at-scale parity test compares them with the oracle's).
+    `typ`: the arithmetic type (the driver's is FP32; the parity test also runs it in FP64, where 1e-6 against the oracle's doubles is meaningful)."""
     from pygraphblas_amd import descriptor as D
-    Matrix, Vector, FP32, BOOL = gb.Matrix, gb.Vector, gb.FP32, gb.BOOL
+    Matrix, Vector, FP32, BOOL = gb.Matrix, gb.Vector, (typ or gb.FP32), gb.BOOL
     n = A.nrows
     ns = len(sources)
     paths = Matrix.dense(FP32, ns, n, 0)
