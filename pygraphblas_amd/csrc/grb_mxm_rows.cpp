@@ -343,9 +343,18 @@ __global__ void k_spb_allow(const uint8_t* __restrict__ mbool, const uint8_t* __
     allowm[j] = (uint8_t)m;
   }
 }
-__global__ void k_spb_long_rows(const uint32_t* __restrict__ rowptr, const uint8_t* __restrict__ allowm, uint32_t nrows, uint32_t* __restrict__ cnt, uint32_t* __restrict__ list) {
-  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < nrows; j += gridDim.x * 256)
-    if (rowptr[j + 1] - rowptr[j] > SPB_LONG && allowm[j]) list[atomicAdd(cnt, 1u)] = j;
+// the long rows some batch row may write, cut into PARTS of SPB_PART entries: rec[r] = (row, first item, parts), item[i] = r.  cnt[0] = rows, cnt[1] = items.
+// (The slots come from atomics: which slot a row gets differs from run to run, what is computed for it does not.)
+constexpr uint32_t SPB_PART = 8192;
+__global__ void k_spb_long_rows(const uint32_t* __restrict__ rowptr, const uint8_t* __restrict__ allowm, uint32_t nrows, uint32_t* __restrict__ cnt, uint32_t* __restrict__ rec, uint32_t* __restrict__ item) {
+  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < nrows; j += gridDim.x * 256) {
+    const uint32_t len = rowptr[j + 1] - rowptr[j];
+    if (len > SPB_LONG && allowm[j]) {
+      const uint32_t np = (len + SPB_PART - 1) / SPB_PART, r = atomicAdd(&cnt[0], 1u), base = atomicAdd(&cnt[1], np);
+      rec[3 * r] = j; rec[3 * r + 1] = base; rec[3 * r + 2] = np;
+      for (uint32_t q = 0; q < np; q++) item[base + q] = r;
+    }
+  }
 }
 template <class T, class SR, int NSP> __device__ __forceinline__ void spb_entry(const SR& sr, T a, const T* __restrict__ ui, const uint8_t* __restrict__ upm, uint32_t c, uint32_t am, T (&acc)[NSP], uint32_t& has) {
   const uint32_t pm = (uint32_t)upm[c] & am;
@@ -444,18 +453,42 @@ __global__ __launch_bounds__(SPMV_THREADS) void k_spb_blocks(const SpmvBlock* __
     }
   }
 }
+// Long rows (round 6, second half).  The first version gave a long row to ONE workgroup of 256 threads, one dependent column -> presence byte -> operand chain
+// per step: the hub rows of R-MAT-22 (1.6e5 entries) took 445 us in the backward level of the BC driver whose mask allows them — a CU forms about one
+// scattered 16-byte gather per 3 clocks, whatever is in flight.  Now: parts of SPB_PART entries, a workgroup of 1024 threads per part with four entries per
+// thread in flight, the part sums into a small array, a second kernel adds a row's parts in part order (fixed: reproducible).
+constexpr uint32_t SPB_LT = 1024, SPB_LU = 4;
 template <class T, class SR, int NSP>
-__global__ __launch_bounds__(256) void k_spb_pull_long(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const T* __restrict__ aval, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ list,
-                                                       uint64_t n, const T* __restrict__ ui, const uint8_t* __restrict__ upm, const uint8_t* __restrict__ allowm, T* __restrict__ tval, uint8_t* __restrict__ tpres,
-                                                       const SR sr) {
-  __shared__ T s_acc[4][NSP]; __shared__ uint32_t s_has[4];
-  const uint32_t nl = *cnt, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-  for (uint32_t k = blockIdx.x; k < nl; k += gridDim.x) {
-    const uint32_t j = list[k], am = allowm[j], b = rowptr[j], e = rowptr[j + 1];
+__global__ __launch_bounds__(SPB_LT) void k_spb_pull_long(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const T* __restrict__ aval, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ rec,
+                                                          const uint32_t* __restrict__ item, const T* __restrict__ ui, const uint8_t* __restrict__ upm, const uint8_t* __restrict__ allowm,
+                                                          T* __restrict__ part_val, uint32_t* __restrict__ part_has, const SR sr) {
+  constexpr uint32_t NW = SPB_LT / 64u;
+  __shared__ T s_acc[NW][NSP]; __shared__ uint32_t s_has[NW];
+  const uint32_t ni = cnt[1], lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  for (uint32_t k = blockIdx.x; k < ni; k += gridDim.x) {
+    const uint32_t r = item[k], j = rec[3 * r], q0 = k - rec[3 * r + 1], am = allowm[j];
+    const uint32_t rb = rowptr[j], re = rowptr[j + 1], b = rb + q0 * SPB_PART, e = (re - b > SPB_PART) ? b + SPB_PART : re;
     T acc[NSP]; uint32_t has = 0;
 #pragma unroll
     for (int sidx = 0; sidx < NSP; sidx++) acc[sidx] = sr.identity;
-    for (uint32_t p = b + threadIdx.x; p < e; p += 256u) spb_entry<T, SR, NSP>(sr, aval ? aval[p] : T(), ui, upm, col[p], am, acc, has);
+    for (uint32_t p0 = b + threadIdx.x; p0 < e; p0 += SPB_LT * SPB_LU) {
+      uint32_t c[SPB_LU], pm[SPB_LU]; T a[SPB_LU], u[SPB_LU][NSP];
+#pragma unroll
+      for (uint32_t q = 0; q < SPB_LU; q++) { const uint32_t p = p0 + q * SPB_LT; const bool ok = p < e; c[q] = ok ? col[p] : 0xFFFFFFFFu; a[q] = (ok && aval) ? aval[p] : T(); }
+#pragma unroll
+      for (uint32_t q = 0; q < SPB_LU; q++) pm[q] = c[q] != 0xFFFFFFFFu ? ((uint32_t)upm[c[q]] & am) : 0u;
+#pragma unroll
+      for (uint32_t q = 0; q < SPB_LU; q++) {
+#pragma unroll
+        for (int sidx = 0; sidx < NSP; sidx++) u[q][sidx] = pm[q] ? ui[(size_t)c[q] * NSP + sidx] : T();
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < SPB_LU; q++) {
+#pragma unroll
+        for (int sidx = 0; sidx < NSP; sidx++) if (pm[q] & (1u << sidx)) { const T pr = sr.mult(a[q], u[q][sidx]); acc[sidx] = (has & (1u << sidx)) ? sr.add(acc[sidx], pr) : pr; }
+        has |= pm[q];
+      }
+    }
 #pragma unroll
     for (int sidx = 0; sidx < NSP; sidx++) {
       T v = (has & (1u << sidx)) ? acc[sidx] : sr.identity;
@@ -469,12 +502,27 @@ __global__ __launch_bounds__(256) void k_spb_pull_long(const uint32_t* __restric
     if (lane == 0) { s_has[wv] = has; for (int sidx = 0; sidx < NSP; sidx++) s_acc[wv][sidx] = acc[sidx]; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      const uint32_t hall = s_has[0] | s_has[1] | s_has[2] | s_has[3];
-      for (int sidx = 0; sidx < NSP; sidx++) if (hall & (1u << sidx)) {
+      uint32_t hall = 0; for (uint32_t w = 0; w < NW; w++) hall |= s_has[w];
+      for (int sidx = 0; sidx < NSP; sidx++) {
         T v = sr.identity; bool first = true;
-        for (int w = 0; w < 4; w++) if (s_has[w] & (1u << sidx)) { v = first ? s_acc[w][sidx] : sr.add(v, s_acc[w][sidx]); first = false; }
-        tval[(uint64_t)sidx * n + j] = v; tpres[(uint64_t)sidx * n + j] = 1;
+        for (uint32_t w = 0; w < NW; w++) if (s_has[w] & (1u << sidx)) { v = first ? s_acc[w][sidx] : sr.add(v, s_acc[w][sidx]); first = false; }
+        part_val[(size_t)k * NSP + sidx] = v;
       }
+      part_has[k] = hall;
+    }
+  }
+}
+template <class T, class SR, int NSP>
+__global__ void k_spb_long_combine(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ rec, const T* __restrict__ part_val, const uint32_t* __restrict__ part_has, uint64_t n,
+                                   T* __restrict__ tval, uint8_t* __restrict__ tpres, const SR sr) {
+  const uint32_t nrw = cnt[0];
+  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < nrw; r += gridDim.x * 256) {
+    const uint32_t j = rec[3 * r], base = rec[3 * r + 1], np = rec[3 * r + 2];
+#pragma unroll
+    for (int sidx = 0; sidx < NSP; sidx++) {
+      T v = sr.identity; bool any = false;
+      for (uint32_t q = 0; q < np; q++) if (part_has[base + q] & (1u << sidx)) { const T pv = part_val[(size_t)(base + q) * NSP + sidx]; v = any ? sr.add(v, pv) : pv; any = true; }
+      if (any) { tval[(uint64_t)sidx * n + j] = v; tpres[(uint64_t)sidx * n + j] = 1; }
     }
   }
 }
@@ -497,12 +545,14 @@ static bool spmm_pull_batch(GrB_Matrix A, DevBitmap& ab, GrB_Matrix Mmask, const
   const bool uses_a = sd.flip ? binop_uses_y(sd.mulop) : binop_uses_x(sd.mulop);
   DevBuf acast; const void* av = uses_a ? cast_values(zcode, B->type->code, R.val.p, R.nnz, acast) : nullptr;
   const int NSP = nr <= 4 ? 4 : 8;
-  DevBuf ui((size_t)nin * NSP * zs + 64), upm(nin + 64), allowm(nout + 64), mb, lcnt(16), llist(((size_t)R.nrows / SPB_LONG + 16 + R.nnz / SPB_LONG) * 4 + 64);
+  DevBuf ui((size_t)nin * NSP * zs + 64), upm(nin + 64), allowm(nout + 64), mb, lcnt(16);
+  const size_t max_long = (size_t)R.nnz / SPB_LONG + 16, max_items = (size_t)R.nnz / SPB_PART + max_long;      // (a long row holds > SPB_LONG entries; its parts: full ones + at most one more)
+  DevBuf lrec(max_long * 12 + 64), litem(max_items * 4 + 64), lpval(max_items * NSP * zs + 64), lphas(max_items * 4 + 64);
   const uint8_t* mbool = nullptr; const uint8_t* mpres = nullptr;
   if (Mmask) { mpres = Mmask->bm.pres.as<uint8_t>(); mbool = (const uint8_t*)cast_values(T_BOOL, Mmask->type->code, Mmask->bm.val.p, (uint64_t)nr * nout, mb); }
   hipLaunchKernelGGL(k_spb_allow, dim3(grid_of(nout)), dim3(256), 0, stream(), mbool, mpres, nr, nout, dv.mask_struct ? 1 : 0, dv.mask_comp ? 1 : 0, allowm.as<uint8_t>());
   GRB_HIP(hipMemsetAsync(tpres.p, 0, (size_t)nr * nout, stream())); GRB_HIP(hipMemsetAsync(lcnt.p, 0, 16, stream()));
-  hipLaunchKernelGGL(k_spb_long_rows, dim3(grid_of(R.nrows)), dim3(256), 0, stream(), R.rowptr.as<uint32_t>(), allowm.as<uint8_t>(), R.nrows, lcnt.as<uint32_t>(), llist.as<uint32_t>());
+  hipLaunchKernelGGL(k_spb_long_rows, dim3(grid_of(R.nrows)), dim3(256), 0, stream(), R.rowptr.as<uint32_t>(), allowm.as<uint8_t>(), R.nrows, lcnt.as<uint32_t>(), lrec.as<uint32_t>(), litem.as<uint32_t>());
   bool ran = dispatch_type(zcode, [&]<class T>() {
     if constexpr (sizeof(T) == 4 || sizeof(T) == 8) {
       auto go = [&](auto NSPc) {
@@ -512,8 +562,9 @@ static bool spmm_pull_batch(GrB_Matrix A, DevBitmap& ab, GrB_Matrix Mmask, const
           typedef decltype(sr) SR;
           if (R.plan_nblocks) hipLaunchKernelGGL((k_spb_blocks<T, SR, N>), dim3(R.plan_nblocks), dim3(SPMV_THREADS), 0, stream(), (const SpmvBlock*)R.plan_blocks.p, R.rowptr.as<uint32_t>(), R.col.as<uint32_t>(),
                                                  (const T*)av, nout, (const T*)ui.p, upm.as<uint8_t>(), allowm.as<uint8_t>(), (T*)tval.p, tpres.as<uint8_t>(), sr);
-          hipLaunchKernelGGL((k_spb_pull_long<T, SR, N>), dim3(2048), dim3(256), 0, stream(), R.rowptr.as<uint32_t>(), R.col.as<uint32_t>(), (const T*)av, lcnt.as<uint32_t>(), llist.as<uint32_t>(), nout,
-                             (const T*)ui.p, upm.as<uint8_t>(), allowm.as<uint8_t>(), (T*)tval.p, tpres.as<uint8_t>(), sr);
+          hipLaunchKernelGGL((k_spb_pull_long<T, SR, N>), dim3(2048), dim3(SPB_LT), 0, stream(), R.rowptr.as<uint32_t>(), R.col.as<uint32_t>(), (const T*)av, lcnt.as<uint32_t>(), lrec.as<uint32_t>(), litem.as<uint32_t>(),
+                             (const T*)ui.p, upm.as<uint8_t>(), allowm.as<uint8_t>(), (T*)lpval.p, lphas.as<uint32_t>(), sr);
+          hipLaunchKernelGGL((k_spb_long_combine<T, SR, N>), dim3(64), dim3(256), 0, stream(), lcnt.as<uint32_t>(), lrec.as<uint32_t>(), (const T*)lpval.p, lphas.as<uint32_t>(), nout, (T*)tval.p, tpres.as<uint8_t>(), sr);
         });
       };
       if (NSP == 4) go(std::integral_constant<int, 4>{}); else go(std::integral_constant<int, 8>{});
