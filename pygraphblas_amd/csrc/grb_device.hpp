@@ -162,25 +162,53 @@ inline void* pinned_scratch() {
   if (!p) GRB_HIP(hipHostMalloc(&p, 16384, hipHostMallocDefault));
   return p;
 }
+// Round 6 (second half): the counters reach the host WITHOUT a copy, a memset and a stream synchronisation.  Every workgroup of a counting kernel adds into the
+// device slot and then draws a ticket; the workgroup that draws the last one reads the totals, zeroes slot and ticket for the next kernel and stores
+// (v0, v1, tag) into three page-locked, GPU-visible HOST words; the host spins on the tag.  Before: hipMemcpyAsync (a blit kernel) + hipMemsetAsync (another)
+// + hipStreamSynchronize per readback — three of them in every sweep of the shortest-path loop's `iseq`, one per level of everything that asks `nvals`.
+struct ScalarPub { unsigned long long* slot; unsigned long long* host; unsigned long long tag; };      // slot: [0], [1] counters, [2] ticket (all zero between kernels)
 struct ScalarSlot {
-  // two 64-bit counters that are zero between uses: the reader re-zeroes them right behind its copy, so the memset is
-  // dispatched while the host waits for the result instead of in front of the next counting kernel
-  static DevBuf& buf() {
-    static thread_local DevBuf b;
-    if (!b.p) { b.alloc(16); GRB_HIP(hipMemsetAsync(b.p, 0, 16, stream())); }
-    return b;
+  struct State { DevBuf dev; unsigned long long* host = nullptr; unsigned long long* host_dev = nullptr; unsigned long long seq = 0; };
+  static State& st() {
+    static thread_local State s;
+    if (!s.dev.p) {
+      s.dev.alloc(32); GRB_HIP(hipMemsetAsync(s.dev.p, 0, 32, stream()));
+      void* h = nullptr; GRB_HIP(hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent)); memset(h, 0, 64); s.host = (unsigned long long*)h;      // (lives as long as the thread's other pinned scratch)
+      void* dp = nullptr; if (hipHostGetDevicePointer(&dp, h, 0) != hipSuccess) { (void)hipGetLastError(); dp = h; }
+      s.host_dev = (unsigned long long*)dp;
+    }
+    return s;
   }
-  void* dev() { return buf().p; }
+  unsigned long long tag = 0;
+  ScalarPub pub() { State& s = st(); tag = ++s.seq; return ScalarPub{(unsigned long long*)s.dev.p, s.host_dev, tag}; }      // one kernel launch per pub()
   void zero() {}
   void read(uint64_t out[2]) {
-    uint64_t* pin = (uint64_t*)pinned_scratch();      // a copy into pageable memory goes through a staging kernel (18 us per readback on this box)
-    GRB_HIP(hipMemcpyAsync(pin, buf().p, 16, hipMemcpyDeviceToHost, stream()));
-    GRB_HIP(hipMemsetAsync(buf().p, 0, 16, stream()));
-    GRB_HIP(hipStreamSynchronize(stream()));
-    out[0] = pin[0]; out[1] = pin[1];
+    State& s = st();
+    volatile unsigned long long* h = s.host;
+    for (int round = 0; round < 2; round++) {
+      for (uint64_t spin = 0; spin < (1ull << 24); spin++) { if (h[2] == tag) { out[0] = h[0]; out[1] = h[1]; return; } __builtin_ia32_pause(); }
+      GRB_HIP(hipStreamSynchronize(stream()));      // (far beyond any counting kernel's time: let a failed launch report itself, then look once more)
+    }
+    fail(GrB_PANIC, "a counting kernel did not publish its result");
   }
   uint64_t read_u64() { uint64_t v[2]; read(v); return v[0]; }
 };
+#if defined(__HIPCC__)
+// thread 0 of EVERY workgroup, after the workgroup's own atomics into p.slot (same thread: program order + the fence)
+__device__ __forceinline__ void scalar_publish(const ScalarPub& p) {
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned long long t = atomicAdd(&p.slot[2], 1ull);
+    if (t == (unsigned long long)gridDim.x - 1ull) {
+      __threadfence();
+      const unsigned long long v0 = atomicExch(&p.slot[0], 0ull), v1 = atomicExch(&p.slot[1], 0ull);
+      atomicExch(&p.slot[2], 0ull);
+      volatile unsigned long long* h = p.host;
+      h[0] = v0; h[1] = v1; __threadfence_system(); h[2] = p.tag;
+    }
+  }
+}
+#endif
 
 // ---- library-backed primitives (grb_prims.hip: rocPRIM scan / radix sort) ------------------------------------
 void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n);            // out[i] = sum in[0..i)

@@ -145,7 +145,8 @@ static inline int grid_capped(uint64_t n, int per_thread, int cap = 512) { const
 
 // (round 4: 128 workgroups, four 16-byte loads in flight per lane — 512 workgroups of two loads each ended in 512 same-address atomics: 10 us for a 4 MB
 //  bitmap, and the shortest-path loop's `iseq` counts two of them per sweep)
-__global__ __launch_bounds__(256) void k_count(const uint8_t* __restrict__ pres, uint64_t n, unsigned long long* out) {
+__global__ __launch_bounds__(256) void k_count(const uint8_t* __restrict__ pres, uint64_t n, const ScalarPub pub) {
+  unsigned long long* const out = pub.slot;
   unsigned long long c = 0;
   // 16 bytes per lane per load
   const uint64_t n16 = n / 16, T = gridDim.x * 256ull;
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(256) void k_count(const uint8_t* __restrict__ pres,
   for (; i < n16; i += T) c += ones(p4[i]);
   for (uint64_t j = n16 * 16 + blockIdx.x * 256ull + threadIdx.x; j < n; j += T) c += pres[j] != 0;
   block_add_u64(c, out);
+  scalar_publish(pub);
 }
 // two device-to-device copies in one launch (GrB_Vector_dup: values + presence bytes — `w = v.dup()` opens every sweep of the shortest-path loop;
 // two hipMemcpyAsync were two launches of the runtime's own copy kernel)
@@ -181,7 +183,7 @@ void dev_copy2(void* d0, const void* s0, uint64_t n0, void* d1, const void* s1, 
 uint64_t count_present(const uint8_t* pres, uint64_t n) {
   if (!n) return 0;
   ScalarSlot slot; slot.zero();
-  hipLaunchKernelGGL(k_count, dim3(grid_capped(n, 16, 128)), dim3(256), 0, stream(), pres, n, (unsigned long long*)slot.dev());
+  hipLaunchKernelGGL(k_count, dim3(grid_capped(n, 16, 128)), dim3(256), 0, stream(), pres, n, slot.pub());
   return slot.read_u64();
 }
 
@@ -241,7 +243,8 @@ void scatter_entries(uint32_t k, const uint32_t* idx_dev, const void* vals_dev, 
 // ---- sum of the row lengths of the present entries (how many edges a push from this frontier would walk) ----------------
 // (round 4: 16 presence bytes per lane and load, two loads in flight, 256 workgroups — four bytes per load, eight dependent rounds per lane and 2 x 512
 //  same-address atomics took 21 us for 4 M positions: the level-2 direction choice of the BFS loop)
-__global__ __launch_bounds__(256) void k_frontier_edges(const uint8_t* __restrict__ pres, const uint32_t* __restrict__ rowptr, uint64_t n, unsigned long long* out, unsigned long long* out_count) {
+__global__ __launch_bounds__(256) void k_frontier_edges(const uint8_t* __restrict__ pres, const uint32_t* __restrict__ rowptr, uint64_t n, const ScalarPub pub, const bool with_count) {
+  unsigned long long* const out = pub.slot; unsigned long long* const out_count = with_count ? pub.slot + 1 : nullptr;
   unsigned long long c = 0, np = 0;
   // the row pointers are only read for present entries
   const uint64_t n16 = n / 16, T = gridDim.x * 256ull;
@@ -260,11 +263,12 @@ __global__ __launch_bounds__(256) void k_frontier_edges(const uint8_t* __restric
   for (uint64_t r = n16 * 16 + blockIdx.x * 256ull + threadIdx.x; r < n; r += T) if (pres[r]) { c += rowptr[r + 1] - rowptr[r]; np++; }
   block_add_u64(c, out);
   if (out_count) { __syncthreads(); block_add_u64(np, out_count); }
+  scalar_publish(pub);
 }
 uint64_t frontier_edges(const uint8_t* pres, const uint32_t* rowptr, uint64_t n) {
   if (!n) return 0;
   ScalarSlot slot; slot.zero();
-  hipLaunchKernelGGL(k_frontier_edges, dim3(grid_capped(n, 16, 256)), dim3(256), 0, stream(), pres, rowptr, n, (unsigned long long*)slot.dev(), (unsigned long long*)nullptr);
+  hipLaunchKernelGGL(k_frontier_edges, dim3(grid_capped(n, 16, 256)), dim3(256), 0, stream(), pres, rowptr, n, slot.pub(), false);
   return slot.read_u64();
 }
 // the same with the number of present entries as a second result: one kernel, one round trip to the host
@@ -272,7 +276,7 @@ uint64_t frontier_edges_and_count(const uint8_t* pres, const uint32_t* rowptr, u
   *count = 0;
   if (!n) return 0;
   ScalarSlot slot; slot.zero();
-  hipLaunchKernelGGL(k_frontier_edges, dim3(grid_capped(n, 16, 256)), dim3(256), 0, stream(), pres, rowptr, n, (unsigned long long*)slot.dev(), (unsigned long long*)slot.dev() + 1);
+  hipLaunchKernelGGL(k_frontier_edges, dim3(grid_capped(n, 16, 256)), dim3(256), 0, stream(), pres, rowptr, n, slot.pub(), true);
   uint64_t v[2]; slot.read(v); *count = v[1]; return v[0];
 }
 
@@ -338,7 +342,8 @@ __global__ void k_reduce_f32_f64(uint64_t n, const float* __restrict__ val, cons
 }
 // BOOL with LOR / LAND (the `while q.reduce_bool()` of a BFS loop): "is any present value true / false" — one kernel, 16 bytes
 // per lane per step, one atomic per workgroup into the self-cleaning counter slot
-__global__ void k_any_byte(uint64_t n, const uint8_t* __restrict__ val, const uint8_t* __restrict__ pres, uint8_t want, unsigned long long* out) {
+__global__ void k_any_byte(uint64_t n, const uint8_t* __restrict__ val, const uint8_t* __restrict__ pres, uint8_t want, const ScalarPub pub) {
+  unsigned long long* const out = pub.slot;
   unsigned long long c = 0;
   const uint64_t n16 = n / 16;
   const uint4* v4 = (const uint4*)val; const uint4* p4 = (const uint4*)pres;
@@ -352,6 +357,7 @@ __global__ void k_any_byte(uint64_t n, const uint8_t* __restrict__ val, const ui
   }
   for (uint64_t i = n16 * 16 + blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) c += (!pres || pres[i]) && ((val[i] != 0) == (want != 0));
   block_add_u64(c, out);
+  scalar_publish(pub);
 }
 // fixed-shape two-level tree: results are run-to-run deterministic for floating point as well
 // up to 64 positions: one lane folds them in index order — one launch instead of two, and for floating point the
@@ -366,7 +372,7 @@ template <class T> __global__ void k_reduce_seq(uint32_t n, const T* __restrict_
 void reduce_values(int code, uint64_t n, const void* val, const uint8_t* pres, int op, const void* identity, void* result_host) {
   if (code == T_BOOL && n && (op == B_LOR || op == B_LAND) && ((uintptr_t)val % 16 == 0) && (!pres || (uintptr_t)pres % 16 == 0)) {
     ScalarSlot slot; slot.zero();
-    hipLaunchKernelGGL(k_any_byte, dim3(grid_capped(n, 16)), dim3(256), 0, stream(), n, (const uint8_t*)val, pres, (uint8_t)(op == B_LOR ? 1 : 0), (unsigned long long*)slot.dev());
+    hipLaunchKernelGGL(k_any_byte, dim3(grid_capped(n, 16)), dim3(256), 0, stream(), n, (const uint8_t*)val, pres, (uint8_t)(op == B_LOR ? 1 : 0), slot.pub());
     const uint64_t hits = slot.read_u64();
     const uint8_t r = op == B_LOR ? (hits != 0) : (hits == 0);        // LOR: some present value is true; LAND: no present value is false
     memcpy(result_host, &r, 1);
