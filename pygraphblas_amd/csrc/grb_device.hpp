@@ -232,6 +232,9 @@ void reduce_values_f32_f64(uint64_t n, const void* val_f32, const uint8_t* pres,
 void vec_ewise(int code, uint64_t n, const void* uval, const uint8_t* upres, const void* vval, const uint8_t* vpres, int op,
                bool is_union, void* tval, uint8_t* tpres);
 void vec_apply(int code, uint64_t n, const void* uval, const uint8_t* upres, int mode, int op, const void* scalar, void* tval, uint8_t* tpres);
+// w<mask, replace> = accum(w, u op v) in one pass, everything in the type `code`; mpres == nullptr: no mask; accum < 0: none; w may alias u, v or the mask
+void vec_ewise_fused(int code, uint64_t n, const void* uval, const uint8_t* upres, const void* vval, const uint8_t* vpres, int op, bool is_union,
+                     int mcode, const void* mval, const uint8_t* mpres, bool mstruct, bool mcomp, int accum, bool replace, void* wval, uint8_t* wpres);
 void vec_assign_scalar(int code, uint64_t n, void* wval, uint8_t* wpres, const uint8_t* allow, const uint8_t* region, const void* scalar, int accum, bool replace);
 // the same over every index with the mask vector read in place (no "allow" pass): `v.assign_scalar(level, mask=q)` of a BFS level is one kernel
 void vec_assign_scalar_masked(int code, uint64_t n, void* wval, uint8_t* wpres, int mcode, const void* mval, const uint8_t* mpres, bool mstruct, bool mcomp, const void* scalar, int accum, bool replace);

@@ -429,6 +429,48 @@ void vec_ewise(int code, uint64_t n, const void* uval, const uint8_t* upres, con
   });
 }
 
+// ---- w<mask, replace> = accum(w, u op v) in ONE pass (round 6, second half) ------------------------------------------------------------------------
+// The general route is three kernels and two temporaries: k_allow (mask -> allow bytes), k_vec_ewise (T = u op v), k_vec_epilogue (w from T).  When every
+// operand, the operator and the accumulator work in w's own type, one kernel does it: the mask is read in place (mask_truth_at), T(i) lives in a register.
+// Element-wise, everything of position i is read before anything of position i is written: w may be u, v or the mask (no __restrict__ on those).
+// (The element-wise steps of the BC driver on its ns x n batches — `bcu.emult(paths, DIV, out=W, mask=S[i], desc=R)`, `W.emult(paths, TIMES, out=bcu, accum=PLUS)`,
+//  `paths.assign_matrix(frontier, accum=PLUS)` — are this; 155 -> ~60 us each at R-MAT-22, ns = 4.)
+template <class T, bool MATH> __global__ void k_vec_ewise_fused(uint64_t n, const T* uval, const uint8_t* upres, const T* vval, const uint8_t* vpres, int op, bool is_union,
+                                                                int mcode, const void* mval, const uint8_t* mpres, bool mstruct, bool mcomp, int accum, bool replace,
+                                                                T* wval, uint8_t* wpres) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {
+    const bool ok = mpres ? ((mpres[i] != 0 && mask_truth_at(mval, mcode, i, mstruct)) != mcomp) : true;
+    if (ok) {
+      const bool a = upres[i] != 0, b = vpres[i] != 0;
+      const bool tp = is_union ? (a || b) : (a && b);
+      T tv{};
+      if (a && b) tv = apply_binop<T, true, MATH>(op, uval[i], vval[i]);
+      else if (tp) tv = a ? uval[i] : vval[i];
+      if (accum >= 0) {
+        if (tp) {
+          if (wpres[i]) wval[i] = apply_binop<T, true, MATH>(accum, wval[i], tv);
+          else { wval[i] = tv; wpres[i] = 1; }
+        }
+      } else {
+        if (tp) wval[i] = tv;
+        wpres[i] = tp ? 1 : 0;
+      }
+    } else if (replace) {
+      wpres[i] = 0;
+    }
+  }
+}
+void vec_ewise_fused(int code, uint64_t n, const void* uval, const uint8_t* upres, const void* vval, const uint8_t* vpres, int op, bool is_union,
+                     int mcode, const void* mval, const uint8_t* mpres, bool mstruct, bool mcomp, int accum, bool replace, void* wval, uint8_t* wpres) {
+  if (!n) return;
+  dispatch_type(code, [&]<class T>() {
+    if (binop_needs_math(op) || (accum >= 0 && binop_needs_math(accum)))
+      hipLaunchKernelGGL((k_vec_ewise_fused<T, true>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (const T*)uval, upres, (const T*)vval, vpres, op, is_union, mcode, mval, mpres, mstruct, mcomp, accum, replace, (T*)wval, wpres);
+    else
+      hipLaunchKernelGGL((k_vec_ewise_fused<T, false>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (const T*)uval, upres, (const T*)vval, vpres, op, is_union, mcode, mval, mpres, mstruct, mcomp, accum, replace, (T*)wval, wpres);
+  });
+}
+
 // ---- apply: unary op, or binary op with one bound scalar (mode 1: z=f(s,x)  mode 2: z=f(x,s)) ----------------------
 template <class T, bool MATH> __global__ void k_vec_apply(uint64_t n, const T* __restrict__ uval, const uint8_t* __restrict__ upres, int mode, int op,
                                                T s, T* __restrict__ tval, uint8_t* __restrict__ tpres) {

@@ -171,12 +171,35 @@ static void vec_ewise_op(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_
   if (is_hyper(w)) { hyper_vec_ewise(w, mask, accum, op, u, v, desc, is_union); return; }      // a size beyond the device layout
   const DescView dv(desc); const uint64_t n = w->n;
   if (u->n != n || v->n != n || (mask && mask->n != n)) fail(GrB_DIMENSION_MISMATCH, "eWise: vector sizes differ");
+  if (!mask && dv.mask_comp) { if (dv.replace) GrB_Vector_clear(w); return; }      // no mask, complemented: nothing may be written
+  if (!mask && !accum && lazy_ewise(w, op, u, v, is_union)) return;      // queued: runs fused with its neighbours when a result is looked at
+  const int xc = op->xtype->code;
+  // one pass when everything works in w's own type (round 6): the mask read in place, T(i) in a register, the write-back in the same store
+  {
+    static const bool off = getenv("GRB_MI355X_EWISE_FUSED") && atoi(getenv("GRB_MI355X_EWISE_FUSED")) == 0;      // measurement / test hook
+    const int wc = w->type->code;
+    const bool same = xc == wc && op->ytype->code == wc && op->ztype->code == wc && u->type->code == wc && v->type->code == wc && wc < T_FC32 &&
+                      (!accum || (check_obj(accum) && accum->xtype->code == wc && accum->ytype->code == wc && accum->ztype->code == wc)) &&
+                      (!mask || mask->type->code < T_FC32);
+    if (!off && same && (mask || accum) && n) {
+      if (accum) check_binop(accum, "accum");
+      vec_to_device(u); vec_to_device(v); if (mask) vec_to_device(mask); vec_to_device(w);
+      const bool uf = u->dnvals_known && u->dnvals == n, vf = v->dnvals_known && v->dnvals == n, wf = w->dnvals_known && w->dnvals == n;
+      const bool t_full = is_union ? (uf || vf) : (uf && vf);
+      const bool stays_full = !mask && accum && (wf || t_full);
+      vec_ewise_fused(wc, n, u->dval.p, u->dpres.as<uint8_t>(), v->dval.p, v->dpres.as<uint8_t>(), op->opcode, is_union,
+                      mask ? mask->type->code : 0, mask ? mask->dval.p : nullptr, mask ? mask->dpres.as<uint8_t>() : nullptr, dv.mask_struct, dv.mask_comp,
+                      accum ? accum->opcode : -1, dv.replace, w->dval.p, w->dpres.as<uint8_t>());
+      vec_invalidate_host(w);
+      w->fe_lb = 0; w->fe_lb_key = 0;
+      w->dnvals_known = stays_full; w->dnvals = stays_full ? n : 0;
+      return;
+    }
+  }
   DevBuf allow_buf; bool nothing = false;
   const uint8_t* allow = vector_allow(mask, dv, n, allow_buf, &nothing);
   if (nothing) { if (dv.replace) GrB_Vector_clear(w); return; }
-  if (!mask && !accum && lazy_ewise(w, op, u, v, is_union)) return;      // queued: runs fused with its neighbours when a result is looked at
   vec_to_device(u); vec_to_device(v);
-  const int xc = op->xtype->code;
   DevBuf uc, vc, tval(n * type_size(xc) + 1), tpres(n + 1);
   const void* uv = cast_values(xc, u->type->code, u->dval.p, n, uc);
   const void* vv = cast_values(xc, v->type->code, v->dval.p, n, vc);
