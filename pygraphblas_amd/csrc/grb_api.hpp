@@ -14,7 +14,7 @@ GrB_Info GrB_Vector_free(GrB_Vector* v);
 }
 
 namespace grb {
-extern std::string g_last_plan;
+extern thread_local std::string g_last_plan;
 extern thread_local std::string g_last_error;   // most recent failure message of this thread (for *_error on another operand)  // human-readable list of kernels launched by the last hot-path call
 
 // Run `body`; translate C++ failures to GrB_Info and remember the message on `obj` (if it has .err).

@@ -27,7 +27,7 @@ static int g_cus = 0;
 static int g_nthreads = 1; static double g_chunk = 65536; static int g_burble = 0;
 static double g_hyper_switch = 0.0625; static int g_format = 0;
 static double g_bitmap_switch[8] = {0.04, 0.05, 0.06, 0.08, 0.10, 0.20, 0.30, 0.40};
-std::string g_last_plan;
+thread_local std::string g_last_plan;      // (per thread: "the last call" is the calling thread's)
 thread_local std::string g_last_error;
 
 // ---- pooled allocator: power-of-two-ish size classes, blocks are never split -------------------
