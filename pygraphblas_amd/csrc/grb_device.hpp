@@ -221,6 +221,7 @@ void sort_pairs_u64(const uint64_t* kin, uint64_t* kout, const uint32_t* vin, ui
 
 // ---- kernels in grb_vecops.hip ---------------------------------------------------------------------------------
 void dev_copy2(void* d0, const void* s0, uint64_t n0, void* d1, const void* s1, uint64_t n1);      // two device-to-device copies (byte counts), one launch
+uint64_t vec_iseq_mismatches(int code, uint64_t n, const void* uval, const uint8_t* upres, const void* vval, const uint8_t* vpres);      // positions where the patterns or the present values of two bitmap vectors of one type differ (one kernel, one polled read-back)
 // min / max of the present finite values (in the type itself), how many present values are NaN or infinite, how many are present;
 // false for types other than INT32 / INT64 / FP32 / FP64
 bool value_range(int code, uint64_t n, const void* val, const uint8_t* pres, void* vmin, void* vmax, uint64_t* nonfinite, uint64_t* count);

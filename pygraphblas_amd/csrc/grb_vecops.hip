@@ -187,6 +187,40 @@ uint64_t count_present(const uint8_t* pres, uint64_t n) {
   return slot.read_u64();
 }
 
+// ---- "same pattern and equal values" of two bitmap vectors in ONE pass (GrBX_Vector_iseq, round 6) ------------------------------------------------
+// What the reference's `Vector.iseq` composes from nvals, nvals, eWiseMult(EQ) into a BOOL vector, nvals and a LAND reduction (pygraphblas/vector.py:188-235) —
+// five kernels, two temporaries and four host round trips in the shortest-path loop's late sweeps — counted as mismatching positions by one kernel:
+// the presence bytes of both, the values only where both are present (NaN differs from NaN, -0.0 equals 0.0: the EQ operator).
+template <class T> __global__ __launch_bounds__(256) void k_vec_iseq(uint64_t n, const T* __restrict__ uval, const uint8_t* __restrict__ upres, const T* __restrict__ vval, const uint8_t* __restrict__ vpres,
+                                                                     const bool aligned, const ScalarPub pub) {
+  unsigned long long c = 0;
+  // four presence bytes of each vector per lane (consecutive lanes, consecutive words: coalesced), the values of the positions both hold — four independent
+  // pairs of loads in flight.  (A first version gave a lane eight consecutive positions: its value loads touched 64 lines per instruction, 25 us for 2 x 37 MB.)
+  const uint64_t n4 = aligned ? n / 4 : 0, TT = gridDim.x * 256ull;
+  for (uint64_t g = blockIdx.x * 256ull + threadIdx.x; g < n4; g += TT) {
+    const uint32_t pu = ((const uint32_t*)upres)[g], pv = ((const uint32_t*)vpres)[g];
+    bool a[4], b[4]; T x[4], y[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { a[k] = ((pu >> (8 * k)) & 0xFFu) != 0; b[k] = ((pv >> (8 * k)) & 0xFFu) != 0; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (a[k] && b[k]) { x[k] = uval[g * 4 + k]; y[k] = vval[g * 4 + k]; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) c += (a[k] != b[k]) || (a[k] && !val_eq(x[k], y[k]));
+  }
+  for (uint64_t i = n4 * 4 + blockIdx.x * 256ull + threadIdx.x; i < n; i += TT) { const bool a = upres[i] != 0, b = vpres[i] != 0; c += (a != b) || (a && !val_eq(uval[i], vval[i])); }
+  block_add_u64(c, pub.slot);
+  scalar_publish(pub);
+}
+uint64_t vec_iseq_mismatches(int code, uint64_t n, const void* uval, const uint8_t* upres, const void* vval, const uint8_t* vpres) {
+  if (!n) return 0;
+  ScalarSlot slot;
+  dispatch_type(code, [&]<class T>() {
+    hipLaunchKernelGGL((k_vec_iseq<T>), dim3(grid_capped(n, 16, 2048)), dim3(256), 0, stream(), n, (const T*)uval, upres, (const T*)vval, vpres,
+                       (((uintptr_t)upres | (uintptr_t)vpres) & 3u) == 0, slot.pub());
+  });
+  return slot.read_u64();
+}
+
 // ---- a few entries into a zeroed bitmap (upload of a sparse host vector: the `q[start] = True` of a BFS, an empty output) ----------
 __global__ void k_scatter_entries(uint32_t k, const uint32_t* __restrict__ idx, const uint8_t* __restrict__ vals, uint32_t ts, uint8_t* __restrict__ val, uint8_t* __restrict__ pres) {
   for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < k; e += gridDim.x * 256u) {

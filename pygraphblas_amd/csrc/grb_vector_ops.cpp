@@ -262,6 +262,20 @@ GrB_Info GrB_Vector_eWiseMult_Monoid(GrB_Vector w, const GrB_Vector mask, const 
 GrB_Info GrB_Vector_eWiseMult_Semiring(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Semiring op, const GrB_Vector u, const GrB_Vector v, const GrB_Descriptor desc) {
   VEC_GUARD(w); if (!op || !u || !v) return GrB_NULL_POINTER; if (!check_obj(op)) return GrB_UNINITIALIZED_OBJECT; return guarded(w, [&] { vec_ewise_op(w, mask, accum, op->mul, u, v, desc, false); }); }
 
+// "Same size, same pattern, equal values" of two vectors of ONE built-in real type as a single pass (what pygraphblas/vector.py:188-235 `Vector.iseq` composes from
+// five calls).  GrB_NO_VALUE: not this function's case (types differ, complex, a size beyond the device layout, no device) — the caller composes it as before.
+GrB_Info GrBX_Vector_iseq(bool* equal, const GrB_Vector u, const GrB_Vector v) {
+  if (!equal || !u || !v) return GrB_NULL_POINTER; if (!check_obj(u) || !check_obj(v)) return GrB_UNINITIALIZED_OBJECT;
+  if (u->type != v->type || u->type->code >= T_FC32 || is_hyper(u) || is_hyper(v) || !device_ok() || u->iso_full || v->iso_full) return GrB_NO_VALUE;
+  if (u->n != v->n) { *equal = false; return GrB_SUCCESS; }
+  if (u == v) { *equal = true; return GrB_SUCCESS; }
+  return guarded(const_cast<GrB_Vector>(u), [&] {
+    vec_to_device(const_cast<GrB_Vector>(u)); vec_to_device(const_cast<GrB_Vector>(v));
+    if (u->dnvals_known && v->dnvals_known && u->dnvals != v->dnvals) { *equal = false; return; }
+    *equal = vec_iseq_mismatches(u->type->code, u->n, u->dval.p, u->dpres.as<uint8_t>(), v->dval.p, v->dpres.as<uint8_t>()) == 0;
+  });
+}
+
 GrB_Info GrB_Vector_apply(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_UnaryOp op, const GrB_Vector u, const GrB_Descriptor desc) {
   VEC_GUARD(w); if (!op || !u) return GrB_NULL_POINTER; if (!check_obj(op)) return GrB_UNINITIALIZED_OBJECT;
   return guarded(w, [&] { if (op->opcode >= U_USER) not_implemented("user-defined unary operator");

@@ -272,8 +272,18 @@ class Vector:
         return self._ewise("eWiseMult", other, mult_op, cast, out, mask, accum, desc, lambda t: t._default_multop())
 
     def iseq(self, other, eq_op=None):
-        """Same pattern and equal values (reference: vector.py:560-580)."""
-        if self.size != other.size or self.nvals != other.nvals:
+        """Same pattern and equal values (reference: vector.py:188-235: size, nvals, eWiseMult(EQ) into BOOL, nvals, LAND-reduce).  Two vectors of one built-in
+        real type compared with that type's own EQ go through the library's one-pass form of exactly that (`GrBX_Vector_iseq`)."""
+        if self.size != other.size:
+            return False
+        if eq_op is None and self.type == other.type:
+            r = C.c_bool(False)
+            info = lib.GrBX_Vector_iseq(C.byref(r), self._h, other._h)
+            if info == 0:
+                return bool(r.value)
+            if info != 1:                       # (1 = GrB_NO_VALUE: not the one-pass case — composed below)
+                check(info, self)
+        if self.nvals != other.nvals:
             return False
         if eq_op is None:
             eq_op = types.promote(self.type, other.type).EQ

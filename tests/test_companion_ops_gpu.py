@@ -82,6 +82,48 @@ def test_select_transpose_pattern_reduce_vector(gpu):
     assert gb.Matrix.sparse(gb.INT64, 5, 5).reduce_int() == 0
 
 
+def test_one_pass_iseq_equals_the_composed_one(gpu):
+    """`Vector.iseq` (pygraphblas/vector.py:188-235: size, nvals, eWiseMult(EQ) into BOOL, nvals, LAND-reduce) has a one-pass form in the library
+    (`GrBX_Vector_iseq`, taken by the mirror for two vectors of one type and the type's own EQ): the same answers as the composed calls on equal vectors,
+    a differing value, a differing pattern with the same entry count, NaN (differs from itself), -0.0 (equals 0.0), empty and full vectors, every type,
+    a length that is not a multiple of eight, and operands with deferred work pending."""
+    import ctypes as C
+    rng = np.random.default_rng(17)
+    def composed(a, b):
+        if a.size != b.size or a.nvals != b.nvals: return False
+        c = a.emult(b, a.type.EQ, cast=gb.BOOL)
+        return c.nvals == a.nvals and bool(c.reduce_bool(gb.BOOL.LAND_MONOID))
+    def fused(a, b):
+        r = C.c_bool(False); info = gb.lib.GrBX_Vector_iseq(C.byref(r), a._h, b._h)
+        assert info == 0, info
+        return bool(r.value)
+    for typ in ("BOOL", "INT8", "UINT16", "INT32", "INT64", "UINT64", "FP32", "FP64"):
+        for n in (1, 7, 64, 1003, 70001):
+            idx, vals = rand_vector(rng, typ, n, float(rng.choice([0.0, 0.3, 1.0])))
+            u = to_vector(typ, n, idx, vals); v = to_vector(typ, n, idx, vals)
+            assert fused(u, v) and composed(u, v) and u.iseq(v), (typ, n)
+            if len(idx):
+                k = int(rng.integers(len(idx))); v2 = vals.copy(); v2[k] = (not v2[k]) if typ == "BOOL" else v2[k] + 1
+                w = to_vector(typ, n, idx, v2)
+                assert not fused(u, w) and not composed(u, w) and not u.iseq(w), (typ, n, "value")
+                if len(idx) < n:                                        # the same number of entries, one of them somewhere else
+                    free = np.setdiff1d(np.arange(n, dtype=np.uint64), idx); i2 = idx.copy(); i2[k] = free[int(rng.integers(len(free)))]; o = np.argsort(i2)
+                    x = to_vector(typ, n, i2[o], vals[o])
+                    assert not fused(u, x) and not composed(u, x) and not u.iseq(x), (typ, n, "pattern")
+    a = to_vector("FP64", 5, np.array([0, 2], np.uint64), np.array([np.nan, -0.0])); b = to_vector("FP64", 5, np.array([0, 2], np.uint64), np.array([np.nan, 0.0]))
+    assert not fused(a, b) and not composed(a, b)
+    c = to_vector("FP64", 5, np.array([2], np.uint64), np.array([-0.0])); d = to_vector("FP64", 5, np.array([2], np.uint64), np.array([0.0]))
+    assert fused(c, d) and composed(c, d)
+    e = gb.Vector.sparse(gb.INT64, 9); f = gb.Vector.sparse(gb.INT64, 9); g = gb.Vector.sparse(gb.INT64, 10)
+    assert fused(e, f) and e.iseq(f) and not e.iseq(g)
+    r = C.c_bool(); assert gb.lib.GrBX_Vector_iseq(C.byref(r), e._h, gb.Vector.sparse(gb.FP64, 9)._h) == 1           # GrB_NO_VALUE: two types — the mirror composes it
+    assert not e.iseq(gb.Vector.sparse(gb.FP64, 10))
+    # deferred work on an operand: p = x + y is queued (non-blocking mode) when it is compared
+    n = 5000; ix, vx = rand_vector(rng, "FP64", n, 1.0); x = to_vector("FP64", n, ix, vx); y = to_vector("FP64", n, ix, vx)
+    p = x.eadd(y, gb.FP64.PLUS); q = x.eadd(y, gb.FP64.PLUS)
+    assert p.iseq(q) and not p.iseq(x)
+
+
 def test_positional_unary_operators(gpu):
     """GxB_POSITIONI / POSITIONI1 / POSITIONJ / POSITIONJ1 (INT32, INT64; the reference lists them in pygraphblas/unaryop.py:55-63 and its notebooks use
     `A.apply(INT64.POSITIONJ)`, `A.positioni1()`): the result has the operand's pattern, an entry's value is its row / column index (0- or 1-based) in

@@ -473,6 +473,7 @@ GrB_Info GrBX_lazy_stats(uint64_t *chains, uint64_t *nodes, uint64_t *fills_fold
 GrB_Info GrBX_chain_jit_stats(uint64_t *compiled, uint64_t *launched); /* deferred element-wise chains compiled with hipRTC (grb_chain_jit.cpp): kernels compiled, launches through them */
 GrB_Info GrBX_chain_jit_stats2(uint64_t *compiled, uint64_t *launched, uint64_t *loaded_from_disk); /* ... and the kernels whose code object came from the disk cache (GRB_MI355X_CACHE_DIR) instead of a compilation */
 GrB_Info GrBX_exact_sum_host(const double *terms, uint64_t n, int significand_bits, double *sum, int *unit_exp_out); /* the 128-bit integer accumulation of the masked product's deterministic mode (grb_exact.hpp) run on the host over `terms`: the exact sum rounded once to 53 / 24 bits */
+GrB_Info GrBX_Vector_iseq(bool *equal, const GrB_Vector u, const GrB_Vector v); /* same size, pattern and values of two vectors of one built-in real type in ONE pass (pygraphblas/vector.py:188-235 Vector.iseq composes it from five calls); GrB_NO_VALUE when that is not the case at hand (types differ, complex, hypersparse): compose it then */
 GrB_Info GrBX_xcd_mapping(char *buf, int len);      /* how workgroups of a full-chip launch map to XCDs ("roundrobin8", or what was observed) */
 /* The exchange steps of the row-partitioned path (one process per GPU; RCCL over xGMI; grb_dist.cpp).  The reference has no
  * distributed code: these replace nothing in it, they are what BASELINE.json's north star adds (SURVEY.md section 8e). */
