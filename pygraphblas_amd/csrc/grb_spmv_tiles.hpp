@@ -217,7 +217,10 @@ template <class F, int... I> __device__ __forceinline__ bool xt_unroll_steps(F&&
 
 // D = prefetch depth, W = waves per workgroup; EXP selects a timing experiment (wrong results!): 1 = no gathers of u (streams
 // only), 2 = loads only (no scan, no stores: what the load side of the pipeline can deliver)
-template <class T, class SR, int D = XT_DEPTH, int W = XT_WAVES, int EXP = 0, bool C16 = xt_fmt<T>::C16>
+// VB = bytes per STORED matrix value (round 6): sizeof(T), or 2 for an integer matrix all of whose values fit 16 signed bits — the plan then keeps the
+// panel-major value plane as int16 (XcdPlan::vbytes) and the lane's four values are one 8-byte load instead of 16 / 32 bytes: the weights of a shortest-path
+// problem (1 ... 255 in INT64) cost 2 of the 12 bytes an entry's stream was.
+template <class T, class SR, int D = XT_DEPTH, int W = XT_WAVES, int EXP = 0, bool C16 = xt_fmt<T>::C16, int VB = (int)sizeof(T)>
 __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, const XtPanel<T>* __restrict__ panels, const SR sr) {
   constexpr int H = xt_hot<T>::H;
   constexpr int NS = D + 3;
@@ -243,7 +246,9 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
   const __amdgpu_buffer_rsrc_t c_rsrc = C16 ? __builtin_amdgcn_make_buffer_rsrc((void*)a.col16, (short)0, (int)(a.ntiles * (uint32_t)WP_ENT * 2u), 0x00020000)
                                             : __builtin_amdgcn_make_buffer_rsrc((void*)a.pcol, (short)0, (int)(a.nnz * 4u), 0x00020000);
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.extras, (short)0, (int)(C16 ? (a.nextras * 2u + 15u) & ~15ull : 0ull), 0x00020000);
-  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.aval, (short)0, (int)(a.aval ? a.nnz * (uint32_t)sizeof(T) : 0u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.aval, (short)0, (int)(!a.aval ? 0u : (VB == (int)sizeof(T) ? a.nnz * (uint32_t)sizeof(T) : a.ntiles * (uint32_t)WP_ENT * (uint32_t)VB)), 0x00020000);
+  // (narrow plane: the range covers whole tiles — the plan's padding is zeros — because a lane's four values are ONE 8-byte load and the range check would
+  //  cut the last lane's live values off with the panel's end; the wide plane's loads are checked dword by dword)
   __syncthreads();
   // Work split (see k_spmv_wavepipe): chunk ids [0, dyn0) are static ranges of s0 chunks dealt to (workgroup, wave), ids >= dyn0
   // are handed out one at a time by the workgroup's LDS counter; workgroup j of the panel owns those congruent to j.
@@ -305,8 +310,17 @@ __global__ __launch_bounds__(W * 64, 1) void k_spmv_tiles(const XtCall<T> call, 
   auto issue_gather = [&](XtStage<T>& s) __attribute__((always_inline)) {
     const bool ok = s.tile != WP_NONE;
     const uint32_t e0 = ok ? s.tile * (uint32_t)WP_ENT : 0u, left = a.nnz - e0, cnt = !ok ? 0u : (left < (uint32_t)WP_ENT ? left : (uint32_t)WP_ENT);
-    if (use_a) xt_stream_load<T, WP_PER>(v_rsrc, ok ? (e0 + lane * WP_PER) * (uint32_t)sizeof(T) : 0xFFFFFFFFu, s.v);
-    else {
+    if (use_a) {
+      if constexpr (VB == (int)sizeof(T)) xt_stream_load<T, WP_PER>(v_rsrc, ok ? (e0 + lane * WP_PER) * (uint32_t)sizeof(T) : 0xFFFFFFFFu, s.v);
+      else {
+        static_assert(VB == 2 && WP_PER == 4, "the narrow value plane holds four int16 per lane: one 8-byte load");
+        uint32_t q[2];
+        xt_stream_load<uint32_t, 2>(v_rsrc, ok ? (e0 + lane * WP_PER) * 2u : 0xFFFFFFFFu, q);
+        if constexpr (std::is_integral<T>::value) {
+          s.v[0] = (T)(int16_t)(q[0] & 0xFFFFu); s.v[1] = (T)(int16_t)(q[0] >> 16); s.v[2] = (T)(int16_t)(q[1] & 0xFFFFu); s.v[3] = (T)(int16_t)(q[1] >> 16);
+        }
+      }
+    } else {
 #pragma unroll
       for (int u = 0; u < WP_PER; u++) s.v[u] = T();
     }

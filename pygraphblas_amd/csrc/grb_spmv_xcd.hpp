@@ -58,6 +58,7 @@ struct XcdPlan {          // lives in DevCSR::xcd (type-erased), built once per 
   DevBuf xhot, partial;   // per-call work buffers kept with the plan (xhot: T[XP*H], the LDS tables' contents)
   uint64_t ne[XPMAX]; uint32_t tbase[XPMAX + 1]; uint32_t ntiles[XPMAX], nhot[XPMAX];      // per stream (NS of them: tile-aligned, one XtPanel and one LDS table each)
   uint64_t F = 0; int tsize = 0; bool has_vals = false; float build_ms = 0;
+  int vbytes = 0;          // bytes per value of the panel-major value plane: sizeof(T), or 2 (int16: an integer matrix whose values all fit — pval then holds int16)
   // round 4: S sub-panels per XCD (virtual panel vp = k * S + s lives in physical panel k).  When an XCD's eighth of the operand does not
   // fit its 4 MiB L2 (R-MAT-25 FP32: 16.8 MB; every rank of a row-partitioned run), the lines of u are dealt to XP * S virtual panels and a
   // physical panel's stream holds its S sub-panels one after the other, each in row-major order: the waves of an XCD walk the stream
@@ -803,6 +804,19 @@ static __global__ void k_xp_neg(const uint32_t* __restrict__ cnt, uint32_t n, ui
 static __global__ void k_xp_unneg(uint32_t* __restrict__ key, uint32_t n) {
   for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) key[c] = 0xFFFFFFFFu - key[c];
 }
+// ---- the narrow value plane (round 6): an integer matrix whose values all fit 16 signed bits keeps them as int16 ---------------------------------
+template <class T> static __global__ void k_xt_fits16(const T* __restrict__ v, uint64_t n, uint32_t* __restrict__ flag) {
+  int bad = 0;
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {
+    const T x = v[i];
+    if constexpr (std::is_signed<T>::value) bad |= (x < (T)-32768 || x > (T)32767) ? 1 : 0; else bad |= x > (T)32767 ? 1 : 0;
+  }
+  if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(flag, 1u);
+}
+template <class T> static __global__ void k_xt_narrow16(const T* __restrict__ v, uint64_t n, int16_t* __restrict__ out) {
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) out[i] = (int16_t)v[i];
+}
+
 template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int force_S = 0) {
   auto grid_n = [](uint64_t n) { uint64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 8192) b = 8192; return (unsigned)b; };
   hipEvent_t ev0, ev1; GRB_HIP(hipEventCreate(&ev0)); GRB_HIP(hipEventCreate(&ev1)); GRB_HIP(hipEventRecord(ev0, stream()));
@@ -920,7 +934,7 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
   // 4. scattering sweep
   DevBuf rowtmp(nstore * 4);
   P->pcol.alloc(nstore * 4);
-  if (with_vals) P->pval.alloc(nstore * sizeof(T));
+  if (with_vals) { P->pval.alloc(nstore * sizeof(T)); GRB_HIP(hipMemsetAsync(P->pval.p, 0, nstore * sizeof(T), stream())); }      // (zeroed: the padding behind a panel's end takes part in the range check of the narrow plane)
   GRB_HIP(hipMemsetAsync(P->pcol.p, 0, nstore * 4, stream()));
   sw.pcol = P->pcol.as<uint32_t>(); sw.pval = with_vals ? P->pval.as<T>() : nullptr; sw.rowtmp = rowtmp.as<uint32_t>();
   hipLaunchKernelGGL((k_xp_sweep<T, true>), dim3(nunits), dim3(XP_ST), 0, stream(), sw);
@@ -1086,6 +1100,21 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
     }
     if (!keep32) { P->pcol.reset(); P->trow.reset(); }
   }
+  // 6c. the narrow value plane: integer values that all fit int16 are kept as int16 (k_spmv_tiles<..., VB = 2>); GRB_MI355X_XT_NARROW=0: never
+  P->vbytes = (int)sizeof(T);
+  if constexpr (std::is_integral<T>::value && (sizeof(T) == 4 || sizeof(T) == 8)) {
+    if (with_vals && !P->sell && wp_env("GRB_MI355X_XT_NARROW", 1) != 0) {
+      DevBuf flag(64); GRB_HIP(hipMemsetAsync(flag.p, 0, 64, stream()));
+      const unsigned g = (unsigned)std::min<uint64_t>((nstore + 255) / 256, 4096);
+      hipLaunchKernelGGL((k_xt_fits16<T>), dim3(g), dim3(256), 0, stream(), P->pval.as<T>(), (uint64_t)nstore, flag.as<uint32_t>());
+      uint32_t hf = 1; GRB_HIP(hipMemcpyAsync(&hf, flag.p, 4, hipMemcpyDeviceToHost, stream())); GRB_HIP(hipStreamSynchronize(stream()));
+      if (hf == 0) {
+        DevBuf narrow(nstore * 2 + 64);
+        hipLaunchKernelGGL((k_xt_narrow16<T>), dim3(g), dim3(256), 0, stream(), P->pval.as<T>(), (uint64_t)nstore, narrow.as<int16_t>());
+        P->pval = std::move(narrow); P->vbytes = 2;
+      }
+    }
+  }
   // 7. the panels' argument block and the per-call buffers
   P->args.alloc(XPMAX * sizeof(XtPanel<T>));
   P->xhot.alloc((size_t)NS * H * sizeof(T) + 8); P->partial.alloc(P->F * sizeof(T) + 8);
@@ -1093,7 +1122,7 @@ template <class T> void build_xcd_plan(DevCSR& M, int ncu, bool with_vals, int f
   memset((void*)ha, 0, sizeof(ha));
   for (uint32_t k = 0; k < NS; k++) {
     XtPanel<T>& a = ha[k];
-    a.pcol = keep32 ? P->pcol.as<uint32_t>() + (size_t)P->tbase[k] * WP_ENT : nullptr; a.aval = with_vals ? P->pval.as<T>() + (size_t)P->tbase[k] * WP_ENT : nullptr;
+    a.pcol = keep32 ? P->pcol.as<uint32_t>() + (size_t)P->tbase[k] * WP_ENT : nullptr; a.aval = with_vals ? (const T*)((const char*)P->pval.p + (size_t)P->tbase[k] * WP_ENT * (size_t)P->vbytes) : nullptr;
     a.trow = keep32 ? P->trow.as<uint32_t>() + P->tbase[k] : nullptr; a.xhot = P->xhot.as<T>() + (size_t)k * H;
     a.col16 = c16 ? P->col16.as<uint16_t>() + (size_t)P->tbase[k] * WP_ENT : nullptr; a.tinfo = c16 ? P->tinfo.as<uint32_t>() + 2 * (size_t)P->tbase[k] : nullptr;
     a.extras = c16 ? P->extras.as<uint16_t>() : nullptr; a.nextras = P->ncold;
@@ -1158,6 +1187,12 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
         launched = true;
       }
     }
+    if constexpr (std::is_integral<T>::value && (sizeof(T) == 4 || sizeof(T) == 8)) {
+      if (!launched && P->vbytes == 2) {
+        hipLaunchKernelGGL((k_spmv_tiles<T, SR, XT_DEPTH, XT_WAVES, 0, xt_fmt<T>::C16, 2>), dim3(ncu), dim3(XT_WAVES * 64), 0, stream(), call, (const XtPanel<T>*)P->args.p, sr);
+        launched = true;
+      }
+    }
     if (!launched) hipLaunchKernelGGL((k_spmv_tiles<T, SR>), dim3(ncu), dim3(XT_WAVES * 64), 0, stream(), call, (const XtPanel<T>*)P->args.p, sr);
     const uint32_t nblocks = (uint32_t)(((uint64_t)M.nrows + XP_RB - 1) / XP_RB);
     static const bool old_merge = wp_env("GRB_MI355X_XP_OLD_MERGE", 0) != 0;       // measurement hook: the per-panel merge kernel
@@ -1187,7 +1222,7 @@ template <class T> bool run_xcd(const SpmvCall& c, const SemiringDesc& d, int nc
     } else
       hipLaunchKernelGGL((k_xp_combine<T, SR>), dim3(nblocks), dim3(XP_CT), 0, stream(), M.nrows, P->blockptr.as<uint32_t>(), P->lrow.as<uint16_t>(), P->partial.as<T>(),
                          (T*)c.tval, c.tpres, sr);
-    g_last_plan += std::string("k_spmv_xcd<") + (sr.is_static ? "static" : "dynamic") + (P->sell ? ",lane-per-piece" : "") + ",subrows=" + std::to_string(P->F) + (P->S > 1 ? ",subpanels=" + std::to_string(P->S) + (P->own ? "/own-tables" : "") : std::string()) + "," + xcd_mapping() + "> ";
+    g_last_plan += std::string("k_spmv_xcd<") + (sr.is_static ? "static" : "dynamic") + (P->sell ? ",lane-per-piece" : "") + (P->vbytes == 2 && P->has_vals ? ",values=int16" : "") + ",subrows=" + std::to_string(P->F) + (P->S > 1 ? ",subpanels=" + std::to_string(P->S) + (P->own ? "/own-tables" : "") : std::string()) + "," + xcd_mapping() + "> ";
   });
   return true;
 }

@@ -151,9 +151,55 @@ def test_rmat22_plus_times_spmv_other_types_exact(gb, torch_dev, typ):
     assert np.array_equal(gp != 0, pres != 0) and np.array_equal(gy[pres != 0].astype(np.float64), y[pres != 0])
     w = A.mxv(x, semiring=T.PLUS_TIMES)                            # second: kernel X
     assert "k_spmv_xcd" in gb.last_kernel_plan()
+    assert ("values=int16" in gb.last_kernel_plan()) == typ.startswith("INT"), gb.last_kernel_plan()      # (round 6: integer values that fit 16 bits are kept as int16 in the plan)
     gy, gp = w.to_dense_arrays()
     assert np.array_equal(gp != 0, pres != 0)
     assert np.array_equal(np.asarray(gy, np.float64)[pres != 0], y[pres != 0])
+
+
+@pytest.mark.parametrize("typ", ["INT64", "INT32", "UINT64", "UINT32"])
+def test_kernel_x_narrow_value_plane_at_its_boundaries(gb, torch_dev, typ, monkeypatch):
+    """Round 6: kernel X's plan keeps the values of an integer matrix as int16 when ALL of them fit (k_spmv_tiles<..., VB = 2>: 2 instead of 4 / 8 bytes of an
+    entry's stream — the weights 1 ... 255 of the shortest-path problem).  Values across the whole int16 range with both extremes present are narrowed, one value
+    just beyond keeps the plan wide; PLUS_TIMES and (signed types) MIN_PLUS against numpy's exact integer arithmetic either way, and the switch that turns
+    the narrow plane off gives the same results."""
+    torch, dev = torch_dev
+    from pygraphblas_amd import rmat
+    S = 17; n = 1 << S
+    rowptr, col = rmat.csr_torch(S, dev, seed=42)
+    nnz = int(col.numel())
+    rp = rowptr.cpu().numpy().view(np.uint32).astype(np.int64); ci = col.cpu().numpy().view(np.uint32).astype(np.int64)
+    signed = typ.startswith("INT"); T = getattr(gb, typ); npt = O.NP[typ]
+    rng = np.random.default_rng(5)
+    xs = rng.integers(0, 4, n).astype(np.int64)
+    nonempty = rp[1:] > rp[:-1]
+    monkeypatch.setenv("GRB_MI355X_SPMV", "xcd")
+    for case, narrow_env in (("fits", "1"), ("edge", "1"), ("beyond", "1"), ("edge", "0")):
+        lo = -32768 if signed else 0
+        v = rng.integers(1, 256, nnz).astype(np.int64) if case == "fits" else rng.integers(lo, 32768, nnz).astype(np.int64)
+        if case != "fits": v[0] = 32767; v[1] = lo
+        if case == "beyond": v[nnz // 2] = 32768; v[nnz // 3] = (-32769 if signed else 40000)
+        monkeypatch.setenv("GRB_MI355X_XT_NARROW", narrow_env)
+        vt = torch.from_numpy(v.astype(npt).view(np.int64 if npt().itemsize == 8 else np.int32)).to(dev)
+        A = gb.Matrix.from_csr(T, n, n, rowptr.data_ptr(), col.data_ptr(), (vt.data_ptr(), nnz), device=True)
+        xt = torch.from_numpy(xs.astype(npt).view(np.int64 if npt().itemsize == 8 else np.int32)).to(dev)
+        x = gb.Vector.from_dense_array((xt.data_ptr(), n), T, device=True)
+        prod = v * xs[ci]
+        want = np.zeros(n, np.int64); np.add.at(want, np.repeat(np.arange(n), np.diff(rp)), prod)
+        w = A.mxv(x, semiring=T.PLUS_TIMES)
+        plan = gb.last_kernel_plan()
+        assert "k_spmv_xcd" in plan and ("values=int16" in plan) == (case != "beyond" and narrow_env == "1"), (case, narrow_env, plan)
+        gy, gp = w.to_dense_arrays()
+        assert np.array_equal(gp != 0, nonempty), (typ, case)
+        assert np.array_equal(gy[nonempty].astype(np.int64), want[nonempty].astype(npt).astype(np.int64)), (typ, case, "PLUS_TIMES")      # (wrap-around of the type included)
+        if signed:
+            w2 = A.mxv(x, semiring=T.MIN_PLUS)
+            assert "k_spmv_xcd" in gb.last_kernel_plan()
+            s2 = v + xs[ci]
+            starts = rp[:-1][nonempty]
+            mn = np.minimum.reduceat(s2, starts)
+            gy2, gp2 = w2.to_dense_arrays()
+            assert np.array_equal(gp2 != 0, nonempty) and np.array_equal(gy2[nonempty].astype(np.int64), mn), (typ, case, "MIN_PLUS")
 
 
 # ---- configs[2] ---------------------------------------------------------------------------------------------------------
