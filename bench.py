@@ -655,6 +655,7 @@ def bench_sssp(cx, scale):
         del plans[:]
         torch.cuda.synchronize(); t = time.perf_counter(); v, sweeps = cx.loops.sssp(A, src, plans=plans); torch.cuda.synchronize(); times.append(time.perf_counter() - t)
     best = sorted(times)[len(times) // 2]                                         # the median run (round 3 reported the minimum)
+    last_plan = cx.gb.last_kernel_plan()                                          # (of the last call of the loop's last run: the one-pass iseq launches no product, so this is the last sweep's)
     gd, gp = v.to_dense_arrays()
     # algorithmic bytes: per sweep the edges leaving the operand's entries (weight + column: 12 B) + the operand's entries (8 B) +
     # the output read and written with its presence bytes (2·9 B per vertex) + the loop's dup and iseq (4 streams of 9 B)
@@ -669,7 +670,8 @@ def bench_sssp(cx, scale):
     out = {"workload": f"SSSP R-MAT-{scale} INT64 MIN_PLUS: v<accum MIN> = v MIN_PLUS A until nothing changes (demo/Intro-Prez.ipynb:1034-1045)", "nnz": nnz, "source": src,
            "sweeps": sweeps, "reached": int((gp != 0).sum()), "seconds": round(best, 5), "first_run_seconds": round(first_s, 5),
            "first_run_builds": "the transpose (vxm pulls along A'), the value range of A, kernel W's then kernel X's plan of the transpose, the chains' code objects",
-           "ms_per_sweep": round(best / sweeps * 1e3, 3), "dtype": "int64", "kernels_per_sweep": list(plans),
+           "ms_per_sweep": round(best / sweeps * 1e3, 3), "dtype": "int64", "kernels_per_sweep": list(plans), "last_sweep_plan": last_plan.strip(),
+           "stored_value_bytes_note": "the algorithmic bytes count a weight as 8 bytes (INT64); kernel X's plan keeps weights that all fit 16 bits as an int16 plane (plan string: values=int16), so 2 of them move",
            "roofline": roof(alg, best, note="sum over sweeps of E_s*12 + V_s*8 (edges leaving / entries of the operand) + 6 vector streams of 9 B per vertex (output read + write, dup, iseq)")}
     if not cx.args.no_cpu_baseline:
         from oracle import oracle as O
