@@ -386,11 +386,12 @@ print(json.dumps({"rdiff": rdiff, "jit": [v.value for v in a]}))
     assert len(list(cache.glob("chain-*.co"))) == 2
 
 
-def test_a_chain_outside_the_pagerank_loop_runs_as_fast_as_the_compiled_shapes(gb, gpu, monkeypatch, capsys):
+def test_a_chain_outside_the_pagerank_loop_runs_as_fast_as_the_compiled_shapes(gb, gpu, monkeypatch, capsys, tmp_path):
     """`reduce(+, abs(x * y - z))` over 2^25 FP32 positions — a chain gap/prmark.py does not contain: four streams of 4 bytes.  The second time the library sees
     it, hipRTC compiles its steps (default mode: GRB_MI355X_CHAIN_JIT=1), and from then on it moves its bytes within 1.3 x of the rate of the ahead-of-time
     shape `reduce(+, abs(x - y))` (k_vec_chain<..., SPEC = 1>: two streams), where the interpreter kernel is bound by instruction issue.  Values against numpy."""
     monkeypatch.delenv("GRB_MI355X_CHAIN_JIT", raising=False)
+    monkeypatch.setenv("GRB_MI355X_CACHE_DIR", str(tmp_path))          # (an empty cache: on a box whose ~/.cache/grb_mi355x holds this chain from an earlier run it would be loaded, not compiled)
     n = 1 << 25
     rng = np.random.default_rng(4)
     xs, ys, zs = (rng.random(n, dtype=np.float32) for _ in range(3))
