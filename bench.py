@@ -100,6 +100,7 @@ def main():
     if "BENCH_DEVICE_OVERRIDE" in os.environ:
         local_rank = int(os.environ["BENCH_DEVICE_OVERRIDE"])
     os.environ["GRB_MI355X_DEVICE"] = str(local_rank)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # (the host driver supports dmabuf IPC only: RCCL between processes needs this — normally exported already)
 
     import numpy as np
     import torch
