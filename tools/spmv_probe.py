@@ -34,13 +34,18 @@ for var in args.variants.split(","):
     tname, sr = var.split(".")
     T = getattr(gb, tname)
     if tname not in mats:
-        vals = rmat.values_torch(nnz, dev, seed=43, dtype=torch.float64 if tname == "FP64" else torch.float32)
-        xs = rmat.values_torch(n, dev, seed=44, dtype=torch.float64 if tname == "FP64" else torch.float32)
+        if tname.startswith("INT"):            # (round 6: integer weights 1 ... 255 — the shortest-path problem's — and operand values 0 ... 999)
+            it = torch.int64 if tname == "INT64" else torch.int32
+            vals = ((rmat.values_torch(nnz, dev, seed=43) * 255.0).to(torch.int64) + 1).to(it)
+            xs = (rmat.values_torch(n, dev, seed=44) * 1000.0).to(it)
+        else:
+            vals = rmat.values_torch(nnz, dev, seed=43, dtype=torch.float64 if tname == "FP64" else torch.float32)
+            xs = rmat.values_torch(n, dev, seed=44, dtype=torch.float64 if tname == "FP64" else torch.float32)
         A = gb.Matrix.from_csr(T, n, n, rowptr.data_ptr(), col.data_ptr(), (vals.data_ptr(), nnz), device=True)
         x = gb.Vector.from_dense_array((xs.data_ptr(), n), T, device=True)
         mats[tname] = (A, x, gb.Vector.sparse(T, n))
     A, x, w = mats[tname]
-    ts = 8 if tname == "FP64" else 4
+    ts = 8 if tname in ("FP64", "INT64") else 4
     runs = [(m, None) for m in args.methods.split(",")] + [("adaptive", lm) for lm in args.loadmodes.split(",") if lm]
     for method, lm in runs:
         os.environ["GRB_MI355X_SPMV"] = method
