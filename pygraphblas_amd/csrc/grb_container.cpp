@@ -213,9 +213,9 @@ bool any_true_lookup(GrB_Vector u, bool* value) {
   *value = u->lor_state == 3; return true;
 }
 
-void vec_invalidate_device(GrB_Vector v) { vec_overwritten(v); v->holes_zero = false; v->holes_big = false; v->lor_state = 0; v->abs_bound = -1; v->small_valid = false; v->dev_valid = false; v->dval.reset(); v->dpres.reset(); v->dnvals = 0; v->dnvals_known = true; v->fe_lb = 0; v->fe_lb_key = 0; }
+void vec_invalidate_device(GrB_Vector v) { vec_overwritten(v); v->holes_zero = false; v->holes_big = false; v->lor_state = 0; v->abs_bound = -1; v->small_valid = false; v->code_valid = false; v->dev_valid = false; v->dval.reset(); v->dpres.reset(); v->dnvals = 0; v->dnvals_known = true; v->fe_lb = 0; v->fe_lb_key = 0; }
 void vec_invalidate_host(GrB_Vector v) {
-  vec_overwritten(v); v->holes_zero = false; v->holes_big = false; v->lor_state = 0; v->abs_bound = -1; v->small_valid = false; v->dev_elem_ops = 0;
+  vec_overwritten(v); v->holes_zero = false; v->holes_big = false; v->lor_state = 0; v->abs_bound = -1; v->small_valid = false; v->code_valid = false; v->dev_elem_ops = 0;
   v->host_valid = false; v->hi.clear(); v->hx.clear(); v->pending.clear(); v->hi.shrink_to_fit(); v->hx.shrink_to_fit();
 }
 void vec_to_host(GrB_Vector v) {

@@ -238,7 +238,9 @@ void vec_ewise_fused(int code, uint64_t n, const void* uval, const uint8_t* upre
                      int mcode, const void* mval, const uint8_t* mpres, bool mstruct, bool mcomp, int accum, bool replace, void* wval, uint8_t* wpres);
 void vec_assign_scalar(int code, uint64_t n, void* wval, uint8_t* wpres, const uint8_t* allow, const uint8_t* region, const void* scalar, int accum, bool replace);
 // the same over every index with the mask vector read in place (no "allow" pass): `v.assign_scalar(level, mask=q)` of a BFS level is one kernel
-void vec_assign_scalar_masked(int code, uint64_t n, void* wval, uint8_t* wpres, int mcode, const void* mval, const uint8_t* mpres, bool mstruct, bool mcomp, const void* scalar, int accum, bool replace);
+bool vec_assign_scalar_masked(int code, uint64_t n, void* wval, uint8_t* wpres, int mcode, const void* mval, const uint8_t* mpres, bool mstruct, bool mcomp, const void* scalar, int accum, bool replace,
+                              uint8_t* code_out = nullptr);      // true: the code bytes (GrB_Vector_opaque::dcode) of every position were written into code_out on the way
+void vec_code_bytes(uint64_t n, const uint8_t* val, const uint8_t* pres, uint8_t* code);      // ... from scratch, for a one-byte-typed vector
 // allow bytes of a mask AND its values cast to BOOL in one pass (the mask is also the operand: `v.vxm(A, mask=v, desc=RC)` with a BOOL semiring)
 void build_allow_and_bool(uint64_t n, int mcode, const void* mval, const uint8_t* mpres, bool structural, bool complement, uint8_t* allow, uint8_t* as_bool);
 void select_value_flags(int code, uint64_t n, const void* val, const uint8_t* pres, int sel, const void* thunk, uint8_t* keep);

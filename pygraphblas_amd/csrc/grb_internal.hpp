@@ -190,6 +190,10 @@ struct GrB_Vector_opaque {
   // a scan and a scatter over all n positions), no counting kernel, no read-back.  small_truthy: every listed value is non-zero.
   // Reset wherever lor_state is.
   std::vector<uint32_t> small_idx; bool small_valid = false, small_truthy = false;
+  // one CODE byte per position of a one-byte-typed vector (round 6): bit 0 = present, bit 1 = present and its value is not zero — what the masked pull of a BFS
+  // level gathers per neighbour as ONE byte instead of a presence byte and a value byte (grb_spmv_kernels.hpp: k_spmv_rowlane_k<..., CODE>).  Written for free by
+  // the masked scalar assign that precedes the product (`v[q] = level`), else by one pass before the pull.  Reset wherever lor_state is.
+  grb::DevBuf dcode; bool code_valid = false;
   uint32_t dev_elem_ops = 0;   // element reads served on the device in a row (grb_container.cpp: after a few dozen the host mirror takes over)
   int sparsity_control = 15;
   std::string err;

@@ -131,7 +131,7 @@ void run_queue(const ChainReduce* red, void* red_result, bool keep = false) {
     if (nval[o].p) { w->dval = std::move(nval[o]); w->dpres = std::move(npres[o]); }
     w->lazy = 0; w->dev_valid = true; w->host_valid = false; w->hi.clear(); w->hx.clear(); w->pending.clear();
     w->dnvals_known = out_full[o]; w->dnvals = out_full[o] ? w->n : 0;
-    w->holes_zero = true; w->holes_big = false; w->fe_lb = 0; w->fe_lb_key = 0; w->lor_state = 0; w->abs_bound = -1; w->small_valid = false;
+    w->holes_zero = true; w->holes_big = false; w->fe_lb = 0; w->fe_lb_key = 0; w->lor_state = 0; w->abs_bound = -1; w->small_valid = false; w->code_valid = false;
   }
   g_q.clear(); g_q_type = -1; g_q_n = 0;
 }
@@ -141,7 +141,7 @@ void materialise_fill(GrB_Vector w) {
   w->lazy = 0;
   w->dval.alloc(n * ts ? n * ts : 1); w->dpres.alloc(n ? n : 1);
   vec_assign_scalar(w->type->code, n, w->dval.p, w->dpres.as<uint8_t>(), nullptr, nullptr, w->lazy_fill, -1, false);
-  w->dev_valid = true; w->host_valid = false; w->dnvals = n; w->dnvals_known = true; w->holes_zero = false; w->holes_big = false; w->lor_state = 0; w->abs_bound = -1; w->small_valid = false;
+  w->dev_valid = true; w->host_valid = false; w->dnvals = n; w->dnvals_known = true; w->holes_zero = false; w->holes_big = false; w->lor_state = 0; w->abs_bound = -1; w->small_valid = false; w->code_valid = false;
 }
 
 }  // namespace
@@ -194,7 +194,7 @@ bool lazy_fill(GrB_Vector w, const void* s_in_w_type) {
   // the buffers go back to the pool: whoever consumes the fill allocates the result
   w->hi.clear(); w->hx.clear(); w->pending.clear(); w->host_valid = false; w->iso_full = false;
   w->dev_valid = false; w->dval.reset(); w->dpres.reset(); w->dnvals = 0; w->dnvals_known = false; w->fe_lb = 0; w->fe_lb_key = 0; w->holes_zero = false; w->holes_big = false;
-  w->lazy = 1; memcpy(w->lazy_fill, s_in_w_type, 16); w->lor_state = 0; w->abs_bound = -1; w->small_valid = false;
+  w->lazy = 1; memcpy(w->lazy_fill, s_in_w_type, 16); w->lor_state = 0; w->abs_bound = -1; w->small_valid = false; w->code_valid = false;
   return true;
 }
 void lazy_fill_consumed(GrB_Vector w) { w->lazy = 0; g_stat_fills_folded++; }
@@ -237,7 +237,7 @@ static bool enqueue(Node nd, GrB_Vector w, int tcode) {
   if (!w->q_reads) { w->hi.clear(); w->hx.clear(); w->pending.clear(); w->host_valid = false; w->iso_full = false; w->dev_valid = false; w->dval.reset(); w->dpres.reset();
                      w->dnvals = 0; w->dnvals_known = false; w->holes_zero = false; w->holes_big = false; }
   else { w->host_valid = false; w->hi.clear(); w->hx.clear(); w->pending.clear(); }
-  w->fe_lb = 0; w->fe_lb_key = 0; w->lor_state = 0; w->abs_bound = -1; w->small_valid = false;
+  w->fe_lb = 0; w->fe_lb_key = 0; w->lor_state = 0; w->abs_bound = -1; w->small_valid = false; w->code_valid = false;
   w->lazy = 2;
   nd.out = w;
   g_q.push_back(nd); g_q_type = tcode; g_q_n = n; g_q_kept = false;

@@ -235,7 +235,20 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
   } else {
     DevCSR& R = useT ? const_cast<DevCSR&>(mat_csc(A)) : A->csr;
     call.M = &R; call.upres = (u_full || fill_holes || big_holes) ? nullptr : u->dpres.as<uint8_t>();
-    if (fused_mask) { call.upres = u->dpres.as<uint8_t>(); call.fm_val = u->dval.as<uint8_t>(); call.fm_flags = (uint8_t)((dv.mask_struct ? 1 : 0) | (dv.mask_comp ? 2 : 0)); }
+    if (fused_mask) {
+      call.upres = u->dpres.as<uint8_t>(); call.fm_val = u->dval.as<uint8_t>(); call.fm_flags = (uint8_t)((dv.mask_struct ? 1 : 0) | (dv.mask_comp ? 2 : 0));
+      // the vector's code bytes (one gather per neighbour instead of two): left behind by the masked assign that wrote it (`v[q] = level`), else made by one pass
+      // over the vector when the matrix is large enough for the pull to repay it (GRB_MI355X_CODE_BYTES=0: never)
+      static const bool code_off = getenv("GRB_MI355X_CODE_BYTES") && atoi(getenv("GRB_MI355X_CODE_BYTES")) == 0;
+      if (!code_off && u->n >= (1u << 16) && R.nnz >= (1u << 20)) {
+        if (!u->code_valid) {
+          if (!u->dcode.p || u->dcode.bytes < u->n + 16) u->dcode.alloc(u->n + 16);
+          vec_code_bytes(u->n, u->dval.as<uint8_t>(), u->dpres.as<uint8_t>(), u->dcode.as<uint8_t>());
+          u->code_valid = true;
+        }
+        call.fm_code = u->dcode.as<uint8_t>();
+      }
+    }
     call.aval = uses_a ? cast_values(sd.zcode, A->type->code, R.val.p, R.nnz, acast) : nullptr;
     // `w += M (+).(x) u` with the monoid's own operator into a full w, no mask: the kernel that writes the row sums can apply the
     // accumulator in the same store — and when w is a fill that was never written (`r[:] = teleport` before the product of

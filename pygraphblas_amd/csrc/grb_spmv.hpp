@@ -50,6 +50,7 @@ struct SpmvCall {
   // operand value = (val[c] != 0) — where the caller would otherwise make allow bytes and BOOL values in a pass of its own (11 us per
   // level at R-MAT-22).  fm_val = the vector's raw value bytes, upres its presence bytes, fm_flags bit 0 structural, bit 1 complement.
   const uint8_t* fm_val = nullptr; uint8_t fm_flags = 0;
+  const uint8_t* fm_code = nullptr;      // (round 6) the vector's code bytes — bit 0 present, bit 1 present and not zero — when it has them: ONE gather per neighbour instead of two
   // push: the operand's entries as a host list of <= 64 ascending indices (GrB_Vector_opaque::small_idx) — no frontier compaction
   const uint32_t* small_idx = nullptr; uint32_t small_n = 0;
   // push, round 5: the mask is that same short list, complemented, every listed value true (the first level of a BFS: `v.vxm(A, mask=v, desc=RC)` with v =

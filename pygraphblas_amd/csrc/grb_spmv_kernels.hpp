@@ -50,6 +50,7 @@ template <class T> struct SpmvKArgs {
   uint32_t nrows;
   uint32_t* any_true; uint32_t any_true_tag;      // BOOL results only (nullptr otherwise): set to the tag when an entry with value true is written
   const uint8_t* fm_val; uint32_t fm_flags;       // SpmvCall::fm_val / fm_flags (row-lane kernel, FUSED instantiation)
+  const uint8_t* fm_code;                         // SpmvCall::fm_code (k_spmv_rowlane_k<..., CODE = true>)
   const uint32_t* fe_rowptr; unsigned long long* fe_host;      // SpmvCall::fe_* (row-lane kernel)
   const uint4* heads; const uint32_t* nonempty;                // DevCSR::heads / nonempty (row-lane kernel, FUSED, K rows per lane)
 };
@@ -338,8 +339,11 @@ constexpr uint32_t FE_MAX_BLOCKS = 2048;      // pairs of host words of the resu
 // while they were: the level-2 pull of the R-MAT-22 BFS took 54 us for 64 MB, the late levels 17 us each for a handful of vertices
 // (65 536 waves of one round trip after the other).  With K rows the K loads of every stage are issued together: all of them are
 // unconditional (an idle slot reads entry 0 of its array and drops it), so they stand in one basic block.
-template <class T, class SR, bool U_FULL, bool FUSED, int K>
+// CODE (round 6, FUSED only): the operand / mask vector comes with code bytes (bit 0 present, bit 1 present and not zero): a neighbour costs ONE byte gather
+// instead of a presence byte and a value byte — the pull is bound by its gathers (~3 CU-clocks each), not by bytes.
+template <class T, class SR, bool U_FULL, bool FUSED, int K, bool CODE = false>
 __global__ __launch_bounds__(1024) void k_spmv_rowlane_k(const SpmvKArgs<T> a, const SR sr) {
+  static_assert(!CODE || FUSED, "code bytes belong to the fused (mask = operand) instantiation");
   const int lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
   const bool use_a = sr.uses_a(), use_u = sr.uses_u();
@@ -355,7 +359,8 @@ __global__ __launch_bounds__(1024) void k_spmv_rowlane_k(const SpmvKArgs<T> a, c
     for (int k = 0; k < K; k++) {
       r[k] = base + 64ull * k + lane; valid[k] = r[k] < a.nrows;
       const uint64_t rr = valid[k] ? r[k] : 0;
-      if constexpr (FUSED) { m0[k] = a.upres[rr]; m1[k] = a.fm_val[rr]; }                       // the mask vector itself
+      if constexpr (CODE) { const uint8_t q = a.fm_code[rr]; m0[k] = q & 1u; m1[k] = q >> 1; }
+      else if constexpr (FUSED) { m0[k] = a.upres[rr]; m1[k] = a.fm_val[rr]; }                  // the mask vector itself
       else { m0[k] = a.allow ? a.allow[rr] : (uint8_t)1; m1[k] = 1; }
       // (without row heads the row pointers are fetched whether or not the row is allowed: one dependent round trip less — the late levels of a
       //  BFS, where half of the 4 M rows are empty and unvisited, are a chain of such trips and little else)
@@ -398,7 +403,9 @@ __global__ __launch_bounds__(1024) void k_spmv_rowlane_k(const SpmvKArgs<T> a, c
         if (!__ballot(any)) break;                                                                 // (a late level: most waves have no live row at all)
         uint8_t pr[K], vb[K];
 #pragma unroll
-        for (int k = 0; k < K; k++) { pr[k] = a.upres[c[k]]; vb[k] = a.fm_val[c[k]]; }                // (an idle slot reads position 0 and drops it)
+        for (int k = 0; k < K; k++) {                                                                // (an idle slot reads position 0 and drops it)
+          if constexpr (CODE) { const uint8_t q = a.fm_code[c[k]]; pr[k] = q & 1u; vb[k] = q >> 1; } else { pr[k] = a.upres[c[k]]; vb[k] = a.fm_val[c[k]]; }
+        }
 #pragma unroll
         for (int k = 0; k < K; k++) {
           if (act[k] && pr[k]) {
@@ -431,9 +438,12 @@ __global__ __launch_bounds__(1024) void k_spmv_rowlane_k(const SpmvKArgs<T> a, c
       uint8_t pr[K]; T uv[K], av[K];
 #pragma unroll
       for (int k = 0; k < K; k++) {
-        if constexpr (U_FULL) pr[k] = 1; else pr[k] = a.upres[c[k]];
-        if constexpr (FUSED) { T t; t = T(a.fm_val[c[k]] != 0); uv[k] = t; }                       // the vector's own byte as BOOL
-        else uv[k] = use_u ? a.uval[c[k]] : T();
+        if constexpr (CODE) { const uint8_t q = a.fm_code[c[k]]; pr[k] = q & 1u; T t; t = T((q >> 1) != 0); uv[k] = t; }
+        else {
+          if constexpr (U_FULL) pr[k] = 1; else pr[k] = a.upres[c[k]];
+          if constexpr (FUSED) { T t; t = T(a.fm_val[c[k]] != 0); uv[k] = t; }                     // the vector's own byte as BOOL
+          else uv[k] = use_u ? a.uval[c[k]] : T();
+        }
         av[k] = use_a ? a.aval[act[k] ? pb[k] + e : 0u] : T();
       }
 #pragma unroll
@@ -458,10 +468,11 @@ __global__ __launch_bounds__(1024) void k_spmv_rowlane_k(const SpmvKArgs<T> a, c
           const uint32_t p = p0 + lane;
           if (p < qe) {
             const uint32_t c = a.col[p];
-            bool pr = true;
-            if constexpr (!U_FULL) pr = a.upres[c] != 0;
+            bool pr = true; uint8_t q = 0;
+            if constexpr (CODE) { q = a.fm_code[c]; pr = (q & 1u) != 0; }
+            else if constexpr (!U_FULL) pr = a.upres[c] != 0;
             if (pr) {
-              T u1; if constexpr (FUSED) { u1 = T(a.fm_val[c] != 0); } else { u1 = use_u ? a.uval[c] : T(); }
+              T u1; if constexpr (CODE) { u1 = T((q >> 1) != 0); } else if constexpr (FUSED) { u1 = T(a.fm_val[c] != 0); } else { u1 = use_u ? a.uval[c] : T(); }
               const T m = sr.mult(use_a ? a.aval[p] : T(), u1); part = phas ? sr.add(part, m) : m; phas = true;
             }
           }
@@ -664,7 +675,7 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
         }
         if constexpr (is_bool<T>::value) {
           if (c.fm_val) {                                                       // the mask is the operand itself: no allow / BOOL-value arrays were made
-            a.fm_val = c.fm_val; a.fm_flags = c.fm_flags;
+            a.fm_val = c.fm_val; a.fm_flags = c.fm_flags; a.fm_code = c.fm_code;
             const int kk = lane_k >= 4 ? 4 : lane_k >= 2 ? 2 : 1;
             static const uint32_t lane_cap = wp_env("GRB_MI355X_LANE_BLOCKS", 256);                    // measurement hooks: grid cap (the kernel strides), threads per workgroup
             static const uint32_t lane_thr = wp_env("GRB_MI355X_LANE_THREADS", 1024);
@@ -675,10 +686,11 @@ template <class T> void run_pull(const SpmvCall& c, const SemiringDesc& d) {
             // (the value bits need the matrix values as one-byte BOOLs where they lie: a BOOL matrix under a Boolean semiring — the adjacency matrix of the BFS)
             const bool vals_in_place = c.aval == M.val.p;
             if (kk > 1 && !no_heads && (!sr.uses_a() || vals_in_place) && spmv_row_heads(M, sr.uses_a() ? (const uint8_t*)M.val.p : nullptr)) { a.heads = (const uint4*)M.heads.p; a.nonempty = M.nonempty.as<uint32_t>(); }
-            if (kk == 4) hipLaunchKernelGGL((k_spmv_rowlane_k<T, SR, false, true, 4>), dim3((unsigned)nbk), dim3(thr), 0, stream(), a, sr);
+            if (kk == 4 && a.fm_code) hipLaunchKernelGGL((k_spmv_rowlane_k<T, SR, false, true, 4, true>), dim3((unsigned)nbk), dim3(thr), 0, stream(), a, sr);
+            else if (kk == 4) hipLaunchKernelGGL((k_spmv_rowlane_k<T, SR, false, true, 4>), dim3((unsigned)nbk), dim3(thr), 0, stream(), a, sr);
             else if (kk == 2) hipLaunchKernelGGL((k_spmv_rowlane_k<T, SR, false, true, 2>), dim3((unsigned)nbk), dim3(thr), 0, stream(), a, sr);
             else hipLaunchKernelGGL((k_spmv_rowlane<T, SR, false, true>), dim3((unsigned)nbk), dim3(thr), 0, stream(), a, sr);
-            g_last_plan += std::string("k_spmv_rowlane<") + (sr.is_static ? "static" : "dynamic") + ",mask=operand> ";
+            g_last_plan += std::string("k_spmv_rowlane<") + (sr.is_static ? "static" : "dynamic") + ",mask=operand" + (kk == 4 && a.fm_code ? ",code bytes" : "") + "> ";
             return;
           }
         }

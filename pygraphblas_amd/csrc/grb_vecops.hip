@@ -562,7 +562,7 @@ template <class T, bool MATH> __global__ void k_vec_assign_scalar_masked(uint64_
 // thread and instruction (7-13 us for 4 M positions; the bytes alone are 6 streams of 4 MB)
 __device__ __forceinline__ uint32_t nz_bytes(uint32_t x) { return ((x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) & 0x80808080u) >> 7; }      // 0x01 in every byte of x that is not zero
 __global__ void k_assign_masked_bytes(uint64_t n, uint8_t* __restrict__ wval, uint8_t* __restrict__ wpres, const uint8_t* __restrict__ mval, const uint8_t* __restrict__ mpres,
-                                      bool mstruct, bool mcomp, uint8_t s, bool replace) {
+                                      bool mstruct, bool mcomp, uint8_t s, bool replace, uint8_t* __restrict__ code) {
   const uint64_t nv = n / 16; const uint32_t s4 = (uint32_t)s * 0x01010101u;
   for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < nv; i += gridDim.x * 256ull) {
     const uint4 mp = ((const uint4*)mpres)[i]; uint4 mv = make_uint4(0, 0, 0, 0);
@@ -578,24 +578,50 @@ __global__ void k_assign_masked_bytes(uint64_t n, uint8_t* __restrict__ wval, ui
       pwp[k] = replace ? ok : (nz_bytes(pwp[k]) | ok);
     }
     ((uint4*)wval)[i] = wv; ((uint4*)wpres)[i] = wp;
+    if (code) {                                                             // the vector's code bytes (GrB_Vector_opaque::dcode): present | (present and not zero) << 1
+      uint4 cd; uint32_t* pc = (uint32_t*)&cd;
+#pragma unroll
+      for (int k = 0; k < 4; k++) pc[k] = pwp[k] | ((nz_bytes(pwv[k]) & pwp[k]) << 1);
+      ((uint4*)code)[i] = cd;
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0)
     for (uint64_t i = nv * 16; i < n; i++) {
       const bool ok = (mpres[i] != 0 && (mstruct || mval[i] != 0)) != mcomp;
       if (ok) { wval[i] = s; wpres[i] = 1; } else if (replace) wpres[i] = 0;
+      if (code) code[i] = (uint8_t)((wpres[i] != 0 ? 1 : 0) | ((wpres[i] != 0 && wval[i] != 0) ? 2 : 0));
     }
 }
-void vec_assign_scalar_masked(int code, uint64_t n, void* wval, uint8_t* wpres, int mcode, const void* mval, const uint8_t* mpres, bool mstruct, bool mcomp, const void* scalar, int accum, bool replace) {
+// the code bytes of a one-byte-typed vector from scratch (a vector that was not written by the kernel above)
+__global__ void k_vec_code_bytes(uint64_t n, const uint8_t* __restrict__ val, const uint8_t* __restrict__ pres, uint8_t* __restrict__ code) {
+  const uint64_t nv = n / 16;
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < nv; i += gridDim.x * 256ull) {
+    const uint4 v = ((const uint4*)val)[i], pp = ((const uint4*)pres)[i];
+    const uint32_t* pv = (const uint32_t*)&v; const uint32_t* pq = (const uint32_t*)&pp;
+    uint4 cd; uint32_t* pc = (uint32_t*)&cd;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint32_t pr = nz_bytes(pq[k]); pc[k] = pr | ((nz_bytes(pv[k]) & pr) << 1); }
+    ((uint4*)code)[i] = cd;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) for (uint64_t i = nv * 16; i < n; i++) code[i] = (uint8_t)((pres[i] != 0 ? 1 : 0) | ((pres[i] != 0 && val[i] != 0) ? 2 : 0));
+}
+void vec_code_bytes(uint64_t n, const uint8_t* val, const uint8_t* pres, uint8_t* code) {
   if (!n) return;
+  hipLaunchKernelGGL(k_vec_code_bytes, dim3(grid_for(n / 16 + 1)), dim3(256), 0, stream(), n, val, pres, code);
+}
+bool vec_assign_scalar_masked(int code, uint64_t n, void* wval, uint8_t* wpres, int mcode, const void* mval, const uint8_t* mpres, bool mstruct, bool mcomp, const void* scalar, int accum, bool replace,
+                              uint8_t* code_out) {
+  if (!n) return false;
   if (accum < 0 && type_size(code) == 1 && type_size(mcode) == 1 && n >= 4096) {      // (the truth of a one-byte value of any type is "not zero")
-    hipLaunchKernelGGL(k_assign_masked_bytes, dim3(grid_for(n / 16)), dim3(256), 0, stream(), n, (uint8_t*)wval, wpres, (const uint8_t*)mval, mpres, mstruct, mcomp, *(const uint8_t*)scalar, replace);
-    return;
+    hipLaunchKernelGGL(k_assign_masked_bytes, dim3(grid_for(n / 16)), dim3(256), 0, stream(), n, (uint8_t*)wval, wpres, (const uint8_t*)mval, mpres, mstruct, mcomp, *(const uint8_t*)scalar, replace, code_out);
+    return code_out != nullptr;                                                         // the code bytes of every position were written on the way
   }
   dispatch_type(code, [&]<class T>() {
     T s; memcpy(&s, scalar, sizeof(T));
     if (accum >= 0 && binop_needs_math(accum)) hipLaunchKernelGGL((k_vec_assign_scalar_masked<T, true>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (T*)wval, wpres, mcode, mval, mpres, mstruct, mcomp, s, accum, replace);
     else hipLaunchKernelGGL((k_vec_assign_scalar_masked<T, false>), dim3(grid_for(n)), dim3(256), 0, stream(), n, (T*)wval, wpres, mcode, mval, mpres, mstruct, mcomp, s, accum, replace);
   });
+  return false;
 }
 
 __global__ void k_allow_and_bool(uint64_t n, int mcode, const void* __restrict__ mval, const uint8_t* __restrict__ mpres, bool structural, bool complement,

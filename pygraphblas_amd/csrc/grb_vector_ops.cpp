@@ -118,9 +118,13 @@ static void vec_assign(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, const 
       // (Round 5, measured and dropped: recording this assign and letting the masked pull that follows apply it on its way over the rows — one launch and
       //  one dependent kernel less per BFS level.  The pull then looks at q beside v wherever it gathers an operand entry: +2 byte gathers per entry
       //  made the level-2 pull of the R-MAT-22 BFS 65 -> 106 us and the whole loop 283 -> 341 us.)
-      vec_assign_scalar_masked(wcode0, n, w->dval.p, w->dpres.as<uint8_t>(), mask->type->code, mask->dval.p, mask->dpres.as<uint8_t>(), dv.mask_struct, dv.mask_comp, s0,
-                               accum ? accum->opcode : -1, dv.replace);
+      // a one-byte-typed output (the level vector of a BFS): its code bytes come out of the same pass (the pull that follows gathers ONE byte per neighbour)
+      uint8_t* code_out = nullptr;
+      if (type_size(wcode0) == 1 && n >= (1u << 16)) { if (!w->dcode.p || w->dcode.bytes < n + 16) w->dcode.alloc(n + 16); code_out = w->dcode.as<uint8_t>(); }
+      const bool coded = vec_assign_scalar_masked(wcode0, n, w->dval.p, w->dpres.as<uint8_t>(), mask->type->code, mask->dval.p, mask->dpres.as<uint8_t>(), dv.mask_struct, dv.mask_comp, s0,
+                               accum ? accum->opcode : -1, dv.replace, code_out);
       vec_invalidate_host(w);
+      w->code_valid = coded;
       if (dv.replace) { w->fe_lb = 0; w->fe_lb_key = 0; }
       // the positions the mask allows are entries of w now: when the mask carries a bound of the edges leaving its TRUE entries (left by the
       // product that made it, any_true_lookup), w's entries include them — `v[q] = level`: the next product's direction choice needs no count
