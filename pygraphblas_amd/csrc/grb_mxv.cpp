@@ -239,7 +239,7 @@ static void mxv_like(GrB_Vector w, GrB_Vector mask, GrB_BinaryOp accum, GrB_Semi
       call.upres = u->dpres.as<uint8_t>(); call.fm_val = u->dval.as<uint8_t>(); call.fm_flags = (uint8_t)((dv.mask_struct ? 1 : 0) | (dv.mask_comp ? 2 : 0));
       // the vector's code bytes (one gather per neighbour instead of two): left behind by the masked assign that wrote it (`v[q] = level`), else made by one pass
       // over the vector when the matrix is large enough for the pull to repay it (GRB_MI355X_CODE_BYTES=0: never)
-      static const bool code_off = getenv("GRB_MI355X_CODE_BYTES") && atoi(getenv("GRB_MI355X_CODE_BYTES")) == 0;
+      const char* ce = getenv("GRB_MI355X_CODE_BYTES"); const bool code_off = ce && atoi(ce) == 0;      // (read per call: a test hook)
       if (!code_off && u->n >= (1u << 16) && R.nnz >= (1u << 20)) {
         if (!u->code_valid) {
           if (!u->dcode.p || u->dcode.bytes < u->n + 16) u->dcode.alloc(u->n + 16);

@@ -399,6 +399,56 @@ def test_reduce_bool_after_a_bool_product_reads_the_kernels_summary(gpu):
     assert sum(sizes) == v.nvals and level > 2
 
 
+def test_code_bytes_of_the_masked_pull_keep_explicit_zeros_exact(gpu, monkeypatch):
+    """Round 6: the fused masked pull (`q<mask = v> = v lor.land A`, one-byte v) gathers ONE code byte per neighbour (bit 0 present, bit 1 present and not zero)
+    instead of a presence byte and a value byte.  A level vector with EXPLICIT ZEROS — present entries whose value is false — must give the oracle's result,
+    pattern included (a row whose only contributions are false has an entry, false): valued / structural / complemented masks, the code bytes left behind by
+    the masked assign (`v[q] = level`) and rebuilt after another writer touched the vector, against the oracle and against the two-gather kernel."""
+    rng = np.random.default_rng(77)
+    n = 1 << 17
+    key = np.unique(rng.integers(0, n * n, size=1300000, dtype=np.int64))
+    I, J = np.divmod(key.astype(np.uint64), np.uint64(n))
+    A_t = O.Tuples("BOOL", n, n, I, J, rng.random(len(key)) < 0.9)                                  # some stored `false` edges too
+    A = to_matrix(A_t)
+    empty = O.row_vector("BOOL", n)
+    def oracle(vi, vx, struct, comp):
+        u = O.row_vector("UINT8", n, vi, vx)
+        return O.vxm(empty, u, A_t, "LOR", "LAND", "BOOL", mask=u, replace=True, mask_comp=comp, mask_struct=struct)
+    for case in range(3):
+        vi = np.sort(rng.choice(n, size=n // 3, replace=False)).astype(np.uint64)
+        vx = rng.integers(0, 4, len(vi)).astype(np.uint8)                                              # a quarter of the entries are explicit zeros
+        for struct, comp in ((False, True), (True, True), (False, False), (True, False)):
+            flags = "R" + ("S" if struct else "") + ("C" if comp else "")
+            want = oracle(vi, vx, struct, comp)
+            got = {}
+            for code in ("1", "0"):
+                monkeypatch.setenv("GRB_MI355X_CODE_BYTES", code)
+                v = to_vector("UINT8", n, vi, vx); q = gb.Vector.sparse(gb.BOOL, n)
+                v.vxm(A, mask=v, out=q, desc=getattr(D, flags))
+                plan = gb.last_kernel_plan()
+                assert "mask=operand" in plan and ("code bytes" in plan) == (code == "1"), plan
+                gi, gx = vector_pairs(q)
+                assert np.array_equal(gi, want.J) and np.array_equal(gx.astype(bool), want.X.astype(bool)), (case, flags, code, plan)
+                got[code] = plan
+    # the producer: v[q] = level writes the code bytes; a later writer (apply in place) invalidates them and the pull rebuilds them
+    monkeypatch.delenv("GRB_MI355X_CODE_BYTES", raising=False)
+    vi = np.sort(rng.choice(n, size=n // 4, replace=False)).astype(np.uint64); vx = rng.integers(0, 3, len(vi)).astype(np.uint8)
+    v = to_vector("UINT8", n, vi, vx)
+    qi = np.sort(rng.choice(n, size=n // 5, replace=False)).astype(np.uint64); qx = rng.random(len(qi)) < 0.7
+    qm = to_vector("BOOL", n, qi, qx)
+    v.assign_scalar(7, mask=qm)
+    dense = np.zeros(n, np.uint8); pres = np.zeros(n, bool); dense[vi.astype(int)] = vx; pres[vi.astype(int)] = True
+    sel = qi[qx].astype(int); dense[sel] = 7; pres[sel] = True
+    out = gb.Vector.sparse(gb.BOOL, n); v.vxm(A, mask=v, out=out, desc=D.RC)
+    want = oracle(np.flatnonzero(pres).astype(np.uint64), dense[pres], False, True)
+    gi, gx = vector_pairs(out); assert np.array_equal(gi, want.J) and np.array_equal(gx.astype(bool), want.X.astype(bool))
+    v.apply(gb.UINT8.IDENTITY, out=v); v.assign_scalar(0, mask=qm, desc=D.S)                           # other writers: every position q holds becomes an explicit zero
+    dense[qi.astype(int)] = 0; pres[qi.astype(int)] = True
+    out2 = gb.Vector.sparse(gb.BOOL, n); v.vxm(A, mask=v, out=out2, desc=D.RC)
+    want2 = oracle(np.flatnonzero(pres).astype(np.uint64), dense[pres], False, True)
+    gi, gx = vector_pairs(out2); assert np.array_equal(gi, want2.J) and np.array_equal(gx.astype(bool), want2.X.astype(bool))
+
+
 def test_min_plus_over_an_operand_with_holes_runs_the_full_operand_kernels(gpu):
     """The sweeps of the reference's shortest-path loop (`v<accum MIN> = v MIN_PLUS A`, demo/Intro-Prez.ipynb:1034-1045): the operand
     has no entry for vertices not reached yet.  grb_mxv.cpp fills the holes with a BIG value, runs a full-operand kernel and
