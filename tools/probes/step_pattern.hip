@@ -47,6 +47,14 @@ __global__ __launch_bounds__(1024, 1) void k_steps(const uint32_t* __restrict__ 
 #pragma unroll
     for (int j = 0; j < G; j++) {
       const uint32_t w = s.c[j];
+      if (GATHER && (GAUX == 300 || GAUX == 301)) {       // the opposite: a step's cold lanes split over TWO (300) or FOUR (301) gather instructions by lane number — fewer active lanes per instruction
+        const bool cold = (w & 0xFFFFu) < cold_thresh; const uint32_t off = (w >> 3) << 3;
+        const int parts = GAUX == 300 ? 2 : 4;
+        v2u acc2 = v2u{0, 0};
+#pragma unroll
+        for (int q = 0; q < parts; q++) { const v2u t = __builtin_amdgcn_raw_buffer_load_b64(u_rs, (int)((cold && (lane % parts) == q) ? off : 0xFFFFFFFFu), 0, 0); acc2.x |= t.x; acc2.y |= t.y; }
+        s.g[j] = acc2;
+      } else
       if (GATHER && GAUX == 200) {       // what compacting the cold lanes of G steps into ONE gather instruction would buy (upper bound: no shuffle cost): step 0 gathers with G x the probability, the others issue nothing
         if (j == 0) s.g[j] = __builtin_amdgcn_raw_buffer_load_b64(u_rs, (int)((w & 0xFFFFu) < cold_thresh * (uint32_t)G ? (w >> 3) << 3 : 0xFFFFFFFFu), 0, 0); else s.g[j] = v2u{0, 0};
       } else
@@ -147,6 +155,8 @@ int main(int argc, char** argv) {
   run<1, 16, true, false, true, 17>("+ gather per step, sc0 sc1", cols, vals, u, ulen, nsteps, cp, sink);
   run<1, 16, true, false, true, 18>("+ gather per step, sc1 nt", cols, vals, u, ulen, nsteps, cp, sink);
   run<1, 16, true, false, true, 19>("+ gather per step, sc0 sc1 nt", cols, vals, u, ulen, nsteps, cp, sink);
+  run<1, 16, true, false, true, 300>("+ gather per step in two half-lane instructions", cols, vals, u, ulen, nsteps, cp, sink);
+  run<1, 16, true, false, true, 301>("+ gather per step in four quarter-lane instructions", cols, vals, u, ulen, nsteps, cp, sink);
   run<4, 4, true, false, true, 200>("16B loads + ONE gather for 4 steps' cold lanes", cols, vals, u, ulen, nsteps, cp, sink);
   run<4, 8, true, false, true, 200>("16B loads + ONE gather for 4 steps' cold lanes", cols, vals, u, ulen, nsteps, cp, sink);
   run<1, 16, true, false, true, 100>("+ cold lanes through the scalar cache", cols, vals, u, ulen, nsteps, cp, sink);
