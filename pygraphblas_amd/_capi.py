@@ -46,9 +46,27 @@ with open(HEADER_PATH) as _f:
             constants[_m.group(1)] = int(_m.group(2))
 
 
+_handles = {}
+
+
 def handle(name):
-    """Value of an exported handle variable (`extern GrB_Semiring NAME;`)."""
-    return C.c_void_p.in_dll(lib, name).value
+    """Value of an exported handle variable (`extern GrB_Semiring NAME;`) — looked up in the library once (the symbol lookup is ~1 us, and
+    `GrB_ALL` is asked for by every whole-vector assign of a loop)."""
+    v = _handles.get(name)
+    if v is None:
+        v = _handles[name] = C.c_void_p.in_dll(lib, name).value
+    return v
+
+
+_all_ptr = None
+
+
+def all_indices():
+    """`GrB_ALL` as the `const GrB_Index *` argument of the assign / extract entry points (one object, made once)."""
+    global _all_ptr
+    if _all_ptr is None:
+        _all_ptr = C.cast(handle("GrB_ALL"), C.c_void_p)
+    return _all_ptr
 
 
 # every GrB_* function returns GrB_Info (int)

@@ -47,7 +47,7 @@ def build_range(rslice, stop_val):
         keep = np.ascontiguousarray(rslice, np.uint64)
         return _p(keep), len(keep), len(keep), keep
     if rslice is None or rslice == slice(None):
-        return C.cast(_capi.handle("GrB_ALL"), C.c_void_p), 0, None, None
+        return _capi.all_indices(), 0, None, None
     start = 0 if rslice.start is None else rslice.start
     stop = stop_val if rslice.stop is None else rslice.stop
     step = rslice.step
@@ -91,7 +91,7 @@ class Matrix:
             fill = typ.default_zero
         if 0 < nrows * ncols < (1 << 32) - 16 and _capi.device_info()["ok"]:  # one fill kernel in HBM (the ns x n batches of the BC sweeps): the
             m = cls.sparse(typ, nrows, ncols)                                  # reference's own `m[:, :] = fill` (pygraphblas/matrix.py:220-230)
-            ALL = C.cast(_capi.handle("GrB_ALL"), C.c_void_p)
+            ALL = _capi.all_indices()
             check(getattr(lib, "GrB_Matrix_assign_" + typ.__name__)(m._h, None, None, typ._c(fill), ALL, u64(nrows), ALL, u64(ncols), None), m)
             return m
         I, J = np.divmod(np.arange(nrows * ncols, dtype=np.uint64), np.uint64(ncols))

@@ -247,12 +247,14 @@ class Vector:
         """`w<mask>(:) = accum(w, value)` (reference: vector.py:1494-1524) — `v.assign_scalar(level, mask=q)` in BFS."""
         mh, ah, dh = get_args(mask, accum, desc)
         if index is None:
-            I, ni = C.cast(_capi.handle("GrB_ALL"), C.c_void_p), 0
+            I, ni = _capi.all_indices(), 0
             keep = None
         else:
             keep = np.ascontiguousarray([index] if np.isscalar(index) else index, np.uint64)
             I, ni = _p(keep), len(keep)
-        fn = getattr(lib, "GrB_Vector_assign_" + self.type.__name__)
+        fn = self.type.__dict__.get("_vector_assign_fn")
+        if fn is None:
+            fn = getattr(lib, "GrB_Vector_assign_" + self.type.__name__); setattr(self.type, "_vector_assign_fn", fn)      # (looked up once per type)
         check(fn(self._h, mh, ah, self.type._c(value), I, u64(ni), dh), self)
 
     def _ewise(self, stem, other, op, cast, out, mask, accum, desc, default):
